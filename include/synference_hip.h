@@ -1,0 +1,185 @@
+/*
+ * synference_hip.h -- C ABI of the MI355X (gfx950) amortised-posterior flow engine.
+ *
+ * Drop-in boundary for ONE path of synthesizer-project/synference: the conditional
+ * normalizing-flow density estimator (MAF / NSF) that the reference reaches through
+ *     ili.utils.load_nde_sbi(...)            ref: src/synference/sbi_runner.py:5123-5146
+ *     estimator_builder(batch_x=, batch_theta=)   ref: src/synference/custom_runner.py:320-326
+ * and evaluates through
+ *     posterior.sample((S,), x=)             ref: src/synference/sbi_runner.py:6438-6442
+ *     posterior.log_prob(x=, theta=)         ref: src/synference/sbi_runner.py:7193-7196
+ *     loss.backward(); clip; optimizer.step()  ref: src/synference/custom_runner.py:585-618
+ *
+ * The reference is pure Python (no FFI of its own), so these entry points are what a
+ * ctypes binding for that path would bind; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every data pointer is a DEVICE pointer to
+ *     contiguous row-major float32 unless the comment says "host".
+ *   - the caller owns every buffer it passes; the library owns the handle, its packed
+ *     weight image and its scratch.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are
+ *     asynchronous on it unless stated.
+ *   - return 0 on success, a negative sf_status otherwise; sf_last_error() returns the
+ *     thread-local message.
+ *   - one handle per (process, device); a handle is not thread-safe.
+ *
+ * Logical parameter layout (the flat vector of sf_flow_set_params / sf_flow_loss_grad),
+ * per transform t = 0..T-1, torch nn.Linear convention W[out][in], row-major:
+ *   MAF: W0[H,D] b0[H] Wc[H,C] bc[H] {Wk[H,H] bk[H]} x NB  Wf[2D,H] bf[2D]
+ *   NSF: Win[H,d_id+C] bin[H] {Wg[H,C] bg[H] W1[H,H] b1[H] W2[H,H] b2[H]} x NB
+ *        Wout[d_tr*(3K-1),H] bout[d_tr*(3K-1)]
+ *        and, when D > 1: lower[D(D-1)/2] upper[D(D-1)/2] udiag[D] lubias[D]
+ *        (tril / triu index order, row-major, as numpy tril_indices(D,-1) / triu_indices(D,1))
+ * MADE masks are implied by (D, H) and applied inside the library (masked entries of
+ * the flat vector are ignored on input and receive zero gradient).
+ */
+#ifndef SYNFERENCE_HIP_H
+#define SYNFERENCE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sf_flow sf_flow;
+typedef struct sf_opt sf_opt;
+
+enum sf_status {
+  SF_OK = 0,
+  SF_ERR_INVALID = -1,     /* bad argument / unsupported shape */
+  SF_ERR_HIP = -2,         /* a HIP runtime call failed */
+  SF_ERR_NO_DEVICE = -3,   /* no gfx950 device visible */
+  SF_ERR_STATE = -4        /* e.g. parameters not set */
+};
+
+enum sf_kind { SF_MAF = 0, SF_NSF = 1 };
+
+/* Static description of one flow.  Pointer members are HOST arrays read during
+ * sf_flow_create only.  Defaults of the upstream stack (sbi/nflows) in brackets. */
+typedef struct sf_flow_desc {
+  int32_t kind;            /* sf_kind */
+  int32_t D;               /* theta dimension, 1..16 */
+  int32_t C;               /* context width seen by the transforms, 1..512 */
+  int32_t H;               /* hidden_features [50], 1..128 */
+  int32_t T;               /* num_transforms [5] */
+  int32_t K;               /* num_bins (NSF) [10], 2..16 */
+  int32_t NB;              /* num_blocks [2], 1..4 */
+  int32_t scale_fn;        /* MAF scale: 0 = softplus(a)+eps [nflows>=0.14], 1 = sigmoid(a+2)+eps */
+  float tail_bound;        /* [3.0] */
+  float min_bin_width;     /* [1e-3] */
+  float min_bin_height;    /* [1e-3] */
+  float min_derivative;    /* [1e-3] */
+  float maf_eps;           /* [1e-3] */
+  float lu_eps;            /* [1e-3] */
+  const float* theta_mean; /* host [D]  z-score buffers (sbi standardizing_transform) */
+  const float* theta_std;  /* host [D] */
+  const float* x_mean;     /* host [C]  (sbi standardizing_net) */
+  const float* x_std;      /* host [C] */
+  const int32_t* perms;    /* host [T*D] MAF RandomPermutation buffers, NULL = identity */
+} sf_flow_desc;
+
+/* ---- lifetime ---------------------------------------------------------------------- */
+/* Builds the layer tables and allocates the packed weight image on the current device.
+ * Replaces: the nn.Module returned by build_fn (custom_runner.py:326). */
+int sf_flow_create(const sf_flow_desc* desc, sf_flow** out);
+void sf_flow_destroy(sf_flow* f);
+int64_t sf_flow_num_params(const sf_flow* f);
+/* floats in the MFMA-tiled weight image (for tests / diagnostics) */
+int64_t sf_flow_packed_size(const sf_flow* f);
+
+/* ---- parameters -------------------------------------------------------------------- */
+/* flat: n = sf_flow_num_params floats in the logical layout; is_device selects host or
+ * device source.  Re-tiles them into the MFMA operand image (a device gather kernel).
+ * Replaces: estimator.load_state_dict (custom_runner.py:563, 709). */
+int sf_flow_set_params(sf_flow* f, const float* flat, int64_t n, int is_device, void* stream);
+
+/* Host-only helpers (no GPU needed; used by the CPU test-suite):
+ * src1/src2[i] = logical index feeding packed float i (or -1); packed = sum of both. */
+int sf_flow_pack_table(const sf_flow* f, int32_t* src1, int32_t* src2, int64_t n_packed);
+/* byte-for-byte description of the packed image for diagnostics (JSON, NUL-terminated) */
+int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen);
+
+/* ---- density direction --------------------------------------------------------------
+ * out[b] = log N(z;0,I) + sum log|det J|  for theta[b,:], x[b,:]   (raw estimator density)
+ * Replaces: flow.log_prob(theta, context=x) (custom_runner.py:604, 646). */
+int sf_flow_log_prob(sf_flow* f, const float* theta /*[B,D]*/, const float* x /*[B,C]*/,
+                     int64_t B, float* out /*[B]*/, void* stream);
+
+/* ---- sampling direction -------------------------------------------------------------
+ * Parity hook: theta = inverse(z | x), logdet = log|det d theta / d z|  (may be NULL). */
+int sf_flow_inverse_from_noise(sf_flow* f, const float* z /*[B,D]*/, const float* x /*[B,C]*/,
+                               int64_t B, float* theta /*[B,D]*/, float* logdet /*[B]*/,
+                               void* stream);
+
+/* One rejection round over a list of output slots (slot = g*S + p):
+ *   noise = Philox4x32-10(seed, stream_id; slot, attempt)  ->  theta = inverse(noise | x[g])
+ *   accepted (finite and lo <= theta <= hi on every dim; lo/hi NULL = accept all finite):
+ *        theta written to out[slot*D ...]
+ *   rejected: slot appended to rejected[] (order unspecified), *n_rejected incremented.
+ * slots == NULL means the dense list slot = slot_base + i, i < n_slots.
+ * n_drawn (may be NULL) [M] int32: += 1 for every candidate drawn for galaxy g.
+ * Replaces: DirectPosterior.sample -> accept_reject_sample (sbi_runner.py:6442; box
+ * predicate custom_runner.py:982-987). */
+int sf_flow_sample_round(sf_flow* f, const float* x /*[M,C]*/, int64_t S,
+                         const uint32_t* slots, int64_t slot_base, int64_t n_slots,
+                         uint32_t attempt, uint64_t seed, uint32_t stream_id,
+                         const float* lo /*[D]*/, const float* hi /*[D]*/,
+                         float* out /*[M*S, D]*/, uint32_t* rejected, uint32_t* n_rejected,
+                         int32_t* n_drawn, void* stream);
+
+/* Whole sampler: runs rounds until every slot of x[0..M) x S is filled or max_attempts
+ * rounds were used; unfilled rows are NaN (sbi_runner.py:6458-6460 convention).
+ * Synchronises the stream between rounds (reads one counter).  n_drawn [M] may be NULL.
+ * Returns the number of unfilled slots through *n_unfilled (host). */
+int sf_flow_sample(sf_flow* f, const float* x /*[M,C]*/, int64_t M, int64_t S,
+                   const float* lo, const float* hi, uint64_t seed, int32_t max_attempts,
+                   float* out /*[M,S,D]*/, int32_t* n_drawn /*[M]*/, int64_t* n_unfilled /*host*/,
+                   void* stream);
+
+/* Accepted fraction of n unconstrained draws per row (stream_id 1): count[g] of n.
+ * Replaces: DirectPosterior.leakage_correction (custom_runner.py:466-473). */
+int sf_flow_acceptance(sf_flow* f, const float* x /*[M,C]*/, int64_t M, int64_t n,
+                       const float* lo, const float* hi, uint64_t seed,
+                       int32_t* count /*[M]*/, void* stream);
+
+/* ---- training -----------------------------------------------------------------------
+ * Forward + backward of  loss_b = -log_prob(theta_b | x_b)  with the parameters given in
+ * `flat` (device, logical layout):
+ *   loss[b] = loss_b                       (may be NULL)
+ *   grad[i] = sum_b w * d loss_b / d flat[i], w = grad_scale (pass 1/B for the mean loss)
+ * grad is overwritten (not accumulated).
+ * Replaces: train_losses = -estimator.log_prob(...); mean().backward()
+ * (custom_runner.py:604-610). */
+int sf_flow_loss_grad(sf_flow* f, const float* flat /*[P]*/, const float* theta, const float* x,
+                      int64_t B, float grad_scale, float* loss /*[B]*/, float* grad /*[P]*/,
+                      void* stream);
+
+/* Fused global-norm clip + Adam / AdamW step on flat vectors.
+ * Replaces: clip_grad_norm_(max_norm) + optimizer.step() (custom_runner.py:613-618). */
+typedef struct sf_adam_desc {
+  float lr, beta1, beta2, eps, weight_decay; /* torch defaults 1e-3, .9, .999, 1e-8, 0 (AdamW .01) */
+  int32_t decoupled;                           /* 0 = Adam (L2 in grad), 1 = AdamW */
+} sf_adam_desc;
+int sf_opt_create(int64_t n, const sf_adam_desc* d, sf_opt** out);
+void sf_opt_destroy(sf_opt* o);
+/* max_norm <= 0 disables clipping; *grad_norm_out (device float, may be NULL) gets the
+ * pre-clip global L2 norm. */
+int sf_adam_step(sf_opt* o, float* params, const float* grad, float max_norm,
+                 float* grad_norm_out, void* stream);
+/* optimizer state access for checkpoints (custom_runner.py:693-704): exp_avg, exp_avg_sq
+ * device pointers [n] and the step counter. */
+int sf_opt_state(sf_opt* o, float** exp_avg, float** exp_avg_sq, int64_t** step_host);
+
+/* ---- misc --------------------------------------------------------------------------- */
+const char* sf_last_error(void);
+const char* sf_version(void);
+/* number of visible HIP devices (0 on a CPU-only box; never fails) */
+int sf_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYNFERENCE_HIP_H */

@@ -1,0 +1,330 @@
+// sf_api.hip -- the C ABI (include/synference_hip.h): handle management and call sequencing.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sf_internal.h"
+#include "sf_train.h"
+
+namespace {
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+  return fail(SF_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define SF_HIP(call)                                  \
+  do {                                                \
+    hipError_t e_ = (call);                           \
+    if (e_ != hipSuccess) return hip_fail(e_, #call); \
+  } while (0)
+}  // namespace
+
+struct sf_flow {
+  SfLayout L;
+  bool dev_ready = false;
+  bool params_set = false;
+  float* d_packed = nullptr;
+  float* d_packedT = nullptr;
+  float* d_cst = nullptr;
+  int32_t *d_s1 = nullptr, *d_s2 = nullptr, *d_t1 = nullptr, *d_t2 = nullptr;
+  float* d_flat = nullptr;      // staging for host-sourced parameters
+  float* d_gpacked = nullptr;   // packed-layout gradient accumulator (training)
+  int32_t* d_gdst = nullptr;    // logical -> packed index for the gradient gather
+  int32_t* d_gdst2 = nullptr;
+  float* d_act = nullptr;       // activation stash (training)
+  size_t act_cap = 0;
+  uint32_t* d_rej[2] = {nullptr, nullptr};
+  size_t rej_cap = 0;
+  uint32_t* d_cnt = nullptr;  // [2] counters
+  float* d_box = nullptr;     // unused placeholder for future device-resident priors
+  SfDev dev() const {
+    SfDev v = L.dev;
+    v.packed = d_packed;
+    v.packedT = d_packedT;
+    v.cst = d_cst;
+    return v;
+  }
+};
+
+static int ensure_device(sf_flow* f) {
+  if (f->dev_ready) return SF_OK;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+    return fail(SF_ERR_NO_DEVICE, "no HIP device visible: the gfx950 flow engine has no CPU fallback");
+  const size_t np = (size_t)f->L.n_packed;
+  SF_HIP(hipMalloc(&f->d_packed, np * sizeof(float)));
+  SF_HIP(hipMemset(f->d_packed, 0, np * sizeof(float)));
+  SF_HIP(hipMalloc(&f->d_cst, f->L.cst.size() * sizeof(float)));
+  SF_HIP(hipMemcpy(f->d_cst, f->L.cst.data(), f->L.cst.size() * sizeof(float), hipMemcpyHostToDevice));
+  SF_HIP(hipMalloc(&f->d_s1, np * sizeof(int32_t)));
+  SF_HIP(hipMalloc(&f->d_s2, np * sizeof(int32_t)));
+  SF_HIP(hipMemcpy(f->d_s1, f->L.src1.data(), np * sizeof(int32_t), hipMemcpyHostToDevice));
+  SF_HIP(hipMemcpy(f->d_s2, f->L.src2.data(), np * sizeof(int32_t), hipMemcpyHostToDevice));
+  SF_HIP(hipMalloc(&f->d_flat, (size_t)f->L.n_params * sizeof(float)));
+  SF_HIP(hipMalloc(&f->d_cnt, 4 * sizeof(uint32_t)));
+  f->dev_ready = true;
+  return SF_OK;
+}
+
+extern "C" {
+
+const char* sf_last_error(void) { return g_err.c_str(); }
+const char* sf_version(void) { return "synference_hip 0.1 (gfx950, mfma_f32_32x32x2)"; }
+int sf_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int sf_flow_create(const sf_flow_desc* desc, sf_flow** out) {
+  if (!desc || !out) return fail(SF_ERR_INVALID, "null argument");
+  if (desc->kind == SF_NSF && desc->D < 2)
+    return fail(SF_ERR_INVALID, "NSF needs D >= 2 (the 1-D ContextSplineMap variant is not built)");
+  sf_flow* f = new sf_flow();
+  if (!sf_build_layout(*desc, f->L)) {
+    std::string e = f->L.error;
+    delete f;
+    return fail(SF_ERR_INVALID, e);
+  }
+  *out = f;
+  return SF_OK;
+}
+
+void sf_flow_destroy(sf_flow* f) {
+  if (!f) return;
+  if (f->dev_ready) {
+    hipFree(f->d_packed); hipFree(f->d_packedT); hipFree(f->d_cst);
+    hipFree(f->d_s1); hipFree(f->d_s2); hipFree(f->d_t1); hipFree(f->d_t2);
+    hipFree(f->d_flat); hipFree(f->d_gpacked); hipFree(f->d_gdst); hipFree(f->d_gdst2);
+    hipFree(f->d_act); hipFree(f->d_rej[0]); hipFree(f->d_rej[1]); hipFree(f->d_cnt);
+  }
+  delete f;
+}
+
+int64_t sf_flow_num_params(const sf_flow* f) { return f ? f->L.n_params : 0; }
+int64_t sf_flow_packed_size(const sf_flow* f) { return f ? f->L.n_packed : 0; }
+
+int sf_flow_pack_table(const sf_flow* f, int32_t* src1, int32_t* src2, int64_t n_packed) {
+  if (!f || !src1 || !src2) return fail(SF_ERR_INVALID, "null argument");
+  if (n_packed != f->L.n_packed) return fail(SF_ERR_INVALID, "n_packed mismatch");
+  std::memcpy(src1, f->L.src1.data(), (size_t)n_packed * sizeof(int32_t));
+  std::memcpy(src2, f->L.src2.data(), (size_t)n_packed * sizeof(int32_t));
+  return SF_OK;
+}
+
+int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen) {
+  if (!f || !buf) return fail(SF_ERR_INVALID, "null argument");
+  const SfDev& v = f->L.dev;
+  std::string s = "{";
+  auto add = [&](const char* k, long val) { s += "\"" + std::string(k) + "\": " + std::to_string(val) + ", "; };
+  add("kind", v.kind); add("D", v.D); add("C", v.C); add("H", v.H); add("T", v.T); add("K", v.K);
+  add("NB", v.NB); add("HT", v.HT); add("PT", v.PT); add("KMAX", v.KMAX); add("JP", v.JP);
+  add("nGu", v.nGu); add("nGc", v.nGc); add("nGh", v.nGh); add("t_stride", v.t_stride);
+  add("o_w0", v.o_w0); add("o_wc", v.o_wc); add("o_b0", v.o_b0); add("o_wk0", v.o_wk[0]);
+  add("o_bk0", v.o_bk[0]); add("o_wk1", v.o_wk[1]); add("o_bk1", v.o_bk[1]); add("o_wf", v.o_wf);
+  add("o_bf", v.o_bf); add("o_winu", v.o_winu); add("o_winc", v.o_winc); add("o_bin", v.o_bin);
+  add("o_wg0", v.o_wg[0]); add("o_bg0", v.o_bg[0]); add("o_w10", v.o_w1[0]); add("o_b10", v.o_b1[0]);
+  add("o_w20", v.o_w2[0]); add("o_b20", v.o_b2[0]); add("o_wg1", v.o_wg[1]); add("o_bg1", v.o_bg[1]);
+  add("o_w11", v.o_w1[1]); add("o_b11", v.o_b1[1]); add("o_w21", v.o_w2[1]); add("o_b21", v.o_b2[1]);
+  add("o_wout", v.o_wout); add("o_bout", v.o_bout); add("o_lu", v.o_lu);
+  add("c_pscale", v.c_pscale); add("c_pshift", v.c_pshift); add("c_tdim", v.c_tdim);
+  add("c_xmean", v.c_xmean); add("c_xstd", v.c_xstd);
+  add("n_params", f->L.n_params); add("n_packed", f->L.n_packed);
+  s += "\"cst\": [";
+  for (size_t i = 0; i < f->L.cst.size(); ++i) {
+    char t[40];
+    std::snprintf(t, sizeof(t), "%.9g%s", f->L.cst[i], i + 1 < f->L.cst.size() ? ", " : "");
+    s += t;
+  }
+  s += "]}";
+  if (s.size() + 1 > buflen) return fail(SF_ERR_INVALID, "buffer too small");
+  std::memcpy(buf, s.c_str(), s.size() + 1);
+  return SF_OK;
+}
+
+int sf_flow_set_params(sf_flow* f, const float* flat, int64_t n, int is_device, void* stream) {
+  if (!f || !flat) return fail(SF_ERR_INVALID, "null argument");
+  if (n != f->L.n_params) return fail(SF_ERR_INVALID, "parameter count mismatch");
+  int rc = ensure_device(f);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const float* src = flat;
+  if (!is_device) {
+    SF_HIP(hipMemcpyAsync(f->d_flat, flat, (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
+    src = f->d_flat;
+  }
+  SF_HIP(sf_launch_pack(src, f->d_s1, f->d_s2, f->d_packed, (long)f->L.n_packed, st));
+  f->params_set = true;
+  return SF_OK;
+}
+
+int sf_flow_log_prob(sf_flow* f, const float* theta, const float* x, int64_t B, float* out, void* stream) {
+  if (!f || !theta || !x || !out) return fail(SF_ERR_INVALID, "null argument");
+  if (!f->params_set) return fail(SF_ERR_STATE, "sf_flow_set_params has not been called");
+  if (B < 0) return fail(SF_ERR_INVALID, "B < 0");
+  SF_HIP(sf_launch_logprob(f->dev(), theta, x, (long)B, out, (hipStream_t)stream));
+  return SF_OK;
+}
+
+int sf_flow_inverse_from_noise(sf_flow* f, const float* z, const float* x, int64_t B, float* theta,
+                               float* logdet, void* stream) {
+  if (!f || !z || !x || !theta) return fail(SF_ERR_INVALID, "null argument");
+  if (!f->params_set) return fail(SF_ERR_STATE, "sf_flow_set_params has not been called");
+  SfSampleArgsHost a;
+  a.x = x; a.z_in = z; a.n_items = (long)B; a.out = theta; a.logdet_out = logdet;
+  SF_HIP(sf_launch_inverse(f->dev(), a, (hipStream_t)stream));
+  return SF_OK;
+}
+
+static void seed_keys(uint64_t seed, uint32_t stream_id, uint32_t& k0, uint32_t& k1) {
+  k0 = (uint32_t)(seed & 0xffffffffu);
+  k1 = (uint32_t)(seed >> 32) ^ stream_id;
+}
+
+int sf_flow_sample_round(sf_flow* f, const float* x, int64_t S, const uint32_t* slots, int64_t slot_base,
+                         int64_t n_slots, uint32_t attempt, uint64_t seed, uint32_t stream_id,
+                         const float* lo, const float* hi, float* out, uint32_t* rejected,
+                         uint32_t* n_rejected, int32_t* n_drawn, void* stream) {
+  if (!f || !x || !out || !rejected || !n_rejected) return fail(SF_ERR_INVALID, "null argument");
+  if (!f->params_set) return fail(SF_ERR_STATE, "sf_flow_set_params has not been called");
+  if (S < 1) return fail(SF_ERR_INVALID, "S < 1");
+  if ((lo == nullptr) != (hi == nullptr)) return fail(SF_ERR_INVALID, "lo and hi must be given together");
+  if ((uint64_t)(slot_base + n_slots) > 0xffffffffull)
+    return fail(SF_ERR_INVALID, "slot ids must fit 32 bits: split the catalogue");
+  SfSampleArgsHost a;
+  a.x = x; a.S = (long)S; a.slots = slots; a.slot_base = (long)slot_base; a.n_items = (long)n_slots;
+  a.attempt = attempt; seed_keys(seed, stream_id, a.k0, a.k1);
+  a.lo = lo; a.hi = hi; a.out = out; a.rejected = rejected; a.n_rejected = n_rejected; a.n_drawn = n_drawn;
+  SF_HIP(sf_launch_inverse(f->dev(), a, (hipStream_t)stream));
+  return SF_OK;
+}
+
+int sf_flow_sample(sf_flow* f, const float* x, int64_t M, int64_t S, const float* lo, const float* hi,
+                   uint64_t seed, int32_t max_attempts, float* out, int32_t* n_drawn, int64_t* n_unfilled,
+                   void* stream) {
+  if (!f || !x || !out) return fail(SF_ERR_INVALID, "null argument");
+  if (!f->params_set) return fail(SF_ERR_STATE, "sf_flow_set_params has not been called");
+  if (M < 0 || S < 1) return fail(SF_ERR_INVALID, "bad M or S");
+  if (max_attempts < 1) max_attempts = 1;
+  const int64_t total = M * S;
+  if (n_unfilled) *n_unfilled = 0;
+  if (total == 0) return SF_OK;
+  if ((uint64_t)total > 0xffffffffull) return fail(SF_ERR_INVALID, "M*S must fit 32 bits: split the catalogue");
+  hipStream_t st = (hipStream_t)stream;
+  // Rejected-slot lists: sized for the worst case of round 0 lazily -- start at total/4 and fall
+  // back to a full-size list only when a round would overflow it.
+  size_t need = (size_t)total;
+  if (f->rej_cap < need) {
+    hipFree(f->d_rej[0]); hipFree(f->d_rej[1]);
+    f->d_rej[0] = f->d_rej[1] = nullptr;
+    SF_HIP(hipMalloc(&f->d_rej[0], need * sizeof(uint32_t)));
+    SF_HIP(hipMalloc(&f->d_rej[1], need * sizeof(uint32_t)));
+    f->rej_cap = need;
+  }
+  if (n_drawn) SF_HIP(sf_launch_fill_i32(n_drawn, (long)M, (int32_t)S, st));
+  int64_t pending = total;
+  const uint32_t* cur = nullptr;
+  int buf = 0;
+  for (int attempt = 0; attempt < max_attempts && pending > 0; ++attempt) {
+    SF_HIP(hipMemsetAsync(f->d_cnt, 0, sizeof(uint32_t), st));
+    int rc = sf_flow_sample_round(f, x, S, cur, 0, pending, (uint32_t)attempt, seed, 0, lo, hi, out,
+                                  f->d_rej[buf], f->d_cnt, n_drawn, stream);
+    if (rc) return rc;
+    uint32_t nrej = 0;
+    SF_HIP(hipMemcpyAsync(&nrej, f->d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SF_HIP(hipStreamSynchronize(st));
+    pending = nrej;
+    cur = f->d_rej[buf];
+    buf ^= 1;
+  }
+  if (pending > 0) SF_HIP(sf_launch_fill_nan_rows(out, cur, (long)pending, f->L.dev.D, st));
+  if (n_unfilled) *n_unfilled = pending;
+  return SF_OK;
+}
+
+int sf_flow_acceptance(sf_flow* f, const float* x, int64_t M, int64_t n, const float* lo, const float* hi,
+                       uint64_t seed, int32_t* count, void* stream) {
+  if (!f || !x || !count || !lo || !hi) return fail(SF_ERR_INVALID, "null argument");
+  if (!f->params_set) return fail(SF_ERR_STATE, "sf_flow_set_params has not been called");
+  if (M < 0 || n < 1) return fail(SF_ERR_INVALID, "bad M or n");
+  if ((uint64_t)(M * n) > 0xffffffffull) return fail(SF_ERR_INVALID, "M*n must fit 32 bits");
+  hipStream_t st = (hipStream_t)stream;
+  SF_HIP(sf_launch_fill_i32(count, (long)M, 0, st));
+  SfSampleArgsHost a;
+  a.x = x; a.S = (long)n; a.n_items = (long)(M * n); seed_keys(seed, 1u, a.k0, a.k1);
+  a.lo = lo; a.hi = hi; a.count = count;
+  SF_HIP(sf_launch_inverse(f->dev(), a, st));
+  return SF_OK;
+}
+
+// ---- training ------------------------------------------------------------------------------
+int sf_flow_loss_grad(sf_flow* f, const float* flat, const float* theta, const float* x, int64_t B,
+                      float grad_scale, float* loss, float* grad, void* stream) {
+  if (!f || !flat || !theta || !x || !grad) return fail(SF_ERR_INVALID, "null argument");
+  int rc = ensure_device(f);
+  if (rc) return rc;
+  std::string err;
+  rc = sf_train_loss_grad(f->L, f->dev(), &f->d_packedT, &f->d_t1, &f->d_t2, &f->d_gpacked, &f->d_gdst,
+                          &f->d_gdst2, &f->d_act, &f->act_cap, f->d_s1, f->d_s2, f->d_packed, flat, theta, x,
+                          (long)B, grad_scale, loss, grad, (hipStream_t)stream, err);
+  if (rc) return fail(rc, err);
+  f->params_set = true;  // forward image now holds `flat`
+  return SF_OK;
+}
+
+struct sf_opt {
+  int64_t n = 0;
+  sf_adam_desc d{};
+  float* m = nullptr;
+  float* v = nullptr;
+  float* norm = nullptr;  // device scalar: sum of squares
+  int64_t step = 0;
+};
+
+int sf_opt_create(int64_t n, const sf_adam_desc* d, sf_opt** out) {
+  if (n < 1 || !d || !out) return fail(SF_ERR_INVALID, "bad argument");
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || nd == 0) return fail(SF_ERR_NO_DEVICE, "no HIP device visible");
+  sf_opt* o = new sf_opt();
+  o->n = n;
+  o->d = *d;
+  SF_HIP(hipMalloc(&o->m, (size_t)n * sizeof(float)));
+  SF_HIP(hipMalloc(&o->v, (size_t)n * sizeof(float)));
+  SF_HIP(hipMalloc(&o->norm, sizeof(float)));
+  SF_HIP(hipMemset(o->m, 0, (size_t)n * sizeof(float)));
+  SF_HIP(hipMemset(o->v, 0, (size_t)n * sizeof(float)));
+  *out = o;
+  return SF_OK;
+}
+void sf_opt_destroy(sf_opt* o) {
+  if (!o) return;
+  hipFree(o->m); hipFree(o->v); hipFree(o->norm);
+  delete o;
+}
+int sf_adam_step(sf_opt* o, float* params, const float* grad, float max_norm, float* grad_norm_out, void* stream) {
+  if (!o || !params || !grad) return fail(SF_ERR_INVALID, "null argument");
+  o->step += 1;
+  const double bc1 = 1.0 - std::pow((double)o->d.beta1, (double)o->step);
+  const double bc2 = 1.0 - std::pow((double)o->d.beta2, (double)o->step);
+  hipError_t e = sf_launch_adam(params, grad, o->m, o->v, o->norm, (long)o->n, o->d, (float)bc1, (float)bc2,
+                                max_norm, grad_norm_out, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "sf_launch_adam");
+  return SF_OK;
+}
+int sf_opt_state(sf_opt* o, float** exp_avg, float** exp_avg_sq, int64_t** step_host) {
+  if (!o) return fail(SF_ERR_INVALID, "null argument");
+  if (exp_avg) *exp_avg = o->m;
+  if (exp_avg_sq) *exp_avg_sq = o->v;
+  if (step_host) *step_host = &o->step;
+  return SF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,125 @@
+// sf_device.h -- register-tile MLP engine on v_mfma_f32_32x32x2_f32 (gfx950 only).
+// Layout conventions: sf_layout.h.  Everything here is __device__ __forceinline__ and
+// statically indexed so that activation tiles live in VGPRs for a whole flow.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "sf_layout.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define SF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ constexpr int sf_row(int r, int h) {
+  return (r & 3) + 8 * (r >> 2) + 4 * h;
+}
+
+// ---- scalar math -------------------------------------------------------------------------
+__device__ __forceinline__ float sf_tanh(float x) {
+  // 1 - 2/(1+e^{2x}); abs error ~1e-7, saturates cleanly at +-1
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+}
+__device__ __forceinline__ float sf_sigmoid(float x) {
+  const float e = __builtin_amdgcn_exp2f(-x * 1.4426950408889634f);
+  return __builtin_amdgcn_rcpf(1.0f + e);
+}
+__device__ __forceinline__ float sf_softplus(float x) {  // torch: threshold 20
+  return x > 20.0f ? x : log1pf(expf(x));
+}
+__device__ __forceinline__ float sf_xhalf(float v) {  // value held by the other row-half
+  return __shfl_xor(v, 32, 64);
+}
+
+// ---- accumulator init from the bias image [mt][h][16] ------------------------------------
+template <int OT, int NS>
+__device__ __forceinline__ void sf_init_bias(f32x16 (&acc)[OT][NS], const float* __restrict__ bp, int h) {
+#pragma unroll
+  for (int mt = 0; mt < OT; ++mt) {
+    const float4* p = reinterpret_cast<const float4*>(bp + (mt * 2 + h) * 16);
+    const float4 b0 = p[0], b1 = p[1], b2 = p[2], b3 = p[3];
+    f32x16 v;
+    v[0] = b0.x; v[1] = b0.y; v[2] = b0.z; v[3] = b0.w;
+    v[4] = b1.x; v[5] = b1.y; v[6] = b1.z; v[7] = b1.w;
+    v[8] = b2.x; v[9] = b2.y; v[10] = b2.z; v[11] = b2.w;
+    v[12] = b3.x; v[13] = b3.y; v[14] = b3.z; v[15] = b3.w;
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) acc[mt][ns] = v;
+  }
+}
+
+// ---- acc[mt] += W[mt, groups kg0..kg0+ng) . in  -------------------------------------------
+// in[IT][NS]: IT input tiles (static); ng active groups (runtime, wave-uniform, <= 4*IT);
+// nGtot: group stride of the weight block.  One float4 load feeds 4*NS MFMAs.
+template <int OT, int NS, int IT, bool RELU>
+__device__ __forceinline__ void sf_mm_acc(f32x16 (&acc)[OT][NS], const f32x16 (&in)[IT][NS],
+                                          const float* __restrict__ wp, int nGtot, int kg0, int ng,
+                                          int lane) {
+  const float4* __restrict__ w4 = reinterpret_cast<const float4*>(wp);
+#pragma unroll
+  for (int mt = 0; mt < OT; ++mt) {
+#pragma unroll
+    for (int g = 0; g < IT * 4; ++g) {
+      if (g < ng) {
+        const float4 w = w4[(mt * nGtot + kg0 + g) * 64 + lane];
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) {
+          float b0 = in[g >> 2][ns][(g & 3) * 4 + 0];
+          float b1 = in[g >> 2][ns][(g & 3) * 4 + 1];
+          float b2 = in[g >> 2][ns][(g & 3) * 4 + 2];
+          float b3 = in[g >> 2][ns][(g & 3) * 4 + 3];
+          if (RELU) {
+            b0 = fmaxf(b0, 0.f); b1 = fmaxf(b1, 0.f); b2 = fmaxf(b2, 0.f); b3 = fmaxf(b3, 0.f);
+          }
+          acc[mt][ns] = SF_MFMA(w.x, b0, acc[mt][ns]);
+          acc[mt][ns] = SF_MFMA(w.y, b1, acc[mt][ns]);
+          acc[mt][ns] = SF_MFMA(w.z, b2, acc[mt][ns]);
+          acc[mt][ns] = SF_MFMA(w.w, b3, acc[mt][ns]);
+        }
+      }
+    }
+  }
+}
+
+// ---- input tiles ----------------------------------------------------------------------------
+// u tile: row rho = physical slot rho (D <= 16 -> registers 0..7 only)
+template <int NS>
+__device__ __forceinline__ void sf_build_u_tile(f32x16 (&ut)[1][NS], const float (&u)[NS][SF_DMAX], int h) {
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) ut[0][ns][r] = h ? u[ns][sf_row(r, 1)] : u[ns][sf_row(r, 0)];
+#pragma unroll
+    for (int r = 8; r < 16; ++r) ut[0][ns][r] = 0.f;
+  }
+}
+
+// context tile kt: row rho = standardised context feature kt*32+rho of the lane's sample
+template <int NS>
+__device__ __forceinline__ void sf_build_ctx_tile(f32x16 (&ct)[1][NS], const float* const (&xr)[NS],
+                                                  const SfDev& m, int kt, int h) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int rho = kt * 32 + sf_row(r, h);
+    const bool ok = rho < m.C;
+    const int rr = ok ? rho : 0;
+    const float mu = m.cst[m.c_xmean + rr], sd = m.cst[m.c_xstd + rr];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+      const float v = (xr[ns][rr] - mu) / sd;
+      ct[0][ns][r] = ok ? v : 0.f;
+    }
+  }
+}
+
+// acc += Wc . e(x) over all context tiles
+template <int OT, int NS>
+__device__ __forceinline__ void sf_ctx_mm(f32x16 (&acc)[OT][NS], const float* const (&xr)[NS],
+                                          const SfDev& m, const float* __restrict__ wp, int lane) {
+  for (int kt = 0; kt * 4 < m.nGc; ++kt) {
+    f32x16 ct[1][NS];
+    sf_build_ctx_tile<NS>(ct, xr, m, kt, lane >> 5);
+    const int ng = min(4, m.nGc - kt * 4);
+    sf_mm_acc<OT, NS, 1, false>(acc, ct, wp, m.nGc, kt * 4, ng, lane);
+  }
+}

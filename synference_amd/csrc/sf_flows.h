@@ -1,0 +1,425 @@
+// sf_flows.h -- the two flow families on the register-tile engine.
+//   MafOps: [UPSTREAM] nflows MaskedAffineAutoregressiveTransform + RandomPermutation
+//           (SURVEY.md B.3), permutations folded into the weight image (sf_layout.cpp).
+//   NsfOps: [UPSTREAM] PiecewiseRationalQuadraticCouplingTransform (ResidualNet conditioner,
+//           GLU context gates) + LULinear.
+// State per lane: u[ns][p] = value of physical slot p for the lane's sample of sample tile ns,
+// replicated in both row halves; logdet[ns] replicated likewise.
+#pragma once
+#include "sf_device.h"
+
+// =============================================================================================
+// MAF
+// =============================================================================================
+template <int HT, int NS>
+struct MafOps {
+  // MADE: (a_p, m_p) for every slot p land in fin[0][ns][2*(p>>1)], [2*(p>>1)+1] on half p&1
+  static __device__ __forceinline__ void made(const SfDev& m, const float* __restrict__ tp,
+                                              const float (&u)[NS][SF_DMAX],
+                                              const float* const (&xr)[NS], f32x16 (&fin)[1][NS],
+                                              int lane) {
+    const int h = lane >> 5;
+    f32x16 a[HT][NS];
+    sf_init_bias<HT, NS>(a, tp + m.o_b0, h);
+    {
+      f32x16 ut[1][NS];
+      sf_build_u_tile<NS>(ut, u, h);
+      sf_mm_acc<HT, NS, 1, false>(a, ut, tp + m.o_w0, m.nGu, 0, m.nGu, lane);
+    }
+    sf_ctx_mm<HT, NS>(a, xr, m, tp + m.o_wc, lane);
+#pragma unroll
+    for (int k = 0; k < SF_NBMAX; ++k) {
+      if (k < m.NB) {
+        f32x16 b[HT][NS];
+        sf_init_bias<HT, NS>(b, tp + m.o_bk[k], h);
+        sf_mm_acc<HT, NS, HT, false>(b, a, tp + m.o_wk[k], m.nGh, 0, m.nGh, lane);
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt)
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[mt][ns][r] = sf_tanh(b[mt][ns][r]);
+      }
+    }
+    sf_init_bias<1, NS>(fin, tp + m.o_bf, h);
+    sf_mm_acc<1, NS, HT, false>(fin, a, tp + m.o_wf, m.nGh, 0, m.nGh, lane);
+  }
+
+  static __device__ __forceinline__ float scale(const SfDev& m, float a) {
+    return (m.scale_fn == 0 ? sf_softplus(a) : sf_sigmoid(a + 2.0f)) + m.eps;
+  }
+
+  // density direction: u <- s*u + m for every transform, logdet += sum log s
+  static __device__ __forceinline__ void forward(const SfDev& m, float (&u)[NS][SF_DMAX],
+                                                 const float* const (&xr)[NS], float (&logdet)[NS],
+                                                 int lane) {
+    const int h = lane >> 5;
+    for (int t = 0; t < m.T; ++t) {
+      const float* tp = m.packed + (size_t)t * m.t_stride;
+      f32x16 fin[1][NS];
+      made(m, tp, u, xr, fin, lane);
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        float ld = 0.f;
+#pragma unroll
+        for (int p = 0; p < SF_DMAX; ++p) {
+          if (p < m.D) {
+            const float s = scale(m, fin[0][ns][2 * (p >> 1)]);
+            const float val = s * u[ns][p] + fin[0][ns][2 * (p >> 1) + 1];
+            const bool mine = (h == (p & 1));
+            const float oth = sf_xhalf(val);
+            u[ns][p] = mine ? val : oth;
+            ld += mine ? logf(s) : 0.f;
+          }
+        }
+        logdet[ns] += ld + sf_xhalf(ld);
+      }
+    }
+  }
+
+  // sampling direction: transforms in reverse, D MADE passes each (AutoregressiveTransform.inverse)
+  static __device__ __forceinline__ void inverse(const SfDev& m, float (&u)[NS][SF_DMAX],
+                                                 const float* const (&xr)[NS], float (&logdet)[NS],
+                                                 int lane) {
+    const int h = lane >> 5;
+    for (int t = m.T - 1; t >= 0; --t) {
+      const float* tp = m.packed + (size_t)t * m.t_stride;
+      float w[NS][SF_DMAX];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+        for (int p = 0; p < SF_DMAX; ++p) w[ns][p] = 0.f;
+      float ldl[NS];
+      for (int pass = 0; pass < m.D; ++pass) {
+        f32x16 fin[1][NS];
+        made(m, tp, w, xr, fin, lane);
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) {
+          float ld = 0.f;
+#pragma unroll
+          for (int p = 0; p < SF_DMAX; ++p) {
+            if (p < m.D) {
+              const float s = scale(m, fin[0][ns][2 * (p >> 1)]);
+              const float val = (u[ns][p] - fin[0][ns][2 * (p >> 1) + 1]) / s;
+              const bool mine = (h == (p & 1));
+              const float oth = sf_xhalf(val);
+              w[ns][p] = mine ? val : oth;
+              ld += mine ? logf(s) : 0.f;
+            }
+          }
+          ldl[ns] = ld + sf_xhalf(ld);
+        }
+      }
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        logdet[ns] -= ldl[ns];
+#pragma unroll
+        for (int p = 0; p < SF_DMAX; ++p) u[ns][p] = w[ns][p];
+      }
+    }
+  }
+};
+
+// =============================================================================================
+// NSF
+// =============================================================================================
+// One rational-quadratic spline evaluation with linear tails
+// ([UPSTREAM] nflows unconstrained_rational_quadratic_spline).  Parameter slots of the PT tiles:
+// widths [0,KM), heights [KM,2KM), interior derivatives [2KM, 3KM-1), KM = (16*PT+1)/3.
+template <int PT>
+struct SfSpline {
+  static constexpr int KM = (PT * 16 + 1) / 3;
+
+  template <int NS>
+  static __device__ __forceinline__ float Q(const f32x16 (&q)[PT][NS], int ns, int s) {
+    return q[s >> 4][ns][s & 15];
+  }
+
+  // softmax-normalised bin sizes of one parameter family -> knots; selects the bin
+  //   BY_VALUE: largest k with v >= knot_k (searchsorted semantics incl. the +1e-6 on the last knot)
+  //   else    : k == idx
+  template <int NS, int OFF, bool BY_VALUE>
+  static __device__ __forceinline__ void knots(const SfDev& m, const f32x16 (&q)[PT][NS], int ns,
+                                               float min_size, float v, int& idx, float& left,
+                                               float& size) {
+    const int K = m.K;
+    const float B = m.tail_bound;
+    float e[KM];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+      if (k < K) {
+        e[k] = Q<NS>(q, ns, OFF + k) * m.inv_sqrt_h;
+        mx = fmaxf(mx, e[k]);
+      }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+      if (k < K) {
+        e[k] = expf(e[k] - mx);
+        sum += e[k];
+      }
+    const float scale = (1.0f - min_size * (float)K);
+    float cs = 0.f, c_lo = -B;
+    left = -B;
+    size = 1.f;
+    if (BY_VALUE) idx = 0;
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+      if (k < K) {
+        cs += min_size + scale * (e[k] / sum);
+        const float c_hi = (k == K - 1) ? B : (2.0f * B * cs - B);
+        const bool sel = BY_VALUE ? (v >= c_lo) : (k == idx);
+        if (sel) {
+          left = c_lo;
+          size = c_hi - c_lo;
+          if (BY_VALUE) idx = k;
+        }
+        c_lo = c_hi;
+      }
+  }
+
+  template <int NS>
+  static __device__ __forceinline__ void eval(const SfDev& m, const f32x16 (&q)[PT][NS], int ns,
+                                              float v, bool inverse, float& out, float& lad) {
+    const int K = m.K;
+    const float B = m.tail_bound;
+    const bool inside = (v >= -B) && (v <= B);
+    const float vc = fminf(fmaxf(v, -B), B);
+    int idx = 0;
+    float x_k, w_k, y_k, h_k;
+    if (!inverse) {
+      knots<NS, 0, true>(m, q, ns, m.min_w, vc, idx, x_k, w_k);
+      knots<NS, KM, false>(m, q, ns, m.min_h, vc, idx, y_k, h_k);
+    } else {
+      knots<NS, KM, true>(m, q, ns, m.min_h, vc, idx, y_k, h_k);
+      knots<NS, 0, false>(m, q, ns, m.min_w, vc, idx, x_k, w_k);
+    }
+    // derivatives at the bin's two knots (boundary knots use the padded constant)
+    const float d_edge = m.min_d + sf_softplus(m.deriv_const);
+    float d_k = d_edge, d_k1 = d_edge;
+#pragma unroll
+    for (int j = 1; j < KM; ++j)
+      if (j < K) {
+        const float dj = m.min_d + sf_softplus(Q<NS>(q, ns, 2 * KM + j - 1));
+        d_k = (j == idx) ? dj : d_k;
+        d_k1 = (j == idx + 1) ? dj : d_k1;
+      }
+    const float s_k = h_k / w_k;
+    float xi;
+    if (!inverse) {
+      xi = (vc - x_k) / w_k;
+      const float om = xi * (1.f - xi);
+      const float num = h_k * (s_k * xi * xi + d_k * om);
+      const float den = s_k + (d_k + d_k1 - 2.f * s_k) * om;
+      out = y_k + num / den;
+    } else {
+      const float dy = vc - y_k;
+      const float tmp = dy * (d_k + d_k1 - 2.f * s_k);
+      const float a = tmp + h_k * (s_k - d_k);
+      const float b = h_k * d_k - tmp;
+      const float c = -s_k * dy;
+      const float disc = b * b - 4.f * a * c;
+      xi = (2.f * c) / (-b - sqrtf(disc));
+      out = xi * w_k + x_k;
+    }
+    const float om = xi * (1.f - xi);
+    const float den = s_k + (d_k + d_k1 - 2.f * s_k) * om;
+    const float dnum = s_k * s_k * (d_k1 * xi * xi + 2.f * s_k * om + d_k * (1.f - xi) * (1.f - xi));
+    lad = logf(dnum) - 2.f * logf(den);
+    if (inverse) lad = -lad;
+    out = inside ? out : v;
+    lad = inside ? lad : 0.f;
+  }
+};
+
+template <int HT, int PT, int NS>
+struct NsfOps {
+  // ResidualNet conditioner -> hidden tiles
+  static __device__ __forceinline__ void resnet(const SfDev& m, const float* __restrict__ tp,
+                                                const float (&u)[NS][SF_DMAX],
+                                                const float* const (&xr)[NS], f32x16 (&hid)[HT][NS],
+                                                int lane) {
+    const int h = lane >> 5;
+    sf_init_bias<HT, NS>(hid, tp + m.o_bin, h);
+    {
+      f32x16 ut[1][NS];
+      sf_build_u_tile<NS>(ut, u, h);
+      sf_mm_acc<HT, NS, 1, false>(hid, ut, tp + m.o_winu, m.nGu, 0, m.nGu, lane);
+    }
+    sf_ctx_mm<HT, NS>(hid, xr, m, tp + m.o_winc, lane);
+#pragma unroll
+    for (int k = 0; k < SF_NBMAX; ++k) {
+      if (k < m.NB) {
+        f32x16 t2[HT][NS];
+        {
+          f32x16 t1[HT][NS];
+          sf_init_bias<HT, NS>(t1, tp + m.o_b1[k], h);
+          sf_mm_acc<HT, NS, HT, true>(t1, hid, tp + m.o_w1[k], m.nGh, 0, m.nGh, lane);
+          sf_init_bias<HT, NS>(t2, tp + m.o_b2[k], h);
+          sf_mm_acc<HT, NS, HT, true>(t2, t1, tp + m.o_w2[k], m.nGh, 0, m.nGh, lane);
+        }
+        // GLU gate, one output tile at a time: hid += t2 * sigmoid(Wg e + bg)
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) {
+          f32x16 g[1][NS];
+          sf_init_bias<1, NS>(g, tp + m.o_bg[k] + mt * 32, h);
+          sf_ctx_mm<1, NS>(g, xr, m, tp + m.o_wg[k] + mt * m.nGc * 256, lane);
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              hid[mt][ns][r] += t2[mt][ns][r] * sf_sigmoid(g[0][ns][r]);
+        }
+      }
+    }
+  }
+
+  // coupling: spline on the transform dims of parity t&1, conditioner on the others
+  static __device__ __forceinline__ void coupling(const SfDev& m, const float* __restrict__ tp, int t,
+                                                  float (&u)[NS][SF_DMAX], const float* const (&xr)[NS],
+                                                  float (&logdet)[NS], bool inverse, int lane) {
+    const int h = lane >> 5;
+    f32x16 hid[HT][NS];
+    resnet(m, tp, u, xr, hid, lane);
+    const int start = t & 1;
+    const int d_tr = (m.D - start + 1) / 2;
+    for (int jp = 0; jp * 2 < d_tr; ++jp) {
+      f32x16 q[PT][NS];
+      sf_init_bias<PT, NS>(q, tp + m.o_bout + jp * PT * 32, h);
+      sf_mm_acc<PT, NS, HT, false>(q, hid, tp + m.o_wout + jp * PT * m.nGh * 256, m.nGh, 0, m.nGh, lane);
+      const int kdim = 2 * jp + h;          // this half's transform-dim index
+      const bool have = kdim < d_tr;
+      const int tgt = start + 2 * kdim;     // its physical slot
+      const int tgt_o = start + 2 * (2 * jp + (1 - h));
+      const bool have_o = (2 * jp + (1 - h)) < d_tr;
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        float vin = 0.f;
+#pragma unroll
+        for (int p = 0; p < SF_DMAX; ++p) vin = (p == tgt) ? u[ns][p] : vin;
+        float vout, lad;
+        SfSpline<PT>::template eval<NS>(m, q, ns, vin, inverse, vout, lad);
+        lad = have ? lad : 0.f;
+        const float vo = sf_xhalf(vout);
+#pragma unroll
+        for (int p = 0; p < SF_DMAX; ++p) {
+          u[ns][p] = (have && p == tgt) ? vout : u[ns][p];
+          u[ns][p] = (have_o && p == tgt_o) ? vo : u[ns][p];
+        }
+        logdet[ns] += lad + sf_xhalf(lad);
+      }
+    }
+  }
+
+  // LULinear:  y = L (U u) + b ;  diag(U) = softplus(udiag) + eps
+  static __device__ __forceinline__ void lu_forward(const SfDev& m, const float* __restrict__ lp,
+                                                    float (&u)[NS][SF_DMAX], float (&logdet)[NS]) {
+    const int D = m.D;
+    const float* Lm = lp;
+    const float* Um = lp + D * D;
+    const float* ud = lp + 2 * D * D;
+    const float* bb = ud + D;
+    float ld = 0.f;
+    float t[NS][SF_DMAX];
+#pragma unroll
+    for (int i = 0; i < SF_DMAX; ++i)
+      if (i < D) {
+        const float dg = sf_softplus(ud[i]) + m.lu_eps;
+        ld += logf(dg);
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) t[ns][i] = dg * u[ns][i];
+#pragma unroll
+        for (int j = 0; j < SF_DMAX; ++j)
+          if (j > i && j < D) {
+            const float w = Um[i * D + j];
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) t[ns][i] += w * u[ns][j];
+          }
+      }
+#pragma unroll
+    for (int i = 0; i < SF_DMAX; ++i)
+      if (i < D) {
+        const float b = bb[i];
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) u[ns][i] = t[ns][i] + b;
+#pragma unroll
+        for (int j = 0; j < SF_DMAX; ++j)
+          if (j < i) {
+            const float w = Lm[i * D + j];
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) u[ns][i] += w * t[ns][j];
+          }
+      }
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) logdet[ns] += ld;
+  }
+
+  // inverse: u = U^{-1} L^{-1} (y - b)
+  static __device__ __forceinline__ void lu_inverse(const SfDev& m, const float* __restrict__ lp,
+                                                    float (&u)[NS][SF_DMAX], float (&logdet)[NS]) {
+    const int D = m.D;
+    const float* Lm = lp;
+    const float* Um = lp + D * D;
+    const float* ud = lp + 2 * D * D;
+    const float* bb = ud + D;
+    float ld = 0.f;
+    float t[NS][SF_DMAX];
+    // forward substitution with unit-lower L
+#pragma unroll
+    for (int i = 0; i < SF_DMAX; ++i)
+      if (i < D) {
+        const float b = bb[i];
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) t[ns][i] = u[ns][i] - b;
+#pragma unroll
+        for (int j = 0; j < SF_DMAX; ++j)
+          if (j < i) {
+            const float w = Lm[i * D + j];
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) t[ns][i] -= w * t[ns][j];
+          }
+      }
+    // back substitution with U
+#pragma unroll
+    for (int ii = 0; ii < SF_DMAX; ++ii) {
+      const int i = SF_DMAX - 1 - ii;
+      if (i < D) {
+        const float dg = sf_softplus(ud[i]) + m.lu_eps;
+        ld += logf(dg);
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) u[ns][i] = t[ns][i];
+#pragma unroll
+        for (int j = 0; j < SF_DMAX; ++j)
+          if (j > i && j < D) {
+            const float w = Um[i * D + j];
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) u[ns][i] -= w * u[ns][j];
+          }
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) u[ns][i] /= dg;
+      }
+    }
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) logdet[ns] -= ld;
+  }
+
+  static __device__ __forceinline__ void forward(const SfDev& m, float (&u)[NS][SF_DMAX],
+                                                 const float* const (&xr)[NS], float (&logdet)[NS],
+                                                 int lane) {
+    for (int t = 0; t < m.T; ++t) {
+      const float* tp = m.packed + (size_t)t * m.t_stride;
+      coupling(m, tp, t, u, xr, logdet, false, lane);
+      if (m.D > 1) lu_forward(m, tp + m.o_lu, u, logdet);
+    }
+  }
+  static __device__ __forceinline__ void inverse(const SfDev& m, float (&u)[NS][SF_DMAX],
+                                                 const float* const (&xr)[NS], float (&logdet)[NS],
+                                                 int lane) {
+    for (int t = m.T - 1; t >= 0; --t) {
+      const float* tp = m.packed + (size_t)t * m.t_stride;
+      if (m.D > 1) lu_inverse(m, tp + m.o_lu, u, logdet);
+      coupling(m, tp, t, u, xr, logdet, true, lane);
+    }
+  }
+};

@@ -1,0 +1,148 @@
+// sf_inst_templates.h -- gfx950 kernel templates of the inference direction (log_prob, inverse,
+// sampler).  One wave handles NS tiles of 32 samples end to end; waves are
+// independent (no LDS, no barriers); weights stream from L2 in the MFMA operand image.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "sf_flows.h"
+#include "sf_internal.h"
+#include "sf_rng.h"
+
+#define SF_LOG_2PI 1.8378770664093453f
+
+// ---------------------------------------------------------------------------------------------
+// log_prob:  out[i] = log N(z;0,I) + logdet          ref: custom_runner.py:604 (via [UPSTREAM] Flow.log_prob)
+// ---------------------------------------------------------------------------------------------
+template <class Ops, int NS>
+__global__ __launch_bounds__(256) void k_logprob(SfDev m, const float* __restrict__ theta,
+                                                 const float* __restrict__ x, long B,
+                                                 float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const long base = ((long)blockIdx.x * 4 + wave) * (32 * NS);
+  if (base >= B) return;
+  float u[NS][SF_DMAX];
+  const float* xr[NS];
+  float logdet[NS];
+  long row[NS];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    row[ns] = base + ns * 32 + c;
+    const long ii = row[ns] < B ? row[ns] : B - 1;
+    xr[ns] = x + ii * m.C;
+    logdet[ns] = m.logdet0;
+#pragma unroll
+    for (int p = 0; p < SF_DMAX; ++p) {
+      u[ns][p] = 0.f;
+      if (p < m.D) {
+        const int td = (int)m.cst[m.c_tdim + p];
+        u[ns][p] = theta[ii * m.D + td] * m.cst[m.c_pscale + p] + m.cst[m.c_pshift + p];
+      }
+    }
+  }
+  Ops::forward(m, u, xr, logdet, lane);
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    float s = 0.f;
+#pragma unroll
+    for (int p = 0; p < SF_DMAX; ++p)
+      if (p < m.D) s += u[ns][p] * u[ns][p];
+    const float lp = -0.5f * s - 0.5f * (float)m.D * SF_LOG_2PI + logdet[ns];
+    if (h == 0 && row[ns] < B) out[row[ns]] = lp;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// inverse / sampler round / acceptance count
+//   z_in != NULL : parity hook, item i uses z_in[i,:], context row i, writes theta[i,:], logdet[i]
+//   else         : item i -> slot (slots[i] or slot_base+i), galaxy g = slot / S, noise from Philox;
+//                  box test; accepted -> out[slot,:], rejected -> appended to rejected[]
+//                  count != NULL: acceptance mode, no writes, count[g] += accepted
+// ref: sbi_runner.py:6442 -> [UPSTREAM] DirectPosterior.sample / accept_reject_sample;
+//      box predicate custom_runner.py:982-987
+// ---------------------------------------------------------------------------------------------
+
+template <class Ops, int NS>
+__global__ __launch_bounds__(256) void k_inverse(SfDev m, SfSampleArgsHost a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const long base = ((long)blockIdx.x * 4 + wave) * (32 * NS);
+  if (base >= a.n_items) return;
+  float u[NS][SF_DMAX];
+  const float* xr[NS];
+  float logdet[NS];
+  long item[NS];
+  uint64_t slot[NS];
+  long gal[NS];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    item[ns] = base + ns * 32 + c;
+    const long it = item[ns] < a.n_items ? item[ns] : a.n_items - 1;
+    logdet[ns] = 0.f;
+#pragma unroll
+    for (int p = 0; p < SF_DMAX; ++p) u[ns][p] = 0.f;
+    if (a.z_in) {
+      slot[ns] = (uint64_t)it;
+      gal[ns] = it;
+#pragma unroll
+      for (int p = 0; p < SF_DMAX; ++p)
+        if (p < m.D) u[ns][p] = a.z_in[it * m.D + p];
+    } else {
+      slot[ns] = a.slots ? (uint64_t)a.slots[it] : (uint64_t)(a.slot_base + it);
+      gal[ns] = (long)(slot[ns] / (uint64_t)a.S);
+#pragma unroll
+      for (int blk = 0; blk < SF_DMAX / 4; ++blk)
+        if (blk * 4 < m.D) {
+          float z4[4];
+          sf_normal4(a.k0, a.k1, slot[ns], a.attempt, (uint32_t)blk, z4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) u[ns][blk * 4 + j] = (blk * 4 + j < m.D) ? z4[j] : 0.f;
+        }
+    }
+    xr[ns] = a.x + gal[ns] * m.C;
+  }
+  Ops::inverse(m, u, xr, logdet, lane);
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    const bool valid = item[ns] < a.n_items;
+    float th[SF_DMAX];
+    bool ok = true;
+#pragma unroll
+    for (int p = 0; p < SF_DMAX; ++p)
+      if (p < m.D) {
+        const int td = (int)m.cst[m.c_tdim + p];
+        th[p] = (u[ns][p] - m.cst[m.c_pshift + p]) / m.cst[m.c_pscale + p];
+        ok = ok && (fabsf(th[p]) <= 3.0e38f);  // finite (NaN compares false)
+        if (a.lo) ok = ok && (th[p] >= a.lo[td]) && (th[p] <= a.hi[td]);
+      }
+    if (a.z_in) {
+      if (valid && h == 0) {
+#pragma unroll
+        for (int p = 0; p < SF_DMAX; ++p)
+          if (p < m.D) a.out[item[ns] * m.D + (int)m.cst[m.c_tdim + p]] = th[p];
+        if (a.logdet_out) a.logdet_out[item[ns]] = logdet[ns] - m.logdet0;
+      }
+    } else if (a.count) {
+      const bool hit = valid && h == 0 && ok;
+      const unsigned long long bal = __ballot(hit);
+      const long g_first = __shfl(gal[ns], 0, 64);
+      const long g_last = __shfl(gal[ns], 31, 64);
+      if (g_first == g_last) {
+        if (lane == 0 && bal) atomicAdd(&a.count[g_first], (int)__popcll(bal));
+      } else if (hit) {
+        atomicAdd(&a.count[gal[ns]], 1);
+      }
+    } else if (valid && h == 0) {
+      if (a.n_drawn && a.attempt > 0) atomicAdd(&a.n_drawn[gal[ns]], 1);
+      if (ok) {
+#pragma unroll
+        for (int p = 0; p < SF_DMAX; ++p)
+          if (p < m.D) a.out[slot[ns] * m.D + (int)m.cst[m.c_tdim + p]] = th[p];
+      } else {
+        const uint32_t pos = atomicAdd(a.n_rejected, 1u);
+        a.rejected[pos] = (uint32_t)slot[ns];
+      }
+    }
+  }
+}
+

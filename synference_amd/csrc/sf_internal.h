@@ -1,0 +1,32 @@
+// sf_internal.h -- launcher prototypes shared by the kernel translation units and sf_api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sf_layout.h"
+
+struct SfSampleArgsHost {
+  const float* x = nullptr;
+  const float* z_in = nullptr;
+  long S = 1;
+  const uint32_t* slots = nullptr;
+  long slot_base = 0;
+  long n_items = 0;
+  uint32_t attempt = 0, k0 = 0, k1 = 0;
+  const float* lo = nullptr;
+  const float* hi = nullptr;
+  float* out = nullptr;
+  float* logdet_out = nullptr;
+  uint32_t* rejected = nullptr;
+  uint32_t* n_rejected = nullptr;
+  int32_t* n_drawn = nullptr;
+  int32_t* count = nullptr;
+};
+
+hipError_t sf_launch_logprob(const SfDev& m, const float* theta, const float* x, long B, float* out,
+                             hipStream_t st);
+hipError_t sf_launch_inverse(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st);
+hipError_t sf_launch_pack(const float* flat, const int32_t* s1, const int32_t* s2, float* packed, long n,
+                          hipStream_t st);
+hipError_t sf_launch_fill_nan_rows(float* out, const uint32_t* slots, long n, int D, hipStream_t st);
+hipError_t sf_launch_fill_i32(int32_t* p, long n, int32_t v, hipStream_t st);

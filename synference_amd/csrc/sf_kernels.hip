@@ -1,0 +1,106 @@
+// sf_kernels.hip -- utility kernels and the (kind, HT) dispatch onto the per-TU instantiations
+// of sf_inst.hip.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "sf_internal.h"
+
+// ---------------------------------------------------------------------------------------------
+// small utility kernels
+// ---------------------------------------------------------------------------------------------
+__global__ void k_pack(const float* __restrict__ flat, const int32_t* __restrict__ s1,
+                       const int32_t* __restrict__ s2, float* __restrict__ packed, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int a = s1[i], b = s2[i];
+  float v = 0.f;
+  if (a >= 0) v = flat[a];
+  if (b >= 0) v += flat[b];
+  packed[i] = v;
+}
+
+__global__ void k_fill_nan_rows(float* __restrict__ out, const uint32_t* __restrict__ slots, long n, int D) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int d = 0; d < D; ++d) out[(long)slots[i] * D + d] = __builtin_nanf("");
+}
+
+__global__ void k_fill_i32(int32_t* p, long n, int32_t v) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dispatch on (kind, HT); PT and NS are resolved inside the instantiation TUs
+// ---------------------------------------------------------------------------------------------
+#define SF_DECL(K, H)                                                                                   \
+  hipError_t sf_launch_logprob_k##K##_h##H(const SfDev&, int, const float*, const float*, long, float*, \
+                                           hipStream_t);                                                \
+  hipError_t sf_launch_inverse_k##K##_h##H(const SfDev&, int, const SfSampleArgsHost&, hipStream_t);
+SF_DECL(0, 1) SF_DECL(0, 2) SF_DECL(0, 3) SF_DECL(0, 4)
+SF_DECL(1, 1) SF_DECL(1, 2) SF_DECL(1, 3) SF_DECL(1, 4)
+
+// sample tiles per wave: SF_NS=1|2 overrides (diagnostics); default 2 while HT <= 2
+int sf_pick_ns(const SfDev& m) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = std::getenv("SF_NS");
+    forced = e ? std::atoi(e) : 0;
+  }
+  if (m.HT > 2) return 1;
+  if (forced == 1 || forced == 2) return forced;
+  return 2;
+}
+
+#define SF_CASE(K, H, FN, ...) \
+  case K * 10 + H: return FN##_k##K##_h##H(__VA_ARGS__);
+
+hipError_t sf_launch_logprob(const SfDev& m, const float* theta, const float* x, long B, float* out,
+                             hipStream_t st) {
+  if (B <= 0) return hipSuccess;
+  const int ns = sf_pick_ns(m);
+  switch (m.kind * 10 + m.HT) {
+    SF_CASE(0, 1, sf_launch_logprob, m, ns, theta, x, B, out, st)
+    SF_CASE(0, 2, sf_launch_logprob, m, ns, theta, x, B, out, st)
+    SF_CASE(0, 3, sf_launch_logprob, m, ns, theta, x, B, out, st)
+    SF_CASE(0, 4, sf_launch_logprob, m, ns, theta, x, B, out, st)
+    SF_CASE(1, 1, sf_launch_logprob, m, ns, theta, x, B, out, st)
+    SF_CASE(1, 2, sf_launch_logprob, m, ns, theta, x, B, out, st)
+    SF_CASE(1, 3, sf_launch_logprob, m, ns, theta, x, B, out, st)
+    SF_CASE(1, 4, sf_launch_logprob, m, ns, theta, x, B, out, st)
+  }
+  return hipErrorInvalidValue;
+}
+
+hipError_t sf_launch_inverse(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
+  if (a.n_items <= 0) return hipSuccess;
+  const int ns = sf_pick_ns(m);
+  switch (m.kind * 10 + m.HT) {
+    SF_CASE(0, 1, sf_launch_inverse, m, ns, a, st)
+    SF_CASE(0, 2, sf_launch_inverse, m, ns, a, st)
+    SF_CASE(0, 3, sf_launch_inverse, m, ns, a, st)
+    SF_CASE(0, 4, sf_launch_inverse, m, ns, a, st)
+    SF_CASE(1, 1, sf_launch_inverse, m, ns, a, st)
+    SF_CASE(1, 2, sf_launch_inverse, m, ns, a, st)
+    SF_CASE(1, 3, sf_launch_inverse, m, ns, a, st)
+    SF_CASE(1, 4, sf_launch_inverse, m, ns, a, st)
+  }
+  return hipErrorInvalidValue;
+}
+
+hipError_t sf_launch_pack(const float* flat, const int32_t* s1, const int32_t* s2, float* packed, long n,
+                          hipStream_t st) {
+  hipLaunchKernelGGL(k_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, flat, s1, s2, packed, n);
+  return hipGetLastError();
+}
+hipError_t sf_launch_fill_nan_rows(float* out, const uint32_t* slots, long n, int D, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_fill_nan_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, slots, n, D);
+  return hipGetLastError();
+}
+hipError_t sf_launch_fill_i32(int32_t* p, long n, int32_t v, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);
+  return hipGetLastError();
+}

@@ -1,0 +1,296 @@
+// sf_layout.cpp -- host-side construction of the MFMA operand image tables.
+// Pure host code (no HIP calls): exercised by the CPU test-suite through
+// sf_flow_pack_table().  Logical layout: include/synference_hip.h.
+#include "sf_layout.h"
+
+#include <cmath>
+#include <cstring>
+#include <functional>
+
+namespace {
+
+struct Emitter {
+  std::vector<int32_t>& s1;
+  std::vector<int32_t>& s2;
+  int64_t cur = 0;  // write cursor (floats)
+
+  int64_t pad_to(int64_t align) {
+    while (cur % align) push(-1, -1);
+    return cur;
+  }
+  void push(int32_t a, int32_t b) {
+    s1.push_back(a);
+    s2.push_back(b);
+    ++cur;
+  }
+  // Weight block: OT output tiles x nG input groups x 64 lanes x 4.
+  // logical index of element (o,i) = base + o*so + i*si ; mask(o,i) false -> structural zero.
+  int64_t linear(int OT, int nG, const std::vector<int>& orow, const std::vector<int>& irow,
+                 int64_t base, int64_t so, int64_t si,
+                 const std::function<bool(int, int)>& mask) {
+    int64_t start = cur;
+    for (int mt = 0; mt < OT; ++mt)
+      for (int kg = 0; kg < nG; ++kg)
+        for (int l = 0; l < 64; ++l)
+          for (int j = 0; j < 4; ++j) {
+            int o = orow[mt * 32 + (l & 31)];
+            int i = irow[kg * 8 + 4 * (l >> 5) + j];
+            if (o >= 0 && i >= 0 && (!mask || mask(o, i)))
+              push((int32_t)(base + o * so + i * si), -1);
+            else
+              push(-1, -1);
+          }
+    return start;
+  }
+  // Bias block [OT][2][16]; up to two logical sources summed (b0 + bc).
+  int64_t bias(int OT, const std::vector<int>& orow, int64_t base1, int64_t base2) {
+    int64_t start = cur;
+    for (int mt = 0; mt < OT; ++mt)
+      for (int h = 0; h < 2; ++h)
+        for (int r = 0; r < 16; ++r) {
+          int o = orow[mt * 32 + sf_tile_row(r, h)];
+          if (o >= 0)
+            push((int32_t)(base1 + o), base2 >= 0 ? (int32_t)(base2 + o) : -1);
+          else
+            push(-1, -1);
+        }
+    return start;
+  }
+};
+
+std::vector<int> iota_rows(int n_valid, int n_total) {
+  std::vector<int> v(n_total, -1);
+  for (int i = 0; i < n_valid && i < n_total; ++i) v[i] = i;
+  return v;
+}
+
+int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace
+
+bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
+  auto fail = [&](const std::string& m) {
+    L.error = m;
+    return false;
+  };
+  if (d.kind != SF_MAF && d.kind != SF_NSF) return fail("kind must be SF_MAF or SF_NSF");
+  if (d.D < 1 || d.D > SF_DMAX) return fail("D must be in 1..16");
+  if (d.C < 1 || d.C > 512) return fail("C must be in 1..512");
+  if (d.H < 1 || d.H > 128) return fail("H must be in 1..128");
+  if (d.T < 1 || d.T > 64) return fail("T must be in 1..64");
+  if (d.NB < 1 || d.NB > SF_NBMAX) return fail("NB must be in 1..4");
+  if (d.kind == SF_NSF && (d.K < 2 || d.K > 16)) return fail("K must be in 2..16");
+  if (!d.theta_mean || !d.theta_std || !d.x_mean || !d.x_std)
+    return fail("z-score buffers must be given");
+
+  const int D = d.D, C = d.C, H = d.H, T = d.T, NB = d.NB, K = d.K;
+  SfDev& v = L.dev;
+  std::memset(&v, 0, sizeof(v));
+  v.kind = d.kind; v.D = D; v.C = C; v.H = H; v.T = T; v.K = K; v.NB = NB;
+  v.scale_fn = d.scale_fn;
+  v.HT = ceil_div(H, 32);
+  v.nGu = ceil_div(D, 8);
+  v.nGc = ceil_div(C, 8);
+  v.nGh = ceil_div(H, 8);
+  v.tail_bound = d.tail_bound; v.min_w = d.min_bin_width; v.min_h = d.min_bin_height;
+  v.min_d = d.min_derivative; v.eps = d.maf_eps; v.lu_eps = d.lu_eps;
+  v.inv_sqrt_h = (float)(1.0 / std::sqrt((double)H));
+  v.deriv_const = (float)std::log(std::exp(1.0 - (double)d.min_derivative) - 1.0);
+
+  const int HT = v.HT;
+  const std::vector<int> hrow_out = iota_rows(H, HT * 32);     // hidden phys row -> logical unit
+  const std::vector<int> hrow_in = iota_rows(H, v.nGh * 8);
+  const std::vector<int> crow_in = iota_rows(C, v.nGc * 8);
+
+  // ---- MAF physical slot maps: sigma_T = identity, sigma_t = sigma_{t+1} o perm_t^{-1} ----
+  std::vector<std::vector<int>> sigma(T + 1, std::vector<int>(D));
+  for (int i = 0; i < D; ++i) sigma[T][i] = i;
+  if (d.kind == SF_MAF) {
+    for (int t = T - 1; t >= 0; --t) {
+      std::vector<int> perm(D);
+      for (int j = 0; j < D; ++j) perm[j] = d.perms ? d.perms[t * D + j] : j;
+      std::vector<char> seen(D, 0);
+      for (int j = 0; j < D; ++j) {
+        if (perm[j] < 0 || perm[j] >= D || seen[perm[j]]) return fail("perms is not a permutation");
+        seen[perm[j]] = 1;
+      }
+      // logical j of transform t+1 input  <-  logical perm[j] of transform t output
+      for (int j = 0; j < D; ++j) sigma[t][perm[j]] = sigma[t + 1][j];
+    }
+  } else {
+    for (int t = 0; t < T; ++t)
+      for (int i = 0; i < D; ++i) sigma[t][i] = i;
+  }
+
+  // ---- constants image ---------------------------------------------------------------------
+  {
+    std::vector<int> tdim(D);  // phys slot p holds logical theta dim tdim[p]
+    for (int i = 0; i < D; ++i) tdim[sigma[0][i]] = i;
+    v.c_pscale = 0; v.c_pshift = SF_DMAX; v.c_tdim = 2 * SF_DMAX;
+    v.c_xmean = 3 * SF_DMAX; v.c_xstd = 3 * SF_DMAX + ((C + 3) / 4) * 4;
+    L.cst.assign(v.c_xstd + ((C + 3) / 4) * 4, 0.f);
+    double ld0 = 0;
+    for (int p = 0; p < D; ++p) {
+      float sd = d.theta_std[tdim[p]], mu = d.theta_mean[tdim[p]];
+      float sc = 1.0f / sd;
+      L.cst[v.c_pscale + p] = sc;
+      L.cst[v.c_pshift + p] = -mu / sd;
+      L.cst[v.c_tdim + p] = (float)tdim[p];
+      ld0 += std::log(std::fabs((double)sc));
+    }
+    v.logdet0 = (float)ld0;
+    for (int i = 0; i < C; ++i) {
+      L.cst[v.c_xmean + i] = d.x_mean[i];
+      L.cst[v.c_xstd + i] = d.x_std[i];
+    }
+    for (int i = C; i < ((C + 3) / 4) * 4; ++i) L.cst[v.c_xstd + i] = 1.f;
+  }
+
+  Emitter E{L.src1, L.src2};
+  int64_t P = 0;  // logical cursor
+
+  if (d.kind == SF_MAF) {
+    const int mx = std::max(1, D - 1), mn = std::min(1, D - 1);
+    auto deg_h = [&](int j) { return j % mx + mn; };
+    for (int t = 0; t < T; ++t) {
+      const int64_t tb = E.pad_to(64);
+      if (t == 1) v.t_stride = (int)tb;
+      // logical offsets
+      const int64_t lW0 = P, lb0 = lW0 + (int64_t)H * D, lWc = lb0 + H, lbc = lWc + (int64_t)H * C;
+      int64_t cur = lbc + H;
+      int64_t lWk[SF_NBMAX], lbk[SF_NBMAX];
+      for (int k = 0; k < NB; ++k) { lWk[k] = cur; lbk[k] = cur + (int64_t)H * H; cur = lbk[k] + H; }
+      const int64_t lWf = cur, lbf = lWf + (int64_t)2 * D * H;
+      P = lbf + 2 * D;
+
+      std::vector<int> sinv(D);  // phys slot -> logical dim of this transform
+      for (int i = 0; i < D; ++i) sinv[sigma[t][i]] = i;
+      std::vector<int> urow(v.nGu * 8, -1);
+      for (int p = 0; p < D; ++p) urow[p] = sinv[p];
+      std::vector<int> frow(32, -1);
+      for (int p = 0; p < D; ++p) {
+        frow[sf_tile_row(2 * (p >> 1), p & 1)] = 2 * sinv[p];
+        frow[sf_tile_row(2 * (p >> 1) + 1, p & 1)] = 2 * sinv[p] + 1;
+      }
+      int o;
+      o = (int)(E.linear(HT, v.nGu, hrow_out, urow, lW0, D, 1,
+                         [&](int j, int i) { return deg_h(j) >= i + 1; }) - tb);
+      if (t == 0) v.o_w0 = o;
+      o = (int)(E.linear(HT, v.nGc, hrow_out, crow_in, lWc, C, 1, nullptr) - tb);
+      if (t == 0) v.o_wc = o;
+      o = (int)(E.bias(HT, hrow_out, lb0, lbc) - tb);
+      if (t == 0) v.o_b0 = o;
+      for (int k = 0; k < NB; ++k) {
+        o = (int)(E.linear(HT, v.nGh, hrow_out, hrow_in, lWk[k], H, 1,
+                           [&](int j, int i) { return deg_h(j) >= deg_h(i); }) - tb);
+        if (t == 0) v.o_wk[k] = o;
+        o = (int)(E.bias(HT, hrow_out, lbk[k], -1) - tb);
+        if (t == 0) v.o_bk[k] = o;
+      }
+      o = (int)(E.linear(1, v.nGh, frow, hrow_in, lWf, H, 1,
+                         [&](int oo, int i) { return (oo / 2 + 1) > deg_h(i); }) - tb);
+      if (t == 0) v.o_wf = o;
+      o = (int)(E.bias(1, frow, lbf, -1) - tb);
+      if (t == 0) v.o_bf = o;
+    }
+  } else {
+    v.PT = K <= 11 ? 2 : 3;  // PT=1 (K<=5) is not instantiated: K<=11 shares the 2-tile layout
+    v.KMAX = (v.PT * 16 + 1) / 3;
+    const int dtr_max = (D + 1) / 2;
+    v.JP = ceil_div(dtr_max, 2);
+    const int NP = 3 * K - 1;
+    for (int t = 0; t < T; ++t) {
+      const int64_t tb = E.pad_to(64);
+      if (t == 1) v.t_stride = (int)tb;
+      std::vector<int> idn, tr;
+      for (int i = 0; i < D; ++i) (((i % 2) == (t % 2)) ? tr : idn).push_back(i);
+      const int d_id = (int)idn.size(), d_tr = (int)tr.size();
+      const int in_dim = d_id + C;
+      const int64_t lWin = P, lbin = lWin + (int64_t)H * in_dim;
+      int64_t cur = lbin + H;
+      int64_t lWg[SF_NBMAX], lbg[SF_NBMAX], lW1[SF_NBMAX], lb1[SF_NBMAX], lW2[SF_NBMAX], lb2[SF_NBMAX];
+      for (int k = 0; k < NB; ++k) {
+        lWg[k] = cur; lbg[k] = lWg[k] + (int64_t)H * C;
+        lW1[k] = lbg[k] + H; lb1[k] = lW1[k] + (int64_t)H * H;
+        lW2[k] = lb1[k] + H; lb2[k] = lW2[k] + (int64_t)H * H;
+        cur = lb2[k] + H;
+      }
+      const int64_t lWout = cur, lbout = lWout + (int64_t)d_tr * NP * H;
+      cur = lbout + (int64_t)d_tr * NP;
+      int64_t lLo = -1, lUp = -1, lDi = -1, lBi = -1;
+      if (D > 1) {
+        const int nl = D * (D - 1) / 2;
+        lLo = cur; lUp = lLo + nl; lDi = lUp + nl; lBi = lDi + D;
+        cur = lBi + D;
+      }
+      P = cur;
+
+      std::vector<int> urow(v.nGu * 8, -1);  // u tile row = phys slot = logical dim
+      for (int j = 0; j < d_id; ++j) urow[idn[j]] = j;
+      std::vector<int> crow(v.nGc * 8, -1);
+      for (int i = 0; i < C; ++i) crow[i] = d_id + i;
+      // spline head rows: [jp][pt][32]
+      std::vector<int> orow(v.JP * v.PT * 32, -1);
+      for (int jp = 0; jp < v.JP; ++jp)
+        for (int pt = 0; pt < v.PT; ++pt)
+          for (int rho = 0; rho < 32; ++rho) {
+            int h = (rho >> 2) & 1, r = (rho & 3) + 4 * (rho >> 3);
+            int s = pt * 16 + r, kdim = 2 * jp + h, row = -1;
+            if (kdim < d_tr) {
+              if (s < v.KMAX) { if (s < K) row = kdim * NP + s; }
+              else if (s < 2 * v.KMAX) { if (s - v.KMAX < K) row = kdim * NP + K + (s - v.KMAX); }
+              else if (s < 3 * v.KMAX - 1) { if (s - 2 * v.KMAX < K - 1) row = kdim * NP + 2 * K + (s - 2 * v.KMAX); }
+            }
+            orow[(jp * v.PT + pt) * 32 + rho] = row;
+          }
+      int o;
+      o = (int)(E.linear(HT, v.nGu, hrow_out, urow, lWin, in_dim, 1, nullptr) - tb);
+      if (t == 0) v.o_winu = o;
+      o = (int)(E.linear(HT, v.nGc, hrow_out, crow, lWin, in_dim, 1, nullptr) - tb);
+      if (t == 0) v.o_winc = o;
+      o = (int)(E.bias(HT, hrow_out, lbin, -1) - tb);
+      if (t == 0) v.o_bin = o;
+      for (int k = 0; k < NB; ++k) {
+        o = (int)(E.linear(HT, v.nGc, hrow_out, crow_in, lWg[k], C, 1, nullptr) - tb);
+        if (t == 0) v.o_wg[k] = o;
+        o = (int)(E.bias(HT, hrow_out, lbg[k], -1) - tb);
+        if (t == 0) v.o_bg[k] = o;
+        o = (int)(E.linear(HT, v.nGh, hrow_out, hrow_in, lW1[k], H, 1, nullptr) - tb);
+        if (t == 0) v.o_w1[k] = o;
+        o = (int)(E.bias(HT, hrow_out, lb1[k], -1) - tb);
+        if (t == 0) v.o_b1[k] = o;
+        o = (int)(E.linear(HT, v.nGh, hrow_out, hrow_in, lW2[k], H, 1, nullptr) - tb);
+        if (t == 0) v.o_w2[k] = o;
+        o = (int)(E.bias(HT, hrow_out, lb2[k], -1) - tb);
+        if (t == 0) v.o_b2[k] = o;
+      }
+      o = (int)(E.linear(v.JP * v.PT, v.nGh, orow, hrow_in, lWout, H, 1, nullptr) - tb);
+      if (t == 0) v.o_wout = o;
+      o = (int)(E.bias(v.JP * v.PT, orow, lbout, -1) - tb);
+      if (t == 0) v.o_bout = o;
+      // LU block: L[D*D] (strict lower), U[D*D] (strict upper), udiag[D], bias[D]
+      {
+        int64_t s = E.pad_to(4);
+        if (t == 0) v.o_lu = (int)(s - tb);
+        std::vector<int32_t> Lm(D * D, -1), Um(D * D, -1);
+        if (D > 1) {
+          int n = 0;
+          for (int i = 0; i < D; ++i)
+            for (int j = 0; j < i; ++j) Lm[i * D + j] = (int32_t)(lLo + n++);
+          n = 0;
+          for (int i = 0; i < D; ++i)
+            for (int j = i + 1; j < D; ++j) Um[i * D + j] = (int32_t)(lUp + n++);
+        }
+        for (int i = 0; i < D * D; ++i) E.push(Lm[i], -1);
+        for (int i = 0; i < D * D; ++i) E.push(Um[i], -1);
+        for (int i = 0; i < D; ++i) E.push(D > 1 ? (int32_t)(lDi + i) : -1, -1);
+        for (int i = 0; i < D; ++i) E.push(D > 1 ? (int32_t)(lBi + i) : -1, -1);
+      }
+    }
+  }
+  E.pad_to(64);
+  if (T == 1) v.t_stride = (int)E.cur;
+  L.n_packed = E.cur;
+  L.n_params = P;
+  return true;
+}

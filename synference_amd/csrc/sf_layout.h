@@ -1,0 +1,65 @@
+// sf_layout.h -- MFMA operand image of a flow ("packed" layout) and the kernel descriptor.
+//
+// Tile convention (v_mfma_f32_32x32x2_f32, one wave = 64 lanes):
+//   lane l:  c = l & 31  (sample column of a 32-sample tile),  h = l >> 5 (row half)
+//   an activation tile is 16 VGPRs a[0..15]; a[r] on lane (c,h) holds feature
+//       row(r,h) = (r & 3) + 8*(r >> 2) + 4*h          of sample c
+//   which is exactly the C/D register map of the 32x32 MFMA, so the accumulator of one
+//   layer is consumed register-by-register as the B operand (K pair = {row(r,0), row(r,1)})
+//   of the next layer: activations never leave registers and never change lanes.
+//   A "group" g = registers 4g..4g+3 = rows 8g..8g+7; weights are stored one float4 per
+//   lane per (output tile, input group):
+//       W4[(mt*nG + kg)*64 + l] = { W[o][i_j] : j=0..3 },  o = orow[mt*32 + (l&31)],
+//                                  i_j = irow[kg*8 + 4*(l>>5) + j]
+//   so one coalesced 1 KiB load feeds four MFMAs (x NS sample tiles).
+//   Bias image: [mt][h][16] = b[orow[mt*32 + row(r,h)]]  (accumulator initial value).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/synference_hip.h"
+
+#define SF_DMAX 16
+#define SF_NBMAX 4
+
+struct SfDev {
+  const float* packed;   // forward operand image, all transforms
+  const float* packedT;  // transposed operand image (backward data-gradient), training only
+  const float* cst;      // constants image (see c_* offsets)
+  int kind, D, C, H, T, K, NB, scale_fn;
+  int HT;    // hidden tiles = ceil(H/32)
+  int PT;    // NSF: tiles of spline parameters per dim pair
+  int KMAX;  // NSF: bins capacity of the PT layout
+  int JP;    // NSF: dim pairs per transform (max over parity)
+  int nGu, nGc, nGh;  // active input groups: u tile, context, hidden
+  int t_stride;       // floats per transform in packed / packedT
+  // offsets in floats relative to the transform base -------------------------------------
+  int o_w0, o_wc, o_b0;                  // MAF initial (u part, context part, b0+bc)
+  int o_wk[SF_NBMAX], o_bk[SF_NBMAX];    // MAF hidden blocks
+  int o_wf, o_bf;                        // MAF final
+  int o_winu, o_winc, o_bin;             // NSF initial
+  int o_wg[SF_NBMAX], o_bg[SF_NBMAX];    // NSF GLU gate
+  int o_w1[SF_NBMAX], o_b1[SF_NBMAX], o_w2[SF_NBMAX], o_b2[SF_NBMAX];
+  int o_wout, o_bout;                    // NSF spline head, [JP][PT] tiles
+  int o_lu;                              // NSF LU block: L[D*D] U[D*D] udiag[D] bias[D]
+  // constants image ------------------------------------------------------------------------
+  int c_pscale, c_pshift, c_tdim, c_xmean, c_xstd;  // tdim stored as float-encoded ints
+  float logdet0;  // sum log|1/theta_std|
+  float tail_bound, min_w, min_h, min_d, eps, lu_eps, inv_sqrt_h, deriv_const;
+};
+
+struct SfLayout {
+  SfDev dev;  // pointers left null
+  int64_t n_params = 0;
+  int64_t n_packed = 0;  // floats in packed (== floats in packedT)
+  std::vector<int32_t> src1, src2;    // forward image gather table
+  std::vector<int32_t> srcT1, srcT2;  // transposed image gather table
+  std::vector<float> cst;             // constants image
+  std::string error;
+};
+
+static inline int sf_tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// Builds tables; returns false and sets L.error on unsupported shapes.
+bool sf_build_layout(const sf_flow_desc& d, SfLayout& L);

@@ -1,0 +1,160 @@
+"""``HipFlow``: one flow handle of the C ABI, fed with torch device tensors.
+
+PyTorch is plumbing here (device memory, streams); every number is produced by the HIP
+library.  There is no eager/CPU fallback: without the library or without a GPU the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .spec import KIND_ID, FlowSpec, num_params
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _f32c(t, device) -> torch.Tensor:
+    t = torch.as_tensor(t)
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class HipFlow:
+    """Owner of an ``sf_flow`` handle."""
+
+    def __init__(self, spec: FlowSpec, device="cuda:0"):
+        self.spec = spec
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self._keep = (spec.theta_mean, spec.theta_std, spec.x_mean, spec.x_std, spec.perms)
+        d = _lib.sf_flow_desc(
+            kind=KIND_ID[spec.kind], D=spec.D, C=spec.C, H=spec.H, T=spec.T, K=spec.K, NB=spec.NB,
+            scale_fn=0 if spec.scale_fn == "softplus" else 1,
+            tail_bound=spec.tail_bound, min_bin_width=spec.min_bin_width, min_bin_height=spec.min_bin_height,
+            min_derivative=spec.min_derivative, maf_eps=spec.maf_eps, lu_eps=spec.lu_eps,
+            theta_mean=spec.theta_mean.ctypes.data_as(_lib.c_f32p),
+            theta_std=spec.theta_std.ctypes.data_as(_lib.c_f32p),
+            x_mean=spec.x_mean.ctypes.data_as(_lib.c_f32p),
+            x_std=spec.x_std.ctypes.data_as(_lib.c_f32p),
+            perms=spec.perms.ctypes.data_as(_lib.c_i32p) if spec.kind == "maf" else None)
+        h = C.c_void_p()
+        _lib.check(self.lib.sf_flow_create(C.byref(d), C.byref(h)))
+        self.handle = h
+        self.n_params = int(self.lib.sf_flow_num_params(h))
+        assert self.n_params == num_params(spec), (self.n_params, num_params(spec))
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h is not None and h.value:
+            self.lib.sf_flow_destroy(h)
+            self.handle = None
+
+    # ---- host-only diagnostics (no GPU) ----------------------------------------------------
+    def packed_size(self) -> int:
+        return int(self.lib.sf_flow_packed_size(self.handle))
+
+    def pack_table(self) -> Tuple[np.ndarray, np.ndarray]:
+        n = self.packed_size()
+        s1 = np.empty(n, np.int32)
+        s2 = np.empty(n, np.int32)
+        _lib.check(self.lib.sf_flow_pack_table(self.handle, s1.ctypes.data_as(_lib.c_i32p),
+                                               s2.ctypes.data_as(_lib.c_i32p), n))
+        return s1, s2
+
+    def describe(self) -> dict:
+        buf = C.create_string_buffer(1 << 16)
+        _lib.check(self.lib.sf_flow_describe(self.handle, buf, len(buf)))
+        return json.loads(buf.value.decode())
+
+    # ---- device calls -----------------------------------------------------------------------
+    def _dev(self):
+        if not torch.cuda.is_available():
+            raise RuntimeError("synference_amd: no GPU visible; the HIP flow engine has no CPU fallback")
+        torch.cuda.set_device(self.device)
+
+    def set_params(self, flat: torch.Tensor) -> None:
+        self._dev()
+        flat = _f32c(flat, self.device)
+        _lib.check(self.lib.sf_flow_set_params(self.handle, _ptr(flat), flat.numel(), 1, _stream(self.device)))
+
+    def log_prob(self, theta, x) -> torch.Tensor:
+        self._dev()
+        theta, x = _f32c(theta, self.device), _f32c(x, self.device)
+        B = theta.shape[0]
+        if theta.shape != (B, self.spec.D) or x.shape != (B, self.spec.C):
+            raise ValueError(f"theta {tuple(theta.shape)} / x {tuple(x.shape)} do not match "
+                             f"(B,{self.spec.D}) / (B,{self.spec.C})")
+        out = torch.empty(B, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.sf_flow_log_prob(self.handle, _ptr(theta), _ptr(x), B, _ptr(out), _stream(self.device)))
+        return out
+
+    def inverse(self, z, x) -> Tuple[torch.Tensor, torch.Tensor]:
+        self._dev()
+        z, x = _f32c(z, self.device), _f32c(x, self.device)
+        B = z.shape[0]
+        if z.shape != (B, self.spec.D) or x.shape != (B, self.spec.C):
+            raise ValueError("shape mismatch")
+        th = torch.empty_like(z)
+        ld = torch.empty(B, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.sf_flow_inverse_from_noise(self.handle, _ptr(z), _ptr(x), B, _ptr(th), _ptr(ld),
+                                                       _stream(self.device)))
+        return th, ld
+
+    def sample(self, x, S: int, lo=None, hi=None, seed: int = 0, max_attempts: int = 64,
+               out: Optional[torch.Tensor] = None, return_counts: bool = False):
+        """samples[M,S,D] (NaN rows where ``max_attempts`` rounds did not fill a slot)."""
+        self._dev()
+        x = _f32c(x, self.device)
+        M = x.shape[0]
+        if x.dim() != 2 or x.shape[1] != self.spec.C:
+            raise ValueError(f"x must be (M,{self.spec.C})")
+        lo_t = None if lo is None else _f32c(lo, self.device)
+        hi_t = None if hi is None else _f32c(hi, self.device)
+        if out is None:
+            out = torch.empty((M, S, self.spec.D), dtype=torch.float32, device=self.device)
+        nd = torch.empty(M, dtype=torch.int32, device=self.device) if return_counts else None
+        unfilled = C.c_int64(0)
+        _lib.check(self.lib.sf_flow_sample(self.handle, _ptr(x), M, S, _ptr(lo_t), _ptr(hi_t),
+                                           C.c_uint64(seed & (2 ** 64 - 1)), max_attempts, _ptr(out), _ptr(nd),
+                                           C.byref(unfilled), _stream(self.device)))
+        self.last_unfilled = int(unfilled.value)
+        return (out, nd) if return_counts else out
+
+    def sample_round(self, x, S, slots, slot_base, n_slots, attempt, seed, lo, hi, out, rejected, n_rejected,
+                     n_drawn=None, stream_id: int = 0):
+        self._dev()
+        _lib.check(self.lib.sf_flow_sample_round(
+            self.handle, _ptr(x), S, _ptr(slots), slot_base, n_slots, attempt, C.c_uint64(seed & (2 ** 64 - 1)),
+            stream_id, _ptr(lo), _ptr(hi), _ptr(out), _ptr(rejected), _ptr(n_rejected), _ptr(n_drawn),
+            _stream(self.device)))
+
+    def acceptance(self, x, n: int, lo, hi, seed: int = 0) -> torch.Tensor:
+        self._dev()
+        x = _f32c(x, self.device)
+        lo_t, hi_t = _f32c(lo, self.device), _f32c(hi, self.device)
+        cnt = torch.empty(x.shape[0], dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.sf_flow_acceptance(self.handle, _ptr(x), x.shape[0], n, _ptr(lo_t), _ptr(hi_t),
+                                               C.c_uint64(seed & (2 ** 64 - 1)), _ptr(cnt), _stream(self.device)))
+        return cnt.to(torch.float32) / float(n)
+
+    def loss_grad(self, flat: torch.Tensor, theta, x, grad_scale: float,
+                  grad_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        self._dev()
+        flat = _f32c(flat, self.device)
+        theta, x = _f32c(theta, self.device), _f32c(x, self.device)
+        B = theta.shape[0]
+        loss = torch.empty(B, dtype=torch.float32, device=self.device)
+        grad = grad_out if grad_out is not None else torch.empty_like(flat)
+        _lib.check(self.lib.sf_flow_loss_grad(self.handle, _ptr(flat), _ptr(theta), _ptr(x), B,
+                                              C.c_float(grad_scale), _ptr(loss), _ptr(grad), _stream(self.device)))
+        return loss, grad

@@ -1,0 +1,49 @@
+"""Shared seeded test cases: (oracle spec, product spec, flat params, theta, x)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from oracle import flows as OF
+from synference_amd.spec import FlowSpec
+
+# name -> (kind, D, C, H, T, K)
+CASES = {
+    "maf_cfg1": ("maf", 5, 10, 50, 5, 10),     # BASELINE cfg1/cfg2
+    "nsf_cfg3": ("nsf", 8, 20, 50, 5, 8),      # BASELINE cfg3
+    "maf_small": ("maf", 2, 3, 16, 2, 10),
+    "maf_wide": ("maf", 12, 40, 69, 3, 10),    # HT=3 path
+    "nsf_odd": ("nsf", 5, 10, 30, 3, 10),      # odd D: d_tr differs by parity; HT=1
+    "nsf_k16": ("nsf", 3, 7, 64, 2, 16),       # PT=3 path
+}
+
+
+def make_case(name: str, seed: int = 0, B: int = 200, spread: float = 0.5):
+    kind, D, C, H, T, K = CASES[name]
+    rng = np.random.default_rng(seed)
+    perms = OF.random_perms(D, T, seed) if kind == "maf" else None
+    st = dict(theta_mean=rng.normal(size=D).astype(np.float32),
+              theta_std=rng.uniform(0.5, 2.0, size=D).astype(np.float32),
+              x_mean=rng.normal(size=C).astype(np.float32),
+              x_std=rng.uniform(0.5, 2.0, size=C).astype(np.float32))
+    ospec = OF.FlowSpec(kind=kind, D=D, C=C, H=H, T=T, K=K, perms=perms,
+                        **{k: v.astype(np.float64) for k, v in st.items()})
+    spec = FlowSpec(kind=kind, D=D, C=C, H=H, T=T, K=K, perms=perms, **st)
+    flat = OF.init_params(ospec, seed + 1)
+    flat = (flat + spread * rng.normal(size=flat.shape) * np.abs(flat).mean()).astype(np.float32)
+    theta = (rng.normal(size=(B, D)) * st["theta_std"] * 1.3 + st["theta_mean"]).astype(np.float32)
+    x = (rng.normal(size=(B, C)) * st["x_std"] + st["x_mean"]).astype(np.float32)
+    return ospec, spec, flat, theta, x
+
+
+def oracle_log_prob(ospec, flat, theta, x, dtype=torch.float64):
+    with torch.no_grad():
+        return OF.log_prob(ospec, torch.as_tensor(flat).to(dtype), torch.as_tensor(theta).to(dtype),
+                           torch.as_tensor(x).to(dtype)).double().numpy()
+
+
+def oracle_inverse(ospec, flat, z, x, dtype=torch.float64):
+    with torch.no_grad():
+        th, ld = OF.inverse_transform(ospec, torch.as_tensor(flat).to(dtype), torch.as_tensor(z).to(dtype),
+                                      torch.as_tensor(x).to(dtype))
+    return th.double().numpy(), ld.double().numpy()

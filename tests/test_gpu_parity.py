@@ -1,0 +1,107 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle on identical seeded inputs.
+
+Tolerances (north_star): |delta log_prob| < 1e-4 against the fp32 AND the fp64 oracle.
+Samples: exact-from-given-noise within 2e-4 relative to the parameter scale; Philox sampler draw
+for draw except for a tiny fraction of accept/reject flips at the box boundary.
+"""
+import numpy as np
+import pytest
+import torch
+
+from cases import CASES, make_case, oracle_inverse, oracle_log_prob
+from oracle import posterior as OP
+
+pytestmark = pytest.mark.gpu
+
+LOGP_TOL = 1e-4
+
+
+def _flow(spec, flat):
+    from synference_amd.engine import HipFlow
+    f = HipFlow(spec, "cuda:0")
+    f.set_params(torch.as_tensor(flat))
+    return f
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_log_prob_matches_oracle(name):
+    ospec, spec, flat, theta, x = make_case(name, B=333)  # ragged: not a multiple of the tile
+    f = _flow(spec, flat)
+    got = f.log_prob(theta, x).cpu().double().numpy()
+    ref64 = oracle_log_prob(ospec, flat, theta, x, torch.float64)
+    ref32 = oracle_log_prob(ospec, flat, theta, x, torch.float32)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref64).max() < LOGP_TOL, np.abs(got - ref64).max()
+    assert np.abs(got - ref32).max() < LOGP_TOL, np.abs(got - ref32).max()
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_inverse_from_noise_matches_oracle(name):
+    ospec, spec, flat, theta, x = make_case(name, B=130)
+    rng = np.random.default_rng(5)
+    z = rng.normal(size=theta.shape).astype(np.float32)
+    f = _flow(spec, flat)
+    th, ld = f.inverse(z, x)
+    th, ld = th.cpu().double().numpy(), ld.cpu().double().numpy()
+    rth, rld = oracle_inverse(ospec, flat, z, x, torch.float64)
+    scale = np.asarray(ospec.theta_std)
+    assert np.abs((th - rth) / scale).max() < 2e-4, np.abs((th - rth) / scale).max()
+    assert np.abs(ld - rld).max() < 2e-4, np.abs(ld - rld).max()
+    # round trip through the HIP density direction: log p(theta) = log N(z) - logdet_inverse
+    lp = f.log_prob(torch.as_tensor(th, dtype=torch.float32), x).cpu().double().numpy()
+    ref = -0.5 * (z.astype(np.float64) ** 2).sum(1) - 0.5 * spec.D * np.log(2 * np.pi) - ld
+    assert np.abs(lp - ref).max() < 5e-4, np.abs(lp - ref).max()
+
+
+def test_tiny_and_empty_batches():
+    ospec, spec, flat, theta, x = make_case("maf_cfg1", B=3)
+    f = _flow(spec, flat)
+    got = f.log_prob(theta, x).cpu().double().numpy()
+    assert np.abs(got - oracle_log_prob(ospec, flat, theta, x)).max() < LOGP_TOL
+    got1 = f.log_prob(theta[:1], x[:1]).cpu().double().numpy()
+    assert abs(got1[0] - got[0]) < 1e-6
+    assert f.log_prob(theta[:0], x[:0]).numel() == 0
+
+
+@pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "nsf_odd"])
+def test_sampler_matches_oracle_draw_for_draw(name):
+    ospec, spec, flat, theta, x = make_case(name, B=6, spread=0.2)
+    S, seed = 257, 2025
+    lo = (np.asarray(ospec.theta_mean) - 1.5 * np.asarray(ospec.theta_std)).astype(np.float32)
+    hi = (np.asarray(ospec.theta_mean) + 1.5 * np.asarray(ospec.theta_std)).astype(np.float32)
+    f = _flow(spec, flat)
+    got, nd = f.sample(x, S, lo, hi, seed=seed, return_counts=True)
+    got, nd = got.cpu().double().numpy(), nd.cpu().numpy()
+    assert f.last_unfilled == 0
+    assert np.isfinite(got).all()
+    assert ((got >= lo) & (got <= hi)).all()
+    ref, rnd = OP.sample(ospec, torch.as_tensor(flat), x, S, seed, lo, hi, dtype=torch.float32)
+    scale = np.asarray(ospec.theta_std)
+    err = np.abs((got - ref) / scale).max(-1)
+    bad = (err > 5e-4).mean()
+    assert bad < 5e-3, (bad, err.max())          # boundary accept/reject flips only
+    assert np.abs(nd - rnd).sum() <= max(3, 0.01 * rnd.sum())
+    assert (nd >= S).all() and nd.sum() > S * len(x)  # the box really rejected something
+
+
+def test_sampler_unbounded_and_acceptance():
+    ospec, spec, flat, theta, x = make_case("maf_cfg1", B=4, spread=0.2)
+    f = _flow(spec, flat)
+    got = f.sample(x, 64, seed=7).cpu().double().numpy()
+    ref, _ = OP.sample(ospec, torch.as_tensor(flat), x, 64, 7, dtype=torch.float32)
+    assert np.abs((got - ref) / np.asarray(ospec.theta_std)).max() < 5e-4
+    lo = (np.asarray(ospec.theta_mean) - 1.0 * np.asarray(ospec.theta_std)).astype(np.float32)
+    hi = (np.asarray(ospec.theta_mean) + 1.0 * np.asarray(ospec.theta_std)).astype(np.float32)
+    acc = f.acceptance(x, 4000, lo, hi, seed=11).cpu().numpy()
+    racc = OP.acceptance(ospec, torch.as_tensor(flat), x, 4000, 11, lo, hi)
+    assert np.abs(acc - racc).max() < 2e-3, (acc, racc)
+
+
+def test_sampler_exhausted_attempts_give_nan_rows():
+    ospec, spec, flat, theta, x = make_case("maf_small", B=2)
+    f = _flow(spec, flat)
+    lo = np.full(spec.D, 1e6, np.float32)
+    hi = np.full(spec.D, 2e6, np.float32)        # unreachable box
+    got = f.sample(x, 40, lo, hi, seed=1, max_attempts=3)
+    assert f.last_unfilled == 80
+    assert torch.isnan(got).all()

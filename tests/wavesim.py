@@ -1,0 +1,222 @@
+"""numpy model of ONE wave of the HIP kernels (test infrastructure, CPU only).
+
+Replays the data flow of synference_amd/csrc/sf_flows.h -- MFMA 32x32x2 lane maps, the packed
+operand image, bias image, u / context tiles, slot maps -- in float64, so that the host-side
+packer (sf_layout.cpp) and the layout conventions can be checked against the oracle without a
+GPU.  It mirrors the kernel's indexing, not its arithmetic shortcuts.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+LANES = np.arange(64)
+C_ = LANES & 31
+H_ = LANES >> 5
+
+
+def row(r, h):
+    return (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+def mfma(a_lane, b_lane, acc):
+    """v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D col=l&31,row=row(r,l>>5)."""
+    A = a_lane.reshape(2, 32).T
+    Bm = b_lane.reshape(2, 32)
+    Dm = A @ Bm
+    for r in range(16):
+        acc[r] += Dm[row(r, H_), C_]
+
+
+def init_bias(packed, off, OT):
+    acc = np.zeros((OT, 16, 64))
+    for mt in range(OT):
+        for r in range(16):
+            acc[mt, r] = packed[off + (mt * 2 + H_) * 16 + r]
+    return acc
+
+
+def mm_acc(acc, tiles, packed, woff, nGtot, kg0, ng, relu=False):
+    OT = acc.shape[0]
+    for mt in range(OT):
+        for g in range(ng):
+            base = woff + ((mt * nGtot + kg0 + g) * 64 + LANES) * 4
+            for j in range(4):
+                b = tiles[g >> 2][(g & 3) * 4 + j]
+                if relu:
+                    b = np.maximum(b, 0)
+                mfma(packed[base + j], b, acc[mt])
+
+
+def u_tile(u):
+    t = np.zeros((16, 64))
+    for r in range(8):
+        t[r] = np.where(H_ == 1, u[row(r, 1)], u[row(r, 0)])
+    return t
+
+
+def ctx_tiles(x_rows, d, cst):
+    """x_rows [64 lanes, C] raw context of each lane's sample."""
+    Cc = d["C"]
+    out = []
+    for kt in range((d["nGc"] + 3) // 4):
+        t = np.zeros((16, 64))
+        for r in range(16):
+            rho = kt * 32 + row(r, H_)
+            ok = rho < Cc
+            rr = np.where(ok, rho, 0)
+            v = (x_rows[LANES, rr] - cst[d["c_xmean"] + rr]) / cst[d["c_xstd"] + rr]
+            t[r] = np.where(ok, v, 0.0)
+        out.append(t)
+    return out
+
+
+def ctx_mm(acc, ct, packed, woff, d):
+    for kt, t in enumerate(ct):
+        ng = min(4, d["nGc"] - kt * 4)
+        mm_acc(acc, [t], packed, woff, d["nGc"], kt * 4, ng)
+
+
+def xhalf(v):
+    return v[LANES ^ 32]
+
+
+def softplus(x):
+    return np.where(x > 20, x, np.log1p(np.exp(np.minimum(x, 20))))
+
+
+def maf_logprob(d, packed, theta32, x32):
+    """theta32 [32,D], x32 [32,C] -> log_prob [32] for one 32-sample tile."""
+    cst = np.asarray(d["cst"])
+    D, HT = d["D"], d["HT"]
+    th = theta32[C_]
+    xr = x32[C_]
+    u = np.zeros((16, 64))
+    for p in range(D):
+        td = int(cst[d["c_tdim"] + p])
+        u[p] = th[:, td] * cst[d["c_pscale"] + p] + cst[d["c_pshift"] + p]
+    logdet = np.full(64, np.sum(np.log(np.abs(cst[d["c_pscale"]:d["c_pscale"] + D]))))
+    ct = ctx_tiles(xr, d, cst)
+    for t in range(d["T"]):
+        tp = t * d["t_stride"]
+        a = init_bias(packed, tp + d["o_b0"], HT)
+        mm_acc(a, [u_tile(u)], packed, tp + d["o_w0"], d["nGu"], 0, d["nGu"])
+        ctx_mm(a, ct, packed, tp + d["o_wc"], d)
+        for k in range(d["NB"]):
+            b = init_bias(packed, tp + d[f"o_bk{k}"], HT)
+            mm_acc(b, list(a), packed, tp + d[f"o_wk{k}"], d["nGh"], 0, d["nGh"])
+            a = np.tanh(b)
+        fin = init_bias(packed, tp + d["o_bf"], 1)
+        mm_acc(fin, list(a), packed, tp + d["o_wf"], d["nGh"], 0, d["nGh"])
+        ld = np.zeros(64)
+        for p in range(D):
+            s = softplus(fin[0, 2 * (p >> 1)]) + 1e-3
+            val = s * u[p] + fin[0, 2 * (p >> 1) + 1]
+            mine = H_ == (p & 1)
+            u[p] = np.where(mine, val, xhalf(val))
+            ld += np.where(mine, np.log(s), 0.0)
+        logdet += ld + xhalf(ld)
+    lp = -0.5 * (u[:D] ** 2).sum(0) - 0.5 * D * np.log(2 * np.pi) + logdet
+    return lp[:32]
+
+
+def _spline_fwd(d, q, v):
+    """q: [PT*16 slots, 64 lanes] ; v [64] -> (out, lad) mirroring SfSpline::eval (forward)."""
+    K, KM, B = d["K"], d["KMAX"], 3.0
+    H = d["H"]
+
+    def knots(off, min_size):
+        e = q[off:off + K] / np.sqrt(H)
+        e = np.exp(e - e.max(0))
+        w = min_size + (1 - min_size * K) * e / e.sum(0)
+        cs = np.cumsum(w, 0)
+        c = np.concatenate([np.full((1, 64), -B), 2 * B * cs[:-1] - B, np.full((1, 64), B)], 0)
+        return c
+
+    inside = (v >= -B) & (v <= B)
+    vc = np.clip(v, -B, B)
+    cw = knots(0, 1e-3)
+    ch = knots(KM, 1e-3)
+    idx = np.zeros(64, int)
+    for k in range(K):
+        idx = np.where(vc >= cw[k], k, idx)
+    L = LANES
+    x_k, w_k = cw[idx, L], cw[idx + 1, L] - cw[idx, L]
+    y_k, h_k = ch[idx, L], ch[idx + 1, L] - ch[idx, L]
+    const = np.log(np.exp(1 - 1e-3) - 1)
+    der = np.concatenate([np.full((1, 64), const), q[2 * KM:2 * KM + K - 1], np.full((1, 64), const)], 0)
+    der = 1e-3 + softplus(der)
+    d_k, d_k1 = der[idx, L], der[idx + 1, L]
+    s_k = h_k / w_k
+    xi = (vc - x_k) / w_k
+    om = xi * (1 - xi)
+    den = s_k + (d_k + d_k1 - 2 * s_k) * om
+    out = y_k + h_k * (s_k * xi * xi + d_k * om) / den
+    dnum = s_k * s_k * (d_k1 * xi * xi + 2 * s_k * om + d_k * (1 - xi) ** 2)
+    lad = np.log(dnum) - 2 * np.log(den)
+    return np.where(inside, out, v), np.where(inside, lad, 0.0)
+
+
+def nsf_logprob(d, packed, theta32, x32):
+    cst = np.asarray(d["cst"])
+    D, HT, PT = d["D"], d["HT"], d["PT"]
+    th = theta32[C_]
+    xr = x32[C_]
+    u = np.zeros((16, 64))
+    for p in range(D):
+        u[p] = th[:, p] * cst[d["c_pscale"] + p] + cst[d["c_pshift"] + p]
+    logdet = np.full(64, np.sum(np.log(np.abs(cst[d["c_pscale"]:d["c_pscale"] + D]))))
+    ct = ctx_tiles(xr, d, cst)
+    sig = lambda z: 1 / (1 + np.exp(-z))
+    for t in range(d["T"]):
+        tp = t * d["t_stride"]
+        hid = init_bias(packed, tp + d["o_bin"], HT)
+        mm_acc(hid, [u_tile(u)], packed, tp + d["o_winu"], d["nGu"], 0, d["nGu"])
+        ctx_mm(hid, ct, packed, tp + d["o_winc"], d)
+        for k in range(d["NB"]):
+            t1 = init_bias(packed, tp + d[f"o_b1{k}"], HT)
+            mm_acc(t1, list(hid), packed, tp + d[f"o_w1{k}"], d["nGh"], 0, d["nGh"], relu=True)
+            t2 = init_bias(packed, tp + d[f"o_b2{k}"], HT)
+            mm_acc(t2, list(t1), packed, tp + d[f"o_w2{k}"], d["nGh"], 0, d["nGh"], relu=True)
+            for mt in range(HT):
+                g = init_bias(packed, tp + d[f"o_bg{k}"] + mt * 32, 1)
+                ctx_mm(g, ct, packed, tp + d[f"o_wg{k}"] + mt * d["nGc"] * 256, d)
+                hid[mt] += t2[mt] * sig(g[0])
+        start = t & 1
+        d_tr = (D - start + 1) // 2
+        for jp in range((d_tr + 1) // 2):
+            q = init_bias(packed, tp + d["o_bout"] + jp * PT * 32, PT)
+            mm_acc(q, list(hid), packed, tp + d["o_wout"] + jp * PT * d["nGh"] * 256, d["nGh"], 0, d["nGh"])
+            qs = q.reshape(PT * 16, 64)
+            kdim = 2 * jp + H_
+            have = kdim < d_tr
+            tgt = start + 2 * kdim
+            tgt_o = start + 2 * (2 * jp + (1 - H_))
+            have_o = (2 * jp + (1 - H_)) < d_tr
+            vin = u[np.minimum(tgt, 15), LANES]
+            vout, lad = _spline_fwd(d, qs, vin)
+            lad = np.where(have, lad, 0.0)
+            vo = xhalf(vout)
+            for p in range(16):
+                u[p] = np.where(have & (p == tgt), vout, u[p])
+                u[p] = np.where(have_o & (p == tgt_o), vo, u[p])
+            logdet += lad + xhalf(lad)
+        if D > 1:
+            lp_ = tp + d["o_lu"]
+            Lm = packed[lp_:lp_ + D * D].reshape(D, D)
+            Um = packed[lp_ + D * D:lp_ + 2 * D * D].reshape(D, D)
+            ud = packed[lp_ + 2 * D * D:lp_ + 2 * D * D + D]
+            bb = packed[lp_ + 2 * D * D + D:lp_ + 2 * D * D + 2 * D]
+            dg = softplus(ud) + 1e-3
+            tt = np.zeros((D, 64))
+            for i in range(D):
+                tt[i] = dg[i] * u[i] + sum(Um[i, j] * u[j] for j in range(i + 1, D))
+            for i in range(D):
+                u[i] = tt[i] + bb[i] + sum(Lm[i, j] * tt[j] for j in range(i))
+            logdet += np.log(dg).sum()
+    lp = -0.5 * (u[:D] ** 2).sum(0) - 0.5 * D * np.log(2 * np.pi) + logdet
+    return lp[:32]
+
+
+def pack(flat, s1, s2):
+    f = np.concatenate([np.asarray(flat, dtype=np.float64), [0.0]])
+    return f[s1] + f[s2]  # index -1 hits the appended zero
