@@ -101,10 +101,10 @@ int sf_flow_create(const sf_flow_desc* desc, sf_flow** out) {
 void sf_flow_destroy(sf_flow* f) {
   if (!f) return;
   if (f->dev_ready) {
-    hipFree(f->d_packed); hipFree(f->d_packedT); hipFree(f->d_cst);
-    hipFree(f->d_s1); hipFree(f->d_s2); hipFree(f->d_t1); hipFree(f->d_t2);
-    hipFree(f->d_flat); hipFree(f->d_gpacked); hipFree(f->d_gdst); hipFree(f->d_gdst2);
-    hipFree(f->d_act); hipFree(f->d_rej[0]); hipFree(f->d_rej[1]); hipFree(f->d_cnt);
+    (void)hipFree(f->d_packed); (void)hipFree(f->d_packedT); (void)hipFree(f->d_cst);
+    (void)hipFree(f->d_s1); (void)hipFree(f->d_s2); (void)hipFree(f->d_t1); (void)hipFree(f->d_t2);
+    (void)hipFree(f->d_flat); (void)hipFree(f->d_gpacked); (void)hipFree(f->d_gdst); (void)hipFree(f->d_gdst2);
+    (void)hipFree(f->d_act); (void)hipFree(f->d_rej[0]); (void)hipFree(f->d_rej[1]); (void)hipFree(f->d_cnt);
   }
   delete f;
 }
@@ -167,7 +167,9 @@ int sf_flow_set_params(sf_flow* f, const float* flat, int64_t n, int is_device, 
 }
 
 int sf_flow_log_prob(sf_flow* f, const float* theta, const float* x, int64_t B, float* out, void* stream) {
-  if (!f || !theta || !x || !out) return fail(SF_ERR_INVALID, "null argument");
+  if (!f) return fail(SF_ERR_INVALID, "null handle");
+  if (B == 0) return SF_OK;
+  if (!theta || !x || !out) return fail(SF_ERR_INVALID, "null argument");
   if (!f->params_set) return fail(SF_ERR_STATE, "sf_flow_set_params has not been called");
   if (B < 0) return fail(SF_ERR_INVALID, "B < 0");
   SF_HIP(sf_launch_logprob(f->dev(), theta, x, (long)B, out, (hipStream_t)stream));
@@ -176,7 +178,9 @@ int sf_flow_log_prob(sf_flow* f, const float* theta, const float* x, int64_t B, 
 
 int sf_flow_inverse_from_noise(sf_flow* f, const float* z, const float* x, int64_t B, float* theta,
                                float* logdet, void* stream) {
-  if (!f || !z || !x || !theta) return fail(SF_ERR_INVALID, "null argument");
+  if (!f) return fail(SF_ERR_INVALID, "null handle");
+  if (B == 0) return SF_OK;
+  if (!z || !x || !theta) return fail(SF_ERR_INVALID, "null argument");
   if (!f->params_set) return fail(SF_ERR_STATE, "sf_flow_set_params has not been called");
   SfSampleArgsHost a;
   a.x = x; a.z_in = z; a.n_items = (long)B; a.out = theta; a.logdet_out = logdet;
@@ -210,7 +214,10 @@ int sf_flow_sample_round(sf_flow* f, const float* x, int64_t S, const uint32_t* 
 int sf_flow_sample(sf_flow* f, const float* x, int64_t M, int64_t S, const float* lo, const float* hi,
                    uint64_t seed, int32_t max_attempts, float* out, int32_t* n_drawn, int64_t* n_unfilled,
                    void* stream) {
-  if (!f || !x || !out) return fail(SF_ERR_INVALID, "null argument");
+  if (!f) return fail(SF_ERR_INVALID, "null handle");
+  if (n_unfilled) *n_unfilled = 0;
+  if (M == 0) return SF_OK;
+  if (!x || !out) return fail(SF_ERR_INVALID, "null argument");
   if (!f->params_set) return fail(SF_ERR_STATE, "sf_flow_set_params has not been called");
   if (M < 0 || S < 1) return fail(SF_ERR_INVALID, "bad M or S");
   if (max_attempts < 1) max_attempts = 1;
@@ -223,7 +230,7 @@ int sf_flow_sample(sf_flow* f, const float* x, int64_t M, int64_t S, const float
   // back to a full-size list only when a round would overflow it.
   size_t need = (size_t)total;
   if (f->rej_cap < need) {
-    hipFree(f->d_rej[0]); hipFree(f->d_rej[1]);
+    (void)hipFree(f->d_rej[0]); (void)hipFree(f->d_rej[1]);
     f->d_rej[0] = f->d_rej[1] = nullptr;
     SF_HIP(hipMalloc(&f->d_rej[0], need * sizeof(uint32_t)));
     SF_HIP(hipMalloc(&f->d_rej[1], need * sizeof(uint32_t)));
@@ -306,7 +313,7 @@ int sf_opt_create(int64_t n, const sf_adam_desc* d, sf_opt** out) {
 }
 void sf_opt_destroy(sf_opt* o) {
   if (!o) return;
-  hipFree(o->m); hipFree(o->v); hipFree(o->norm);
+  (void)hipFree(o->m); (void)hipFree(o->v); (void)hipFree(o->norm);
   delete o;
 }
 int sf_adam_step(sf_opt* o, float* params, const float* grad, float max_norm, float* grad_norm_out, void* stream) {
