@@ -27,33 +27,6 @@ int hip_fail(hipError_t e, const char* what) {
   } while (0)
 }  // namespace
 
-struct sf_flow {
-  SfLayout L;
-  bool dev_ready = false;
-  bool params_set = false;
-  float* d_packed = nullptr;
-  float* d_packedT = nullptr;
-  float* d_cst = nullptr;
-  int32_t *d_s1 = nullptr, *d_s2 = nullptr, *d_t1 = nullptr, *d_t2 = nullptr;
-  float* d_flat = nullptr;      // staging for host-sourced parameters
-  float* d_gpacked = nullptr;   // packed-layout gradient accumulator (training)
-  int32_t* d_gdst = nullptr;    // logical -> packed index for the gradient gather
-  int32_t* d_gdst2 = nullptr;
-  float* d_act = nullptr;       // activation stash (training)
-  size_t act_cap = 0;
-  uint32_t* d_rej[2] = {nullptr, nullptr};
-  size_t rej_cap = 0;
-  uint32_t* d_cnt = nullptr;  // [2] counters
-  float* d_box = nullptr;     // unused placeholder for future device-resident priors
-  SfDev dev() const {
-    SfDev v = L.dev;
-    v.packed = d_packed;
-    v.packedT = d_packedT;
-    v.cst = d_cst;
-    return v;
-  }
-};
-
 static int ensure_device(sf_flow* f) {
   if (f->dev_ready) return SF_OK;
   int n = 0;
@@ -103,7 +76,7 @@ void sf_flow_destroy(sf_flow* f) {
   if (f->dev_ready) {
     (void)hipFree(f->d_packed); (void)hipFree(f->d_packedT); (void)hipFree(f->d_cst);
     (void)hipFree(f->d_s1); (void)hipFree(f->d_s2); (void)hipFree(f->d_t1); (void)hipFree(f->d_t2);
-    (void)hipFree(f->d_flat); (void)hipFree(f->d_gpacked); (void)hipFree(f->d_gdst); (void)hipFree(f->d_gdst2);
+    (void)hipFree(f->d_flat); (void)hipFree(f->d_gpacked); (void)hipFree(f->d_gdst);
     (void)hipFree(f->d_act); (void)hipFree(f->d_rej[0]); (void)hipFree(f->d_rej[1]); (void)hipFree(f->d_cnt);
   }
   delete f;
@@ -275,15 +248,15 @@ int sf_flow_acceptance(sf_flow* f, const float* x, int64_t M, int64_t n, const f
 // ---- training ------------------------------------------------------------------------------
 int sf_flow_loss_grad(sf_flow* f, const float* flat, const float* theta, const float* x, int64_t B,
                       float grad_scale, float* loss, float* grad, void* stream) {
-  if (!f || !flat || !theta || !x || !grad) return fail(SF_ERR_INVALID, "null argument");
+  if (!f || !flat || !grad) return fail(SF_ERR_INVALID, "null argument");
+  if (B > 0 && (!theta || !x)) return fail(SF_ERR_INVALID, "null argument");
+  if (B < 0) return fail(SF_ERR_INVALID, "B < 0");
   int rc = ensure_device(f);
   if (rc) return rc;
   std::string err;
-  rc = sf_train_loss_grad(f->L, f->dev(), &f->d_packedT, &f->d_t1, &f->d_t2, &f->d_gpacked, &f->d_gdst,
-                          &f->d_gdst2, &f->d_act, &f->act_cap, f->d_s1, f->d_s2, f->d_packed, flat, theta, x,
-                          (long)B, grad_scale, loss, grad, (hipStream_t)stream, err);
+  rc = sf_train_loss_grad(f, flat, theta, x, (long)B, grad_scale, loss, grad, (hipStream_t)stream, err);
   if (rc) return fail(rc, err);
-  f->params_set = true;  // forward image now holds `flat`
+  f->params_set = true;  // the forward image now holds `flat`
   return SF_OK;
 }
 

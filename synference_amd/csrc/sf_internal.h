@@ -30,3 +30,29 @@ hipError_t sf_launch_pack(const float* flat, const int32_t* s1, const int32_t* s
                           hipStream_t st);
 hipError_t sf_launch_fill_nan_rows(float* out, const uint32_t* slots, long n, int D, hipStream_t st);
 hipError_t sf_launch_fill_i32(int32_t* p, long n, int32_t v, hipStream_t st);
+
+// ---- the handle (shared by sf_api.hip and sf_train.hip) -------------------------------------
+struct sf_flow {
+  SfLayout L;
+  bool dev_ready = false;
+  bool params_set = false;
+  float* d_packed = nullptr;    // forward operand image
+  float* d_packedT = nullptr;   // transposed operand image (training, lazily built)
+  float* d_cst = nullptr;
+  int32_t *d_s1 = nullptr, *d_s2 = nullptr, *d_t1 = nullptr, *d_t2 = nullptr;
+  float* d_flat = nullptr;      // staging for host-sourced parameters
+  float* d_gpacked = nullptr;   // gradient image (atomic accumulation target)
+  int32_t* d_gdst = nullptr;    // logical parameter -> gradient image index
+  float* d_act = nullptr;       // activation stash (training)
+  size_t act_cap = 0;           // floats
+  uint32_t* d_rej[2] = {nullptr, nullptr};
+  size_t rej_cap = 0;
+  uint32_t* d_cnt = nullptr;
+  SfDev dev() const {
+    SfDev v = L.dev;
+    v.packed = d_packed;
+    v.packedT = d_packedT;
+    v.cst = d_cst;
+    return v;
+  }
+};

@@ -12,15 +12,17 @@ namespace {
 struct Emitter {
   std::vector<int32_t>& s1;
   std::vector<int32_t>& s2;
+  std::vector<int32_t>* gidx = nullptr;  // gradient-image index of each packed float
   int64_t cur = 0;  // write cursor (floats)
 
   int64_t pad_to(int64_t align) {
     while (cur % align) push(-1, -1);
     return cur;
   }
-  void push(int32_t a, int32_t b) {
+  void push(int32_t a, int32_t b, int64_t g = -1) {
     s1.push_back(a);
     s2.push_back(b);
+    if (gidx) gidx->push_back((int32_t)(g >= 0 ? g : cur));
     ++cur;
   }
   // Weight block: OT output tiles x nG input groups x 64 lanes x 4.
@@ -35,10 +37,11 @@ struct Emitter {
           for (int j = 0; j < 4; ++j) {
             int o = orow[mt * 32 + (l & 31)];
             int i = irow[kg * 8 + 4 * (l >> 5) + j];
+            const int64_t g = start + (((int64_t)mt * nG + kg) * 4 + j) * 64 + l;
             if (o >= 0 && i >= 0 && (!mask || mask(o, i)))
-              push((int32_t)(base + o * so + i * si), -1);
+              push((int32_t)(base + o * so + i * si), -1, g);
             else
-              push(-1, -1);
+              push(-1, -1, g);
           }
     return start;
   }
@@ -49,10 +52,11 @@ struct Emitter {
       for (int h = 0; h < 2; ++h)
         for (int r = 0; r < 16; ++r) {
           int o = orow[mt * 32 + sf_tile_row(r, h)];
+          const int64_t g = start + mt * 32 + sf_tile_row(r, h);
           if (o >= 0)
-            push((int32_t)(base1 + o), base2 >= 0 ? (int32_t)(base2 + o) : -1);
+            push((int32_t)(base1 + o), base2 >= 0 ? (int32_t)(base2 + o) : -1, g);
           else
-            push(-1, -1);
+            push(-1, -1, g);
         }
     return start;
   }
@@ -146,7 +150,9 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
     for (int i = C; i < ((C + 3) / 4) * 4; ++i) L.cst[v.c_xstd + i] = 1.f;
   }
 
-  Emitter E{L.src1, L.src2};
+  std::vector<int32_t> gidx;
+  Emitter E{L.src1, L.src2, &gidx};
+  Emitter ET{L.srcT1, L.srcT2, nullptr};  // transposed image
   int64_t P = 0;  // logical cursor
 
   if (d.kind == SF_MAF) {
@@ -192,6 +198,26 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
       if (t == 0) v.o_wf = o;
       o = (int)(E.bias(1, frow, lbf, -1) - tb);
       if (t == 0) v.o_bf = o;
+      // ---- transposed operands for the data-gradient pass: delta_in = W^T delta_out ----
+      {
+        const int64_t tbT = ET.pad_to(64);
+        if (t == 1) v.tT_stride = (int)tbT;
+        v.nGf = ceil_div(2 * ((D + 1) / 2), 4);
+        std::vector<int> urow32(32, -1);
+        for (int p = 0; p < D; ++p) urow32[p] = sinv[p];
+        // "o" = forward INPUT index, "i" = forward OUTPUT index: W[i][o] at base + o + i*in_dim
+        o = (int)(ET.linear(HT, v.nGf, hrow_out, frow, lWf, 1, H,
+                            [&](int unit, int oo) { return (oo / 2 + 1) > deg_h(unit); }) - tbT);
+        if (t == 0) v.oT_wf = o;
+        for (int k = 0; k < NB; ++k) {
+          o = (int)(ET.linear(HT, v.nGh, hrow_out, hrow_in, lWk[k], 1, H,
+                              [&](int uin, int uout) { return deg_h(uout) >= deg_h(uin); }) - tbT);
+          if (t == 0) v.oT_wk[k] = o;
+        }
+        o = (int)(ET.linear(1, v.nGh, urow32, hrow_in, lW0, 1, D,
+                            [&](int dim, int unit) { return deg_h(unit) >= dim + 1; }) - tbT);
+        if (t == 0) v.oT_w0 = o;
+      }
     }
   } else {
     v.PT = K <= 11 ? 2 : 3;  // PT=1 (K<=5) is not instantiated: K<=11 shares the 2-tile layout
@@ -289,8 +315,15 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
     }
   }
   E.pad_to(64);
-  if (T == 1) v.t_stride = (int)E.cur;
+  ET.pad_to(64);
+  if (T == 1) { v.t_stride = (int)E.cur; v.tT_stride = (int)ET.cur; }
   L.n_packed = E.cur;
+  L.n_packedT = ET.cur;
   L.n_params = P;
+  L.gdst.assign((size_t)P, -1);
+  for (int64_t i = 0; i < E.cur; ++i) {
+    if (L.src1[i] >= 0) L.gdst[L.src1[i]] = gidx[i];
+    if (L.src2[i] >= 0) L.gdst[L.src2[i]] = gidx[i];
+  }
   return true;
 }

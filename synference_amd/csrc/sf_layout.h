@@ -43,6 +43,11 @@ struct SfDev {
   int o_w1[SF_NBMAX], o_b1[SF_NBMAX], o_w2[SF_NBMAX], o_b2[SF_NBMAX];
   int o_wout, o_bout;                    // NSF spline head, [JP][PT] tiles
   int o_lu;                              // NSF LU block: L[D*D] U[D*D] udiag[D] bias[D]
+  // transposed image (data-gradient operands W^T), offsets relative to t*tT_stride ---------
+  int tT_stride;
+  int nGf;                               // MAF: active groups of the final-layer output tile
+  int oT_wf, oT_wk[SF_NBMAX], oT_w0;     // MAF
+  int oT_wout, oT_w1[SF_NBMAX], oT_w2[SF_NBMAX], oT_winu;  // NSF (oT_wout: [JP] blocks)
   // constants image ------------------------------------------------------------------------
   int c_pscale, c_pshift, c_tdim, c_xmean, c_xstd;  // tdim stored as float-encoded ints
   float logdet0;  // sum log|1/theta_std|
@@ -55,6 +60,11 @@ struct SfLayout {
   int64_t n_packed = 0;  // floats in packed (== floats in packedT)
   std::vector<int32_t> src1, src2;    // forward image gather table
   std::vector<int32_t> srcT1, srcT2;  // transposed image gather table
+  int64_t n_packedT = 0;
+  // gradient image: same block offsets as the forward image, but inside a weight block the
+  // order is [mt][kg][j][lane] (256 contiguous bytes per atomic wave-instruction) and a bias
+  // block is [mt][32 rows].  gdst[i] = gradient-image index of logical parameter i, or -1.
+  std::vector<int32_t> gdst;
   std::vector<float> cst;             // constants image
   std::string error;
 };

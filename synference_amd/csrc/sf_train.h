@@ -6,12 +6,11 @@
 
 #include "sf_layout.h"
 
-// Forward + backward; lazily builds the transposed operand image / gradient tables on first use.
-int sf_train_loss_grad(const SfLayout& L, SfDev dev, float** d_packedT, int32_t** d_t1, int32_t** d_t2,
-                       float** d_gpacked, int32_t** d_gdst, int32_t** d_gdst2, float** d_act, size_t* act_cap,
-                       const int32_t* d_s1, const int32_t* d_s2, float* d_packed, const float* flat,
-                       const float* theta, const float* x, long B, float grad_scale, float* loss, float* grad,
-                       hipStream_t st, std::string& err);
+struct sf_flow;
+// Forward + backward of -log_prob; lazily builds the transposed operand image, the gradient image
+// and the activation stash on first use.  Returns 0 or a negative sf_status with `err` set.
+int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const float* x, long B,
+                       float grad_scale, float* loss, float* grad, hipStream_t st, std::string& err);
 
 hipError_t sf_launch_adam(float* params, const float* grad, float* m, float* v, float* norm_scratch, long n,
                           const sf_adam_desc& d, float bc1, float bc2, float max_norm, float* grad_norm_out,
