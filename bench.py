@@ -1,0 +1,259 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the amortised-posterior flow path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): NPE MAF (5 transforms, 50 hidden) on the 10k-galaxy 10-filter
+NIRCam-like mock; one "step" = ``sample_posterior`` over the 2 000-galaxy test catalogue with
+1 000 accepted draws per galaxy (the reference's published benchmark loop, ref:
+src/synference/sbi_runner.py:6438-6442, S=1000 as in examples/paper/model_testing.ipynb:1543-1554),
+prior-box rejection included.  value = accepted posterior samples / s over all ranks (each rank owns
+its own 2 000-galaxy shard: weak scaling, no data-path collective).  The flow-train theta.x pairs/s leg
+(forward+backward+RCCL all-reduce+clip+Adam) is timed right after with the same barrier protocol and
+reported in the "train" object of the same JSON line.
+
+Inputs are synthetic (synference_amd/synthetic.py) and resident in HBM before the
+timed region; weights are random-init + a short seeded warm-up fit so the posterior is non-trivial.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work per unit, SURVEY.md 8(d): mask-aware MACs x2, MAF cfg1
+F_SAMPLE_PER_DRAW = 175_150.0
+F_SAMPLE_PER_GALAXY = 5_000.0
+F_LOGPROB_PER_ROW = 40_030.0
+PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA (= vector) dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--galaxies", type=int, default=2000, help="test-catalogue rows per GPU")
+    ap.add_argument("--draws", type=int, default=1000)
+    ap.add_argument("--train-batch", type=int, default=16384, help="per-GPU training batch of the train leg")
+    ap.add_argument("--train-steps", type=int, default=0, help="0 = same as --steps")
+    ap.add_argument("--fit-steps", type=int, default=300, help="untimed seeded warm-up fit")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def barrier_sync(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(t, world, dev):
+    if world == 1:
+        return t
+    v = torch.tensor([t], dtype=torch.float64, device=dev)
+    dist.all_reduce(v, op=dist.ReduceOp.MAX)
+    return float(v.item())
+
+
+def cpu_baseline(spec, flat, x_rows, lo, hi, S, budget_s):
+    """Reference-style CPU path: the oracle restatement driven one galaxy at a time, S accepted draws
+    each with prior-box rejection (SURVEY.md 8d / BASELINE.md B1), one thread, bounded wall time."""
+    from oracle import flows as OF
+    from oracle import posterior as OP
+    torch.set_num_threads(1)
+    ospec = OF.FlowSpec(kind=spec.kind, D=spec.D, C=spec.C, H=spec.H, T=spec.T, K=spec.K, NB=spec.NB,
+                        perms=spec.perms, theta_mean=spec.theta_mean.astype(np.float64),
+                        theta_std=spec.theta_std.astype(np.float64), x_mean=spec.x_mean.astype(np.float64),
+                        x_std=spec.x_std.astype(np.float64))
+    fl = torch.as_tensor(flat, dtype=torch.float32)
+    times = []
+    t_all = time.perf_counter()
+    g = 0
+    while g < len(x_rows) and (time.perf_counter() - t_all) < budget_s:
+        t0 = time.perf_counter()
+        OP.sample(ospec, fl, x_rows[g:g + 1], S, 2025 + g, lo, hi, dtype=torch.float32)
+        times.append(time.perf_counter() - t0)
+        g += 1
+    med = float(np.median(times))
+    # batched CPU number on all host cores so the GPU ratio is not credited for removing the loop
+    ncores = min(16, os.cpu_count() or 1)  # the box's CPU share for one GPU
+    torch.set_num_threads(ncores)
+    nb = min(len(x_rows), 64)
+    OP.sample(ospec, fl, x_rows[:4], S, 6, lo, hi, dtype=torch.float32)  # thread-pool warm-up
+    t0 = time.perf_counter()
+    OP.sample(ospec, fl, x_rows[:nb], S, 7, lo, hi, dtype=torch.float32)
+    tb = time.perf_counter() - t0
+    return {"value": S / med, "unit": "samples/s", "cores": 1, "kind": "port",
+            "sample": f"{len(times)} galaxies x {S} accepted draws, one galaxy per call (oracle/posterior.py, "
+                      f"torch fp32, 1 thread); median {med:.4f} s/object "
+                      f"(16-84%: {np.percentile(times, 16):.4f}-{np.percentile(times, 84):.4f})",
+            "batched_all_cores": {"value": nb * S / tb, "cores": ncores,
+                                  "sample": f"{nb} galaxies x {S} draws in one call"}}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP flow engine has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    from synference_amd.estimator import build_flow
+    from synference_amd.posterior import FlowPosterior
+    from synference_amd.priors import prior_from_parameters
+    from synference_amd.runner import HipAdam
+    from synference_amd.synthetic import make_catalogue
+
+    # ---------------- data: 10k x 10-filter library (train) + per-rank test catalogue, all in HBM
+    D, C = 5, 10
+    x_lib, th_lib, names = make_catalogue(10_000, C, D, seed=1234)
+    x_test, th_test, _ = make_catalogue(a.galaxies, C, D, seed=4321 + rank)
+    rs = np.random.RandomState(0)
+    idx = rs.permutation(len(x_lib))
+    tr = idx[: int(0.8 * len(idx))]
+    prior = prior_from_parameters(th_lib[tr], names)
+    gen = torch.Generator().manual_seed(42)
+    est = build_flow("maf", th_lib[tr], x_lib[tr], hidden_features=50, num_transforms=5, device=dev,
+                     generator=gen).to(dev)
+    flow = est.flow
+    flat = est.flat.data
+    Xtr = torch.as_tensor(x_lib[tr]).to(dev)
+    Ttr = torch.as_tensor(th_lib[tr], dtype=torch.float32).to(dev)
+    grad = torch.empty_like(flat)
+    # ---------------- untimed seeded warm-up fit (identical on every rank)
+    opt = HipAdam(flat, lr=1e-3)
+    g2 = torch.Generator().manual_seed(7)
+    for _ in range(a.fit_steps):
+        bi = torch.randint(0, len(tr), (2048,), generator=g2).to(dev)
+        flow.loss_grad(flat, Ttr[bi], Xtr[bi], 1.0 / 2048, grad_out=grad)
+        opt.step(grad, 5.0)
+    flow.set_params(flat)
+    post = FlowPosterior(est, prior.to(dev), seed=2025)
+    lo, hi = prior.low.to(dev), prior.high.to(dev)
+    X = torch.as_tensor(x_test).to(dev)
+    M, S = X.shape[0], a.draws
+    out = torch.empty((M, S, D), dtype=torch.float32, device=dev)
+    rej = [torch.empty(M * S, dtype=torch.int32, device=dev) for _ in range(2)]
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
+    drawn = [0]
+
+    def sample_step(k, timed):
+        """sample_posterior over the catalogue: dense round 0 + retry rounds until every slot is filled."""
+        seed = 1000 + k
+        pending, cur, attempt = M * S, None, 0
+        while pending > 0 and attempt < 64:
+            cnt.zero_()
+            if timed and attempt == 0:
+                ev0[k].record()
+            flow.sample_round(X, S, cur, 0, pending, attempt, seed, lo, hi, out, rej[attempt & 1], cnt)
+            if timed and attempt == 0:
+                ev1[k].record()
+            drawn[0] += pending
+            pending = int(cnt.item())
+            cur = rej[attempt & 1]
+            attempt += 1
+        return pending
+
+    for k in range(a.warmup):
+        sample_step(0, False)
+    drawn[0] = 0
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    unfilled = 0
+    for k in range(a.steps):
+        unfilled += sample_step(k, True)
+    barrier_sync(world)
+    t_samp = max_over_ranks(time.perf_counter() - t0, world, dev)
+    k0_ms = float(np.mean([ev0[k].elapsed_time(ev1[k]) for k in range(a.steps)]))
+    accept = (a.steps * M * S) / max(drawn[0], 1)
+    value = world * a.steps * (M * S - 0) / t_samp
+    flops_launch = F_SAMPLE_PER_DRAW * M * S + F_SAMPLE_PER_GALAXY * M
+    achieved = flops_launch / (k0_ms * 1e-3) / 1e12
+
+    # ---------------- train leg: fwd+bwd (+ all-reduce) + clip + Adam at the per-GPU batch
+    tsteps = a.train_steps or a.steps
+    B = a.train_batch
+    gscale = 1.0 / (B * world)
+    opt2 = HipAdam(flat, lr=1e-4)
+    bidx = [torch.randint(0, len(tr), (B,), generator=g2).to(dev) for _ in range(4)]
+
+    def train_step(k):
+        bi = bidx[k % 4]
+        flow.loss_grad(flat, Ttr[bi], Xtr[bi], gscale, grad_out=grad)
+        if world > 1:
+            dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+        opt2.step(grad, 5.0)
+
+    for k in range(max(a.warmup, 1)):
+        train_step(k)
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for k in range(tsteps):
+        train_step(k)
+    barrier_sync(world)
+    t_train = max_over_ranks(time.perf_counter() - t0, world, dev)
+    pairs = world * tsteps * B / t_train
+    # reference-default batch (64) for comparison, single launch chain per step
+    b64 = torch.randint(0, len(tr), (64,), generator=g2).to(dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(50):
+        flow.loss_grad(flat, Ttr[b64], Xtr[b64], 1.0 / 64, grad_out=grad)
+        opt2.step(grad, 5.0)
+    torch.cuda.synchronize()
+    pairs64 = 50 * 64 / (time.perf_counter() - t0)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    rec = {
+        "metric": "posterior samples/sec (accepted, prior-box rejection included)",
+        "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * t_samp / a.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: NPE MAF T=5 H=50 on 10k-galaxy 10-filter mock; "
+                               f"sample_posterior over {M} test galaxies x {S} draws per GPU",
+                   "galaxies_per_gpu": M, "draws_per_galaxy": S, "theta_dim": D, "filters": C,
+                   "parallelism": f"rows sharded over {world} GPU(s), no collective",
+                   "acceptance": accept, "unfilled_slots": unfilled},
+        "roofline": {"bound": "mfma", "kernel": "k_inverse<MafOps<2,NS>> (dense round 0)",
+                     "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                     "launch_ms": k0_ms, "flops_per_launch": flops_launch,
+                     "note": "algorithmic = mask-aware 175150 FLOP/draw + 5000/galaxy (SURVEY 8d)"},
+        "train": {"metric": "flow-train theta.x pairs/sec (fwd+bwd+allreduce+clip+Adam)", "value": pairs,
+                  "unit": "pairs/s", "per_gpu_batch": B, "steps": tsteps, "ms_per_step": 1e3 * t_train / tsteps,
+                  "achieved_tflops": pairs * 3 * F_LOGPROB_PER_ROW / 1e12,
+                  "batch64_pairs_per_s_1gpu": pairs64},
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        rec["cpu_baseline"] = cpu_baseline(est.spec, flat.cpu().numpy(), x_test, prior.low.numpy(),
+                                           prior.high.numpy(), S, a.cpu_seconds)
+    print(json.dumps(rec))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

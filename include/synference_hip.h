@@ -157,6 +157,13 @@ int sf_flow_loss_grad(sf_flow* f, const float* flat /*[P]*/, const float* theta,
                       int64_t B, float grad_scale, float* loss /*[B]*/, float* grad /*[P]*/,
                       void* stream);
 
+/* Same with per-sample weights: grad[i] = sum_b grad_scale * weights[b] * d loss_b / d flat[i]
+ * (weights NULL = all ones).  This is the vector-Jacobian product torch.autograd needs for an
+ * arbitrary reduction of the per-sample losses. */
+int sf_flow_loss_grad_weighted(sf_flow* f, const float* flat, const float* theta, const float* x,
+                               int64_t B, float grad_scale, const float* weights /*[B]*/,
+                               float* loss, float* grad, void* stream);
+
 /* Fused global-norm clip + Adam / AdamW step on flat vectors.
  * Replaces: clip_grad_norm_(max_norm) + optimizer.step() (custom_runner.py:613-618). */
 typedef struct sf_adam_desc {
@@ -169,6 +176,12 @@ void sf_opt_destroy(sf_opt* o);
  * pre-clip global L2 norm. */
 int sf_adam_step(sf_opt* o, float* params, const float* grad, float max_norm,
                  float* grad_norm_out, void* stream);
+/* Stateless form: the caller owns exp_avg / exp_avg_sq [n] (device) and the step counter (the
+ * value AFTER this update, >= 1).  scratch: 2 device floats; scratch[1] receives the pre-clip
+ * global L2 norm.  This is the form the Python runner uses so that optimizer state lives in
+ * torch tensors and checkpoints like the reference's (custom_runner.py:693-704). */
+int sf_adam_apply(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  const sf_adam_desc* d, int64_t step, float max_norm, float* scratch, void* stream);
 /* optimizer state access for checkpoints (custom_runner.py:693-704): exp_avg, exp_avg_sq
  * device pointers [n] and the step counter. */
 int sf_opt_state(sf_opt* o, float** exp_avg, float** exp_avg_sq, int64_t** step_host);

@@ -56,9 +56,13 @@ PROTOTYPES = {
                                      C.c_uint64, C.c_void_p, C.c_void_p]),
     "sf_flow_loss_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sf_flow_loss_grad_weighted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                             C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sf_opt_create": (C.c_int, [C.c_int64, C.POINTER(sf_adam_desc), C.POINTER(C.c_void_p)]),
     "sf_opt_destroy": (None, [C.c_void_p]),
     "sf_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "sf_adam_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                C.POINTER(sf_adam_desc), C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
     "sf_opt_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                C.POINTER(C.POINTER(C.c_int64))]),
     "sf_last_error": (C.c_char_p, []),

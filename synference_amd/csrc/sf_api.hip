@@ -246,18 +246,24 @@ int sf_flow_acceptance(sf_flow* f, const float* x, int64_t M, int64_t n, const f
 }
 
 // ---- training ------------------------------------------------------------------------------
-int sf_flow_loss_grad(sf_flow* f, const float* flat, const float* theta, const float* x, int64_t B,
-                      float grad_scale, float* loss, float* grad, void* stream) {
+int sf_flow_loss_grad_weighted(sf_flow* f, const float* flat, const float* theta, const float* x, int64_t B,
+                               float grad_scale, const float* weights, float* loss, float* grad,
+                               void* stream) {
   if (!f || !flat || !grad) return fail(SF_ERR_INVALID, "null argument");
   if (B > 0 && (!theta || !x)) return fail(SF_ERR_INVALID, "null argument");
   if (B < 0) return fail(SF_ERR_INVALID, "B < 0");
   int rc = ensure_device(f);
   if (rc) return rc;
   std::string err;
-  rc = sf_train_loss_grad(f, flat, theta, x, (long)B, grad_scale, loss, grad, (hipStream_t)stream, err);
+  rc = sf_train_loss_grad(f, flat, theta, x, (long)B, grad_scale, weights, loss, grad, (hipStream_t)stream, err);
   if (rc) return fail(rc, err);
   f->params_set = true;  // the forward image now holds `flat`
   return SF_OK;
+}
+
+int sf_flow_loss_grad(sf_flow* f, const float* flat, const float* theta, const float* x, int64_t B,
+                      float grad_scale, float* loss, float* grad, void* stream) {
+  return sf_flow_loss_grad_weighted(f, flat, theta, x, B, grad_scale, nullptr, loss, grad, stream);
 }
 
 struct sf_opt {
@@ -296,6 +302,17 @@ int sf_adam_step(sf_opt* o, float* params, const float* grad, float max_norm, fl
   const double bc2 = 1.0 - std::pow((double)o->d.beta2, (double)o->step);
   hipError_t e = sf_launch_adam(params, grad, o->m, o->v, o->norm, (long)o->n, o->d, (float)bc1, (float)bc2,
                                 max_norm, grad_norm_out, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "sf_launch_adam");
+  return SF_OK;
+}
+int sf_adam_apply(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  const sf_adam_desc* d, int64_t step, float max_norm, float* scratch, void* stream) {
+  if (!params || !grad || !exp_avg || !exp_avg_sq || !d || !scratch) return fail(SF_ERR_INVALID, "null argument");
+  if (n < 1 || step < 1) return fail(SF_ERR_INVALID, "bad n or step");
+  const double bc1 = 1.0 - std::pow((double)d->beta1, (double)step);
+  const double bc2 = 1.0 - std::pow((double)d->beta2, (double)step);
+  hipError_t e = sf_launch_adam(params, grad, exp_avg, exp_avg_sq, scratch, (long)n, *d, (float)bc1, (float)bc2,
+                                max_norm, scratch + 1, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "sf_launch_adam");
   return SF_OK;
 }

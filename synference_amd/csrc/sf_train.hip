@@ -83,6 +83,7 @@ struct SfTrainArgs {
   const float* x;
   long B;
   float w;           // gradient weight of every sample (grad_scale)
+  const float* wts;  // optional per-sample weights [B] (multiplied by w)
   float* loss;       // [B] or null
   float* gimg;       // gradient image
   float4* act;       // activation stash
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256) void k_maf_train(SfDev m, SfTrainArgs a) {
     logdet[0] += ld + sf_xhalf(ld);
   }
   float G[SF_DMAX];  // dL/d(output of the current transform), replicated in both halves
-  const float w = valid ? a.w : 0.f;
+  const float w = valid ? (a.wts ? a.w * a.wts[row] : a.w) : 0.f;
   {
     float ss = 0.f;
 #pragma unroll
@@ -379,7 +380,8 @@ static hipError_t launch_maf_train(const SfDev& m, const SfTrainArgs& a, hipStre
   } while (0)
 
 int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const float* x, long B,
-                       float grad_scale, float* loss, float* grad, hipStream_t st, std::string& err) {
+                       float grad_scale, const float* weights, float* loss, float* grad, hipStream_t st,
+                       std::string& err) {
   const SfLayout& L = f->L;
   if (L.dev.kind != SF_MAF) {
     err = "sf_flow_loss_grad: the NSF backward kernels are not built in this library yet";
@@ -413,7 +415,7 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
   SF_TRY(hipMemsetAsync(f->d_gpacked, 0, (size_t)L.n_packed * sizeof(float), st));
   if (B > 0) {
     SfTrainArgs a;
-    a.theta = theta; a.x = x; a.B = B; a.w = grad_scale; a.loss = loss; a.gimg = f->d_gpacked;
+    a.theta = theta; a.x = x; a.B = B; a.w = grad_scale; a.wts = weights; a.loss = loss; a.gimg = f->d_gpacked;
     a.act = reinterpret_cast<float4*>(f->d_act); a.act_per_wave = act_per_wave;
     const SfDev m = f->dev();
     switch (m.HT) {

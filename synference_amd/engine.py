@@ -148,13 +148,16 @@ class HipFlow:
         return cnt.to(torch.float32) / float(n)
 
     def loss_grad(self, flat: torch.Tensor, theta, x, grad_scale: float,
-                  grad_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                  grad_out: Optional[torch.Tensor] = None, weights: Optional[torch.Tensor] = None
+                  ) -> Tuple[torch.Tensor, torch.Tensor]:
         self._dev()
         flat = _f32c(flat, self.device)
         theta, x = _f32c(theta, self.device), _f32c(x, self.device)
         B = theta.shape[0]
         loss = torch.empty(B, dtype=torch.float32, device=self.device)
         grad = grad_out if grad_out is not None else torch.empty_like(flat)
-        _lib.check(self.lib.sf_flow_loss_grad(self.handle, _ptr(flat), _ptr(theta), _ptr(x), B,
-                                              C.c_float(grad_scale), _ptr(loss), _ptr(grad), _stream(self.device)))
+        wts = None if weights is None else _f32c(weights, self.device)
+        _lib.check(self.lib.sf_flow_loss_grad_weighted(self.handle, _ptr(flat), _ptr(theta), _ptr(x), B,
+                                                       C.c_float(grad_scale), _ptr(wts), _ptr(loss), _ptr(grad),
+                                                       _stream(self.device)))
         return loss, grad

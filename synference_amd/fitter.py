@@ -1,0 +1,275 @@
+"""``SBI_Fitter`` surface of the reference for the amortised-posterior flow path, HIP backend.
+
+Same method names, argument meaning and error behaviour as ref: src/synference/sbi_runner.py for
+  run_single_sbi (4392-4435), create_priors (3442-3450), split_dataset (3407-3440),
+  sample_posterior (6350-6474), log_prob (7162-7198), fit_catalogue sampling + quantile section
+  (2948-2989, 3230-3282), evaluate_model's flow-derived metrics (6484-6735).
+What is NOT here (out of scope): library generation, feature engineering from
+raw fluxes, noise models, Optuna search, MDN / likelihood / ratio engines, MCMC / VI samplers,
+plotting.  Asking for them raises ``ValueError`` rather than falling through to another backend.
+
+The per-galaxy Python loops of the reference (6438-6442, 7193-7196) collapse into one catalogue
+call on the GPU; return types and shapes are the reference's ((N,S,D) float64 ndarray; (N,) float64).
+"""
+from __future__ import annotations
+
+import logging
+import os
+import time
+from typing import Callable, List, Optional, Union
+
+import numpy as np
+import torch
+
+from .estimator import SUPPORTED_MODELS, load_nde_hip
+from .priors import CustomIndependentUniform, prior_from_parameters
+from .runner import HIPRunner, NumpyLoader
+
+logger = logging.getLogger("synference_amd")
+
+
+class SBI_Fitter:
+    device = "cuda"
+
+    def __init__(self, name: str, parameter_names: list, raw_observation_names: list = None,
+                 raw_observation_grid: np.ndarray = None, parameter_array: np.ndarray = None,
+                 parameter_units: list = None, raw_observation_units: list = None, simulator: callable = None,
+                 feature_array: np.ndarray = None, feature_names: list = None, feature_units: list = None,
+                 library_path: str = None, supplementary_parameters: np.ndarray = None,
+                 supplementary_parameter_names: list = None, supplementary_parameter_units: list = None,
+                 device: str = "cuda", observation_type: str = "photometry") -> None:
+        if simulator is not None or library_path is not None:
+            raise ValueError("the HIP backend starts from a feature array and a parameter array; library "
+                             "loading and online simulators are outside the accelerated path")
+        self.name = name
+        self.parameter_names = list(parameter_names)
+        self.fitted_parameter_names = list(parameter_names)
+        self.simple_fitted_parameter_names = [str(p).split("/")[-1] for p in parameter_names]
+        self.fitted_parameter_units = parameter_units
+        self.raw_observation_names = raw_observation_names
+        self.feature_names = feature_names if feature_names is not None else raw_observation_names
+        self.feature_units = feature_units
+        self.device = device
+        self.observation_type = observation_type
+        self.feature_array = None
+        self.fitted_parameter_array = None
+        self.has_features = False
+        if feature_array is not None:
+            # reference: feature_array.astype(np.float32), (N, C) (sbi_runner.py:2150)
+            self.feature_array = np.ascontiguousarray(np.asarray(feature_array).astype(np.float32))
+            self.has_features = True
+        if parameter_array is not None:
+            self.fitted_parameter_array = np.asarray(parameter_array)
+            if self.fitted_parameter_array.shape[1] != len(self.parameter_names):
+                raise ValueError("parameter_array must be (N, len(parameter_names))")
+        self.has_simulator = False
+        self.posteriors = None
+        self.stats = None
+        self._prior = None
+        self._train_indices = self._test_indices = None
+        self._X_train = self._y_train = self._X_test = self._y_test = None
+        self.fitted_model_name = None
+
+    # ---------------------------------------------------------------------------------------
+    def split_dataset(self, train_fraction: float = 0.8, random_seed: int = None, verbose: bool = True) -> tuple:
+        if random_seed is not None:
+            np.random.seed(random_seed)
+        if not self.has_features:
+            raise ValueError("Feature array not created. Please create the feature array first.")
+        n = self.feature_array.shape[0]
+        idx = np.arange(n)
+        np.random.shuffle(idx)
+        k = int(n * train_fraction)
+        return idx[:k], idx[k:]
+
+    def create_priors(self, override_prior_ranges: dict = {}, prior=CustomIndependentUniform, verbose: bool = True,
+                      debug_sample_acceptance: bool = False, extend_prior_range_pc: float = 0.0,
+                      set_self: bool = False):
+        if not self.has_features:
+            raise ValueError("Feature array not created and no simulator.\n"
+                             "                Please create the feature array first.")
+        if self.fitted_parameter_array is None:
+            raise ValueError("Parameter grid not created. Please create the parameter grid first.")
+        p = prior_from_parameters(self.fitted_parameter_array, self.fitted_parameter_names,
+                                  override_prior_ranges, extend_prior_range_pc, device="cpu")
+        if verbose:
+            logger.info("Prior ranges:")
+            for n_, lo, hi in zip(self.fitted_parameter_names, p.low.tolist(), p.high.tolist()):
+                logger.info(f"{n_}: {lo:.2f} - {hi:.2f}")
+        if set_self:
+            self._prior = p
+        return p
+
+    # ---------------------------------------------------------------------------------------
+    def run_single_sbi(self, train_test_fraction: float = 0.8, random_seed: Optional[int] = None,
+                       backend: str = "hip", engine: Union[str, List[str]] = "NPE",
+                       train_indices: Optional[np.ndarray] = None, test_indices: Optional[np.ndarray] = None,
+                       n_nets: int = 1, model_type: Union[str, List[str]] = "maf",
+                       hidden_features: Union[int, List[int]] = 50, num_components: Union[int, List[int]] = 4,
+                       num_transforms: Union[int, List[int]] = 4, training_batch_size: int = 64,
+                       learning_rate: float = 1e-4, validation_fraction: float = 0.2, stop_after_epochs: int = 15,
+                       clip_max_norm: float = 5.0, additional_model_args: dict = {}, save_model: bool = True,
+                       verbose: bool = True, prior_method: str = "ili", out_dir: str = None, plot: bool = False,
+                       name_append: str = "timestamp", set_self: bool = True, learning_type: str = "offline",
+                       override_prior_ranges: dict = {}, evaluate_model: bool = False,
+                       num_posterior_draws_per_sample: int = 1000, embedding_net=None,
+                       max_num_epochs: Optional[int] = None, **unused) -> tuple:
+        """Train an ensemble of n_nets flows; returns (posteriors, stats) like the reference."""
+        if backend != "hip":
+            raise ValueError(f"backend '{backend}' is not available in synference_amd: use backend='hip'")
+        if learning_type != "offline":
+            raise ValueError("only learning_type='offline' (amortised NPE) is on the HIP path")
+        if prior_method != "ili":
+            raise ValueError("only prior_method='ili' (box prior from the training parameters) is built")
+        if not self.has_features or self.fitted_parameter_array is None:
+            raise ValueError("feature_array and parameter_array must be set before training")
+        engines = [engine] * n_nets if isinstance(engine, str) else list(engine)
+        models = [model_type] * n_nets if isinstance(model_type, str) else list(model_type)
+        hf = [hidden_features] * n_nets if isinstance(hidden_features, int) else list(hidden_features)
+        nt = [num_transforms] * n_nets if isinstance(num_transforms, int) else list(num_transforms)
+        for m in models:
+            if m not in SUPPORTED_MODELS:
+                raise ValueError(f"model_type '{m}' is not on the HIP path; supported: {SUPPORTED_MODELS}")
+        if train_indices is None:
+            train_indices, test_indices = self.split_dataset(train_test_fraction, random_seed, verbose)
+        X_train = self.feature_array[train_indices]
+        y_train = self.fitted_parameter_array[train_indices]
+        X_test = self.feature_array[test_indices] if test_indices is not None else None
+        y_test = self.fitted_parameter_array[test_indices] if test_indices is not None else None
+        saved = self.fitted_parameter_array
+        try:  # priors span the TRAINING parameters like the reference (sbi_runner.py:3519-3520 on the grid)
+            prior = self.create_priors(override_prior_ranges, verbose=verbose)
+        finally:
+            self.fitted_parameter_array = saved
+        nets = []
+        for i in range(n_nets):
+            args = dict(hidden_features=hf[i], num_transforms=nt[i])
+            args.update(additional_model_args)
+            nets.append(load_nde_hip(engines[i], model=models[i], embedding_net=embedding_net, **args))
+        train_args = dict(training_batch_size=training_batch_size, learning_rate=learning_rate,
+                          validation_fraction=validation_fraction, stop_after_epochs=stop_after_epochs,
+                          clip_max_norm=clip_max_norm, log_every=1 if verbose else 0)
+        if max_num_epochs is not None:
+            train_args["max_num_epochs"] = max_num_epochs
+        stamp = time.strftime("%Y%m%d_%H%M%S") if name_append == "timestamp" else str(name_append)
+        run_name = f"{self.name}_{stamp}_"
+        trainer = HIPRunner.load(backend="hip", engine=engines[0], prior=prior, nets=nets, train_args=train_args,
+                                 out_dir=(out_dir if save_model else None), device=self.device, name=run_name)
+        t0 = time.time()
+        try:
+            posteriors, stats = trainer(NumpyLoader(X_train, y_train), seed=random_seed)
+        except Exception as e:  # sbi_runner.py:4940-4941
+            raise RuntimeError(f"Error during SBI training: {e}") from e
+        self.training_time = time.time() - t0
+        if set_self:
+            self.posteriors, self.stats, self._prior = posteriors, stats, prior
+            self._train_indices, self._test_indices = train_indices, test_indices
+            self._X_train, self._y_train, self._X_test, self._y_test = X_train, y_train, X_test, y_test
+            self.fitted_model_name = run_name
+        if evaluate_model and X_test is not None:
+            self.evaluate_model(posteriors=posteriors, X_test=X_test, y_test=y_test,
+                                num_samples=num_posterior_draws_per_sample)
+        return posteriors, stats
+
+    # ---------------------------------------------------------------------------------------
+    def sample_posterior(self, X_test: np.ndarray = None, sample_method: str = "direct", sample_kwargs: dict = {},
+                         posteriors: object = None, num_samples: int = 1000, timeout_seconds_per_test=30,
+                         log_times=False, seed: Optional[int] = None, **kwargs) -> np.ndarray:
+        """(num_objects, num_samples, num_parameters) float64; NaN rows where sampling failed
+        (ref: sbi_runner.py:6436, 6458-6460); a single observation returns (num_samples, num_parameters)."""
+        if posteriors is None:
+            posteriors = self.posteriors
+        if X_test is None:
+            if getattr(self, "_X_test", None) is not None:
+                X_test = self._X_test
+            else:
+                raise ValueError("X_test must be provided or set in the object.")
+        if sample_method != "direct":
+            raise ValueError("Invalid sample method for the HIP backend. Use 'direct'.")
+        X = np.asarray(X_test, dtype=np.float32)
+        single = X.ndim == 1 or (X.ndim == 2 and X.shape[0] == 1)
+        if X.ndim == 1:
+            X = X[None, :]
+        t0 = time.time()
+        try:
+            s = posteriors.sample_catalogue(torch.as_tensor(X), num_samples, seed)
+            samples = s.double().cpu().numpy()
+        except Exception as e:
+            logger.error(f"Error occurred while sampling: {e}")
+            samples = np.full((len(X), num_samples, len(self.fitted_parameter_names)), np.nan)
+        if log_times and len(X):
+            per = (time.time() - t0) / len(X)
+            logger.info(f"Median time per sample: {per:.5f} seconds (catalogue call, {len(X)} objects).")
+            self.last_time_per_object = per
+        return np.squeeze(samples, 0) if single else samples
+
+    def log_prob(self, X: np.ndarray, y: np.ndarray, posteriors: object = None, verbose=True,
+                 norm_posterior: bool = True, num_rejection_samples: int = 10000) -> np.ndarray:
+        """(N,) float64 posterior log-density of y[i] given X[i]  (ref: sbi_runner.py:7188-7198; upstream
+        DirectPosterior default norm_posterior=True -> leakage-corrected)."""
+        if posteriors is None:
+            posteriors = self.posteriors
+        lp = posteriors.log_prob_catalogue(torch.as_tensor(np.asarray(y, dtype=np.float32)),
+                                           torch.as_tensor(np.asarray(X, dtype=np.float32)),
+                                           norm_posterior, num_rejection_samples)
+        return lp.double().cpu().numpy()
+
+    def fit_catalogue(self, observations, columns_to_feature_names: dict = None, num_samples: int = 1000,
+                      quantiles=(0.16, 0.5, 0.84), sample_method: str = "direct", append_to_input: bool = True,
+                      return_samples: bool = False, log_times: bool = False, seed: Optional[int] = None, **unused):
+        """Sampling + quantile section of the reference's fit_catalogue (sbi_runner.py:3230-3282).
+
+        ``observations`` is a pandas DataFrame / dict of columns / (N, C) array already expressed in the
+        feature space the model was trained on (the flux -> feature conversion of lines 3061-3068 is
+        outside the accelerated path).  Rows containing NaN are masked and get NaN quantiles."""
+        import pandas as pd
+        if isinstance(observations, np.ndarray):
+            df = pd.DataFrame(observations, columns=list(self.feature_names)[: observations.shape[1]])
+        elif isinstance(observations, dict):
+            df = pd.DataFrame(observations)
+        else:
+            df = observations.copy()
+        cols = list(self.feature_names)
+        if columns_to_feature_names:
+            df = df.rename(columns=columns_to_feature_names)
+        missing = [c for c in cols if c not in df.columns]
+        if missing:
+            raise ValueError(f"observations lack the feature columns {missing}")
+        feats = df[cols].to_numpy(dtype=np.float32)
+        obs_mask = ~np.isfinite(feats).all(1)
+        samples = np.full((len(df), num_samples, len(self.fitted_parameter_names)), np.nan)
+        if (~obs_mask).any():
+            samples[~obs_mask] = self.sample_posterior(feats[~obs_mask], sample_method=sample_method,
+                                                       num_samples=num_samples, log_times=log_times, seed=seed)
+        samples_quant = samples.transpose(2, 0, 1)
+        table = df.copy() if append_to_input else pd.DataFrame({"ID": np.arange(len(df)) + 1})
+        for i, param in enumerate(self.simple_fitted_parameter_names):
+            with np.errstate(invalid="ignore"):
+                q = np.nanquantile(samples_quant[i], quantiles, axis=1) if (~obs_mask).any() else \
+                    np.full((len(quantiles), len(df)), np.nan)
+            for j, quant in enumerate(q):
+                col = np.asarray(quant, dtype=np.float64)
+                col[obs_mask] = np.nan
+                table[f"{param}_{int(quantiles[j] * 100)}"] = col
+        return (table, samples) if return_samples else table
+
+    def evaluate_model(self, posteriors=None, X_test=None, y_test=None, num_samples: int = 1000,
+                       independent_metrics: bool = True, seed: Optional[int] = None, **unused) -> dict:
+        """Flow-derived metrics of the reference's evaluate_model (sbi_runner.py:6484-6735): per-parameter
+        MSE / RMSE / R^2 of the posterior mean, mean log-prob, PIT (7128-7160)."""
+        posteriors = posteriors if posteriors is not None else self.posteriors
+        X_test = self._X_test if X_test is None else X_test
+        y_test = self._y_test if y_test is None else y_test
+        s = self.sample_posterior(X_test, posteriors=posteriors, num_samples=num_samples, seed=seed)
+        mean = np.nanmean(s, axis=1)
+        y = np.asarray(y_test, dtype=np.float64)
+        mse = np.nanmean((mean - y) ** 2, 0)
+        ss_tot = np.sum((y - y.mean(0)) ** 2, 0)
+        r2 = 1.0 - np.nansum((mean - y) ** 2, 0) / np.where(ss_tot > 0, ss_tot, np.nan)
+        lp = self.log_prob(X_test, y_test, posteriors=posteriors, norm_posterior=False)
+        pit = np.nanmean(s < y[:, None, :], axis=1)
+        metrics = {"mse": mse.tolist(), "rmse": np.sqrt(mse).tolist(), "r_squared": r2.tolist(),
+                   "mean_log_prob": float(np.mean(lp[np.isfinite(lp)])) if np.isfinite(lp).any() else float("nan"),
+                   "pit_mean": pit.mean(0).tolist(), "pit_std": pit.std(0).tolist()}
+        self.last_metrics = metrics
+        return metrics

@@ -1,0 +1,274 @@
+"""Posterior protocol of the reference on the HIP engine.
+
+``SBI_Fitter`` consumes: ``.sample((S,), x=)`` (ref: sbi_runner.py:6442 through
+ili ``DirectSampler``), ``.log_prob(x=, theta=)`` (7196) with optional
+``leakage_correction_params`` (custom_runner.py:466-473), ``.sample_batched((S,), x=X)`` ->
+``(S,N,D)`` (custom_runner.py:489-493), indexable ``.posteriors`` / ``.weights`` / ``.name`` /
+``.signatures`` (custom_runner.py:278-285).  ``FlowPosterior`` restates [UPSTREAM] sbi
+``DirectPosterior`` and ``EnsemblePosterior`` restates sbi ``EnsemblePosterior``;
+the catalogue-wide calls (``sample_catalogue`` / ``log_prob_catalogue``) are what the reference's
+per-galaxy Python loops collapse into.
+
+Rejection schedule: every output slot (galaxy g, draw p) is its own rejection sampler on the
+Philox stream (slot, attempt); accepted draws are i.i.d. from the flow restricted to the prior
+box exactly as with sbi's batch loop, but the result does not depend on batching.
+"""
+from __future__ import annotations
+
+import logging
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .estimator import FlowEstimator
+from .priors import CustomIndependentUniform
+
+logger = logging.getLogger("synference_amd")
+
+_MAX_SLOTS_PER_CALL = 1 << 27  # keeps slot ids in 32 bits and scratch lists modest
+
+
+def _as_x2d(x, C, device):
+    x = torch.as_tensor(x, dtype=torch.float32, device=device)
+    if x.dim() == 1:
+        x = x[None, :]
+    if x.dim() != 2 or x.shape[1] != C:
+        raise ValueError(f"x must have trailing dimension {C}, got {tuple(x.shape)}")
+    return x.contiguous()
+
+
+class FlowPosterior:
+    """q(theta | x) restricted to the prior support ([UPSTREAM] sbi DirectPosterior)."""
+
+    def __init__(self, posterior_estimator: FlowEstimator, prior: Optional[CustomIndependentUniform] = None,
+                 max_sampling_attempts: int = 64, seed: int = 0):
+        self.posterior_estimator = posterior_estimator
+        self.prior = prior
+        self.max_sampling_attempts = int(max_sampling_attempts)
+        self._seed = int(seed)
+        self._calls = 0
+        self.name = ""
+        self.signatures = None
+        self.last_acceptance = None
+
+    # ---- helpers ----------------------------------------------------------------------------
+    @property
+    def device(self):
+        return self.posterior_estimator.flat.device
+
+    @property
+    def spec(self):
+        return self.posterior_estimator.spec
+
+    def to(self, device):
+        self.posterior_estimator.to(device)
+        if self.prior is not None:
+            self.prior = self.prior.to(device)
+        return self
+
+    def _box(self):
+        if self.prior is None:
+            return None, None
+        return self.prior.low.to(self.device), self.prior.high.to(self.device)
+
+    def _next_seed(self, seed):
+        if seed is not None:
+            return int(seed)
+        self._calls += 1
+        return (self._seed * 0x9E3779B97F4A7C15 + self._calls) & (2 ** 63 - 1)
+
+    # ---- catalogue-wide fast paths ----------------------------------------------------------
+    def sample_catalogue(self, X, num_samples: int, seed: Optional[int] = None, return_counts=False):
+        """(N,S,D) float32 device tensor of accepted draws for every row of X (NaN rows on failure)."""
+        est = self.posterior_estimator
+        X = _as_x2d(X, self.spec.C, self.device)
+        est._sync_params()
+        lo, hi = self._box()
+        seed = self._next_seed(seed)
+        N, S = X.shape[0], int(num_samples)
+        out = torch.empty((N, S, self.spec.D), dtype=torch.float32, device=self.device)
+        counts = torch.empty(N, dtype=torch.int32, device=self.device)
+        rows_per = max(1, _MAX_SLOTS_PER_CALL // max(S, 1))
+        unfilled = 0
+        for r0 in range(0, N, rows_per):
+            r1 = min(N, r0 + rows_per)
+            # slot ids restart per chunk: fold the chunk start into the seed so streams stay distinct
+            o, c = est.flow.sample(X[r0:r1], S, lo, hi, seed=seed + 0x632BE59BD9B4E019 * (r0 // rows_per),
+                                   max_attempts=self.max_sampling_attempts, out=out[r0:r1], return_counts=True)
+            counts[r0:r1] = c
+            unfilled += est.flow.last_unfilled
+        self.last_acceptance = (S / counts.float().clamp_min(1)).mean().item() if N else None
+        if unfilled:
+            logger.error(f"{unfilled} posterior draws could not be placed inside the prior support after "
+                         f"{self.max_sampling_attempts} attempts; those rows are NaN.")
+        if self.last_acceptance is not None and self.last_acceptance < 0.01:
+            logger.warning(f"Only {self.last_acceptance * 100:.3f}% of the proposed samples were accepted: "
+                           "the posterior mass is largely outside the prior support.")
+        return (out, counts) if return_counts else out
+
+    def log_prob_catalogue(self, theta, X, norm_posterior: bool = True, num_rejection_samples: int = 10000,
+                           seed: Optional[int] = None):
+        """[UPSTREAM] DirectPosterior.log_prob for aligned rows: raw density, -inf outside the prior
+        support, minus log(acceptance(x)) when ``norm_posterior``."""
+        est = self.posterior_estimator
+        theta = torch.as_tensor(theta, dtype=torch.float32, device=self.device)
+        if theta.dim() == 1:
+            theta = theta[None, :]
+        X = _as_x2d(X, self.spec.C, self.device)
+        if X.shape[0] == 1 and theta.shape[0] > 1:
+            X = X.expand(theta.shape[0], -1).contiguous()
+        est._sync_params()
+        lp = est.flow.log_prob(theta, X)
+        lo, hi = self._box()
+        if lo is not None:
+            inside = ((theta >= lo) & (theta <= hi)).all(-1)
+            lp = torch.where(inside, lp, torch.full_like(lp, float("-inf")))
+            if norm_posterior:
+                ux, inv = torch.unique(X, dim=0, return_inverse=True)
+                acc = est.flow.acceptance(ux, int(num_rejection_samples), lo, hi, seed=self._next_seed(seed))
+                lp = lp - torch.log(acc.clamp_min(1e-30))[inv]
+        return lp
+
+    # ---- sbi surface ------------------------------------------------------------------------
+    def sample(self, sample_shape=(1,), x=None, show_progress_bars=False, seed: Optional[int] = None, **_):
+        S = int(np.prod(sample_shape)) if len(tuple(sample_shape)) else 1
+        x = _as_x2d(x, self.spec.C, self.device)
+        if x.shape[0] != 1:
+            raise ValueError("sample() takes ONE observation; use sample_batched() for a catalogue")
+        out = self.sample_catalogue(x, S, seed)[0]
+        return out.reshape(*tuple(sample_shape), self.spec.D)
+
+    def sample_batched(self, sample_shape=(1,), x=None, show_progress_bars=False, seed: Optional[int] = None, **_):
+        S = int(np.prod(sample_shape))
+        out = self.sample_catalogue(x, S, seed)  # (N,S,D)
+        return out.permute(1, 0, 2).contiguous()  # sbi convention (S,N,D)
+
+    def log_prob(self, theta, x=None, norm_posterior: bool = True, leakage_correction_params=None, **_):
+        p = dict(leakage_correction_params or {})
+        return self.log_prob_catalogue(theta, x, norm_posterior, p.get("num_rejection_samples", 10000))
+
+    def log_prob_batched(self, theta, x, norm_posterior: bool = True, **_):
+        """theta (S,N,D), x (N,C) -> (S,N)."""
+        theta = torch.as_tensor(theta, dtype=torch.float32, device=self.device)
+        S, N, D = theta.shape
+        X = _as_x2d(x, self.spec.C, self.device)
+        lp = self.log_prob_catalogue(theta.reshape(S * N, D), X.repeat(S, 1), norm_posterior)
+        return lp.reshape(S, N)
+
+    def potential_fn(self, theta, x):
+        return self.log_prob_catalogue(theta, x, norm_posterior=False)
+
+
+class EnsemblePosterior:
+    """Weighted mixture of posteriors ([UPSTREAM] sbi EnsemblePosterior; built in the reference at
+    custom_runner.py:278-283, weights from validation log-probs in ili's runner)."""
+
+    def __init__(self, posteriors: Sequence[FlowPosterior], weights=None, theta_transform=None, seed: int = 0):
+        self.posteriors: List[FlowPosterior] = list(posteriors)
+        n = len(self.posteriors)
+        w = torch.ones(n) / n if weights is None else torch.as_tensor(weights, dtype=torch.float32).detach().cpu()
+        self._weights = w / w.sum()
+        self.theta_transform = theta_transform
+        self.name = ""
+        self.signatures = None
+        self._seed = int(seed)
+        self._calls = 0
+
+    def __len__(self):
+        return len(self.posteriors)
+
+    @property
+    def weights(self):
+        return self._weights
+
+    @property
+    def device(self):
+        return self.posteriors[0].device
+
+    @property
+    def prior(self):
+        return self.posteriors[0].prior
+
+    def to(self, device):
+        for p in self.posteriors:
+            p.to(device)
+        return self
+
+    def _next_seed(self, seed):
+        if seed is not None:
+            return int(seed)
+        self._calls += 1
+        return (self._seed * 0x9E3779B97F4A7C15 + 0x51ED27 + self._calls) & (2 ** 63 - 1)
+
+    def sample_catalogue(self, X, num_samples: int, seed: Optional[int] = None):
+        """Per row: multinomial(weights, S) split; member e fills positions [cum_{e-1}, cum_e)."""
+        if len(self.posteriors) == 1:
+            return self.posteriors[0].sample_catalogue(X, num_samples, self._next_seed(seed))
+        p0 = self.posteriors[0]
+        dev, D, S = p0.device, p0.spec.D, int(num_samples)
+        X = _as_x2d(X, p0.spec.C, dev)
+        N = X.shape[0]
+        seed = self._next_seed(seed)
+        out = torch.full((N, S, D), float("nan"), dtype=torch.float32, device=dev)
+        w = self._weights.double().numpy()
+        counts = np.random.default_rng(seed & 0xFFFFFFFF).multinomial(S, w / w.sum(), size=N)
+        cum = np.concatenate([np.zeros((N, 1), np.int64), np.cumsum(counts, 1)], 1)
+        rows_per = max(1, (_MAX_SLOTS_PER_CALL // 4) // max(S, 1))
+        pos = torch.arange(S, device=dev)[None, :]
+        for r0 in range(0, N, rows_per):
+            r1 = min(N, r0 + rows_per)
+            cum_d = torch.as_tensor(cum[r0:r1], device=dev)
+            for e, post in enumerate(self.posteriors):
+                mask = (pos >= cum_d[:, e:e + 1]) & (pos < cum_d[:, e + 1:e + 2])
+                slots = torch.nonzero(mask.reshape(-1)).reshape(-1).to(torch.int32)  # bit pattern == uint32
+                _sample_slot_list(post, X[r0:r1], S, slots, seed + 0x632BE59BD9B4E019 * (r0 // rows_per),
+                                  out[r0:r1])
+        return out
+
+    def sample(self, sample_shape=(1,), x=None, show_progress_bars=False, seed: Optional[int] = None, **_):
+        S = int(np.prod(sample_shape)) if len(tuple(sample_shape)) else 1
+        x = _as_x2d(x, self.posteriors[0].spec.C, self.device)
+        if x.shape[0] != 1:
+            raise ValueError("sample() takes ONE observation; use sample_batched() for a catalogue")
+        return self.sample_catalogue(x, S, seed)[0].reshape(*tuple(sample_shape), -1)
+
+    def sample_batched(self, sample_shape=(1,), x=None, show_progress_bars=False, seed: Optional[int] = None, **_):
+        return self.sample_catalogue(x, int(np.prod(sample_shape)), seed).permute(1, 0, 2).contiguous()
+
+    def log_prob_catalogue(self, theta, X, norm_posterior: bool = True, num_rejection_samples: int = 10000):
+        lps = torch.stack([p.log_prob_catalogue(theta, X, norm_posterior, num_rejection_samples)
+                           for p in self.posteriors], 0)
+        logw = torch.log(self._weights.to(lps.device))[:, None]
+        return torch.logsumexp(lps + logw, dim=0)
+
+    def log_prob(self, theta, x=None, norm_posterior: bool = True, leakage_correction_params=None, **_):
+        p = dict(leakage_correction_params or {})
+        return self.log_prob_catalogue(theta, x, norm_posterior, p.get("num_rejection_samples", 10000))
+
+    def potential_fn(self, theta, x):
+        return self.log_prob_catalogue(theta, x, norm_posterior=False)
+
+
+def _sample_slot_list(post: FlowPosterior, X, S: int, slots: torch.Tensor, seed: int, out: torch.Tensor):
+    """Rejection rounds over an explicit slot list (ensemble members own disjoint slot sets)."""
+    n = int(slots.numel())
+    if n == 0:
+        return
+    est = post.posterior_estimator
+    est._sync_params()
+    lo, hi = post._box()
+    dev = X.device
+    rej = [torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)]
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    cur, pending = slots.contiguous(), n
+    for attempt in range(post.max_sampling_attempts):
+        cnt.zero_()
+        est.flow.sample_round(X, S, cur, 0, pending, attempt, seed, lo, hi, out, rej[attempt & 1], cnt)
+        pending = int(cnt.item())
+        cur = rej[attempt & 1]
+        if pending == 0:
+            return
+    bad = cur[:pending].long()
+    out.reshape(-1, out.shape[-1])[bad] = float("nan")
+    logger.error(f"{pending} posterior draws could not be placed inside the prior support.")

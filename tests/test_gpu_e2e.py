@@ -1,0 +1,121 @@
+"""End-to-end through the reference's API surface on the GPU (SBI_Fitter -> HIPRunner -> posterior)."""
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fitted(tmp_path_factory):
+    from synference_amd import SBI_Fitter
+    from synference_amd.synthetic import make_catalogue
+    x, theta, names = make_catalogue(4000, 10, 5, seed=1)
+    f = SBI_Fitter("e2e", names, [f"F{i}" for i in range(10)], feature_array=x, parameter_array=theta)
+    out = tmp_path_factory.mktemp("models")
+    post, stats = f.run_single_sbi(model_type="maf", hidden_features=50, num_transforms=5, n_nets=2,
+                                   training_batch_size=256, learning_rate=2e-3, stop_after_epochs=3,
+                                   max_num_epochs=12, random_seed=3, out_dir=str(out), verbose=False,
+                                   name_append="t")
+    return f, post, stats, out
+
+
+def test_training_reduces_loss_and_fills_stats(fitted):
+    f, post, stats, out = fitted
+    assert len(post) == 2 and len(stats) == 2
+    for s in stats:
+        for k in ("training_log_probs", "validation_log_probs", "best_validation_log_prob", "epochs_trained",
+                  "training_loss", "validation_loss", "best_validation_loss", "converged"):
+            assert k in s
+        assert s["training_loss"][-1] < s["training_loss"][0] - 0.5
+        assert s["training_log_probs"][0] == -s["training_loss"][0]
+    assert abs(float(post.weights.sum()) - 1.0) < 1e-6
+    assert (out / "e2e_t_posterior.pkl").exists() and (out / "e2e_t_summary.json").exists()
+
+
+def test_sample_posterior_contract(fitted):
+    f, post, stats, _ = fitted
+    X = f._X_test[:50]
+    s = f.sample_posterior(X, num_samples=200, seed=5)
+    assert s.shape == (50, 200, 5) and s.dtype == np.float64
+    assert np.isfinite(s).all()
+    lo, hi = f._prior.low.numpy(), f._prior.high.numpy()
+    assert ((s >= lo) & (s <= hi)).all()
+    one = f.sample_posterior(X[0], num_samples=64, seed=5)
+    assert one.shape == (64, 5)
+    # the trained posterior must be informative: posterior mean closer to truth than the prior mean
+    mean = s.mean(1)
+    y = f._y_test[:50]
+    prior_mean = (lo + hi) / 2
+    assert np.mean((mean[:, 0] - y[:, 0]) ** 2) < 0.7 * np.mean((prior_mean[0] - y[:, 0]) ** 2)
+
+
+def test_log_prob_contract_and_ensemble_mixture(fitted):
+    f, post, stats, _ = fitted
+    X, y = f._X_test[:40], f._y_test[:40]
+    raw = f.log_prob(X, y, norm_posterior=False)
+    assert raw.shape == (40,) and raw.dtype == np.float64 and np.isfinite(raw).all()
+    # mixture rule: logsumexp_i(log w_i + lp_i)
+    lps = np.stack([p.log_prob_catalogue(torch.as_tensor(y, dtype=torch.float32), torch.as_tensor(X),
+                                         norm_posterior=False).double().cpu().numpy() for p in post.posteriors])
+    w = post.weights.double().numpy()
+    ref = np.log((np.exp(lps - lps.max(0)) * w[:, None]).sum(0)) + lps.max(0)
+    assert np.abs(raw - ref).max() < 1e-4
+    norm = f.log_prob(X, y, norm_posterior=True, num_rejection_samples=2000)
+    assert (norm >= raw - 1e-5).all()      # acceptance <= 1 can only raise the normalised density
+    outside = y.copy()
+    outside[:, 0] = 1e3
+    assert np.isneginf(f.log_prob(X, outside)).all()
+
+
+def test_fit_catalogue_quantiles_and_nan_rows(fitted):
+    import pandas as pd
+    f, post, stats, _ = fitted
+    X = f._X_test[:20].copy()
+    X[3, 2] = np.nan
+    df = pd.DataFrame(X, columns=f.feature_names)
+    table = f.fit_catalogue(df, num_samples=300, seed=1)
+    for p in f.simple_fitted_parameter_names:
+        for q in (16, 50, 84):
+            assert f"{p}_{q}" in table.columns
+        v = table[[f"{p}_16", f"{p}_50", f"{p}_84"]].to_numpy()
+        assert np.isnan(v[3]).all()
+        ok = np.delete(v, 3, axis=0)
+        assert (ok[:, 0] <= ok[:, 1]).all() and (ok[:, 1] <= ok[:, 2]).all()
+
+
+def test_posterior_pickle_roundtrip(fitted):
+    f, post, stats, out = fitted
+    with open(out / "e2e_t_posterior.pkl", "rb") as fh:
+        p2 = pickle.load(fh)
+    p2.to("cuda:0")
+    X = f._X_test[:5]
+    a = post.sample_catalogue(torch.as_tensor(X), 50, seed=9).cpu().numpy()
+    b = p2.sample_catalogue(torch.as_tensor(X), 50, seed=9).cpu().numpy()
+    assert np.array_equal(a, b)
+
+
+def test_unsupported_requests_fail_loudly(fitted):
+    f, *_ = fitted
+    with pytest.raises(ValueError):
+        f.run_single_sbi(model_type="mdn")
+    with pytest.raises(ValueError):
+        f.run_single_sbi(backend="sbi")
+    with pytest.raises(ValueError):
+        f.sample_posterior(f._X_test[:2], sample_method="emcee")
+
+
+def test_autograd_estimator_matches_direct_loss_grad(fitted):
+    """nn.Module surface: mean(-log_prob).backward() == the direct uniform-weight HIP backward."""
+    f, post, _, _ = fitted
+    est = post.posteriors[0].posterior_estimator
+    th = torch.as_tensor(f._y_test[:100], dtype=torch.float32, device="cuda")
+    x = torch.as_tensor(f._X_test[:100], device="cuda")
+    est.zero_grad(set_to_none=True)
+    losses = est.loss(th, x)
+    (losses * torch.linspace(0.5, 1.5, 100, device="cuda")).mean().backward()
+    g_auto = est.flat.grad.clone()
+    _, g_ref = est.flow.loss_grad(est.flat.detach(), th, x, 1.0 / 100, weights=torch.linspace(0.5, 1.5, 100))
+    assert (g_auto - g_ref).abs().max() <= 1e-5 * g_ref.abs().max() + 1e-8
