@@ -1,0 +1,211 @@
+"""Pins for the CPU oracle that do not depend on any library (SURVEY.md 8c "what pins the build's
+results instead"): analytic / self-consistency known answers.  The upstream stack is not importable
+here and the reference ships no golden vectors for this path, so parity stays "unpinned" in the
+formal sense; these tests are what holds the oracle in place."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import flows as OF
+from oracle import philox
+from oracle import posterior as OP
+
+
+def _spec(kind, D, C, H=16, T=3, K=6, seed=0):
+    perms = OF.random_perms(D, T, seed) if kind == "maf" else None
+    return OF.FlowSpec(kind=kind, D=D, C=C, H=H, T=T, K=K, perms=perms)
+
+
+def _rand_params(spec, seed=1, jitter=0.5):
+    p = OF.init_params(spec, seed)
+    rng = np.random.default_rng(seed)
+    return torch.tensor(p + jitter * rng.normal(size=p.shape) * np.abs(p).mean())
+
+
+@pytest.mark.parametrize("kind,D,C", [("maf", 5, 10), ("maf", 2, 3), ("nsf", 8, 20), ("nsf", 5, 4), ("nsf", 2, 3)])
+def test_inverse_of_forward_is_identity_and_logdets_cancel(kind, D, C):
+    spec = _spec(kind, D, C)
+    p = _rand_params(spec)
+    g = torch.Generator().manual_seed(0)
+    th = torch.randn(17, D, generator=g, dtype=torch.float64) * 1.5
+    x = torch.randn(17, C, generator=g, dtype=torch.float64)
+    z, ld = OF.forward_transform(spec, p, th, x)
+    th2, ld2 = OF.inverse_transform(spec, p, z, x)
+    assert (th2 - th).abs().max() < 1e-10
+    assert (ld + ld2).abs().max() < 1e-10
+
+
+@pytest.mark.parametrize("kind,D,C", [("maf", 4, 3), ("nsf", 4, 3), ("nsf", 3, 2)])
+def test_logdet_equals_autograd_jacobian(kind, D, C):
+    spec = _spec(kind, D, C)
+    p = _rand_params(spec)
+    g = torch.Generator().manual_seed(1)
+    th = torch.randn(3, D, generator=g, dtype=torch.float64)
+    x = torch.randn(3, C, generator=g, dtype=torch.float64)
+    _, ld = OF.forward_transform(spec, p, th, x)
+    for i in range(3):
+        J = torch.autograd.functional.jacobian(
+            lambda t: OF.forward_transform(spec, p, t[None], x[i:i + 1])[0][0], th[i])
+        assert abs(torch.linalg.slogdet(J)[1].item() - ld[i].item()) < 1e-10
+
+
+def test_made_is_autoregressive_and_first_output_ignores_everything():
+    """d out_i / d in_j = 0 for j >= i; output degree 1 is connected to no hidden unit."""
+    D, C, H = 5, 3, 20
+    spec = OF.FlowSpec(kind="maf", D=D, C=C, H=H, T=1)
+    p = _rand_params(spec)
+    P = OF.views(spec, p)
+    masks = tuple(torch.tensor(m) for m in OF.made_masks(D, H))
+    u = torch.randn(1, D, dtype=torch.float64)
+    e = torch.randn(1, C, dtype=torch.float64)
+
+    def f(uu):
+        a, m = OF._made(spec, P, 0, uu[None], e, masks)
+        return torch.cat([a[0], m[0]])
+
+    J = torch.autograd.functional.jacobian(f, u[0])  # [2D, D]
+    for i in range(D):
+        for j in range(i, D):
+            assert J[i, j].abs() < 1e-14 and J[D + i, j].abs() < 1e-14
+    a0, m0 = OF._made(spec, P, 0, u, e, masks)
+    a1, m1 = OF._made(spec, P, 0, u + 3.0, e * -2.0, masks)
+    assert a0[0, 0] == a1[0, 0] == P["t0.bf"][0] and m0[0, 0] == m1[0, 0] == P["t0.bf"][1]
+    deg_in, deg_h, deg_out = OF.made_degrees(D, H)
+    assert deg_h.min() == 1 and deg_h.max() == D - 1 and list(deg_out[:4]) == [1, 1, 2, 2]
+
+
+def test_maf_hand_computed_micro_case():
+    """D=2, H=2, one transform, integer weights: log_prob by hand."""
+    spec = OF.FlowSpec(kind="maf", D=2, C=1, H=2, T=1, NB=1)
+    lay = {n: (s, o) for n, s, o in OF.param_layout(spec)}
+    p = torch.zeros(OF.num_params(spec), dtype=torch.float64)
+
+    def setp(name, val):
+        s, o = lay[name]
+        p[o:o + int(np.prod(s))] = torch.tensor(val, dtype=torch.float64).reshape(-1)
+
+    setp("t0.W0", [[1.0, 5.0], [2.0, 7.0]])  # column 2 is masked (degree 2 feeds nothing)
+    setp("t0.b0", [0.0, 0.0]); setp("t0.Wc", [[1.0], [0.0]]); setp("t0.bc", [0.0, 1.0])
+    setp("t0.W1", [[1.0, 0.0], [0.0, 1.0]]); setp("t0.b1", [0.0, 0.0])
+    setp("t0.Wf", [[9.0, 9.0], [9.0, 9.0], [1.0, 0.0], [0.0, 2.0]])  # rows 0,1 (dim 1) fully masked
+    setp("t0.bf", [0.5, -1.0, 0.0, 0.25])
+    th = torch.tensor([[0.3, -0.7]], dtype=torch.float64)
+    x = torch.tensor([[2.0]], dtype=torch.float64)
+    h0 = np.array([1 * 0.3 + 2.0, 2 * 0.3 + 1.0])
+    h1 = np.tanh(h0)
+    a = [0.5, 1.0 * h1[0]]
+    m = [-1.0, 2.0 * h1[1] + 0.25]
+    s = [math.log1p(math.exp(v)) + 1e-3 for v in a]
+    z = [s[0] * 0.3 + m[0], s[1] * -0.7 + m[1]]
+    expect = -0.5 * (z[0] ** 2 + z[1] ** 2) - math.log(2 * math.pi) + math.log(s[0]) + math.log(s[1])
+    got = OF.log_prob(spec, p, th, x).item()
+    assert abs(got - expect) < 1e-12
+
+
+def test_spline_identity_at_init_tails_monotone_and_c1():
+    spec = OF.FlowSpec(kind="nsf", D=2, C=1, H=8, T=1, K=5)
+    # all-zero logits + the padded derivative constant everywhere -> the spline is the identity
+    q = torch.zeros(1, 1, 3 * 5 - 1, dtype=torch.float64)
+    q[..., 10:] = math.log(math.exp(1 - 1e-3) - 1)
+    v = torch.linspace(-2.9, 2.9, 59, dtype=torch.float64)[:, None]
+    out, lad = OF.rq_spline(spec, v, q.expand(59, 1, -1), inverse=False)
+    assert (out - v).abs().max() < 1e-12 and lad.abs().max() < 1e-12
+    # outside the tail bound: identity, logdet 0, for any parameters
+    g = torch.Generator().manual_seed(3)
+    qr = torch.randn(4, 1, 14, generator=g, dtype=torch.float64) * 3
+    vo = torch.tensor([[-3.5], [3.0001], [10.0], [-3.0001]], dtype=torch.float64)
+    out, lad = OF.rq_spline(spec, vo, qr, inverse=False)
+    assert torch.equal(out, vo) and torch.equal(lad, torch.zeros_like(lad))
+    # monotone, C1 across knots, logdet = log derivative, inverse exact
+    qq = qr[:1].expand(2001, 1, 14)
+    vv = torch.linspace(-3, 3, 2001, dtype=torch.float64)[:, None].clone().requires_grad_(True)
+    out, lad = OF.rq_spline(spec, vv, qq, inverse=False)
+    assert (out[1:] > out[:-1]).all()
+    (d,) = torch.autograd.grad(out.sum(), vv)
+    assert (torch.log(d) - lad).abs().max() < 1e-9
+    # C1: the derivative just left and just right of every interior knot agrees, and equals 1 at +-B
+    cw, _ = OF._knots(spec, qr[0, 0, :5] / math.sqrt(spec.H), spec.min_bin_width)
+    kn = cw[1:-1]
+    both = torch.cat([kn - 1e-7, kn + 1e-7, torch.tensor([-3 + 1e-9, 3 - 1e-9], dtype=torch.float64)])[:, None]
+    both = both.clone().requires_grad_(True)
+    o2, _ = OF.rq_spline(spec, both, qr[:1].expand(len(both), 1, 14), inverse=False)
+    (d2,) = torch.autograd.grad(o2.sum(), both)
+    assert (d2[:4] - d2[4:8]).abs().max() < 1e-4
+    assert (d2[8:] - 1).abs().max() < 1e-6
+    assert abs(out[0].item() + 3) < 1e-12 and abs(out[-1].item() - 3) < 1e-12
+    back, lad2 = OF.rq_spline(spec, out.detach(), qq, inverse=True)
+    assert (back - vv.detach()).abs().max() < 1e-9 and (lad2 + lad.detach()).abs().max() < 1e-9
+
+
+def test_lu_identity_init_and_logdet():
+    spec = OF.FlowSpec(kind="nsf", D=4, C=2, H=8, T=1, K=4)
+    p = torch.tensor(OF.init_params(spec, 0))
+    P = OF.views(spec, p)
+    L, U, diag = OF._lu_mats(spec, P, 0)
+    assert torch.allclose(L, torch.eye(4, dtype=torch.float64)) and (diag - 1).abs().max() < 1e-12
+    assert torch.allclose(U, torch.eye(4, dtype=torch.float64))
+    # index order: tril_indices / triu_indices row-major
+    p2 = p.clone()
+    lay = {n: o for n, s, o in OF.param_layout(spec)}
+    p2[lay["t0.lu.lower"]:lay["t0.lu.lower"] + 6] = torch.arange(1, 7, dtype=torch.float64)
+    p2[lay["t0.lu.upper"]:lay["t0.lu.upper"] + 6] = -torch.arange(1, 7, dtype=torch.float64)
+    L, U, _ = OF._lu_mats(spec, OF.views(spec, p2), 0)
+    assert L[1, 0] == 1 and L[2, 0] == 2 and L[2, 1] == 3 and L[3, 2] == 6
+    assert U[0, 1] == -1 and U[0, 3] == -3 and U[1, 2] == -4 and U[2, 3] == -6
+
+
+def test_density_integrates_to_one_2d():
+    spec = _spec("nsf", 2, 2, H=8, T=2, K=4)
+    p = _rand_params(spec, jitter=0.3)
+    x = torch.tensor([[0.3, -0.4]], dtype=torch.float64)
+    g = torch.linspace(-9, 9, 721, dtype=torch.float64)
+    tt = torch.stack(torch.meshgrid(g, g, indexing="ij"), -1).reshape(-1, 2)
+    lp = OF.log_prob(spec, p, tt, x.expand(len(tt), -1))
+    integral = torch.exp(lp).sum().item() * (g[1] - g[0]).item() ** 2
+    assert abs(integral - 1.0) < 2e-3
+
+
+def test_standardize_stats_and_param_counts():
+    rng = np.random.default_rng(0)
+    th, x = rng.normal(size=(100, 3)) * [1, 10, 0], rng.normal(size=(100, 4))
+    st = OF.standardize_stats(th, x)
+    assert st["theta_std"][2] == pytest.approx(1e-14) and abs(st["theta_std"][1] - th[:, 1].std(ddof=1)) < 1e-5
+    assert OF.num_params(OF.FlowSpec(kind="maf", D=5, C=10, H=50, T=5)) == 32300
+    assert OF.num_params(OF.FlowSpec(kind="nsf", D=8, C=20, H=50, T=5, K=8)) == 91570
+
+
+def test_philox_known_answers_random123():
+    r = philox.philox4x32_10([0], [0], [0], [0], 0, 0)
+    assert [int(a[0]) for a in r] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    r = philox.philox4x32_10([0xffffffff], [0xffffffff], [0xffffffff], [0xffffffff], 0xffffffff, 0xffffffff)
+    assert [int(a[0]) for a in r] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    r = philox.philox4x32_10([0x243f6a88], [0x85a308d3], [0x13198a2e], [0x03707344], 0xa4093822, 0x299f31d0)
+    assert [int(a[0]) for a in r] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    z = philox.normal(5, np.arange(100000, dtype=np.uint64), 0, 3)
+    assert np.abs(z.mean(0)).max() < 0.02 and np.abs(z.std(0) - 1).max() < 0.02
+
+
+def test_rejection_sampler_and_ensemble_semantics():
+    spec = _spec("maf", 3, 2, H=8, T=2)
+    p = _rand_params(spec, jitter=0.2).float()
+    x = np.random.default_rng(0).normal(size=(4, 2)).astype(np.float32)
+    free, nd = OP.sample(spec, p, x, 300, 11)
+    assert (nd == 300).all()
+    lo, hi = np.quantile(free.reshape(-1, 3), 0.1, 0), np.quantile(free.reshape(-1, 3), 0.9, 0)
+    s, nd = OP.sample(spec, p, x, 300, 11, lo, hi)
+    assert OP.in_box(s.astype(np.float32), lo.astype(np.float32), hi.astype(np.float32)).all() and (nd > 300).all()
+    keep = OP.in_box(free.astype(np.float32), lo.astype(np.float32), hi.astype(np.float32))
+    assert np.array_equal(s[keep], free[keep])           # accepted first attempts are untouched
+    acc = OP.acceptance(spec, p, x, 3000, 5, lo, hi)
+    assert np.abs(acc - 300.0 / nd).max() < 0.08
+    lp = OP.posterior_log_prob(spec, p, free[0, :5], np.repeat(x[:1], 5, 0), lo, hi)
+    assert np.isneginf(lp[~keep[0, :5]]).all() and np.isfinite(lp[keep[0, :5]]).all()
+    out = OP.ensemble_sample([spec, spec], [p, p * 1.01], [0.25, 0.75], x, 200, 3, lo, hi)
+    assert np.isfinite(out).all()
+    cnt = OP.ensemble_counts([0.25, 0.75], 200, 4, 3)
+    assert (cnt.sum(1) == 200).all() and abs(cnt[:, 1].mean() / 200 - 0.75) < 0.1
+    e = OP.ensemble_log_prob([spec, spec], [p, p], [0.3, 0.7], free[0, :5], np.repeat(x[:1], 5, 0))
+    one = OP.posterior_log_prob(spec, p, free[0, :5], np.repeat(x[:1], 5, 0))
+    assert np.abs(e - one).max() < 1e-9
