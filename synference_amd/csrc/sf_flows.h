@@ -233,6 +233,146 @@ struct SfSpline {
   }
 };
 
+// Forward + backward of one spline evaluation (density direction), hand-derived; the numpy twin
+// is tests/spline_bwd_model.py (checked against torch.autograd on the oracle).
+//   L = Go*out + Gl*lad  ->  dv = dL/dv, dq[slot] = dL/d(raw parameter in that slot)
+template <int PT>
+struct SfSplineBwd {
+  static constexpr int KM = SfSpline<PT>::KM;
+
+  // one parameter family (widths or heights): softmax -> knots, bin select, and the pieces needed
+  // to back-propagate (p_k kept in e[], idx)
+  template <int NS, int OFF, bool BY_VALUE>
+  static __device__ __forceinline__ void family_fwd(const SfDev& m, const f32x16 (&q)[PT][NS], int ns,
+                                                    float min_size, float v, int& idx, float& left,
+                                                    float& size, float (&e)[KM]) {
+    const int K = m.K;
+    const float B = m.tail_bound;
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+      if (k < K) {
+        e[k] = SfSpline<PT>::template Q<NS>(q, ns, OFF + k) * m.inv_sqrt_h;
+        mx = fmaxf(mx, e[k]);
+      }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+      if (k < K) {
+        e[k] = expf(e[k] - mx);
+        sum += e[k];
+      }
+    const float scale = (1.0f - min_size * (float)K);
+    float cs = 0.f, c_lo = -B;
+    left = -B;
+    size = 1.f;
+    if (BY_VALUE) idx = 0;
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+      if (k < K) {
+        e[k] = e[k] / sum;  // p_k
+        cs += min_size + scale * e[k];
+        const float c_hi = (k == K - 1) ? B : (2.0f * B * cs - B);
+        const bool sel = BY_VALUE ? (v >= c_lo) : (k == idx);
+        if (sel) {
+          left = c_lo;
+          size = c_hi - c_lo;
+          if (BY_VALUE) idx = k;
+        }
+        c_lo = c_hi;
+      }
+  }
+
+  // gradient wrt the raw logits of a family given dL/d(left knot) and dL/d(bin size)
+  template <int NS, int OFF>
+  static __device__ __forceinline__ void family_bwd(const SfDev& m, const float (&p)[KM], int idx, float L_left,
+                                                    float L_size, float min_size, f32x16 (&dq)[PT][NS], int ns) {
+    const int K = m.K;
+    const float Lc0 = L_left - L_size, Lc1 = L_size;
+    const float f = 2.0f * m.tail_bound * (1.0f - min_size * (float)K);
+    const bool c1_interior = idx <= K - 2;
+    float S = 0.f;
+#pragma unroll
+    for (int i = 0; i < KM; ++i)
+      if (i < K) {
+        const float dp = f * ((i < idx ? Lc0 : 0.f) + ((c1_interior && i <= idx) ? Lc1 : 0.f));
+        S += p[i] * dp;
+      }
+#pragma unroll
+    for (int i = 0; i < KM; ++i)
+      if (i < K) {
+        const float dp = f * ((i < idx ? Lc0 : 0.f) + ((c1_interior && i <= idx) ? Lc1 : 0.f));
+        dq[(OFF + i) >> 4][ns][(OFF + i) & 15] = p[i] * (dp - S) * m.inv_sqrt_h;
+      }
+  }
+
+  template <int NS>
+  static __device__ __forceinline__ void eval(const SfDev& m, const f32x16 (&q)[PT][NS], int ns, float v,
+                                              float Go, float Gl, float& out, float& lad, float& dv,
+                                              f32x16 (&dq)[PT][NS]) {
+    const int K = m.K;
+    const float B = m.tail_bound;
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[pt][ns][r] = 0.f;
+    const bool inside = (v >= -B) && (v <= B);
+    const float vc = fminf(fmaxf(v, -B), B);
+    int idx = 0;
+    float x_k, w_k, y_k, h_k;
+    float pw[KM], ph[KM];
+    family_fwd<NS, 0, true>(m, q, ns, m.min_w, vc, idx, x_k, w_k, pw);
+    family_fwd<NS, KM, false>(m, q, ns, m.min_h, vc, idx, y_k, h_k, ph);
+    const float d_edge = m.min_d + sf_softplus(m.deriv_const);
+    float d_k = d_edge, d_k1 = d_edge;
+#pragma unroll
+    for (int j = 1; j < KM; ++j)
+      if (j < K) {
+        const float dj = m.min_d + sf_softplus(SfSpline<PT>::template Q<NS>(q, ns, 2 * KM + j - 1));
+        d_k = (j == idx) ? dj : d_k;
+        d_k1 = (j == idx + 1) ? dj : d_k1;
+      }
+    const float s = h_k / w_k;
+    const float xi = (vc - x_k) / w_k;
+    const float om = xi * (1.f - xi);
+    const float A = d_k + d_k1 - 2.f * s;
+    const float N = s * xi * xi + d_k * om;
+    const float den = s + A * om;
+    const float Mq = d_k1 * xi * xi + 2.f * s * om + d_k * (1.f - xi) * (1.f - xi);
+    const float dnum = s * s * Mq;
+    const float o_in = y_k + h_k * N / den;
+    const float l_in = logf(dnum) - 2.f * logf(den);
+    out = inside ? o_in : v;
+    lad = inside ? l_in : 0.f;
+    // partials wrt z in {s, d_k, d_k1, xi}
+    const float go = inside ? Go : 0.f, gl = inside ? Gl : 0.f;
+    const float inv_den = 1.f / den, inv_dnum = 1.f / dnum;
+    const float cN = go * h_k * inv_den;             // coefficient of N_z
+    const float cD = -go * h_k * N * inv_den * inv_den - 2.f * gl * inv_den;  // coefficient of D_z
+    const float cQ = gl * inv_dnum;                  // coefficient of Q_z
+    const float L_s = cN * (xi * xi) + cD * (1.f - 2.f * om) + cQ * (2.f * s * Mq + 2.f * s * s * om);
+    const float L_dk = cN * om + cD * om + cQ * (s * s * (1.f - xi) * (1.f - xi));
+    const float L_dk1 = cD * om + cQ * (s * s * xi * xi);
+    const float L_xi = cN * (2.f * s * xi + d_k * (1.f - 2.f * xi)) + cD * (A * (1.f - 2.f * xi)) +
+                       cQ * (s * s * (2.f * d_k1 * xi + 2.f * s * (1.f - 2.f * xi) - 2.f * d_k * (1.f - xi)));
+    const float inv_w = 1.f / w_k;
+    const float L_y = go;
+    const float L_h = go * N * inv_den + L_s * inv_w;
+    const float L_w = -(L_s * s + L_xi * xi) * inv_w;
+    const float L_x = -L_xi * inv_w;
+    dv = inside ? L_xi * inv_w : Go;
+    family_bwd<NS, 0>(m, pw, idx, L_x, L_w, m.min_w, dq, ns);
+    family_bwd<NS, KM>(m, ph, idx, L_y, L_h, m.min_h, dq, ns);
+#pragma unroll
+    for (int j = 1; j < KM; ++j)
+      if (j < K) {
+        const float raw = SfSpline<PT>::template Q<NS>(q, ns, 2 * KM + j - 1);
+        const float g = ((j == idx) ? L_dk : 0.f) + ((j == idx + 1) ? L_dk1 : 0.f);
+        dq[(2 * KM + j - 1) >> 4][ns][(2 * KM + j - 1) & 15] = g * sf_sigmoid(raw);
+      }
+  }
+};
+
 template <int HT, int PT, int NS>
 struct NsfOps {
   // ResidualNet conditioner -> hidden tiles
@@ -275,13 +415,11 @@ struct NsfOps {
     }
   }
 
-  // coupling: spline on the transform dims of parity t&1, conditioner on the others
-  static __device__ __forceinline__ void coupling(const SfDev& m, const float* __restrict__ tp, int t,
-                                                  float (&u)[NS][SF_DMAX], const float* const (&xr)[NS],
-                                                  float (&logdet)[NS], bool inverse, int lane) {
+  // spline head + RQ spline on the transform dims of parity t&1, given the conditioner state
+  static __device__ __forceinline__ void spline_apply(const SfDev& m, const float* __restrict__ tp, int t,
+                                                      const f32x16 (&hid)[HT][NS], float (&u)[NS][SF_DMAX],
+                                                      float (&logdet)[NS], bool inverse, int lane) {
     const int h = lane >> 5;
-    f32x16 hid[HT][NS];
-    resnet(m, tp, u, xr, hid, lane);
     const int start = t & 1;
     const int d_tr = (m.D - start + 1) / 2;
     for (int jp = 0; jp * 2 < d_tr; ++jp) {
@@ -310,6 +448,15 @@ struct NsfOps {
         logdet[ns] += lad + sf_xhalf(lad);
       }
     }
+  }
+
+  // coupling: conditioner on the identity dims, spline on the others
+  static __device__ __forceinline__ void coupling(const SfDev& m, const float* __restrict__ tp, int t,
+                                                  float (&u)[NS][SF_DMAX], const float* const (&xr)[NS],
+                                                  float (&logdet)[NS], bool inverse, int lane) {
+    f32x16 hid[HT][NS];
+    resnet(m, tp, u, xr, hid, lane);
+    spline_apply(m, tp, t, hid, u, logdet, inverse, lane);
   }
 
   // LULinear:  y = L (U u) + b ;  diag(U) = softplus(udiag) + eps

@@ -312,6 +312,26 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
         for (int i = 0; i < D; ++i) E.push(D > 1 ? (int32_t)(lDi + i) : -1, -1);
         for (int i = 0; i < D; ++i) E.push(D > 1 ? (int32_t)(lBi + i) : -1, -1);
       }
+      // ---- transposed operands for the data-gradient pass ("o" = forward input, "i" = forward output)
+      {
+        const int64_t tbT = ET.pad_to(64);
+        if (t == 1) v.tT_stride = (int)tbT;
+        for (int jp = 0; jp < v.JP; ++jp) {
+          std::vector<int> qrow(orow.begin() + jp * v.PT * 32, orow.begin() + (jp + 1) * v.PT * 32);
+          o = (int)(ET.linear(HT, v.PT * 4, hrow_out, qrow, lWout, 1, H, nullptr) - tbT);
+          if (t == 0 && jp == 0) v.oT_wout = o;
+        }
+        for (int k = 0; k < NB; ++k) {
+          o = (int)(ET.linear(HT, v.nGh, hrow_out, hrow_in, lW2[k], 1, H, nullptr) - tbT);
+          if (t == 0) v.oT_w2[k] = o;
+          o = (int)(ET.linear(HT, v.nGh, hrow_out, hrow_in, lW1[k], 1, H, nullptr) - tbT);
+          if (t == 0) v.oT_w1[k] = o;
+        }
+        std::vector<int> urow32(32, -1);
+        for (int j = 0; j < d_id; ++j) urow32[idn[j]] = j;
+        o = (int)(ET.linear(1, v.nGh, urow32, hrow_in, lWin, 1, in_dim, nullptr) - tbT);
+        if (t == 0) v.oT_winu = o;
+      }
     }
   }
   E.pad_to(64);

@@ -1,0 +1,15 @@
+// sf_train_args.h -- argument block of the training kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct SfTrainArgs {
+  const float* theta;
+  const float* x;
+  long B;
+  float w;           // gradient weight of every sample (grad_scale)
+  const float* wts;  // optional per-sample weights [B] (multiplied by w)
+  float* loss;       // [B] or null
+  float* gimg;       // gradient image
+  float4* act;       // activation stash
+  long act_per_wave; // float4 per wave
+};

@@ -1,0 +1,50 @@
+// sf_train_inst.hip -- one translation unit per SF_HT: instantiates the training kernels.
+#include "sf_train_kernels.h"
+
+#ifndef SF_HT
+#error "compile with -DSF_HT=1..4"
+#endif
+#define SF_CAT_(a, b) a##b
+#define SF_CAT(a, b) SF_CAT_(a, b)
+
+template <class K>
+static hipError_t set_shmem(K kernel, size_t bytes) {
+  return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+hipError_t SF_CAT(sf_launch_maf_train_h, SF_HT)(const SfDev& m, const SfTrainArgs& a, hipStream_t st) {
+  const long waves = (a.B + 31) / 32;
+  const long grid = (waves + 3) / 4;
+  const size_t shmem = (size_t)4 * (2 * SF_HT) * SF_TL * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = set_shmem(k_maf_train<SF_HT>, shmem);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  hipLaunchKernelGGL((k_maf_train<SF_HT>), dim3((unsigned)grid), dim3(256), shmem, st, m, a);
+  return hipGetLastError();
+}
+
+template <int PT>
+static hipError_t launch_nsf(const SfDev& m, const SfTrainArgs& a, hipStream_t st) {
+  const long waves = (a.B + 31) / 32;
+  const long grid = (waves + 3) / 4;
+  const size_t shmem = (size_t)4 * SfNsfLds<SF_HT, PT>::tiles * SF_TL * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = set_shmem(k_nsf_train<SF_HT, PT>, shmem);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  hipLaunchKernelGGL((k_nsf_train<SF_HT, PT>), dim3((unsigned)grid), dim3(256), shmem, st, m, a);
+  return hipGetLastError();
+}
+
+hipError_t SF_CAT(sf_launch_nsf_train_h, SF_HT)(const SfDev& m, const SfTrainArgs& a, hipStream_t st) {
+  switch (m.PT) {
+    case 2: return launch_nsf<2>(m, a, st);
+    case 3: return launch_nsf<3>(m, a, st);
+  }
+  return hipErrorInvalidValue;
+}

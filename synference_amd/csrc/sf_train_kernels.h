@@ -1,0 +1,591 @@
+// sf_train_kernels.h -- forward+backward kernels of -log_prob (see the header comment in sf_train.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "sf_flows.h"
+#include "sf_internal.h"
+#include "sf_train_args.h"
+
+#define SF_TL 1056  // floats per transposed tile in LDS: 32 rows x 33
+
+
+template <bool RELU = false>
+__device__ __forceinline__ void sf_tile_to_lds(float* __restrict__ dst, const f32x16& t, int c, int h) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dst[sf_row(r, h) * 33 + c] = RELU ? fmaxf(t[r], 0.f) : t[r];
+}
+__device__ __forceinline__ void sf_stash_store(float4* __restrict__ base, int tile, const f32x16& t, int lane) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    base[(tile * 4 + q) * 64 + lane] = make_float4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
+}
+__device__ __forceinline__ void sf_stash_load(const float4* __restrict__ base, int tile, f32x16& t, int lane) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 v = base[(tile * 4 + q) * 64 + lane];
+    t[4 * q] = v.x; t[4 * q + 1] = v.y; t[4 * q + 2] = v.z; t[4 * q + 3] = v.w;
+  }
+}
+
+// gradient of one linear layer's weights (and optionally bias):
+//   gw block [mt][kg][j][lane] += sum_s in[i][s] * delta[o][s]
+// lds: (IT + OT) transposed tiles; in tiles first.
+template <int OT, int IT, bool RELU_IN = false>
+__device__ __forceinline__ void sf_grad_w(float* __restrict__ lds, const f32x16 (&delta)[OT][1],
+                                          const f32x16 (&in)[IT][1], float* __restrict__ gw,
+                                          float* __restrict__ gb, int nGtot, int kg0, int ng, int lane) {
+  const int c = lane & 31, h = lane >> 5;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int kt = 0; kt < IT; ++kt) sf_tile_to_lds<RELU_IN>(lds + kt * SF_TL, in[kt][0], c, h);
+#pragma unroll
+  for (int mt = 0; mt < OT; ++mt) sf_tile_to_lds<false>(lds + (IT + mt) * SF_TL, delta[mt][0], c, h);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int rd = c * 33 + h;
+#pragma unroll
+  for (int mt = 0; mt < OT; ++mt) {
+    float bsum = 0.f;
+    const float* ld = lds + (IT + mt) * SF_TL + rd;
+#pragma unroll
+    for (int kt = 0; kt < IT; ++kt) {
+      if (kt * 4 < ng) {
+        const float* li = lds + kt * SF_TL + rd;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const float a = li[2 * k];
+          const float b = ld[2 * k];
+          if (kt == 0) bsum += b;
+          acc = SF_MFMA(a, b, acc);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (kt * 4 + g < ng) {
+            float* dst = gw + (((size_t)mt * nGtot + kg0 + kt * 4 + g) * 4) * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(dst + j * 64, acc[4 * g + j]);
+          }
+      }
+    }
+    if (gb) {
+      bsum += sf_xhalf(bsum);
+      if (h == 0) atomicAdd(gb + mt * 32 + c, bsum);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int HT>
+__global__ __launch_bounds__(256) void k_maf_train(SfDev m, SfTrainArgs a) {
+  extern __shared__ float lds_all[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const long wid = (long)blockIdx.x * 4 + wave;
+  const long base = wid * 32;
+  if (base >= a.B) return;
+  float* lds = lds_all + wave * (2 * HT) * SF_TL;
+  float4* stash = a.act + wid * a.act_per_wave;
+  const int TPT = (m.NB + 1) * HT + 1;  // stash tiles per transform: u, h0, a_1..a_NB
+
+  const long row = base + c;
+  const bool valid = row < a.B;
+  const long ii = valid ? row : a.B - 1;
+  const float* xr[1] = {a.x + ii * m.C};
+  float u[1][SF_DMAX];
+  float logdet[1] = {m.logdet0};
+#pragma unroll
+  for (int p = 0; p < SF_DMAX; ++p) {
+    u[0][p] = 0.f;
+    if (p < m.D) {
+      const int td = (int)m.cst[m.c_tdim + p];
+      u[0][p] = a.theta[ii * m.D + td] * m.cst[m.c_pscale + p] + m.cst[m.c_pshift + p];
+    }
+  }
+  using Ops = MafOps<HT, 1>;
+
+  // ------------------------------------------------------------------ forward (with stash)
+  for (int t = 0; t < m.T; ++t) {
+    const float* tp = m.packed + (size_t)t * m.t_stride;
+    {
+      f32x16 ut;
+#pragma unroll
+      for (int p = 0; p < SF_DMAX; ++p) ut[p] = u[0][p];
+      sf_stash_store(stash, t * TPT, ut, lane);
+    }
+    f32x16 act[HT][1];
+    sf_init_bias<HT, 1>(act, tp + m.o_b0, h);
+    {
+      f32x16 ut[1][1];
+      sf_build_u_tile<1>(ut, u, h);
+      sf_mm_acc<HT, 1, 1, false>(act, ut, tp + m.o_w0, m.nGu, 0, m.nGu, lane);
+    }
+    sf_ctx_mm<HT, 1>(act, xr, m, tp + m.o_wc, lane);
+#pragma unroll
+    for (int mt = 0; mt < HT; ++mt) sf_stash_store(stash, t * TPT + 1 + mt, act[mt][0], lane);
+#pragma unroll
+    for (int k = 0; k < SF_NBMAX; ++k) {
+      if (k < m.NB) {
+        f32x16 b[HT][1];
+        sf_init_bias<HT, 1>(b, tp + m.o_bk[k], h);
+        sf_mm_acc<HT, 1, HT, false>(b, act, tp + m.o_wk[k], m.nGh, 0, m.nGh, lane);
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) act[mt][0][r] = sf_tanh(b[mt][0][r]);
+          sf_stash_store(stash, t * TPT + 1 + (k + 1) * HT + mt, act[mt][0], lane);
+        }
+      }
+    }
+    f32x16 fin[1][1];
+    sf_init_bias<1, 1>(fin, tp + m.o_bf, h);
+    sf_mm_acc<1, 1, HT, false>(fin, act, tp + m.o_wf, m.nGh, 0, m.nGh, lane);
+    float ld = 0.f;
+#pragma unroll
+    for (int p = 0; p < SF_DMAX; ++p) {
+      if (p < m.D) {
+        const float s = Ops::scale(m, fin[0][0][2 * (p >> 1)]);
+        const float val = s * u[0][p] + fin[0][0][2 * (p >> 1) + 1];
+        const bool mine = (h == (p & 1));
+        const float oth = sf_xhalf(val);
+        u[0][p] = mine ? val : oth;
+        ld += mine ? logf(s) : 0.f;
+      }
+    }
+    logdet[0] += ld + sf_xhalf(ld);
+  }
+  float G[SF_DMAX];  // dL/d(output of the current transform), replicated in both halves
+  const float w = valid ? (a.wts ? a.w * a.wts[row] : a.w) : 0.f;
+  {
+    float ss = 0.f;
+#pragma unroll
+    for (int p = 0; p < SF_DMAX; ++p) {
+      G[p] = 0.f;
+      if (p < m.D) {
+        ss += u[0][p] * u[0][p];
+        G[p] = w * u[0][p];
+      }
+    }
+    if (a.loss && valid && h == 0)
+      a.loss[row] = 0.5f * ss + 0.5f * (float)m.D * 1.8378770664093453f - logdet[0];
+  }
+
+  // ------------------------------------------------------------------ backward
+  for (int t = m.T - 1; t >= 0; --t) {
+    const float* tp = m.packed + (size_t)t * m.t_stride;
+    const float* tpT = m.packedT + (size_t)t * m.tT_stride;
+    float* gp = a.gimg + (size_t)t * m.t_stride;
+    float uin[1][SF_DMAX];
+    {
+      f32x16 ut;
+      sf_stash_load(stash, t * TPT, ut, lane);
+#pragma unroll
+      for (int p = 0; p < SF_DMAX; ++p) uin[0][p] = ut[p];
+    }
+    f32x16 ak[HT][1];  // activation feeding the layer whose gradient is being formed
+#pragma unroll
+    for (int mt = 0; mt < HT; ++mt) sf_stash_load(stash, t * TPT + 1 + m.NB * HT + mt, ak[mt][0], lane);
+    // recompute the head
+    f32x16 fin[1][1];
+    sf_init_bias<1, 1>(fin, tp + m.o_bf, h);
+    sf_mm_acc<1, 1, HT, false>(fin, ak, tp + m.o_wf, m.nGh, 0, m.nGh, lane);
+    f32x16 dfin[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dfin[0][0][r] = 0.f;
+    float Gd[SF_DMAX];
+#pragma unroll
+    for (int p = 0; p < SF_DMAX; ++p) {
+      Gd[p] = 0.f;
+      if (p < m.D) {
+        const float av = fin[0][0][2 * (p >> 1)];
+        const float s = Ops::scale(m, av);
+        const float dsda = (m.scale_fn == 0) ? sf_sigmoid(av)
+                                             : sf_sigmoid(av + 2.0f) * (1.0f - sf_sigmoid(av + 2.0f));
+        const float ds = G[p] * uin[0][p] - w / s;
+        const bool mine = (h == (p & 1));
+        dfin[0][0][2 * (p >> 1)] = mine ? ds * dsda : dfin[0][0][2 * (p >> 1)];
+        dfin[0][0][2 * (p >> 1) + 1] = mine ? G[p] : dfin[0][0][2 * (p >> 1) + 1];
+        const float gd = G[p] * s;
+        const float oth = sf_xhalf(gd);
+        Gd[p] = mine ? gd : oth;
+      }
+    }
+    // head: dWf, dbf ; delta_h = Wf^T dfin
+    sf_grad_w<1, HT>(lds, dfin, ak, gp + m.o_wf, gp + m.o_bf, m.nGh, 0, m.nGh, lane);
+    f32x16 dh[HT][1];
+#pragma unroll
+    for (int mt = 0; mt < HT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dh[mt][0][r] = 0.f;
+    sf_mm_acc<HT, 1, 1, false>(dh, dfin, tpT + m.oT_wf, m.nGf, 0, m.nGf, lane);
+#pragma unroll
+    for (int kk = 0; kk < SF_NBMAX; ++kk) {
+      const int k = SF_NBMAX - 1 - kk;
+      if (k < m.NB) {
+        f32x16 dpre[HT][1];
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dpre[mt][0][r] = dh[mt][0][r] * (1.0f - ak[mt][0][r] * ak[mt][0][r]);
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) sf_stash_load(stash, t * TPT + 1 + k * HT + mt, ak[mt][0], lane);
+        sf_grad_w<HT, HT>(lds, dpre, ak, gp + m.o_wk[k], gp + m.o_bk[k], m.nGh, 0, m.nGh, lane);
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dh[mt][0][r] = 0.f;
+        sf_mm_acc<HT, 1, HT, false>(dh, dpre, tpT + m.oT_wk[k], m.nGh, 0, m.nGh, lane);
+      }
+    }
+    // initial layer: dW0 (u tile), dWc (context tiles), d(b0+bc)
+    {
+      f32x16 ut[1][1];
+      sf_build_u_tile<1>(ut, uin, h);
+      sf_grad_w<HT, 1>(lds, dh, ut, gp + m.o_w0, gp + m.o_b0, m.nGu, 0, m.nGu, lane);
+    }
+    for (int kt = 0; kt * 4 < m.nGc; ++kt) {
+      f32x16 ct[1][1];
+      sf_build_ctx_tile<1>(ct, xr, m, kt, h);
+      sf_grad_w<HT, 1>(lds, dh, ct, gp + m.o_wc, nullptr, m.nGc, kt * 4, min(4, m.nGc - kt * 4), lane);
+    }
+    // delta_u = W0^T delta_h0
+    f32x16 du[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) du[0][0][r] = 0.f;
+    sf_mm_acc<1, 1, HT, false>(du, dh, tpT + m.oT_w0, m.nGh, 0, m.nGh, lane);
+#pragma unroll
+    for (int p = 0; p < SF_DMAX; ++p) {
+      if (p < m.D) {
+        const float v = du[0][0][(p & 3) + 4 * (p >> 3)];
+        const float oth = sf_xhalf(v);
+        G[p] = Gd[p] + ((h == ((p >> 2) & 1)) ? v : oth);
+      }
+    }
+  }
+}
+
+
+// =============================================================================================
+// NSF forward + backward
+// =============================================================================================
+// sum over the 32 samples of one row half (both halves hold identical values)
+__device__ __forceinline__ float sf_half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int HT, int PT>
+struct SfNsfLds {  // transposed tiles needed at once by sf_grad_w
+  static constexpr int tiles = (2 * HT > HT + PT) ? 2 * HT : HT + PT;
+};
+
+template <int HT, int PT>
+__global__ __launch_bounds__(256) void k_nsf_train(SfDev m, SfTrainArgs a) {
+  extern __shared__ float lds_all[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const long wid = (long)blockIdx.x * 4 + wave;
+  const long base = wid * 32;
+  if (base >= a.B) return;
+  float* lds = lds_all + wave * SfNsfLds<HT, PT>::tiles * SF_TL;
+  float4* stash = a.act + wid * a.act_per_wave;
+  // stash tiles per transform: [0] u_in, [1..HT] h_0, per block k: t1, t2, h_{k+1} (HT each), last: u'
+  const int TPT = 2 + (3 * m.NB + 1) * HT;
+  using Ops = NsfOps<HT, PT, 1>;
+
+  const long row = base + c;
+  const bool valid = row < a.B;
+  const long ii = valid ? row : a.B - 1;
+  const float* xr[1] = {a.x + ii * m.C};
+  float u[1][SF_DMAX];
+  float logdet[1] = {m.logdet0};
+#pragma unroll
+  for (int p = 0; p < SF_DMAX; ++p) {
+    u[0][p] = 0.f;
+    if (p < m.D) u[0][p] = a.theta[ii * m.D + p] * m.cst[m.c_pscale + p] + m.cst[m.c_pshift + p];
+  }
+  auto store_u = [&](int tile) {
+    f32x16 ut;
+#pragma unroll
+    for (int p = 0; p < SF_DMAX; ++p) ut[p] = u[0][p];
+    sf_stash_store(stash, tile, ut, lane);
+  };
+
+  // ------------------------------------------------------------------ forward (with stash)
+  for (int t = 0; t < m.T; ++t) {
+    const float* tp = m.packed + (size_t)t * m.t_stride;
+    const int sb = t * TPT;
+    store_u(sb);
+    f32x16 hid[HT][1];
+    sf_init_bias<HT, 1>(hid, tp + m.o_bin, h);
+    {
+      f32x16 ut[1][1];
+      sf_build_u_tile<1>(ut, u, h);
+      sf_mm_acc<HT, 1, 1, false>(hid, ut, tp + m.o_winu, m.nGu, 0, m.nGu, lane);
+    }
+    sf_ctx_mm<HT, 1>(hid, xr, m, tp + m.o_winc, lane);
+#pragma unroll
+    for (int mt = 0; mt < HT; ++mt) sf_stash_store(stash, sb + 1 + mt, hid[mt][0], lane);
+#pragma unroll
+    for (int k = 0; k < SF_NBMAX; ++k) {
+      if (k < m.NB) {
+        const int bb = sb + 1 + HT + k * 3 * HT;
+        f32x16 t2[HT][1];
+        {
+          f32x16 t1[HT][1];
+          sf_init_bias<HT, 1>(t1, tp + m.o_b1[k], h);
+          sf_mm_acc<HT, 1, HT, true>(t1, hid, tp + m.o_w1[k], m.nGh, 0, m.nGh, lane);
+#pragma unroll
+          for (int mt = 0; mt < HT; ++mt) sf_stash_store(stash, bb + mt, t1[mt][0], lane);
+          sf_init_bias<HT, 1>(t2, tp + m.o_b2[k], h);
+          sf_mm_acc<HT, 1, HT, true>(t2, t1, tp + m.o_w2[k], m.nGh, 0, m.nGh, lane);
+        }
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) {
+          sf_stash_store(stash, bb + HT + mt, t2[mt][0], lane);
+          f32x16 g[1][1];
+          sf_init_bias<1, 1>(g, tp + m.o_bg[k] + mt * 32, h);
+          sf_ctx_mm<1, 1>(g, xr, m, tp + m.o_wg[k] + mt * m.nGc * 256, lane);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) hid[mt][0][r] += t2[mt][0][r] * sf_sigmoid(g[0][0][r]);
+          sf_stash_store(stash, bb + 2 * HT + mt, hid[mt][0], lane);
+        }
+      }
+    }
+    Ops::spline_apply(m, tp, t, hid, u, logdet, false, lane);
+    store_u(sb + TPT - 1);
+    if (m.D > 1) Ops::lu_forward(m, tp + m.o_lu, u, logdet);
+  }
+  float G[SF_DMAX];
+  const float w = valid ? (a.wts ? a.w * a.wts[row] : a.w) : 0.f;
+  {
+    float ss = 0.f;
+#pragma unroll
+    for (int p = 0; p < SF_DMAX; ++p) {
+      G[p] = 0.f;
+      if (p < m.D) {
+        ss += u[0][p] * u[0][p];
+        G[p] = w * u[0][p];
+      }
+    }
+    if (a.loss && valid && h == 0)
+      a.loss[row] = 0.5f * ss + 0.5f * (float)m.D * 1.8378770664093453f - logdet[0];
+  }
+
+  // ------------------------------------------------------------------ backward
+  for (int t = m.T - 1; t >= 0; --t) {
+    const float* tp = m.packed + (size_t)t * m.t_stride;
+    const float* tpT = m.packedT + (size_t)t * m.tT_stride;
+    float* gp = a.gimg + (size_t)t * m.t_stride;
+    const int sb = t * TPT;
+    const int D = m.D;
+    float up[SF_DMAX], uin[1][SF_DMAX];
+    {
+      f32x16 ut;
+      sf_stash_load(stash, sb + TPT - 1, ut, lane);
+#pragma unroll
+      for (int p = 0; p < SF_DMAX; ++p) up[p] = ut[p];
+      sf_stash_load(stash, sb, ut, lane);
+#pragma unroll
+      for (int p = 0; p < SF_DMAX; ++p) uin[0][p] = ut[p];
+    }
+    // ---- LULinear backward:  y = L t + b, t = U u'
+    if (D > 1) {
+      const float* lp = tp + m.o_lu;
+      float* gl = gp + m.o_lu;
+      const float* Lm = lp;
+      const float* Um = lp + D * D;
+      const float* ud = lp + 2 * D * D;
+      float tt[SF_DMAX], dt[SF_DMAX], dg[SF_DMAX];
+#pragma unroll
+      for (int i = 0; i < SF_DMAX; ++i) {
+        tt[i] = 0.f; dt[i] = 0.f; dg[i] = 1.f;
+        if (i < D) {
+          dg[i] = sf_softplus(ud[i]) + m.lu_eps;
+          tt[i] = dg[i] * up[i];
+#pragma unroll
+          for (int j = 0; j < SF_DMAX; ++j)
+            if (j > i && j < D) tt[i] += Um[i * D + j] * up[j];
+        }
+      }
+      // dt = L^T G ; dL_ij += G_i t_j ; dbias += G
+#pragma unroll
+      for (int j = 0; j < SF_DMAX; ++j)
+        if (j < D) {
+          dt[j] = G[j];
+#pragma unroll
+          for (int i = 0; i < SF_DMAX; ++i)
+            if (i > j && i < D) dt[j] += Lm[i * D + j] * G[i];
+        }
+#pragma unroll
+      for (int i = 0; i < SF_DMAX; ++i)
+        if (i < D) {
+          const float sb_ = sf_half_sum(G[i]);
+          if (lane == 0) atomicAdd(gl + 2 * D * D + D + i, sb_);
+#pragma unroll
+          for (int j = 0; j < SF_DMAX; ++j)
+            if (j < i) {
+              const float sv = sf_half_sum(G[i] * tt[j]);
+              if (lane == 0) atomicAdd(gl + i * D + j, sv);
+            }
+        }
+      // du' = U^T dt ; dU_ij += dt_i u'_j ; d udiag
+      float Gn[SF_DMAX];
+#pragma unroll
+      for (int j = 0; j < SF_DMAX; ++j) {
+        Gn[j] = 0.f;
+        if (j < D) {
+          Gn[j] = dg[j] * dt[j];
+#pragma unroll
+          for (int i = 0; i < SF_DMAX; ++i)
+            if (i < j) Gn[j] += Um[i * D + j] * dt[i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < SF_DMAX; ++i)
+        if (i < D) {
+          const float ddiag = dt[i] * up[i] - w / dg[i];
+          const float sd = sf_half_sum(ddiag * sf_sigmoid(ud[i]));
+          if (lane == 0) atomicAdd(gl + 2 * D * D + i, sd);
+#pragma unroll
+          for (int j = 0; j < SF_DMAX; ++j)
+            if (j > i && j < D) {
+              const float sv = sf_half_sum(dt[i] * up[j]);
+              if (lane == 0) atomicAdd(gl + D * D + i * D + j, sv);
+            }
+        }
+#pragma unroll
+      for (int p = 0; p < SF_DMAX; ++p) G[p] = Gn[p];
+    }
+    // ---- spline head + spline backward
+    f32x16 hN[HT][1];
+#pragma unroll
+    for (int mt = 0; mt < HT; ++mt) sf_stash_load(stash, sb + 1 + HT + (m.NB - 1) * 3 * HT + 2 * HT + mt, hN[mt][0], lane);
+    f32x16 dh[HT][1];
+#pragma unroll
+    for (int mt = 0; mt < HT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dh[mt][0][r] = 0.f;
+    {
+      const int start = t & 1;
+      const int d_tr = (D - start + 1) / 2;
+      for (int jp = 0; jp * 2 < d_tr; ++jp) {
+        f32x16 q[PT][1];
+        sf_init_bias<PT, 1>(q, tp + m.o_bout + jp * PT * 32, h);
+        sf_mm_acc<PT, 1, HT, false>(q, hN, tp + m.o_wout + jp * PT * m.nGh * 256, m.nGh, 0, m.nGh, lane);
+        const int kdim = 2 * jp + h;
+        const bool have = kdim < d_tr;
+        const int tgt = start + 2 * kdim;
+        const int tgt_o = start + 2 * (2 * jp + (1 - h));
+        const bool have_o = (2 * jp + (1 - h)) < d_tr;
+        float vin = 0.f, Go = 0.f;
+#pragma unroll
+        for (int p = 0; p < SF_DMAX; ++p) {
+          vin = (p == tgt) ? uin[0][p] : vin;
+          Go = (p == tgt) ? G[p] : Go;
+        }
+        f32x16 dq[PT][1];
+        float vout, lad, dv;
+        SfSplineBwd<PT>::template eval<1>(m, q, 0, vin, have ? Go : 0.f, have ? -w : 0.f, vout, lad, dv, dq);
+        dv = have ? dv : 0.f;
+        const float dvo = sf_xhalf(dv);
+#pragma unroll
+        for (int p = 0; p < SF_DMAX; ++p) {
+          G[p] = (have && p == tgt) ? dv : G[p];
+          G[p] = (have_o && p == tgt_o) ? dvo : G[p];
+        }
+        sf_grad_w<PT, HT>(lds, dq, hN, gp + m.o_wout + jp * PT * m.nGh * 256, gp + m.o_bout + jp * PT * 32,
+                          m.nGh, 0, m.nGh, lane);
+        sf_mm_acc<HT, 1, PT, false>(dh, dq, tpT + m.oT_wout + jp * HT * (PT * 4) * 256, PT * 4, 0, PT * 4, lane);
+      }
+    }
+    // ---- ResidualNet backward
+#pragma unroll
+    for (int kk = 0; kk < SF_NBMAX; ++kk) {
+      const int k = SF_NBMAX - 1 - kk;
+      if (k < m.NB) {
+        const int bb = sb + 1 + HT + k * 3 * HT;
+        f32x16 dt2[HT][1];
+        {
+          f32x16 dgate[HT][1];
+#pragma unroll
+          for (int mt = 0; mt < HT; ++mt) {
+            f32x16 t2;
+            sf_stash_load(stash, bb + HT + mt, t2, lane);
+            f32x16 g[1][1];
+            sf_init_bias<1, 1>(g, tp + m.o_bg[k] + mt * 32, h);
+            sf_ctx_mm<1, 1>(g, xr, m, tp + m.o_wg[k] + mt * m.nGc * 256, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float sg = sf_sigmoid(g[0][0][r]);
+              dt2[mt][0][r] = dh[mt][0][r] * sg;
+              dgate[mt][0][r] = dh[mt][0][r] * t2[r] * sg * (1.f - sg);
+            }
+          }
+          for (int kt = 0; kt * 4 < m.nGc; ++kt) {
+            f32x16 ct[1][1];
+            sf_build_ctx_tile<1>(ct, xr, m, kt, h);
+            sf_grad_w<HT, 1>(lds, dgate, ct, gp + m.o_wg[k], kt == 0 ? gp + m.o_bg[k] : nullptr, m.nGc, kt * 4,
+                             min(4, m.nGc - kt * 4), lane);
+          }
+        }
+        f32x16 t1[HT][1];
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) sf_stash_load(stash, bb + mt, t1[mt][0], lane);
+        sf_grad_w<HT, HT, true>(lds, dt2, t1, gp + m.o_w2[k], gp + m.o_b2[k], m.nGh, 0, m.nGh, lane);
+        f32x16 dt1[HT][1];
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dt1[mt][0][r] = 0.f;
+        sf_mm_acc<HT, 1, HT, false>(dt1, dt2, tpT + m.oT_w2[k], m.nGh, 0, m.nGh, lane);
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dt1[mt][0][r] = t1[mt][0][r] > 0.f ? dt1[mt][0][r] : 0.f;
+        // h_k = input of this block
+        f32x16 hk[HT][1];
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt)
+          sf_stash_load(stash, k == 0 ? sb + 1 + mt : sb + 1 + HT + (k - 1) * 3 * HT + 2 * HT + mt, hk[mt][0], lane);
+        sf_grad_w<HT, HT, true>(lds, dt1, hk, gp + m.o_w1[k], gp + m.o_b1[k], m.nGh, 0, m.nGh, lane);
+        f32x16 dr0[HT][1];
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dr0[mt][0][r] = 0.f;
+        sf_mm_acc<HT, 1, HT, false>(dr0, dt1, tpT + m.oT_w1[k], m.nGh, 0, m.nGh, lane);
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dh[mt][0][r] += hk[mt][0][r] > 0.f ? dr0[mt][0][r] : 0.f;
+      }
+    }
+    // ---- initial layer
+    {
+      f32x16 ut[1][1];
+      sf_build_u_tile<1>(ut, uin, h);
+      sf_grad_w<HT, 1>(lds, dh, ut, gp + m.o_winu, gp + m.o_bin, m.nGu, 0, m.nGu, lane);
+    }
+    for (int kt = 0; kt * 4 < m.nGc; ++kt) {
+      f32x16 ct[1][1];
+      sf_build_ctx_tile<1>(ct, xr, m, kt, h);
+      sf_grad_w<HT, 1>(lds, dh, ct, gp + m.o_winc, nullptr, m.nGc, kt * 4, min(4, m.nGc - kt * 4), lane);
+    }
+    f32x16 du[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) du[0][0][r] = 0.f;
+    sf_mm_acc<1, 1, HT, false>(du, dh, tpT + m.oT_winu, m.nGh, 0, m.nGh, lane);
+#pragma unroll
+    for (int p = 0; p < SF_DMAX; ++p) {
+      if (p < D) {
+        const float v = du[0][0][(p & 3) + 4 * (p >> 3)];
+        const float oth = sf_xhalf(v);
+        G[p] += (h == ((p >> 2) & 1)) ? v : oth;
+      }
+    }
+  }
+}
