@@ -51,16 +51,21 @@ __device__ __forceinline__ void sf_init_bias(f32x16 (&acc)[OT][NS], const float*
 // ---- acc[mt] += W[mt, groups kg0..kg0+ng) . in  -------------------------------------------
 // in[IT][NS]: IT input tiles (static); ng active groups (runtime, wave-uniform, <= 4*IT);
 // nGtot: group stride of the weight block.  One float4 load feeds 4*NS MFMAs.
-template <int OT, int NS, int IT, bool RELU>
+// lim (optional): per-output-tile group limit (block-triangular masked layers).
+struct SfKLim {
+  int v[4];
+};
+template <int OT, int NS, int IT, bool RELU, bool LIM = false>
 __device__ __forceinline__ void sf_mm_acc(f32x16 (&acc)[OT][NS], const f32x16 (&in)[IT][NS],
                                           const float* __restrict__ wp, int nGtot, int kg0, int ng,
-                                          int lane) {
+                                          int lane, SfKLim lim = SfKLim{{0, 0, 0, 0}}) {
   const float4* __restrict__ w4 = reinterpret_cast<const float4*>(wp);
 #pragma unroll
   for (int mt = 0; mt < OT; ++mt) {
+    const int ngm = LIM ? min(ng, lim.v[mt]) : ng;
 #pragma unroll
     for (int g = 0; g < IT * 4; ++g) {
-      if (g < ng) {
+      if (g < ngm) {
         const float4 w = w4[(mt * nGtot + kg0 + g) * 64 + lane];
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns) {
@@ -79,6 +84,48 @@ __device__ __forceinline__ void sf_mm_acc(f32x16 (&acc)[OT][NS], const f32x16 (&
       }
     }
   }
+}
+
+// single output tile `mt` of a multi-tile block (static mt), all other arguments as above
+template <int NS, int IT, bool RELU>
+__device__ __forceinline__ void sf_mm_acc_tile(f32x16 (&acc)[NS], const f32x16 (&in)[IT][NS],
+                                               const float* __restrict__ wp, int nGtot, int mt, int ng,
+                                               int lane) {
+  const float4* __restrict__ w4 = reinterpret_cast<const float4*>(wp);
+#pragma unroll
+  for (int g = 0; g < IT * 4; ++g) {
+    if (g < ng) {
+      const float4 w = w4[(mt * nGtot + g) * 64 + lane];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        float b0 = in[g >> 2][ns][(g & 3) * 4 + 0];
+        float b1 = in[g >> 2][ns][(g & 3) * 4 + 1];
+        float b2 = in[g >> 2][ns][(g & 3) * 4 + 2];
+        float b3 = in[g >> 2][ns][(g & 3) * 4 + 3];
+        if (RELU) {
+          b0 = fmaxf(b0, 0.f); b1 = fmaxf(b1, 0.f); b2 = fmaxf(b2, 0.f); b3 = fmaxf(b3, 0.f);
+        }
+        acc[ns] = SF_MFMA(w.x, b0, acc[ns]);
+        acc[ns] = SF_MFMA(w.y, b1, acc[ns]);
+        acc[ns] = SF_MFMA(w.z, b2, acc[ns]);
+        acc[ns] = SF_MFMA(w.w, b3, acc[ns]);
+      }
+    }
+  }
+}
+
+// bias image of ONE output tile mt -> acc[ns]
+template <int NS>
+__device__ __forceinline__ void sf_init_bias_tile(f32x16 (&acc)[NS], const float* __restrict__ bp, int mt, int h) {
+  const float4* p = reinterpret_cast<const float4*>(bp + (mt * 2 + h) * 16);
+  const float4 b0 = p[0], b1 = p[1], b2 = p[2], b3 = p[3];
+  f32x16 v;
+  v[0] = b0.x; v[1] = b0.y; v[2] = b0.z; v[3] = b0.w;
+  v[4] = b1.x; v[5] = b1.y; v[6] = b1.z; v[7] = b1.w;
+  v[8] = b2.x; v[9] = b2.y; v[10] = b2.z; v[11] = b2.w;
+  v[12] = b3.x; v[13] = b3.y; v[14] = b3.z; v[15] = b3.w;
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) acc[ns] = v;
 }
 
 // ---- input tiles ----------------------------------------------------------------------------

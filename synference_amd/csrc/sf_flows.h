@@ -32,7 +32,8 @@ struct MafOps {
       if (k < m.NB) {
         f32x16 b[HT][NS];
         sf_init_bias<HT, NS>(b, tp + m.o_bk[k], h);
-        sf_mm_acc<HT, NS, HT, false>(b, a, tp + m.o_wk[k], m.nGh, 0, m.nGh, lane);
+        sf_mm_acc<HT, NS, HT, false, true>(b, a, tp + m.o_wk[k], m.nGh, 0, m.nGh, lane,
+                                           SfKLim{{m.mt_kend[0], m.mt_kend[1], m.mt_kend[2], m.mt_kend[3]}});
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt)
 #pragma unroll
@@ -78,9 +79,9 @@ struct MafOps {
   }
 
   // sampling direction: transforms in reverse, D MADE passes each (AutoregressiveTransform.inverse)
-  static __device__ __forceinline__ void inverse(const SfDev& m, float (&u)[NS][SF_DMAX],
-                                                 const float* const (&xr)[NS], float (&logdet)[NS],
-                                                 int lane) {
+  static __device__ __forceinline__ void inverse_full(const SfDev& m, float (&u)[NS][SF_DMAX],
+                                                      const float* const (&xr)[NS], float (&logdet)[NS],
+                                                      int lane) {
     const int h = lane >> 5;
     for (int t = m.T - 1; t >= 0; --t) {
       const float* tp = m.packed + (size_t)t * m.t_stride;
@@ -93,22 +94,7 @@ struct MafOps {
       for (int pass = 0; pass < m.D; ++pass) {
         f32x16 fin[1][NS];
         made(m, tp, w, xr, fin, lane);
-#pragma unroll
-        for (int ns = 0; ns < NS; ++ns) {
-          float ld = 0.f;
-#pragma unroll
-          for (int p = 0; p < SF_DMAX; ++p) {
-            if (p < m.D) {
-              const float s = scale(m, fin[0][ns][2 * (p >> 1)]);
-              const float val = (u[ns][p] - fin[0][ns][2 * (p >> 1) + 1]) / s;
-              const bool mine = (h == (p & 1));
-              const float oth = sf_xhalf(val);
-              w[ns][p] = mine ? val : oth;
-              ld += mine ? logf(s) : 0.f;
-            }
-          }
-          ldl[ns] = ld + sf_xhalf(ld);
-        }
+        affine_inverse(m, fin, u, w, ldl, h);
       }
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns) {
@@ -117,6 +103,111 @@ struct MafOps {
         for (int p = 0; p < SF_DMAX; ++p) u[ns][p] = w[ns][p];
       }
     }
+  }
+
+  // w <- (v - m)/s for every slot from the head tile; ldl = sum log s
+  static __device__ __forceinline__ void affine_inverse(const SfDev& m, const f32x16 (&fin)[1][NS],
+                                                        const float (&v)[NS][SF_DMAX], float (&w)[NS][SF_DMAX],
+                                                        float (&ldl)[NS], int h) {
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+      float ld = 0.f;
+#pragma unroll
+      for (int p = 0; p < SF_DMAX; ++p) {
+        if (p < m.D) {
+          const float s = scale(m, fin[0][ns][2 * (p >> 1)]);
+          const float val = (v[ns][p] - fin[0][ns][2 * (p >> 1) + 1]) / s;
+          const bool mine = (h == (p & 1));
+          const float oth = sf_xhalf(val);
+          w[ns][p] = mine ? val : oth;
+          ld += mine ? logf(s) : 0.f;
+        }
+      }
+      ldl[ns] = ld + sf_xhalf(ld);
+    }
+  }
+
+  // Incremental form of the same D passes.  Hidden units are stored sorted by MADE degree with each
+  // degree group inside one tile (sf_layout.cpp), so pass p only has to (re)compute the ONE hidden
+  // tile holding the units of degree p-1 -- their inputs became final in pass p-1 -- over the input
+  // groups of degree <= p-1; everything of lower degree is already final and is kept in registers.
+  // Masked weights are structural zeros, so every value that the D full passes would end with is
+  // produced by the identical fma chain: results are bit-identical to inverse_full.
+  // The context product (b0 + bc + Wc e) is hoisted out of the passes.
+  static __device__ __forceinline__ void inverse_incremental(const SfDev& m, float (&u)[NS][SF_DMAX],
+                                                             const float* const (&xr)[NS],
+                                                             float (&logdet)[NS], int lane) {
+    const int h = lane >> 5;
+    for (int t = m.T - 1; t >= 0; --t) {
+      const float* tp = m.packed + (size_t)t * m.t_stride;
+      f32x16 c0[HT][NS];
+      sf_init_bias<HT, NS>(c0, tp + m.o_b0, h);
+      sf_ctx_mm<HT, NS>(c0, xr, m, tp + m.o_wc, lane);
+      f32x16 act[3][HT][NS];  // act[0] = initial layer, act[k+1] = output of block k (NB <= 2)
+#pragma unroll
+      for (int k = 0; k <= 2; ++k)
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt)
+#pragma unroll
+          for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) act[k][mt][ns][r] = 0.f;
+      float w[NS][SF_DMAX];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+        for (int p = 0; p < SF_DMAX; ++p) w[ns][p] = 0.f;
+      float ldl[NS];
+      for (int p = 1; p <= m.D; ++p) {
+        int kprev = 0;
+        if (p >= 2) {
+          const int tile = m.g_tile[p - 1];
+          const int kend = m.g_kend[p - 1];
+          kprev = kend;
+          f32x16 ut[1][NS];
+          sf_build_u_tile<NS>(ut, w, h);
+#pragma unroll
+          for (int mt = 0; mt < HT; ++mt) {
+            if (mt == tile) {
+#pragma unroll
+              for (int ns = 0; ns < NS; ++ns) act[0][mt][ns] = c0[mt][ns];
+              sf_mm_acc_tile<NS, 1, false>(act[0][mt], ut, tp + m.o_w0, m.nGu, mt, m.nGu, lane);
+#pragma unroll
+              for (int k = 0; k < 2; ++k) {
+                if (k < m.NB) {
+                  f32x16 b[NS];
+                  sf_init_bias_tile<NS>(b, tp + m.o_bk[k], mt, h);
+                  sf_mm_acc_tile<NS, HT, false>(b, act[k], tp + m.o_wk[k], m.nGh, mt, kend, lane);
+#pragma unroll
+                  for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) act[k + 1][mt][ns][r] = sf_tanh(b[ns][r]);
+                }
+              }
+            }
+          }
+        }
+        f32x16 fin[1][NS];
+        sf_init_bias<1, NS>(fin, tp + m.o_bf, h);
+        // head over the final block's activations of degree <= p-1
+        if (m.NB == 1) sf_mm_acc<1, NS, HT, false>(fin, act[1], tp + m.o_wf, m.nGh, 0, kprev, lane);
+        else sf_mm_acc<1, NS, HT, false>(fin, act[2], tp + m.o_wf, m.nGh, 0, kprev, lane);
+        affine_inverse(m, fin, u, w, ldl, h);
+      }
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        logdet[ns] -= ldl[ns];
+#pragma unroll
+        for (int p = 0; p < SF_DMAX; ++p) u[ns][p] = w[ns][p];
+      }
+    }
+  }
+
+  static __device__ __forceinline__ void inverse(const SfDev& m, float (&u)[NS][SF_DMAX],
+                                                 const float* const (&xr)[NS], float (&logdet)[NS],
+                                                 int lane) {
+    if (m.inc_ok && m.NB <= 2) inverse_incremental(m, u, xr, logdet, lane);
+    else inverse_full(m, u, xr, logdet, lane);
   }
 };
 

@@ -42,7 +42,7 @@ SF_DECL(0, 1) SF_DECL(0, 2) SF_DECL(0, 3) SF_DECL(0, 4)
 SF_DECL(1, 1) SF_DECL(1, 2) SF_DECL(1, 3) SF_DECL(1, 4)
 
 // sample tiles per wave: SF_NS=1|2 overrides (diagnostics); default 2 while HT <= 2
-int sf_pick_ns(const SfDev& m) {
+int sf_pick_ns(const SfDev& m, bool inverse) {
   static int forced = -1;
   if (forced < 0) {
     const char* e = std::getenv("SF_NS");
@@ -50,6 +50,8 @@ int sf_pick_ns(const SfDev& m) {
   }
   if (m.HT > 2) return 1;
   if (forced == 1 || forced == 2) return forced;
+  // the incremental MAF inverse keeps three activation sets alive: one sample tile per wave
+  if (inverse && m.kind == SF_MAF && m.inc_ok && m.NB <= 2) return 1;
   return 2;
 }
 
@@ -59,7 +61,7 @@ int sf_pick_ns(const SfDev& m) {
 hipError_t sf_launch_logprob(const SfDev& m, const float* theta, const float* x, long B, float* out,
                              hipStream_t st) {
   if (B <= 0) return hipSuccess;
-  const int ns = sf_pick_ns(m);
+  const int ns = sf_pick_ns(m, false);
   switch (m.kind * 10 + m.HT) {
     SF_CASE(0, 1, sf_launch_logprob, m, ns, theta, x, B, out, st)
     SF_CASE(0, 2, sf_launch_logprob, m, ns, theta, x, B, out, st)
@@ -75,7 +77,7 @@ hipError_t sf_launch_logprob(const SfDev& m, const float* theta, const float* x,
 
 hipError_t sf_launch_inverse(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
   if (a.n_items <= 0) return hipSuccess;
-  const int ns = sf_pick_ns(m);
+  const int ns = sf_pick_ns(m, true);
   switch (m.kind * 10 + m.HT) {
     SF_CASE(0, 1, sf_launch_inverse, m, ns, a, st)
     SF_CASE(0, 2, sf_launch_inverse, m, ns, a, st)

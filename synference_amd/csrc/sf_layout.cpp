@@ -101,9 +101,63 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
   v.inv_sqrt_h = (float)(1.0 / std::sqrt((double)H));
   v.deriv_const = (float)std::log(std::exp(1.0 - (double)d.min_derivative) - 1.0);
 
+  // ---- hidden physical row -> logical unit ---------------------------------------------------
+  // NSF: identity.  MAF: units sorted by MADE degree, every degree group kept inside one tile when
+  // that fits in <= 4 tiles (then the masked HxH blocks are block-lower-triangular in tile/group
+  // units and the autoregressive inverse can be evaluated incrementally).
+  std::vector<int> hrow_full(4 * 32, -1);
+  v.inc_ok = 0;
+  if (d.kind == SF_MAF) {
+    const int mx = std::max(1, D - 1), mn = std::min(1, D - 1);
+    const int G = mx;  // degree values mn .. mn+G-1
+    std::vector<std::vector<int>> grp(G);
+    for (int j = 0; j < H; ++j) grp[j % mx].push_back(j);  // degree = j % mx + mn
+    // aligned placement
+    std::vector<int> rows(4 * 32, -1);
+    int tile = 0, used = 0;
+    bool ok = true;
+    std::vector<int> gt(G), gend(G);
+    for (int g = 0; g < G && ok; ++g) {
+      const int n = (int)grp[g].size();
+      if (n > 32) { ok = false; break; }
+      if (used + n > 32) { ++tile; used = 0; }
+      if (tile >= 4) { ok = false; break; }
+      for (int q = 0; q < n; ++q) rows[tile * 32 + used + q] = grp[g][q];
+      used += n;
+      gt[g] = tile;
+      gend[g] = tile * 32 + used;  // exclusive end row of degrees <= this one
+    }
+    if (ok && D <= SF_DMAX) {
+      hrow_full = rows;
+      v.HT = std::max(v.HT, tile + 1);
+      v.inc_ok = (D >= 2) ? 1 : 0;
+      for (int g = 0; g < G; ++g) {
+        // degree value (g + mn) is stored at index (g + mn); index 0 unused when mn == 1
+        v.g_tile[g + mn] = gt[g];
+        v.g_kend[g + mn] = ceil_div(gend[g], 8);
+      }
+      v.nGh = ceil_div(gend[G - 1], 8);
+    } else {  // degree-sorted but unaligned: plain contiguous rows
+      int r = 0;
+      for (int g = 0; g < G; ++g)
+        for (int j : grp[g]) hrow_full[r++] = j;
+    }
+  } else {
+    for (int j = 0; j < H; ++j) hrow_full[j] = j;
+  }
   const int HT = v.HT;
-  const std::vector<int> hrow_out = iota_rows(H, HT * 32);     // hidden phys row -> logical unit
-  const std::vector<int> hrow_in = iota_rows(H, v.nGh * 8);
+  for (int mt = 0; mt < 4; ++mt) v.mt_kend[mt] = v.nGh;
+  if (d.kind == SF_MAF && v.inc_ok) {
+    const int mn = std::min(1, D - 1), G = std::max(1, D - 1);
+    for (int mt = 0; mt < 4; ++mt) {
+      int k = 0;
+      for (int g = 0; g < G; ++g)
+        if (v.g_tile[g + mn] == mt) k = std::max(k, v.g_kend[g + mn]);
+      if (k > 0) v.mt_kend[mt] = k;
+    }
+  }
+  const std::vector<int> hrow_out(hrow_full.begin(), hrow_full.begin() + HT * 32);
+  const std::vector<int> hrow_in(hrow_full.begin(), hrow_full.begin() + v.nGh * 8);
   const std::vector<int> crow_in = iota_rows(C, v.nGc * 8);
 
   // ---- MAF physical slot maps: sigma_T = identity, sigma_t = sigma_{t+1} o perm_t^{-1} ----

@@ -48,6 +48,12 @@ struct SfDev {
   int nGf;                               // MAF: active groups of the final-layer output tile
   int oT_wf, oT_wk[SF_NBMAX], oT_w0;     // MAF
   int oT_wout, oT_w1[SF_NBMAX], oT_w2[SF_NBMAX], oT_winu;  // NSF (oT_wout: [JP] blocks)
+  // MAF degree-sorted hidden layout (sf_layout.cpp): units of MADE degree g (1..D-1) occupy whole
+  // rows of ONE tile g_tile[g]; covering every unit of degree <= g takes g_kend[g] input groups.
+  // inc_ok = 1 when no degree group straddles a tile (enables the incremental inverse).
+  int inc_ok;
+  int g_tile[SF_DMAX], g_kend[SF_DMAX];
+  int mt_kend[4];  // input groups needed by hidden output tile mt (== nGh when not degree-sorted)
   // constants image ------------------------------------------------------------------------
   int c_pscale, c_pshift, c_tdim, c_xmean, c_xstd;  // tdim stored as float-encoded ints
   float logdet0;  // sum log|1/theta_std|
