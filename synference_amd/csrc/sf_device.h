@@ -31,6 +31,23 @@ __device__ __forceinline__ float sf_xhalf(float v) {  // value held by the other
   return __shfl_xor(v, 32, 64);
 }
 
+// ---- transform base pointer ------------------------------------------------------------------
+// LDSW: the whole operand image of transform t is copied into the workgroup's LDS once and every
+// wave of the (512-thread) workgroup reads its MFMA A operands from there with ds_read_b128;
+// otherwise weights stream from L2.  Must be called by every thread of the workgroup.
+template <bool LDSW>
+__device__ __forceinline__ const float* sf_stage(const SfDev& m, int t, float* lds) {
+  const float* src = m.packed + (size_t)t * m.t_stride;
+  if (!LDSW) return src;
+  __syncthreads();  // previous transform's image no longer in use
+  const float4* __restrict__ s4 = reinterpret_cast<const float4*>(src);
+  float4* __restrict__ d4 = reinterpret_cast<float4*>(lds);
+  const int n4 = m.t_stride >> 2;
+  for (int i = threadIdx.x; i < n4; i += blockDim.x) d4[i] = s4[i];
+  __syncthreads();
+  return lds;
+}
+
 // ---- accumulator init from the bias image [mt][h][16] ------------------------------------
 template <int OT, int NS>
 __device__ __forceinline__ void sf_init_bias(f32x16 (&acc)[OT][NS], const float* __restrict__ bp, int h) {

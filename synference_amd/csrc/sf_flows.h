@@ -11,7 +11,7 @@
 // =============================================================================================
 // MAF
 // =============================================================================================
-template <int HT, int NS>
+template <int HT, int NS, bool LDSW = false>
 struct MafOps {
   // MADE: (a_p, m_p) for every slot p land in fin[0][ns][2*(p>>1)], [2*(p>>1)+1] on half p&1
   static __device__ __forceinline__ void made(const SfDev& m, const float* __restrict__ tp,
@@ -53,10 +53,10 @@ struct MafOps {
   // density direction: u <- s*u + m for every transform, logdet += sum log s
   static __device__ __forceinline__ void forward(const SfDev& m, float (&u)[NS][SF_DMAX],
                                                  const float* const (&xr)[NS], float (&logdet)[NS],
-                                                 int lane) {
+                                                 int lane, float* lds = nullptr) {
     const int h = lane >> 5;
     for (int t = 0; t < m.T; ++t) {
-      const float* tp = m.packed + (size_t)t * m.t_stride;
+      const float* tp = sf_stage<LDSW>(m, t, lds);
       f32x16 fin[1][NS];
       made(m, tp, u, xr, fin, lane);
 #pragma unroll
@@ -81,10 +81,10 @@ struct MafOps {
   // sampling direction: transforms in reverse, D MADE passes each (AutoregressiveTransform.inverse)
   static __device__ __forceinline__ void inverse_full(const SfDev& m, float (&u)[NS][SF_DMAX],
                                                       const float* const (&xr)[NS], float (&logdet)[NS],
-                                                      int lane) {
+                                                      int lane, float* lds = nullptr) {
     const int h = lane >> 5;
     for (int t = m.T - 1; t >= 0; --t) {
-      const float* tp = m.packed + (size_t)t * m.t_stride;
+      const float* tp = sf_stage<LDSW>(m, t, lds);
       float w[NS][SF_DMAX];
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns)
@@ -136,10 +136,10 @@ struct MafOps {
   // The context product (b0 + bc + Wc e) is hoisted out of the passes.
   static __device__ __forceinline__ void inverse_incremental(const SfDev& m, float (&u)[NS][SF_DMAX],
                                                              const float* const (&xr)[NS],
-                                                             float (&logdet)[NS], int lane) {
+                                                             float (&logdet)[NS], int lane, float* lds = nullptr) {
     const int h = lane >> 5;
     for (int t = m.T - 1; t >= 0; --t) {
-      const float* tp = m.packed + (size_t)t * m.t_stride;
+      const float* tp = sf_stage<LDSW>(m, t, lds);
       f32x16 c0[HT][NS];
       sf_init_bias<HT, NS>(c0, tp + m.o_b0, h);
       sf_ctx_mm<HT, NS>(c0, xr, m, tp + m.o_wc, lane);
@@ -205,9 +205,9 @@ struct MafOps {
 
   static __device__ __forceinline__ void inverse(const SfDev& m, float (&u)[NS][SF_DMAX],
                                                  const float* const (&xr)[NS], float (&logdet)[NS],
-                                                 int lane) {
-    if (m.inc_ok && m.NB <= 2) inverse_incremental(m, u, xr, logdet, lane);
-    else inverse_full(m, u, xr, logdet, lane);
+                                                 int lane, float* lds = nullptr) {
+    if (m.inc_ok && m.NB <= 2) inverse_incremental(m, u, xr, logdet, lane, lds);
+    else inverse_full(m, u, xr, logdet, lane, lds);
   }
 };
 
@@ -464,7 +464,7 @@ struct SfSplineBwd {
   }
 };
 
-template <int HT, int PT, int NS>
+template <int HT, int PT, int NS, bool LDSW = false>
 struct NsfOps {
   // ResidualNet conditioner -> hidden tiles
   static __device__ __forceinline__ void resnet(const SfDev& m, const float* __restrict__ tp,
@@ -644,18 +644,18 @@ struct NsfOps {
 
   static __device__ __forceinline__ void forward(const SfDev& m, float (&u)[NS][SF_DMAX],
                                                  const float* const (&xr)[NS], float (&logdet)[NS],
-                                                 int lane) {
+                                                 int lane, float* lds = nullptr) {
     for (int t = 0; t < m.T; ++t) {
-      const float* tp = m.packed + (size_t)t * m.t_stride;
+      const float* tp = sf_stage<LDSW>(m, t, lds);
       coupling(m, tp, t, u, xr, logdet, false, lane);
       if (m.D > 1) lu_forward(m, tp + m.o_lu, u, logdet);
     }
   }
   static __device__ __forceinline__ void inverse(const SfDev& m, float (&u)[NS][SF_DMAX],
                                                  const float* const (&xr)[NS], float (&logdet)[NS],
-                                                 int lane) {
+                                                 int lane, float* lds = nullptr) {
     for (int t = m.T - 1; t >= 0; --t) {
-      const float* tp = m.packed + (size_t)t * m.t_stride;
+      const float* tp = sf_stage<LDSW>(m, t, lds);
       if (m.D > 1) lu_inverse(m, tp + m.o_lu, u, logdet);
       coupling(m, tp, t, u, xr, logdet, true, lane);
     }

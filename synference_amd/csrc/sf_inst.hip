@@ -10,31 +10,65 @@
 #define SF_CAT_(a, b, c, d) a##b##c##d
 #define SF_CAT(a, b, c, d) SF_CAT_(a, b, c, d)
 
-template <class Ops, int NS>
+// LDS-staged variant when one transform's operand image fits the 160 KiB LDS (with slack)
+static inline bool sf_fits_lds(const SfDev& m) { return (size_t)m.t_stride * sizeof(float) <= 156 * 1024; }
+
+template <class K>
+static hipError_t set_shmem(K kernel, size_t bytes, bool& done) {
+  if (done) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) done = true;
+  return e;
+}
+
+template <class OpsG, class OpsL, int NS>
 static hipError_t launch_logprob(const SfDev& m, const float* theta, const float* x, long B, float* out,
                                  hipStream_t st) {
-  const long per_block = 4L * 32 * NS;
-  const long grid = (B + per_block - 1) / per_block;
-  hipLaunchKernelGGL((k_logprob<Ops, NS>), dim3((unsigned)grid), dim3(256), 0, st, m, theta, x, B, out);
+  if (sf_fits_lds(m)) {
+    static bool attr = false;
+    const size_t sh = (size_t)m.t_stride * sizeof(float);
+    hipError_t e = set_shmem(k_logprob<OpsL, NS, true>, sh, attr);
+    if (e != hipSuccess) return e;
+    const long per_block = 8L * 32 * NS;
+    hipLaunchKernelGGL((k_logprob<OpsL, NS, true>), dim3((unsigned)((B + per_block - 1) / per_block)), dim3(512),
+                       sh, st, m, theta, x, B, out);
+  } else {
+    const long per_block = 4L * 32 * NS;
+    hipLaunchKernelGGL((k_logprob<OpsG, NS, false>), dim3((unsigned)((B + per_block - 1) / per_block)), dim3(256),
+                       0, st, m, theta, x, B, out);
+  }
   return hipGetLastError();
 }
-template <class Ops, int NS>
+template <class OpsG, class OpsL, int NS>
 static hipError_t launch_inverse(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
-  const long per_block = 4L * 32 * NS;
-  const long grid = (a.n_items + per_block - 1) / per_block;
-  hipLaunchKernelGGL((k_inverse<Ops, NS>), dim3((unsigned)grid), dim3(256), 0, st, m, a);
+  if (sf_fits_lds(m)) {
+    static bool attr = false;
+    const size_t sh = (size_t)m.t_stride * sizeof(float);
+    hipError_t e = set_shmem(k_inverse<OpsL, NS, true>, sh, attr);
+    if (e != hipSuccess) return e;
+    const long per_block = 8L * 32 * NS;
+    hipLaunchKernelGGL((k_inverse<OpsL, NS, true>), dim3((unsigned)((a.n_items + per_block - 1) / per_block)),
+                       dim3(512), sh, st, m, a);
+  } else {
+    const long per_block = 4L * 32 * NS;
+    hipLaunchKernelGGL((k_inverse<OpsG, NS, false>), dim3((unsigned)((a.n_items + per_block - 1) / per_block)),
+                       dim3(256), 0, st, m, a);
+  }
   return hipGetLastError();
 }
 
 #if SF_KIND == 0
-#define OPS(NS) MafOps<SF_HT, NS>
-#define SF_PT_SWITCH(NS, CALL) { using O = OPS(NS); return CALL; }
+#define SF_PT_SWITCH(NS, FN, ...)                                                          \
+  { using OG = MafOps<SF_HT, NS, false>; using OL = MafOps<SF_HT, NS, true>;               \
+    return FN<OG, OL, NS>(__VA_ARGS__); }
 #else
-#define SF_PT_SWITCH(NS, CALL)                                          \
-  switch (m.PT) {                                                       \
-    case 2: { using O = NsfOps<SF_HT, 2, NS>; return CALL; }            \
-    case 3: { using O = NsfOps<SF_HT, 3, NS>; return CALL; }            \
-    default: return hipErrorInvalidValue;                               \
+#define SF_PT_SWITCH(NS, FN, ...)                                                          \
+  switch (m.PT) {                                                                          \
+    case 2: { using OG = NsfOps<SF_HT, 2, NS, false>; using OL = NsfOps<SF_HT, 2, NS, true>; \
+              return FN<OG, OL, NS>(__VA_ARGS__); }                                        \
+    case 3: { using OG = NsfOps<SF_HT, 3, NS, false>; using OL = NsfOps<SF_HT, 3, NS, true>; \
+              return FN<OG, OL, NS>(__VA_ARGS__); }                                        \
+    default: return hipErrorInvalidValue;                                                  \
   }
 #endif
 
@@ -42,15 +76,15 @@ hipError_t SF_CAT(sf_launch_logprob_k, SF_KIND, _h, SF_HT)(const SfDev& m, int n
                                                            const float* x, long B, float* out,
                                                            hipStream_t st) {
 #if SF_HT <= 2
-  if (ns == 2) SF_PT_SWITCH(2, (launch_logprob<O, 2>(m, theta, x, B, out, st)))
+  if (ns == 2) SF_PT_SWITCH(2, launch_logprob, m, theta, x, B, out, st)
 #endif
-  SF_PT_SWITCH(1, (launch_logprob<O, 1>(m, theta, x, B, out, st)))
+  SF_PT_SWITCH(1, launch_logprob, m, theta, x, B, out, st)
 }
 
 hipError_t SF_CAT(sf_launch_inverse_k, SF_KIND, _h, SF_HT)(const SfDev& m, int ns, const SfSampleArgsHost& a,
                                                            hipStream_t st) {
 #if SF_HT <= 2
-  if (ns == 2) SF_PT_SWITCH(2, (launch_inverse<O, 2>(m, a, st)))
+  if (ns == 2) SF_PT_SWITCH(2, launch_inverse, m, a, st)
 #endif
-  SF_PT_SWITCH(1, (launch_inverse<O, 1>(m, a, st)))
+  SF_PT_SWITCH(1, launch_inverse, m, a, st)
 }

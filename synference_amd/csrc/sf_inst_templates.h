@@ -13,14 +13,16 @@
 // ---------------------------------------------------------------------------------------------
 // log_prob:  out[i] = log N(z;0,I) + logdet          ref: custom_runner.py:604 (via [UPSTREAM] Flow.log_prob)
 // ---------------------------------------------------------------------------------------------
-template <class Ops, int NS>
-__global__ __launch_bounds__(256) void k_logprob(SfDev m, const float* __restrict__ theta,
-                                                 const float* __restrict__ x, long B,
-                                                 float* __restrict__ out) {
+extern __shared__ float sf_lds_image[];
+
+template <class Ops, int NS, bool LDSW>
+__global__ __launch_bounds__(LDSW ? 512 : 256) void k_logprob(SfDev m, const float* __restrict__ theta,
+                                                              const float* __restrict__ x, long B,
+                                                              float* __restrict__ out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, h = lane >> 5;
-  const long base = ((long)blockIdx.x * 4 + wave) * (32 * NS);
-  if (base >= B) return;
+  const long base = ((long)blockIdx.x * (LDSW ? 8 : 4) + wave) * (32 * NS);
+  if (!LDSW && base >= B) return;  // LDSW: every wave takes part in the staging barriers
   float u[NS][SF_DMAX];
   const float* xr[NS];
   float logdet[NS];
@@ -40,7 +42,7 @@ __global__ __launch_bounds__(256) void k_logprob(SfDev m, const float* __restric
       }
     }
   }
-  Ops::forward(m, u, xr, logdet, lane);
+  Ops::forward(m, u, xr, logdet, lane, sf_lds_image);
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) {
     float s = 0.f;
@@ -62,12 +64,12 @@ __global__ __launch_bounds__(256) void k_logprob(SfDev m, const float* __restric
 //      box predicate custom_runner.py:982-987
 // ---------------------------------------------------------------------------------------------
 
-template <class Ops, int NS>
-__global__ __launch_bounds__(256) void k_inverse(SfDev m, SfSampleArgsHost a) {
+template <class Ops, int NS, bool LDSW>
+__global__ __launch_bounds__(LDSW ? 512 : 256) void k_inverse(SfDev m, SfSampleArgsHost a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, h = lane >> 5;
-  const long base = ((long)blockIdx.x * 4 + wave) * (32 * NS);
-  if (base >= a.n_items) return;
+  const long base = ((long)blockIdx.x * (LDSW ? 8 : 4) + wave) * (32 * NS);
+  if (!LDSW && base >= a.n_items) return;
   float u[NS][SF_DMAX];
   const float* xr[NS];
   float logdet[NS];
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256) void k_inverse(SfDev m, SfSampleArgsHost a) {
     }
     xr[ns] = a.x + gal[ns] * m.C;
   }
-  Ops::inverse(m, u, xr, logdet, lane);
+  Ops::inverse(m, u, xr, logdet, lane, sf_lds_image);
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) {
     const bool valid = item[ns] < a.n_items;
