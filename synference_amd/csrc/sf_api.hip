@@ -109,7 +109,8 @@ int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen) {
   add("o_w11", v.o_w1[1]); add("o_b11", v.o_b1[1]); add("o_w21", v.o_w2[1]); add("o_b21", v.o_b2[1]);
   add("o_wout", v.o_wout); add("o_bout", v.o_bout); add("o_lu", v.o_lu);
   add("c_pscale", v.c_pscale); add("c_pshift", v.c_pshift); add("c_tdim", v.c_tdim);
-  add("c_xmean", v.c_xmean); add("c_xstd", v.c_xstd);
+  add("c_xmean", v.c_xmean); add("c_xstd", v.c_xstd); add("c_dslot", v.c_dslot);
+  add("inc_ok", v.inc_ok);
   add("n_params", f->L.n_params); add("n_packed", f->L.n_packed);
   s += "\"cst\": [";
   for (size_t i = 0; i < f->L.cst.size(); ++i) {

@@ -24,8 +24,12 @@ __device__ __forceinline__ float sf_sigmoid(float x) {
   const float e = __builtin_amdgcn_exp2f(-x * 1.4426950408889634f);
   return __builtin_amdgcn_rcpf(1.0f + e);
 }
+// hardware exp2/log2 forms (v_exp_f32 / v_log_f32, ~1 ulp): used for every in-flow transcendental
+__device__ __forceinline__ float sf_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float sf_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+__device__ __forceinline__ float sf_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 __device__ __forceinline__ float sf_softplus(float x) {  // torch: threshold 20
-  return x > 20.0f ? x : log1pf(expf(x));
+  return x > 20.0f ? x : sf_log(1.0f + sf_exp(x));
 }
 __device__ __forceinline__ float sf_xhalf(float v) {  // value held by the other row-half
   return __shfl_xor(v, 32, 64);

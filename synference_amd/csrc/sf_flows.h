@@ -70,7 +70,7 @@ struct MafOps {
             const bool mine = (h == (p & 1));
             const float oth = sf_xhalf(val);
             u[ns][p] = mine ? val : oth;
-            ld += mine ? logf(s) : 0.f;
+            ld += mine ? sf_log(s) : 0.f;
           }
         }
         logdet[ns] += ld + sf_xhalf(ld);
@@ -116,11 +116,11 @@ struct MafOps {
       for (int p = 0; p < SF_DMAX; ++p) {
         if (p < m.D) {
           const float s = scale(m, fin[0][ns][2 * (p >> 1)]);
-          const float val = (v[ns][p] - fin[0][ns][2 * (p >> 1) + 1]) / s;
+          const float val = sf_div(v[ns][p] - fin[0][ns][2 * (p >> 1) + 1], s);
           const bool mine = (h == (p & 1));
           const float oth = sf_xhalf(val);
           w[ns][p] = mine ? val : oth;
-          ld += mine ? logf(s) : 0.f;
+          ld += mine ? sf_log(s) : 0.f;
         }
       }
       ldl[ns] = ld + sf_xhalf(ld);
@@ -158,6 +158,8 @@ struct MafOps {
 #pragma unroll
         for (int p = 0; p < SF_DMAX; ++p) w[ns][p] = 0.f;
       float ldl[NS];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) ldl[ns] = 0.f;
       for (int p = 1; p <= m.D; ++p) {
         int kprev = 0;
         if (p >= 2) {
@@ -192,7 +194,23 @@ struct MafOps {
         // head over the final block's activations of degree <= p-1
         if (m.NB == 1) sf_mm_acc<1, NS, HT, false>(fin, act[1], tp + m.o_wf, m.nGh, 0, kprev, lane);
         else sf_mm_acc<1, NS, HT, false>(fin, act[2], tp + m.o_wf, m.nGh, 0, kprev, lane);
-        affine_inverse(m, fin, u, w, ldl, h);
+        // only the dimension of degree p becomes final in this pass
+        const int slot = (int)m.cst[m.c_dslot + t * SF_DMAX + (p - 1)];
+#pragma unroll
+        for (int q = 0; q < SF_DMAX; ++q) {
+          if (q == slot) {
+#pragma unroll
+            for (int ns = 0; ns < NS; ++ns) {
+              const float s = scale(m, fin[0][ns][2 * (q >> 1)]);
+              const float val = sf_div(u[ns][q] - fin[0][ns][2 * (q >> 1) + 1], s);
+              const bool mine = (h == (q & 1));
+              const float oth = sf_xhalf(val);
+              w[ns][q] = mine ? val : oth;
+              const float ld = mine ? sf_log(s) : 0.f;
+              ldl[ns] += ld + sf_xhalf(ld);
+            }
+          }
+        }
       }
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns) {
@@ -247,7 +265,7 @@ struct SfSpline {
 #pragma unroll
     for (int k = 0; k < KM; ++k)
       if (k < K) {
-        e[k] = expf(e[k] - mx);
+        e[k] = sf_exp(e[k] - mx);
         sum += e[k];
       }
     const float scale = (1.0f - min_size * (float)K);
@@ -258,7 +276,7 @@ struct SfSpline {
 #pragma unroll
     for (int k = 0; k < KM; ++k)
       if (k < K) {
-        cs += min_size + scale * (e[k] / sum);
+        cs += min_size + scale * sf_div(e[k], sum);
         const float c_hi = (k == K - 1) ? B : (2.0f * B * cs - B);
         const bool sel = BY_VALUE ? (v >= c_lo) : (k == idx);
         if (sel) {
@@ -317,7 +335,7 @@ struct SfSpline {
     const float om = xi * (1.f - xi);
     const float den = s_k + (d_k + d_k1 - 2.f * s_k) * om;
     const float dnum = s_k * s_k * (d_k1 * xi * xi + 2.f * s_k * om + d_k * (1.f - xi) * (1.f - xi));
-    lad = logf(dnum) - 2.f * logf(den);
+    lad = sf_log(dnum) - 2.f * sf_log(den);
     if (inverse) lad = -lad;
     out = inside ? out : v;
     lad = inside ? lad : 0.f;
@@ -350,7 +368,7 @@ struct SfSplineBwd {
 #pragma unroll
     for (int k = 0; k < KM; ++k)
       if (k < K) {
-        e[k] = expf(e[k] - mx);
+        e[k] = sf_exp(e[k] - mx);
         sum += e[k];
       }
     const float scale = (1.0f - min_size * (float)K);
@@ -361,7 +379,7 @@ struct SfSplineBwd {
 #pragma unroll
     for (int k = 0; k < KM; ++k)
       if (k < K) {
-        e[k] = e[k] / sum;  // p_k
+        e[k] = sf_div(e[k], sum);  // p_k
         cs += min_size + scale * e[k];
         const float c_hi = (k == K - 1) ? B : (2.0f * B * cs - B);
         const bool sel = BY_VALUE ? (v >= c_lo) : (k == idx);
@@ -432,7 +450,7 @@ struct SfSplineBwd {
     const float Mq = d_k1 * xi * xi + 2.f * s * om + d_k * (1.f - xi) * (1.f - xi);
     const float dnum = s * s * Mq;
     const float o_in = y_k + h_k * N / den;
-    const float l_in = logf(dnum) - 2.f * logf(den);
+    const float l_in = sf_log(dnum) - 2.f * sf_log(den);
     out = inside ? o_in : v;
     lad = inside ? l_in : 0.f;
     // partials wrt z in {s, d_k, d_k1, xi}
@@ -564,7 +582,7 @@ struct NsfOps {
     for (int i = 0; i < SF_DMAX; ++i)
       if (i < D) {
         const float dg = sf_softplus(ud[i]) + m.lu_eps;
-        ld += logf(dg);
+        ld += sf_log(dg);
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns) t[ns][i] = dg * u[ns][i];
 #pragma unroll
@@ -624,7 +642,7 @@ struct NsfOps {
       const int i = SF_DMAX - 1 - ii;
       if (i < D) {
         const float dg = sf_softplus(ud[i]) + m.lu_eps;
-        ld += logf(dg);
+        ld += sf_log(dg);
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns) u[ns][i] = t[ns][i];
 #pragma unroll

@@ -202,6 +202,10 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
       L.cst[v.c_xstd + i] = d.x_std[i];
     }
     for (int i = C; i < ((C + 3) / 4) * 4; ++i) L.cst[v.c_xstd + i] = 1.f;
+    v.c_dslot = (int)L.cst.size();
+    L.cst.resize(L.cst.size() + (size_t)T * SF_DMAX, 0.f);
+    for (int t = 0; t < T; ++t)
+      for (int i = 0; i < D; ++i) L.cst[v.c_dslot + t * SF_DMAX + i] = (float)sigma[t][i];  // degree i+1
   }
 
   std::vector<int32_t> gidx;

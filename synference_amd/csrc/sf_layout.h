@@ -56,6 +56,7 @@ struct SfDev {
   int mt_kend[4];  // input groups needed by hidden output tile mt (== nGh when not degree-sorted)
   // constants image ------------------------------------------------------------------------
   int c_pscale, c_pshift, c_tdim, c_xmean, c_xstd;  // tdim stored as float-encoded ints
+  int c_dslot;  // MAF: [t][p-1] = physical slot of the dimension with MADE degree p (float-encoded)
   float logdet0;  // sum log|1/theta_std|
   float tail_bound, min_w, min_h, min_d, eps, lu_eps, inv_sqrt_h, deriv_const;
 };

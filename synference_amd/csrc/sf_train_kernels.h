@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void k_maf_train(SfDev m, SfTrainArgs a) {
         const bool mine = (h == (p & 1));
         const float oth = sf_xhalf(val);
         u[0][p] = mine ? val : oth;
-        ld += mine ? logf(s) : 0.f;
+        ld += mine ? sf_log(s) : 0.f;
       }
     }
     logdet[0] += ld + sf_xhalf(ld);
