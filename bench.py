@@ -116,6 +116,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
+    from synference_amd.engine import retry_width
     from synference_amd.estimator import build_flow
     from synference_amd.posterior import FlowPosterior
     from synference_amd.priors import prior_from_parameters
@@ -156,27 +157,37 @@ def main():
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
     drawn = [0]
+    rounds = [0]
+    rej0 = [0]
 
     def sample_step(k, timed):
         """sample_posterior over the catalogue: dense round 0 + retry rounds until every slot is filled."""
         seed = 1000 + k
-        pending, cur, attempt = M * S, None, 0
+        pending, cur, attempt, r = M * S, None, 0, 0
         while pending > 0 and attempt < 64:
+            A = retry_width(pending, attempt, 64)
             cnt.zero_()
             if timed and attempt == 0:
                 ev0[k].record()
-            flow.sample_round(X, S, cur, 0, pending, attempt, seed, lo, hi, out, rej[attempt & 1], cnt)
+            flow.sample_round(X, S, cur, 0, pending, attempt, seed, lo, hi, out, rej[r & 1], cnt,
+                              attempts_per_slot=A)
             if timed and attempt == 0:
                 ev1[k].record()
-            drawn[0] += pending
+            drawn[0] += pending * A
+            rounds[0] += 1
             pending = int(cnt.item())
-            cur = rej[attempt & 1]
-            attempt += 1
+            if attempt == 0:
+                rej0[0] += pending
+            cur = rej[r & 1]
+            attempt += A
+            r += 1
         return pending
 
     for k in range(a.warmup):
         sample_step(0, False)
     drawn[0] = 0
+    rounds[0] = 0
+    rej0[0] = 0
     barrier_sync(world)
     t0 = time.perf_counter()
     unfilled = 0
@@ -185,7 +196,7 @@ def main():
     barrier_sync(world)
     t_samp = max_over_ranks(time.perf_counter() - t0, world, dev)
     k0_ms = float(np.mean([ev0[k].elapsed_time(ev1[k]) for k in range(a.steps)]))
-    accept = (a.steps * M * S) / max(drawn[0], 1)
+    accept = 1.0 - rej0[0] / float(a.steps * M * S)
     value = world * a.steps * (M * S - 0) / t_samp
     flops_launch = F_SAMPLE_PER_DRAW * M * S + F_SAMPLE_PER_GALAXY * M
     achieved = flops_launch / (k0_ms * 1e-3) / 1e12
@@ -236,7 +247,8 @@ def main():
                                f"sample_posterior over {M} test galaxies x {S} draws per GPU",
                    "galaxies_per_gpu": M, "draws_per_galaxy": S, "theta_dim": D, "filters": C,
                    "parallelism": f"rows sharded over {world} GPU(s), no collective",
-                   "acceptance": accept, "unfilled_slots": unfilled},
+                   "acceptance": accept, "rounds_per_step": rounds[0] / a.steps,
+                   "unfilled_slots": unfilled},
         "roofline": {"bound": "mfma", "kernel": "k_inverse<MafOps<2,NS>> (dense round 0)",
                      "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,

@@ -114,18 +114,22 @@ int sf_flow_inverse_from_noise(sf_flow* f, const float* z /*[B,D]*/, const float
                                int64_t B, float* theta /*[B,D]*/, float* logdet /*[B]*/,
                                void* stream);
 
-/* One rejection round over a list of output slots (slot = g*S + p):
+/* One rejection round over a list of output slots (slot = g*S + p).  For every listed slot the
+ * attempts attempt .. attempt+attempts_per_slot-1 are evaluated together (attempts_per_slot a power
+ * of two <= 32) and the LOWEST accepted one is kept, so the result is the same as trying them one
+ * after the other:
  *   noise = Philox4x32-10(seed, stream_id; slot, attempt)  ->  theta = inverse(noise | x[g])
  *   accepted (finite and lo <= theta <= hi on every dim; lo/hi NULL = accept all finite):
  *        theta written to out[slot*D ...]
  *   rejected: slot appended to rejected[] (order unspecified), *n_rejected incremented.
  * slots == NULL means the dense list slot = slot_base + i, i < n_slots.
- * n_drawn (may be NULL) [M] int32: += 1 for every candidate drawn for galaxy g.
+ * n_drawn (may be NULL) [M] int32: += attempts consumed (up to and including the accepted one) for
+ * galaxy g, in rounds with attempt > 0 (round 0 is accounted for by the caller: S per galaxy).
  * Replaces: DirectPosterior.sample -> accept_reject_sample (sbi_runner.py:6442; box
  * predicate custom_runner.py:982-987). */
 int sf_flow_sample_round(sf_flow* f, const float* x /*[M,C]*/, int64_t S,
                          const uint32_t* slots, int64_t slot_base, int64_t n_slots,
-                         uint32_t attempt, uint64_t seed, uint32_t stream_id,
+                         uint32_t attempt, int32_t attempts_per_slot, uint64_t seed, uint32_t stream_id,
                          const float* lo /*[D]*/, const float* hi /*[D]*/,
                          float* out /*[M*S, D]*/, uint32_t* rejected, uint32_t* n_rejected,
                          int32_t* n_drawn, void* stream);

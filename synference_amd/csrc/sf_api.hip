@@ -168,7 +168,8 @@ static void seed_keys(uint64_t seed, uint32_t stream_id, uint32_t& k0, uint32_t&
 }
 
 int sf_flow_sample_round(sf_flow* f, const float* x, int64_t S, const uint32_t* slots, int64_t slot_base,
-                         int64_t n_slots, uint32_t attempt, uint64_t seed, uint32_t stream_id,
+                         int64_t n_slots, uint32_t attempt, int32_t attempts_per_slot, uint64_t seed,
+                         uint32_t stream_id,
                          const float* lo, const float* hi, float* out, uint32_t* rejected,
                          uint32_t* n_rejected, int32_t* n_drawn, void* stream) {
   if (!f || !x || !out || !rejected || !n_rejected) return fail(SF_ERR_INVALID, "null argument");
@@ -177,9 +178,11 @@ int sf_flow_sample_round(sf_flow* f, const float* x, int64_t S, const uint32_t* 
   if ((lo == nullptr) != (hi == nullptr)) return fail(SF_ERR_INVALID, "lo and hi must be given together");
   if ((uint64_t)(slot_base + n_slots) > 0xffffffffull)
     return fail(SF_ERR_INVALID, "slot ids must fit 32 bits: split the catalogue");
+  const int A = attempts_per_slot;
+  if (A < 1 || A > 32 || (A & (A - 1))) return fail(SF_ERR_INVALID, "attempts_per_slot must be 1,2,4,8,16 or 32");
   SfSampleArgsHost a;
-  a.x = x; a.S = (long)S; a.slots = slots; a.slot_base = (long)slot_base; a.n_items = (long)n_slots;
-  a.attempt = attempt; seed_keys(seed, stream_id, a.k0, a.k1);
+  a.x = x; a.S = (long)S; a.slots = slots; a.slot_base = (long)slot_base; a.n_items = (long)n_slots * A;
+  a.attempts_per_slot = A; a.attempt = attempt; seed_keys(seed, stream_id, a.k0, a.k1);
   a.lo = lo; a.hi = hi; a.out = out; a.rejected = rejected; a.n_rejected = n_rejected; a.n_drawn = n_drawn;
   SF_HIP(sf_launch_inverse(f->dev(), a, (hipStream_t)stream));
   return SF_OK;
@@ -214,9 +217,16 @@ int sf_flow_sample(sf_flow* f, const float* x, int64_t M, int64_t S, const float
   int64_t pending = total;
   const uint32_t* cur = nullptr;
   int buf = 0;
-  for (int attempt = 0; attempt < max_attempts && pending > 0; ++attempt) {
+  int attempt = 0;
+  while (attempt < max_attempts && pending > 0) {
+    // round 0: one attempt per slot; retry rounds: several attempts per pending slot so that the
+    // (latency-bound) tail needs only a few launches
+    int A = 1;
+    if (attempt > 0) {
+      while (A < 32 && (int64_t)(2 * A) * pending <= 262144 && attempt + 2 * A <= max_attempts) A *= 2;
+    }
     SF_HIP(hipMemsetAsync(f->d_cnt, 0, sizeof(uint32_t), st));
-    int rc = sf_flow_sample_round(f, x, S, cur, 0, pending, (uint32_t)attempt, seed, 0, lo, hi, out,
+    int rc = sf_flow_sample_round(f, x, S, cur, 0, pending, (uint32_t)attempt, A, seed, 0, lo, hi, out,
                                   f->d_rej[buf], f->d_cnt, n_drawn, stream);
     if (rc) return rc;
     uint32_t nrej = 0;
@@ -225,6 +235,7 @@ int sf_flow_sample(sf_flow* f, const float* x, int64_t M, int64_t S, const float
     pending = nrej;
     cur = f->d_rej[buf];
     buf ^= 1;
+    attempt += A;
   }
   if (pending > 0) SF_HIP(sf_launch_fill_nan_rows(out, cur, (long)pending, f->L.dev.D, st));
   if (n_unfilled) *n_unfilled = pending;

@@ -90,13 +90,15 @@ __global__ __launch_bounds__(LDSW ? 512 : 256) void k_inverse(SfDev m, SfSampleA
       for (int p = 0; p < SF_DMAX; ++p)
         if (p < m.D) u[ns][p] = a.z_in[it * m.D + p];
     } else {
-      slot[ns] = a.slots ? (uint64_t)a.slots[it] : (uint64_t)(a.slot_base + it);
+      const long ps = it / a.attempts_per_slot;  // listed slot; A consecutive items share it
+      slot[ns] = a.slots ? (uint64_t)a.slots[ps] : (uint64_t)(a.slot_base + ps);
       gal[ns] = (long)(slot[ns] / (uint64_t)a.S);
+      const uint32_t att = a.attempt + (uint32_t)(it % a.attempts_per_slot);
 #pragma unroll
       for (int blk = 0; blk < SF_DMAX / 4; ++blk)
         if (blk * 4 < m.D) {
           float z4[4];
-          sf_normal4(a.k0, a.k1, slot[ns], a.attempt, (uint32_t)blk, z4);
+          sf_normal4(a.k0, a.k1, slot[ns], att, (uint32_t)blk, z4);
 #pragma unroll
           for (int j = 0; j < 4; ++j) u[ns][blk * 4 + j] = (blk * 4 + j < m.D) ? z4[j] : 0.f;
         }
@@ -134,15 +136,24 @@ __global__ __launch_bounds__(LDSW ? 512 : 256) void k_inverse(SfDev m, SfSampleA
       } else if (hit) {
         atomicAdd(&a.count[gal[ns]], 1);
       }
-    } else if (valid && h == 0) {
-      if (a.n_drawn && a.attempt > 0) atomicAdd(&a.n_drawn[gal[ns]], 1);
-      if (ok) {
+    } else {
+      // A consecutive lanes hold attempts att..att+A-1 of one slot: the lowest accepted one wins
+      const int A = a.attempts_per_slot;
+      const unsigned long long bal = __ballot(valid && h == 0 && ok);
+      const int grp0 = (c / A) * A;
+      const uint32_t gmask = (uint32_t)((bal >> grp0) & ((A >= 32) ? 0xffffffffull : ((1ull << A) - 1ull)));
+      const int first = gmask ? (int)__builtin_ctz(gmask) : -1;
+      const int me = c - grp0;
+      if (valid && h == 0) {
+        if (me == 0 && a.n_drawn && a.attempt > 0) atomicAdd(&a.n_drawn[gal[ns]], first >= 0 ? first + 1 : A);
+        if (ok && me == first) {
 #pragma unroll
-        for (int p = 0; p < SF_DMAX; ++p)
-          if (p < m.D) a.out[slot[ns] * m.D + (int)m.cst[m.c_tdim + p]] = th[p];
-      } else {
-        const uint32_t pos = atomicAdd(a.n_rejected, 1u);
-        a.rejected[pos] = (uint32_t)slot[ns];
+          for (int p = 0; p < SF_DMAX; ++p)
+            if (p < m.D) a.out[slot[ns] * m.D + (int)m.cst[m.c_tdim + p]] = th[p];
+        } else if (first < 0 && me == 0) {
+          const uint32_t pos = atomicAdd(a.n_rejected, 1u);
+          a.rejected[pos] = (uint32_t)slot[ns];
+        }
       }
     }
   }

@@ -13,6 +13,7 @@ struct SfSampleArgsHost {
   long slot_base = 0;
   long n_items = 0;
   uint32_t attempt = 0, k0 = 0, k1 = 0;
+  int attempts_per_slot = 1;  // A: consecutive attempts evaluated per listed slot (power of two <= 32)
   const float* lo = nullptr;
   const float* hi = nullptr;
   float* out = nullptr;

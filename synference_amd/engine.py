@@ -16,6 +16,15 @@ from . import _lib
 from .spec import KIND_ID, FlowSpec, num_params
 
 
+def retry_width(pending: int, attempt: int, max_attempts: int) -> int:
+    """Attempts evaluated per pending slot in a retry round (same rule as sf_flow_sample)."""
+    A = 1
+    if attempt > 0:
+        while A < 32 and 2 * A * pending <= 262144 and attempt + 2 * A <= max_attempts:
+            A *= 2
+    return A
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -131,10 +140,11 @@ class HipFlow:
         return (out, nd) if return_counts else out
 
     def sample_round(self, x, S, slots, slot_base, n_slots, attempt, seed, lo, hi, out, rejected, n_rejected,
-                     n_drawn=None, stream_id: int = 0):
+                     n_drawn=None, stream_id: int = 0, attempts_per_slot: int = 1):
         self._dev()
         _lib.check(self.lib.sf_flow_sample_round(
-            self.handle, _ptr(x), S, _ptr(slots), slot_base, n_slots, attempt, C.c_uint64(seed & (2 ** 64 - 1)),
+            self.handle, _ptr(x), S, _ptr(slots), slot_base, n_slots, attempt, attempts_per_slot,
+            C.c_uint64(seed & (2 ** 64 - 1)),
             stream_id, _ptr(lo), _ptr(hi), _ptr(out), _ptr(rejected), _ptr(n_rejected), _ptr(n_drawn),
             _stream(self.device)))
 

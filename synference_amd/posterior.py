@@ -261,12 +261,17 @@ def _sample_slot_list(post: FlowPosterior, X, S: int, slots: torch.Tensor, seed:
     dev = X.device
     rej = [torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)]
     cnt = torch.zeros(1, dtype=torch.int32, device=dev)
-    cur, pending = slots.contiguous(), n
-    for attempt in range(post.max_sampling_attempts):
+    cur, pending, attempt, k = slots.contiguous(), n, 0, 0
+    from .engine import retry_width
+    while attempt < post.max_sampling_attempts:
+        A = retry_width(pending, attempt, post.max_sampling_attempts)
         cnt.zero_()
-        est.flow.sample_round(X, S, cur, 0, pending, attempt, seed, lo, hi, out, rej[attempt & 1], cnt)
+        est.flow.sample_round(X, S, cur, 0, pending, attempt, seed, lo, hi, out, rej[k & 1], cnt,
+                              attempts_per_slot=A)
         pending = int(cnt.item())
-        cur = rej[attempt & 1]
+        cur = rej[k & 1]
+        attempt += A
+        k += 1
         if pending == 0:
             return
     bad = cur[:pending].long()
