@@ -36,6 +36,31 @@ F_LOGPROB_PER_ROW = 40_030.0
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA (= vector) dense peak
 
 
+def executed_mfma_flops_per_draw(d):
+    """FLOPs the MAF sampler kernel actually issues on the MFMA pipe per draw (dense padded tiles of
+    the incremental inverse): group-steps x 4 MFMAs x 32x32x2 MACs x 2 / 32 samples."""
+    D, T, NB, HT = d["D"], d["T"], d["NB"], d["HT"]
+    if d["inc_ok"] and NB <= 2:
+        steps = HT * d["nGc"]                                           # hoisted context product
+        steps += sum(d["nGu"] + NB * d["g_kend"][p - 1] for p in range(2, D + 1))   # one hidden tile per pass
+        steps += sum(d["g_kend"][p - 1] if p >= 2 else 0 for p in range(1, D + 1))  # head per pass
+    else:
+        steps = D * (HT * (d["nGu"] + d["nGc"]) + NB * sum(d["mt_kend"][:HT]) + d["nGh"])
+    return T * steps * 4 * (32 * 32 * 2) * 2 / 32.0
+
+
+def pmc_traffic():
+    """HBM bytes per dense round-0 launch from the committed rocprofv3 PMC passes (profiles/), collected
+    with the same command; None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as fh:
+        d = json.load(fh)
+    return d.get("hbm_bytes_per_launch"), os.path.basename(files[-1])
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,6 +225,10 @@ def main():
     value = world * a.steps * (M * S - 0) / t_samp
     flops_launch = F_SAMPLE_PER_DRAW * M * S + F_SAMPLE_PER_GALAXY * M
     achieved = flops_launch / (k0_ms * 1e-3) / 1e12
+    traffic, traffic_src = pmc_traffic()
+    exe_per_draw = executed_mfma_flops_per_draw(flow.describe())
+    executed = exe_per_draw * M * S / (k0_ms * 1e-3) / 1e12
+    minimal = F_LOGPROB_PER_ROW * M * S / (k0_ms * 1e-3) / 1e12
 
     # ---------------- train leg: fwd+bwd (+ all-reduce) + clip + Adam at the per-GPU batch
     tsteps = a.train_steps or a.steps
@@ -251,9 +280,17 @@ def main():
                    "unfilled_slots": unfilled},
         "roofline": {"bound": "mfma", "kernel": "k_inverse<MafOps<2,NS>> (dense round 0)",
                      "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                     "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": 4.0 * D * M * S + 4.0 * C * M,
                      "launch_ms": k0_ms, "flops_per_launch": flops_launch,
-                     "note": "algorithmic = mask-aware 175150 FLOP/draw + 5000/galaxy (SURVEY 8d)"},
+                     "note": "achieved uses the SURVEY 8d contract figure for the REFERENCE algorithm (D full MADE "
+                             "passes per transform: 175150 mask-aware FLOP/draw + 5000/galaxy). The kernel obtains "
+                             "bit-identical draws with an incremental inverse that executes fewer FLOPs: see "
+                             "executed_* (dense padded MFMA FLOPs actually issued) and minimal_* (mask-aware FLOPs "
+                             "of one MADE evaluation per transform, 40030/draw).",
+                     "executed_mfma_flop_per_draw": exe_per_draw, "executed_mfma_tflops": executed,
+                     "executed_mfma_frac": executed / PEAK_FP32_TFLOPS,
+                     "minimal_algorithm_tflops": minimal, "minimal_algorithm_frac": minimal / PEAK_FP32_TFLOPS},
         "train": {"metric": "flow-train theta.x pairs/sec (fwd+bwd+allreduce+clip+Adam)", "value": pairs,
                   "unit": "pairs/s", "per_gpu_batch": B, "steps": tsteps, "ms_per_step": 1e3 * t_train / tsteps,
                   "achieved_tflops": pairs * 3 * F_LOGPROB_PER_ROW / 1e12,

@@ -112,6 +112,12 @@ int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen) {
   add("c_xmean", v.c_xmean); add("c_xstd", v.c_xstd); add("c_dslot", v.c_dslot);
   add("inc_ok", v.inc_ok);
   add("n_params", f->L.n_params); add("n_packed", f->L.n_packed);
+  s += "\"g_kend\": [";
+  for (int i = 0; i < SF_DMAX; ++i) s += std::to_string(v.g_kend[i]) + (i + 1 < SF_DMAX ? ", " : "], ");
+  s += "\"g_tile\": [";
+  for (int i = 0; i < SF_DMAX; ++i) s += std::to_string(v.g_tile[i]) + (i + 1 < SF_DMAX ? ", " : "], ");
+  s += "\"mt_kend\": [";
+  for (int i = 0; i < 4; ++i) s += std::to_string(v.mt_kend[i]) + (i + 1 < 4 ? ", " : "], ");
   s += "\"cst\": [";
   for (size_t i = 0; i < f->L.cst.size(); ++i) {
     char t[40];

@@ -119,3 +119,42 @@ def test_autograd_estimator_matches_direct_loss_grad(fitted):
     g_auto = est.flat.grad.clone()
     _, g_ref = est.flow.loss_grad(est.flat.detach(), th, x, 1.0 / 100, weights=torch.linspace(0.5, 1.5, 100))
     assert (g_auto - g_ref).abs().max() <= 1e-5 * g_ref.abs().max() + 1e-8
+
+
+def test_nsf_fit_and_ensemble_sampling_match_oracle(tmp_path):
+    """NSF through the same surface, then a 2-member ensemble (one MAF-free: two NSFs) sampled on the GPU
+    against the oracle's ensemble rule (multinomial split per row, member order)."""
+    from cases import make_case
+    from oracle import posterior as OP
+    from synference_amd import SBI_Fitter
+    from synference_amd.estimator import FlowEstimator
+    from synference_amd.posterior import EnsemblePosterior, FlowPosterior
+    from synference_amd.priors import CustomIndependentUniform
+    from synference_amd.synthetic import make_catalogue
+    x, theta, names = make_catalogue(3000, 20, 8, seed=2)
+    f = SBI_Fitter("nsf", names, [f"F{i}" for i in range(20)], feature_array=x, parameter_array=theta)
+    post, stats = f.run_single_sbi(model_type="nsf", hidden_features=50, num_transforms=3,
+                                   additional_model_args={"num_bins": 8}, training_batch_size=256,
+                                   learning_rate=2e-3, stop_after_epochs=2, max_num_epochs=6, random_seed=1,
+                                   save_model=False, verbose=False)
+    assert stats[0]["training_loss"][-1] < stats[0]["training_loss"][0] - 0.5
+    s = f.sample_posterior(f._X_test[:10], num_samples=100, seed=3)
+    assert s.shape == (10, 100, 8) and np.isfinite(s).all()
+    # ---- ensemble vs oracle, draw for draw
+    o1, s1, fl1, _, xx = make_case("nsf_odd", seed=0, B=5, spread=0.2)
+    o2, s2, fl2, _, _ = make_case("nsf_odd", seed=0, B=5, spread=0.25)
+    free, _ = OP.sample(o1, torch.as_tensor(fl1), xx, 300, 99, dtype=torch.float32)
+    lo = np.quantile(free.reshape(-1, s1.D), 0.03, axis=0).astype(np.float32)
+    hi = np.quantile(free.reshape(-1, s1.D), 0.97, axis=0).astype(np.float32)
+    prior = CustomIndependentUniform(lo, hi, device="cuda")
+    ests = [FlowEstimator(s1, torch.as_tensor(fl1)).to("cuda"), FlowEstimator(s2, torch.as_tensor(fl2)).to("cuda")]
+    ens = EnsemblePosterior([FlowPosterior(e, prior) for e in ests], weights=[0.3, 0.7])
+    got = ens.sample_catalogue(torch.as_tensor(xx), 128, seed=17).cpu().double().numpy()
+    ref = OP.ensemble_sample([o1, o2], [torch.as_tensor(fl1), torch.as_tensor(fl2)], [0.3, 0.7], xx, 128, 17, lo, hi)
+    err = np.abs((got - ref) / (hi - lo)).max(-1)
+    assert np.isfinite(got).all() and (err > 5e-4).mean() < 1e-2, (err > 5e-4).mean()
+    lp = ens.log_prob_catalogue(torch.as_tensor(ref[:, 0].astype(np.float32)), torch.as_tensor(xx),
+                                norm_posterior=False).cpu().double().numpy()
+    rlp = OP.ensemble_log_prob([o1, o2], [torch.as_tensor(fl1), torch.as_tensor(fl2)], [0.3, 0.7],
+                               ref[:, 0].astype(np.float32), xx, lo, hi)
+    assert np.abs(lp - rlp).max() < 2e-4
