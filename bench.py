@@ -29,10 +29,15 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic work per unit, SURVEY.md 8(d): mask-aware MACs x2, MAF cfg1
-F_SAMPLE_PER_DRAW = 175_150.0
-F_SAMPLE_PER_GALAXY = 5_000.0
-F_LOGPROB_PER_ROW = 40_030.0
+# algorithmic work per unit, SURVEY.md 8(d): mask-aware MACs x2
+WORKLOADS = {
+    # BASELINE configs[1] (the default, quoted metric): MAF 5x50 on the 10k-galaxy 10-filter mock
+    "maf_cfg2": dict(kind="maf", D=5, C=10, K=10, n_lib=10_000, galaxies=2000, f_draw=175_150.0, f_gal=5_000.0,
+                     f_lp=40_030.0, label="BASELINE configs[1]: NPE MAF T=5 H=50 on 10k-galaxy 10-filter mock"),
+    # BASELINE configs[2]: NSF (8 bins) on the 100k-galaxy 20-filter mock
+    "nsf_cfg3": dict(kind="nsf", D=8, C=20, K=8, n_lib=100_000, galaxies=20000, f_draw=148_640.0, f_gal=30_000.0,
+                     f_lp=178_640.0, label="BASELINE configs[2]: NPE NSF T=5 H=50 K=8 on 100k-galaxy 20-filter mock"),
+}
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA (= vector) dense peak
 
 
@@ -40,6 +45,11 @@ def executed_mfma_flops_per_draw(d):
     """FLOPs the MAF sampler kernel actually issues on the MFMA pipe per draw (dense padded tiles of
     the incremental inverse): group-steps x 4 MFMAs x 32x32x2 MACs x 2 / 32 samples."""
     D, T, NB, HT = d["D"], d["T"], d["NB"], d["HT"]
+    if d["kind"] == 1:  # NSF: conditioner + GLU gates + spline head per transform
+        steps = HT * (d["nGu"] + d["nGc"]) + NB * (2 * HT * d["nGh"] + HT * d["nGc"])
+        d_tr = [(D - (t & 1) + 1) // 2 for t in range(T)]
+        heads = sum(((dt + 1) // 2) * d["PT"] * d["nGh"] for dt in d_tr)
+        return (T * steps + heads) * 4 * (32 * 32 * 2) * 2 / 32.0
     if d["inc_ok"] and NB <= 2:
         steps = HT * d["nGc"]                                           # hoisted context product
         steps += sum(d["nGu"] + NB * d["g_kend"][p - 1] for p in range(2, D + 1))   # one hidden tile per pass
@@ -66,11 +76,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--galaxies", type=int, default=2000, help="test-catalogue rows per GPU")
+    ap.add_argument("--workload", default="maf_cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--galaxies", type=int, default=0, help="test-catalogue rows per GPU (0 = workload default)")
     ap.add_argument("--draws", type=int, default=1000)
     ap.add_argument("--train-batch", type=int, default=16384, help="per-GPU training batch of the train leg")
     ap.add_argument("--train-steps", type=int, default=0, help="0 = same as --steps")
-    ap.add_argument("--fit-steps", type=int, default=300, help="untimed seeded warm-up fit")
+    ap.add_argument("--fit-steps", type=int, default=4000, help="untimed seeded warm-up fit")
+    ap.add_argument("--fit-lr", type=float, default=2e-3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -134,11 +146,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP flow engine has no CPU fallback)")
+    # rehearsal knobs (never set by the driver): all ranks on one device / gloo instead of RCCL
+    if os.environ.get("SF_BENCH_ONE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("SF_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from synference_amd.engine import retry_width
@@ -149,16 +168,18 @@ def main():
     from synference_amd.synthetic import make_catalogue
 
     # ---------------- data: 10k x 10-filter library (train) + per-rank test catalogue, all in HBM
-    D, C = 5, 10
-    x_lib, th_lib, names = make_catalogue(10_000, C, D, seed=1234)
-    x_test, th_test, _ = make_catalogue(a.galaxies, C, D, seed=4321 + rank)
+    wl = WORKLOADS[a.workload]
+    D, C = wl["D"], wl["C"]
+    n_gal = a.galaxies or wl["galaxies"]
+    x_lib, th_lib, names = make_catalogue(wl["n_lib"], C, D, seed=1234)
+    x_test, th_test, _ = make_catalogue(n_gal, C, D, seed=4321 + rank)
     rs = np.random.RandomState(0)
     idx = rs.permutation(len(x_lib))
     tr = idx[: int(0.8 * len(idx))]
     prior = prior_from_parameters(th_lib[tr], names)
     gen = torch.Generator().manual_seed(42)
-    est = build_flow("maf", th_lib[tr], x_lib[tr], hidden_features=50, num_transforms=5, device=dev,
-                     generator=gen).to(dev)
+    est = build_flow(wl["kind"], th_lib[tr], x_lib[tr], hidden_features=50, num_transforms=5, num_bins=wl["K"],
+                     device=dev, generator=gen).to(dev)
     flow = est.flow
     flat = est.flat.data
     Xtr = torch.as_tensor(x_lib[tr]).to(dev)
@@ -167,10 +188,14 @@ def main():
     # ---------------- untimed seeded warm-up fit (identical on every rank)
     opt = HipAdam(flat, lr=1e-3)
     g2 = torch.Generator().manual_seed(7)
-    for _ in range(a.fit_steps):
+    fit_loss = float("nan")
+    for it in range(a.fit_steps):
         bi = torch.randint(0, len(tr), (2048,), generator=g2).to(dev)
-        flow.loss_grad(flat, Ttr[bi], Xtr[bi], 1.0 / 2048, grad_out=grad)
+        opt.desc.lr = a.fit_lr * 0.5 * (1.0 + np.cos(np.pi * it / max(a.fit_steps, 1)))  # cosine decay
+        lossv, _ = flow.loss_grad(flat, Ttr[bi], Xtr[bi], 1.0 / 2048, grad_out=grad)
         opt.step(grad, 5.0)
+        if it == a.fit_steps - 1:
+            fit_loss = float(lossv.mean().item())
     flow.set_params(flat)
     post = FlowPosterior(est, prior.to(dev), seed=2025)
     lo, hi = prior.low.to(dev), prior.high.to(dev)
@@ -190,7 +215,7 @@ def main():
         seed = 1000 + k
         pending, cur, attempt, r = M * S, None, 0, 0
         while pending > 0 and attempt < 64:
-            A = retry_width(pending, attempt, 64)
+            A = retry_width(pending, attempt, 64, M * S)
             cnt.zero_()
             if timed and attempt == 0:
                 ev0[k].record()
@@ -223,12 +248,12 @@ def main():
     k0_ms = float(np.mean([ev0[k].elapsed_time(ev1[k]) for k in range(a.steps)]))
     accept = 1.0 - rej0[0] / float(a.steps * M * S)
     value = world * a.steps * (M * S - 0) / t_samp
-    flops_launch = F_SAMPLE_PER_DRAW * M * S + F_SAMPLE_PER_GALAXY * M
+    flops_launch = wl["f_draw"] * M * S + wl["f_gal"] * M
     achieved = flops_launch / (k0_ms * 1e-3) / 1e12
-    traffic, traffic_src = pmc_traffic()
+    traffic, traffic_src = pmc_traffic() if a.workload == "maf_cfg2" and M == 2000 and S == 1000 else (None, None)
     exe_per_draw = executed_mfma_flops_per_draw(flow.describe())
     executed = exe_per_draw * M * S / (k0_ms * 1e-3) / 1e12
-    minimal = F_LOGPROB_PER_ROW * M * S / (k0_ms * 1e-3) / 1e12
+    minimal = (wl["f_lp"] if wl["kind"] == "maf" else wl["f_draw"]) * M * S / (k0_ms * 1e-3) / 1e12
 
     # ---------------- train leg: fwd+bwd (+ all-reduce) + clip + Adam at the per-GPU batch
     tsteps = a.train_steps or a.steps
@@ -272,28 +297,31 @@ def main():
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * t_samp / a.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: NPE MAF T=5 H=50 on 10k-galaxy 10-filter mock; "
-                               f"sample_posterior over {M} test galaxies x {S} draws per GPU",
+        "config": {"workload": f"{wl['label']}; sample_posterior over {M} test galaxies x {S} draws per GPU",
+                   "name": a.workload,
                    "galaxies_per_gpu": M, "draws_per_galaxy": S, "theta_dim": D, "filters": C,
                    "parallelism": f"rows sharded over {world} GPU(s), no collective",
-                   "acceptance": accept, "rounds_per_step": rounds[0] / a.steps,
+                   "acceptance": accept, "fit_steps": a.fit_steps, "fit_final_loss": fit_loss, "rounds_per_step": rounds[0] / a.steps,
                    "unfilled_slots": unfilled},
-        "roofline": {"bound": "mfma", "kernel": "k_inverse<MafOps<2,NS>> (dense round 0)",
+        "roofline": {"bound": "mfma", "kernel": ("k_inverse<MafOps<2,1,LDS>>" if wl["kind"] == "maf" else "k_inverse<NsfOps<2,2,2,LDS>>")
+                               + " (dense round 0)",
                      "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": 4.0 * D * M * S + 4.0 * C * M,
                      "launch_ms": k0_ms, "flops_per_launch": flops_launch,
-                     "note": "achieved uses the SURVEY 8d contract figure for the REFERENCE algorithm (D full MADE "
-                             "passes per transform: 175150 mask-aware FLOP/draw + 5000/galaxy). The kernel obtains "
-                             "bit-identical draws with an incremental inverse that executes fewer FLOPs: see "
-                             "executed_* (dense padded MFMA FLOPs actually issued) and minimal_* (mask-aware FLOPs "
-                             "of one MADE evaluation per transform, 40030/draw).",
+                     "note": ("achieved uses the SURVEY 8d contract figure for the REFERENCE algorithm (D full MADE "
+                              "passes per transform: 175150 mask-aware FLOP/draw + 5000/galaxy). The kernel obtains "
+                              "bit-identical draws with an incremental inverse that executes fewer FLOPs: see "
+                              "executed_* (dense padded MFMA FLOPs actually issued) and minimal_* (mask-aware FLOPs "
+                              "of one MADE evaluation per transform, 40030/draw).") if wl["kind"] == "maf" else
+                             "achieved uses the SURVEY 8d figure 148640 FLOP/draw + 30000/galaxy; executed_* = dense "
+                             "padded MFMA FLOPs actually issued",
                      "executed_mfma_flop_per_draw": exe_per_draw, "executed_mfma_tflops": executed,
                      "executed_mfma_frac": executed / PEAK_FP32_TFLOPS,
                      "minimal_algorithm_tflops": minimal, "minimal_algorithm_frac": minimal / PEAK_FP32_TFLOPS},
         "train": {"metric": "flow-train theta.x pairs/sec (fwd+bwd+allreduce+clip+Adam)", "value": pairs,
                   "unit": "pairs/s", "per_gpu_batch": B, "steps": tsteps, "ms_per_step": 1e3 * t_train / tsteps,
-                  "achieved_tflops": pairs * 3 * F_LOGPROB_PER_ROW / 1e12,
+                  "achieved_tflops": pairs * 3 * wl["f_lp"] / 1e12,
                   "batch64_pairs_per_s_1gpu": pairs64},
     }
     if world == 1 and not a.no_cpu_baseline:

@@ -264,7 +264,7 @@ def _sample_slot_list(post: FlowPosterior, X, S: int, slots: torch.Tensor, seed:
     cur, pending, attempt, k = slots.contiguous(), n, 0, 0
     from .engine import retry_width
     while attempt < post.max_sampling_attempts:
-        A = retry_width(pending, attempt, post.max_sampling_attempts)
+        A = retry_width(pending, attempt, post.max_sampling_attempts, n)
         cnt.zero_()
         est.flow.sample_round(X, S, cur, 0, pending, attempt, seed, lo, hi, out, rej[k & 1], cnt,
                               attempts_per_slot=A)

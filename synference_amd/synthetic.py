@@ -22,13 +22,18 @@ def parameter_box(D: int):
     return np.array(box, dtype=np.float64), names
 
 
-def make_catalogue(N: int, C: int, D: int, seed: int = 1234, noise: float = 0.1) -> Tuple[np.ndarray, np.ndarray, list]:
-    """Returns (x[N,C] float32, theta[N,D] float64 like the reference's parameter array, names)."""
+def make_catalogue(N: int, C: int, D: int, seed: int = 1234, noise: float = 0.1,
+                   model_seed: int = 1234) -> Tuple[np.ndarray, np.ndarray, list]:
+    """Returns (x[N,C] float32, theta[N,D] float64 like the reference's parameter array, names).
+
+    ``model_seed`` fixes the mock forward model (A, W, phi); ``seed`` draws theta and the noise, so
+    catalogues made with different ``seed`` values come from the SAME simulator."""
     box, names = parameter_box(D)
-    rng = np.random.default_rng(seed)
-    A = rng.normal(size=(C, D))
-    W = rng.normal(size=(C, D))
-    phi = rng.uniform(0, 2 * np.pi, size=C)
+    mrng = np.random.default_rng(model_seed)
+    A = mrng.normal(size=(C, D))
+    W = mrng.normal(size=(C, D))
+    phi = mrng.uniform(0, 2 * np.pi, size=C)
+    rng = np.random.default_rng([seed, 77])
     theta = rng.uniform(box[:, 0], box[:, 1], size=(N, D))
     mid, half = box.mean(1), (box[:, 1] - box[:, 0]) / np.sqrt(12.0)
     t = (theta - mid) / half
