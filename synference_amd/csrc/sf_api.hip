@@ -103,6 +103,8 @@ int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen) {
   add("nGu", v.nGu); add("nGc", v.nGc); add("nGh", v.nGh); add("t_stride", v.t_stride);
   add("o_w0", v.o_w0); add("o_wc", v.o_wc); add("o_b0", v.o_b0); add("o_wk0", v.o_wk[0]);
   add("o_bk0", v.o_bk[0]); add("o_wk1", v.o_wk[1]); add("o_bk1", v.o_bk[1]); add("o_wf", v.o_wf);
+  add("o_wk2", v.o_wk[2]); add("o_bk2", v.o_bk[2]); add("o_wk3", v.o_wk[3]); add("o_bk3", v.o_bk[3]);
+  add("scale_fn", v.scale_fn);
   add("o_bf", v.o_bf); add("o_winu", v.o_winu); add("o_winc", v.o_winc); add("o_bin", v.o_bin);
   add("o_wg0", v.o_wg[0]); add("o_bg0", v.o_bg[0]); add("o_w10", v.o_w1[0]); add("o_b10", v.o_b1[0]);
   add("o_w20", v.o_w2[0]); add("o_b20", v.o_b2[0]); add("o_wg1", v.o_wg[1]); add("o_bg1", v.o_bg[1]);

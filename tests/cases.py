@@ -15,20 +15,25 @@ CASES = {
     "maf_wide": ("maf", 12, 40, 69, 3, 10),    # HT=3 path
     "nsf_odd": ("nsf", 5, 10, 30, 3, 10),      # odd D: d_tr differs by parity; HT=1
     "nsf_k16": ("nsf", 3, 7, 64, 2, 16),       # PT=3 path
+    "maf_d1": ("maf", 1, 4, 8, 2, 10),         # one parameter: no autoregressive inputs at all
+    "maf_nb3": ("maf", 4, 6, 24, 2, 10, dict(NB=3)),            # num_blocks=3 -> full-pass inverse fallback
+    "nsf_nb1": ("nsf", 4, 6, 24, 2, 5, dict(NB=1)),             # num_blocks=1, K=5
+    "maf_sig2": ("maf", 3, 5, 20, 2, 10, dict(scale_fn="sigmoid2")),  # nflows<=0.13 scale parametrisation
 }
 
 
 def make_case(name: str, seed: int = 0, B: int = 200, spread: float = 0.5):
-    kind, D, C, H, T, K = CASES[name]
+    kind, D, C, H, T, K = CASES[name][:6]
+    extra = CASES[name][6] if len(CASES[name]) > 6 else {}
     rng = np.random.default_rng(seed)
     perms = OF.random_perms(D, T, seed) if kind == "maf" else None
     st = dict(theta_mean=rng.normal(size=D).astype(np.float32),
               theta_std=rng.uniform(0.5, 2.0, size=D).astype(np.float32),
               x_mean=rng.normal(size=C).astype(np.float32),
               x_std=rng.uniform(0.5, 2.0, size=C).astype(np.float32))
-    ospec = OF.FlowSpec(kind=kind, D=D, C=C, H=H, T=T, K=K, perms=perms,
+    ospec = OF.FlowSpec(kind=kind, D=D, C=C, H=H, T=T, K=K, perms=perms, **extra,
                         **{k: v.astype(np.float64) for k, v in st.items()})
-    spec = FlowSpec(kind=kind, D=D, C=C, H=H, T=T, K=K, perms=perms, **st)
+    spec = FlowSpec(kind=kind, D=D, C=C, H=H, T=T, K=K, perms=perms, **extra, **st)
     flat = OF.init_params(ospec, seed + 1)
     flat = (flat + spread * rng.normal(size=flat.shape) * np.abs(flat).mean()).astype(np.float32)
     theta = (rng.normal(size=(B, D)) * st["theta_std"] * 1.3 + st["theta_mean"]).astype(np.float32)

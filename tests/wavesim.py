@@ -109,7 +109,8 @@ def maf_logprob(d, packed, theta32, x32):
         mm_acc(fin, list(a), packed, tp + d["o_wf"], d["nGh"], 0, d["nGh"])
         ld = np.zeros(64)
         for p in range(D):
-            s = softplus(fin[0, 2 * (p >> 1)]) + 1e-3
+            a_ = fin[0, 2 * (p >> 1)]
+            s = (softplus(a_) if d.get("scale_fn", 0) == 0 else 1 / (1 + np.exp(-(a_ + 2.0)))) + 1e-3
             val = s * u[p] + fin[0, 2 * (p >> 1) + 1]
             mine = H_ == (p & 1)
             u[p] = np.where(mine, val, xhalf(val))
