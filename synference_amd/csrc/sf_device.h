@@ -76,7 +76,7 @@ __device__ __forceinline__ void sf_init_bias(f32x16 (&acc)[OT][NS], const float*
 struct SfKLim {
   int v[4];
 };
-template <int OT, int NS, int IT, bool RELU, bool LIM = false>
+template <int OT, int NS, int IT, bool RELU, bool LIM = false, bool PF = false>
 __device__ __forceinline__ void sf_mm_acc(f32x16 (&acc)[OT][NS], const f32x16 (&in)[IT][NS],
                                           const float* __restrict__ wp, int nGtot, int kg0, int ng,
                                           int lane, SfKLim lim = SfKLim{{0, 0, 0, 0}}) {
@@ -84,10 +84,18 @@ __device__ __forceinline__ void sf_mm_acc(f32x16 (&acc)[OT][NS], const f32x16 (&
 #pragma unroll
   for (int mt = 0; mt < OT; ++mt) {
     const int ngm = LIM ? min(ng, lim.v[mt]) : ng;
+    float4 wpre[PF ? IT * 4 : 1];
+    if (PF) {
+      // issue every fragment load of this output tile before the first MFMA (indices past the
+      // active range are clamped: duplicate, cache-resident loads) so their latencies overlap
+      const int last = ngm > 0 ? ngm - 1 : 0;
+#pragma unroll
+      for (int g = 0; g < IT * 4; ++g) wpre[g] = w4[(mt * nGtot + kg0 + min(g, last)) * 64 + lane];
+    }
 #pragma unroll
     for (int g = 0; g < IT * 4; ++g) {
       if (g < ngm) {
-        const float4 w = w4[(mt * nGtot + kg0 + g) * 64 + lane];
+        const float4 w = PF ? wpre[PF ? g : 0] : w4[(mt * nGtot + kg0 + g) * 64 + lane];
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns) {
           float b0 = in[g >> 2][ns][(g & 3) * 4 + 0];

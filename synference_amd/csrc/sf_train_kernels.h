@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_maf_train(SfDev m, SfTrainArgs a) {
     {
       f32x16 ut[1][1];
       sf_build_u_tile<1>(ut, u, h);
-      sf_mm_acc<HT, 1, 1, false>(act, ut, tp + m.o_w0, m.nGu, 0, m.nGu, lane);
+      sf_mm_acc<HT, 1, 1, false, false, true>(act, ut, tp + m.o_w0, m.nGu, 0, m.nGu, lane);
     }
     sf_ctx_mm<HT, 1>(act, xr, m, tp + m.o_wc, lane);
 #pragma unroll
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_maf_train(SfDev m, SfTrainArgs a) {
       if (k < m.NB) {
         f32x16 b[HT][1];
         sf_init_bias<HT, 1>(b, tp + m.o_bk[k], h);
-        sf_mm_acc<HT, 1, HT, false>(b, act, tp + m.o_wk[k], m.nGh, 0, m.nGh, lane);
+        sf_mm_acc<HT, 1, HT, false, false, true>(b, act, tp + m.o_wk[k], m.nGh, 0, m.nGh, lane);
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) {
 #pragma unroll
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_maf_train(SfDev m, SfTrainArgs a) {
     }
     f32x16 fin[1][1];
     sf_init_bias<1, 1>(fin, tp + m.o_bf, h);
-    sf_mm_acc<1, 1, HT, false>(fin, act, tp + m.o_wf, m.nGh, 0, m.nGh, lane);
+    sf_mm_acc<1, 1, HT, false, false, true>(fin, act, tp + m.o_wf, m.nGh, 0, m.nGh, lane);
     float ld = 0.f;
 #pragma unroll
     for (int p = 0; p < SF_DMAX; ++p) {
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_maf_train(SfDev m, SfTrainArgs a) {
     // recompute the head
     f32x16 fin[1][1];
     sf_init_bias<1, 1>(fin, tp + m.o_bf, h);
-    sf_mm_acc<1, 1, HT, false>(fin, ak, tp + m.o_wf, m.nGh, 0, m.nGh, lane);
+    sf_mm_acc<1, 1, HT, false, false, true>(fin, ak, tp + m.o_wf, m.nGh, 0, m.nGh, lane);
     f32x16 dfin[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) dfin[0][0][r] = 0.f;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void k_maf_train(SfDev m, SfTrainArgs a) {
     for (int mt = 0; mt < HT; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dh[mt][0][r] = 0.f;
-    sf_mm_acc<HT, 1, 1, false>(dh, dfin, tpT + m.oT_wf, m.nGf, 0, m.nGf, lane);
+    sf_mm_acc<HT, 1, 1, false, false, true>(dh, dfin, tpT + m.oT_wf, m.nGf, 0, m.nGf, lane);
 #pragma unroll
     for (int kk = 0; kk < SF_NBMAX; ++kk) {
       const int k = SF_NBMAX - 1 - kk;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void k_maf_train(SfDev m, SfTrainArgs a) {
         for (int mt = 0; mt < HT; ++mt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) dh[mt][0][r] = 0.f;
-        sf_mm_acc<HT, 1, HT, false>(dh, dpre, tpT + m.oT_wk[k], m.nGh, 0, m.nGh, lane);
+        sf_mm_acc<HT, 1, HT, false, false, true>(dh, dpre, tpT + m.oT_wk[k], m.nGh, 0, m.nGh, lane);
       }
     }
     // initial layer: dW0 (u tile), dWc (context tiles), d(b0+bc)
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void k_maf_train(SfDev m, SfTrainArgs a) {
     f32x16 du[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) du[0][0][r] = 0.f;
-    sf_mm_acc<1, 1, HT, false>(du, dh, tpT + m.oT_w0, m.nGh, 0, m.nGh, lane);
+    sf_mm_acc<1, 1, HT, false, false, true>(du, dh, tpT + m.oT_w0, m.nGh, 0, m.nGh, lane);
 #pragma unroll
     for (int p = 0; p < SF_DMAX; ++p) {
       if (p < m.D) {
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void k_nsf_train(SfDev m, SfTrainArgs a) {
     {
       f32x16 ut[1][1];
       sf_build_u_tile<1>(ut, u, h);
-      sf_mm_acc<HT, 1, 1, false>(hid, ut, tp + m.o_winu, m.nGu, 0, m.nGu, lane);
+      sf_mm_acc<HT, 1, 1, false, false, true>(hid, ut, tp + m.o_winu, m.nGu, 0, m.nGu, lane);
     }
     sf_ctx_mm<HT, 1>(hid, xr, m, tp + m.o_winc, lane);
 #pragma unroll
@@ -337,11 +337,11 @@ __global__ __launch_bounds__(256) void k_nsf_train(SfDev m, SfTrainArgs a) {
         {
           f32x16 t1[HT][1];
           sf_init_bias<HT, 1>(t1, tp + m.o_b1[k], h);
-          sf_mm_acc<HT, 1, HT, true>(t1, hid, tp + m.o_w1[k], m.nGh, 0, m.nGh, lane);
+          sf_mm_acc<HT, 1, HT, true, false, true>(t1, hid, tp + m.o_w1[k], m.nGh, 0, m.nGh, lane);
 #pragma unroll
           for (int mt = 0; mt < HT; ++mt) sf_stash_store(stash, bb + mt, t1[mt][0], lane);
           sf_init_bias<HT, 1>(t2, tp + m.o_b2[k], h);
-          sf_mm_acc<HT, 1, HT, true>(t2, t1, tp + m.o_w2[k], m.nGh, 0, m.nGh, lane);
+          sf_mm_acc<HT, 1, HT, true, false, true>(t2, t1, tp + m.o_w2[k], m.nGh, 0, m.nGh, lane);
         }
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) {
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void k_nsf_train(SfDev m, SfTrainArgs a) {
       for (int jp = 0; jp * 2 < d_tr; ++jp) {
         f32x16 q[PT][1];
         sf_init_bias<PT, 1>(q, tp + m.o_bout + jp * PT * 32, h);
-        sf_mm_acc<PT, 1, HT, false>(q, hN, tp + m.o_wout + jp * PT * m.nGh * 256, m.nGh, 0, m.nGh, lane);
+        sf_mm_acc<PT, 1, HT, false, false, true>(q, hN, tp + m.o_wout + jp * PT * m.nGh * 256, m.nGh, 0, m.nGh, lane);
         const int kdim = 2 * jp + h;
         const bool have = kdim < d_tr;
         const int tgt = start + 2 * kdim;
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void k_nsf_train(SfDev m, SfTrainArgs a) {
         }
         sf_grad_w<PT, HT>(lds, dq, hN, gp + m.o_wout + jp * PT * m.nGh * 256, gp + m.o_bout + jp * PT * 32,
                           m.nGh, 0, m.nGh, lane);
-        sf_mm_acc<HT, 1, PT, false>(dh, dq, tpT + m.oT_wout + jp * HT * (PT * 4) * 256, PT * 4, 0, PT * 4, lane);
+        sf_mm_acc<HT, 1, PT, false, false, true>(dh, dq, tpT + m.oT_wout + jp * HT * (PT * 4) * 256, PT * 4, 0, PT * 4, lane);
       }
     }
     // ---- ResidualNet backward
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256) void k_nsf_train(SfDev m, SfTrainArgs a) {
         for (int mt = 0; mt < HT; ++mt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) dt1[mt][0][r] = 0.f;
-        sf_mm_acc<HT, 1, HT, false>(dt1, dt2, tpT + m.oT_w2[k], m.nGh, 0, m.nGh, lane);
+        sf_mm_acc<HT, 1, HT, false, false, true>(dt1, dt2, tpT + m.oT_w2[k], m.nGh, 0, m.nGh, lane);
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt)
 #pragma unroll
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) void k_nsf_train(SfDev m, SfTrainArgs a) {
         for (int mt = 0; mt < HT; ++mt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) dr0[mt][0][r] = 0.f;
-        sf_mm_acc<HT, 1, HT, false>(dr0, dt1, tpT + m.oT_w1[k], m.nGh, 0, m.nGh, lane);
+        sf_mm_acc<HT, 1, HT, false, false, true>(dr0, dt1, tpT + m.oT_w1[k], m.nGh, 0, m.nGh, lane);
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt)
 #pragma unroll
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256) void k_nsf_train(SfDev m, SfTrainArgs a) {
     f32x16 du[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) du[0][0][r] = 0.f;
-    sf_mm_acc<1, 1, HT, false>(du, dh, tpT + m.oT_winu, m.nGh, 0, m.nGh, lane);
+    sf_mm_acc<1, 1, HT, false, false, true>(du, dh, tpT + m.oT_winu, m.nGh, 0, m.nGh, lane);
 #pragma unroll
     for (int p = 0; p < SF_DMAX; ++p) {
       if (p < D) {
