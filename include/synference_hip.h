@@ -163,10 +163,13 @@ int sf_flow_loss_grad(sf_flow* f, const float* flat /*[P]*/, const float* theta,
 
 /* Same with per-sample weights: grad[i] = sum_b grad_scale * weights[b] * d loss_b / d flat[i]
  * (weights NULL = all ones).  This is the vector-Jacobian product torch.autograd needs for an
- * arbitrary reduction of the per-sample losses. */
+ * arbitrary reduction of the per-sample losses.
+ * dctx (may be NULL) [B,C]: overwritten with grad_scale * weights[b] * d loss_b / d x[b,:] -- the
+ * gradient reaching the context, i.e. what an embedding net in front of the flow back-propagates
+ * (embedding_net kwarg, ref: sbi_runner.py:4432, custom_runner.py:321). */
 int sf_flow_loss_grad_weighted(sf_flow* f, const float* flat, const float* theta, const float* x,
                                int64_t B, float grad_scale, const float* weights /*[B]*/,
-                               float* loss, float* grad, void* stream);
+                               float* loss, float* grad, float* dctx /*[B,C]*/, void* stream);
 
 /* Fused global-norm clip + Adam / AdamW step on flat vectors.
  * Replaces: clip_grad_norm_(max_norm) + optimizer.step() (custom_runner.py:613-618). */

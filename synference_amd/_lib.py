@@ -57,7 +57,8 @@ PROTOTYPES = {
     "sf_flow_loss_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "sf_flow_loss_grad_weighted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
-                                             C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                             C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p]),
     "sf_opt_create": (C.c_int, [C.c_int64, C.POINTER(sf_adam_desc), C.POINTER(C.c_void_p)]),
     "sf_opt_destroy": (None, [C.c_void_p]),
     "sf_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),

@@ -271,14 +271,14 @@ int sf_flow_acceptance(sf_flow* f, const float* x, int64_t M, int64_t n, const f
 // ---- training ------------------------------------------------------------------------------
 int sf_flow_loss_grad_weighted(sf_flow* f, const float* flat, const float* theta, const float* x, int64_t B,
                                float grad_scale, const float* weights, float* loss, float* grad,
-                               void* stream) {
+                               float* dctx, void* stream) {
   if (!f || !flat || !grad) return fail(SF_ERR_INVALID, "null argument");
   if (B > 0 && (!theta || !x)) return fail(SF_ERR_INVALID, "null argument");
   if (B < 0) return fail(SF_ERR_INVALID, "B < 0");
   int rc = ensure_device(f);
   if (rc) return rc;
   std::string err;
-  rc = sf_train_loss_grad(f, flat, theta, x, (long)B, grad_scale, weights, loss, grad, (hipStream_t)stream, err);
+  rc = sf_train_loss_grad(f, flat, theta, x, (long)B, grad_scale, weights, loss, grad, dctx, (hipStream_t)stream, err);
   if (rc) return fail(rc, err);
   f->params_set = true;  // the forward image now holds `flat`
   return SF_OK;
@@ -286,7 +286,7 @@ int sf_flow_loss_grad_weighted(sf_flow* f, const float* flat, const float* theta
 
 int sf_flow_loss_grad(sf_flow* f, const float* flat, const float* theta, const float* x, int64_t B,
                       float grad_scale, float* loss, float* grad, void* stream) {
-  return sf_flow_loss_grad_weighted(f, flat, theta, x, B, grad_scale, nullptr, loss, grad, stream);
+  return sf_flow_loss_grad_weighted(f, flat, theta, x, B, grad_scale, nullptr, loss, grad, nullptr, stream);
 }
 
 struct sf_opt {

@@ -275,6 +275,9 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
         o = (int)(ET.linear(1, v.nGh, urow32, hrow_in, lW0, 1, D,
                             [&](int dim, int unit) { return deg_h(unit) >= dim + 1; }) - tbT);
         if (t == 0) v.oT_w0 = o;
+        const int CT = ceil_div(C, 32);
+        o = (int)(ET.linear(CT, v.nGh, iota_rows(C, CT * 32), hrow_in, lWc, 1, C, nullptr) - tbT);
+        if (t == 0) v.oT_wc = o;
       }
     }
   } else {
@@ -389,6 +392,15 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
         for (int j = 0; j < d_id; ++j) urow32[idn[j]] = j;
         o = (int)(ET.linear(1, v.nGh, urow32, hrow_in, lWin, 1, in_dim, nullptr) - tbT);
         if (t == 0) v.oT_winu = o;
+        const int CT = ceil_div(C, 32);
+        std::vector<int> crow32(CT * 32, -1);
+        for (int i = 0; i < C; ++i) crow32[i] = d_id + i;
+        o = (int)(ET.linear(CT, v.nGh, crow32, hrow_in, lWin, 1, in_dim, nullptr) - tbT);
+        if (t == 0) v.oT_wc = o;
+        for (int k = 0; k < NB; ++k) {
+          o = (int)(ET.linear(CT, v.nGh, iota_rows(C, CT * 32), hrow_in, lWg[k], 1, C, nullptr) - tbT);
+          if (t == 0) v.oT_wg[k] = o;
+        }
       }
     }
   }

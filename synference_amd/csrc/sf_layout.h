@@ -48,6 +48,8 @@ struct SfDev {
   int nGf;                               // MAF: active groups of the final-layer output tile
   int oT_wf, oT_wk[SF_NBMAX], oT_w0;     // MAF
   int oT_wout, oT_w1[SF_NBMAX], oT_w2[SF_NBMAX], oT_winu;  // NSF (oT_wout: [JP] blocks)
+  int oT_wc;                // context-gradient operands: MAF Wc^T / NSF Win_c^T, [ceil(C/32)] tiles
+  int oT_wg[SF_NBMAX];      // NSF gate Wg^T
   // MAF degree-sorted hidden layout (sf_layout.cpp): units of MADE degree g (1..D-1) occupy whole
   // rows of ONE tile g_tile[g]; covering every unit of degree <= g takes g_kend[g] input groups.
   // inc_ok = 1 when no degree group straddles a tile (enables the incremental inverse).

@@ -99,8 +99,8 @@ SF_TDECL(1) SF_TDECL(2) SF_TDECL(3) SF_TDECL(4)
   } while (0)
 
 int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const float* x, long B,
-                       float grad_scale, const float* weights, float* loss, float* grad, hipStream_t st,
-                       std::string& err) {
+                       float grad_scale, const float* weights, float* loss, float* grad, float* dctx,
+                       hipStream_t st, std::string& err) {
   const SfLayout& L = f->L;
   // ---- lazily built training state
   if (!f->d_packedT) {
@@ -128,9 +128,10 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
   SF_TRY(sf_launch_pack(flat, f->d_s1, f->d_s2, f->d_packed, (long)L.n_packed, st));
   SF_TRY(sf_launch_pack(flat, f->d_t1, f->d_t2, f->d_packedT, (long)L.n_packedT, st));
   SF_TRY(hipMemsetAsync(f->d_gpacked, 0, (size_t)L.n_packed * sizeof(float), st));
+  if (dctx && B > 0) SF_TRY(hipMemsetAsync(dctx, 0, (size_t)B * L.dev.C * sizeof(float), st));
   if (B > 0) {
     SfTrainArgs a;
-    a.theta = theta; a.x = x; a.B = B; a.w = grad_scale; a.wts = weights; a.loss = loss; a.gimg = f->d_gpacked;
+    a.theta = theta; a.x = x; a.B = B; a.w = grad_scale; a.wts = weights; a.loss = loss; a.dctx = dctx; a.gimg = f->d_gpacked;
     a.act = reinterpret_cast<float4*>(f->d_act); a.act_per_wave = act_per_wave;
     const SfDev m = f->dev();
     const bool maf = m.kind == SF_MAF;

@@ -9,6 +9,7 @@ struct SfTrainArgs {
   float w;           // gradient weight of every sample (grad_scale)
   const float* wts;  // optional per-sample weights [B] (multiplied by w)
   float* loss;       // [B] or null
+  float* dctx;       // [B,C] or null: += d(sum_b w_b loss_b)/d x[b,:] (context gradient, raw x units)
   float* gimg;       // gradient image
   float4* act;       // activation stash
   long act_per_wave; // float4 per wave

@@ -78,6 +78,25 @@ __device__ __forceinline__ void sf_grad_w(float* __restrict__ lds, const f32x16 
   __builtin_amdgcn_wave_barrier();
 }
 
+// context gradient: dctx[row, f] += (W^T delta)[f] / x_std[f] for every context feature f (the lane that
+// holds (sample, feature) owns that address: plain read-modify-write, no atomics)
+template <int HT>
+__device__ __forceinline__ void sf_ctx_grad(const SfDev& m, const f32x16 (&delta)[HT][1], const float* __restrict__ wT,
+                                            float* __restrict__ dctx_row, bool valid, int lane) {
+  const int h = lane >> 5;
+  for (int kt = 0; kt * 32 < m.C; ++kt) {
+    f32x16 de[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) de[0][0][r] = 0.f;
+    sf_mm_acc<1, 1, HT, false, false, true>(de, delta, wT + (size_t)kt * m.nGh * 256, m.nGh, 0, m.nGh, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = kt * 32 + sf_row(r, h);
+      if (valid && f < m.C) dctx_row[f] += de[0][0][r] / m.cst[m.c_xstd + f];
+    }
+  }
+}
+
 template <int HT>
 __global__ __launch_bounds__(256) void k_maf_train(SfDev m, SfTrainArgs a) {
   extern __shared__ float lds_all[];
@@ -250,6 +269,7 @@ __global__ __launch_bounds__(256) void k_maf_train(SfDev m, SfTrainArgs a) {
       sf_build_ctx_tile<1>(ct, xr, m, kt, h);
       sf_grad_w<HT, 1>(lds, dh, ct, gp + m.o_wc, nullptr, m.nGc, kt * 4, min(4, m.nGc - kt * 4), lane);
     }
+    if (a.dctx) sf_ctx_grad<HT>(m, dh, tpT + m.oT_wc, a.dctx + ii * m.C, valid, lane);
     // delta_u = W0^T delta_h0
     f32x16 du[1][1];
 #pragma unroll
@@ -531,6 +551,7 @@ __global__ __launch_bounds__(256) void k_nsf_train(SfDev m, SfTrainArgs a) {
             sf_grad_w<HT, 1>(lds, dgate, ct, gp + m.o_wg[k], kt == 0 ? gp + m.o_bg[k] : nullptr, m.nGc, kt * 4,
                              min(4, m.nGc - kt * 4), lane);
           }
+          if (a.dctx) sf_ctx_grad<HT>(m, dgate, tpT + m.oT_wg[k], a.dctx + ii * m.C, valid, lane);
         }
         f32x16 t1[HT][1];
 #pragma unroll
@@ -575,6 +596,7 @@ __global__ __launch_bounds__(256) void k_nsf_train(SfDev m, SfTrainArgs a) {
       sf_build_ctx_tile<1>(ct, xr, m, kt, h);
       sf_grad_w<HT, 1>(lds, dh, ct, gp + m.o_winc, nullptr, m.nGc, kt * 4, min(4, m.nGc - kt * 4), lane);
     }
+    if (a.dctx) sf_ctx_grad<HT>(m, dh, tpT + m.oT_wc, a.dctx + ii * m.C, valid, lane);
     f32x16 du[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) du[0][0][r] = 0.f;

@@ -160,8 +160,8 @@ class HipFlow:
         return cnt.to(torch.float32) / float(n)
 
     def loss_grad(self, flat: torch.Tensor, theta, x, grad_scale: float,
-                  grad_out: Optional[torch.Tensor] = None, weights: Optional[torch.Tensor] = None
-                  ) -> Tuple[torch.Tensor, torch.Tensor]:
+                  grad_out: Optional[torch.Tensor] = None, weights: Optional[torch.Tensor] = None,
+                  dctx_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         self._dev()
         flat = _f32c(flat, self.device)
         theta, x = _f32c(theta, self.device), _f32c(x, self.device)
@@ -171,5 +171,5 @@ class HipFlow:
         wts = None if weights is None else _f32c(weights, self.device)
         _lib.check(self.lib.sf_flow_loss_grad_weighted(self.handle, _ptr(flat), _ptr(theta), _ptr(x), B,
                                                        C.c_float(grad_scale), _ptr(wts), _ptr(loss), _ptr(grad),
-                                                       _stream(self.device)))
+                                                       _ptr(dctx_out), _stream(self.device)))
         return loss, grad

@@ -37,16 +37,21 @@ class _NegLogProb(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         flat, theta, x = ctx.saved_tensors
-        _, grad = ctx.est.flow.loss_grad(flat.detach(), theta, x, 1.0, weights=gout.contiguous())
+        dctx = torch.empty_like(x) if ctx.needs_input_grad[2] else None
+        _, grad = ctx.est.flow.loss_grad(flat.detach(), theta, x, 1.0, weights=gout.contiguous(), dctx_out=dctx)
         ctx.est._packed_version = None  # loss_grad re-tiled the image from `flat`; re-check next call
-        return grad, None, None, None
+        return (grad if ctx.needs_input_grad[0] else None), None, dctx, None
 
 
 class FlowEstimator(nn.Module):
     """Conditional flow q(theta | x) with ONE flat fp32 parameter (logical layout of the C ABI)."""
 
     def __init__(self, spec: FlowSpec, flat: Optional[torch.Tensor] = None, device="cuda:0",
-                 generator: Optional[torch.Generator] = None):
+                 generator: Optional[torch.Generator] = None, embedding_net: Optional[nn.Module] = None,
+                 x_mean=None, x_std=None):
+        """``embedding_net`` (optional, any nn.Module): the flow then sees
+        ``embedding_net((x - x_mean) / x_std)`` as its context (sbi: Sequential(Standardize, embedding),
+        SURVEY.md B.2) and ``spec.C`` is the EMBEDDED width with a no-op in-flow standardisation."""
         super().__init__()
         self.spec = spec
         if flat is None:
@@ -57,7 +62,18 @@ class FlowEstimator(nn.Module):
         self._flow: Optional[HipFlow] = None
         self._device = torch.device(device)
         self._packed_version = None
-        self.embedding_net = nn.Identity()
+        self.embedding_net = embedding_net if embedding_net is not None else nn.Identity()
+        self.has_embedding = not isinstance(self.embedding_net, nn.Identity)
+        if self.has_embedding:
+            self.register_buffer("x_mean_raw", torch.as_tensor(np.asarray(x_mean), dtype=torch.float32))
+            self.register_buffer("x_std_raw", torch.as_tensor(np.asarray(x_std), dtype=torch.float32))
+
+    def embed(self, x):
+        """Context handed to the flow for raw features x (identity embedding: x itself)."""
+        x = torch.as_tensor(x, dtype=torch.float32, device=self.flat.device)
+        if not self.has_embedding:
+            return x
+        return self.embedding_net((x - self.x_mean_raw) / self.x_std_raw)
 
     # ---- plumbing ---------------------------------------------------------------------------
     @property
@@ -102,11 +118,11 @@ class FlowEstimator(nn.Module):
     def log_prob(self, inputs, context=None, condition=None):
         x = context if context is not None else condition
         theta = torch.as_tensor(inputs, dtype=torch.float32, device=self.flat.device)
-        x = torch.as_tensor(x, dtype=torch.float32, device=self.flat.device)
-        if torch.is_grad_enabled() and self.flat.requires_grad:
-            return -_NegLogProb.apply(self.flat, theta, x, self)
+        e = self.embed(x)
+        if torch.is_grad_enabled() and (self.flat.requires_grad or e.requires_grad):
+            return -_NegLogProb.apply(self.flat, theta, e.contiguous(), self)
         self._sync_params()
-        return self.flow.log_prob(theta, x)
+        return self.flow.log_prob(theta, e)
 
     def loss(self, theta, x):
         """sbi >= 0.23 estimator API: per-sample negative log-likelihood (custom_runner.py:596-601)."""
@@ -115,8 +131,9 @@ class FlowEstimator(nn.Module):
     def sample(self, num_samples: int, context, seed: int = 0):
         """nflows ``Flow.sample(n, context)`` -> (M, n, D), unconstrained draws."""
         self._sync_params()
-        return self.flow.sample(torch.as_tensor(context, dtype=torch.float32, device=self.flat.device),
-                                int(num_samples), seed=seed)
+        with torch.no_grad():
+            e = self.embed(context)
+        return self.flow.sample(e, int(num_samples), seed=seed)
 
     def sample_and_log_prob(self, num_samples, context, seed: int = 0):
         s = self.sample(num_samples, context, seed)
@@ -133,9 +150,6 @@ def build_flow(model: str, batch_theta, batch_x, hidden_features: int = 50, num_
                embedding_net: Optional[nn.Module] = None, device="cuda:0",
                generator: Optional[torch.Generator] = None, **extra) -> FlowEstimator:
     """sbi ``build_maf`` / ``build_nsf`` ([UPSTREAM]) on the HIP engine."""
-    if embedding_net is not None and not isinstance(embedding_net, nn.Identity):
-        raise NotImplementedError("only the identity embedding net is on the HIP path in this build "
-                                  "(SURVEY.md 8a row a6 lists the FCN embedding as a later row)")
     if model not in SUPPORTED_MODELS:
         raise ValueError(f"model '{model}' is not on the HIP path; supported: {SUPPORTED_MODELS}")
     theta = torch.as_tensor(np.asarray(batch_theta.detach().cpu() if torch.is_tensor(batch_theta) else batch_theta),
@@ -149,6 +163,15 @@ def build_flow(model: str, batch_theta, batch_x, hidden_features: int = 50, num_
     if z_score_x in (None, "none", False):
         st["x_mean"], st["x_std"] = np.zeros(C, np.float32), np.ones(C, np.float32)
     perms = random_perms(D, num_transforms, generator) if model == "maf" else None
+    if embedding_net is not None and not isinstance(embedding_net, nn.Identity):
+        # sbi: C_e = embedding_net(standardised x[:1]).numel(); the flow does not standardise again
+        with torch.no_grad():
+            probe = embedding_net(((x[:2] - torch.as_tensor(st["x_mean"])) / torch.as_tensor(st["x_std"])))
+        Ce = int(probe[0].numel())
+        spec = FlowSpec(kind=model, D=D, C=Ce, H=int(hidden_features), T=int(num_transforms), K=int(num_bins),
+                        NB=int(num_blocks), perms=perms, theta_mean=st["theta_mean"], theta_std=st["theta_std"])
+        return FlowEstimator(spec, device=device, generator=generator, embedding_net=embedding_net,
+                             x_mean=st["x_mean"], x_std=st["x_std"])
     spec = FlowSpec(kind=model, D=D, C=C, H=int(hidden_features), T=int(num_transforms), K=int(num_bins),
                     NB=int(num_blocks), perms=perms, **st)
     est = FlowEstimator(spec, device=device, generator=generator)

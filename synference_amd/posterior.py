@@ -67,6 +67,17 @@ class FlowPosterior:
             self.prior = self.prior.to(device)
         return self
 
+    def _embed(self, X):
+        """raw features -> the (N, C) context the flow consumes (embedding nets run once per galaxy)."""
+        est = self.posterior_estimator
+        if not getattr(est, "has_embedding", False):
+            return _as_x2d(X, self.spec.C, self.device)
+        X = torch.as_tensor(X, dtype=torch.float32, device=self.device)
+        if X.dim() == 1:
+            X = X[None, :]
+        with torch.no_grad():
+            return est.embed(X).contiguous()
+
     def _box(self):
         if self.prior is None:
             return None, None
@@ -82,7 +93,7 @@ class FlowPosterior:
     def sample_catalogue(self, X, num_samples: int, seed: Optional[int] = None, return_counts=False):
         """(N,S,D) float32 device tensor of accepted draws for every row of X (NaN rows on failure)."""
         est = self.posterior_estimator
-        X = _as_x2d(X, self.spec.C, self.device)
+        X = self._embed(X)
         est._sync_params()
         lo, hi = self._box()
         seed = self._next_seed(seed)
@@ -115,7 +126,7 @@ class FlowPosterior:
         theta = torch.as_tensor(theta, dtype=torch.float32, device=self.device)
         if theta.dim() == 1:
             theta = theta[None, :]
-        X = _as_x2d(X, self.spec.C, self.device)
+        X = self._embed(X)
         if X.shape[0] == 1 and theta.shape[0] > 1:
             X = X.expand(theta.shape[0], -1).contiguous()
         est._sync_params()
@@ -133,7 +144,8 @@ class FlowPosterior:
     # ---- sbi surface ------------------------------------------------------------------------
     def sample(self, sample_shape=(1,), x=None, show_progress_bars=False, seed: Optional[int] = None, **_):
         S = int(np.prod(sample_shape)) if len(tuple(sample_shape)) else 1
-        x = _as_x2d(x, self.spec.C, self.device)
+        x = torch.as_tensor(x, dtype=torch.float32, device=self.device)
+        x = x[None, :] if x.dim() == 1 else x
         if x.shape[0] != 1:
             raise ValueError("sample() takes ONE observation; use sample_batched() for a catalogue")
         out = self.sample_catalogue(x, S, seed)[0]
@@ -152,7 +164,7 @@ class FlowPosterior:
         """theta (S,N,D), x (N,C) -> (S,N)."""
         theta = torch.as_tensor(theta, dtype=torch.float32, device=self.device)
         S, N, D = theta.shape
-        X = _as_x2d(x, self.spec.C, self.device)
+        X = torch.as_tensor(x, dtype=torch.float32, device=self.device)
         lp = self.log_prob_catalogue(theta.reshape(S * N, D), X.repeat(S, 1), norm_posterior)
         return lp.reshape(S, N)
 
@@ -207,7 +219,8 @@ class EnsemblePosterior:
             return self.posteriors[0].sample_catalogue(X, num_samples, self._next_seed(seed))
         p0 = self.posteriors[0]
         dev, D, S = p0.device, p0.spec.D, int(num_samples)
-        X = _as_x2d(X, p0.spec.C, dev)
+        X = torch.as_tensor(X, dtype=torch.float32, device=dev)
+        X = X[None, :] if X.dim() == 1 else X
         N = X.shape[0]
         seed = self._next_seed(seed)
         out = torch.full((N, S, D), float("nan"), dtype=torch.float32, device=dev)
@@ -222,13 +235,14 @@ class EnsemblePosterior:
             for e, post in enumerate(self.posteriors):
                 mask = (pos >= cum_d[:, e:e + 1]) & (pos < cum_d[:, e + 1:e + 2])
                 slots = torch.nonzero(mask.reshape(-1)).reshape(-1).to(torch.int32)  # bit pattern == uint32
-                _sample_slot_list(post, X[r0:r1], S, slots, seed + 0x632BE59BD9B4E019 * (r0 // rows_per),
-                                  out[r0:r1])
+                _sample_slot_list(post, post._embed(X[r0:r1]), S, slots,
+                                  seed + 0x632BE59BD9B4E019 * (r0 // rows_per), out[r0:r1])
         return out
 
     def sample(self, sample_shape=(1,), x=None, show_progress_bars=False, seed: Optional[int] = None, **_):
         S = int(np.prod(sample_shape)) if len(tuple(sample_shape)) else 1
-        x = _as_x2d(x, self.posteriors[0].spec.C, self.device)
+        x = torch.as_tensor(x, dtype=torch.float32, device=self.device)
+        x = x[None, :] if x.dim() == 1 else x
         if x.shape[0] != 1:
             raise ValueError("sample() takes ONE observation; use sample_batched() for a catalogue")
         return self.sample_catalogue(x, S, seed)[0].reshape(*tuple(sample_shape), -1)

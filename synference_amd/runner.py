@@ -91,6 +91,55 @@ class HipAdam:
         self.step_count = int(sd["step"])
 
 
+class TorchEmbeddingTrainOps:
+    """Compute backend of ``train_flow`` when an embedding net sits in front of the flow: the flow's
+    forward / backward (incl. the context gradient) still run in the HIP library through
+    ``FlowEstimator``'s autograd function; the embedding module and the optimiser step are torch's."""
+
+    def __init__(self, estimator: FlowEstimator):
+        self.est = estimator
+        self.params = [p for p in estimator.parameters() if p.requires_grad]
+
+    def loss_grad(self, flat, theta, x, scale, grad_out):
+        for p in self.params:
+            p.grad = None
+        losses = self.est.loss(theta, x)
+        (losses.sum() * scale).backward()
+        return losses.detach()
+
+    def refresh(self, flat):
+        self.est._packed_version = None
+
+    def log_prob(self, theta, x):
+        with torch.no_grad():
+            return self.est.log_prob(theta, context=x)
+
+    def make_optimizer(self, flat, lr, weight_decay, decoupled):
+        ops = self
+
+        class _Opt:
+            def __init__(s):
+                s.o = (torch.optim.AdamW if decoupled else torch.optim.Adam)(ops.params, lr=lr,
+                                                                             weight_decay=weight_decay)
+
+            def step(s, grad, max_norm):  # grads live on the parameters (autograd); `grad` is unused
+                _, world = _dist_info()
+                if world > 1:
+                    for p in ops.params:
+                        dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+                if max_norm:
+                    torch.nn.utils.clip_grad_norm_(ops.params, max_norm)
+                s.o.step()
+                ops.est._packed_version = None
+
+            def state_dict(s):
+                return s.o.state_dict()
+
+            def load_state_dict(s, sd):
+                s.o.load_state_dict(sd)
+        return _Opt()
+
+
 class HipTrainOps:
     """Compute backend of ``train_flow``: the HIP library.  (The CPU test-suite injects a test double
     with the same four methods to exercise the epoch loop and the data-parallel logic under gloo.)"""
@@ -109,6 +158,19 @@ class HipTrainOps:
 
     def make_optimizer(self, flat, lr, weight_decay, decoupled):
         return HipAdam(flat, lr=lr, weight_decay=weight_decay, decoupled=decoupled)
+
+
+def _get_state(estimator, embedded):
+    if embedded:
+        return {k: v.detach().clone() for k, v in estimator.state_dict().items()}
+    return estimator.flat.data.clone()
+
+
+def _set_state(estimator, state, embedded):
+    if embedded:
+        estimator.load_state_dict(state)
+    else:
+        estimator.flat.data.copy_(state)
 
 
 def _dist_info():
@@ -133,7 +195,9 @@ def train_flow(estimator: FlowEstimator, theta: torch.Tensor, x: torch.Tensor, *
     rank, world = _dist_info()
     dev = theta.device
     flat = estimator.flat
-    ops = ops if ops is not None else HipTrainOps(estimator)
+    embedded = bool(getattr(estimator, "has_embedding", False))
+    if ops is None:
+        ops = TorchEmbeddingTrainOps(estimator) if embedded else HipTrainOps(estimator)
     gen = torch.Generator().manual_seed(seed if seed is not None else int(time.time()))
     N = theta.shape[0]
     if val_theta is None:
@@ -168,13 +232,16 @@ def train_flow(estimator: FlowEstimator, theta: torch.Tensor, x: torch.Tensor, *
     ckpt = f"{save_dir}checkpoint_posterior.pt" if save_dir else None
     if ckpt and os.path.exists(ckpt):  # custom_runner.py:559-573
         ck = torch.load(ckpt, map_location="cpu")
-        flat.data.copy_(ck["model_state_dict"]["flat"])
+        if embedded:
+            estimator.load_state_dict(ck["model_state_dict"])
+        else:
+            flat.data.copy_(ck["model_state_dict"]["flat"])
         opt.load_state_dict(ck["optimizer_state_dict"])
         epoch, train_log, val_log = ck.get("epoch", 0), ck.get("train_loss", []), ck.get("val_loss", [])
         since, best_val = ck.get("epochs_since_improvement", 0), ck.get("best_val_loss", float("inf"))
         best_state = ck.get("best_model_state_dict", None)
         if best_state is not None:
-            best_state = best_state["flat"].to(dev)
+            best_state = ({k: v.to(dev) for k, v in best_state.items()} if embedded else best_state["flat"].to(dev))
         logger.info(f"Resumed from epoch {epoch} with best validation loss {best_val:.4f}")
 
     t0 = time.time()
@@ -187,7 +254,7 @@ def train_flow(estimator: FlowEstimator, theta: torch.Tensor, x: torch.Tensor, *
         for b in range(nb_tr):
             idx = order[b * bs_tr:(b + 1) * bs_tr]
             loss = ops.loss_grad(flat.data, theta[idx], x[idx], gscale, grad)
-            if world > 1:
+            if world > 1 and not embedded:
                 dist.all_reduce(grad, op=dist.ReduceOp.SUM)
             opt.step(grad, clip_max_norm)
             tl += loss.double().sum()
@@ -209,7 +276,7 @@ def train_flow(estimator: FlowEstimator, theta: torch.Tensor, x: torch.Tensor, *
         val_log.append(val_avg)
         if val_avg < best_val:  # custom_runner.py:655-660
             best_val, since = val_avg, 0
-            best_state = flat.data.clone()
+            best_state = _get_state(estimator, embedded)
         else:
             since += 1
         elapsed = time.time() - t0
@@ -220,13 +287,16 @@ def train_flow(estimator: FlowEstimator, theta: torch.Tensor, x: torch.Tensor, *
             on_epoch(epoch, train_avg, val_avg)
         if rank == 0 and ckpt and epoch % 10 == 0:  # custom_runner.py:690-706
             os.makedirs(os.path.dirname(ckpt) or ".", exist_ok=True)
-            torch.save({"epoch": epoch, "model_state_dict": {"flat": flat.data.cpu()},
+            torch.save({"epoch": epoch,
+                        "model_state_dict": ({k: v.cpu() for k, v in estimator.state_dict().items()} if embedded
+                                             else {"flat": flat.data.cpu()}),
                         "optimizer_state_dict": opt.state_dict(), "train_loss": train_log, "val_loss": val_log,
                         "epochs_since_improvement": since, "best_val_loss": best_val,
-                        "best_model_state_dict": None if best_state is None else {"flat": best_state.cpu()},
+                        "best_model_state_dict": None if best_state is None else (
+                            {k: v.cpu() for k, v in best_state.items()} if embedded else {"flat": best_state.cpu()}),
                         "time_elapsed": elapsed}, ckpt)
     if best_state is not None:
-        flat.data.copy_(best_state)
+        _set_state(estimator, best_state, embedded)
     ops.refresh(flat.data)
     estimator._packed_version = (flat.data_ptr(), flat._version)
     estimator.zero_grad(set_to_none=True)

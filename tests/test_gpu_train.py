@@ -73,3 +73,61 @@ def test_adam_step_matches_torch():
             assert abs(norm.item() - tn.item()) / tn.item() < 1e-5
             assert (p.cpu().double() - p_ref.detach()).abs().max() < 2e-6
         lib.sf_opt_destroy(h)
+
+
+@pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "nsf_odd", "maf_wide"])
+def test_context_gradient_matches_autograd(name):
+    """dctx = d(sum_b w_b * -log p_b)/dx, the gradient an embedding net in front of the flow receives."""
+    from synference_amd.engine import HipFlow
+    ospec, spec, flat, theta, x = make_case(name, B=70)
+    w = np.random.default_rng(3).uniform(0.5, 1.5, size=70).astype(np.float32)
+    f = HipFlow(spec, "cuda:0")
+    dctx = torch.empty(70, spec.C, device="cuda")
+    f.loss_grad(torch.as_tensor(flat), theta, x, 1.0, weights=torch.as_tensor(w), dctx_out=dctx)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    lp = OF.log_prob(ospec, torch.tensor(flat).double(), torch.as_tensor(theta).double(), xt)
+    (-(lp * torch.as_tensor(w).double()).sum()).backward()
+    ref = xt.grad.numpy()
+    err = np.abs(dctx.cpu().double().numpy() - ref).max() / max(np.abs(ref).max(), 1e-12)
+    assert err < 2e-4, err
+
+
+def test_torch_embedding_net_trains_through_the_hip_flow():
+    """Any nn.Module embedding: forward in torch, flow + context gradient in HIP, joint gradients equal
+    the oracle's (same module in fp64 in front of the oracle flow)."""
+    import copy
+    from synference_amd.estimator import build_flow
+    rng = np.random.default_rng(0)
+    B, D, C = 96, 4, 12
+    theta = rng.normal(size=(B, D)).astype(np.float32)
+    x = (rng.normal(size=(B, C)) * 3 + 1).astype(np.float32)
+    torch.manual_seed(0)
+    emb = torch.nn.Sequential(torch.nn.Linear(C, 16), torch.nn.SiLU(), torch.nn.Linear(16, 6))
+    est = build_flow("nsf", theta, x, hidden_features=24, num_transforms=2, num_bins=6,
+                     embedding_net=copy.deepcopy(emb), device="cuda:0",
+                     generator=torch.Generator().manual_seed(1)).to("cuda")
+    assert est.spec.C == 6 and est.has_embedding
+    losses = est.loss(torch.as_tensor(theta).cuda(), torch.as_tensor(x).cuda())
+    losses.mean().backward()
+    # oracle twin
+    s = est.spec
+    ospec = OF.FlowSpec(kind="nsf", D=D, C=6, H=24, T=2, K=6, theta_mean=s.theta_mean.astype(np.float64),
+                        theta_std=s.theta_std.astype(np.float64))
+    emb64 = copy.deepcopy(emb).double()
+    p = est.flat.detach().cpu().double().requires_grad_(True)
+    xs = (torch.as_tensor(x).double() - est.x_mean_raw.cpu().double()) / est.x_std_raw.cpu().double()
+    ref_loss = -OF.log_prob(ospec, p, torch.as_tensor(theta).double(), emb64(xs))
+    ref_loss.mean().backward()
+    assert (losses.detach().cpu().double() - ref_loss.detach()).abs().max() < 1e-4
+    g = est.flat.grad.cpu().double()
+    assert (g - p.grad).abs().max() < 2e-4 * p.grad.abs().max()
+    for (n, q), (_, r) in zip(est.embedding_net.named_parameters(), emb64.named_parameters()):
+        assert (q.grad.cpu().double() - r.grad).abs().max() < 2e-4 * max(r.grad.abs().max().item(), 1e-9), n
+    # and the runner trains it (generic autograd path) and samples through it
+    from synference_amd.posterior import FlowPosterior
+    from synference_amd.runner import train_flow
+    out = train_flow(est, torch.as_tensor(theta).cuda(), torch.as_tensor(x).cuda(), batch_size=32,
+                     learning_rate=5e-3, stop_after_epochs=3, max_num_epochs=6, seed=0, log_every=0)
+    assert out["training_loss"][-1] < out["training_loss"][0]
+    smp = FlowPosterior(est, None).sample_catalogue(x[:5], 40, seed=1)
+    assert smp.shape == (5, 40, D) and torch.isfinite(smp).all()
