@@ -193,6 +193,31 @@ int sf_adam_apply(float* params, const float* grad, float* exp_avg, float* exp_a
  * device pointers [n] and the step counter. */
 int sf_opt_state(sf_opt* o, float** exp_avg, float** exp_avg_sq, int64_t** step_host);
 
+/* ---- embedding MLP (context path) ---------------------------------------------------------
+ * The optional fully connected embedding net in front of the flow ([UPSTREAM] ili FCN(n_hidden,
+ * act_fn="SiLU"): Linear -> act -> ... -> Linear, no activation after the last layer; mentioned at
+ * ref: examples/sbi/scripts/train_spectral_model.py:316-317, passed as the embedding_net kwarg,
+ * ref: sbi_runner.py:4432).  Flat parameter layout: per layer W[out,in] row-major then b[out]. */
+typedef struct sf_mlp sf_mlp;
+enum sf_act { SF_ACT_SILU = 0, SF_ACT_RELU = 1, SF_ACT_TANH = 2 };
+typedef struct sf_mlp_desc {
+  int32_t n_in;        /* input width, 1..512 */
+  int32_t n_layers;    /* 1..4 */
+  int32_t widths[4];   /* output width of each layer, 1..128 */
+  int32_t act;         /* sf_act */
+  const float* x_mean; /* host [n_in] or NULL: inputs are standardised as (x - mean)/std in-kernel */
+  const float* x_std;  /* host [n_in] or NULL */
+} sf_mlp_desc;
+int sf_mlp_create(const sf_mlp_desc* d, sf_mlp** out);
+void sf_mlp_destroy(sf_mlp* m);
+int64_t sf_mlp_num_params(const sf_mlp* m);
+/* out[b,:] = MLP(x[b,:]) with the parameters in `flat` (device) */
+int sf_mlp_forward(sf_mlp* m, const float* flat, const float* x /*[B,n_in]*/, int64_t B,
+                   float* out /*[B,n_out]*/, void* stream);
+/* grad[i] = sum_b dout[b,:] . d out[b,:] / d flat[i]   (overwritten) */
+int sf_mlp_backward(sf_mlp* m, const float* flat, const float* x, const float* dout /*[B,n_out]*/,
+                    int64_t B, float* grad /*[P]*/, void* stream);
+
 /* ---- misc --------------------------------------------------------------------------- */
 const char* sf_last_error(void);
 const char* sf_version(void);

@@ -29,6 +29,11 @@ class sf_flow_desc(C.Structure):
     ]
 
 
+class sf_mlp_desc(C.Structure):
+    _fields_ = [("n_in", C.c_int32), ("n_layers", C.c_int32), ("widths", C.c_int32 * 4), ("act", C.c_int32),
+                ("x_mean", c_f32p), ("x_std", c_f32p)]
+
+
 class sf_adam_desc(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("weight_decay", C.c_float), ("decoupled", C.c_int32)]
@@ -66,6 +71,12 @@ PROTOTYPES = {
                                 C.POINTER(sf_adam_desc), C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
     "sf_opt_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                C.POINTER(C.POINTER(C.c_int64))]),
+    "sf_mlp_create": (C.c_int, [C.POINTER(sf_mlp_desc), C.POINTER(C.c_void_p)]),
+    "sf_mlp_destroy": (None, [C.c_void_p]),
+    "sf_mlp_num_params": (C.c_int64, [C.c_void_p]),
+    "sf_mlp_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "sf_mlp_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                  C.c_void_p]),
     "sf_last_error": (C.c_char_p, []),
     "sf_version": (C.c_char_p, []),
     "sf_device_count": (C.c_int, []),

@@ -289,6 +289,10 @@ int sf_flow_loss_grad(sf_flow* f, const float* flat, const float* theta, const f
   return sf_flow_loss_grad_weighted(f, flat, theta, x, B, grad_scale, nullptr, loss, grad, nullptr, stream);
 }
 
+}  // extern "C"
+void sf_set_error(const std::string& msg) { g_err = msg; }
+extern "C" {
+
 struct sf_opt {
   int64_t n = 0;
   sf_adam_desc d{};

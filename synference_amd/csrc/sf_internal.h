@@ -32,6 +32,9 @@ hipError_t sf_launch_pack(const float* flat, const int32_t* s1, const int32_t* s
 hipError_t sf_launch_fill_nan_rows(float* out, const uint32_t* slots, long n, int D, hipStream_t st);
 hipError_t sf_launch_fill_i32(int32_t* p, long n, int32_t v, hipStream_t st);
 
+#include <string>
+void sf_set_error(const std::string& msg);  // thread-local message behind sf_last_error()
+
 // ---- the handle (shared by sf_api.hip and sf_train.hip) -------------------------------------
 struct sf_flow {
   SfLayout L;

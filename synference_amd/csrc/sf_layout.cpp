@@ -417,3 +417,58 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
   }
   return true;
 }
+
+// =============================================================================================
+// embedding MLP
+// =============================================================================================
+bool sf_build_mlp_layout(const sf_mlp_desc& d, SfMlpLayout& L) {
+  auto fail = [&](const std::string& m) { L.error = m; return false; };
+  if (d.n_in < 1 || d.n_in > 512) return fail("n_in must be in 1..512");
+  if (d.n_layers < 1 || d.n_layers > SF_MLP_LMAX) return fail("n_layers must be in 1..4");
+  if (d.act < 0 || d.act > 2) return fail("unknown activation");
+  int wmax = 0;
+  for (int l = 0; l < d.n_layers; ++l) {
+    if (d.widths[l] < 1 || d.widths[l] > 128) return fail("layer widths must be in 1..128");
+    wmax = std::max(wmax, d.widths[l]);
+  }
+  SfMlpDev& v = L.dev;
+  std::memset(&v, 0, sizeof(v));
+  v.n_in = d.n_in; v.L = d.n_layers; v.act = d.act; v.n_out = d.widths[d.n_layers - 1];
+  v.HT = ceil_div(wmax, 32);
+  L.cst.assign(2 * ((d.n_in + 3) / 4) * 4, 1.f);
+  for (int i = 0; i < d.n_in; ++i) {
+    L.cst[i] = d.x_mean ? d.x_mean[i] : 0.f;
+    L.cst[((d.n_in + 3) / 4) * 4 + i] = d.x_std ? d.x_std[i] : 1.f;
+  }
+  std::vector<int32_t> gidx;
+  Emitter E{L.src1, L.src2, &gidx};
+  Emitter ET{L.srcT1, L.srcT2, nullptr};
+  int64_t P = 0;
+  int in_w = d.n_in;
+  for (int l = 0; l < d.n_layers; ++l) {
+    const int out_w = d.widths[l];
+    v.width[l] = out_w;
+    v.nG[l] = ceil_div(in_w, 8);
+    v.nGo[l] = ceil_div(out_w, 8);
+    const int64_t lW = P, lb = lW + (int64_t)out_w * in_w;
+    P = lb + out_w;
+    E.pad_to(64);
+    v.o_w[l] = (int)E.linear(v.HT, v.nG[l], iota_rows(out_w, v.HT * 32), iota_rows(in_w, v.nG[l] * 8), lW, in_w, 1, nullptr);
+    v.o_b[l] = (int)E.bias(v.HT, iota_rows(out_w, v.HT * 32), lb, -1);
+    if (l > 0) {  // delta_in = W^T delta_out : rows = previous layer's units, K = this layer's outputs
+      ET.pad_to(64);
+      v.oT_w[l] = (int)ET.linear(v.HT, v.nGo[l], iota_rows(in_w, v.HT * 32), iota_rows(out_w, v.nGo[l] * 8), lW, 1,
+                                 in_w, nullptr);
+    }
+    in_w = out_w;
+  }
+  E.pad_to(64);
+  ET.pad_to(64);
+  L.n_packed = E.cur;
+  L.n_packedT = ET.cur;
+  L.n_params = P;
+  L.gdst.assign((size_t)P, -1);
+  for (int64_t i = 0; i < E.cur; ++i)
+    if (L.src1[i] >= 0) L.gdst[L.src1[i]] = gidx[i];
+  return true;
+}

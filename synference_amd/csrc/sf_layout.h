@@ -82,3 +82,24 @@ static inline int sf_tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 
 
 // Builds tables; returns false and sets L.error on unsupported shapes.
 bool sf_build_layout(const sf_flow_desc& d, SfLayout& L);
+
+// ---- embedding MLP ---------------------------------------------------------------------------
+#define SF_MLP_LMAX 4
+struct SfMlpDev {
+  const float* packed;
+  const float* packedT;
+  const float* cst;  // [x_mean n_in][x_std n_in]
+  int n_in, n_out, L, act, HT;
+  int nG[SF_MLP_LMAX];     // input groups of layer l
+  int nGo[SF_MLP_LMAX];    // groups covering layer l's outputs (transposed operand K)
+  int width[SF_MLP_LMAX];
+  int o_w[SF_MLP_LMAX], o_b[SF_MLP_LMAX], oT_w[SF_MLP_LMAX];
+};
+struct SfMlpLayout {
+  SfMlpDev dev;
+  int64_t n_params = 0, n_packed = 0, n_packedT = 0;
+  std::vector<int32_t> src1, src2, srcT1, srcT2, gdst;
+  std::vector<float> cst;
+  std::string error;
+};
+bool sf_build_mlp_layout(const sf_mlp_desc& d, SfMlpLayout& L);

@@ -165,9 +165,16 @@ def build_flow(model: str, batch_theta, batch_x, hidden_features: int = 50, num_
     perms = random_perms(D, num_transforms, generator) if model == "maf" else None
     if embedding_net is not None and not isinstance(embedding_net, nn.Identity):
         # sbi: C_e = embedding_net(standardised x[:1]).numel(); the flow does not standardise again
-        with torch.no_grad():
-            probe = embedding_net(((x[:2] - torch.as_tensor(st["x_mean"])) / torch.as_tensor(st["x_std"])))
-        Ce = int(probe[0].numel())
+        from .embedding import FCN
+        if isinstance(embedding_net, FCN):
+            if embedding_net.n_input is None:
+                embedding_net.initialize(C)
+            Ce = embedding_net.n_hidden[-1]
+        else:
+            with torch.no_grad():
+                pdev = next(iter(embedding_net.parameters()), torch.zeros(1)).device
+                probe = embedding_net(((x[:2] - torch.as_tensor(st["x_mean"])) / torch.as_tensor(st["x_std"])).to(pdev))
+            Ce = int(probe[0].numel())
         spec = FlowSpec(kind=model, D=D, C=Ce, H=int(hidden_features), T=int(num_transforms), K=int(num_bins),
                         NB=int(num_blocks), perms=perms, theta_mean=st["theta_mean"], theta_std=st["theta_std"])
         return FlowEstimator(spec, device=device, generator=generator, embedding_net=embedding_net,

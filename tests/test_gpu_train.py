@@ -131,3 +131,55 @@ def test_torch_embedding_net_trains_through_the_hip_flow():
     assert out["training_loss"][-1] < out["training_loss"][0]
     smp = FlowPosterior(est, None).sample_catalogue(x[:5], 40, seed=1)
     assert smp.shape == (5, 40, D) and torch.isfinite(smp).all()
+
+
+@pytest.mark.parametrize("widths,act,n_in", [([32, 16], "SiLU", 10), ([64, 50, 8], "ReLU", 37), ([20], "Tanh", 5),
+                                              ([100, 64, 32, 12], "SiLU", 70)])
+def test_hip_fcn_forward_backward_match_torch(widths, act, n_in):
+    """The HIP embedding MLP vs the same MLP in torch fp64 (ili FCN semantics: no activation after the last layer)."""
+    from synference_amd.embedding import FCN
+    g = torch.Generator().manual_seed(0)
+    m = FCN(widths, act, n_input=n_in, generator=g).to("cuda")
+    x = torch.randn(75, n_in, generator=g) * 2
+    layers, n_prev = [], n_in
+    T = m.named_tensors()
+    for l, w in enumerate(widths):
+        lin = torch.nn.Linear(n_prev, w).double()
+        lin.weight.data.copy_(T[f"layers.{l}.weight"].cpu().double()); lin.bias.data.copy_(T[f"layers.{l}.bias"].cpu().double())
+        layers.append(lin)
+        if l + 1 < len(widths):
+            layers.append({"SiLU": torch.nn.SiLU(), "ReLU": torch.nn.ReLU(), "Tanh": torch.nn.Tanh()}[act])
+        n_prev = w
+    ref = torch.nn.Sequential(*layers)
+    out = m(x.cuda())
+    rout = ref(x.double())
+    assert out.shape == (75, widths[-1])
+    assert (out.cpu().double() - rout).abs().max() < 1e-4 * max(1.0, rout.abs().max().item())
+    gout = torch.randn(75, widths[-1], generator=g)
+    (out * gout.cuda()).sum().backward()
+    (rout * gout.double()).sum().backward()
+    lay, _ = m.layout()
+    gflat = m.flat.grad.cpu().double()
+    for name, shape, off in lay:
+        l = int(name.split(".")[1])
+        lin = [q for q in ref if isinstance(q, torch.nn.Linear)][l]
+        rg = (lin.weight.grad if name.endswith("weight") else lin.bias.grad).reshape(-1)
+        k = rg.numel()
+        assert (gflat[off:off + k] - rg).abs().max() < 2e-4 * max(rg.abs().max().item(), 1e-9), name
+
+
+def test_hip_fcn_embedding_in_front_of_the_flow_end_to_end():
+    from synference_amd import FCN, SBI_Fitter
+    from synference_amd.synthetic import make_catalogue
+    x, theta, names = make_catalogue(3000, 10, 5, seed=5)
+    f = SBI_Fitter("fcn", names, [f"F{i}" for i in range(10)], feature_array=x, parameter_array=theta)
+    post, stats = f.run_single_sbi(model_type="maf", hidden_features=50, num_transforms=3, training_batch_size=256,
+                                   learning_rate=2e-3, stop_after_epochs=2, max_num_epochs=8, random_seed=2,
+                                   save_model=False, verbose=False, embedding_net=FCN([32, 8]))
+    est = post.posteriors[0].posterior_estimator
+    assert est.has_embedding and est.spec.C == 8
+    assert stats[0]["training_loss"][-1] < stats[0]["training_loss"][0] - 0.3
+    s = f.sample_posterior(f._X_test[:8], num_samples=64, seed=1)
+    assert s.shape == (8, 64, 5) and np.isfinite(s).all()
+    lp = f.log_prob(f._X_test[:8], f._y_test[:8], norm_posterior=False)
+    assert np.isfinite(lp).all()
