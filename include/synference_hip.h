@@ -218,6 +218,13 @@ int sf_mlp_forward(sf_mlp* m, const float* flat, const float* x /*[B,n_in]*/, in
 int sf_mlp_backward(sf_mlp* m, const float* flat, const float* x, const float* dout /*[B,n_out]*/,
                     int64_t B, float* grad /*[P]*/, void* stream);
 
+/* ---- posterior summaries on the device ---------------------------------------------------
+ * out[g,d,k] = quantile q[k] (numpy 'linear' rule) of samples[g,:,d], NaN draws ignored (all NaN -> NaN).
+ * Replaces np.quantile(samples_i, quantiles, axis=1) of fit_catalogue (ref: sbi_runner.py:3270-3282)
+ * without moving the (N,S,D) draws to the host.  q: DEVICE [Q]; 1 <= S <= 8192. */
+int sf_quantiles(const float* samples /*[N,S,D]*/, int64_t N, int64_t S, int32_t D,
+                 const float* q /*[Q]*/, int32_t Q, float* out /*[N,D,Q]*/, void* stream);
+
 /* ---- misc --------------------------------------------------------------------------- */
 const char* sf_last_error(void);
 const char* sf_version(void);

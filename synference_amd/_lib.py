@@ -77,6 +77,8 @@ PROTOTYPES = {
     "sf_mlp_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "sf_mlp_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                   C.c_void_p]),
+    "sf_quantiles": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                               C.c_void_p]),
     "sf_last_error": (C.c_char_p, []),
     "sf_version": (C.c_char_p, []),
     "sf_device_count": (C.c_int, []),

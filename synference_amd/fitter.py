@@ -216,7 +216,8 @@ class SBI_Fitter:
 
     def fit_catalogue(self, observations, columns_to_feature_names: dict = None, num_samples: int = 1000,
                       quantiles=(0.16, 0.5, 0.84), sample_method: str = "direct", append_to_input: bool = True,
-                      return_samples: bool = False, log_times: bool = False, seed: Optional[int] = None, **unused):
+                      return_samples: bool = False, log_times: bool = False, seed: Optional[int] = None,
+                      device_quantiles: bool = True, **unused):
         """Sampling + quantile section of the reference's fit_catalogue (sbi_runner.py:3230-3282).
 
         ``observations`` is a pandas DataFrame / dict of columns / (N, C) array already expressed in the
@@ -237,6 +238,20 @@ class SBI_Fitter:
             raise ValueError(f"observations lack the feature columns {missing}")
         feats = df[cols].to_numpy(dtype=np.float32)
         obs_mask = ~np.isfinite(feats).all(1)
+        if device_quantiles and not return_samples and num_samples <= 8192:
+            # f3: quantiles reduced on the GPU; only (N, D, Q) floats cross PCIe
+            from .posterior import device_quantiles as _dq
+            table = df.copy() if append_to_input else pd.DataFrame({"ID": np.arange(len(df)) + 1})
+            qarr = np.full((len(df), len(self.fitted_parameter_names), len(quantiles)), np.nan)
+            if (~obs_mask).any():
+                if sample_method != "direct":
+                    raise ValueError("Invalid sample method for the HIP backend. Use 'direct'.")
+                s_dev = self.posteriors.sample_catalogue(torch.as_tensor(feats[~obs_mask]), num_samples, seed)
+                qarr[~obs_mask] = _dq(s_dev, quantiles).double().cpu().numpy()
+            for i, param in enumerate(self.simple_fitted_parameter_names):
+                for j, qv in enumerate(quantiles):
+                    table[f"{param}_{int(qv * 100)}"] = qarr[:, i, j]
+            return table
         samples = np.full((len(df), num_samples, len(self.fitted_parameter_names)), np.nan)
         if (~obs_mask).any():
             samples[~obs_mask] = self.sample_posterior(feats[~obs_mask], sample_method=sample_method,

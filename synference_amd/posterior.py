@@ -264,6 +264,23 @@ class EnsemblePosterior:
         return self.log_prob_catalogue(theta, x, norm_posterior=False)
 
 
+def device_quantiles(samples: torch.Tensor, quantiles) -> torch.Tensor:
+    """(N,S,D) float32 device draws -> (N,D,Q) quantiles on the device (sf_quantiles; numpy 'linear' rule,
+    NaN draws ignored).  Counterpart of the host pass at ref: sbi_runner.py:3270-3282."""
+    import ctypes as C
+    from . import _lib
+    if samples.device.type != "cuda":
+        raise RuntimeError("device_quantiles needs the draws on the GPU")
+    samples = samples.contiguous().float()
+    N, S, D = samples.shape
+    q = torch.as_tensor(np.asarray(quantiles, dtype=np.float32), device=samples.device)
+    out = torch.empty((N, D, q.numel()), dtype=torch.float32, device=samples.device)
+    st = C.c_void_p(torch.cuda.current_stream(samples.device).cuda_stream)
+    _lib.check(_lib.load().sf_quantiles(C.c_void_p(samples.data_ptr()), N, S, D, C.c_void_p(q.data_ptr()), q.numel(),
+                                        C.c_void_p(out.data_ptr()), st))
+    return out
+
+
 def _sample_slot_list(post: FlowPosterior, X, S: int, slots: torch.Tensor, seed: int, out: torch.Tensor):
     """Rejection rounds over an explicit slot list (ensemble members own disjoint slot sets)."""
     n = int(slots.numel())

@@ -158,3 +158,30 @@ def test_nsf_fit_and_ensemble_sampling_match_oracle(tmp_path):
     rlp = OP.ensemble_log_prob([o1, o2], [torch.as_tensor(fl1), torch.as_tensor(fl2)], [0.3, 0.7],
                                ref[:, 0].astype(np.float32), xx, lo, hi)
     assert np.abs(lp - rlp).max() < 2e-4
+
+
+def test_device_quantiles_match_numpy(fitted):
+    from synference_amd.posterior import device_quantiles
+    rng = np.random.default_rng(0)
+    for S in (1, 7, 1000, 1024, 3000):
+        a = rng.normal(size=(6, S, 3)).astype(np.float32)
+        if S >= 7:
+            a[1, :3, 0] = np.nan          # a few NaN draws: ignored
+            a[2, :, 1] = np.nan           # all NaN -> NaN
+        got = device_quantiles(torch.as_tensor(a).cuda(), [0.16, 0.5, 0.84]).cpu().numpy()
+        with np.errstate(all="ignore"):
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                ref = np.nanquantile(a.astype(np.float64), [0.16, 0.5, 0.84], axis=1).transpose(1, 2, 0)
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        assert np.nanmax(np.abs(got - ref)) < 2e-6 * max(1.0, np.nanmax(np.abs(ref)))
+    # the fitter's two routes agree
+    f = fitted[0]
+    import pandas as pd
+    df = pd.DataFrame(f._X_test[:12], columns=f.feature_names)
+    t_dev = f.fit_catalogue(df, num_samples=500, seed=4, device_quantiles=True)
+    t_host = f.fit_catalogue(df, num_samples=500, seed=4, device_quantiles=False)
+    for c in t_dev.columns:
+        if c.endswith(("_16", "_50", "_84")):
+            assert np.allclose(t_dev[c].to_numpy(), t_host[c].to_numpy(), rtol=1e-5, atol=1e-5), c
