@@ -53,7 +53,7 @@ def executed_mfma_flops_per_draw(d):
     if d["inc_ok"] and NB <= 2:
         steps = HT * d["nGc"]                                           # hoisted context product
         steps += sum(d["nGu"] + NB * d["g_kend"][p - 1] for p in range(2, D + 1))   # one hidden tile per pass
-        steps += sum(d["g_kend"][p - 1] if p >= 2 else 0 for p in range(1, D + 1))  # head per pass
+        # (the two head rows per pass are VALU dot products, not MFMA)
     else:
         steps = D * (HT * (d["nGu"] + d["nGc"]) + NB * sum(d["mt_kend"][:HT]) + d["nGh"])
     return T * steps * 4 * (32 * 32 * 2) * 2 / 32.0

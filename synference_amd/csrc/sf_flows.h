@@ -133,7 +133,8 @@ struct MafOps {
   // groups of degree <= p-1; everything of lower degree is already final and is kept in registers.
   // Masked weights are structural zeros, so every value that the D full passes would end with is
   // produced by the identical fma chain: results are bit-identical to inverse_full.
-  // The context product (b0 + bc + Wc e) is hoisted out of the passes.
+  // The context product (b0 + bc + Wc e) is hoisted out of the passes; the two head rows needed per
+  // pass are VALU dot products (so the head differs from inverse_full by fp32 summation order only).
   static __device__ __forceinline__ void inverse_incremental(const SfDev& m, float (&u)[NS][SF_DMAX],
                                                              const float* const (&xr)[NS],
                                                              float (&logdet)[NS], int lane, float* lds = nullptr) {
@@ -161,11 +162,9 @@ struct MafOps {
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns) ldl[ns] = 0.f;
       for (int p = 1; p <= m.D; ++p) {
-        int kprev = 0;
         if (p >= 2) {
           const int tile = m.g_tile[p - 1];
           const int kend = m.g_kend[p - 1];
-          kprev = kend;
           f32x16 ut[1][NS];
           sf_build_u_tile<NS>(ut, w, h);
 #pragma unroll
@@ -189,25 +188,40 @@ struct MafOps {
             }
           }
         }
-        f32x16 fin[1][NS];
-        sf_init_bias<1, NS>(fin, tp + m.o_bf, h);
-        // head over the final block's activations of degree <= p-1
-        if (m.NB == 1) sf_mm_acc<1, NS, HT, false>(fin, act[1], tp + m.o_wf, m.nGh, 0, kprev, lane);
-        else sf_mm_acc<1, NS, HT, false>(fin, act[2], tp + m.o_wf, m.nGh, 0, kprev, lane);
-        // only the dimension of degree p becomes final in this pass
+        // head: only the (a, m) rows of the dimension that becomes final in this pass are needed, so
+        // instead of a 32-row MFMA tile they are two dot products over the lane's own activation
+        // registers (each row half holds half of the hidden units; weights broadcast from the image)
         const int slot = (int)m.cst[m.c_dslot + t * SF_DMAX + (p - 1)];
+        const float* hv = tp + m.o_hv + (size_t)slot * 4 * (HT * 16) + h * (HT * 16);
+        float pa[NS], pm[NS];
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) pa[ns] = pm[ns] = 0.f;
+        if (p >= 2) {
+#pragma unroll
+          for (int mt = 0; mt < HT; ++mt)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+              const float4 wa = *reinterpret_cast<const float4*>(hv + mt * 16 + q4 * 4);
+              const float4 wm = *reinterpret_cast<const float4*>(hv + 2 * (HT * 16) + mt * 16 + q4 * 4);
+#pragma unroll
+              for (int ns = 0; ns < NS; ++ns) {
+                const f32x16& av = (m.NB == 1) ? act[1][mt][ns] : act[2][mt][ns];
+                pa[ns] += wa.x * av[q4 * 4] + wa.y * av[q4 * 4 + 1] + wa.z * av[q4 * 4 + 2] + wa.w * av[q4 * 4 + 3];
+                pm[ns] += wm.x * av[q4 * 4] + wm.y * av[q4 * 4 + 1] + wm.z * av[q4 * 4 + 2] + wm.w * av[q4 * 4 + 3];
+              }
+            }
+        }
+        const float ba = tp[m.o_hvb + 2 * slot], bm = tp[m.o_hvb + 2 * slot + 1];
 #pragma unroll
         for (int q = 0; q < SF_DMAX; ++q) {
           if (q == slot) {
 #pragma unroll
             for (int ns = 0; ns < NS; ++ns) {
-              const float s = scale(m, fin[0][ns][2 * (q >> 1)]);
-              const float val = sf_div(u[ns][q] - fin[0][ns][2 * (q >> 1) + 1], s);
-              const bool mine = (h == (q & 1));
-              const float oth = sf_xhalf(val);
-              w[ns][q] = mine ? val : oth;
-              const float ld = mine ? sf_log(s) : 0.f;
-              ldl[ns] += ld + sf_xhalf(ld);
+              const float av = ba + pa[ns] + sf_xhalf(pa[ns]);
+              const float mv = bm + pm[ns] + sf_xhalf(pm[ns]);
+              const float s = scale(m, av);
+              w[ns][q] = sf_div(u[ns][q] - mv, s);
+              ldl[ns] += sf_log(s);
             }
           }
         }

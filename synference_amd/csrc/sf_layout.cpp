@@ -256,6 +256,26 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
       if (t == 0) v.o_wf = o;
       o = (int)(E.bias(1, frow, lbf, -1) - tb);
       if (t == 0) v.o_bf = o;
+      // head rows once more, laid out for a per-lane dot product (incremental inverse): for physical
+      // slot q the (a, m) rows, split by row half h, indexed like the lane's activation registers
+      {
+        int64_t s0 = E.pad_to(4);
+        if (t == 0) v.o_hv = (int)(s0 - tb);
+        for (int q = 0; q < D; ++q)
+          for (int ab = 0; ab < 2; ++ab)
+            for (int h = 0; h < 2; ++h)
+              for (int mt = 0; mt < HT; ++mt)
+                for (int r = 0; r < 16; ++r) {
+                  const int unit = hrow_full[mt * 32 + sf_tile_row(r, h)];
+                  const int orow_l = 2 * sinv[q] + ab;
+                  const bool on = unit >= 0 && (orow_l / 2 + 1) > deg_h(unit);
+                  E.push(on ? (int32_t)(lWf + (int64_t)orow_l * H + unit) : -1, -1);
+                }
+        int64_t s1 = E.pad_to(4);
+        if (t == 0) v.o_hvb = (int)(s1 - tb);
+        for (int q = 0; q < D; ++q)
+          for (int ab = 0; ab < 2; ++ab) E.push((int32_t)(lbf + 2 * sinv[q] + ab), -1);
+      }
       // ---- transposed operands for the data-gradient pass: delta_in = W^T delta_out ----
       {
         const int64_t tbT = ET.pad_to(64);
@@ -412,8 +432,8 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
   L.n_params = P;
   L.gdst.assign((size_t)P, -1);
   for (int64_t i = 0; i < E.cur; ++i) {
-    if (L.src1[i] >= 0) L.gdst[L.src1[i]] = gidx[i];
-    if (L.src2[i] >= 0) L.gdst[L.src2[i]] = gidx[i];
+    if (L.src1[i] >= 0 && L.gdst[L.src1[i]] < 0) L.gdst[L.src1[i]] = gidx[i];  // first image copy owns the gradient
+    if (L.src2[i] >= 0 && L.gdst[L.src2[i]] < 0) L.gdst[L.src2[i]] = gidx[i];
   }
   return true;
 }

@@ -38,6 +38,7 @@ struct SfDev {
   int o_w0, o_wc, o_b0;                  // MAF initial (u part, context part, b0+bc)
   int o_wk[SF_NBMAX], o_bk[SF_NBMAX];    // MAF hidden blocks
   int o_wf, o_bf;                        // MAF final
+  int o_hv, o_hvb;                       // MAF head rows for the VALU form: [slot][a|m][half][HT*16], bias [slot][a|m]
   int o_winu, o_winc, o_bin;             // NSF initial
   int o_wg[SF_NBMAX], o_bg[SF_NBMAX];    // NSF GLU gate
   int o_w1[SF_NBMAX], o_b1[SF_NBMAX], o_w2[SF_NBMAX], o_b2[SF_NBMAX];
