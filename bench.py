@@ -37,6 +37,10 @@ WORKLOADS = {
     # BASELINE configs[2]: NSF (8 bins) on the 100k-galaxy 20-filter mock
     "nsf_cfg3": dict(kind="nsf", D=8, C=20, K=8, n_lib=100_000, galaxies=20000, f_draw=148_640.0, f_gal=30_000.0,
                      f_lp=178_640.0, label="BASELINE configs[2]: NPE NSF T=5 H=50 K=8 on 100k-galaxy 20-filter mock"),
+    # the reference's own production model (examples/sbi/configs/best_params.yaml: NSF, 15 transforms, 69 hidden;
+    # the model behind the published 0.047 s/object H100 timing) on the cfg3-shaped mock
+    "nsf_prod": dict(kind="nsf", D=8, C=20, K=10, n_lib=100_000, galaxies=1000, f_draw=0.0, f_gal=0.0, f_lp=0.0,
+                     H=69, T=15, label="reference production NSF (T=15, H=69, K=10) on the 20-filter mock"),
 }
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA (= vector) dense peak
 
@@ -178,8 +182,8 @@ def main():
     tr = idx[: int(0.8 * len(idx))]
     prior = prior_from_parameters(th_lib[tr], names)
     gen = torch.Generator().manual_seed(42)
-    est = build_flow(wl["kind"], th_lib[tr], x_lib[tr], hidden_features=50, num_transforms=5, num_bins=wl["K"],
-                     device=dev, generator=gen).to(dev)
+    est = build_flow(wl["kind"], th_lib[tr], x_lib[tr], hidden_features=wl.get("H", 50),
+                     num_transforms=wl.get("T", 5), num_bins=wl["K"], device=dev, generator=gen).to(dev)
     flow = est.flow
     flat = est.flat.data
     Xtr = torch.as_tensor(x_lib[tr]).to(dev)

@@ -112,7 +112,7 @@ int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen) {
   add("o_wout", v.o_wout); add("o_bout", v.o_bout); add("o_lu", v.o_lu);
   add("c_pscale", v.c_pscale); add("c_pshift", v.c_pshift); add("c_tdim", v.c_tdim);
   add("c_xmean", v.c_xmean); add("c_xstd", v.c_xstd); add("c_dslot", v.c_dslot);
-  add("inc_ok", v.inc_ok);
+  add("inc_ok", v.inc_ok); add("n_parts", v.n_parts); add("part_max", v.part_max);
   add("n_params", f->L.n_params); add("n_packed", f->L.n_packed);
   s += "\"g_kend\": [";
   for (int i = 0; i < SF_DMAX; ++i) s += std::to_string(v.g_kend[i]) + (i + 1 < SF_DMAX ? ", " : "], ");

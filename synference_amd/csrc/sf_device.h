@@ -40,16 +40,21 @@ __device__ __forceinline__ float sf_xhalf(float v) {  // value held by the other
 // wave of the (512-thread) workgroup reads its MFMA A operands from there with ds_read_b128;
 // otherwise weights stream from L2.  Must be called by every thread of the workgroup.
 template <bool LDSW>
-__device__ __forceinline__ const float* sf_stage(const SfDev& m, int t, float* lds) {
+__device__ __forceinline__ const float* sf_stage_part(const SfDev& m, int t, int part, float* lds) {
   const float* src = m.packed + (size_t)t * m.t_stride;
   if (!LDSW) return src;
-  __syncthreads();  // previous transform's image no longer in use
-  const float4* __restrict__ s4 = reinterpret_cast<const float4*>(src);
+  const int lo = m.part_off[part], hi = m.part_off[part + 1];
+  __syncthreads();  // previous image no longer in use
+  const float4* __restrict__ s4 = reinterpret_cast<const float4*>(src + lo);
   float4* __restrict__ d4 = reinterpret_cast<float4*>(lds);
-  const int n4 = m.t_stride >> 2;
+  const int n4 = (hi - lo) >> 2;
   for (int i = threadIdx.x; i < n4; i += blockDim.x) d4[i] = s4[i];
   __syncthreads();
-  return lds;
+  return lds - lo;  // so that (returned + block offset) lands inside the staged part
+}
+template <bool LDSW>
+__device__ __forceinline__ const float* sf_stage(const SfDev& m, int t, float* lds) {
+  return sf_stage_part<LDSW>(m, t, 0, lds);
 }
 
 // ---- accumulator init from the bias image [mt][h][16] ------------------------------------

@@ -499,11 +499,14 @@ struct SfSplineBwd {
 template <int HT, int PT, int NS, bool LDSW = false>
 struct NsfOps {
   // ResidualNet conditioner -> hidden tiles
-  static __device__ __forceinline__ void resnet(const SfDev& m, const float* __restrict__ tp,
-                                                const float (&u)[NS][SF_DMAX],
-                                                const float* const (&xr)[NS], f32x16 (&hid)[HT][NS],
-                                                int lane) {
+  // returns the (possibly LDS) base pointer valid for the spline head
+  static __device__ __forceinline__ const float* resnet(const SfDev& m, int t, float* lds, const float* tp0,
+                                                        const float (&u)[NS][SF_DMAX],
+                                                        const float* const (&xr)[NS], f32x16 (&hid)[HT][NS],
+                                                        int lane) {
     const int h = lane >> 5;
+    int part = 0;
+    const float* tp = tp0;  // part 0 was staged by the caller
     sf_init_bias<HT, NS>(hid, tp + m.o_bin, h);
     {
       f32x16 ut[1][NS];
@@ -514,6 +517,10 @@ struct NsfOps {
 #pragma unroll
     for (int k = 0; k < SF_NBMAX; ++k) {
       if (k < m.NB) {
+        if (LDSW && m.blk_part[k] != part) {
+          part = m.blk_part[k];
+          tp = sf_stage_part<LDSW>(m, t, part, lds);
+        }
         f32x16 t2[HT][NS];
         {
           f32x16 t1[HT][NS];
@@ -536,6 +543,8 @@ struct NsfOps {
         }
       }
     }
+    if (LDSW && m.head_part != part) tp = sf_stage_part<LDSW>(m, t, m.head_part, lds);
+    return tp;
   }
 
   // spline head + RQ spline on the transform dims of parity t&1, given the conditioner state
@@ -574,11 +583,11 @@ struct NsfOps {
   }
 
   // coupling: conditioner on the identity dims, spline on the others
-  static __device__ __forceinline__ void coupling(const SfDev& m, const float* __restrict__ tp, int t,
+  static __device__ __forceinline__ void coupling(const SfDev& m, int t, float* lds, const float* tp0,
                                                   float (&u)[NS][SF_DMAX], const float* const (&xr)[NS],
                                                   float (&logdet)[NS], bool inverse, int lane) {
     f32x16 hid[HT][NS];
-    resnet(m, tp, u, xr, hid, lane);
+    const float* tp = resnet(m, t, lds, tp0, u, xr, hid, lane);
     spline_apply(m, tp, t, hid, u, logdet, inverse, lane);
   }
 
@@ -678,18 +687,26 @@ struct NsfOps {
                                                  const float* const (&xr)[NS], float (&logdet)[NS],
                                                  int lane, float* lds = nullptr) {
     for (int t = 0; t < m.T; ++t) {
-      const float* tp = sf_stage<LDSW>(m, t, lds);
-      coupling(m, tp, t, u, xr, logdet, false, lane);
-      if (m.D > 1) lu_forward(m, tp + m.o_lu, u, logdet);
+      const float* tp0 = sf_stage_part<LDSW>(m, t, 0, lds);
+      coupling(m, t, lds, tp0, u, xr, logdet, false, lane);
+      // LU parameters: from the staged image when the whole transform is one part, else from global
+      // (two call sites, not a pointer select, so each keeps its address space)
+      if (m.D > 1) {
+        if (LDSW && m.n_parts == 1) lu_forward(m, tp0 + m.o_lu, u, logdet);
+        else lu_forward(m, m.packed + (size_t)t * m.t_stride + m.o_lu, u, logdet);
+      }
     }
   }
   static __device__ __forceinline__ void inverse(const SfDev& m, float (&u)[NS][SF_DMAX],
                                                  const float* const (&xr)[NS], float (&logdet)[NS],
                                                  int lane, float* lds = nullptr) {
     for (int t = m.T - 1; t >= 0; --t) {
-      const float* tp = sf_stage<LDSW>(m, t, lds);
-      if (m.D > 1) lu_inverse(m, tp + m.o_lu, u, logdet);
-      coupling(m, tp, t, u, xr, logdet, true, lane);
+      const float* tp0 = sf_stage_part<LDSW>(m, t, 0, lds);
+      if (m.D > 1) {
+        if (LDSW && m.n_parts == 1) lu_inverse(m, tp0 + m.o_lu, u, logdet);
+        else lu_inverse(m, m.packed + (size_t)t * m.t_stride + m.o_lu, u, logdet);
+      }
+      coupling(m, t, lds, tp0, u, xr, logdet, true, lane);
     }
   }
 };

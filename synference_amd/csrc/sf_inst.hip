@@ -11,7 +11,7 @@
 #define SF_CAT(a, b, c, d) SF_CAT_(a, b, c, d)
 
 // LDS-staged variant when one transform's operand image fits the 160 KiB LDS (with slack)
-static inline bool sf_fits_lds(const SfDev& m) { return (size_t)m.t_stride * sizeof(float) <= 156 * 1024; }
+static inline bool sf_fits_lds(const SfDev& m) { return m.n_parts > 0; }
 
 template <class K>
 static hipError_t set_shmem(K kernel, size_t bytes, bool& done) {
@@ -26,7 +26,7 @@ static hipError_t launch_logprob(const SfDev& m, const float* theta, const float
                                  hipStream_t st) {
   if (sf_fits_lds(m)) {
     static bool attr = false;
-    const size_t sh = (size_t)m.t_stride * sizeof(float);
+    const size_t sh = (size_t)m.part_max * sizeof(float);
     hipError_t e = set_shmem(k_logprob<OpsL, NS, true>, sh, attr);
     if (e != hipSuccess) return e;
     const long per_block = 8L * 32 * NS;
@@ -43,7 +43,7 @@ template <class OpsG, class OpsL, int NS>
 static hipError_t launch_inverse(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
   if (sf_fits_lds(m)) {
     static bool attr = false;
-    const size_t sh = (size_t)m.t_stride * sizeof(float);
+    const size_t sh = (size_t)m.part_max * sizeof(float);
     hipError_t e = set_shmem(k_inverse<OpsL, NS, true>, sh, attr);
     if (e != hipSuccess) return e;
     const long per_block = 8L * 32 * NS;

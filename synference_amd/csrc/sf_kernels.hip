@@ -50,8 +50,10 @@ int sf_pick_ns(const SfDev& m, bool inverse) {
   }
   if (m.HT > 2) return 1;
   if (forced == 1 || forced == 2) return forced;
-  // the incremental MAF inverse keeps three activation sets alive: one sample tile per wave
-  if (inverse && m.kind == SF_MAF && m.inc_ok && m.NB <= 2) return 1;
+  // measured on MI355X: with the operand image in LDS (512-thread workgroups) one 32-sample tile per wave
+  // is faster for every kernel (fewer registers, no spills); two tiles per wave only pay off when the
+  // weights stream from L2 (oversized images)
+  if (m.n_parts > 0) return 1;
   return 2;
 }
 

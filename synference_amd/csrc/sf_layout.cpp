@@ -427,6 +427,45 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
   E.pad_to(64);
   ET.pad_to(64);
   if (T == 1) { v.t_stride = (int)E.cur; v.tT_stride = (int)ET.cur; }
+  // ---- LDS staging plan (budget: 156 KiB of the 160 KiB LDS) ---------------------------------
+  {
+    const int budget = 156 * 1024 / 4;
+    std::vector<int> cuts;  // block boundaries (float offsets) in execution order, first = 0, last = end
+    if (d.kind == SF_MAF) {
+      cuts = {0, v.t_stride};
+    } else {
+      cuts.push_back(0);
+      for (int k = 0; k < NB; ++k) cuts.push_back(v.o_wg[k]);  // block k starts at its gate weights
+      cuts.push_back(v.o_wout);
+      cuts.push_back(v.t_stride);  // spline head + the small LU block (LU is used from LDS only when n_parts == 1)
+    }
+    v.n_parts = 0;
+    v.part_max = 0;
+    bool ok = true;
+    int start = 0;
+    std::vector<int> item_part(cuts.size() - 1, 0);
+    v.part_off[0] = 0;
+    for (size_t i = 0; i + 1 < cuts.size(); ++i) {
+      const int item = cuts[i + 1] - cuts[i];
+      if (item > budget) { ok = false; break; }
+      if (cuts[i + 1] - start > budget) {  // close the current part before this item
+        if (v.n_parts >= 3) { ok = false; break; }
+        v.part_off[++v.n_parts] = cuts[i];
+        start = cuts[i];
+      }
+      item_part[i] = v.n_parts;
+    }
+    if (ok) {
+      v.part_off[++v.n_parts] = cuts.back();
+      for (int p = 0; p < v.n_parts; ++p) v.part_max = std::max(v.part_max, v.part_off[p + 1] - v.part_off[p]);
+      if (d.kind == SF_NSF) {
+        for (int k = 0; k < NB; ++k) v.blk_part[k] = item_part[1 + k];
+        v.head_part = item_part[1 + NB];
+      }
+    } else {
+      v.n_parts = 0;
+    }
+  }
   L.n_packed = E.cur;
   L.n_packedT = ET.cur;
   L.n_params = P;

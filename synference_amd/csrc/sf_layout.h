@@ -34,6 +34,10 @@ struct SfDev {
   int JP;    // NSF: dim pairs per transform (max over parity)
   int nGu, nGc, nGh;  // active input groups: u tile, context, hidden
   int t_stride;       // floats per transform in packed / packedT
+  // LDS staging plan of one transform's image: part p = floats [part_off[p], part_off[p+1]); parts are
+  // whole layer blocks in execution order; n_parts == 0 -> some block exceeds the LDS budget (stream from L2)
+  int n_parts, part_off[5], part_max;
+  int blk_part[SF_NBMAX], head_part;  // NSF: part holding block k / the spline head
   // offsets in floats relative to the transform base -------------------------------------
   int o_w0, o_wc, o_b0;                  // MAF initial (u part, context part, b0+bc)
   int o_wk[SF_NBMAX], o_bk[SF_NBMAX];    // MAF hidden blocks
