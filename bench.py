@@ -87,6 +87,8 @@ def parse():
     ap.add_argument("--train-steps", type=int, default=0, help="0 = same as --steps")
     ap.add_argument("--fit-steps", type=int, default=4000, help="untimed seeded warm-up fit")
     ap.add_argument("--fit-lr", type=float, default=2e-3)
+    ap.add_argument("--hidden-bf16", action="store_true",
+                    help="opt-in bf16 MFMA operands for the hidden HxH layers of the sampler (BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -184,6 +186,10 @@ def main():
     gen = torch.Generator().manual_seed(42)
     est = build_flow(wl["kind"], th_lib[tr], x_lib[tr], hidden_features=wl.get("H", 50),
                      num_transforms=wl.get("T", 5), num_bins=wl["K"], device=dev, generator=gen).to(dev)
+    if a.hidden_bf16:
+        import dataclasses
+        est.spec = dataclasses.replace(est.spec, hidden_bf16=True)
+        est._flow = None
     flow = est.flow
     flat = est.flat.data
     Xtr = torch.as_tensor(x_lib[tr]).to(dev)
@@ -300,7 +306,8 @@ def main():
         "metric": "posterior samples/sec (accepted, prior-box rejection included)",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * t_samp / a.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32" if not a.hidden_bf16 else "bf16 hidden-layer MFMA operands, f32 elsewhere",
+        "data": "synthetic",
         "config": {"workload": f"{wl['label']}; sample_posterior over {M} test galaxies x {S} draws per GPU",
                    "name": a.workload,
                    "galaxies_per_gpu": M, "draws_per_galaxy": S, "theta_dim": D, "filters": C,

@@ -68,6 +68,9 @@ typedef struct sf_flow_desc {
   int32_t K;               /* num_bins (NSF) [10], 2..16 */
   int32_t NB;              /* num_blocks [2], 1..4 */
   int32_t scale_fn;        /* MAF scale: 0 = softplus(a)+eps [nflows>=0.14], 1 = sigmoid(a+2)+eps */
+  int32_t hidden_bf16;     /* 0 = fp32 everywhere [default]; 1 = the hidden H x H layers of the INFERENCE kernels
+                              (log_prob / inverse / sampler) use bf16 MFMA operands with fp32 accumulation
+                              (BASELINE configs[4]); everything else, and all training, stays fp32 */
   float tail_bound;        /* [3.0] */
   float min_bin_width;     /* [1e-3] */
   float min_bin_height;    /* [1e-3] */

@@ -58,6 +58,7 @@ class FlowSpec:
     maf_eps: float = 1e-3
     lu_eps: float = 1e-3
     scale_fn: str = "softplus"  # nflows>=0.14; "sigmoid2" = sigmoid(a+2) (nflows<=0.13)
+    hidden_bf16: bool = False  # emulate the HIP bf16 mode: hidden HxH operands rounded to bf16, wide accumulate
     theta_mean: Optional[np.ndarray] = None
     theta_std: Optional[np.ndarray] = None
     x_mean: Optional[np.ndarray] = None
@@ -246,6 +247,11 @@ def _scale_from_unconstrained(spec: FlowSpec, a: torch.Tensor) -> torch.Tensor:
     return torch.sigmoid(a + 2.0) + spec.maf_eps
 
 
+def _bf(spec: FlowSpec, t: torch.Tensor) -> torch.Tensor:
+    """bf16 rounding (round to nearest even) of an MFMA operand when the bf16 mode is emulated."""
+    return t.to(torch.bfloat16).to(t.dtype) if spec.hidden_bf16 else t
+
+
 def _made(spec: FlowSpec, P: Dict[str, torch.Tensor], t: int, u: torch.Tensor,
           e: torch.Tensor, masks) -> Tuple[torch.Tensor, torch.Tensor]:
     """nflows MADE.forward (feed-forward blocks): returns (a, m) each [B, D]."""
@@ -253,7 +259,7 @@ def _made(spec: FlowSpec, P: Dict[str, torch.Tensor], t: int, u: torch.Tensor,
     p = f"t{t}."
     h = F.linear(u, P[p + "W0"] * M0, P[p + "b0"]) + F.linear(e, P[p + "Wc"], P[p + "bc"])
     for k in range(spec.NB):
-        h = torch.tanh(F.linear(h, P[p + f"W{k + 1}"] * Mh, P[p + f"b{k + 1}"]))
+        h = torch.tanh(F.linear(_bf(spec, h), _bf(spec, P[p + f"W{k + 1}"] * Mh), P[p + f"b{k + 1}"]))
     out = F.linear(h, P[p + "Wf"] * Mf, P[p + "bf"]).view(-1, spec.D, 2)
     return out[..., 0], out[..., 1]
 
@@ -265,8 +271,8 @@ def _resnet(spec: FlowSpec, P: Dict[str, torch.Tensor], t: int, u_id: torch.Tens
     h = F.linear(torch.cat([u_id, e], dim=1), P[p + "Win"], P[p + "bin"])
     for k in range(spec.NB):
         b = p + f"blk{k}."
-        tt = F.linear(F.relu(h), P[b + "W1"], P[b + "b1"])
-        tt = F.linear(F.relu(tt), P[b + "W2"], P[b + "b2"])
+        tt = F.linear(_bf(spec, F.relu(h)), _bf(spec, P[b + "W1"]), P[b + "b1"])
+        tt = F.linear(_bf(spec, F.relu(tt)), _bf(spec, P[b + "W2"]), P[b + "b2"])
         tt = tt * torch.sigmoid(F.linear(e, P[b + "Wg"], P[b + "bg"]))
         h = h + tt
     return F.linear(h, P[p + "Wout"], P[p + "bout"])

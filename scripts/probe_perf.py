@@ -13,8 +13,10 @@ def timeit(fn, n=5):
     return min(t), float(np.median(t))
 
 g = torch.Generator().manual_seed(0)
+BF = os.environ.get("SF_PROBE_BF16") == "1"
 for kind, D, C, K, M, S in [("maf", 5, 10, 10, 2000, 1000), ("nsf", 8, 20, 8, 2000, 1000)]:
-    spec = FlowSpec(kind=kind, D=D, C=C, H=50, T=5, K=K, perms=random_perms(D, 5, g) if kind == "maf" else None)
+    spec = FlowSpec(kind=kind, D=D, C=C, H=50, T=5, K=K, perms=random_perms(D, 5, g) if kind == "maf" else None,
+                    hidden_bf16=BF)
     f = HipFlow(spec); flat = init_params(spec, g); f.set_params(flat)
     x = torch.randn(M, C, device="cuda"); th = torch.randn(M * 100, D, device="cuda"); xx = x.repeat_interleave(100, 0)
     out = torch.empty(M, S, D, device="cuda")

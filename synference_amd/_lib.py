@@ -22,6 +22,7 @@ class sf_flow_desc(C.Structure):
     _fields_ = [
         ("kind", C.c_int32), ("D", C.c_int32), ("C", C.c_int32), ("H", C.c_int32),
         ("T", C.c_int32), ("K", C.c_int32), ("NB", C.c_int32), ("scale_fn", C.c_int32),
+        ("hidden_bf16", C.c_int32),
         ("tail_bound", C.c_float), ("min_bin_width", C.c_float), ("min_bin_height", C.c_float),
         ("min_derivative", C.c_float), ("maf_eps", C.c_float), ("lu_eps", C.c_float),
         ("theta_mean", c_f32p), ("theta_std", c_f32p), ("x_mean", c_f32p), ("x_std", c_f32p),

@@ -41,6 +41,11 @@ static int ensure_device(sf_flow* f) {
   SF_HIP(hipMalloc(&f->d_s2, np * sizeof(int32_t)));
   SF_HIP(hipMemcpy(f->d_s1, f->L.src1.data(), np * sizeof(int32_t), hipMemcpyHostToDevice));
   SF_HIP(hipMemcpy(f->d_s2, f->L.src2.data(), np * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (f->L.n_packedB > 0) {
+    SF_HIP(hipMalloc(&f->d_packedB, (size_t)f->L.n_packedB * sizeof(unsigned short)));
+    SF_HIP(hipMalloc(&f->d_bsrc, (size_t)f->L.n_packedB * sizeof(int32_t)));
+    SF_HIP(hipMemcpy(f->d_bsrc, f->L.srcB.data(), (size_t)f->L.n_packedB * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   SF_HIP(hipMalloc(&f->d_flat, (size_t)f->L.n_params * sizeof(float)));
   SF_HIP(hipMalloc(&f->d_cnt, 4 * sizeof(uint32_t)));
   f->dev_ready = true;
@@ -74,7 +79,7 @@ int sf_flow_create(const sf_flow_desc* desc, sf_flow** out) {
 void sf_flow_destroy(sf_flow* f) {
   if (!f) return;
   if (f->dev_ready) {
-    (void)hipFree(f->d_packed); (void)hipFree(f->d_packedT); (void)hipFree(f->d_cst);
+    (void)hipFree(f->d_packed); (void)hipFree(f->d_packedT); (void)hipFree(f->d_cst); (void)hipFree(f->d_packedB); (void)hipFree(f->d_bsrc);
     (void)hipFree(f->d_s1); (void)hipFree(f->d_s2); (void)hipFree(f->d_t1); (void)hipFree(f->d_t2);
     (void)hipFree(f->d_flat); (void)hipFree(f->d_gpacked); (void)hipFree(f->d_gdst);
     (void)hipFree(f->d_act); (void)hipFree(f->d_rej[0]); (void)hipFree(f->d_rej[1]); (void)hipFree(f->d_cnt);
@@ -112,7 +117,7 @@ int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen) {
   add("o_wout", v.o_wout); add("o_bout", v.o_bout); add("o_lu", v.o_lu);
   add("c_pscale", v.c_pscale); add("c_pshift", v.c_pshift); add("c_tdim", v.c_tdim);
   add("c_xmean", v.c_xmean); add("c_xstd", v.c_xstd); add("c_dslot", v.c_dslot);
-  add("inc_ok", v.inc_ok); add("n_parts", v.n_parts); add("part_max", v.part_max);
+  add("inc_ok", v.inc_ok); add("hidden_bf16", v.hidden_bf16); add("tB_stride", v.tB_stride); add("n_parts", v.n_parts); add("part_max", v.part_max);
   add("n_params", f->L.n_params); add("n_packed", f->L.n_packed);
   s += "\"g_kend\": [";
   for (int i = 0; i < SF_DMAX; ++i) s += std::to_string(v.g_kend[i]) + (i + 1 < SF_DMAX ? ", " : "], ");
@@ -144,6 +149,7 @@ int sf_flow_set_params(sf_flow* f, const float* flat, int64_t n, int is_device, 
     src = f->d_flat;
   }
   SF_HIP(sf_launch_pack(src, f->d_s1, f->d_s2, f->d_packed, (long)f->L.n_packed, st));
+  if (f->L.n_packedB > 0) SF_HIP(sf_launch_pack_bf16(src, f->d_bsrc, f->d_packedB, (long)f->L.n_packedB, st));
   f->params_set = true;
   return SF_OK;
 }

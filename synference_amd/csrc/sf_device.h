@@ -49,6 +49,12 @@ __device__ __forceinline__ const float* sf_stage_part(const SfDev& m, int t, int
   float4* __restrict__ d4 = reinterpret_cast<float4*>(lds);
   const int n4 = (hi - lo) >> 2;
   for (int i = threadIdx.x; i < n4; i += blockDim.x) d4[i] = s4[i];
+  if (m.hidden_bf16) {  // single-part images only (sf_layout.cpp): bf16 hidden operands right behind the fp32 image
+    const uint4* __restrict__ sb = reinterpret_cast<const uint4*>(m.packedB + (size_t)t * m.tB_stride);
+    uint4* __restrict__ db = reinterpret_cast<uint4*>(lds + m.t_stride);
+    const int nb = m.tB_stride >> 3;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) db[i] = sb[i];
+  }
   __syncthreads();
   return lds - lo;  // so that (returned + block offset) lands inside the staged part
 }
@@ -118,6 +124,69 @@ __device__ __forceinline__ void sf_mm_acc(f32x16 (&acc)[OT][NS], const f32x16 (&
       }
     }
   }
+}
+
+// ---- bf16 operands for the hidden H x H layers (opt-in, inference only) -----------------------
+// v_mfma_f32_32x32x16_bf16 consumes registers 8s..8s+7 of an accumulator-layout tile as the B fragment of
+// the 16-row k-step s (element j of row-half h = row 16s + 8(j>>2) + 4h + (j&3)); the weight image stores
+// the A fragment in the same k order (sf_layout.cpp emit_bf16).  fp32 accumulation.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int NS, int IT, bool RELU>
+__device__ __forceinline__ bf16x8 sf_bfrag(const f32x16 (&in)[IT][NS], int ns, int ks) {
+  bf16x8 b;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float v = in[ks >> 1][ns][8 * (ks & 1) + j];
+    if (RELU) v = fmaxf(v, 0.f);
+    b[j] = (__bf16)v;
+  }
+  return b;
+}
+
+template <int OT, int NS, int IT, bool RELU, bool LIM = false>
+__device__ __forceinline__ void sf_mm_acc_bf16(f32x16 (&acc)[OT][NS], const f32x16 (&in)[IT][NS],
+                                               const unsigned short* __restrict__ wB, int nKStot, int nks,
+                                               int lane, SfKLim lim = SfKLim{{0, 0, 0, 0}}) {
+  const uint4* __restrict__ w4 = reinterpret_cast<const uint4*>(wB);
+#pragma unroll
+  for (int mt = 0; mt < OT; ++mt) {
+    const int nk = LIM ? min(nks, lim.v[mt]) : nks;
+#pragma unroll
+    for (int ks = 0; ks < IT * 2; ++ks) {
+      if (ks < nk) {
+        const uint4 wv = w4[(mt * nKStot + ks) * 64 + lane];
+        const bf16x8 a = __builtin_bit_cast(bf16x8, wv);
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+          acc[mt][ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, sf_bfrag<NS, IT, RELU>(in, ns, ks), acc[mt][ns], 0, 0, 0);
+      }
+    }
+  }
+}
+
+template <int NS, int IT, bool RELU>
+__device__ __forceinline__ void sf_mm_acc_bf16_tile(f32x16 (&acc)[NS], const f32x16 (&in)[IT][NS],
+                                                    const unsigned short* __restrict__ wB, int nKStot, int mt,
+                                                    int nks, int lane) {
+  const uint4* __restrict__ w4 = reinterpret_cast<const uint4*>(wB);
+#pragma unroll
+  for (int ks = 0; ks < IT * 2; ++ks) {
+    if (ks < nks) {
+      const uint4 wv = w4[(mt * nKStot + ks) * 64 + lane];
+      const bf16x8 a = __builtin_bit_cast(bf16x8, wv);
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns)
+        acc[ns] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, sf_bfrag<NS, IT, RELU>(in, ns, ks), acc[ns], 0, 0, 0);
+    }
+  }
+}
+
+// bf16 image base of transform t (LDS copy right behind the fp32 image, or global)
+template <bool LDSW>
+__device__ __forceinline__ const unsigned short* sf_bf16_base(const SfDev& m, int t, float* lds) {
+  if (LDSW) return reinterpret_cast<const unsigned short*>(lds + m.t_stride);
+  return m.packedB + (size_t)t * m.tB_stride;
 }
 
 // single output tile `mt` of a multi-tile block (static mt), all other arguments as above

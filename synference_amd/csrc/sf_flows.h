@@ -11,13 +11,13 @@
 // =============================================================================================
 // MAF
 // =============================================================================================
-template <int HT, int NS, bool LDSW = false>
+template <int HT, int NS, bool LDSW = false, bool BF = false>
 struct MafOps {
   // MADE: (a_p, m_p) for every slot p land in fin[0][ns][2*(p>>1)], [2*(p>>1)+1] on half p&1
   static __device__ __forceinline__ void made(const SfDev& m, const float* __restrict__ tp,
                                               const float (&u)[NS][SF_DMAX],
                                               const float* const (&xr)[NS], f32x16 (&fin)[1][NS],
-                                              int lane) {
+                                              int lane, const unsigned short* __restrict__ tpB = nullptr) {
     const int h = lane >> 5;
     f32x16 a[HT][NS];
     sf_init_bias<HT, NS>(a, tp + m.o_b0, h);
@@ -32,8 +32,13 @@ struct MafOps {
       if (k < m.NB) {
         f32x16 b[HT][NS];
         sf_init_bias<HT, NS>(b, tp + m.o_bk[k], h);
-        sf_mm_acc<HT, NS, HT, false, true>(b, a, tp + m.o_wk[k], m.nGh, 0, m.nGh, lane,
-                                           SfKLim{{m.mt_kend[0], m.mt_kend[1], m.mt_kend[2], m.mt_kend[3]}});
+        if (BF)
+          sf_mm_acc_bf16<HT, NS, HT, false, true>(b, a, tpB + m.oB_wk[k], m.nKS, m.nKS, lane,
+                                                  SfKLim{{(m.mt_kend[0] + 1) >> 1, (m.mt_kend[1] + 1) >> 1,
+                                                          (m.mt_kend[2] + 1) >> 1, (m.mt_kend[3] + 1) >> 1}});
+        else
+          sf_mm_acc<HT, NS, HT, false, true>(b, a, tp + m.o_wk[k], m.nGh, 0, m.nGh, lane,
+                                             SfKLim{{m.mt_kend[0], m.mt_kend[1], m.mt_kend[2], m.mt_kend[3]}});
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt)
 #pragma unroll
@@ -58,7 +63,7 @@ struct MafOps {
     for (int t = 0; t < m.T; ++t) {
       const float* tp = sf_stage<LDSW>(m, t, lds);
       f32x16 fin[1][NS];
-      made(m, tp, u, xr, fin, lane);
+      made(m, tp, u, xr, fin, lane, sf_bf16_base<LDSW>(m, t, lds));
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns) {
         float ld = 0.f;
@@ -93,7 +98,7 @@ struct MafOps {
       float ldl[NS];
       for (int pass = 0; pass < m.D; ++pass) {
         f32x16 fin[1][NS];
-        made(m, tp, w, xr, fin, lane);
+        made(m, tp, w, xr, fin, lane, sf_bf16_base<LDSW>(m, t, lds));
         affine_inverse(m, fin, u, w, ldl, h);
       }
 #pragma unroll
@@ -178,7 +183,11 @@ struct MafOps {
                 if (k < m.NB) {
                   f32x16 b[NS];
                   sf_init_bias_tile<NS>(b, tp + m.o_bk[k], mt, h);
-                  sf_mm_acc_tile<NS, HT, false>(b, act[k], tp + m.o_wk[k], m.nGh, mt, kend, lane);
+                  if (BF)
+                    sf_mm_acc_bf16_tile<NS, HT, false>(b, act[k], sf_bf16_base<LDSW>(m, t, lds) + m.oB_wk[k], m.nKS, mt,
+                                                       (kend + 1) >> 1, lane);
+                  else
+                    sf_mm_acc_tile<NS, HT, false>(b, act[k], tp + m.o_wk[k], m.nGh, mt, kend, lane);
 #pragma unroll
                   for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
@@ -496,7 +505,7 @@ struct SfSplineBwd {
   }
 };
 
-template <int HT, int PT, int NS, bool LDSW = false>
+template <int HT, int PT, int NS, bool LDSW = false, bool BF = false>
 struct NsfOps {
   // ResidualNet conditioner -> hidden tiles
   // returns the (possibly LDS) base pointer valid for the spline head
@@ -525,9 +534,15 @@ struct NsfOps {
         {
           f32x16 t1[HT][NS];
           sf_init_bias<HT, NS>(t1, tp + m.o_b1[k], h);
-          sf_mm_acc<HT, NS, HT, true>(t1, hid, tp + m.o_w1[k], m.nGh, 0, m.nGh, lane);
           sf_init_bias<HT, NS>(t2, tp + m.o_b2[k], h);
-          sf_mm_acc<HT, NS, HT, true>(t2, t1, tp + m.o_w2[k], m.nGh, 0, m.nGh, lane);
+          if (BF) {
+            const unsigned short* tpB = sf_bf16_base<LDSW>(m, t, lds);
+            sf_mm_acc_bf16<HT, NS, HT, true>(t1, hid, tpB + m.oB_w1[k], m.nKS, m.nKS, lane);
+            sf_mm_acc_bf16<HT, NS, HT, true>(t2, t1, tpB + m.oB_w2[k], m.nKS, m.nKS, lane);
+          } else {
+            sf_mm_acc<HT, NS, HT, true>(t1, hid, tp + m.o_w1[k], m.nGh, 0, m.nGh, lane);
+            sf_mm_acc<HT, NS, HT, true>(t2, t1, tp + m.o_w2[k], m.nGh, 0, m.nGh, lane);
+          }
         }
         // GLU gate, one output tile at a time: hid += t2 * sigmoid(Wg e + bg)
 #pragma unroll

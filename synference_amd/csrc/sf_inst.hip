@@ -21,6 +21,27 @@ static hipError_t set_shmem(K kernel, size_t bytes, bool& done) {
   return e;
 }
 
+template <class OpsB>
+static hipError_t launch_logprob_bf16(const SfDev& m, const float* theta, const float* x, long B, float* out,
+                                      hipStream_t st) {
+  static bool attr = false;
+  const size_t sh = (size_t)m.part_max * sizeof(float) + (size_t)m.tB_stride * sizeof(unsigned short);
+  hipError_t e = set_shmem(k_logprob<OpsB, 1, true>, sh, attr);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((k_logprob<OpsB, 1, true>), dim3((unsigned)((B + 255) / 256)), dim3(512), sh, st, m, theta, x, B,
+                     out);
+  return hipGetLastError();
+}
+template <class OpsB>
+static hipError_t launch_inverse_bf16(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
+  static bool attr = false;
+  const size_t sh = (size_t)m.part_max * sizeof(float) + (size_t)m.tB_stride * sizeof(unsigned short);
+  hipError_t e = set_shmem(k_inverse<OpsB, 1, true>, sh, attr);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((k_inverse<OpsB, 1, true>), dim3((unsigned)((a.n_items + 255) / 256)), dim3(512), sh, st, m, a);
+  return hipGetLastError();
+}
+
 template <class OpsG, class OpsL, int NS>
 static hipError_t launch_logprob(const SfDev& m, const float* theta, const float* x, long B, float* out,
                                  hipStream_t st) {
@@ -58,6 +79,17 @@ static hipError_t launch_inverse(const SfDev& m, const SfSampleArgsHost& a, hipS
 }
 
 #if SF_KIND == 0
+#define SF_BF_SWITCH(FN, ...) { using OB = MafOps<SF_HT, 1, true, true>; return FN<OB>(__VA_ARGS__); }
+#else
+#define SF_BF_SWITCH(FN, ...)                                                              \
+  switch (m.PT) {                                                                          \
+    case 2: { using OB = NsfOps<SF_HT, 2, 1, true, true>; return FN<OB>(__VA_ARGS__); }    \
+    case 3: { using OB = NsfOps<SF_HT, 3, 1, true, true>; return FN<OB>(__VA_ARGS__); }    \
+    default: return hipErrorInvalidValue;                                                  \
+  }
+#endif
+
+#if SF_KIND == 0
 #define SF_PT_SWITCH(NS, FN, ...)                                                          \
   { using OG = MafOps<SF_HT, NS, false>; using OL = MafOps<SF_HT, NS, true>;               \
     return FN<OG, OL, NS>(__VA_ARGS__); }
@@ -75,6 +107,7 @@ static hipError_t launch_inverse(const SfDev& m, const SfSampleArgsHost& a, hipS
 hipError_t SF_CAT(sf_launch_logprob_k, SF_KIND, _h, SF_HT)(const SfDev& m, int ns, const float* theta,
                                                            const float* x, long B, float* out,
                                                            hipStream_t st) {
+  if (m.hidden_bf16) SF_BF_SWITCH(launch_logprob_bf16, m, theta, x, B, out, st)
 #if SF_HT <= 2
   if (ns == 2) SF_PT_SWITCH(2, launch_logprob, m, theta, x, B, out, st)
 #endif
@@ -83,6 +116,7 @@ hipError_t SF_CAT(sf_launch_logprob_k, SF_KIND, _h, SF_HT)(const SfDev& m, int n
 
 hipError_t SF_CAT(sf_launch_inverse_k, SF_KIND, _h, SF_HT)(const SfDev& m, int ns, const SfSampleArgsHost& a,
                                                            hipStream_t st) {
+  if (m.hidden_bf16) SF_BF_SWITCH(launch_inverse_bf16, m, a, st)
 #if SF_HT <= 2
   if (ns == 2) SF_PT_SWITCH(2, launch_inverse, m, a, st)
 #endif

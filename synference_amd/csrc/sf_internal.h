@@ -29,6 +29,7 @@ hipError_t sf_launch_logprob(const SfDev& m, const float* theta, const float* x,
 hipError_t sf_launch_inverse(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st);
 hipError_t sf_launch_pack(const float* flat, const int32_t* s1, const int32_t* s2, float* packed, long n,
                           hipStream_t st);
+hipError_t sf_launch_pack_bf16(const float* flat, const int32_t* src, unsigned short* out, long n, hipStream_t st);
 hipError_t sf_launch_fill_nan_rows(float* out, const uint32_t* slots, long n, int D, hipStream_t st);
 hipError_t sf_launch_fill_i32(int32_t* p, long n, int32_t v, hipStream_t st);
 
@@ -43,6 +44,8 @@ struct sf_flow {
   float* d_packed = nullptr;    // forward operand image
   float* d_packedT = nullptr;   // transposed operand image (training, lazily built)
   float* d_cst = nullptr;
+  unsigned short* d_packedB = nullptr;  // bf16 hidden operand image (hidden_bf16)
+  int32_t* d_bsrc = nullptr;
   int32_t *d_s1 = nullptr, *d_s2 = nullptr, *d_t1 = nullptr, *d_t2 = nullptr;
   float* d_flat = nullptr;      // staging for host-sourced parameters
   float* d_gpacked = nullptr;   // gradient image (atomic accumulation target)
@@ -57,6 +60,7 @@ struct sf_flow {
     v.packed = d_packed;
     v.packedT = d_packedT;
     v.cst = d_cst;
+    v.packedB = d_packedB;
     return v;
   }
 };

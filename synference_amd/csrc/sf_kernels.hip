@@ -20,6 +20,15 @@ __global__ void k_pack(const float* __restrict__ flat, const int32_t* __restrict
   packed[i] = v;
 }
 
+__global__ void k_pack_bf16(const float* __restrict__ flat, const int32_t* __restrict__ src,
+                            unsigned short* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int a = src[i];
+  const __bf16 v = (__bf16)(a >= 0 ? flat[a] : 0.f);  // round to nearest even
+  out[i] = __builtin_bit_cast(unsigned short, v);
+}
+
 __global__ void k_fill_nan_rows(float* __restrict__ out, const uint32_t* __restrict__ slots, long n, int D) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -96,6 +105,11 @@ hipError_t sf_launch_inverse(const SfDev& m, const SfSampleArgsHost& a, hipStrea
 hipError_t sf_launch_pack(const float* flat, const int32_t* s1, const int32_t* s2, float* packed, long n,
                           hipStream_t st) {
   hipLaunchKernelGGL(k_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, flat, s1, s2, packed, n);
+  return hipGetLastError();
+}
+hipError_t sf_launch_pack_bf16(const float* flat, const int32_t* src, unsigned short* out, long n, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_pack_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, flat, src, out, n);
   return hipGetLastError();
 }
 hipError_t sf_launch_fill_nan_rows(float* out, const uint32_t* slots, long n, int D, hipStream_t st) {

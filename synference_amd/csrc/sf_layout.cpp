@@ -159,6 +159,24 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
   const std::vector<int> hrow_out(hrow_full.begin(), hrow_full.begin() + HT * 32);
   const std::vector<int> hrow_in(hrow_full.begin(), hrow_full.begin() + v.nGh * 8);
   const std::vector<int> crow_in = iota_rows(C, v.nGc * 8);
+  v.hidden_bf16 = d.hidden_bf16 ? 1 : 0;
+  v.nKS = ceil_div(v.nGh, 2);
+  // bf16 hidden block: [mt][ks][lane][8]; element j of lane (c,h) is input row 16ks + 8(j>>2) + 4h + (j&3)
+  // (the k-order in which v_mfma_f32_32x32x16_bf16 consumes registers 8ks'..8ks'+7 of an accumulator tile)
+  auto emit_bf16 = [&](int64_t base, const std::function<bool(int, int)>& mask) -> int64_t {
+    while (L.srcB.size() % 8) L.srcB.push_back(-1);
+    const int64_t start = (int64_t)L.srcB.size();
+    for (int mt = 0; mt < HT; ++mt)
+      for (int ks = 0; ks < v.nKS; ++ks)
+        for (int l = 0; l < 64; ++l)
+          for (int j = 0; j < 8; ++j) {
+            const int o = hrow_full[mt * 32 + (l & 31)];
+            const int rho = 16 * ks + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
+            const int i = rho < 128 ? hrow_full[rho] : -1;
+            L.srcB.push_back((o >= 0 && i >= 0 && (!mask || mask(o, i))) ? (int32_t)(base + (int64_t)o * H + i) : -1);
+          }
+    return start;
+  };
 
   // ---- MAF physical slot maps: sigma_T = identity, sigma_t = sigma_{t+1} o perm_t^{-1} ----
   std::vector<std::vector<int>> sigma(T + 1, std::vector<int>(D));
@@ -250,6 +268,15 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
         if (t == 0) v.o_wk[k] = o;
         o = (int)(E.bias(HT, hrow_out, lbk[k], -1) - tb);
         if (t == 0) v.o_bk[k] = o;
+        if (v.hidden_bf16) {
+          if (k == 0) {
+            while (L.srcB.size() % 64) L.srcB.push_back(-1);
+            if (t == 1) v.tB_stride = (int)L.srcB.size();
+          }
+          const int64_t tbB = (int64_t)t * (t >= 1 ? v.tB_stride : 0);
+          const int64_t sB = emit_bf16(lWk[k], [&](int j, int i) { return deg_h(j) >= deg_h(i); });
+          if (t == 0) v.oB_wk[k] = (int)(sB - tbB);
+        }
       }
       o = (int)(E.linear(1, v.nGh, frow, hrow_in, lWf, H, 1,
                          [&](int oo, int i) { return (oo / 2 + 1) > deg_h(i); }) - tb);
@@ -370,6 +397,16 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
         if (t == 0) v.o_w2[k] = o;
         o = (int)(E.bias(HT, hrow_out, lb2[k], -1) - tb);
         if (t == 0) v.o_b2[k] = o;
+        if (v.hidden_bf16) {
+          if (k == 0) {
+            while (L.srcB.size() % 64) L.srcB.push_back(-1);
+            if (t == 1) v.tB_stride = (int)L.srcB.size();
+          }
+          const int64_t tbB = (int64_t)t * (t >= 1 ? v.tB_stride : 0);
+          const int64_t s1 = emit_bf16(lW1[k], nullptr);
+          const int64_t s2 = emit_bf16(lW2[k], nullptr);
+          if (t == 0) { v.oB_w1[k] = (int)(s1 - tbB); v.oB_w2[k] = (int)(s2 - tbB); }
+        }
       }
       o = (int)(E.linear(v.JP * v.PT, v.nGh, orow, hrow_in, lWout, H, 1, nullptr) - tb);
       if (t == 0) v.o_wout = o;
@@ -426,7 +463,9 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
   }
   E.pad_to(64);
   ET.pad_to(64);
-  if (T == 1) { v.t_stride = (int)E.cur; v.tT_stride = (int)ET.cur; }
+  while (L.srcB.size() % 64) L.srcB.push_back(-1);
+  if (T == 1) { v.t_stride = (int)E.cur; v.tT_stride = (int)ET.cur; v.tB_stride = (int)L.srcB.size(); }
+  L.n_packedB = (int64_t)L.srcB.size();
   // ---- LDS staging plan (budget: 156 KiB of the 160 KiB LDS) ---------------------------------
   {
     const int budget = 156 * 1024 / 4;
@@ -464,6 +503,11 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
       }
     } else {
       v.n_parts = 0;
+    }
+    if (v.hidden_bf16) {
+      const int need = v.t_stride + (v.tB_stride + 1) / 2;  // floats: fp32 image + bf16 image of one transform
+      if (v.n_parts != 1 || need > budget)
+        return fail("hidden_bf16: one transform's fp32 + bf16 operand images must fit the 156 KiB LDS budget");
     }
   }
   L.n_packed = E.cur;

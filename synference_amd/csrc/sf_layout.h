@@ -61,6 +61,10 @@ struct SfDev {
   int inc_ok;
   int g_tile[SF_DMAX], g_kend[SF_DMAX];
   int mt_kend[4];  // input groups needed by hidden output tile mt (== nGh when not degree-sorted)
+  // bf16 operand image of the hidden HxH layers (inference, opt-in): [mt][ks][lane][8] bf16, ks = 16-row steps
+  const unsigned short* packedB;
+  int hidden_bf16, nKS, tB_stride;            // nKS = ceil(nGh/2); strides / offsets in bf16 elements
+  int oB_wk[SF_NBMAX], oB_w1[SF_NBMAX], oB_w2[SF_NBMAX];
   // constants image ------------------------------------------------------------------------
   int c_pscale, c_pshift, c_tdim, c_xmean, c_xstd;  // tdim stored as float-encoded ints
   int c_dslot;  // MAF: [t][p-1] = physical slot of the dimension with MADE degree p (float-encoded)
@@ -79,6 +83,8 @@ struct SfLayout {
   // order is [mt][kg][j][lane] (256 contiguous bytes per atomic wave-instruction) and a bias
   // block is [mt][32 rows].  gdst[i] = gradient-image index of logical parameter i, or -1.
   std::vector<int32_t> gdst;
+  std::vector<int32_t> srcB;          // bf16 hidden image gather table (one entry per bf16 element)
+  int64_t n_packedB = 0;
   std::vector<float> cst;             // constants image
   std::string error;
 };

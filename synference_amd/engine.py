@@ -50,7 +50,7 @@ class HipFlow:
         self._keep = (spec.theta_mean, spec.theta_std, spec.x_mean, spec.x_std, spec.perms)
         d = _lib.sf_flow_desc(
             kind=KIND_ID[spec.kind], D=spec.D, C=spec.C, H=spec.H, T=spec.T, K=spec.K, NB=spec.NB,
-            scale_fn=0 if spec.scale_fn == "softplus" else 1,
+            scale_fn=0 if spec.scale_fn == "softplus" else 1, hidden_bf16=1 if spec.hidden_bf16 else 0,
             tail_bound=spec.tail_bound, min_bin_width=spec.min_bin_width, min_bin_height=spec.min_bin_height,
             min_derivative=spec.min_derivative, maf_eps=spec.maf_eps, lu_eps=spec.lu_eps,
             theta_mean=spec.theta_mean.ctypes.data_as(_lib.c_f32p),

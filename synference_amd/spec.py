@@ -35,6 +35,7 @@ class FlowSpec:
     maf_eps: float = 1e-3
     lu_eps: float = 1e-3
     scale_fn: str = "softplus"   # "sigmoid2" = sigmoid(a+2) of nflows <= 0.13
+    hidden_bf16: bool = False    # bf16 MFMA operands for the hidden HxH layers of the inference kernels
     theta_mean: Optional[np.ndarray] = None
     theta_std: Optional[np.ndarray] = None
     x_mean: Optional[np.ndarray] = None
@@ -67,7 +68,7 @@ class FlowSpec:
 
     def to_dict(self) -> dict:
         d = {k: getattr(self, k) for k in ("kind", "D", "C", "H", "T", "K", "NB", "tail_bound", "min_bin_width",
-                                           "min_bin_height", "min_derivative", "maf_eps", "lu_eps", "scale_fn")}
+                                           "min_bin_height", "min_derivative", "maf_eps", "lu_eps", "scale_fn", "hidden_bf16")}
         for k in ("theta_mean", "theta_std", "x_mean", "x_std", "perms"):
             d[k] = getattr(self, k).tolist()
         return d

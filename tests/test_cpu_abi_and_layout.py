@@ -32,7 +32,7 @@ def test_desc_struct_matches_header_field_order():
     hdr = (ROOT / "include" / "synference_hip.h").read_text()
     body = hdr[hdr.index("typedef struct sf_flow_desc {"):hdr.index("} sf_flow_desc;")]
     fields = re.findall(r"(?:int32_t|float|const float\*|const int32_t\*)\s+([a-zA-Z_]+)(?:,\s*([a-zA-Z_]+))*;", body)
-    names = re.findall(r"\b([a-zA-Z_]+)\s*[;,]", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
+    names = re.findall(r"\b([a-zA-Z_][a-zA-Z_0-9]*)\s*[;,]", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
     assert names == [f[0] for f in _lib.sf_flow_desc._fields_]
 
 

@@ -108,3 +108,46 @@ def test_sampler_exhausted_attempts_give_nan_rows():
     got = f.sample(x, 40, lo, hi, seed=1, max_attempts=3)
     assert f.last_unfilled == 80
     assert torch.isnan(got).all()
+
+
+# ---------------------------------------------------------------------------------------------------
+# opt-in bf16 mode (BASELINE configs[4]): hidden H x H layers with bf16 MFMA operands, fp32 accumulate
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "nsf_odd", "maf_small"])
+def test_bf16_hidden_mode_matches_bf16_emulating_oracle(name):
+    """Tight: against the oracle with the SAME operand rounding (weights and hidden activations of the
+    H x H layers rounded to bf16, wide accumulation).  Loose: the stated distance to the fp32 flow."""
+    import dataclasses
+    ospec, spec, flat, theta, x = make_case(name, B=150)
+    spec_b = dataclasses.replace(spec, hidden_bf16=True)
+    ospec_b = dataclasses.replace(ospec, hidden_bf16=True)
+    f = _flow(spec_b, flat)
+    got = f.log_prob(theta, x).cpu().double().numpy()
+    ref_b = oracle_log_prob(ospec_b, flat, theta, x, torch.float64)
+    ref_f = oracle_log_prob(ospec, flat, theta, x, torch.float64)
+    # activations that sit on a bf16 rounding boundary can round differently (fp32 vs fp64 producer):
+    # allow a small fraction of rows at the bf16 level, the rest must be tight
+    err = np.abs(got - ref_b)
+    assert np.median(err) < 2e-4 and (err > 5e-3).mean() < 0.05, (np.median(err), err.max())
+    assert np.abs(got - ref_f).max() < 0.25, np.abs(got - ref_f).max()   # documented bf16-vs-fp32 tolerance
+    assert np.abs(ref_b - ref_f).max() > 1e-5                             # the mode really changes arithmetic
+    rng = np.random.default_rng(5)
+    z = rng.normal(size=theta.shape).astype(np.float32)
+    th, ld = f.inverse(z, x)
+    rth, rld = oracle_inverse(ospec_b, flat, z, x, torch.float64)
+    e2 = np.abs((th.cpu().double().numpy() - rth) / np.asarray(ospec.theta_std)).max(-1)
+    assert np.median(e2) < 5e-4 and (e2 > 2e-2).mean() < 0.05, (np.median(e2), e2.max())
+    # sampler runs and is reproducible in this mode
+    s1 = f.sample(x[:4], 64, seed=3).cpu().numpy()
+    assert np.isfinite(s1).all() and np.array_equal(s1, f.sample(x[:4], 64, seed=3).cpu().numpy())
+
+
+def test_bf16_mode_leaves_training_in_fp32():
+    import dataclasses
+    from test_gpu_train import oracle_loss_grad
+    ospec, spec, flat, theta, x = make_case("maf_cfg1", B=64)
+    f = _flow(dataclasses.replace(spec, hidden_bf16=True), flat)
+    loss, grad = f.loss_grad(torch.as_tensor(flat), theta, x, 1.0 / 64)
+    rloss, rgrad = oracle_loss_grad(ospec, flat, theta, x)
+    assert np.abs(loss.cpu().double().numpy() - rloss).max() < 1e-4
+    assert np.abs(grad.cpu().double().numpy() - rgrad).max() < 2e-4 * np.abs(rgrad).max()
