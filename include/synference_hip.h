@@ -228,6 +228,13 @@ int sf_mlp_backward(sf_mlp* m, const float* flat, const float* x, const float* d
 int sf_quantiles(const float* samples /*[N,S,D]*/, int64_t N, int64_t S, int32_t D,
                  const float* q /*[Q]*/, int32_t Q, float* out /*[N,D,Q]*/, void* stream);
 
+/* ---- feature transform on the device ------------------------------------------------------
+ * mag = -2.5 log10(flux_nJy / 1000) + 23.9 ; negative flux or NaN -> mag_limit ; mag > mag_limit -> mag_limit
+ * optional: mag_err = 2.5 err / (ln 10 flux).  All buffers [n] device, 16-byte aligned; err / mag_err may be NULL.
+ * Replaces the numpy pass at ref: sbi_runner.py:1698-1716 (AB branch) and 1927-1932 (faint limit). */
+int sf_flux_to_abmag(const float* flux_njy, const float* err_njy, int64_t n, float mag_limit,
+                     float* mag, float* mag_err, void* stream);
+
 /* ---- misc --------------------------------------------------------------------------- */
 const char* sf_last_error(void);
 const char* sf_version(void);

@@ -80,6 +80,7 @@ PROTOTYPES = {
                                   C.c_void_p]),
     "sf_quantiles": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                C.c_void_p]),
+    "sf_flux_to_abmag": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sf_last_error": (C.c_char_p, []),
     "sf_version": (C.c_char_p, []),
     "sf_device_count": (C.c_int, []),

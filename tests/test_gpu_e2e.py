@@ -185,3 +185,21 @@ def test_device_quantiles_match_numpy(fitted):
     for c in t_dev.columns:
         if c.endswith(("_16", "_50", "_84")):
             assert np.allclose(t_dev[c].to_numpy(), t_host[c].to_numpy(), rtol=1e-5, atol=1e-5), c
+
+
+def test_flux_to_abmag_matches_reference_formula():
+    from synference_amd.features import flux_to_abmag
+    rng = np.random.default_rng(0)
+    f = (10 ** rng.uniform(-3, 5, size=(1001, 7))).astype(np.float32)
+    f[3, 2] = -5.0; f[4, 1] = 0.0; f[5, 0] = np.nan; f[6, 6] = 1e-30
+    e = (0.1 * np.abs(f) + 1).astype(np.float32)
+    mag, merr = flux_to_abmag(torch.as_tensor(f).cuda(), torch.as_tensor(e).cuda(), 50.0)
+    with np.errstate(all="ignore"):
+        ref = -2.5 * np.log10(f.astype(np.float64) / 1000.0) + 23.9      # sbi_runner.py:1705
+        ref[f < 0] = 50.0                                                  # :1706, :1714
+        ref[~np.isfinite(ref)] = 50.0
+        ref[ref > 50.0] = 50.0                                             # :1932
+        rerr = 2.5 * e.astype(np.float64) / (np.log(10) * f.astype(np.float64))
+    assert np.abs(mag.cpu().double().numpy() - ref).max() < 2e-5
+    ok = np.isfinite(rerr) & (f > 0)
+    assert np.abs(merr.cpu().double().numpy()[ok] - rerr[ok]).max() < 1e-4 * np.abs(rerr[ok]).max()
