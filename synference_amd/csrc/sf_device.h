@@ -48,7 +48,20 @@ __device__ __forceinline__ const float* sf_stage_part(const SfDev& m, int t, int
   const float4* __restrict__ s4 = reinterpret_cast<const float4*>(src + lo);
   float4* __restrict__ d4 = reinterpret_cast<float4*>(lds);
   const int n4 = (hi - lo) >> 2;
-  for (int i = threadIdx.x; i < n4; i += blockDim.x) d4[i] = s4[i];
+  // 8 loads in flight per thread: the CU has nothing else to run during staging (one workgroup per CU)
+  for (int b0 = threadIdx.x; b0 < n4; b0 += blockDim.x * 8) {
+    float4 tmp[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = b0 + k * blockDim.x;
+      tmp[k] = s4[i < n4 ? i : b0];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = b0 + k * blockDim.x;
+      if (i < n4) d4[i] = tmp[k];
+    }
+  }
   if (m.hidden_bf16) {  // single-part images only (sf_layout.cpp): bf16 hidden operands right behind the fp32 image
     const uint4* __restrict__ sb = reinterpret_cast<const uint4*>(m.packedB + (size_t)t * m.tB_stride);
     uint4* __restrict__ db = reinterpret_cast<uint4*>(lds + m.t_stride);

@@ -1,6 +1,8 @@
 // sf_inst.hip -- one translation unit per (SF_KIND, SF_HT): instantiates the inference kernels
 // for that hidden-tile count and exports plain launchers (sf_internal.h, sf_launch_*_k?_h?).
 // NS (32-sample tiles per wave) is a runtime choice among the instantiated values.
+#include <cstdlib>
+
 #include "sf_inst_templates.h"
 
 #ifndef SF_KIND
@@ -12,6 +14,15 @@
 
 // LDS-staged variant when one transform's operand image fits the 160 KiB LDS (with slack)
 static inline bool sf_fits_lds(const SfDev& m) { return m.n_parts > 0; }
+// waves per workgroup of the LDS-staged kernels: 8 (one workgroup per CU) unless two 4-wave workgroups
+// fit the LDS side by side -- then one workgroup's staging barriers overlap the other's compute.
+// SF_WPB=4|8 overrides (diagnostics).
+static inline int sf_lds_wpb(size_t shmem_bytes) {
+  static int forced = -1;
+  if (forced < 0) { const char* e = std::getenv("SF_WPB"); forced = e ? std::atoi(e) : 0; }
+  if (forced == 4 || forced == 8) return forced;
+  return 2 * shmem_bytes <= 156 * 1024 ? 4 : 8;
+}
 
 template <class K>
 static hipError_t set_shmem(K kernel, size_t bytes, bool& done) {
@@ -28,8 +39,9 @@ static hipError_t launch_logprob_bf16(const SfDev& m, const float* theta, const 
   const size_t sh = (size_t)m.part_max * sizeof(float) + (size_t)m.tB_stride * sizeof(unsigned short);
   hipError_t e = set_shmem(k_logprob<OpsB, 1, true>, sh, attr);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_logprob<OpsB, 1, true>), dim3((unsigned)((B + 255) / 256)), dim3(512), sh, st, m, theta, x, B,
-                     out);
+  const int wpb = sf_lds_wpb(sh);
+  hipLaunchKernelGGL((k_logprob<OpsB, 1, true>), dim3((unsigned)((B + 32 * wpb - 1) / (32 * wpb))), dim3(64 * wpb), sh, st,
+                     m, theta, x, B, out);
   return hipGetLastError();
 }
 template <class OpsB>
@@ -38,7 +50,9 @@ static hipError_t launch_inverse_bf16(const SfDev& m, const SfSampleArgsHost& a,
   const size_t sh = (size_t)m.part_max * sizeof(float) + (size_t)m.tB_stride * sizeof(unsigned short);
   hipError_t e = set_shmem(k_inverse<OpsB, 1, true>, sh, attr);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_inverse<OpsB, 1, true>), dim3((unsigned)((a.n_items + 255) / 256)), dim3(512), sh, st, m, a);
+  const int wpb = sf_lds_wpb(sh);
+  hipLaunchKernelGGL((k_inverse<OpsB, 1, true>), dim3((unsigned)((a.n_items + 32 * wpb - 1) / (32 * wpb))), dim3(64 * wpb),
+                     sh, st, m, a);
   return hipGetLastError();
 }
 
@@ -50,8 +64,9 @@ static hipError_t launch_logprob(const SfDev& m, const float* theta, const float
     const size_t sh = (size_t)m.part_max * sizeof(float);
     hipError_t e = set_shmem(k_logprob<OpsL, NS, true>, sh, attr);
     if (e != hipSuccess) return e;
-    const long per_block = 8L * 32 * NS;
-    hipLaunchKernelGGL((k_logprob<OpsL, NS, true>), dim3((unsigned)((B + per_block - 1) / per_block)), dim3(512),
+    const int wpb = sf_lds_wpb(sh);
+    const long per_block = (long)wpb * 32 * NS;
+    hipLaunchKernelGGL((k_logprob<OpsL, NS, true>), dim3((unsigned)((B + per_block - 1) / per_block)), dim3(64 * wpb),
                        sh, st, m, theta, x, B, out);
   } else {
     const long per_block = 4L * 32 * NS;
@@ -67,9 +82,10 @@ static hipError_t launch_inverse(const SfDev& m, const SfSampleArgsHost& a, hipS
     const size_t sh = (size_t)m.part_max * sizeof(float);
     hipError_t e = set_shmem(k_inverse<OpsL, NS, true>, sh, attr);
     if (e != hipSuccess) return e;
-    const long per_block = 8L * 32 * NS;
+    const int wpb = sf_lds_wpb(sh);
+    const long per_block = (long)wpb * 32 * NS;
     hipLaunchKernelGGL((k_inverse<OpsL, NS, true>), dim3((unsigned)((a.n_items + per_block - 1) / per_block)),
-                       dim3(512), sh, st, m, a);
+                       dim3(64 * wpb), sh, st, m, a);
   } else {
     const long per_block = 4L * 32 * NS;
     hipLaunchKernelGGL((k_inverse<OpsG, NS, false>), dim3((unsigned)((a.n_items + per_block - 1) / per_block)),

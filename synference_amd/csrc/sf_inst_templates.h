@@ -21,7 +21,7 @@ __global__ __launch_bounds__(LDSW ? 512 : 256) void k_logprob(SfDev m, const flo
                                                               float* __restrict__ out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, h = lane >> 5;
-  const long base = ((long)blockIdx.x * (LDSW ? 8 : 4) + wave) * (32 * NS);
+  const long base = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * (32 * NS);
   if (!LDSW && base >= B) return;  // LDSW: every wave takes part in the staging barriers
   float u[NS][SF_DMAX];
   const float* xr[NS];
@@ -68,7 +68,7 @@ template <class Ops, int NS, bool LDSW>
 __global__ __launch_bounds__(LDSW ? 512 : 256) void k_inverse(SfDev m, SfSampleArgsHost a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, h = lane >> 5;
-  const long base = ((long)blockIdx.x * (LDSW ? 8 : 4) + wave) * (32 * NS);
+  const long base = ((long)blockIdx.x * (blockDim.x >> 6) + wave) * (32 * NS);
   if (!LDSW && base >= a.n_items) return;
   float u[NS][SF_DMAX];
   const float* xr[NS];
