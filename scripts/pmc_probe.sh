@@ -1,0 +1,26 @@
+#!/bin/bash
+# On the GPU box: PMC passes over scripts/probe_maf.py (one dense MAF sampling round per launch).
+# usage: scripts/pmc_probe.sh <tag>   (env such as SF_MAF16 is inherited)
+set -e
+TAG=$1
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+RAW=/tmp/pmcprobe_$TAG; rm -rf $RAW; mkdir -p $RAW gpurun_out
+i=0
+for pass in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_BRANCH SQ_INSTS_VALU_TRANS_F32" \
+            "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS" \
+            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU SQ_LEVEL_WAVES"; do
+  i=$((i+1))
+  SF_PROBE_N=3 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $RAW/p$i -- python3 scripts/probe_maf.py > $RAW/p$i.out 2> $RAW/p$i.err || { tail -5 $RAW/p$i.err; exit 1; }
+done
+python3 - "$RAW" "$TAG" <<'PY' | tee gpurun_out/pmc_probe_$1.txt
+import csv, glob, sys, collections
+raw, tag = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(list); name = None
+for f in glob.glob(raw + '/p*/*/*_counter_collection.csv'):
+    for r in csv.DictReader(open(f)):
+        if ('k_inverse' in r['Kernel_Name'] or 'k_maf_inv16' in r['Kernel_Name']) and int(r['Grid_Size']) > 1000000:
+            acc[r['Counter_Name']].append(float(r['Counter_Value'])); name = r['Kernel_Name']
+            regs = (r.get('VGPR_Count'), r.get('Accum_VGPR_Count'), r.get('LDS_Block_Size'), r.get('Scratch_Size'), r['Grid_Size'], r['Workgroup_Size'])
+print(tag, name, 'vgpr/agpr/lds/scratch/grid/wg', regs)
+for k in sorted(acc): print(f"{k:32s} {sum(acc[k])/len(acc[k]):16.0f}  n={len(acc[k])}")
+PY

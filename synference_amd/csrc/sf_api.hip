@@ -41,6 +41,14 @@ static int ensure_device(sf_flow* f) {
   SF_HIP(hipMalloc(&f->d_s2, np * sizeof(int32_t)));
   SF_HIP(hipMemcpy(f->d_s1, f->L.src1.data(), np * sizeof(int32_t), hipMemcpyHostToDevice));
   SF_HIP(hipMemcpy(f->d_s2, f->L.src2.data(), np * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (f->L.dev.m16_ok && f->L.n_packed16 > 0) {
+    const size_t n16 = (size_t)f->L.n_packed16;
+    SF_HIP(hipMalloc(&f->d_packed16, n16 * sizeof(float)));
+    SF_HIP(hipMalloc(&f->d_s16a, n16 * sizeof(int32_t)));
+    SF_HIP(hipMalloc(&f->d_s16b, n16 * sizeof(int32_t)));
+    SF_HIP(hipMemcpy(f->d_s16a, f->L.src16a.data(), n16 * sizeof(int32_t), hipMemcpyHostToDevice));
+    SF_HIP(hipMemcpy(f->d_s16b, f->L.src16b.data(), n16 * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   if (f->L.n_packedB > 0) {
     SF_HIP(hipMalloc(&f->d_packedB, (size_t)f->L.n_packedB * sizeof(unsigned short)));
     SF_HIP(hipMalloc(&f->d_bsrc, (size_t)f->L.n_packedB * sizeof(int32_t)));
@@ -80,6 +88,7 @@ void sf_flow_destroy(sf_flow* f) {
   if (!f) return;
   if (f->dev_ready) {
     (void)hipFree(f->d_packed); (void)hipFree(f->d_packedT); (void)hipFree(f->d_cst); (void)hipFree(f->d_packedB); (void)hipFree(f->d_bsrc);
+    (void)hipFree(f->d_packed16); (void)hipFree(f->d_s16a); (void)hipFree(f->d_s16b);
     (void)hipFree(f->d_s1); (void)hipFree(f->d_s2); (void)hipFree(f->d_t1); (void)hipFree(f->d_t2);
     (void)hipFree(f->d_flat); (void)hipFree(f->d_gpacked); (void)hipFree(f->d_gdst);
     (void)hipFree(f->d_act); (void)hipFree(f->d_rej[0]); (void)hipFree(f->d_rej[1]); (void)hipFree(f->d_cnt);
@@ -149,6 +158,7 @@ int sf_flow_set_params(sf_flow* f, const float* flat, int64_t n, int is_device, 
     src = f->d_flat;
   }
   SF_HIP(sf_launch_pack(src, f->d_s1, f->d_s2, f->d_packed, (long)f->L.n_packed, st));
+  if (f->d_packed16) SF_HIP(sf_launch_pack(src, f->d_s16a, f->d_s16b, f->d_packed16, (long)f->L.n_packed16, st));
   if (f->L.n_packedB > 0) SF_HIP(sf_launch_pack_bf16(src, f->d_bsrc, f->d_packedB, (long)f->L.n_packedB, st));
   f->params_set = true;
   return SF_OK;

@@ -27,6 +27,8 @@ struct SfSampleArgsHost {
 hipError_t sf_launch_logprob(const SfDev& m, const float* theta, const float* x, long B, float* out,
                              hipStream_t st);
 hipError_t sf_launch_inverse(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st);
+bool sf_maf16_enabled(const SfDev& m, const SfSampleArgsHost& a);
+hipError_t sf_launch_maf_inv16(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st);
 hipError_t sf_launch_pack(const float* flat, const int32_t* s1, const int32_t* s2, float* packed, long n,
                           hipStream_t st);
 hipError_t sf_launch_pack_bf16(const float* flat, const int32_t* src, unsigned short* out, long n, hipStream_t st);
@@ -46,6 +48,8 @@ struct sf_flow {
   float* d_cst = nullptr;
   unsigned short* d_packedB = nullptr;  // bf16 hidden operand image (hidden_bf16)
   int32_t* d_bsrc = nullptr;
+  float* d_packed16 = nullptr;          // 16-row image of the incremental MAF inverse (sf_maf16.hip)
+  int32_t *d_s16a = nullptr, *d_s16b = nullptr;
   int32_t *d_s1 = nullptr, *d_s2 = nullptr, *d_t1 = nullptr, *d_t2 = nullptr;
   float* d_flat = nullptr;      // staging for host-sourced parameters
   float* d_gpacked = nullptr;   // gradient image (atomic accumulation target)
@@ -61,6 +65,7 @@ struct sf_flow {
     v.packedT = d_packedT;
     v.cst = d_cst;
     v.packedB = d_packedB;
+    v.packed16 = d_packed16;
     return v;
   }
 };

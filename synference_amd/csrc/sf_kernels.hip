@@ -88,6 +88,7 @@ hipError_t sf_launch_logprob(const SfDev& m, const float* theta, const float* x,
 
 hipError_t sf_launch_inverse(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
   if (a.n_items <= 0) return hipSuccess;
+  if (sf_maf16_enabled(m, a)) return sf_launch_maf_inv16(m, a, st);
   const int ns = sf_pick_ns(m, true);
   switch (m.kind * 10 + m.HT) {
     SF_CASE(0, 1, sf_launch_inverse, m, ns, a, st)

@@ -106,7 +106,9 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
   // that fits in <= 4 tiles (then the masked HxH blocks are block-lower-triangular in tile/group
   // units and the autoregressive inverse can be evaluated incrementally).
   std::vector<int> hrow_full(4 * 32, -1);
+  std::vector<int> h16row(4 * 16, -1);
   v.inc_ok = 0;
+  v.m16_ok = 0;
   if (d.kind == SF_MAF) {
     const int mx = std::max(1, D - 1), mn = std::min(1, D - 1);
     const int G = mx;  // degree values mn .. mn+G-1
@@ -141,6 +143,24 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
       int r = 0;
       for (int g = 0; g < G; ++g)
         for (int j : grp[g]) hrow_full[r++] = j;
+    }
+    // 16-row tiles for the 16x16x4 incremental inverse: whole degree groups, at most 4 tiles
+    {
+      h16row.assign(4 * 16, -1);
+      int tile16 = 0, used16 = 0;
+      bool ok16 = (D >= 2 && NB <= 2);
+      for (int g = 0; g < G && ok16; ++g) {
+        const int n = (int)grp[g].size();
+        if (n > 16) { ok16 = false; break; }
+        if (used16 + n > 16) { ++tile16; used16 = 0; }
+        if (tile16 >= 4) { ok16 = false; break; }
+        for (int q = 0; q < n; ++q) h16row[tile16 * 16 + used16 + q] = grp[g][q];
+        used16 += n;
+        v.g16_tile[g + mn] = tile16;
+      }
+      v.m16_ok = ok16 ? 1 : 0;
+      v.nT16 = ok16 ? tile16 + 1 : 0;
+      v.nC16 = ceil_div(C, 16);
     }
   } else {
     for (int j = 0; j < H; ++j) hrow_full[j] = j;
@@ -326,6 +346,64 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
         o = (int)(ET.linear(CT, v.nGh, iota_rows(C, CT * 32), hrow_in, lWc, 1, C, nullptr) - tbT);
         if (t == 0) v.oT_wc = o;
       }
+      // ---- 16-row-granular image for the incremental inverse ------------------------------------
+      if (v.m16_ok) {
+        auto push16 = [&](int32_t a, int32_t b) { L.src16a.push_back(a); L.src16b.push_back(b); };
+        while (L.src16a.size() % 64) push16(-1, -1);
+        const int64_t tb16 = (int64_t)L.src16a.size();
+        if (t == 1) v.t16_stride = (int)tb16;
+        auto here = [&]() { return (int)((int64_t)L.src16a.size() - tb16); };
+        // weight block [ot][it][64 lanes][4]: lane l: out row ot*16+(l&15), in rows it*16 + 4*(l>>4) + r
+        auto linear16 = [&](int OT, int IT, const std::vector<int>& orow, const std::vector<int>& irow, int64_t base,
+                            int in_dim, const std::function<bool(int, int)>& mask) {
+          for (int ot = 0; ot < OT; ++ot)
+            for (int it = 0; it < IT; ++it)
+              for (int l = 0; l < 64; ++l)
+                for (int r = 0; r < 4; ++r) {
+                  const int oo = orow[ot * 16 + (l & 15)], ii = irow[it * 16 + 4 * (l >> 4) + r];
+                  push16((oo >= 0 && ii >= 0 && (!mask || mask(oo, ii))) ? (int32_t)(base + (int64_t)oo * in_dim + ii) : -1, -1);
+                }
+        };
+        auto bias16 = [&](int OT, const std::vector<int>& orow, int64_t b1, int64_t b2) {
+          for (int ot = 0; ot < OT; ++ot)
+            for (int g4 = 0; g4 < 4; ++g4)
+              for (int r = 0; r < 4; ++r) {
+                const int oo = orow[ot * 16 + 4 * g4 + r];
+                push16(oo >= 0 ? (int32_t)(b1 + oo) : -1, (oo >= 0 && b2 >= 0) ? (int32_t)(b2 + oo) : -1);
+              }
+        };
+        std::vector<int> u16(16, -1);
+        for (int p = 0; p < D; ++p) u16[p] = sinv[p];
+        const std::vector<int> c16 = iota_rows(C, v.nC16 * 16);
+        const int NT = v.nT16;
+        if (t == 0) v.o16_w0 = here();
+        linear16(NT, 1, h16row, u16, lW0, D, [&](int j, int i) { return deg_h(j) >= i + 1; });
+        if (t == 0) v.o16_wc = here();
+        linear16(NT, v.nC16, h16row, c16, lWc, C, nullptr);
+        if (t == 0) v.o16_b0 = here();
+        bias16(NT, h16row, lb0, lbc);
+        for (int k = 0; k < NB && k < 2; ++k) {
+          if (t == 0) v.o16_wk[k] = here();
+          linear16(NT, NT, h16row, h16row, lWk[k], H, [&](int j, int i) { return deg_h(j) >= deg_h(i); });
+          if (t == 0) v.o16_bk[k] = here();
+          bias16(NT, h16row, lbk[k], -1);
+        }
+        // head rows for the per-lane dot product: [slot][a|m][g4][tile (4)][r]
+        if (t == 0) v.o16_hv = here();
+        for (int q = 0; q < D; ++q)
+          for (int ab = 0; ab < 2; ++ab)
+            for (int g4 = 0; g4 < 4; ++g4)
+              for (int tl = 0; tl < 4; ++tl)
+                for (int r = 0; r < 4; ++r) {
+                  const int unit = tl < NT ? h16row[tl * 16 + 4 * g4 + r] : -1;
+                  const int orow_l = 2 * sinv[q] + ab;
+                  const bool on = unit >= 0 && (orow_l / 2 + 1) > deg_h(unit);
+                  push16(on ? (int32_t)(lWf + (int64_t)orow_l * H + unit) : -1, -1);
+                }
+        if (t == 0) v.o16_hvb = here();
+        for (int q = 0; q < D; ++q)
+          for (int ab = 0; ab < 2; ++ab) push16((int32_t)(lbf + 2 * sinv[q] + ab), -1);
+      }
     }
   } else {
     v.PT = K <= 11 ? 2 : 3;  // PT=1 (K<=5) is not instantiated: K<=11 shares the 2-tile layout
@@ -464,7 +542,13 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
   E.pad_to(64);
   ET.pad_to(64);
   while (L.srcB.size() % 64) L.srcB.push_back(-1);
-  if (T == 1) { v.t_stride = (int)E.cur; v.tT_stride = (int)ET.cur; v.tB_stride = (int)L.srcB.size(); }
+  while (L.src16a.size() % 64) { L.src16a.push_back(-1); L.src16b.push_back(-1); }
+  if (T == 1) {
+    v.t_stride = (int)E.cur; v.tT_stride = (int)ET.cur; v.tB_stride = (int)L.srcB.size();
+    v.t16_stride = (int)L.src16a.size();
+  }
+  L.n_packed16 = (int64_t)L.src16a.size();
+  if (v.m16_ok && (size_t)v.t16_stride * sizeof(float) > 156 * 1024) v.m16_ok = 0;
   L.n_packedB = (int64_t)L.srcB.size();
   // ---- LDS staging plan (budget: 156 KiB of the 160 KiB LDS) ---------------------------------
   {

@@ -65,6 +65,13 @@ struct SfDev {
   const unsigned short* packedB;
   int hidden_bf16, nKS, tB_stride;            // nKS = ceil(nGh/2); strides / offsets in bf16 elements
   int oB_wk[SF_NBMAX], oB_w1[SF_NBMAX], oB_w2[SF_NBMAX];
+  // 16-row-granular image of the incremental MAF inverse (v_mfma_f32_16x16x4_f32; sf_maf16.h) --------------
+  //   tile = 16 samples x 16 rows in 4 VGPRs: lane l: sample l&15, rows 4*(l>>4)+r; degree groups packed whole
+  //   into <= 4 tiles of 16 rows.  m16_ok = 0 when that packing does not exist (then the 32-row path is used).
+  const float* packed16;
+  int m16_ok, nT16, nC16, t16_stride;
+  int o16_w0, o16_wc, o16_b0, o16_wk[2], o16_bk[2], o16_hv, o16_hvb;
+  int g16_tile[SF_DMAX];  // tile that holds the hidden units of MADE degree g
   // constants image ------------------------------------------------------------------------
   int c_pscale, c_pshift, c_tdim, c_xmean, c_xstd;  // tdim stored as float-encoded ints
   int c_dslot;  // MAF: [t][p-1] = physical slot of the dimension with MADE degree p (float-encoded)
@@ -84,6 +91,8 @@ struct SfLayout {
   // block is [mt][32 rows].  gdst[i] = gradient-image index of logical parameter i, or -1.
   std::vector<int32_t> gdst;
   std::vector<int32_t> srcB;          // bf16 hidden image gather table (one entry per bf16 element)
+  std::vector<int32_t> src16a, src16b;  // 16-row image gather table (sum of two sources, like src1/src2)
+  int64_t n_packed16 = 0;
   int64_t n_packedB = 0;
   std::vector<float> cst;             // constants image
   std::string error;

@@ -1,0 +1,315 @@
+// sf_maf16.hip -- incremental MAF inverse / sampler on v_mfma_f32_16x16x4_f32 (16-row granularity).
+//
+// Same algorithm and the same C-ABI entry points as k_inverse<MafOps> (sf_flows.h, sf_inst_templates.h); only
+// the tile geometry differs so that a 12-13 unit MADE degree group costs one 16-row tile instead of a 32-row one:
+//   lane l: sample s = l & 15 of a 16-sample tile, row group g4 = l >> 4; a tile is 4 VGPRs, a[r] = row 4*g4 + r
+//   C/D layout of the 16x16x4 MFMA == B-operand order of the next layer (k-step r <-> register r), so the
+//   activations stay in registers exactly as in the 32-row engine.
+//   weights: float4[(ot*IT + it)*64 + l] = W[ot*16 + (l&15)][it*16 + 4*(l>>4) + r], r = 0..3 (sf_layout.cpp)
+// One wave = one tile of 16 draws, 4 waves per workgroup; the transform's 16-row image is staged in LDS.  The
+// draw itself also lives in tile layout (lane (s, g4) owns physical slots 4*g4..4*g4+3), so Philox, the box test
+// and the output writes are split over the four row groups instead of being repeated by them.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "sf_device.h"
+#include "sf_internal.h"
+#include "sf_rng.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define SF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float sf_sum4groups(float v) {  // sum over the 4 row groups of a sample
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ f32x4 sf_mma16(float4 w, const f32x4& in, f32x4 acc) {
+  acc = SF_MFMA16(w.x, in[0], acc);
+  acc = SF_MFMA16(w.y, in[1], acc);
+  acc = SF_MFMA16(w.z, in[2], acc);
+  acc = SF_MFMA16(w.w, in[3], acc);
+  return acc;
+}
+__device__ __forceinline__ f32x4 sf_ld4(const float* p) {
+  const float4 b = *reinterpret_cast<const float4*>(p);
+  f32x4 r;
+  r[0] = b.x; r[1] = b.y; r[2] = b.z; r[3] = b.w;
+  return r;
+}
+// weight fragment of (out tile ot, in tile it) of a block with IT input tiles
+__device__ __forceinline__ float4 sf_w16(const float* wp, int IT, int ot, int it, int lane) {
+  return reinterpret_cast<const float4*>(wp)[(ot * IT + it) * 64 + lane];
+}
+
+extern __shared__ float sf_lds16[];
+
+struct SfPass16 {
+  f32x4 act[3][4];  // act[0] = initial layer, act[k+1] = output of block k; [tile]
+  f32x4 c0[4];      // b0 + bc + Wc e(x), per tile
+  f32x4 ut;         // finished dimensions of this transform, tile layout: slot 4*g4 + r
+  float ldl;
+};
+
+// One autoregressive pass with the degree group in (static) tile OT: recompute that tile of every hidden
+// layer from the finished dimensions, then the (a, m) head rows of physical slot sl as per-lane dot products.
+template <int OT, int NB>
+__device__ __forceinline__ void sf_pass16(const SfDev& m, const float* tp, SfPass16& S, int NT, int sl, float u_sl,
+                                          int lane, int g4) {
+  // everything that does not depend on this pass's new dimension first: weight fragments, partial sums
+  const float* hv = tp + m.o16_hv + sl * 128 + g4 * 16;
+  float4 w0 = sf_w16(tp + m.o16_w0, 1, OT, 0, lane);
+  float4 wk[2][OT + 1];
+  f32x4 bk[2];
+  float4 ha[OT + 1], hm[OT + 1];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    bk[k] = sf_ld4(tp + m.o16_bk[k] + (OT * 4 + g4) * 4);
+#pragma unroll
+    for (int it = 0; it <= OT; ++it) wk[k][it] = sf_w16(tp + m.o16_wk[k], NT, OT, it, lane);
+  }
+#pragma unroll
+  for (int tl = 0; tl <= OT; ++tl) {
+    ha[tl] = *reinterpret_cast<const float4*>(hv + tl * 4);
+    hm[tl] = *reinterpret_cast<const float4*>(hv + 64 + tl * 4);
+  }
+  const float ba = tp[m.o16_hvb + 2 * sl], bm = tp[m.o16_hvb + 2 * sl + 1];
+  float pa = 0.f, pm = 0.f;
+#pragma unroll
+  for (int tl = 0; tl < OT; ++tl) {
+    const f32x4& av = S.act[NB][tl];
+    pa += ha[tl].x * av[0] + ha[tl].y * av[1] + ha[tl].z * av[2] + ha[tl].w * av[3];
+    pm += hm[tl].x * av[0] + hm[tl].y * av[1] + hm[tl].z * av[2] + hm[tl].w * av[3];
+  }
+#pragma unroll
+  for (int k = 0; k < NB; ++k)
+#pragma unroll
+    for (int it = 0; it < OT; ++it) bk[k] = sf_mma16(wk[k][it], S.act[k][it], bk[k]);
+  // the dependent chain
+  S.act[0][OT] = sf_mma16(w0, S.ut, S.c0[OT]);
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    const f32x4 b = sf_mma16(wk[k][OT], S.act[k][OT], bk[k]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S.act[k + 1][OT][r] = sf_tanh(b[r]);
+  }
+  {
+    const f32x4& av = S.act[NB][OT];
+    pa += ha[OT].x * av[0] + ha[OT].y * av[1] + ha[OT].z * av[2] + ha[OT].w * av[3];
+    pm += hm[OT].x * av[0] + hm[OT].y * av[1] + hm[OT].z * av[2] + hm[OT].w * av[3];
+  }
+  const float av = ba + sf_sum4groups(pa);
+  const float mv = bm + sf_sum4groups(pm);
+  const float sc = (m.scale_fn == 0 ? sf_softplus(av) : sf_sigmoid(av + 2.0f)) + m.eps;
+  const float wv = sf_div(u_sl - mv, sc);
+  S.ldl += sf_log(sc);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) S.ut[r] = (g4 == (sl >> 2) && r == (sl & 3)) ? wv : S.ut[r];
+}
+
+// value of physical slot sl from a tile-layout register quad, broadcast to every row group
+__device__ __forceinline__ float sf_slot16(const f32x4& t, int sl, int lane) {
+  const int r = sl & 3;
+  const float v = r == 0 ? t[0] : (r == 1 ? t[1] : (r == 2 ? t[2] : t[3]));
+  return __shfl(v, (lane & 15) + 16 * (sl >> 2), 64);
+}
+
+template <int NB>
+__global__ __launch_bounds__(256, 3) void k_maf_inv16(SfDev m, SfSampleArgsHost a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = lane & 15, g4 = lane >> 4;
+  // (no early exit: every wave takes part in the staging barriers)
+  const long item = ((long)blockIdx.x * 4 + wave) * 16 + s;
+  const bool valid = item < a.n_items;
+  const long it = valid ? item : a.n_items - 1;
+  // tile layout: this lane holds physical slots 4*g4 .. 4*g4+3 of sample s
+  f32x4 u;
+  uint64_t slot;
+  long gal;
+  if (a.z_in) {
+    slot = (uint64_t)it;
+    gal = it;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) u[r] = (4 * g4 + r < m.D) ? a.z_in[it * m.D + 4 * g4 + r] : 0.f;
+  } else {
+    const long ps = it / a.attempts_per_slot;  // listed slot; A consecutive items share it
+    slot = a.slots ? (uint64_t)a.slots[ps] : (uint64_t)(a.slot_base + ps);
+    gal = (long)(slot / (uint64_t)a.S);
+    const uint32_t att = a.attempt + (uint32_t)(it % a.attempts_per_slot);
+    float z4[4];
+    sf_normal4(a.k0, a.k1, slot, att, (uint32_t)g4, z4);  // Philox block g4 = dimensions 4*g4 .. 4*g4+3
+#pragma unroll
+    for (int r = 0; r < 4; ++r) u[r] = (4 * g4 + r < m.D) ? z4[r] : 0.f;
+  }
+  const float* xr = a.x + gal * m.C;
+  float logdet = 0.f;
+
+  // standardised context, tile ic: rows 16*ic + 4*g4 + r  (tile 0 is kept in registers across the transforms)
+  auto ctx_tile = [&](int ic) {
+    f32x4 ct;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rho = ic * 16 + 4 * g4 + r;
+      const bool ok = rho < m.C;
+      const int rr = ok ? rho : 0;
+      const float v = (xr[rr] - m.cst[m.c_xmean + rr]) / m.cst[m.c_xstd + rr];
+      ct[r] = ok ? v : 0.f;
+    }
+    return ct;
+  };
+  const f32x4 ct0 = ctx_tile(0);
+
+  const int NT = m.nT16;
+  uint32_t tile_bits = 0;  // g16_tile packed 2 bits per degree (static indexing keeps the argument in SGPRs)
+#pragma unroll
+  for (int q = 0; q < SF_DMAX; ++q) tile_bits |= (uint32_t)(m.g16_tile[q] & 3) << (2 * q);
+  for (int t = m.T - 1; t >= 0; --t) {
+    // ---- stage this transform's 16-row image (8 loads in flight per thread)
+    __syncthreads();
+    {
+      const float4* __restrict__ s4 = reinterpret_cast<const float4*>(m.packed16 + (size_t)t * m.t16_stride);
+      float4* __restrict__ d4 = reinterpret_cast<float4*>(sf_lds16);
+      const int n4 = m.t16_stride >> 2;
+      for (int i = threadIdx.x; i < n4; i += 8 * 256) {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = s4[i + j * 256 < n4 ? i + j * 256 : i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (i + j * 256 < n4) d4[i + j * 256] = v[j];
+      }
+    }
+    __syncthreads();
+    const float* tp = sf_lds16;
+    SfPass16 S;
+    // context product hoisted out of the passes: c0 = b0 + bc + Wc e
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot)
+      if (ot < NT) {
+        S.c0[ot] = sf_ld4(tp + m.o16_b0 + (ot * 4 + g4) * 4);
+        S.c0[ot] = sf_mma16(sf_w16(tp + m.o16_wc, m.nC16, ot, 0, lane), ct0, S.c0[ot]);
+      }
+    for (int ic = 1; ic < m.nC16; ++ic) {
+      const f32x4 ct = ctx_tile(ic);
+#pragma unroll
+      for (int ot = 0; ot < 4; ++ot)
+        if (ot < NT) S.c0[ot] = sf_mma16(sf_w16(tp + m.o16_wc, m.nC16, ot, ic, lane), ct, S.c0[ot]);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S.act[k][ot][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S.ut[r] = 0.f;
+    S.ldl = 0.f;
+    // physical slot of the dimension with MADE degree p: lane q holds entry q, read back with v_readlane
+    const int dsl = (int)m.cst[m.c_dslot + t * SF_DMAX + s];
+    {
+      // pass 1: the dimension of degree 1 depends on the context only (head bias)
+      const int sl = __builtin_amdgcn_readlane(dsl, 0);
+      const float av = tp[m.o16_hvb + 2 * sl], mv = tp[m.o16_hvb + 2 * sl + 1];
+      const float sc = (m.scale_fn == 0 ? sf_softplus(av) : sf_sigmoid(av + 2.0f)) + m.eps;
+      const float wv = sf_div(sf_slot16(u, sl, lane) - mv, sc);
+      S.ldl += sf_log(sc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S.ut[r] = (g4 == (sl >> 2) && r == (sl & 3)) ? wv : S.ut[r];
+    }
+    for (int p = 2; p <= m.D; ++p) {
+      const int sl = __builtin_amdgcn_readlane(dsl, p - 1);
+      const float u_sl = sf_slot16(u, sl, lane);
+      switch ((tile_bits >> (2 * (p - 1))) & 3u) {
+        case 0: sf_pass16<0, NB>(m, tp, S, NT, sl, u_sl, lane, g4); break;
+        case 1: sf_pass16<1, NB>(m, tp, S, NT, sl, u_sl, lane, g4); break;
+        case 2: sf_pass16<2, NB>(m, tp, S, NT, sl, u_sl, lane, g4); break;
+        default: sf_pass16<3, NB>(m, tp, S, NT, sl, u_sl, lane, g4); break;
+      }
+    }
+    logdet -= S.ldl;
+    u = S.ut;
+  }
+
+  // ---------------------------------------------------------------- un-standardise, box test, outputs
+  // each lane owns 4 physical slots of its sample; a draw is accepted when all 4 row groups agree
+  float th[4];
+  bool ok = true;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int p = 4 * g4 + r;
+    th[r] = 0.f;
+    if (p < m.D) {
+      const int td = (int)m.cst[m.c_tdim + p];
+      th[r] = (u[r] - m.cst[m.c_pshift + p]) / m.cst[m.c_pscale + p];
+      ok = ok && (fabsf(th[r]) <= 3.0e38f);  // finite (NaN compares false)
+      if (a.lo) ok = ok && (th[r] >= a.lo[td]) && (th[r] <= a.hi[td]);
+    }
+  }
+  const unsigned long long okb = __ballot(ok);
+  const uint32_t acc16 = (uint32_t)(okb & (okb >> 16) & (okb >> 32) & (okb >> 48) & 0xffffull) &
+                         (uint32_t)(__ballot(valid) & 0xffffull);
+  const bool accepted = (acc16 >> s) & 1u;
+  if (a.z_in) {
+    if (valid) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * g4 + r < m.D) a.out[item * m.D + (int)m.cst[m.c_tdim + 4 * g4 + r]] = th[r];
+      if (a.logdet_out && g4 == 0) a.logdet_out[item] = logdet - m.logdet0;
+    }
+  } else if (a.count) {
+    const long g_first = __shfl(gal, 0, 64);
+    const long g_last = __shfl(gal, 15, 64);
+    if (g_first == g_last) {
+      if (lane == 0 && acc16) atomicAdd(&a.count[g_first], (int)__popc(acc16));
+    } else if (accepted && g4 == 0) {
+      atomicAdd(&a.count[gal], 1);
+    }
+  } else {
+    // A <= 16 consecutive items hold attempts att..att+A-1 of one slot: the lowest accepted one wins
+    const int A = a.attempts_per_slot;
+    const int grp0 = (s / A) * A;
+    const uint32_t gmask = (acc16 >> grp0) & ((1u << A) - 1u);
+    const int first = gmask ? (int)__builtin_ctz(gmask) : -1;
+    const int me = s - grp0;
+    if (valid) {
+      if (g4 == 0 && me == 0 && a.n_drawn && a.attempt > 0) atomicAdd(&a.n_drawn[gal], first >= 0 ? first + 1 : A);
+      if (me == first) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * g4 + r < m.D) a.out[slot * m.D + (int)m.cst[m.c_tdim + 4 * g4 + r]] = th[r];
+      } else if (first < 0 && me == 0 && g4 == 0) {
+        const uint32_t pos = atomicAdd(a.n_rejected, 1u);
+        a.rejected[pos] = (uint32_t)slot;
+      }
+    }
+  }
+}
+
+// SF_MAF16=0 disables the path (diagnostics / A-B runs).  A = 32 retry rounds stay on the 32-row kernel.
+bool sf_maf16_enabled(const SfDev& m, const SfSampleArgsHost& a) {
+  static int env = -1;
+  if (env < 0) {
+    const char* e = std::getenv("SF_MAF16");
+    env = e ? std::atoi(e) : 1;
+  }
+  return env != 0 && m.kind == SF_MAF && m.m16_ok && !m.hidden_bf16 && m.packed16 != nullptr &&
+         a.attempts_per_slot <= 16;
+}
+
+template <int NB>
+static hipError_t sf_launch16(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
+  static bool attr = false;
+  const size_t sh = (size_t)m.t16_stride * sizeof(float);
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_maf_inv16<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  const long per_block = 4L * 16;
+  hipLaunchKernelGGL(k_maf_inv16<NB>, dim3((unsigned)((a.n_items + per_block - 1) / per_block)), dim3(256), sh, st, m, a);
+  return hipGetLastError();
+}
+hipError_t sf_launch_maf_inv16(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
+  return m.NB == 1 ? sf_launch16<1>(m, a, st) : sf_launch16<2>(m, a, st);
+}

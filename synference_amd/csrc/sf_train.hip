@@ -126,6 +126,7 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
     f->act_cap = need;
   }
   SF_TRY(sf_launch_pack(flat, f->d_s1, f->d_s2, f->d_packed, (long)L.n_packed, st));
+  if (f->d_packed16) SF_TRY(sf_launch_pack(flat, f->d_s16a, f->d_s16b, f->d_packed16, (long)L.n_packed16, st));
   if (L.n_packedB > 0) SF_TRY(sf_launch_pack_bf16(flat, f->d_bsrc, f->d_packedB, (long)L.n_packedB, st));
   SF_TRY(sf_launch_pack(flat, f->d_t1, f->d_t2, f->d_packedT, (long)L.n_packedT, st));
   SF_TRY(hipMemsetAsync(f->d_gpacked, 0, (size_t)L.n_packed * sizeof(float), st));
