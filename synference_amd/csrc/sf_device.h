@@ -275,14 +275,20 @@ __device__ __forceinline__ void sf_build_ctx_tile(f32x16 (&ct)[1][NS], const flo
   }
 }
 
-// acc += Wc . e(x) over all context tiles
+// acc += Wc . e(x) over all context tiles.  pre: the first standardised context tile built once by the caller
+// (hoisted out of the transform loop), or nullptr to build it here.
 template <int OT, int NS>
 __device__ __forceinline__ void sf_ctx_mm(f32x16 (&acc)[OT][NS], const float* const (&xr)[NS],
-                                          const SfDev& m, const float* __restrict__ wp, int lane) {
+                                          const SfDev& m, const float* __restrict__ wp, int lane,
+                                          const f32x16 (*pre)[1][NS] = nullptr) {
   for (int kt = 0; kt * 4 < m.nGc; ++kt) {
-    f32x16 ct[1][NS];
-    sf_build_ctx_tile<NS>(ct, xr, m, kt, lane >> 5);
     const int ng = min(4, m.nGc - kt * 4);
-    sf_mm_acc<OT, NS, 1, false>(acc, ct, wp, m.nGc, kt * 4, ng, lane);
+    if (kt == 0 && pre) {
+      sf_mm_acc<OT, NS, 1, false>(acc, *pre, wp, m.nGc, 0, ng, lane);
+    } else {
+      f32x16 ct[1][NS];
+      sf_build_ctx_tile<NS>(ct, xr, m, kt, lane >> 5);
+      sf_mm_acc<OT, NS, 1, false>(acc, ct, wp, m.nGc, kt * 4, ng, lane);
+    }
   }
 }

@@ -17,7 +17,8 @@ struct MafOps {
   static __device__ __forceinline__ void made(const SfDev& m, const float* __restrict__ tp,
                                               const float (&u)[NS][SF_DMAX],
                                               const float* const (&xr)[NS], f32x16 (&fin)[1][NS],
-                                              int lane, const unsigned short* __restrict__ tpB = nullptr) {
+                                              int lane, const unsigned short* __restrict__ tpB = nullptr,
+                                              const f32x16 (*pre)[1][NS] = nullptr) {
     const int h = lane >> 5;
     f32x16 a[HT][NS];
     sf_init_bias<HT, NS>(a, tp + m.o_b0, h);
@@ -26,7 +27,7 @@ struct MafOps {
       sf_build_u_tile<NS>(ut, u, h);
       sf_mm_acc<HT, NS, 1, false>(a, ut, tp + m.o_w0, m.nGu, 0, m.nGu, lane);
     }
-    sf_ctx_mm<HT, NS>(a, xr, m, tp + m.o_wc, lane);
+    sf_ctx_mm<HT, NS>(a, xr, m, tp + m.o_wc, lane, pre);
 #pragma unroll
     for (int k = 0; k < SF_NBMAX; ++k) {
       if (k < m.NB) {
@@ -60,10 +61,14 @@ struct MafOps {
                                                  const float* const (&xr)[NS], float (&logdet)[NS],
                                                  int lane, float* lds = nullptr) {
     const int h = lane >> 5;
+    // first standardised context tile, built once for all transforms (one sample tile per wave only: registers)
+    f32x16 ct0[1][NS];
+    if (NS == 1) sf_build_ctx_tile<NS>(ct0, xr, m, 0, lane >> 5);
+    const f32x16 (*pre)[1][NS] = (NS == 1) ? &ct0 : nullptr;
     for (int t = 0; t < m.T; ++t) {
       const float* tp = sf_stage<LDSW>(m, t, lds);
       f32x16 fin[1][NS];
-      made(m, tp, u, xr, fin, lane, sf_bf16_base<LDSW>(m, t, lds));
+      made(m, tp, u, xr, fin, lane, sf_bf16_base<LDSW>(m, t, lds), pre);
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns) {
         float ld = 0.f;
@@ -88,6 +93,10 @@ struct MafOps {
                                                       const float* const (&xr)[NS], float (&logdet)[NS],
                                                       int lane, float* lds = nullptr) {
     const int h = lane >> 5;
+    // first standardised context tile, built once for all transforms (one sample tile per wave only: registers)
+    f32x16 ct0[1][NS];
+    if (NS == 1) sf_build_ctx_tile<NS>(ct0, xr, m, 0, lane >> 5);
+    const f32x16 (*pre)[1][NS] = (NS == 1) ? &ct0 : nullptr;
     for (int t = m.T - 1; t >= 0; --t) {
       const float* tp = sf_stage<LDSW>(m, t, lds);
       float w[NS][SF_DMAX];
@@ -98,7 +107,7 @@ struct MafOps {
       float ldl[NS];
       for (int pass = 0; pass < m.D; ++pass) {
         f32x16 fin[1][NS];
-        made(m, tp, w, xr, fin, lane, sf_bf16_base<LDSW>(m, t, lds));
+        made(m, tp, w, xr, fin, lane, sf_bf16_base<LDSW>(m, t, lds), pre);
         affine_inverse(m, fin, u, w, ldl, h);
       }
 #pragma unroll
@@ -144,11 +153,15 @@ struct MafOps {
                                                              const float* const (&xr)[NS],
                                                              float (&logdet)[NS], int lane, float* lds = nullptr) {
     const int h = lane >> 5;
+    // first standardised context tile, built once for all transforms (one sample tile per wave only: registers)
+    f32x16 ct0[1][NS];
+    if (NS == 1) sf_build_ctx_tile<NS>(ct0, xr, m, 0, lane >> 5);
+    const f32x16 (*pre)[1][NS] = (NS == 1) ? &ct0 : nullptr;
     for (int t = m.T - 1; t >= 0; --t) {
       const float* tp = sf_stage<LDSW>(m, t, lds);
       f32x16 c0[HT][NS];
       sf_init_bias<HT, NS>(c0, tp + m.o_b0, h);
-      sf_ctx_mm<HT, NS>(c0, xr, m, tp + m.o_wc, lane);
+      sf_ctx_mm<HT, NS>(c0, xr, m, tp + m.o_wc, lane, pre);
       f32x16 act[3][HT][NS];  // act[0] = initial layer, act[k+1] = output of block k (NB <= 2)
 #pragma unroll
       for (int k = 0; k <= 2; ++k)
@@ -512,7 +525,7 @@ struct NsfOps {
   static __device__ __forceinline__ const float* resnet(const SfDev& m, int t, float* lds, const float* tp0,
                                                         const float (&u)[NS][SF_DMAX],
                                                         const float* const (&xr)[NS], f32x16 (&hid)[HT][NS],
-                                                        int lane) {
+                                                        int lane, const f32x16 (*pre)[1][NS] = nullptr) {
     const int h = lane >> 5;
     int part = 0;
     const float* tp = tp0;  // part 0 was staged by the caller
@@ -522,7 +535,7 @@ struct NsfOps {
       sf_build_u_tile<NS>(ut, u, h);
       sf_mm_acc<HT, NS, 1, false>(hid, ut, tp + m.o_winu, m.nGu, 0, m.nGu, lane);
     }
-    sf_ctx_mm<HT, NS>(hid, xr, m, tp + m.o_winc, lane);
+    sf_ctx_mm<HT, NS>(hid, xr, m, tp + m.o_winc, lane, pre);
 #pragma unroll
     for (int k = 0; k < SF_NBMAX; ++k) {
       if (k < m.NB) {
@@ -549,7 +562,7 @@ struct NsfOps {
         for (int mt = 0; mt < HT; ++mt) {
           f32x16 g[1][NS];
           sf_init_bias<1, NS>(g, tp + m.o_bg[k] + mt * 32, h);
-          sf_ctx_mm<1, NS>(g, xr, m, tp + m.o_wg[k] + mt * m.nGc * 256, lane);
+          sf_ctx_mm<1, NS>(g, xr, m, tp + m.o_wg[k] + mt * m.nGc * 256, lane, pre);
 #pragma unroll
           for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
@@ -600,9 +613,10 @@ struct NsfOps {
   // coupling: conditioner on the identity dims, spline on the others
   static __device__ __forceinline__ void coupling(const SfDev& m, int t, float* lds, const float* tp0,
                                                   float (&u)[NS][SF_DMAX], const float* const (&xr)[NS],
-                                                  float (&logdet)[NS], bool inverse, int lane) {
+                                                  float (&logdet)[NS], bool inverse, int lane,
+                                                  const f32x16 (*pre)[1][NS] = nullptr) {
     f32x16 hid[HT][NS];
-    const float* tp = resnet(m, t, lds, tp0, u, xr, hid, lane);
+    const float* tp = resnet(m, t, lds, tp0, u, xr, hid, lane, pre);
     spline_apply(m, tp, t, hid, u, logdet, inverse, lane);
   }
 
@@ -701,9 +715,13 @@ struct NsfOps {
   static __device__ __forceinline__ void forward(const SfDev& m, float (&u)[NS][SF_DMAX],
                                                  const float* const (&xr)[NS], float (&logdet)[NS],
                                                  int lane, float* lds = nullptr) {
+    // first standardised context tile, built once for all transforms (one sample tile per wave only: registers)
+    f32x16 ct0[1][NS];
+    if (NS == 1) sf_build_ctx_tile<NS>(ct0, xr, m, 0, lane >> 5);
+    const f32x16 (*pre)[1][NS] = (NS == 1) ? &ct0 : nullptr;
     for (int t = 0; t < m.T; ++t) {
       const float* tp0 = sf_stage_part<LDSW>(m, t, 0, lds);
-      coupling(m, t, lds, tp0, u, xr, logdet, false, lane);
+      coupling(m, t, lds, tp0, u, xr, logdet, false, lane, pre);
       // LU parameters: from the staged image when the whole transform is one part, else from global
       // (two call sites, not a pointer select, so each keeps its address space)
       if (m.D > 1) {
@@ -715,13 +733,17 @@ struct NsfOps {
   static __device__ __forceinline__ void inverse(const SfDev& m, float (&u)[NS][SF_DMAX],
                                                  const float* const (&xr)[NS], float (&logdet)[NS],
                                                  int lane, float* lds = nullptr) {
+    // first standardised context tile, built once for all transforms (one sample tile per wave only: registers)
+    f32x16 ct0[1][NS];
+    if (NS == 1) sf_build_ctx_tile<NS>(ct0, xr, m, 0, lane >> 5);
+    const f32x16 (*pre)[1][NS] = (NS == 1) ? &ct0 : nullptr;
     for (int t = m.T - 1; t >= 0; --t) {
       const float* tp0 = sf_stage_part<LDSW>(m, t, 0, lds);
       if (m.D > 1) {
         if (LDSW && m.n_parts == 1) lu_inverse(m, tp0 + m.o_lu, u, logdet);
         else lu_inverse(m, m.packed + (size_t)t * m.t_stride + m.o_lu, u, logdet);
       }
-      coupling(m, t, lds, tp0, u, xr, logdet, true, lane);
+      coupling(m, t, lds, tp0, u, xr, logdet, true, lane, pre);
     }
   }
 };
