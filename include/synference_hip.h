@@ -137,6 +137,16 @@ int sf_flow_sample_round(sf_flow* f, const float* x /*[M,C]*/, int64_t S,
                          float* out /*[M*S, D]*/, uint32_t* rejected, uint32_t* n_rejected,
                          int32_t* n_drawn, void* stream);
 
+/* Optional, for callers that drive the rounds themselves: evaluate everything that depends on a context row
+ * alone (the conditioner's context products; in the reference they are recomputed for every one of the S draws
+ * of a galaxy inside DirectPosterior.sample, sbi_runner.py:6442) once per row of x[0..M), into a table owned by
+ * the handle.  Later sf_flow_sample_round calls that pass the SAME x pointer read the table instead; x must not
+ * change until sf_flow_release_context (or the next prepare / set_params / loss_grad, which drop the table).
+ * Purely an optimisation: same noise stream, draws equal up to fp32 summation order.  Tables above SF_CTAB_MAX_MB (default
+ * 4096) are not built.  sf_flow_sample and sf_flow_acceptance do this internally. */
+int sf_flow_prepare_context(sf_flow* f, const float* x /*[M,C]*/, int64_t M, void* stream);
+int sf_flow_release_context(sf_flow* f);
+
 /* Whole sampler: runs rounds until every slot of x[0..M) x S is filled or max_attempts
  * rounds were used; unfilled rows are NaN (sbi_runner.py:6458-6460 convention).
  * Synchronises the stream between rounds (reads one counter).  n_drawn [M] may be NULL.

@@ -55,6 +55,8 @@ PROTOTYPES = {
     "sf_flow_sample_round": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
                                        C.c_uint32, C.c_int32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sf_flow_prepare_context": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "sf_flow_release_context": (C.c_int, [C.c_void_p]),
     "sf_flow_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                  C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64),
                                  C.c_void_p]),

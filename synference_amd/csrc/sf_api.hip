@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -88,7 +89,7 @@ void sf_flow_destroy(sf_flow* f) {
   if (!f) return;
   if (f->dev_ready) {
     (void)hipFree(f->d_packed); (void)hipFree(f->d_packedT); (void)hipFree(f->d_cst); (void)hipFree(f->d_packedB); (void)hipFree(f->d_bsrc);
-    (void)hipFree(f->d_packed16); (void)hipFree(f->d_s16a); (void)hipFree(f->d_s16b);
+    (void)hipFree(f->d_ctab); (void)hipFree(f->d_packed16); (void)hipFree(f->d_s16a); (void)hipFree(f->d_s16b);
     (void)hipFree(f->d_s1); (void)hipFree(f->d_s2); (void)hipFree(f->d_t1); (void)hipFree(f->d_t2);
     (void)hipFree(f->d_flat); (void)hipFree(f->d_gpacked); (void)hipFree(f->d_gdst);
     (void)hipFree(f->d_act); (void)hipFree(f->d_rej[0]); (void)hipFree(f->d_rej[1]); (void)hipFree(f->d_cnt);
@@ -161,6 +162,7 @@ int sf_flow_set_params(sf_flow* f, const float* flat, int64_t n, int is_device, 
   if (f->d_packed16) SF_HIP(sf_launch_pack(src, f->d_s16a, f->d_s16b, f->d_packed16, (long)f->L.n_packed16, st));
   if (f->L.n_packedB > 0) SF_HIP(sf_launch_pack_bf16(src, f->d_bsrc, f->d_packedB, (long)f->L.n_packedB, st));
   f->params_set = true;
+  f->ctab_x = nullptr;  // a context table built from the old parameters is stale
   return SF_OK;
 }
 
@@ -191,6 +193,60 @@ static void seed_keys(uint64_t seed, uint32_t stream_id, uint32_t& k0, uint32_t&
   k1 = (uint32_t)(seed >> 32) ^ stream_id;
 }
 
+// ---- per-galaxy context table ---------------------------------------------------------------
+static size_t ctab_limit_bytes() {
+  static long v = -1;
+  if (v < 0) {
+    const char* e = std::getenv("SF_CTAB_MAX_MB");  // 0 disables the table
+    v = e ? std::atol(e) : 4096;
+  }
+  return (size_t)v << 20;
+}
+
+int sf_flow_prepare_context(sf_flow* f, const float* x, int64_t M, void* stream) {
+  if (!f) return fail(SF_ERR_INVALID, "null handle");
+  f->ctab_x = nullptr;
+  f->ctab_M = 0;
+  if (M == 0) return SF_OK;
+  if (!x) return fail(SF_ERR_INVALID, "null argument");
+  if (M < 0) return fail(SF_ERR_INVALID, "M < 0");
+  if (!f->params_set) return fail(SF_ERR_STATE, "sf_flow_set_params has not been called");
+  SfDev m = f->dev();
+  int R = 0, NV = 0;
+  sf_ctab_shape(m, R, NV);
+  const size_t need = (size_t)M * m.T * NV * R;
+  if (need == 0 || need * sizeof(float) > ctab_limit_bytes()) return SF_OK;  // no table: kernels evaluate the context per draw
+  if (f->ctab_cap < need) {
+    (void)hipFree(f->d_ctab);
+    f->d_ctab = nullptr;
+    f->ctab_cap = 0;
+    SF_HIP(hipMalloc(&f->d_ctab, need * sizeof(float)));
+    f->ctab_cap = need;
+  }
+  m.ctab_R = R; m.ctab_NV = NV;
+  SF_HIP(sf_launch_ctab(m, x, (long)M, f->d_ctab, (hipStream_t)stream));
+  f->ctab_x = x;
+  f->ctab_M = M;
+  return SF_OK;
+}
+
+int sf_flow_release_context(sf_flow* f) {
+  if (!f) return fail(SF_ERR_INVALID, "null handle");
+  f->ctab_x = nullptr;
+  f->ctab_M = 0;
+  return SF_OK;
+}
+
+// device view for a sampling launch over context rows x: attaches the table when it was prepared for x
+static SfDev sampler_dev(const sf_flow* f, const float* x) {
+  SfDev m = f->dev();
+  if (f->ctab_x != nullptr && f->ctab_x == x) {
+    sf_ctab_shape(m, m.ctab_R, m.ctab_NV);
+    m.ctab = f->d_ctab;
+  }
+  return m;
+}
+
 int sf_flow_sample_round(sf_flow* f, const float* x, int64_t S, const uint32_t* slots, int64_t slot_base,
                          int64_t n_slots, uint32_t attempt, int32_t attempts_per_slot, uint64_t seed,
                          uint32_t stream_id,
@@ -208,7 +264,9 @@ int sf_flow_sample_round(sf_flow* f, const float* x, int64_t S, const uint32_t* 
   a.x = x; a.S = (long)S; a.slots = slots; a.slot_base = (long)slot_base; a.n_items = (long)n_slots * A;
   a.attempts_per_slot = A; a.attempt = attempt; seed_keys(seed, stream_id, a.k0, a.k1);
   a.lo = lo; a.hi = hi; a.out = out; a.rejected = rejected; a.n_rejected = n_rejected; a.n_drawn = n_drawn;
-  SF_HIP(sf_launch_inverse(f->dev(), a, (hipStream_t)stream));
+  if (f->ctab_x == x && (uint64_t)(slot_base + n_slots) > (uint64_t)f->ctab_M * (uint64_t)S && slots == nullptr)
+    return fail(SF_ERR_INVALID, "slots reach past the rows given to sf_flow_prepare_context");
+  SF_HIP(sf_launch_inverse(sampler_dev(f, x), a, (hipStream_t)stream));
   return SF_OK;
 }
 
@@ -238,6 +296,10 @@ int sf_flow_sample(sf_flow* f, const float* x, int64_t M, int64_t S, const float
     f->rej_cap = need;
   }
   if (n_drawn) SF_HIP(sf_launch_fill_i32(n_drawn, (long)M, (int32_t)S, st));
+  {
+    int rc = sf_flow_prepare_context(f, x, M, stream);
+    if (rc) return rc;
+  }
   int64_t pending = total;
   const uint32_t* cur = nullptr;
   int buf = 0;
@@ -255,7 +317,7 @@ int sf_flow_sample(sf_flow* f, const float* x, int64_t M, int64_t S, const float
     SF_HIP(hipMemsetAsync(f->d_cnt, 0, sizeof(uint32_t), st));
     int rc = sf_flow_sample_round(f, x, S, cur, 0, pending, (uint32_t)attempt, A, seed, 0, lo, hi, out,
                                   f->d_rej[buf], f->d_cnt, n_drawn, stream);
-    if (rc) return rc;
+    if (rc) { f->ctab_x = nullptr; return rc; }
     uint32_t nrej = 0;
     SF_HIP(hipMemcpyAsync(&nrej, f->d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     SF_HIP(hipStreamSynchronize(st));
@@ -264,6 +326,7 @@ int sf_flow_sample(sf_flow* f, const float* x, int64_t M, int64_t S, const float
     buf ^= 1;
     attempt += A;
   }
+  f->ctab_x = nullptr;
   if (pending > 0) SF_HIP(sf_launch_fill_nan_rows(out, cur, (long)pending, f->L.dev.D, st));
   if (n_unfilled) *n_unfilled = pending;
   return SF_OK;
@@ -280,7 +343,13 @@ int sf_flow_acceptance(sf_flow* f, const float* x, int64_t M, int64_t n, const f
   SfSampleArgsHost a;
   a.x = x; a.S = (long)n; a.n_items = (long)(M * n); seed_keys(seed, 1u, a.k0, a.k1);
   a.lo = lo; a.hi = hi; a.count = count;
-  SF_HIP(sf_launch_inverse(f->dev(), a, st));
+  {
+    int rc = sf_flow_prepare_context(f, x, M, stream);
+    if (rc) return rc;
+  }
+  const SfDev m = sampler_dev(f, x);
+  f->ctab_x = nullptr;
+  SF_HIP(sf_launch_inverse(m, a, st));
   return SF_OK;
 }
 
@@ -297,6 +366,7 @@ int sf_flow_loss_grad_weighted(sf_flow* f, const float* flat, const float* theta
   rc = sf_train_loss_grad(f, flat, theta, x, (long)B, grad_scale, weights, loss, grad, dctx, (hipStream_t)stream, err);
   if (rc) return fail(rc, err);
   f->params_set = true;  // the forward image now holds `flat`
+  f->ctab_x = nullptr;
   return SF_OK;
 }
 

@@ -93,6 +93,29 @@ __device__ __forceinline__ void sf_init_bias(f32x16 (&acc)[OT][NS], const float*
   }
 }
 
+// ---- tiles from the per-galaxy context table (rows in tile order; lane's rows 8j + 4h + 0..3) --------------
+template <int OT, int NS>
+__device__ __forceinline__ void sf_ctab_load(f32x16 (&acc)[OT][NS], const float* const (&cg)[NS], int off, int h) {
+#pragma unroll
+  for (int mt = 0; mt < OT; ++mt)
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(cg[ns] + off + mt * 32 + 8 * j + 4 * h);
+        acc[mt][ns][4 * j] = v.x; acc[mt][ns][4 * j + 1] = v.y; acc[mt][ns][4 * j + 2] = v.z; acc[mt][ns][4 * j + 3] = v.w;
+      }
+}
+template <int OT>
+__device__ __forceinline__ void sf_ctab_store(const f32x16 (&acc)[OT][1], float* dst, int h) {
+#pragma unroll
+  for (int mt = 0; mt < OT; ++mt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<float4*>(dst + mt * 32 + 8 * j + 4 * h) =
+          make_float4(acc[mt][0][4 * j], acc[mt][0][4 * j + 1], acc[mt][0][4 * j + 2], acc[mt][0][4 * j + 3]);
+}
+
 // ---- acc[mt] += W[mt, groups kg0..kg0+ng) . in  -------------------------------------------
 // in[IT][NS]: IT input tiles (static); ng active groups (runtime, wave-uniform, <= 4*IT);
 // nGtot: group stride of the weight block.  One float4 load feeds 4*NS MFMAs.

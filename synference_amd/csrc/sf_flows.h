@@ -259,7 +259,8 @@ struct MafOps {
 
   static __device__ __forceinline__ void inverse(const SfDev& m, float (&u)[NS][SF_DMAX],
                                                  const float* const (&xr)[NS], float (&logdet)[NS],
-                                                 int lane, float* lds = nullptr) {
+                                                 int lane, float* lds = nullptr,
+                                                 const float* const (*cg)[NS] = nullptr) {  // (no table on this path)
     if (m.inc_ok && m.NB <= 2) inverse_incremental(m, u, xr, logdet, lane, lds);
     else inverse_full(m, u, xr, logdet, lane, lds);
   }
@@ -525,17 +526,19 @@ struct NsfOps {
   static __device__ __forceinline__ const float* resnet(const SfDev& m, int t, float* lds, const float* tp0,
                                                         const float (&u)[NS][SF_DMAX],
                                                         const float* const (&xr)[NS], f32x16 (&hid)[HT][NS],
-                                                        int lane, const f32x16 (*pre)[1][NS] = nullptr) {
+                                                        int lane, const f32x16 (*pre)[1][NS] = nullptr,
+                                                        const float* const (*cg)[NS] = nullptr) {
     const int h = lane >> 5;
     int part = 0;
     const float* tp = tp0;  // part 0 was staged by the caller
-    sf_init_bias<HT, NS>(hid, tp + m.o_bin, h);
+    if (cg) sf_ctab_load<HT, NS>(hid, *cg, (t * m.ctab_NV) * m.ctab_R, h);  // bin + Win_c e(x) from the galaxy table
+    else sf_init_bias<HT, NS>(hid, tp + m.o_bin, h);
     {
       f32x16 ut[1][NS];
       sf_build_u_tile<NS>(ut, u, h);
       sf_mm_acc<HT, NS, 1, false>(hid, ut, tp + m.o_winu, m.nGu, 0, m.nGu, lane);
     }
-    sf_ctx_mm<HT, NS>(hid, xr, m, tp + m.o_winc, lane, pre);
+    if (!cg) sf_ctx_mm<HT, NS>(hid, xr, m, tp + m.o_winc, lane, pre);
 #pragma unroll
     for (int k = 0; k < SF_NBMAX; ++k) {
       if (k < m.NB) {
@@ -561,8 +564,12 @@ struct NsfOps {
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) {
           f32x16 g[1][NS];
-          sf_init_bias<1, NS>(g, tp + m.o_bg[k] + mt * 32, h);
-          sf_ctx_mm<1, NS>(g, xr, m, tp + m.o_wg[k] + mt * m.nGc * 256, lane, pre);
+          if (cg) {
+            sf_ctab_load<1, NS>(g, *cg, (t * m.ctab_NV + 1 + k) * m.ctab_R + mt * 32, h);
+          } else {
+            sf_init_bias<1, NS>(g, tp + m.o_bg[k] + mt * 32, h);
+            sf_ctx_mm<1, NS>(g, xr, m, tp + m.o_wg[k] + mt * m.nGc * 256, lane, pre);
+          }
 #pragma unroll
           for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
@@ -614,9 +621,10 @@ struct NsfOps {
   static __device__ __forceinline__ void coupling(const SfDev& m, int t, float* lds, const float* tp0,
                                                   float (&u)[NS][SF_DMAX], const float* const (&xr)[NS],
                                                   float (&logdet)[NS], bool inverse, int lane,
-                                                  const f32x16 (*pre)[1][NS] = nullptr) {
+                                                  const f32x16 (*pre)[1][NS] = nullptr,
+                                                  const float* const (*cg)[NS] = nullptr) {
     f32x16 hid[HT][NS];
-    const float* tp = resnet(m, t, lds, tp0, u, xr, hid, lane, pre);
+    const float* tp = resnet(m, t, lds, tp0, u, xr, hid, lane, pre, cg);
     spline_apply(m, tp, t, hid, u, logdet, inverse, lane);
   }
 
@@ -732,7 +740,8 @@ struct NsfOps {
   }
   static __device__ __forceinline__ void inverse(const SfDev& m, float (&u)[NS][SF_DMAX],
                                                  const float* const (&xr)[NS], float (&logdet)[NS],
-                                                 int lane, float* lds = nullptr) {
+                                                 int lane, float* lds = nullptr,
+                                                 const float* const (*cg)[NS] = nullptr) {
     // first standardised context tile, built once for all transforms (one sample tile per wave only: registers)
     f32x16 ct0[1][NS];
     if (NS == 1) sf_build_ctx_tile<NS>(ct0, xr, m, 0, lane >> 5);
@@ -743,7 +752,7 @@ struct NsfOps {
         if (LDSW && m.n_parts == 1) lu_inverse(m, tp0 + m.o_lu, u, logdet);
         else lu_inverse(m, m.packed + (size_t)t * m.t_stride + m.o_lu, u, logdet);
       }
-      coupling(m, t, lds, tp0, u, xr, logdet, true, lane, pre);
+      coupling(m, t, lds, tp0, u, xr, logdet, true, lane, pre, cg);
     }
   }
 };

@@ -138,3 +138,10 @@ hipError_t SF_CAT(sf_launch_inverse_k, SF_KIND, _h, SF_HT)(const SfDev& m, int n
 #endif
   SF_PT_SWITCH(1, launch_inverse, m, a, st)
 }
+
+#if SF_KIND == 1
+hipError_t SF_CAT(sf_launch_ctab_k, SF_KIND, _h, SF_HT)(const SfDev& m, const float* x, long M, float* tab, hipStream_t st) {
+  hipLaunchKernelGGL((k_nsf_ctab<SF_HT>), dim3((unsigned)((M + 127) / 128)), dim3(256), 0, st, m, x, M, tab);
+  return hipGetLastError();
+}
+#endif

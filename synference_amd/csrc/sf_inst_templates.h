@@ -105,7 +105,13 @@ __global__ __launch_bounds__(LDSW ? 512 : 256) void k_inverse(SfDev m, SfSampleA
     }
     xr[ns] = a.x + gal[ns] * m.C;
   }
-  Ops::inverse(m, u, xr, logdet, lane, sf_lds_image);
+  // per-galaxy context table (sampling rounds only; wave-uniform choice)
+  const bool use_tab = m.ctab != nullptr && a.z_in == nullptr;
+  const float* cg[NS];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) cg[ns] = use_tab ? m.ctab + (size_t)gal[ns] * m.T * m.ctab_NV * m.ctab_R : nullptr;
+  if (use_tab) Ops::inverse(m, u, xr, logdet, lane, sf_lds_image, &cg);
+  else Ops::inverse(m, u, xr, logdet, lane, sf_lds_image);
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) {
     const bool valid = item[ns] < a.n_items;
@@ -159,3 +165,42 @@ __global__ __launch_bounds__(LDSW ? 512 : 256) void k_inverse(SfDev m, SfSampleA
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// NSF per-galaxy context table (sf_flow_prepare_context): tab[gal][t][v][row], rows in tile order
+//   v = 0: bin + Win_c e(x);  v = 1+k: bg_k + Wg_k e(x)     (SfDev::ctab)
+// One wave = 32 galaxies; weights stream from the global operand image (tiny kernel).
+// ---------------------------------------------------------------------------------------------
+template <int HT>
+__global__ __launch_bounds__(256) void k_nsf_ctab(SfDev m, const float* __restrict__ x, long M, float* __restrict__ tab) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 31, h = lane >> 5;
+  const long base = ((long)blockIdx.x * 4 + wave) * 32;
+  if (base >= M) return;
+  const long gal = base + c;
+  const bool valid = gal < M;
+  const float* xr[1] = {x + (valid ? gal : M - 1) * m.C};
+  f32x16 ct0[1][1];
+  sf_build_ctx_tile<1>(ct0, xr, m, 0, h);
+  for (int t = 0; t < m.T; ++t) {
+    const float* tp = m.packed + (size_t)t * m.t_stride;
+    float* dst = tab + ((size_t)gal * m.T + t) * m.ctab_NV * m.ctab_R;
+    {
+      f32x16 hid[HT][1];
+      sf_init_bias<HT, 1>(hid, tp + m.o_bin, h);
+      sf_ctx_mm<HT, 1>(hid, xr, m, tp + m.o_winc, lane, &ct0);
+      if (valid) sf_ctab_store<HT>(hid, dst, h);
+    }
+#pragma unroll
+    for (int k = 0; k < SF_NBMAX; ++k)
+      if (k < m.NB) {
+#pragma unroll
+        for (int mt = 0; mt < HT; ++mt) {
+          f32x16 g[1][1];
+          sf_init_bias<1, 1>(g, tp + m.o_bg[k] + mt * 32, h);
+          sf_ctx_mm<1, 1>(g, xr, m, tp + m.o_wg[k] + mt * m.nGc * 256, lane, &ct0);
+          if (valid) sf_ctab_store<1>(g, dst + (1 + k) * m.ctab_R + mt * 32, h);
+        }
+      }
+  }
+}

@@ -29,6 +29,10 @@ hipError_t sf_launch_logprob(const SfDev& m, const float* theta, const float* x,
 hipError_t sf_launch_inverse(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st);
 bool sf_maf16_enabled(const SfDev& m, const SfSampleArgsHost& a);
 hipError_t sf_launch_maf_inv16(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st);
+// per-galaxy context table: rows/variants for this flow (0 = the flow has no table path), builder
+void sf_ctab_shape(const SfDev& m, int& R, int& NV);
+hipError_t sf_launch_ctab(const SfDev& m, const float* x, long M, float* tab, hipStream_t st);
+hipError_t sf_launch_maf_ctab16(const SfDev& m, const float* x, long M, float* tab, hipStream_t st);
 hipError_t sf_launch_pack(const float* flat, const int32_t* s1, const int32_t* s2, float* packed, long n,
                           hipStream_t st);
 hipError_t sf_launch_pack_bf16(const float* flat, const int32_t* src, unsigned short* out, long n, hipStream_t st);
@@ -59,6 +63,10 @@ struct sf_flow {
   uint32_t* d_rej[2] = {nullptr, nullptr};
   size_t rej_cap = 0;
   uint32_t* d_cnt = nullptr;
+  float* d_ctab = nullptr;       // per-galaxy context table (sf_flow_prepare_context)
+  size_t ctab_cap = 0;           // floats
+  const float* ctab_x = nullptr; // context rows the table was built from (NULL = no valid table)
+  int64_t ctab_M = 0;
   SfDev dev() const {
     SfDev v = L.dev;
     v.packed = d_packed;
@@ -66,6 +74,7 @@ struct sf_flow {
     v.cst = d_cst;
     v.packedB = d_packedB;
     v.packed16 = d_packed16;
+    v.ctab = nullptr;  // set per launch by the sampler entry points
     return v;
   }
 };

@@ -49,6 +49,10 @@ __global__ void k_fill_i32(int32_t* p, long n, int32_t v) {
   hipError_t sf_launch_inverse_k##K##_h##H(const SfDev&, int, const SfSampleArgsHost&, hipStream_t);
 SF_DECL(0, 1) SF_DECL(0, 2) SF_DECL(0, 3) SF_DECL(0, 4)
 SF_DECL(1, 1) SF_DECL(1, 2) SF_DECL(1, 3) SF_DECL(1, 4)
+hipError_t sf_launch_ctab_k1_h1(const SfDev&, const float*, long, float*, hipStream_t);
+hipError_t sf_launch_ctab_k1_h2(const SfDev&, const float*, long, float*, hipStream_t);
+hipError_t sf_launch_ctab_k1_h3(const SfDev&, const float*, long, float*, hipStream_t);
+hipError_t sf_launch_ctab_k1_h4(const SfDev&, const float*, long, float*, hipStream_t);
 
 // sample tiles per wave: SF_NS=1|2 overrides (diagnostics); default 2 while HT <= 2
 int sf_pick_ns(const SfDev& m, bool inverse) {
@@ -103,6 +107,24 @@ hipError_t sf_launch_inverse(const SfDev& m, const SfSampleArgsHost& a, hipStrea
   return hipErrorInvalidValue;
 }
 
+// per-galaxy context table (sampling): which flows have one, and its builder
+void sf_ctab_shape(const SfDev& m, int& R, int& NV) {
+  R = 0; NV = 0;
+  if (m.hidden_bf16) return;
+  if (m.kind == SF_NSF) { R = m.HT * 32; NV = 1 + m.NB; }
+  else if (m.kind == SF_MAF && m.m16_ok) { R = m.nT16 * 16; NV = 1; }
+}
+hipError_t sf_launch_ctab(const SfDev& m, const float* x, long M, float* tab, hipStream_t st) {
+  if (M <= 0) return hipSuccess;
+  if (m.kind == SF_MAF) return sf_launch_maf_ctab16(m, x, M, tab, st);
+  switch (m.HT) {
+    case 1: return sf_launch_ctab_k1_h1(m, x, M, tab, st);
+    case 2: return sf_launch_ctab_k1_h2(m, x, M, tab, st);
+    case 3: return sf_launch_ctab_k1_h3(m, x, M, tab, st);
+    case 4: return sf_launch_ctab_k1_h4(m, x, M, tab, st);
+  }
+  return hipErrorInvalidValue;
+}
 hipError_t sf_launch_pack(const float* flat, const int32_t* s1, const int32_t* s2, float* packed, long n,
                           hipStream_t st) {
   hipLaunchKernelGGL(k_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, flat, s1, s2, packed, n);

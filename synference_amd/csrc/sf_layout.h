@@ -72,6 +72,12 @@ struct SfDev {
   int m16_ok, nT16, nC16, t16_stride;
   int o16_w0, o16_wc, o16_b0, o16_wk[2], o16_bk[2], o16_hv, o16_hvb;
   int g16_tile[SF_DMAX];  // tile that holds the hidden units of MADE degree g
+  // per-galaxy context table (sampling only; sf_flow_prepare_context): everything that depends on the context
+  // row alone, evaluated once per galaxy instead of once per draw.  [gal][t][v][row], row in tile order:
+  //   MAF (16-row path): v = 0: b0 + bc + Wc e(x)                                   R = nT16*16
+  //   NSF              : v = 0: bin + Win_c e(x);  v = 1+k: bg_k + Wg_k e(x)         R = HT*32
+  const float* ctab;
+  int ctab_R, ctab_NV;
   // constants image ------------------------------------------------------------------------
   int c_pscale, c_pshift, c_tdim, c_xmean, c_xstd;  // tdim stored as float-encoded ints
   int c_dslot;  // MAF: [t][p-1] = physical slot of the dimension with MADE degree p (float-encoded)

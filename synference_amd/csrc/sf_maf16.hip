@@ -158,7 +158,9 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16(SfDev m, SfSampleArgsHost 
     }
     return ct;
   };
-  const f32x4 ct0 = ctx_tile(0);
+  const float* ctg = (m.ctab && !a.z_in) ? m.ctab + (size_t)gal * m.T * m.ctab_R : nullptr;  // wave-uniform choice
+  f32x4 ct0;
+  if (!ctg) ct0 = ctx_tile(0);
 
   const int NT = m.nT16;
   uint32_t tile_bits = 0;  // g16_tile packed 2 bits per degree (static indexing keeps the argument in SGPRs)
@@ -184,17 +186,23 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16(SfDev m, SfSampleArgsHost 
     const float* tp = sf_lds16;
     SfPass16 S;
     // context product hoisted out of the passes: c0 = b0 + bc + Wc e
-#pragma unroll
-    for (int ot = 0; ot < 4; ++ot)
-      if (ot < NT) {
-        S.c0[ot] = sf_ld4(tp + m.o16_b0 + (ot * 4 + g4) * 4);
-        S.c0[ot] = sf_mma16(sf_w16(tp + m.o16_wc, m.nC16, ot, 0, lane), ct0, S.c0[ot]);
-      }
-    for (int ic = 1; ic < m.nC16; ++ic) {
-      const f32x4 ct = ctx_tile(ic);
+    if (ctg) {  // per-galaxy table (sf_flow_prepare_context): same values, computed once per galaxy
 #pragma unroll
       for (int ot = 0; ot < 4; ++ot)
-        if (ot < NT) S.c0[ot] = sf_mma16(sf_w16(tp + m.o16_wc, m.nC16, ot, ic, lane), ct, S.c0[ot]);
+        if (ot < NT) S.c0[ot] = *reinterpret_cast<const f32x4*>(ctg + (size_t)t * m.ctab_R + ot * 16 + 4 * g4);
+    } else {
+#pragma unroll
+      for (int ot = 0; ot < 4; ++ot)
+        if (ot < NT) {
+          S.c0[ot] = sf_ld4(tp + m.o16_b0 + (ot * 4 + g4) * 4);
+          S.c0[ot] = sf_mma16(sf_w16(tp + m.o16_wc, m.nC16, ot, 0, lane), ct0, S.c0[ot]);
+        }
+      for (int ic = 1; ic < m.nC16; ++ic) {
+        const f32x4 ct = ctx_tile(ic);
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot)
+          if (ot < NT) S.c0[ot] = sf_mma16(sf_w16(tp + m.o16_wc, m.nC16, ot, ic, lane), ct, S.c0[ot]);
+      }
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k)
@@ -284,6 +292,49 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16(SfDev m, SfSampleArgsHost 
       }
     }
   }
+}
+
+// Per-galaxy context table of the 16-row path: tab[gal][t][row] = b0 + bc + Wc e(x_gal), rows in tile order.
+// One wave = 16 galaxies; same MFMA sequence as the in-kernel evaluation, so the sampler's draws do not change.
+__global__ __launch_bounds__(256) void k_maf_ctab16(SfDev m, const float* __restrict__ x, long M, float* __restrict__ tab) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = lane & 15, g4 = lane >> 4;
+  const long gal = ((long)blockIdx.x * 4 + wave) * 16 + s;
+  if (((long)blockIdx.x * 4 + wave) * 16 >= M) return;
+  const bool valid = gal < M;
+  const float* xr = x + (valid ? gal : M - 1) * m.C;
+  const int NT = m.nT16;
+  for (int t = 0; t < m.T; ++t) {
+    const float* tp = m.packed16 + (size_t)t * m.t16_stride;
+    f32x4 c0[4];
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot)
+      if (ot < NT) c0[ot] = sf_ld4(tp + m.o16_b0 + (ot * 4 + g4) * 4);
+    for (int ic = 0; ic < m.nC16; ++ic) {
+      f32x4 ct;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rho = ic * 16 + 4 * g4 + r;
+        const bool ok = rho < m.C;
+        const int rr = ok ? rho : 0;
+        const float v = (xr[rr] - m.cst[m.c_xmean + rr]) / m.cst[m.c_xstd + rr];
+        ct[r] = ok ? v : 0.f;
+      }
+#pragma unroll
+      for (int ot = 0; ot < 4; ++ot)
+        if (ot < NT) c0[ot] = sf_mma16(sf_w16(tp + m.o16_wc, m.nC16, ot, ic, lane), ct, c0[ot]);
+    }
+    if (valid) {
+#pragma unroll
+      for (int ot = 0; ot < 4; ++ot)
+        if (ot < NT)
+          *reinterpret_cast<f32x4*>(tab + ((size_t)gal * m.T + t) * m.ctab_R + ot * 16 + 4 * g4) = c0[ot];
+    }
+  }
+}
+hipError_t sf_launch_maf_ctab16(const SfDev& m, const float* x, long M, float* tab, hipStream_t st) {
+  hipLaunchKernelGGL(k_maf_ctab16, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, st, m, x, M, tab);
+  return hipGetLastError();
 }
 
 // SF_MAF16=0 disables the path (diagnostics / A-B runs).  A = 32 retry rounds stay on the 32-row kernel.

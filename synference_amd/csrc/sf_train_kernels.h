@@ -113,6 +113,8 @@ __global__ __launch_bounds__(256) void k_maf_train(SfDev m, SfTrainArgs a) {
   const bool valid = row < a.B;
   const long ii = valid ? row : a.B - 1;
   const float* xr[1] = {a.x + ii * m.C};
+  f32x16 ct0[1][1];  // first standardised context tile, reused by every context product and weight gradient
+  sf_build_ctx_tile<1>(ct0, xr, m, 0, lane >> 5);
   float u[1][SF_DMAX];
   float logdet[1] = {m.logdet0};
 #pragma unroll
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void k_maf_train(SfDev m, SfTrainArgs a) {
       sf_build_u_tile<1>(ut, u, h);
       sf_mm_acc<HT, 1, 1, false, false, true>(act, ut, tp + m.o_w0, m.nGu, 0, m.nGu, lane);
     }
-    sf_ctx_mm<HT, 1>(act, xr, m, tp + m.o_wc, lane);
+    sf_ctx_mm<HT, 1>(act, xr, m, tp + m.o_wc, lane, &ct0);
 #pragma unroll
     for (int mt = 0; mt < HT; ++mt) sf_stash_store(stash, t * TPT + 1 + mt, act[mt][0], lane);
 #pragma unroll
@@ -266,7 +268,8 @@ __global__ __launch_bounds__(256) void k_maf_train(SfDev m, SfTrainArgs a) {
     }
     for (int kt = 0; kt * 4 < m.nGc; ++kt) {
       f32x16 ct[1][1];
-      sf_build_ctx_tile<1>(ct, xr, m, kt, h);
+      if (kt == 0) ct[0][0] = ct0[0][0];
+      else sf_build_ctx_tile<1>(ct, xr, m, kt, h);
       sf_grad_w<HT, 1>(lds, dh, ct, gp + m.o_wc, nullptr, m.nGc, kt * 4, min(4, m.nGc - kt * 4), lane);
     }
     if (a.dctx) sf_ctx_grad<HT>(m, dh, tpT + m.oT_wc, a.dctx + ii * m.C, valid, lane);
@@ -320,6 +323,8 @@ __global__ __launch_bounds__(256) void k_nsf_train(SfDev m, SfTrainArgs a) {
   const bool valid = row < a.B;
   const long ii = valid ? row : a.B - 1;
   const float* xr[1] = {a.x + ii * m.C};
+  f32x16 ct0[1][1];  // first standardised context tile, reused by every context product and weight gradient
+  sf_build_ctx_tile<1>(ct0, xr, m, 0, lane >> 5);
   float u[1][SF_DMAX];
   float logdet[1] = {m.logdet0};
 #pragma unroll
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(256) void k_nsf_train(SfDev m, SfTrainArgs a) {
       sf_build_u_tile<1>(ut, u, h);
       sf_mm_acc<HT, 1, 1, false, false, true>(hid, ut, tp + m.o_winu, m.nGu, 0, m.nGu, lane);
     }
-    sf_ctx_mm<HT, 1>(hid, xr, m, tp + m.o_winc, lane);
+    sf_ctx_mm<HT, 1>(hid, xr, m, tp + m.o_winc, lane, &ct0);
 #pragma unroll
     for (int mt = 0; mt < HT; ++mt) sf_stash_store(stash, sb + 1 + mt, hid[mt][0], lane);
 #pragma unroll
@@ -368,7 +373,7 @@ __global__ __launch_bounds__(256) void k_nsf_train(SfDev m, SfTrainArgs a) {
           sf_stash_store(stash, bb + HT + mt, t2[mt][0], lane);
           f32x16 g[1][1];
           sf_init_bias<1, 1>(g, tp + m.o_bg[k] + mt * 32, h);
-          sf_ctx_mm<1, 1>(g, xr, m, tp + m.o_wg[k] + mt * m.nGc * 256, lane);
+          sf_ctx_mm<1, 1>(g, xr, m, tp + m.o_wg[k] + mt * m.nGc * 256, lane, &ct0);
 #pragma unroll
           for (int r = 0; r < 16; ++r) hid[mt][0][r] += t2[mt][0][r] * sf_sigmoid(g[0][0][r]);
           sf_stash_store(stash, bb + 2 * HT + mt, hid[mt][0], lane);
@@ -537,7 +542,7 @@ __global__ __launch_bounds__(256) void k_nsf_train(SfDev m, SfTrainArgs a) {
             sf_stash_load(stash, bb + HT + mt, t2, lane);
             f32x16 g[1][1];
             sf_init_bias<1, 1>(g, tp + m.o_bg[k] + mt * 32, h);
-            sf_ctx_mm<1, 1>(g, xr, m, tp + m.o_wg[k] + mt * m.nGc * 256, lane);
+            sf_ctx_mm<1, 1>(g, xr, m, tp + m.o_wg[k] + mt * m.nGc * 256, lane, &ct0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const float sg = sf_sigmoid(g[0][0][r]);
@@ -547,7 +552,8 @@ __global__ __launch_bounds__(256) void k_nsf_train(SfDev m, SfTrainArgs a) {
           }
           for (int kt = 0; kt * 4 < m.nGc; ++kt) {
             f32x16 ct[1][1];
-            sf_build_ctx_tile<1>(ct, xr, m, kt, h);
+            if (kt == 0) ct[0][0] = ct0[0][0];
+            else sf_build_ctx_tile<1>(ct, xr, m, kt, h);
             sf_grad_w<HT, 1>(lds, dgate, ct, gp + m.o_wg[k], kt == 0 ? gp + m.o_bg[k] : nullptr, m.nGc, kt * 4,
                              min(4, m.nGc - kt * 4), lane);
           }
@@ -593,7 +599,8 @@ __global__ __launch_bounds__(256) void k_nsf_train(SfDev m, SfTrainArgs a) {
     }
     for (int kt = 0; kt * 4 < m.nGc; ++kt) {
       f32x16 ct[1][1];
-      sf_build_ctx_tile<1>(ct, xr, m, kt, h);
+      if (kt == 0) ct[0][0] = ct0[0][0];
+      else sf_build_ctx_tile<1>(ct, xr, m, kt, h);
       sf_grad_w<HT, 1>(lds, dh, ct, gp + m.o_winc, nullptr, m.nGc, kt * 4, min(4, m.nGc - kt * 4), lane);
     }
     if (a.dctx) sf_ctx_grad<HT>(m, dh, tpT + m.oT_wc, a.dctx + ii * m.C, valid, lane);

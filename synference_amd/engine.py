@@ -141,6 +141,14 @@ class HipFlow:
         self.last_unfilled = int(unfilled.value)
         return (out, nd) if return_counts else out
 
+    def prepare_context(self, x) -> None:
+        """Per-galaxy context table for the sample_round calls that follow with this same tensor ``x``."""
+        self._dev()
+        _lib.check(self.lib.sf_flow_prepare_context(self.handle, _ptr(x), x.shape[0], _stream(self.device)))
+
+    def release_context(self) -> None:
+        _lib.check(self.lib.sf_flow_release_context(self.handle))
+
     def sample_round(self, x, S, slots, slot_base, n_slots, attempt, seed, lo, hi, out, rejected, n_rejected,
                      n_drawn=None, stream_id: int = 0, attempts_per_slot: int = 1):
         self._dev()

@@ -294,17 +294,21 @@ def _sample_slot_list(post: FlowPosterior, X, S: int, slots: torch.Tensor, seed:
     cnt = torch.zeros(1, dtype=torch.int32, device=dev)
     cur, pending, attempt, k = slots.contiguous(), n, 0, 0
     from .engine import retry_width
-    while attempt < post.max_sampling_attempts:
-        A = retry_width(pending, attempt, post.max_sampling_attempts, n)
-        cnt.zero_()
-        est.flow.sample_round(X, S, cur, 0, pending, attempt, seed, lo, hi, out, rej[k & 1], cnt,
-                              attempts_per_slot=A)
-        pending = int(cnt.item())
-        cur = rej[k & 1]
-        attempt += A
-        k += 1
-        if pending == 0:
-            return
+    est.flow.prepare_context(X)
+    try:
+        while attempt < post.max_sampling_attempts:
+            A = retry_width(pending, attempt, post.max_sampling_attempts, n)
+            cnt.zero_()
+            est.flow.sample_round(X, S, cur, 0, pending, attempt, seed, lo, hi, out, rej[k & 1], cnt,
+                                  attempts_per_slot=A)
+            pending = int(cnt.item())
+            cur = rej[k & 1]
+            attempt += A
+            k += 1
+            if pending == 0:
+                return
+    finally:
+        est.flow.release_context()
     bad = cur[:pending].long()
     out.reshape(-1, out.shape[-1])[bad] = float("nan")
     logger.error(f"{pending} posterior draws could not be placed inside the prior support.")
