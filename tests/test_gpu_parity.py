@@ -100,6 +100,46 @@ def test_sampler_unbounded_and_acceptance():
     assert np.abs(acc - racc).max() < 2e-3, (acc, racc)
 
 
+@pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "nsf_odd", "maf_wide", "nsf_nb1"])
+def test_context_table_round_equals_per_draw_round(name):
+    """sf_flow_prepare_context only moves the context products out of the per-draw work: a dense round and a
+    retry round over a slot list give the same draws and the same rejected set with and without the table.
+    S = 7 puts several galaxies (and a ragged tail) inside every wave."""
+    ospec, spec, flat, theta, x = make_case(name, B=37, spread=0.2)
+    f = _flow(spec, flat)
+    S, seed = 7, 31
+    X = torch.as_tensor(x, dtype=torch.float32, device="cuda:0").contiguous()
+    n = X.shape[0] * S
+    free = f.sample(X, 300, seed=5).reshape(-1, spec.D).cpu().numpy()
+    free = free[np.isfinite(free).all(-1)]
+    lo = torch.as_tensor(np.quantile(free, 0.05, axis=0), dtype=torch.float32, device="cuda:0")
+    hi = torch.as_tensor(np.quantile(free, 0.95, axis=0), dtype=torch.float32, device="cuda:0")
+
+    def rounds(use_table):
+        out = torch.full((X.shape[0], S, spec.D), float("nan"), dtype=torch.float32, device="cuda:0")
+        rej = [torch.zeros(n, dtype=torch.int32, device="cuda:0") for _ in range(2)]
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+        if use_table:
+            f.prepare_context(X)
+        f.sample_round(X, S, None, 0, n, 0, seed, lo, hi, out, rej[0], cnt)
+        n0 = int(cnt.item())
+        cnt.zero_()
+        f.sample_round(X, S, rej[0], 0, n0, 1, seed, lo, hi, out, rej[1], cnt, attempts_per_slot=4)
+        n1 = int(cnt.item())
+        if use_table:
+            f.release_context()
+        return out.cpu().numpy(), set(rej[0][:n0].cpu().tolist()), set(rej[1][:n1].cpu().tolist())
+
+    a, ra0, ra1 = rounds(False)
+    b, rb0, rb1 = rounds(True)
+    assert 0 < len(ra0) < n
+    assert len(ra0 ^ rb0) <= 1 and len(ra1 ^ rb1) <= 1          # at most a boundary flip
+    both = np.isfinite(a).all(-1) & np.isfinite(b).all(-1)
+    assert both.sum() >= n - len(ra1) - 2
+    scale = np.asarray(ospec.theta_std)
+    assert np.abs((a[both] - b[both]) / scale).max() < 1e-4
+
+
 def test_sampler_exhausted_attempts_give_nan_rows():
     ospec, spec, flat, theta, x = make_case("maf_small", B=2)
     f = _flow(spec, flat)
