@@ -257,7 +257,7 @@ int sf_flow_sample_round(sf_flow* f, const float* x, int64_t S, const uint32_t* 
                          uint32_t* n_rejected, int32_t* n_drawn, void* stream) {
   if (!f || !x || !out || !rejected || !n_rejected) return fail(SF_ERR_INVALID, "null argument");
   if (!f->params_set) return fail(SF_ERR_STATE, "sf_flow_set_params has not been called");
-  if (S < 1) return fail(SF_ERR_INVALID, "S < 1");
+  if (S < 1 || S > 0x7fffffffll) return fail(SF_ERR_INVALID, "S must be in 1 .. 2^31-1");
   if ((lo == nullptr) != (hi == nullptr)) return fail(SF_ERR_INVALID, "lo and hi must be given together");
   if ((uint64_t)(slot_base + n_slots) > 0xffffffffull)
     return fail(SF_ERR_INVALID, "slot ids must fit 32 bits: split the catalogue");
@@ -339,7 +339,7 @@ int sf_flow_acceptance(sf_flow* f, const float* x, int64_t M, int64_t n, const f
                        uint64_t seed, int32_t* count, void* stream) {
   if (!f || !x || !count || !lo || !hi) return fail(SF_ERR_INVALID, "null argument");
   if (!f->params_set) return fail(SF_ERR_STATE, "sf_flow_set_params has not been called");
-  if (M < 0 || n < 1) return fail(SF_ERR_INVALID, "bad M or n");
+  if (M < 0 || n < 1 || n > 0x7fffffffll) return fail(SF_ERR_INVALID, "bad M or n");
   if ((uint64_t)(M * n) > 0xffffffffull) return fail(SF_ERR_INVALID, "M*n must fit 32 bits");
   hipStream_t st = (hipStream_t)stream;
   SF_HIP(sf_launch_fill_i32(count, (long)M, 0, st));

@@ -39,11 +39,33 @@ __device__ __forceinline__ float sf_xhalf(float v) {  // value held by the other
 // LDSW: the whole operand image of transform t is copied into the workgroup's LDS once and every
 // wave of the (512-thread) workgroup reads its MFMA A operands from there with ds_read_b128;
 // otherwise weights stream from L2.  Must be called by every thread of the workgroup.
+// A zero the optimiser cannot see through.  Added to the per-transform operand base so that the hundreds of
+// weight-fragment addresses derived from it are recomputed (cheap SALU adds) inside the transform loop instead of
+// being hoisted out of it as loop invariants and spilled (v_writelane / v_readlane) for lack of SGPRs.
+__device__ __forceinline__ int sf_opaque_zero() {
+  int z;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+  return z;
+}
+// Per-iteration view of the model descriptor: the loop bounds carry an opaque zero, so the many predicates
+// derived from them (k < K, kg < nGh, p < D ...) are evaluated where they are used (one s_cmp each) instead of
+// being hoisted out of the transform loop as 64-bit masks that then live in spilled SGPRs.
+__device__ __forceinline__ SfDev sf_iter_view(const SfDev& m) {
+  SfDev v = m;
+  const int z = sf_opaque_zero();
+  v.K += z; v.D += z; v.C += z; v.NB += z; v.nGu += z; v.nGc += z; v.nGh += z;
+  return v;
+}
 template <bool LDSW>
 __device__ __forceinline__ const float* sf_stage_part(const SfDev& m, int t, int part, float* lds) {
-  const float* src = m.packed + (size_t)t * m.t_stride;
+  const float* src = m.packed + (size_t)t * m.t_stride + sf_opaque_zero();
   if (!LDSW) return src;
-  const int lo = m.part_off[part], hi = m.part_off[part + 1];
+  int lo = 0, hi = 0;  // part_off[part], part_off[part + 1] without a runtime-indexed load (keeps the descriptor in SGPRs)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    lo = (q == part) ? m.part_off[q] : lo;
+    hi = (q == part) ? m.part_off[q + 1] : hi;
+  }
   __syncthreads();  // previous image no longer in use
   const float4* __restrict__ s4 = reinterpret_cast<const float4*>(src + lo);
   float4* __restrict__ d4 = reinterpret_cast<float4*>(lds);
@@ -69,7 +91,7 @@ __device__ __forceinline__ const float* sf_stage_part(const SfDev& m, int t, int
     for (int i = threadIdx.x; i < nb; i += blockDim.x) db[i] = sb[i];
   }
   __syncthreads();
-  return lds - lo;  // so that (returned + block offset) lands inside the staged part
+  return lds - lo + sf_opaque_zero();  // so that (returned + block offset) lands inside the staged part
 }
 template <bool LDSW>
 __device__ __forceinline__ const float* sf_stage(const SfDev& m, int t, float* lds) {
@@ -292,7 +314,7 @@ __device__ __forceinline__ void sf_build_ctx_tile(f32x16 (&ct)[1][NS], const flo
     const float mu = m.cst[m.c_xmean + rr], sd = m.cst[m.c_xstd + rr];
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
-      const float v = (xr[ns][rr] - mu) / sd;
+      const float v = sf_div(xr[ns][rr] - mu, sd);
       ct[0][ns][r] = ok ? v : 0.f;
     }
   }

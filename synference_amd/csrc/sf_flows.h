@@ -351,14 +351,14 @@ struct SfSpline {
         d_k = (j == idx) ? dj : d_k;
         d_k1 = (j == idx + 1) ? dj : d_k1;
       }
-    const float s_k = h_k / w_k;
+    const float s_k = sf_div(h_k, w_k);
     float xi;
     if (!inverse) {
-      xi = (vc - x_k) / w_k;
+      xi = sf_div(vc - x_k, w_k);
       const float om = xi * (1.f - xi);
       const float num = h_k * (s_k * xi * xi + d_k * om);
       const float den = s_k + (d_k + d_k1 - 2.f * s_k) * om;
-      out = y_k + num / den;
+      out = y_k + sf_div(num, den);
     } else {
       const float dy = vc - y_k;
       const float tmp = dy * (d_k + d_k1 - 2.f * s_k);
@@ -366,7 +366,7 @@ struct SfSpline {
       const float b = h_k * d_k - tmp;
       const float c = -s_k * dy;
       const float disc = b * b - 4.f * a * c;
-      xi = (2.f * c) / (-b - sqrtf(disc));
+      xi = sf_div(2.f * c, -b - __builtin_amdgcn_sqrtf(disc));
       out = xi * w_k + x_k;
     }
     const float om = xi * (1.f - xi);
@@ -593,24 +593,29 @@ struct NsfOps {
       f32x16 q[PT][NS];
       sf_init_bias<PT, NS>(q, tp + m.o_bout + jp * PT * 32, h);
       sf_mm_acc<PT, NS, HT, false>(q, hid, tp + m.o_wout + jp * PT * m.nGh * 256, m.nGh, 0, m.nGh, lane);
-      const int kdim = 2 * jp + h;          // this half's transform-dim index
-      const bool have = kdim < d_tr;
-      const int tgt = start + 2 * kdim;     // its physical slot
-      const int tgt_o = start + 2 * (2 * jp + (1 - h));
-      const bool have_o = (2 * jp + (1 - h)) < d_tr;
+      // the two row halves evaluate the two transform dims of this pair: half 0 the dim in physical slot
+      // sA, half 1 the one in slot sB (wave-uniform slot numbers -> scalar compares, no per-lane masks)
+      const int sA = start + 4 * jp, sB = sA + 2;
+      const bool haveA = 2 * jp < d_tr, haveB = 2 * jp + 1 < d_tr;
+      const bool have = h == 0 ? haveA : haveB;
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns) {
-        float vin = 0.f;
+        float uA = 0.f, uB = 0.f;
 #pragma unroll
-        for (int p = 0; p < SF_DMAX; ++p) vin = (p == tgt) ? u[ns][p] : vin;
+        for (int p = 0; p < SF_DMAX; ++p) {
+          uA = (p == sA) ? u[ns][p] : uA;
+          uB = (p == sB) ? u[ns][p] : uB;
+        }
+        const float vin = h == 0 ? uA : uB;
         float vout, lad;
         SfSpline<PT>::template eval<NS>(m, q, ns, vin, inverse, vout, lad);
         lad = have ? lad : 0.f;
         const float vo = sf_xhalf(vout);
+        const float nA = h == 0 ? vout : vo, nB = h == 0 ? vo : vout;
 #pragma unroll
         for (int p = 0; p < SF_DMAX; ++p) {
-          u[ns][p] = (have && p == tgt) ? vout : u[ns][p];
-          u[ns][p] = (have_o && p == tgt_o) ? vo : u[ns][p];
+          u[ns][p] = (haveA && p == sA) ? nA : u[ns][p];
+          u[ns][p] = (haveB && p == sB) ? nB : u[ns][p];
         }
         logdet[ns] += lad + sf_xhalf(lad);
       }
@@ -712,22 +717,24 @@ struct NsfOps {
 #pragma unroll
             for (int ns = 0; ns < NS; ++ns) u[ns][i] -= w * u[ns][j];
           }
+        const float rdg = __builtin_amdgcn_rcpf(dg);
 #pragma unroll
-        for (int ns = 0; ns < NS; ++ns) u[ns][i] /= dg;
+        for (int ns = 0; ns < NS; ++ns) u[ns][i] *= rdg;
       }
     }
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) logdet[ns] -= ld;
   }
 
-  static __device__ __forceinline__ void forward(const SfDev& m, float (&u)[NS][SF_DMAX],
+  static __device__ __forceinline__ void forward(const SfDev& m0, float (&u)[NS][SF_DMAX],
                                                  const float* const (&xr)[NS], float (&logdet)[NS],
                                                  int lane, float* lds = nullptr) {
     // first standardised context tile, built once for all transforms (one sample tile per wave only: registers)
     f32x16 ct0[1][NS];
-    if (NS == 1) sf_build_ctx_tile<NS>(ct0, xr, m, 0, lane >> 5);
+    if (NS == 1) sf_build_ctx_tile<NS>(ct0, xr, m0, 0, lane >> 5);
     const f32x16 (*pre)[1][NS] = (NS == 1) ? &ct0 : nullptr;
-    for (int t = 0; t < m.T; ++t) {
+    for (int t = 0; t < m0.T; ++t) {
+      const SfDev m = sf_iter_view(m0);
       const float* tp0 = sf_stage_part<LDSW>(m, t, 0, lds);
       coupling(m, t, lds, tp0, u, xr, logdet, false, lane, pre);
       // LU parameters: from the staged image when the whole transform is one part, else from global
@@ -738,15 +745,16 @@ struct NsfOps {
       }
     }
   }
-  static __device__ __forceinline__ void inverse(const SfDev& m, float (&u)[NS][SF_DMAX],
+  static __device__ __forceinline__ void inverse(const SfDev& m0, float (&u)[NS][SF_DMAX],
                                                  const float* const (&xr)[NS], float (&logdet)[NS],
                                                  int lane, float* lds = nullptr,
                                                  const float* const (*cg)[NS] = nullptr) {
     // first standardised context tile, built once for all transforms (one sample tile per wave only: registers)
     f32x16 ct0[1][NS];
-    if (NS == 1) sf_build_ctx_tile<NS>(ct0, xr, m, 0, lane >> 5);
+    if (NS == 1) sf_build_ctx_tile<NS>(ct0, xr, m0, 0, lane >> 5);
     const f32x16 (*pre)[1][NS] = (NS == 1) ? &ct0 : nullptr;
-    for (int t = m.T - 1; t >= 0; --t) {
+    for (int t = m0.T - 1; t >= 0; --t) {
+      const SfDev m = sf_iter_view(m0);
       const float* tp0 = sf_stage_part<LDSW>(m, t, 0, lds);
       if (m.D > 1) {
         if (LDSW && m.n_parts == 1) lu_inverse(m, tp0 + m.o_lu, u, logdet);

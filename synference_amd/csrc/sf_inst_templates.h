@@ -90,10 +90,10 @@ __global__ __launch_bounds__(LDSW ? 512 : 256) void k_inverse(SfDev m, SfSampleA
       for (int p = 0; p < SF_DMAX; ++p)
         if (p < m.D) u[ns][p] = a.z_in[it * m.D + p];
     } else {
-      const long ps = it / a.attempts_per_slot;  // listed slot; A consecutive items share it
+      const long ps = it >> a.log2_attempts;  // listed slot; A (a power of two) consecutive items share it
       slot[ns] = a.slots ? (uint64_t)a.slots[ps] : (uint64_t)(a.slot_base + ps);
-      gal[ns] = (long)(slot[ns] / (uint64_t)a.S);
-      const uint32_t att = a.attempt + (uint32_t)(it % a.attempts_per_slot);
+      gal[ns] = (long)((uint32_t)slot[ns] / (uint32_t)a.S);  // slot ids fit 32 bits (checked by the API)
+      const uint32_t att = a.attempt + (uint32_t)(it & (long)(a.attempts_per_slot - 1));
 #pragma unroll
       for (int blk = 0; blk < SF_DMAX / 4; ++blk)
         if (blk * 4 < m.D) {
@@ -110,8 +110,7 @@ __global__ __launch_bounds__(LDSW ? 512 : 256) void k_inverse(SfDev m, SfSampleA
   const float* cg[NS];
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) cg[ns] = use_tab ? m.ctab + (size_t)gal[ns] * m.T * m.ctab_NV * m.ctab_R : nullptr;
-  if (use_tab) Ops::inverse(m, u, xr, logdet, lane, sf_lds_image, &cg);
-  else Ops::inverse(m, u, xr, logdet, lane, sf_lds_image);
+  Ops::inverse(m, u, xr, logdet, lane, sf_lds_image, use_tab ? &cg : nullptr);
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) {
     const bool valid = item[ns] < a.n_items;

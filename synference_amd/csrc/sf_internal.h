@@ -14,6 +14,7 @@ struct SfSampleArgsHost {
   long n_items = 0;
   uint32_t attempt = 0, k0 = 0, k1 = 0;
   int attempts_per_slot = 1;  // A: consecutive attempts evaluated per listed slot (power of two <= 32)
+  int log2_attempts = 0;      // log2(A) (set by sf_launch_inverse)
   const float* lo = nullptr;
   const float* hi = nullptr;
   float* out = nullptr;

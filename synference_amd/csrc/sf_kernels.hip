@@ -90,8 +90,11 @@ hipError_t sf_launch_logprob(const SfDev& m, const float* theta, const float* x,
   return hipErrorInvalidValue;
 }
 
-hipError_t sf_launch_inverse(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
-  if (a.n_items <= 0) return hipSuccess;
+hipError_t sf_launch_inverse(const SfDev& m, const SfSampleArgsHost& a_in, hipStream_t st) {
+  if (a_in.n_items <= 0) return hipSuccess;
+  SfSampleArgsHost a = a_in;
+  a.log2_attempts = 0;
+  while ((1 << a.log2_attempts) < a.attempts_per_slot) ++a.log2_attempts;
   if (sf_maf16_enabled(m, a)) return sf_launch_maf_inv16(m, a, st);
   const int ns = sf_pick_ns(m, true);
   switch (m.kind * 10 + m.HT) {

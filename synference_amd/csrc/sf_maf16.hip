@@ -133,10 +133,10 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16(SfDev m, SfSampleArgsHost 
 #pragma unroll
     for (int r = 0; r < 4; ++r) u[r] = (4 * g4 + r < m.D) ? a.z_in[it * m.D + 4 * g4 + r] : 0.f;
   } else {
-    const long ps = it / a.attempts_per_slot;  // listed slot; A consecutive items share it
+    const long ps = it >> a.log2_attempts;  // listed slot; A (a power of two) consecutive items share it
     slot = a.slots ? (uint64_t)a.slots[ps] : (uint64_t)(a.slot_base + ps);
-    gal = (long)(slot / (uint64_t)a.S);
-    const uint32_t att = a.attempt + (uint32_t)(it % a.attempts_per_slot);
+    gal = (long)((uint32_t)slot / (uint32_t)a.S);  // slot ids fit 32 bits (checked by the API)
+    const uint32_t att = a.attempt + (uint32_t)(it & (long)(a.attempts_per_slot - 1));
     float z4[4];
     sf_normal4(a.k0, a.k1, slot, att, (uint32_t)g4, z4);  // Philox block g4 = dimensions 4*g4 .. 4*g4+3
 #pragma unroll
