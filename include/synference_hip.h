@@ -245,6 +245,25 @@ int sf_quantiles(const float* samples /*[N,S,D]*/, int64_t N, int64_t S, int32_t
 int sf_flux_to_abmag(const float* flux_njy, const float* err_njy, int64_t n, float mag_limit,
                      float* mag, float* mag_err, void* stream);
 
+/* asinh magnitudes with per-band softening f_b [C] (nJy, device): flux / err [N,C] row-major in nJy.
+ *   mag = -2.5 log10(e) (asinh(f / 2 f_b) + ln(f_b / 3631 Jy)),  mag_err = 2.5 log10(e) err / sqrt(f^2 + (2 f_b)^2)
+ * Replaces ref: utils.py:647-704 (f_jy_to_asinh, f_jy_err_to_asinh) as used at sbi_runner.py:1718-1731. */
+int sf_flux_to_asinh(const float* flux_njy, const float* err_njy, int64_t N, int32_t C, const float* f_b_njy /*[C]*/,
+                     float* mag, float* mag_err, void* stream);
+
+/* Depth-noise scatter of library photometry: out[(i*n_scatters + s), c] = flux[i,c] + sigma_ic * N(0,1),
+ * sigma_ic = max(sigma[c], |flux[i,c]| * min_flux_pc_error / 100); err_out (may be NULL) receives sigma_ic.
+ * sigma [C] device = depth / depth_sigma in the units of flux.  Noise from the Philox stream (seed, stream 2).
+ * Replaces ref: sbi_runner.py:580-691 (_apply_depths, 0-D / 1-D depths). */
+int sf_scatter_depths(const float* flux /*[N,C]*/, int64_t N, int32_t C, const float* sigma /*[C]*/,
+                      int32_t n_scatters, float min_flux_pc_error, uint64_t seed,
+                      float* out /*[N*n_scatters,C]*/, float* err_out, void* stream);
+
+/* PIT ranks of the truths among the posterior draws: out[g,d] = #{draws < truth} / #{finite draws}.
+ * Replaces the host pass at ref: sbi_runner.py:7153-7158. */
+int sf_pit_ranks(const float* samples /*[N,S,D]*/, const float* truth /*[N,D]*/, int64_t N, int64_t S, int32_t D,
+                 float* out /*[N,D]*/, void* stream);
+
 /* ---- misc --------------------------------------------------------------------------- */
 const char* sf_last_error(void);
 const char* sf_version(void);

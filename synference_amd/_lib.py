@@ -55,6 +55,11 @@ PROTOTYPES = {
     "sf_flow_sample_round": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
                                        C.c_uint32, C.c_int32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sf_flux_to_asinh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
+    "sf_scatter_depths": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_uint64,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sf_pit_ranks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "sf_flow_prepare_context": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "sf_flow_release_context": (C.c_int, [C.c_void_p]),
     "sf_flow_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,

@@ -275,16 +275,38 @@ class SBI_Fitter:
         posteriors = posteriors if posteriors is not None else self.posteriors
         X_test = self._X_test if X_test is None else X_test
         y_test = self._y_test if y_test is None else y_test
-        s = self.sample_posterior(X_test, posteriors=posteriors, num_samples=num_samples, seed=seed)
-        mean = np.nanmean(s, axis=1)
+        # draws stay on the device: only (N, D) summaries cross PCIe
+        X32 = torch.as_tensor(np.asarray(X_test, dtype=np.float32))
+        sd = posteriors.sample_catalogue(X32, num_samples, seed)
+        mean = torch.nanmean(sd, dim=1).double().cpu().numpy()
         y = np.asarray(y_test, dtype=np.float64)
         mse = np.nanmean((mean - y) ** 2, 0)
         ss_tot = np.sum((y - y.mean(0)) ** 2, 0)
         r2 = 1.0 - np.nansum((mean - y) ** 2, 0) / np.where(ss_tot > 0, ss_tot, np.nan)
         lp = self.log_prob(X_test, y_test, posteriors=posteriors, norm_posterior=False)
-        pit = np.nanmean(s < y[:, None, :], axis=1)
+        from .features import pit_ranks
+        pit = pit_ranks(sd, torch.as_tensor(y, dtype=torch.float32)).double().cpu().numpy()
         metrics = {"mse": mse.tolist(), "rmse": np.sqrt(mse).tolist(), "r_squared": r2.tolist(),
                    "mean_log_prob": float(np.mean(lp[np.isfinite(lp)])) if np.isfinite(lp).any() else float("nan"),
-                   "pit_mean": pit.mean(0).tolist(), "pit_std": pit.std(0).tolist()}
+                   "pit_mean": np.nanmean(pit, 0).tolist(), "pit_std": np.nanstd(pit, 0).tolist()}
         self.last_metrics = metrics
         return metrics
+
+    def calculate_PIT(self, X: np.ndarray, y: np.ndarray, num_samples: int = 1000, posteriors=None,
+                      samples=None, seed: Optional[int] = None) -> np.ndarray:
+        """Sorted, max-normalised probability integral transform values, one per row
+        (ref: sbi_runner.py:7128-7160: ``mean(samples[i] < y[i])`` over draws and parameters).  The draws are
+        ranked on the device (``sf_pit_ranks``)."""
+        from .features import pit_ranks
+        posteriors = posteriors if posteriors is not None else self.posteriors
+        if samples is None:
+            sd = posteriors.sample_catalogue(torch.as_tensor(np.asarray(X, dtype=np.float32)), num_samples, seed)
+        else:
+            sd = torch.as_tensor(np.asarray(samples, dtype=np.float32)).to(self.device)
+        y2 = np.asarray(y, dtype=np.float32).reshape(sd.shape[0], -1)
+        n_valid = torch.isfinite(sd).sum(1).double().cpu().numpy()
+        ranks = pit_ranks(sd, torch.as_tensor(y2)).double().cpu().numpy()
+        # reference semantics: NaN draws compare False but stay in the denominator
+        pit = np.nan_to_num(ranks * n_valid, nan=0.0).sum(1) / (sd.shape[1] * sd.shape[2])
+        pit = np.sort(pit)
+        return pit / pit[-1]

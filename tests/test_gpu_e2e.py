@@ -203,3 +203,59 @@ def test_flux_to_abmag_matches_reference_formula():
     assert np.abs(mag.cpu().double().numpy() - ref).max() < 2e-5
     ok = np.isfinite(rerr) & (f > 0)
     assert np.abs(merr.cpu().double().numpy()[ok] - rerr[ok]).max() < 1e-4 * np.abs(rerr[ok]).max()
+
+
+def test_flux_to_asinh_matches_oracle():
+    from oracle import features as OF
+    from synference_amd.features import flux_to_asinh
+    rng = np.random.default_rng(1)
+    f = (rng.normal(0, 1, size=(777, 9)) * 10 ** rng.uniform(-1, 5, size=(777, 9))).astype(np.float32)   # both signs
+    e = (0.1 * np.abs(f) + 1).astype(np.float32)
+    fb = (10 ** rng.uniform(0, 2, size=9)).astype(np.float32)
+    mag, merr = flux_to_asinh(torch.as_tensor(f).cuda(), fb, torch.as_tensor(e).cuda())
+    rm, re = OF.flux_to_asinh(f, fb, e)
+    assert np.abs(mag.cpu().double().numpy() - rm).max() < 5e-5
+    assert np.abs(merr.cpu().double().numpy() - re).max() < 1e-5 * max(1.0, np.abs(re).max())
+    m_scalar = flux_to_asinh(torch.as_tensor(f).cuda(), 5.0)
+    assert np.abs(m_scalar.cpu().double().numpy() - OF.flux_to_asinh(f, 5.0)).max() < 5e-5
+
+
+def test_scatter_depths_matches_oracle_draw_for_draw():
+    from oracle import features as OF
+    from synference_amd.features import scatter_depths
+    rng = np.random.default_rng(2)
+    f = rng.uniform(-5, 200, size=(501, 10)).astype(np.float32)
+    depths = rng.uniform(1, 30, size=10).astype(np.float32)
+    out, err = scatter_depths(torch.as_tensor(f).cuda(), depths, n_scatters=3, depth_sigma=5.0, min_flux_pc_error=1.5,
+                              seed=77, return_errors=True)
+    ro, rs = OF.scatter_depths(f, depths, 3, 5.0, 1.5, 77)
+    assert out.shape == (1503, 10)
+    assert np.abs(err.cpu().double().numpy() - rs).max() < 1e-5
+    assert np.abs(out.cpu().double().numpy() - ro).max() < 2e-4        # same Philox stream, fp32 Box-Muller
+    assert scatter_depths(torch.as_tensor(f[:0]).cuda(), depths).shape == (0, 10)
+
+
+def test_pit_ranks_match_oracle():
+    from oracle import features as OF
+    from synference_amd.features import pit_ranks
+    rng = np.random.default_rng(3)
+    s = rng.normal(size=(37, 300, 4)).astype(np.float32)
+    s[5, :, 2] = np.nan; s[6, ::3, 1] = np.nan
+    t = rng.normal(size=(37, 4)).astype(np.float32)
+    got = pit_ranks(torch.as_tensor(s).cuda(), torch.as_tensor(t)).cpu().double().numpy()
+    ref = OF.pit_ranks(s, t)
+    assert np.isnan(got[5, 2]) and np.isnan(ref[5, 2])
+    ok = np.isfinite(ref)
+    assert np.abs(got[ok] - ref[ok]).max() < 1e-6
+
+
+def test_calculate_pit_matches_reference_definition(fitted):
+    f = fitted[0]
+    X, y = f._X_test[:64], f._y_test[:64]
+    s = f.sample_posterior(X, num_samples=200, seed=11)
+    pit = f.calculate_PIT(X, y, samples=s)
+    ref = np.sort(np.array([np.mean(s[i] < y[i]) for i in range(len(y))]))     # sbi_runner.py:7153-7158
+    ref = ref / ref[-1]
+    assert pit.shape == (64,) and np.abs(pit - ref).max() < 1e-6
+    m = f.evaluate_model(X_test=X, y_test=y, num_samples=200, seed=11)
+    assert len(m["pit_mean"]) == y.shape[1] and all(0.0 <= v <= 1.0 for v in m["pit_mean"])

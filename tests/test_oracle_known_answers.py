@@ -209,3 +209,49 @@ def test_rejection_sampler_and_ensemble_semantics():
     e = OP.ensemble_log_prob([spec, spec], [p, p], [0.3, 0.7], free[0, :5], np.repeat(x[:1], 5, 0))
     one = OP.posterior_log_prob(spec, p, free[0, :5], np.repeat(x[:1], 5, 0))
     assert np.abs(e - one).max() < 1e-9
+
+
+# ---------------------------------------------------------------------------------------------------
+# feature transforms (oracle/features.py): closed forms
+# ---------------------------------------------------------------------------------------------------
+def test_asinh_magnitude_limits_and_error():
+    from oracle import features as F
+    fb = np.array([5.0, 20.0])                                   # nJy
+    # zero flux: mag = -2.5 log10(f_b / 3631 Jy)  (the softening magnitude; 5 nJy -> 29.65 AB)
+    m0 = F.flux_to_asinh(np.zeros((1, 2)), fb)
+    assert np.allclose(m0[0], -2.5 * np.log10(fb * 1e-9 / 3631.0), atol=1e-12)
+    assert abs(m0[0, 0] - 29.65) < 0.01
+    # bright limit: asinh magnitude -> AB magnitude
+    f = np.array([[1e6, 3e7]])
+    ab = -2.5 * np.log10(f * 1e-3) + 23.9
+    assert np.allclose(F.flux_to_asinh(f, fb), ab, atol=2e-3)
+    # negative flux is finite and fainter than the zero point, antisymmetric about it
+    mp, mn = F.flux_to_asinh(np.array([[7.0, 7.0]]), fb), F.flux_to_asinh(np.array([[-7.0, -7.0]]), fb)
+    assert np.allclose(mp + mn, 2 * m0, atol=1e-12) and (mn > m0).all()
+    # error: d mag / d f * sigma
+    f1 = np.array([[12.0, 40.0]]); s = np.array([[0.5, 2.0]])
+    _, e = F.flux_to_asinh(f1, fb, s)
+    h = 1e-4
+    num = (F.flux_to_asinh(f1 + h, fb) - F.flux_to_asinh(f1 - h, fb)) / (2 * h)
+    assert np.allclose(e, np.abs(num) * s, rtol=1e-6)
+
+
+def test_scatter_depths_statistics_and_layout():
+    from oracle import features as F
+    f = np.tile(np.array([[100.0, 10.0, -3.0]]), (4000, 1))
+    out, sig = F.scatter_depths(f, np.array([5.0, 10.0, 2.0]), n_scatters=3, depth_sigma=5.0, min_flux_pc_error=2.0, seed=9)
+    assert out.shape == (12000, 3) and sig.shape == out.shape
+    assert np.allclose(sig[0], [2.0, 2.0, 0.4])                   # max(depth/5, 2 % of |flux|)
+    z = (out - np.repeat(f, 3, 0)) / sig
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02
+    out2, _ = F.scatter_depths(f, np.array([5.0, 10.0, 2.0]), n_scatters=3, depth_sigma=5.0, min_flux_pc_error=2.0, seed=9)
+    assert (out == out2).all()                                    # counter-based: reproducible
+
+
+def test_pit_ranks_known_answer():
+    from oracle import features as F
+    s = np.arange(10, dtype=float).reshape(1, 10, 1).repeat(2, 2)
+    s[0, 3, 1] = np.nan
+    r = F.pit_ranks(s, np.array([[4.5, 4.5]]))
+    assert np.allclose(r, [[0.5, 4 / 9]])
+    assert np.isnan(F.pit_ranks(np.full((1, 4, 1), np.nan), np.zeros((1, 1)))).all()
