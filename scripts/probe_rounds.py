@@ -35,7 +35,7 @@ for rep in range(2):
     while pending > 0 and attempt < 64:
         A = 1
         if attempt > 0:
-            while A < 32 and 2 * A * pending <= budget and attempt + 2 * A <= 64: A *= 2
+            while A < 16 and 2 * A * pending <= budget and attempt + 2 * A <= 64: A *= 2
         cnt.zero_(); torch.cuda.synchronize(); t0 = time.perf_counter()
         flow.sample_round(X, S, cur, 0, pending, attempt, 5, lo, hi, out, rej[r & 1], cnt, attempts_per_slot=A)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0

@@ -315,7 +315,7 @@ int sf_flow_sample(sf_flow* f, const float* x, int64_t M, int64_t S, const float
       // speculation budget ~ the work one latency-bound round could do anyway (measured: a round of
       // ~2.6e5 items costs the same 0.5-1.1 ms as a round of 1 item)
       const int64_t budget = 262144;
-      while (A < 32 && (int64_t)(2 * A) * pending <= budget && attempt + 2 * A <= max_attempts) A *= 2;
+      while (A < 16 && (int64_t)(2 * A) * pending <= budget && attempt + 2 * A <= max_attempts) A *= 2;
     }
     SF_HIP(hipMemsetAsync(f->d_cnt, 0, sizeof(uint32_t), st));
     int rc = sf_flow_sample_round(f, x, S, cur, 0, pending, (uint32_t)attempt, A, seed, 0, lo, hi, out,

@@ -18,11 +18,12 @@ from .spec import KIND_ID, FlowSpec, num_params
 
 def retry_width(pending: int, attempt: int, max_attempts: int, total: int = 0) -> int:
     """Attempts evaluated per pending slot in a retry round (same rule as sf_flow_sample): speculate only
-    up to the work a latency-bound round could do anyway (~2.6e5 items)."""
+    up to the work a latency-bound round could do anyway (~2.6e5 items), at most 16 attempts per slot (the
+    16-row MAF kernel resolves a slot within one 16-draw tile)."""
     A = 1
     if attempt > 0:
         budget = 262144
-        while A < 32 and 2 * A * pending <= budget and attempt + 2 * A <= max_attempts:
+        while A < 16 and 2 * A * pending <= budget and attempt + 2 * A <= max_attempts:
             A *= 2
     return A
 
