@@ -163,6 +163,7 @@ int sf_flow_set_params(sf_flow* f, const float* flat, int64_t n, int is_device, 
   }
   SF_HIP(sf_launch_pack(src, f->d_s1, f->d_s2, f->d_packed, (long)f->L.n_packed, st));
   if (f->d_packed16) SF_HIP(sf_launch_pack(src, f->d_s16a, f->d_s16b, f->d_packed16, (long)f->L.n_packed16, st));
+  f->packed16_stale = false;
   if (f->L.n_packedB > 0) SF_HIP(sf_launch_pack_bf16(src, f->d_bsrc, f->d_packedB, (long)f->L.n_packedB, st));
   f->params_set = true;
   f->ctab_x = nullptr;  // a context table built from the old parameters is stale

@@ -54,6 +54,7 @@ struct sf_flow {
   unsigned short* d_packedB = nullptr;  // bf16 hidden operand image (hidden_bf16)
   int32_t* d_bsrc = nullptr;
   float* d_packed16 = nullptr;          // 16-row image of the incremental MAF inverse (sf_maf16.hip)
+  bool packed16_stale = false;          // loss_grad refreshed only the forward image
   int32_t *d_s16a = nullptr, *d_s16b = nullptr;
   int32_t *d_s1 = nullptr, *d_s2 = nullptr, *d_t1 = nullptr, *d_t2 = nullptr;
   float* d_flat = nullptr;      // staging for host-sourced parameters
@@ -74,7 +75,7 @@ struct sf_flow {
     v.packedT = d_packedT;
     v.cst = d_cst;
     v.packedB = d_packedB;
-    v.packed16 = d_packed16;
+    v.packed16 = packed16_stale ? nullptr : d_packed16;
     v.ctab = nullptr;  // set per launch by the sampler entry points
     return v;
   }

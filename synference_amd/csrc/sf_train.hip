@@ -51,9 +51,72 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
   }
 }
 
+// One-launch form for small parameter vectors (n <= 131072): every workgroup first reduces the WHOLE gradient to
+// its squared norm (L2-resident re-reads, a fixed summation order -> the clip coefficient is deterministic), then
+// updates its own slice.  Replaces memset + k_sqnorm + k_adam.
+__global__ __launch_bounds__(1024) void k_adam_fused(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, float* __restrict__ sq_out, long n,
+                                                    sf_adam_desc d, float bc1, float bc2, float max_norm,
+                                                    float* __restrict__ norm_out) {
+  float s = 0.f;
+  {
+    // 1024 threads x float4, 4 loads in flight: the whole vector in <= 8 trips
+    const float4* __restrict__ g4 = reinterpret_cast<const float4*>(g);
+    const long n4 = n >> 2;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (long i = threadIdx.x; i < n4; i += 4 * 1024) {
+      const float4 a = g4[i];
+      const float4 b = i + 1024 < n4 ? g4[i + 1024] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 c = i + 2048 < n4 ? g4[i + 2048] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 e = i + 3072 < n4 ? g4[i + 3072] : make_float4(0.f, 0.f, 0.f, 0.f);
+      s0 += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+      s1 += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+      s2 += c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
+      s3 += e.x * e.x + e.y * e.y + e.z * e.z + e.w * e.w;
+    }
+    s = (s0 + s1) + (s2 + s3);
+    for (long i = (n4 << 2) + threadIdx.x; i < n; i += 1024) s += g[i] * g[i];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  __shared__ float part[16];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  float sq = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) sq += part[w];
+  const float total = sqrtf(sq);
+  float coef = 1.f;
+  if (max_norm > 0.f) coef = fminf(max_norm / (total + 1e-6f), 1.0f);  // torch clip_grad_norm_
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *sq_out = sq;
+    if (norm_out) *norm_out = total;
+  }
+  const float step_size = d.lr / bc1;
+  const float inv_sqrt_bc2 = rsqrtf(bc2);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float pi = p[i];
+    float gi = g[i] * coef;
+    if (d.decoupled) pi *= (1.f - d.lr * d.weight_decay);
+    else if (d.weight_decay != 0.f) gi += d.weight_decay * pi;
+    const float mi = d.beta1 * m[i] + (1.f - d.beta1) * gi;
+    const float vi = d.beta2 * v[i] + (1.f - d.beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + d.eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+
 hipError_t sf_launch_adam(float* params, const float* grad, float* m, float* v, float* norm_scratch, long n,
                           const sf_adam_desc& d, float bc1, float bc2, float max_norm, float* grad_norm_out,
                           hipStream_t st) {
+  if (n <= 131072 && ((uintptr_t)grad & 15) == 0) {  // (the fused kernel reads the gradient as float4)
+    const int nb = (int)((n + 4095) / 4096);
+    hipLaunchKernelGGL(k_adam_fused, dim3(nb < 1 ? 1 : nb), dim3(1024), 0, st, params, grad, m, v, norm_scratch, n, d, bc1,
+                       bc2, max_norm, grad_norm_out);
+    return hipGetLastError();
+  }
   hipError_t e = hipMemsetAsync(norm_scratch, 0, sizeof(float), st);
   if (e != hipSuccess) return e;
   const int blocks = (int)((n + 1023) / 1024 < 256 ? (n + 1023) / 1024 : 256);
@@ -82,6 +145,35 @@ __global__ void k_grad_gather(const float* __restrict__ gimg, const int32_t* __r
   if (i >= n) return;
   const int g = gdst[i];
   grad[i] = g >= 0 ? gimg[g] : 0.f;
+}
+
+// one launch for everything a training step needs before the flow kernel: forward image, transposed image,
+// zeroed gradient image (and zeroed context-gradient rows)
+__global__ void k_train_prep(const float* __restrict__ flat, const int32_t* __restrict__ s1, const int32_t* __restrict__ s2,
+                             float* __restrict__ packed, long n1, const int32_t* __restrict__ t1,
+                             const int32_t* __restrict__ t2, float* __restrict__ packedT, long n2,
+                             float* __restrict__ gimg, float* __restrict__ dctx, long n4) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n1) {
+    const int a = s1[i], b = s2[i];
+    float v = 0.f;
+    if (a >= 0) v = flat[a];
+    if (b >= 0) v += flat[b];
+    packed[i] = v;
+    gimg[i] = 0.f;
+    return;
+  }
+  i -= n1;
+  if (i < n2) {
+    const int a = t1[i], b = t2[i];
+    float v = 0.f;
+    if (a >= 0) v = flat[a];
+    if (b >= 0) v += flat[b];
+    packedT[i] = v;
+    return;
+  }
+  i -= n2;
+  if (i < n4) dctx[i] = 0.f;
 }
 
 #define SF_TDECL(H)                                                                         \
@@ -125,12 +217,17 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
     SF_TRY(hipMalloc(&f->d_act, need * sizeof(float)));
     f->act_cap = need;
   }
-  SF_TRY(sf_launch_pack(flat, f->d_s1, f->d_s2, f->d_packed, (long)L.n_packed, st));
-  if (f->d_packed16) SF_TRY(sf_launch_pack(flat, f->d_s16a, f->d_s16b, f->d_packed16, (long)L.n_packed16, st));
+  {
+    const long n4 = (dctx && B > 0) ? B * (long)L.dev.C : 0;
+    const long tot = (long)L.n_packed + (long)L.n_packedT + n4;
+    hipLaunchKernelGGL(k_train_prep, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, flat, f->d_s1, f->d_s2, f->d_packed,
+                       (long)L.n_packed, f->d_t1, f->d_t2, f->d_packedT, (long)L.n_packedT, f->d_gpacked, dctx, n4);
+    SF_TRY(hipGetLastError());
+  }
+  // the 16-row sampler image is not needed for training: it is refreshed by the next sf_flow_set_params, and until
+  // then the sampler uses the 32-row kernel on the (fresh) forward image
+  f->packed16_stale = f->d_packed16 != nullptr;
   if (L.n_packedB > 0) SF_TRY(sf_launch_pack_bf16(flat, f->d_bsrc, f->d_packedB, (long)L.n_packedB, st));
-  SF_TRY(sf_launch_pack(flat, f->d_t1, f->d_t2, f->d_packedT, (long)L.n_packedT, st));
-  SF_TRY(hipMemsetAsync(f->d_gpacked, 0, (size_t)L.n_packed * sizeof(float), st));
-  if (dctx && B > 0) SF_TRY(hipMemsetAsync(dctx, 0, (size_t)B * L.dev.C * sizeof(float), st));
   if (B > 0) {
     SfTrainArgs a;
     a.theta = theta; a.x = x; a.B = B; a.w = grad_scale; a.wts = weights; a.loss = loss; a.dctx = dctx; a.gimg = f->d_gpacked;
