@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(SfMlpDev m, SfMlpArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) ain[mt][0][r] = sf_act_f(m.act, zin[mt][0][r]);
       }
-      sf_grad_w<HT, HT>(lds, d, ain, a.gimg + m.o_w[l], a.gimg + m.o_b[l], m.nG[l], 0, m.nG[l], lane);
+      sf_grad_w_local<HT, HT>(lds, d, ain, a.gimg + m.o_w[l], a.gimg + m.o_b[l], m.nG[l], 0, m.nG[l], lane);
       f32x16 din[HT][1];
 #pragma unroll
       for (int mt = 0; mt < HT; ++mt)
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(SfMlpDev m, SfMlpArgs a) {
   for (int kt = 0; kt * 4 < m.nG[0]; ++kt) {
     f32x16 ct[1][1];
     sf_mlp_in_tile(ct, xr, m, kt, h);
-    sf_grad_w<HT, 1>(lds, d, ct, a.gimg + m.o_w[0], kt == 0 ? a.gimg + m.o_b[0] : nullptr, m.nG[0], kt * 4,
+    sf_grad_w_local<HT, 1>(lds, d, ct, a.gimg + m.o_w[0], kt == 0 ? a.gimg + m.o_b[0] : nullptr, m.nG[0], kt * 4,
                      min(4, m.nG[0] - kt * 4), lane);
   }
 }

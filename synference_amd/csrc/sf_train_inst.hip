@@ -13,31 +13,29 @@ static hipError_t set_shmem(K kernel, size_t bytes) {
 }
 
 hipError_t SF_CAT(sf_launch_maf_train_h, SF_HT)(const SfDev& m, const SfTrainArgs& a, hipStream_t st) {
-  const long waves = (a.B + 31) / 32;
-  const long grid = (waves + 3) / 4;
-  const size_t shmem = (size_t)4 * (2 * SF_HT) * SF_TL * sizeof(float);
+  const long grid = (a.B + 31) / 32;  // one workgroup (producer + consumer wave) per 32-sample tile
+  const size_t shmem = (size_t)2 * (SF_JOB_HDR + (2 * SF_HT) * SF_TL) * sizeof(float);
   static bool attr = false;
   if (!attr) {
     hipError_t e = set_shmem(k_maf_train<SF_HT>, shmem);
     if (e != hipSuccess) return e;
     attr = true;
   }
-  hipLaunchKernelGGL((k_maf_train<SF_HT>), dim3((unsigned)grid), dim3(256), shmem, st, m, a);
+  hipLaunchKernelGGL((k_maf_train<SF_HT>), dim3((unsigned)grid), dim3(128), shmem, st, m, a);
   return hipGetLastError();
 }
 
 template <int PT>
 static hipError_t launch_nsf(const SfDev& m, const SfTrainArgs& a, hipStream_t st) {
-  const long waves = (a.B + 31) / 32;
-  const long grid = (waves + 3) / 4;
-  const size_t shmem = (size_t)4 * SfNsfLds<SF_HT, PT>::tiles * SF_TL * sizeof(float);
+  const long grid = (a.B + 31) / 32;
+  const size_t shmem = (size_t)2 * (SF_JOB_HDR + SfNsfLds<SF_HT, PT>::tiles * SF_TL) * sizeof(float);
   static bool attr = false;
   if (!attr) {
     hipError_t e = set_shmem(k_nsf_train<SF_HT, PT>, shmem);
     if (e != hipSuccess) return e;
     attr = true;
   }
-  hipLaunchKernelGGL((k_nsf_train<SF_HT, PT>), dim3((unsigned)grid), dim3(256), shmem, st, m, a);
+  hipLaunchKernelGGL((k_nsf_train<SF_HT, PT>), dim3((unsigned)grid), dim3(128), shmem, st, m, a);
   return hipGetLastError();
 }
 

@@ -27,11 +27,111 @@ __device__ __forceinline__ void sf_stash_load(const float4* __restrict__ base, i
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradients: producer / consumer wave pair.
+//   gw block [mt][kg][j][lane] += sum_s in[i][s] * delta[o][s]
+// A workgroup is TWO waves that own one 32-sample tile.  Wave 0 (producer) runs forward + backward; whenever a
+// layer's delta tile is ready it drops (in tiles, delta tiles, job descriptor) transposed into one of two LDS
+// buffers and passes a workgroup barrier.  Wave 1 (consumer) sits in a loop: barrier, read the descriptor, do the
+// MFMAs over the 32 samples and the f32 atomics into the gradient image.  The consumer interprets descriptors, so
+// the two waves cannot disagree on the job sequence; the producer ends with a stop descriptor.  Effect: the ~50 %
+// of a tile's MFMA work that is weight gradients leaves the latency chain of the data path and runs on another
+// SIMD (the waves of a workgroup are spread over the SIMDs of a CU).
+//   barrier protocol: job i lives in buffer i&1; the producer arrives at barrier i after writing it, the consumer
+//   arrives at barrier i before reading it, hence at barrier i+1 only after finishing job i -- which is what the
+//   producer waits for before it may overwrite buffer i&1 with job i+2.
+// ---------------------------------------------------------------------------------------------
+#define SF_JOB_HDR 16  // floats reserved for the descriptor in front of the tiles
+struct SfGradPipe {
+  float* lds;   // two buffers of `stride` floats
+  int stride;
+  int i;
+};
+
+template <int OT, int IT, bool RELU_IN = false>
+__device__ __forceinline__ void sf_grad_w(SfGradPipe& P, const f32x16 (&delta)[OT][1], const f32x16 (&in)[IT][1],
+                                          float* __restrict__ gw, float* __restrict__ gb, int nGtot, int kg0, int ng,
+                                          int lane) {
+  const int c = lane & 31, h = lane >> 5;
+  float* buf = P.lds + (P.i & 1) * P.stride;
+  float* tiles = buf + SF_JOB_HDR;
+#pragma unroll
+  for (int kt = 0; kt < IT; ++kt) sf_tile_to_lds<RELU_IN>(tiles + kt * SF_TL, in[kt][0], c, h);
+#pragma unroll
+  for (int mt = 0; mt < OT; ++mt) sf_tile_to_lds<false>(tiles + (IT + mt) * SF_TL, delta[mt][0], c, h);
+  if (lane == 0) {
+    int* d = reinterpret_cast<int*>(buf);
+    d[0] = OT; d[1] = IT; d[2] = nGtot; d[3] = kg0; d[4] = ng; d[5] = 0;  // d[5]: stop flag
+    const unsigned long long pw = (unsigned long long)gw, pb = (unsigned long long)gb;
+    d[6] = (int)(unsigned)pw; d[7] = (int)(unsigned)(pw >> 32);
+    d[8] = (int)(unsigned)pb; d[9] = (int)(unsigned)(pb >> 32);
+  }
+  __syncthreads();
+  ++P.i;
+}
+
+__device__ __forceinline__ void sf_grad_stop(SfGradPipe& P, int lane) {
+  if (lane == 0) reinterpret_cast<int*>(P.lds + (P.i & 1) * P.stride)[5] = 1;
+  __syncthreads();
+  ++P.i;
+}
+
+// the consumer wave: runs until the stop descriptor
+__device__ __forceinline__ void sf_grad_consumer(float* __restrict__ lds, int stride, int lane) {
+  const int c = lane & 31, h = lane >> 5;
+  const int rd = c * 33 + h;
+  for (int i = 0;; ++i) {
+    __syncthreads();
+    const float* buf = lds + (i & 1) * stride;
+    const int* d = reinterpret_cast<const int*>(buf);
+    if (__builtin_amdgcn_readfirstlane(d[5])) break;
+    const int OT = __builtin_amdgcn_readfirstlane(d[0]), IT = __builtin_amdgcn_readfirstlane(d[1]);
+    const int nGtot = __builtin_amdgcn_readfirstlane(d[2]), kg0 = __builtin_amdgcn_readfirstlane(d[3]);
+    const int ng = __builtin_amdgcn_readfirstlane(d[4]);
+    float* gw = reinterpret_cast<float*>((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(d[6]) |
+                                         ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(d[7]) << 32));
+    float* gb = reinterpret_cast<float*>((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(d[8]) |
+                                         ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(d[9]) << 32));
+    const float* tiles = buf + SF_JOB_HDR;
+    for (int mt = 0; mt < OT; ++mt) {
+      float bsum = 0.f;
+      const float* ld = tiles + (IT + mt) * SF_TL + rd;
+      for (int kt = 0; kt < IT; ++kt) {
+        if (kt * 4 < ng) {
+          const float* li = tiles + kt * SF_TL + rd;
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const float a = li[2 * k];
+            const float b = ld[2 * k];
+            if (kt == 0) bsum += b;
+            acc = SF_MFMA(a, b, acc);
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            if (kt * 4 + g < ng) {
+              float* dst = gw + (((size_t)mt * nGtot + kg0 + kt * 4 + g) * 4) * 64 + lane;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) atomicAdd(dst + j * 64, acc[4 * g + j]);
+            }
+        }
+      }
+      if (gb) {
+        bsum += sf_xhalf(bsum);
+        if (h == 0) atomicAdd(gb + mt * 32 + c, bsum);
+      }
+    }
+  }
+}
+
+// single-wave form (used by the embedding MLP backward, sf_mlp.hip): the same wave transposes and consumes.
 // gradient of one linear layer's weights (and optionally bias):
 //   gw block [mt][kg][j][lane] += sum_s in[i][s] * delta[o][s]
 // lds: (IT + OT) transposed tiles; in tiles first.
 template <int OT, int IT, bool RELU_IN = false>
-__device__ __forceinline__ void sf_grad_w(float* __restrict__ lds, const f32x16 (&delta)[OT][1],
+__device__ __forceinline__ void sf_grad_w_local(float* __restrict__ lds, const f32x16 (&delta)[OT][1],
                                           const f32x16 (&in)[IT][1], float* __restrict__ gw,
                                           float* __restrict__ gb, int nGtot, int kg0, int ng, int lane) {
   const int c = lane & 31, h = lane >> 5;
@@ -98,14 +198,18 @@ __device__ __forceinline__ void sf_ctx_grad(const SfDev& m, const f32x16 (&delta
 }
 
 template <int HT>
-__global__ __launch_bounds__(256) void k_maf_train(SfDev m, SfTrainArgs a) {
+__global__ __launch_bounds__(128, 2) void k_maf_train(SfDev m, SfTrainArgs a) {
   extern __shared__ float lds_all[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, h = lane >> 5;
-  const long wid = (long)blockIdx.x * 4 + wave;
+  const long wid = (long)blockIdx.x;  // one 32-sample tile per workgroup: wave 0 producer, wave 1 weight-gradient consumer
   const long base = wid * 32;
   if (base >= a.B) return;
-  float* lds = lds_all + wave * (2 * HT) * SF_TL;
+  SfGradPipe lds = {lds_all, SF_JOB_HDR + (2 * HT) * SF_TL, 0};
+  if (wave == 1) {
+    sf_grad_consumer(lds_all, lds.stride, lane);
+    return;
+  }
   float4* stash = a.act + wid * a.act_per_wave;
   const int TPT = (m.NB + 1) * HT + 1;  // stash tiles per transform: u, h0, a_1..a_NB
 
@@ -287,6 +391,7 @@ __global__ __launch_bounds__(256) void k_maf_train(SfDev m, SfTrainArgs a) {
       }
     }
   }
+  sf_grad_stop(lds, lane);
 }
 
 
@@ -306,14 +411,18 @@ struct SfNsfLds {  // transposed tiles needed at once by sf_grad_w
 };
 
 template <int HT, int PT>
-__global__ __launch_bounds__(256) void k_nsf_train(SfDev m, SfTrainArgs a) {
+__global__ __launch_bounds__(128) void k_nsf_train(SfDev m, SfTrainArgs a) {
   extern __shared__ float lds_all[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, h = lane >> 5;
-  const long wid = (long)blockIdx.x * 4 + wave;
+  const long wid = (long)blockIdx.x;  // one 32-sample tile per workgroup: wave 0 producer, wave 1 weight-gradient consumer
   const long base = wid * 32;
   if (base >= a.B) return;
-  float* lds = lds_all + wave * SfNsfLds<HT, PT>::tiles * SF_TL;
+  SfGradPipe lds = {lds_all, SF_JOB_HDR + SfNsfLds<HT, PT>::tiles * SF_TL, 0};
+  if (wave == 1) {
+    sf_grad_consumer(lds_all, lds.stride, lane);
+    return;
+  }
   float4* stash = a.act + wid * a.act_per_wave;
   // stash tiles per transform: [0] u_in, [1..HT] h_0, per block k: t1, t2, h_{k+1} (HT each), last: u'
   const int TPT = 2 + (3 * m.NB + 1) * HT;
@@ -617,4 +726,5 @@ __global__ __launch_bounds__(256) void k_nsf_train(SfDev m, SfTrainArgs a) {
       }
     }
   }
+  sf_grad_stop(lds, lane);
 }
