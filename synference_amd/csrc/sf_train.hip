@@ -139,12 +139,17 @@ hipError_t sf_launch_adam(float* params, const float* grad, float* m, float* v, 
 //                      they are added to the gradient image with 256-byte-contiguous f32 atomics
 //   bias gradients   : row sums of the delta tile, taken from the B operands already read
 // ---------------------------------------------------------------------------------------------
-__global__ void k_grad_gather(const float* __restrict__ gimg, const int32_t* __restrict__ gdst,
+__global__ void k_grad_gather(const float* __restrict__ gimg, long stride, const int32_t* __restrict__ gdst,
                               float* __restrict__ grad, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int g = gdst[i];
-  grad[i] = g >= 0 ? gimg[g] : 0.f;
+  float v = 0.f;
+  if (g >= 0) {
+#pragma unroll
+    for (int c = 0; c < SF_GCOPIES; ++c) v += gimg[(size_t)c * stride + g];  // fixed order over the replicas
+  }
+  grad[i] = v;
 }
 
 // one launch for everything a training step needs before the flow kernel: forward image, transposed image,
@@ -160,7 +165,8 @@ __global__ void k_train_prep(const float* __restrict__ flat, const int32_t* __re
     if (a >= 0) v = flat[a];
     if (b >= 0) v += flat[b];
     packed[i] = v;
-    gimg[i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < SF_GCOPIES; ++c) gimg[(size_t)c * n1 + i] = 0.f;
     return;
   }
   i -= n1;
@@ -201,7 +207,7 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
     SF_TRY(hipMalloc(&f->d_t2, (size_t)L.n_packedT * sizeof(int32_t)));
     SF_TRY(hipMemcpy(f->d_t1, L.srcT1.data(), (size_t)L.n_packedT * sizeof(int32_t), hipMemcpyHostToDevice));
     SF_TRY(hipMemcpy(f->d_t2, L.srcT2.data(), (size_t)L.n_packedT * sizeof(int32_t), hipMemcpyHostToDevice));
-    SF_TRY(hipMalloc(&f->d_gpacked, (size_t)L.n_packed * sizeof(float)));
+    SF_TRY(hipMalloc(&f->d_gpacked, (size_t)SF_GCOPIES * L.n_packed * sizeof(float)));
     SF_TRY(hipMalloc(&f->d_gdst, (size_t)L.n_params * sizeof(int32_t)));
     SF_TRY(hipMemcpy(f->d_gdst, L.gdst.data(), (size_t)L.n_params * sizeof(int32_t), hipMemcpyHostToDevice));
   }
@@ -230,7 +236,7 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
   if (L.n_packedB > 0) SF_TRY(sf_launch_pack_bf16(flat, f->d_bsrc, f->d_packedB, (long)L.n_packedB, st));
   if (B > 0) {
     SfTrainArgs a;
-    a.theta = theta; a.x = x; a.B = B; a.w = grad_scale; a.wts = weights; a.loss = loss; a.dctx = dctx; a.gimg = f->d_gpacked;
+    a.theta = theta; a.x = x; a.B = B; a.w = grad_scale; a.wts = weights; a.loss = loss; a.dctx = dctx; a.gimg = f->d_gpacked; a.gimg_stride = (long)L.n_packed;
     a.act = reinterpret_cast<float4*>(f->d_act); a.act_per_wave = act_per_wave;
     const SfDev m = f->dev();
     const bool maf = m.kind == SF_MAF;
@@ -243,7 +249,7 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
     }
   }
   hipLaunchKernelGGL(k_grad_gather, dim3((unsigned)((L.n_params + 255) / 256)), dim3(256), 0, st,
-                     f->d_gpacked, f->d_gdst, grad, (long)L.n_params);
+                     f->d_gpacked, (long)L.n_packed, f->d_gdst, grad, (long)L.n_params);
   SF_TRY(hipGetLastError());
   return SF_OK;
 }

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#define SF_GCOPIES 8
+
 struct SfTrainArgs {
   const float* theta;
   const float* x;
@@ -10,7 +12,8 @@ struct SfTrainArgs {
   const float* wts;  // optional per-sample weights [B] (multiplied by w)
   float* loss;       // [B] or null
   float* dctx;       // [B,C] or null: += d(sum_b w_b loss_b)/d x[b,:] (context gradient, raw x units)
-  float* gimg;       // gradient image
+  float* gimg;       // gradient image: SF_GCOPIES replicas of gimg_stride floats (one per XCD, summed by the gather)
+  long gimg_stride;
   float4* act;       // activation stash
   long act_per_wave; // float4 per wave
 };

@@ -51,7 +51,7 @@ struct SfGradPipe {
 template <int OT, int IT, bool RELU_IN = false>
 __device__ __forceinline__ void sf_grad_w(SfGradPipe& P, const f32x16 (&delta)[OT][1], const f32x16 (&in)[IT][1],
                                           float* __restrict__ gw, float* __restrict__ gb, int nGtot, int kg0, int ng,
-                                          int lane) {
+                                          int lane, SfKLim lim = SfKLim{{1 << 20, 1 << 20, 1 << 20, 1 << 20}}) {
   const int c = lane & 31, h = lane >> 5;
   float* buf = P.lds + (P.i & 1) * P.stride;
   float* tiles = buf + SF_JOB_HDR;
@@ -65,6 +65,7 @@ __device__ __forceinline__ void sf_grad_w(SfGradPipe& P, const f32x16 (&delta)[O
     const unsigned long long pw = (unsigned long long)gw, pb = (unsigned long long)gb;
     d[6] = (int)(unsigned)pw; d[7] = (int)(unsigned)(pw >> 32);
     d[8] = (int)(unsigned)pb; d[9] = (int)(unsigned)(pb >> 32);
+    d[10] = lim.v[0]; d[11] = lim.v[1]; d[12] = lim.v[2]; d[13] = lim.v[3];  // per-output-tile group limit (masked layers)
   }
   __syncthreads();
   ++P.i;
@@ -96,8 +97,10 @@ __device__ __forceinline__ void sf_grad_consumer(float* __restrict__ lds, int st
     for (int mt = 0; mt < OT; ++mt) {
       float bsum = 0.f;
       const float* ld = tiles + (IT + mt) * SF_TL + rd;
+      // groups past the limit are structurally masked weights (block-triangular MADE layers): no gradient needed
+      const int ngm = min(ng, __builtin_amdgcn_readfirstlane(d[10 + mt]) - kg0);
       for (int kt = 0; kt < IT; ++kt) {
-        if (kt * 4 < ng) {
+        if (kt * 4 < ngm || (kt == 0 && gb)) {
           const float* li = tiles + kt * SF_TL + rd;
           f32x16 acc;
 #pragma unroll
@@ -111,10 +114,13 @@ __device__ __forceinline__ void sf_grad_consumer(float* __restrict__ lds, int st
           }
 #pragma unroll
           for (int g = 0; g < 4; ++g)
-            if (kt * 4 + g < ng) {
+            if (kt * 4 + g < ngm) {
               float* dst = gw + (((size_t)mt * nGtot + kg0 + kt * 4 + g) * 4) * 64 + lane;
+              // padded output rows are exact zeros in all four values: no atomic traffic for those lanes
+              if ((acc[4 * g] != 0.f) | (acc[4 * g + 1] != 0.f) | (acc[4 * g + 2] != 0.f) | (acc[4 * g + 3] != 0.f)) {
 #pragma unroll
-              for (int j = 0; j < 4; ++j) atomicAdd(dst + j * 64, acc[4 * g + j]);
+                for (int j = 0; j < 4; ++j) atomicAdd(dst + j * 64, acc[4 * g + j]);
+              }
             }
         }
       }
@@ -210,6 +216,10 @@ __global__ __launch_bounds__(128, 2) void k_maf_train(SfDev m, SfTrainArgs a) {
     sf_grad_consumer(lds_all, lds.stride, lane);
     return;
   }
+  // gradient-image replica of this XCD: f32 atomics from different XCDs then never meet on an address
+  int xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  float* gimg_x = a.gimg + (size_t)(xcc & (SF_GCOPIES - 1)) * a.gimg_stride;
   float4* stash = a.act + wid * a.act_per_wave;
   const int TPT = (m.NB + 1) * HT + 1;  // stash tiles per transform: u, h0, a_1..a_NB
 
@@ -301,7 +311,7 @@ __global__ __launch_bounds__(128, 2) void k_maf_train(SfDev m, SfTrainArgs a) {
   for (int t = m.T - 1; t >= 0; --t) {
     const float* tp = m.packed + (size_t)t * m.t_stride;
     const float* tpT = m.packedT + (size_t)t * m.tT_stride;
-    float* gp = a.gimg + (size_t)t * m.t_stride;
+    float* gp = gimg_x + (size_t)t * m.t_stride;
     float uin[1][SF_DMAX];
     {
       f32x16 ut;
@@ -356,7 +366,8 @@ __global__ __launch_bounds__(128, 2) void k_maf_train(SfDev m, SfTrainArgs a) {
           for (int r = 0; r < 16; ++r) dpre[mt][0][r] = dh[mt][0][r] * (1.0f - ak[mt][0][r] * ak[mt][0][r]);
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) sf_stash_load(stash, t * TPT + 1 + k * HT + mt, ak[mt][0], lane);
-        sf_grad_w<HT, HT>(lds, dpre, ak, gp + m.o_wk[k], gp + m.o_bk[k], m.nGh, 0, m.nGh, lane);
+        sf_grad_w<HT, HT>(lds, dpre, ak, gp + m.o_wk[k], gp + m.o_bk[k], m.nGh, 0, m.nGh, lane,
+                          SfKLim{{m.mt_kend[0], m.mt_kend[1], m.mt_kend[2], m.mt_kend[3]}});
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt)
 #pragma unroll
@@ -423,6 +434,10 @@ __global__ __launch_bounds__(128) void k_nsf_train(SfDev m, SfTrainArgs a) {
     sf_grad_consumer(lds_all, lds.stride, lane);
     return;
   }
+  // gradient-image replica of this XCD: f32 atomics from different XCDs then never meet on an address
+  int xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  float* gimg_x = a.gimg + (size_t)(xcc & (SF_GCOPIES - 1)) * a.gimg_stride;
   float4* stash = a.act + wid * a.act_per_wave;
   // stash tiles per transform: [0] u_in, [1..HT] h_0, per block k: t1, t2, h_{k+1} (HT each), last: u'
   const int TPT = 2 + (3 * m.NB + 1) * HT;
@@ -513,7 +528,7 @@ __global__ __launch_bounds__(128) void k_nsf_train(SfDev m, SfTrainArgs a) {
   for (int t = m.T - 1; t >= 0; --t) {
     const float* tp = m.packed + (size_t)t * m.t_stride;
     const float* tpT = m.packedT + (size_t)t * m.tT_stride;
-    float* gp = a.gimg + (size_t)t * m.t_stride;
+    float* gp = gimg_x + (size_t)t * m.t_stride;
     const int sb = t * TPT;
     const int D = m.D;
     float up[SF_DMAX], uin[1][SF_DMAX];
