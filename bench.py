@@ -72,7 +72,7 @@ def pmc_traffic():
     """HBM bytes per dense round-0 launch from the committed rocprofv3 PMC passes (profiles/), collected
     with the same command; None when no summary is committed."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary.json")))
     if not files:
         return None, None
     with open(files[-1]) as fh:
