@@ -129,6 +129,13 @@ int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen) {
   add("c_xmean", v.c_xmean); add("c_xstd", v.c_xstd); add("c_dslot", v.c_dslot);
   add("inc_ok", v.inc_ok); add("hidden_bf16", v.hidden_bf16); add("tB_stride", v.tB_stride); add("n_parts", v.n_parts); add("part_max", v.part_max);
   add("n_params", f->L.n_params); add("n_packed", f->L.n_packed);
+  {
+    int R = 0, NV = 0;
+    SfDev vv = v;
+    vv.packed16 = reinterpret_cast<const float*>(1);  // shape query only: as if the 16-row image were fresh
+    sf_ctab_shape(vv, R, NV);
+    add("ctab_floats_per_galaxy", (long)v.T * NV * R);
+  }
   add("m16_ok", v.m16_ok); add("nT16", v.nT16); add("nC16", v.nC16); add("t16_stride", v.t16_stride);
   s += "\"g16_tile\": [";
   for (int i = 0; i < SF_DMAX; ++i) s += std::to_string(v.g16_tile[i]) + (i + 1 < SF_DMAX ? ", " : "], ");

@@ -101,6 +101,10 @@ class FlowPosterior:
         out = torch.empty((N, S, self.spec.D), dtype=torch.float32, device=self.device)
         counts = torch.empty(N, dtype=torch.int32, device=self.device)
         rows_per = max(1, _MAX_SLOTS_PER_CALL // max(S, 1))
+        # keep the per-galaxy context table of a chunk within 2 GiB so that it is always built
+        per_gal = 4 * int(est.flow.describe().get("ctab_floats_per_galaxy", 0))
+        if per_gal > 0:
+            rows_per = max(1, min(rows_per, (2 << 30) // per_gal))
         unfilled = 0
         for r0 in range(0, N, rows_per):
             r1 = min(N, r0 + rows_per)
