@@ -295,15 +295,19 @@ def main():
     barrier_sync(world)
     t_train = max_over_ranks(time.perf_counter() - t0, world, dev)
     pairs = world * tsteps * B / t_train
-    # reference-default batch (64) for comparison, single launch chain per step
-    b64 = torch.randint(0, len(tr), (64,), generator=g2).to(dev)
+    # reference-default batch (64): 200 steps in one library call (what train_flow does per epoch on one device)
+    order64 = torch.randint(0, len(tr), (200 * 64,), generator=g2).to(dev)
+    tl64 = torch.zeros((), dtype=torch.float64, device=dev)
+    flow.train_epoch(flat, Ttr, Xtr, order64, 20, 64, 1.0 / 64, opt2.exp_avg, opt2.exp_avg_sq, opt2.desc, opt2.step_count,
+                     5.0, opt2.scratch, grad, tl64)
+    opt2.step_count += 20
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(50):
-        flow.loss_grad(flat, Ttr[b64], Xtr[b64], 1.0 / 64, grad_out=grad)
-        opt2.step(grad, 5.0)
+    flow.train_epoch(flat, Ttr, Xtr, order64, 200, 64, 1.0 / 64, opt2.exp_avg, opt2.exp_avg_sq, opt2.desc, opt2.step_count,
+                     5.0, opt2.scratch, grad, tl64)
+    opt2.step_count += 200
     torch.cuda.synchronize()
-    pairs64 = 50 * 64 / (time.perf_counter() - t0)
+    pairs64 = 200 * 64 / (time.perf_counter() - t0)
 
     if rank != 0:
         if world > 1:

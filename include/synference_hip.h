@@ -174,6 +174,14 @@ int sf_flow_loss_grad(sf_flow* f, const float* flat /*[P]*/, const float* theta,
                       int64_t B, float grad_scale, float* loss /*[B]*/, float* grad /*[P]*/,
                       void* stream);
 
+/* Same, with the mini-batch gather fused into the kernel: batch row b reads theta[rows[b],:] / x[rows[b],:] of the
+ * training arrays (rows: DEVICE int64 [B]); loss / dctx stay batch-indexed.  loss_sum (may be NULL): DEVICE double,
+ * += sum_b (-log p_b), the epoch loss accumulator of custom_runner.py:608-611 without a per-step reduction. */
+int sf_flow_loss_grad_rows(sf_flow* f, const float* flat, const float* theta /*[N,D]*/, const float* x /*[N,C]*/,
+                           const int64_t* rows /*[B]*/, int64_t B, float grad_scale, const float* weights,
+                           float* loss, double* loss_sum, float* grad, float* dctx, void* stream);
+
+
 /* Same with per-sample weights: grad[i] = sum_b grad_scale * weights[b] * d loss_b / d flat[i]
  * (weights NULL = all ones).  This is the vector-Jacobian product torch.autograd needs for an
  * arbitrary reduction of the per-sample losses.
@@ -202,6 +210,17 @@ int sf_adam_step(sf_opt* o, float* params, const float* grad, float max_norm,
  * torch tensors and checkpoints like the reference's (custom_runner.py:693-704). */
 int sf_adam_apply(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   const sf_adam_desc* d, int64_t step, float max_norm, float* scratch, void* stream);
+
+/* One training epoch on a single device without returning to the host between steps
+ * (ref: the batch loop of custom_runner.py:585-618): for b < n_batches:
+ *   rows = order[b*batch .. (b+1)*batch);  grad = d/dflat sum_rows grad_scale * (-log p);  clip + Adam(W) step
+ *   number step0 + b + 1 on flat (state exp_avg / exp_avg_sq, scratch [2] as in sf_adam_apply).
+ * order: DEVICE int64 [n_batches*batch] (the epoch's shuffled training rows); grad: DEVICE scratch [P].
+ * Data-parallel training keeps using sf_flow_loss_grad_rows + all-reduce + sf_adam_apply per step. */
+int sf_flow_train_epoch(sf_flow* f, float* flat, const float* theta, const float* x, const int64_t* order,
+                        int64_t n_batches, int64_t batch, float grad_scale, float* exp_avg, float* exp_avg_sq,
+                        const sf_adam_desc* d, int64_t step0, float max_norm, float* scratch /*[2]*/,
+                        float* grad /*[P]*/, double* loss_sum, void* stream);
 /* optimizer state access for checkpoints (custom_runner.py:693-704): exp_avg, exp_avg_sq
  * device pointers [n] and the step counter. */
 int sf_opt_state(sf_opt* o, float** exp_avg, float** exp_avg_sq, int64_t** step_host);

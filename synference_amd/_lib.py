@@ -69,6 +69,12 @@ PROTOTYPES = {
                                      C.c_uint64, C.c_void_p, C.c_void_p]),
     "sf_flow_loss_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sf_flow_loss_grad_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                         C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]),
+    "sf_flow_train_epoch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                      C.c_float, C.c_void_p, C.c_void_p, C.POINTER(sf_adam_desc), C.c_int64, C.c_float,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sf_flow_loss_grad_weighted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                              C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p]),

@@ -374,10 +374,45 @@ int sf_flow_loss_grad_weighted(sf_flow* f, const float* flat, const float* theta
   int rc = ensure_device(f);
   if (rc) return rc;
   std::string err;
-  rc = sf_train_loss_grad(f, flat, theta, x, (long)B, grad_scale, weights, loss, grad, dctx, (hipStream_t)stream, err);
+  rc = sf_train_loss_grad(f, flat, theta, x, nullptr, (long)B, grad_scale, weights, loss, nullptr, grad, dctx,
+                          (hipStream_t)stream, err);
   if (rc) return fail(rc, err);
   f->params_set = true;  // the forward image now holds `flat`
   f->ctab_x = nullptr;
+  return SF_OK;
+}
+
+int sf_flow_loss_grad_rows(sf_flow* f, const float* flat, const float* theta, const float* x, const int64_t* rows,
+                           int64_t B, float grad_scale, const float* weights, float* loss, double* loss_sum,
+                           float* grad, float* dctx, void* stream) {
+  if (!f || !flat || !grad) return fail(SF_ERR_INVALID, "null argument");
+  if (B > 0 && (!theta || !x || !rows)) return fail(SF_ERR_INVALID, "null argument");
+  if (B < 0) return fail(SF_ERR_INVALID, "B < 0");
+  int rc = ensure_device(f);
+  if (rc) return rc;
+  std::string err;
+  rc = sf_train_loss_grad(f, flat, theta, x, reinterpret_cast<const long long*>(rows), (long)B, grad_scale, weights, loss,
+                          loss_sum, grad, dctx, (hipStream_t)stream, err);
+  if (rc) return fail(rc, err);
+  f->params_set = true;
+  f->ctab_x = nullptr;
+  return SF_OK;
+}
+
+int sf_flow_train_epoch(sf_flow* f, float* flat, const float* theta, const float* x, const int64_t* order,
+                        int64_t n_batches, int64_t batch, float grad_scale, float* exp_avg, float* exp_avg_sq,
+                        const sf_adam_desc* d, int64_t step0, float max_norm, float* scratch, float* grad,
+                        double* loss_sum, void* stream) {
+  if (!f || !flat || !theta || !x || !order || !exp_avg || !exp_avg_sq || !d || !scratch || !grad)
+    return fail(SF_ERR_INVALID, "null argument");
+  if (n_batches < 0 || batch < 1 || step0 < 0) return fail(SF_ERR_INVALID, "bad n_batches, batch or step0");
+  for (int64_t b = 0; b < n_batches; ++b) {
+    int rc = sf_flow_loss_grad_rows(f, flat, theta, x, order + b * batch, batch, grad_scale, nullptr, nullptr, loss_sum, grad,
+                                    nullptr, stream);
+    if (rc) return rc;
+    rc = sf_adam_apply(flat, grad, exp_avg, exp_avg_sq, f->L.n_params, d, step0 + b + 1, max_norm, scratch, stream);
+    if (rc) return rc;
+  }
   return SF_OK;
 }
 

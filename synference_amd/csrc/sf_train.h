@@ -9,8 +9,8 @@
 struct sf_flow;
 // Forward + backward of -log_prob; lazily builds the transposed operand image, the gradient image
 // and the activation stash on first use.  Returns 0 or a negative sf_status with `err` set.
-int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const float* x, long B,
-                       float grad_scale, const float* weights, float* loss, float* grad, float* dctx,
+int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const float* x, const long long* idx, long B,
+                       float grad_scale, const float* weights, float* loss, double* loss_sum, float* grad, float* dctx,
                        hipStream_t st,
                        std::string& err);
 

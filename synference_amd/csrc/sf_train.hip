@@ -196,8 +196,8 @@ SF_TDECL(1) SF_TDECL(2) SF_TDECL(3) SF_TDECL(4)
     }                                                                        \
   } while (0)
 
-int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const float* x, long B,
-                       float grad_scale, const float* weights, float* loss, float* grad, float* dctx,
+int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const float* x, const long long* idx, long B,
+                       float grad_scale, const float* weights, float* loss, double* loss_sum, float* grad, float* dctx,
                        hipStream_t st, std::string& err) {
   const SfLayout& L = f->L;
   // ---- lazily built training state
@@ -236,7 +236,7 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
   if (L.n_packedB > 0) SF_TRY(sf_launch_pack_bf16(flat, f->d_bsrc, f->d_packedB, (long)L.n_packedB, st));
   if (B > 0) {
     SfTrainArgs a;
-    a.theta = theta; a.x = x; a.B = B; a.w = grad_scale; a.wts = weights; a.loss = loss; a.dctx = dctx; a.gimg = f->d_gpacked; a.gimg_stride = (long)L.n_packed;
+    a.theta = theta; a.x = x; a.idx = idx; a.loss_sum = loss_sum; a.B = B; a.w = grad_scale; a.wts = weights; a.loss = loss; a.dctx = dctx; a.gimg = f->d_gpacked; a.gimg_stride = (long)L.n_packed;
     a.act = reinterpret_cast<float4*>(f->d_act); a.act_per_wave = act_per_wave;
     const SfDev m = f->dev();
     const bool maf = m.kind == SF_MAF;

@@ -10,6 +10,8 @@ struct SfTrainArgs {
   long B;
   float w;           // gradient weight of every sample (grad_scale)
   const float* wts;  // optional per-sample weights [B] (multiplied by w)
+  const long long* idx;  // optional [B]: batch row b reads theta / x row idx[b] (gather fused into the kernel)
+  double* loss_sum;  // optional device scalar: += sum_b loss_b (unweighted), one f64 atomic per tile
   float* loss;       // [B] or null
   float* dctx;       // [B,C] or null: += d(sum_b w_b loss_b)/d x[b,:] (context gradient, raw x units)
   float* gimg;       // gradient image: SF_GCOPIES replicas of gimg_stride floats (one per XCD, summed by the gather)

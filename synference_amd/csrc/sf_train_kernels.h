@@ -226,7 +226,8 @@ __global__ __launch_bounds__(128, 2) void k_maf_train(SfDev m, SfTrainArgs a) {
   const long row = base + c;
   const bool valid = row < a.B;
   const long ii = valid ? row : a.B - 1;
-  const float* xr[1] = {a.x + ii * m.C};
+  const long src = a.idx ? (long)a.idx[ii] : ii;  // library row behind batch row ii
+  const float* xr[1] = {a.x + src * m.C};
   f32x16 ct0[1][1];  // first standardised context tile, reused by every context product and weight gradient
   sf_build_ctx_tile<1>(ct0, xr, m, 0, lane >> 5);
   float u[1][SF_DMAX];
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(128, 2) void k_maf_train(SfDev m, SfTrainArgs a) {
     u[0][p] = 0.f;
     if (p < m.D) {
       const int td = (int)m.cst[m.c_tdim + p];
-      u[0][p] = a.theta[ii * m.D + td] * m.cst[m.c_pscale + p] + m.cst[m.c_pshift + p];
+      u[0][p] = a.theta[src * m.D + td] * m.cst[m.c_pscale + p] + m.cst[m.c_pshift + p];
     }
   }
   using Ops = MafOps<HT, 1>;
@@ -303,8 +304,14 @@ __global__ __launch_bounds__(128, 2) void k_maf_train(SfDev m, SfTrainArgs a) {
         G[p] = w * u[0][p];
       }
     }
-    if (a.loss && valid && h == 0)
-      a.loss[row] = 0.5f * ss + 0.5f * (float)m.D * 1.8378770664093453f - logdet[0];
+    const float nll = 0.5f * ss + 0.5f * (float)m.D * 1.8378770664093453f - logdet[0];
+    if (a.loss && valid && h == 0) a.loss[row] = nll;
+    if (a.loss_sum) {
+      float t = (valid && h == 0) ? nll : 0.f;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+      if (lane == 0) atomicAdd(a.loss_sum, (double)t);
+    }
   }
 
   // ------------------------------------------------------------------ backward
@@ -446,7 +453,8 @@ __global__ __launch_bounds__(128) void k_nsf_train(SfDev m, SfTrainArgs a) {
   const long row = base + c;
   const bool valid = row < a.B;
   const long ii = valid ? row : a.B - 1;
-  const float* xr[1] = {a.x + ii * m.C};
+  const long src = a.idx ? (long)a.idx[ii] : ii;  // library row behind batch row ii
+  const float* xr[1] = {a.x + src * m.C};
   f32x16 ct0[1][1];  // first standardised context tile, reused by every context product and weight gradient
   sf_build_ctx_tile<1>(ct0, xr, m, 0, lane >> 5);
   float u[1][SF_DMAX];
@@ -454,7 +462,7 @@ __global__ __launch_bounds__(128) void k_nsf_train(SfDev m, SfTrainArgs a) {
 #pragma unroll
   for (int p = 0; p < SF_DMAX; ++p) {
     u[0][p] = 0.f;
-    if (p < m.D) u[0][p] = a.theta[ii * m.D + p] * m.cst[m.c_pscale + p] + m.cst[m.c_pshift + p];
+    if (p < m.D) u[0][p] = a.theta[src * m.D + p] * m.cst[m.c_pscale + p] + m.cst[m.c_pshift + p];
   }
   auto store_u = [&](int tile) {
     f32x16 ut;
@@ -520,8 +528,14 @@ __global__ __launch_bounds__(128) void k_nsf_train(SfDev m, SfTrainArgs a) {
         G[p] = w * u[0][p];
       }
     }
-    if (a.loss && valid && h == 0)
-      a.loss[row] = 0.5f * ss + 0.5f * (float)m.D * 1.8378770664093453f - logdet[0];
+    const float nll = 0.5f * ss + 0.5f * (float)m.D * 1.8378770664093453f - logdet[0];
+    if (a.loss && valid && h == 0) a.loss[row] = nll;
+    if (a.loss_sum) {
+      float t = (valid && h == 0) ? nll : 0.f;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+      if (lane == 0) atomicAdd(a.loss_sum, (double)t);
+    }
   }
 
   // ------------------------------------------------------------------ backward

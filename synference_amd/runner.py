@@ -150,6 +150,12 @@ class HipTrainOps:
     def loss_grad(self, flat, theta, x, scale, grad_out):
         return self.flow.loss_grad(flat, theta, x, scale, grad_out=grad_out)[0]
 
+    def train_epoch(self, flat, theta, x, order, n_batches, batch, scale, opt, max_norm, grad, loss_sum):
+        """All steps of an epoch in one library call (no host round trip per step); single device only."""
+        self.flow.train_epoch(flat, theta, x, order, n_batches, batch, scale, opt.exp_avg, opt.exp_avg_sq, opt.desc,
+                              opt.step_count, max_norm if max_norm is not None else 0.0, opt.scratch, grad, loss_sum)
+        opt.step_count += n_batches
+
     def refresh(self, flat):
         self.flow.set_params(flat)
 
@@ -226,6 +232,10 @@ def train_flow(estimator: FlowEstimator, theta: torch.Tensor, x: torch.Tensor, *
                              optimizer_choice == "AdamW")
     grad = torch.empty_like(flat.data)
     gscale = 1.0 / (bs_tr * world)
+    # single device, flow-only parameters, library optimiser: run each epoch's batch loop inside the library
+    fused_epoch = (world == 1 and not embedded and hasattr(ops, "train_epoch") and isinstance(opt, HipAdam)
+                   and theta.dtype == torch.float32 and x.dtype == torch.float32
+                   and theta.is_contiguous() and x.is_contiguous())
 
     best_val, since, best_state = float("inf"), 0, None
     train_log, val_log, epoch = [], [], 0
@@ -251,13 +261,17 @@ def train_flow(estimator: FlowEstimator, theta: torch.Tensor, x: torch.Tensor, *
         # ---- train: fresh random order of this rank's shard (SubsetRandomSampler)
         order = tr_idx[torch.randperm(n_tr, generator=gen).to(dev)]
         tl = torch.zeros((), dtype=torch.float64, device=dev)
-        for b in range(nb_tr):
-            idx = order[b * bs_tr:(b + 1) * bs_tr]
-            loss = ops.loss_grad(flat.data, theta[idx], x[idx], gscale, grad)
-            if world > 1 and not embedded:
-                dist.all_reduce(grad, op=dist.ReduceOp.SUM)
-            opt.step(grad, clip_max_norm)
-            tl += loss.double().sum()
+        if fused_epoch:
+            # the whole batch loop in one library call: row gather fused into the kernel, loss summed on the device
+            ops.train_epoch(flat.data, theta, x, order.contiguous(), nb_tr, bs_tr, gscale, opt, clip_max_norm, grad, tl)
+        else:
+            for b in range(nb_tr):
+                idx = order[b * bs_tr:(b + 1) * bs_tr]
+                loss = ops.loss_grad(flat.data, theta[idx], x[idx], gscale, grad)
+                if world > 1 and not embedded:
+                    dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+                opt.step(grad, clip_max_norm)
+                tl += loss.double().sum()
         rows_seen += nb_tr * bs_tr * world
         epoch += 1
         # ---- validate (no_grad): raw per-sample losses under the updated parameters

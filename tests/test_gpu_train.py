@@ -183,3 +183,68 @@ def test_hip_fcn_embedding_in_front_of_the_flow_end_to_end():
     assert s.shape == (8, 64, 5) and np.isfinite(s).all()
     lp = f.log_prob(f._X_test[:8], f._y_test[:8], norm_posterior=False)
     assert np.isfinite(lp).all()
+
+
+@pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3"])
+def test_fused_epoch_equals_the_per_step_loop(name):
+    """sf_flow_train_epoch (row gather fused into the kernel, loss summed on the device, no host round trip per
+    step) reproduces the per-step path: loss_grad on gathered rows + clip + Adam.  f32 atomics may reorder sums."""
+    from synference_amd.engine import HipFlow
+    from synference_amd.runner import HipAdam, HipTrainOps
+    ospec, spec, flat0, theta, x = make_case(name, B=900)
+    dev = torch.device("cuda:0")
+    T = torch.as_tensor(theta, dtype=torch.float32, device=dev).contiguous()
+    X = torch.as_tensor(x, dtype=torch.float32, device=dev).contiguous()
+    g = torch.Generator().manual_seed(3)
+    order = torch.randperm(900, generator=g).to(dev)
+    nb, bs = 7, 96                                   # ragged: 96 is not a multiple of the 32-row tile... it is; 7*96 < 900
+
+    def run(fused):
+        f = HipFlow(spec, dev)
+        flat = torch.as_tensor(flat0, dtype=torch.float32, device=dev).clone()
+        opt = HipAdam(flat, lr=3e-3)
+        grad = torch.empty_like(flat)
+        tl = torch.zeros((), dtype=torch.float64, device=dev)
+        if fused:
+            class E:  # minimal estimator stand-in for HipTrainOps
+                flow = f
+            HipTrainOps(E).train_epoch(flat, T, X, order, nb, bs, 1.0 / bs, opt, 5.0, grad, tl)
+        else:
+            for b in range(nb):
+                idx = order[b * bs:(b + 1) * bs]
+                loss, _ = f.loss_grad(flat, T[idx], X[idx], 1.0 / bs, grad_out=grad)
+                opt.step(grad, 5.0)
+                tl += loss.double().sum()
+        return flat.cpu().double().numpy(), float(tl.item()), opt.step_count
+
+    fa, la, sa = run(False)
+    fb, lb, sb = run(True)
+    assert sa == sb == nb
+    assert abs(la - lb) < 1e-3 * max(1.0, abs(la)), (la, lb)
+    assert np.abs(fa - np.asarray(flat0, dtype=np.float64)).max() > 1e-3       # the parameters really moved
+    assert np.abs(fa - fb).max() < 2e-4, np.abs(fa - fb).max()
+
+
+def test_loss_grad_rows_equals_gathered_loss_grad():
+    import ctypes as C
+    from synference_amd import _lib
+    from synference_amd.engine import HipFlow
+    ospec, spec, flat0, theta, x = make_case("nsf_odd", B=300)
+    dev = torch.device("cuda:0")
+    f = HipFlow(spec, dev)
+    flat = torch.as_tensor(flat0, dtype=torch.float32, device=dev)
+    T = torch.as_tensor(theta, dtype=torch.float32, device=dev).contiguous()
+    X = torch.as_tensor(x, dtype=torch.float32, device=dev).contiguous()
+    rows = torch.tensor([5, 299, 0, 17, 17, 123] * 9 + [42], device=dev, dtype=torch.int64)   # duplicates, B = 55 (ragged)
+    B = rows.numel()
+    loss_ref, grad_ref = f.loss_grad(flat, T[rows], X[rows], 1.0 / B)
+    grad_ref = grad_ref.clone()
+    loss = torch.empty(B, device=dev); grad = torch.empty_like(flat)
+    lsum = torch.zeros((), dtype=torch.float64, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(_lib.load().sf_flow_loss_grad_rows(f.handle, p(flat), p(T), p(X), p(rows), B, C.c_float(1.0 / B), None,
+                                                  p(loss), p(lsum), p(grad), None, st))
+    assert torch.allclose(loss, loss_ref, atol=1e-6)
+    assert abs(float(lsum.item()) - float(loss_ref.double().sum().item())) < 1e-3
+    assert (grad - grad_ref).abs().max().item() < 1e-5 * max(1.0, grad_ref.abs().max().item())
