@@ -64,7 +64,7 @@ static int ensure_device(sf_flow* f) {
 extern "C" {
 
 const char* sf_last_error(void) { return g_err.c_str(); }
-const char* sf_version(void) { return "synference_hip 0.1 (gfx950, mfma_f32_32x32x2)"; }
+const char* sf_version(void) { return "synference_hip 0.2 (gfx950; mfma_f32_32x32x2 / 16x16x4)"; }
 int sf_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -1,6 +1,8 @@
-// sf_inst_templates.h -- gfx950 kernel templates of the inference direction (log_prob, inverse,
-// sampler).  One wave handles NS tiles of 32 samples end to end; waves are
-// independent (no LDS, no barriers); weights stream from L2 in the MFMA operand image.
+// sf_inst_templates.h -- gfx950 kernel templates of the inference direction on the 32-row register-tile engine
+// (log_prob, inverse, sampler, NSF context table).  One wave handles NS tiles of 32 samples end to end.
+// LDSW = true: the workgroup stages one transform's operand image in LDS per transform (two barriers) and the
+// waves read their MFMA A fragments from there; LDSW = false: waves are independent and weights stream from L2.
+// The default MAF sampler is the 16-row kernel in sf_maf16.hip; k_inverse<MafOps> is its fallback.
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -1,0 +1,49 @@
+"""The C ABI driven from a plain C program (no Python objects, no torch tensors in the signatures): the drop-in
+boundary a maintainer's FFI would bind (include/synference_hip.h)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from cases import make_case, oracle_log_prob
+from oracle import posterior as OP
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3"])
+def test_c_program_through_the_abi_matches_the_oracle(name, tmp_path):
+    exe = tmp_path / "sf_c_client"
+    lib = os.path.join(ROOT, "synference_amd", "lib")
+    # plain gcc: the program only needs the two C headers and the two shared libraries
+    subprocess.run(["gcc", "-std=c11", "-O1", os.path.join(ROOT, "tests", "c_client", "sf_c_client.c"),
+                    "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", os.path.join(ROOT, "include"),
+                    "-L", lib, "-lsynference_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                    f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True, capture_output=True)
+    ospec, spec, flat, theta, x = make_case(name, B=40, spread=0.2)
+    S, seed = 64, 77
+    free, _ = OP.sample(ospec, torch.as_tensor(flat), x, 300, 5, dtype=torch.float32)
+    lo = np.quantile(free.reshape(-1, spec.D), 0.03, axis=0).astype(np.float32)
+    hi = np.quantile(free.reshape(-1, spec.D), 0.97, axis=0).astype(np.float32)
+    kind = 0 if spec.kind == "maf" else 1
+    hdr = np.array([kind, spec.D, spec.C, spec.H, spec.T, spec.K, spec.NB, len(theta), S, len(flat), seed], dtype=np.int32)
+    with open(tmp_path / "in.bin", "wb") as fh:
+        for a in (hdr, spec.theta_mean, spec.theta_std, spec.x_mean, spec.x_std, spec.perms.astype(np.int32),
+                  np.asarray(flat, np.float32), np.asarray(theta, np.float32), np.asarray(x, np.float32), lo, hi):
+            fh.write(np.ascontiguousarray(a).tobytes())
+    r = subprocess.run([str(exe), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "unfilled=0" in r.stdout
+    raw = np.fromfile(tmp_path / "out.bin", dtype=np.float32)
+    B, D = len(theta), spec.D
+    lp, s = raw[:B].astype(np.float64), raw[B:B + B * S * D].reshape(B, S, D).astype(np.float64)
+    nd = raw[B + B * S * D:].view(np.int32)
+    assert np.abs(lp - oracle_log_prob(ospec, flat, theta, x, torch.float64)).max() < 1e-4
+    ref, rnd = OP.sample(ospec, torch.as_tensor(flat), x, S, seed, lo, hi, dtype=torch.float32)
+    err = np.abs((s - ref) / (hi - lo)).max(-1)
+    assert (err > 5e-4).mean() < 5e-3                       # boundary accept/reject flips only
+    assert ((s >= lo) & (s <= hi)).all() and (nd >= S).all()
+    assert np.abs(nd - rnd).sum() <= max(3, 0.01 * rnd.sum())
