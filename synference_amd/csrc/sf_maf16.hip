@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16(SfDev m, SfSampleArgsHost 
       const int rho = ic * 16 + 4 * g4 + r;
       const bool ok = rho < m.C;
       const int rr = ok ? rho : 0;
-      const float v = (xr[rr] - m.cst[m.c_xmean + rr]) / m.cst[m.c_xstd + rr];
+      const float v = sf_div(xr[rr] - m.cst[m.c_xmean + rr], m.cst[m.c_xstd + rr]);
       ct[r] = ok ? v : 0.f;
     }
     return ct;
@@ -163,6 +163,15 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16(SfDev m, SfSampleArgsHost 
   if (!ctg) ct0 = ctx_tile(0);
 
   const int NT = m.nT16;
+  // activation tiles of the three layers: a pass only reads tiles that an earlier pass of the SAME transform has
+  // written (tile index <= its own), so they are cleared once, not per transform
+  SfPass16 S;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S.act[k][ot][r] = 0.f;
   uint32_t tile_bits = 0;  // g16_tile packed 2 bits per degree (static indexing keeps the argument in SGPRs)
 #pragma unroll
   for (int q = 0; q < SF_DMAX; ++q) tile_bits |= (uint32_t)(m.g16_tile[q] & 3) << (2 * q);
@@ -184,7 +193,6 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16(SfDev m, SfSampleArgsHost 
     }
     __syncthreads();
     const float* tp = sf_lds16;
-    SfPass16 S;
     // context product hoisted out of the passes: c0 = b0 + bc + Wc e
     if (ctg) {  // per-galaxy table (sf_flow_prepare_context): same values, computed once per galaxy
 #pragma unroll
@@ -204,12 +212,6 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16(SfDev m, SfSampleArgsHost 
           if (ot < NT) S.c0[ot] = sf_mma16(sf_w16(tp + m.o16_wc, m.nC16, ot, ic, lane), ct, S.c0[ot]);
       }
     }
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-      for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) S.act[k][ot][r] = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) S.ut[r] = 0.f;
     S.ldl = 0.f;
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16(SfDev m, SfSampleArgsHost 
     th[r] = 0.f;
     if (p < m.D) {
       const int td = (int)m.cst[m.c_tdim + p];
-      th[r] = (u[r] - m.cst[m.c_pshift + p]) / m.cst[m.c_pscale + p];
+      th[r] = sf_div(u[r] - m.cst[m.c_pshift + p], m.cst[m.c_pscale + p]);
       ok = ok && (fabsf(th[r]) <= 3.0e38f);  // finite (NaN compares false)
       if (a.lo) ok = ok && (th[r] >= a.lo[td]) && (th[r] <= a.hi[td]);
     }
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(256) void k_maf_ctab16(SfDev m, const float* __rest
         const int rho = ic * 16 + 4 * g4 + r;
         const bool ok = rho < m.C;
         const int rr = ok ? rho : 0;
-        const float v = (xr[rr] - m.cst[m.c_xmean + rr]) / m.cst[m.c_xstd + rr];
+        const float v = sf_div(xr[rr] - m.cst[m.c_xmean + rr], m.cst[m.c_xstd + rr]);
         ct[r] = ok ? v : 0.f;
       }
 #pragma unroll

@@ -32,11 +32,11 @@ __device__ __forceinline__ void sf_normal4(uint32_t k0, uint32_t k1, uint64_t sl
   sf_philox4x32_10((uint32_t)slot, (uint32_t)(slot >> 32), attempt, blk, k0, k1, r);
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    const float rad = sqrtf(-2.0f * logf(sf_u01(r[2 * q])));
-    const float ang = 6.2831855f * sf_u01(r[2 * q + 1]);
-    float sn, cs;
-    sincosf(ang, &sn, &cs);
-    z[2 * q] = rad * cs;
-    z[2 * q + 1] = rad * sn;
+    // hardware forms: v_log_f32 (log2), v_sqrt_f32, and v_sin/v_cos_f32, which take the angle in turns -- the
+    // uniform itself, no 2 pi multiply and no range reduction (|dz| <~ 1e-6 against libm; the oracle uses libm)
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(sf_u01(r[2 * q])));
+    const float turn = sf_u01(r[2 * q + 1]);
+    z[2 * q] = rad * __builtin_amdgcn_cosf(turn);
+    z[2 * q + 1] = rad * __builtin_amdgcn_sinf(turn);
   }
 }
