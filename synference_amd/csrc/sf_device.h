@@ -70,26 +70,19 @@ __device__ __forceinline__ const float* sf_stage_part(const SfDev& m, int t, int
   const float4* __restrict__ s4 = reinterpret_cast<const float4*>(src + lo);
   float4* __restrict__ d4 = reinterpret_cast<float4*>(lds);
   const int n4 = (hi - lo) >> 2;
-  // 8 loads in flight per thread: the CU has nothing else to run during staging (one workgroup per CU)
-  for (int b0 = threadIdx.x; b0 < n4; b0 += blockDim.x * 8) {
-    float4 tmp[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int i = b0 + k * blockDim.x;
-      tmp[k] = s4[i < n4 ? i : b0];
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int i = b0 + k * blockDim.x;
-      if (i < n4) d4[i] = tmp[k];
-    }
-  }
+  // direct global -> LDS copies (global_load_lds_dwordx4): no staging registers, no ds_write; the LDS destination of
+  // a wave-instruction is its (wave-uniform) base + lane * 16 bytes
+  const int lane_ = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < n4; i += blockDim.x)
+    __builtin_amdgcn_global_load_lds((const void*)(s4 + i), (void __attribute__((address_space(3)))*)(d4 + (i - lane_)), 16, 0, 0);
   if (m.hidden_bf16) {  // single-part images only (sf_layout.cpp): bf16 hidden operands right behind the fp32 image
     const uint4* __restrict__ sb = reinterpret_cast<const uint4*>(m.packedB + (size_t)t * m.tB_stride);
     uint4* __restrict__ db = reinterpret_cast<uint4*>(lds + m.t_stride);
     const int nb = m.tB_stride >> 3;
-    for (int i = threadIdx.x; i < nb; i += blockDim.x) db[i] = sb[i];
+    for (int i = threadIdx.x; i < nb; i += blockDim.x)
+      __builtin_amdgcn_global_load_lds((const void*)(sb + i), (void __attribute__((address_space(3)))*)(db + (i - lane_)), 16, 0, 0);
   }
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the copies have landed
   __syncthreads();
   return lds - lo + sf_opaque_zero();  // so that (returned + block offset) lands inside the staged part
 }

@@ -176,20 +176,19 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16(SfDev m, SfSampleArgsHost 
 #pragma unroll
   for (int q = 0; q < SF_DMAX; ++q) tile_bits |= (uint32_t)(m.g16_tile[q] & 3) << (2 * q);
   for (int t = m.T - 1; t >= 0; --t) {
-    // ---- stage this transform's 16-row image (8 loads in flight per thread)
+    // ---- stage this transform's 16-row image (direct-to-LDS loads)
     __syncthreads();
     {
       const float4* __restrict__ s4 = reinterpret_cast<const float4*>(m.packed16 + (size_t)t * m.t16_stride);
       float4* __restrict__ d4 = reinterpret_cast<float4*>(sf_lds16);
       const int n4 = m.t16_stride >> 2;
-      for (int i = threadIdx.x; i < n4; i += 8 * 256) {
-        float4 v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = s4[i + j * 256 < n4 ? i + j * 256 : i];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (i + j * 256 < n4) d4[i + j * 256] = v[j];
-      }
+      // direct global -> LDS copies (global_load_lds_dwordx4): no staging registers, no ds_write; the LDS
+      // destination of a wave-instruction is its (wave-uniform) base + lane * 16 bytes
+      const int lane_ = threadIdx.x & 63;
+      for (int i = threadIdx.x; i < n4; i += 256)
+        __builtin_amdgcn_global_load_lds((const void*)(s4 + i),
+                                         (void __attribute__((address_space(3)))*)(d4 + (i - lane_)), 16, 0, 0);
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0), other counters untouched: the copies have landed
     }
     __syncthreads();
     const float* tp = sf_lds16;
