@@ -14,12 +14,14 @@ done
 python3 - "$RAW" "$TAG" <<'PY' | tee gpurun_out/pmc_train_$1.txt
 import csv, glob, sys, collections
 raw, tag = sys.argv[1], sys.argv[2]
-acc = collections.defaultdict(list); name = None
+acc = collections.defaultdict(list); name = None; durs = []
 for f in glob.glob(raw + '/p*/*/*_counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         if '_train' in r['Kernel_Name']:
             acc[r['Counter_Name']].append(float(r['Counter_Value'])); name = r['Kernel_Name']
+            durs.append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
             regs = (r.get('VGPR_Count'), r.get('Accum_VGPR_Count'), r.get('LDS_Block_Size'), r.get('Scratch_Size'), r['Grid_Size'], r['Workgroup_Size'])
 print(tag, name, 'vgpr/agpr/lds/scratch/grid/wg', regs)
+print(f"{'kernel_us_under_pmc':32s} {sum(durs)/len(durs):16.1f}  n={len(durs)}")
 for k in sorted(acc): print(f"{k:32s} {sum(acc[k])/len(acc[k]):16.0f}  n={len(acc[k])}")
 PY
