@@ -99,6 +99,11 @@ int64_t sf_flow_packed_size(const sf_flow* f);
  * Replaces: estimator.load_state_dict (custom_runner.py:563, 709). */
 int sf_flow_set_params(sf_flow* f, const float* flat, int64_t n, int is_device, void* stream);
 
+/* Copies the logical vector last given to sf_flow_set_params back out (host or device destination).
+ * SF_ERR_STATE after sf_flow_loss_grad*: during training the caller's vector is the master copy.
+ * Replaces: estimator.state_dict() (custom_runner.py:658). */
+int sf_flow_get_params(sf_flow* f, float* flat, int64_t n, int is_device, void* stream);
+
 /* Host-only helpers (no GPU needed; used by the CPU test-suite):
  * src1/src2[i] = logical index feeding packed float i (or -1); packed = sum of both. */
 int sf_flow_pack_table(const sf_flow* f, int32_t* src1, int32_t* src2, int64_t n_packed);

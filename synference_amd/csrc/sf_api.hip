@@ -163,17 +163,28 @@ int sf_flow_set_params(sf_flow* f, const float* flat, int64_t n, int is_device, 
   int rc = ensure_device(f);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  const float* src = flat;
-  if (!is_device) {
-    SF_HIP(hipMemcpyAsync(f->d_flat, flat, (size_t)n * sizeof(float), hipMemcpyHostToDevice, st));
-    src = f->d_flat;
-  }
+  // the handle keeps its own copy of the logical vector (sf_flow_get_params)
+  SF_HIP(hipMemcpyAsync(f->d_flat, flat, (size_t)n * sizeof(float), is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+  const float* src = f->d_flat;
+  f->flat_valid = true;
   SF_HIP(sf_launch_pack(src, f->d_s1, f->d_s2, f->d_packed, (long)f->L.n_packed, st));
   if (f->d_packed16) SF_HIP(sf_launch_pack(src, f->d_s16a, f->d_s16b, f->d_packed16, (long)f->L.n_packed16, st));
   f->packed16_stale = false;
   if (f->L.n_packedB > 0) SF_HIP(sf_launch_pack_bf16(src, f->d_bsrc, f->d_packedB, (long)f->L.n_packedB, st));
   f->params_set = true;
   f->ctab_x = nullptr;  // a context table built from the old parameters is stale
+  return SF_OK;
+}
+
+int sf_flow_get_params(sf_flow* f, float* flat, int64_t n, int is_device, void* stream) {
+  if (!f || !flat) return fail(SF_ERR_INVALID, "null argument");
+  if (n != f->L.n_params) return fail(SF_ERR_INVALID, "parameter count mismatch");
+  if (!f->params_set || !f->flat_valid)
+    return fail(SF_ERR_STATE, "no parameters held by the handle: after sf_flow_loss_grad the caller's vector is the master copy "
+                              "(call sf_flow_set_params first)");
+  hipStream_t st = (hipStream_t)stream;
+  SF_HIP(hipMemcpyAsync(flat, f->d_flat, (size_t)n * sizeof(float), is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+  if (!is_device) SF_HIP(hipStreamSynchronize(st));
   return SF_OK;
 }
 
@@ -378,6 +389,7 @@ int sf_flow_loss_grad_weighted(sf_flow* f, const float* flat, const float* theta
                           (hipStream_t)stream, err);
   if (rc) return fail(rc, err);
   f->params_set = true;  // the forward image now holds `flat`
+  f->flat_valid = false; // ... but the handle's own copy of the logical vector does not
   f->ctab_x = nullptr;
   return SF_OK;
 }
@@ -395,6 +407,7 @@ int sf_flow_loss_grad_rows(sf_flow* f, const float* flat, const float* theta, co
                           loss_sum, grad, dctx, (hipStream_t)stream, err);
   if (rc) return fail(rc, err);
   f->params_set = true;
+  f->flat_valid = false;
   f->ctab_x = nullptr;
   return SF_OK;
 }

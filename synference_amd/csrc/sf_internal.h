@@ -48,6 +48,7 @@ struct sf_flow {
   SfLayout L;
   bool dev_ready = false;
   bool params_set = false;
+  bool flat_valid = false;      // d_flat holds the vector last given to sf_flow_set_params
   float* d_packed = nullptr;    // forward operand image
   float* d_packedT = nullptr;   // transposed operand image (training, lazily built)
   float* d_cst = nullptr;

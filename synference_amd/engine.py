@@ -99,6 +99,13 @@ class HipFlow:
         flat = _f32c(flat, self.device)
         _lib.check(self.lib.sf_flow_set_params(self.handle, _ptr(flat), flat.numel(), 1, _stream(self.device)))
 
+    def get_params(self) -> torch.Tensor:
+        """The logical parameter vector held by the handle (device tensor)."""
+        self._dev()
+        out = torch.empty(num_params(self.spec), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.sf_flow_get_params(self.handle, _ptr(out), out.numel(), 1, _stream(self.device)))
+        return out
+
     def log_prob(self, theta, x) -> torch.Tensor:
         self._dev()
         theta, x = _f32c(theta, self.device), _f32c(x, self.device)

@@ -191,3 +191,15 @@ def test_bf16_mode_leaves_training_in_fp32():
     rloss, rgrad = oracle_loss_grad(ospec, flat, theta, x)
     assert np.abs(loss.cpu().double().numpy() - rloss).max() < 1e-4
     assert np.abs(grad.cpu().double().numpy() - rgrad).max() < 2e-4 * np.abs(rgrad).max()
+
+
+def test_get_params_round_trip_and_state_error():
+    ospec, spec, flat, theta, x = make_case("nsf_odd", B=40)
+    f = _flow(spec, flat)
+    got = f.get_params().cpu().numpy()
+    assert np.array_equal(got, np.asarray(flat, dtype=np.float32))
+    f.loss_grad(torch.as_tensor(flat), theta, x, 1.0 / 40)
+    with pytest.raises(RuntimeError, match="master copy"):
+        f.get_params()
+    f.set_params(torch.as_tensor(flat) * 0.5)
+    assert np.allclose(f.get_params().cpu().numpy(), 0.5 * np.asarray(flat, dtype=np.float32))
