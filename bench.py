@@ -217,38 +217,23 @@ def main():
     X = torch.as_tensor(x_test).to(dev)
     M, S = X.shape[0], a.draws
     out = torch.empty((M, S, D), dtype=torch.float32, device=dev)
-    rej = [torch.empty(M * S, dtype=torch.int32, device=dev) for _ in range(2)]
-    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps)]
+    dense_ms = []
     drawn = [0]
     rounds = [0]
     rej0 = [0]
 
     def sample_step(k, timed):
-        """sample_posterior over the catalogue: dense round 0 + retry rounds until every slot is filled."""
-        seed = 1000 + k
-        pending, cur, attempt, r = M * S, None, 0, 0
-        flow.prepare_context(X)   # per-galaxy context products (part of the timed work)
-        while pending > 0 and attempt < 64:
-            A = retry_width(pending, attempt, 64, M * S)
-            cnt.zero_()
-            if timed and attempt == 0:
-                ev0[k].record()
-            flow.sample_round(X, S, cur, 0, pending, attempt, seed, lo, hi, out, rej[r & 1], cnt,
-                              attempts_per_slot=A)
-            if timed and attempt == 0:
-                ev1[k].record()
-            drawn[0] += pending * A
-            rounds[0] += 1
-            pending = int(cnt.item())
-            if attempt == 0:
-                rej0[0] += pending
-            cur = rej[r & 1]
-            attempt += A
-            r += 1
-        flow.release_context()
-        return pending
+        """sample_posterior over the catalogue through the library's own sampler (sf_flow_sample): per-galaxy context
+        table, dense round 0, retry rounds until every slot is filled -- exactly what FlowPosterior.sample_catalogue
+        runs.  The library brackets round 0 with HIP events on this stream (sf_flow_sample_stats)."""
+        flow.sample(X, S, lo, hi, seed=1000 + k, max_attempts=64, out=out)
+        st = flow.last_sample_stats
+        if timed:
+            dense_ms.append(st["dense_ms"])
+        drawn[0] += st["evaluations"]
+        rounds[0] += st["rounds"]
+        rej0[0] += st["rejected_round0"]
+        return flow.last_unfilled
 
     for k in range(a.warmup):
         sample_step(0, False)
@@ -262,7 +247,7 @@ def main():
         unfilled += sample_step(k, True)
     barrier_sync(world)
     t_samp = max_over_ranks(time.perf_counter() - t0, world, dev)
-    k0_ms = float(np.mean([ev0[k].elapsed_time(ev1[k]) for k in range(a.steps)]))
+    k0_ms = float(np.mean(dense_ms))
     accept = 1.0 - rej0[0] / float(a.steps * M * S)
     value = world * a.steps * (M * S - 0) / t_samp
     flops_launch = wl["f_draw"] * M * S   # the per-galaxy part (f_gal * M) runs once per step in the context-table kernel

@@ -161,6 +161,10 @@ int sf_flow_sample(sf_flow* f, const float* x /*[M,C]*/, int64_t M, int64_t S,
                    float* out /*[M,S,D]*/, int32_t* n_drawn /*[M]*/, int64_t* n_unfilled /*host*/,
                    void* stream);
 
+/* Figures of the last sf_flow_sample call (host [4]): duration of its dense round 0 in ms (HIP events on the call's
+ * stream), number of rounds, slots rejected by round 0, flow evaluations over all rounds. */
+int sf_flow_sample_stats(const sf_flow* f, float* stats4);
+
 /* Accepted fraction of n unconstrained draws per row (stream_id 1): count[g] of n.
  * Replaces: DirectPosterior.leakage_correction (custom_runner.py:466-473). */
 int sf_flow_acceptance(sf_flow* f, const float* x /*[M,C]*/, int64_t M, int64_t n,

@@ -66,6 +66,7 @@ PROTOTYPES = {
     "sf_flow_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                  C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64),
                                  C.c_void_p]),
+    "sf_flow_sample_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "sf_flow_acceptance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                      C.c_uint64, C.c_void_p, C.c_void_p]),
     "sf_flow_loss_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,

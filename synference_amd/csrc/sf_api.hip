@@ -56,7 +56,10 @@ static int ensure_device(sf_flow* f) {
     SF_HIP(hipMemcpy(f->d_bsrc, f->L.srcB.data(), (size_t)f->L.n_packedB * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   SF_HIP(hipMalloc(&f->d_flat, (size_t)f->L.n_params * sizeof(float)));
-  SF_HIP(hipMalloc(&f->d_cnt, 4 * sizeof(uint32_t)));
+  SF_HIP(hipMalloc(&f->d_cnt, SF_MAX_ROUNDS * sizeof(uint32_t)));
+  SF_HIP(hipHostMalloc((void**)&f->h_cnt, SF_MAX_ROUNDS * sizeof(uint32_t), hipHostMallocDefault));
+  SF_HIP(hipEventCreate(&f->ev_dense[0]));
+  SF_HIP(hipEventCreate(&f->ev_dense[1]));
   f->dev_ready = true;
   return SF_OK;
 }
@@ -89,6 +92,7 @@ void sf_flow_destroy(sf_flow* f) {
   if (!f) return;
   if (f->dev_ready) {
     (void)hipFree(f->d_packed); (void)hipFree(f->d_packedT); (void)hipFree(f->d_cst); (void)hipFree(f->d_packedB); (void)hipFree(f->d_bsrc);
+    (void)hipHostFree(f->h_cnt); if (f->ev_dense[0]) (void)hipEventDestroy(f->ev_dense[0]); if (f->ev_dense[1]) (void)hipEventDestroy(f->ev_dense[1]);
     (void)hipFree(f->d_ctab); (void)hipFree(f->d_packed16); (void)hipFree(f->d_s16a); (void)hipFree(f->d_s16b);
     (void)hipFree(f->d_s1); (void)hipFree(f->d_s2); (void)hipFree(f->d_t1); (void)hipFree(f->d_t2);
     (void)hipFree(f->d_flat); (void)hipFree(f->d_gpacked); (void)hipFree(f->d_gdst);
@@ -326,31 +330,50 @@ int sf_flow_sample(sf_flow* f, const float* x, int64_t M, int64_t S, const float
   const uint32_t* cur = nullptr;
   int buf = 0;
   int attempt = 0;
+  int round = 0;
+  double items = 0.0;
+  float rej0 = 0.f;
+  SF_HIP(hipMemsetAsync(f->d_cnt, 0, SF_MAX_ROUNDS * sizeof(uint32_t), st));  // one counter per round
   while (attempt < max_attempts && pending > 0) {
-    // round 0: one attempt per slot; retry rounds: several attempts per pending slot so that the
-    // (latency-bound) tail needs only a few launches
+    // round 0: one attempt per slot; retry rounds: several attempts per pending slot (at most 16: the 16-row
+    // kernel resolves a slot inside one 16-draw tile) so that the tail needs only a few launches; the
+    // speculation budget is the work a latency-bound round can absorb
     int A = 1;
     if (attempt > 0) {
-      // speculation budget ~ the work one latency-bound round could do anyway (measured: a round of
-      // ~2.6e5 items costs the same 0.5-1.1 ms as a round of 1 item)
       const int64_t budget = 262144;
       while (A < 16 && (int64_t)(2 * A) * pending <= budget && attempt + 2 * A <= max_attempts) A *= 2;
     }
-    SF_HIP(hipMemsetAsync(f->d_cnt, 0, sizeof(uint32_t), st));
+    uint32_t* cnt = f->d_cnt + (round % SF_MAX_ROUNDS);
+    if (round > 0 && round % SF_MAX_ROUNDS == 0) SF_HIP(hipMemsetAsync(f->d_cnt, 0, SF_MAX_ROUNDS * sizeof(uint32_t), st));
+    if (round == 0) SF_HIP(hipEventRecord(f->ev_dense[0], st));
     int rc = sf_flow_sample_round(f, x, S, cur, 0, pending, (uint32_t)attempt, A, seed, 0, lo, hi, out,
-                                  f->d_rej[buf], f->d_cnt, n_drawn, stream);
+                                  f->d_rej[buf], cnt, n_drawn, stream);
     if (rc) { f->ctab_x = nullptr; return rc; }
-    uint32_t nrej = 0;
-    SF_HIP(hipMemcpyAsync(&nrej, f->d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    if (round == 0) SF_HIP(hipEventRecord(f->ev_dense[1], st));
+    SF_HIP(hipMemcpyAsync(f->h_cnt, cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, st));  // pinned: no staging copy
     SF_HIP(hipStreamSynchronize(st));
-    pending = nrej;
+    items += (double)pending * A;
+    pending = f->h_cnt[0];
+    if (round == 0) rej0 = (float)pending;
     cur = f->d_rej[buf];
     buf ^= 1;
     attempt += A;
+    ++round;
+  }
+  {
+    float ms = 0.f;
+    if (round > 0 && hipEventElapsedTime(&ms, f->ev_dense[0], f->ev_dense[1]) != hipSuccess) ms = 0.f;
+    f->last_stats[0] = ms; f->last_stats[1] = (float)round; f->last_stats[2] = rej0; f->last_stats[3] = (float)items;
   }
   f->ctab_x = nullptr;
   if (pending > 0) SF_HIP(sf_launch_fill_nan_rows(out, cur, (long)pending, f->L.dev.D, st));
   if (n_unfilled) *n_unfilled = pending;
+  return SF_OK;
+}
+
+int sf_flow_sample_stats(const sf_flow* f, float* stats4) {
+  if (!f || !stats4) return fail(SF_ERR_INVALID, "null argument");
+  for (int i = 0; i < 4; ++i) stats4[i] = f->last_stats[i];
   return SF_OK;
 }
 

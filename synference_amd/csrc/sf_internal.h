@@ -44,6 +44,7 @@ hipError_t sf_launch_fill_i32(int32_t* p, long n, int32_t v, hipStream_t st);
 void sf_set_error(const std::string& msg);  // thread-local message behind sf_last_error()
 
 // ---- the handle (shared by sf_api.hip and sf_train.hip) -------------------------------------
+#define SF_MAX_ROUNDS 80
 struct sf_flow {
   SfLayout L;
   bool dev_ready = false;
@@ -65,7 +66,10 @@ struct sf_flow {
   size_t act_cap = 0;           // floats
   uint32_t* d_rej[2] = {nullptr, nullptr};
   size_t rej_cap = 0;
-  uint32_t* d_cnt = nullptr;
+  uint32_t* d_cnt = nullptr;     // SF_MAX_ROUNDS rejected-slot counters (one per round of a sf_flow_sample call)
+  uint32_t* h_cnt = nullptr;     // pinned host mirror for the per-round read-back
+  hipEvent_t ev_dense[2] = {nullptr, nullptr};  // brackets round 0 of the last sf_flow_sample call
+  float last_stats[4] = {0.f, 0.f, 0.f, 0.f};   // dense-round ms, rounds, rejected after round 0, items evaluated
   float* d_ctab = nullptr;       // per-galaxy context table (sf_flow_prepare_context)
   size_t ctab_cap = 0;           // floats
   const float* ctab_x = nullptr; // context rows the table was built from (NULL = no valid table)

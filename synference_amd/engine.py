@@ -147,6 +147,9 @@ class HipFlow:
                                            C.c_uint64(seed & (2 ** 64 - 1)), max_attempts, _ptr(out), _ptr(nd),
                                            C.byref(unfilled), _stream(self.device)))
         self.last_unfilled = int(unfilled.value)
+        st4 = (C.c_float * 4)()
+        _lib.check(self.lib.sf_flow_sample_stats(self.handle, st4))
+        self.last_sample_stats = dict(dense_ms=st4[0], rounds=int(st4[1]), rejected_round0=int(st4[2]), evaluations=st4[3])
         return (out, nd) if return_counts else out
 
     def prepare_context(self, x) -> None:
