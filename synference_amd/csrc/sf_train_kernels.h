@@ -204,7 +204,8 @@ __device__ __forceinline__ void sf_ctx_grad(const SfDev& m, const f32x16 (&delta
 }
 
 template <int HT>
-__global__ __launch_bounds__(128, 2) void k_maf_train(SfDev m, SfTrainArgs a) {
+__global__ __launch_bounds__(128, 2) void k_maf_train(SfDev m0, SfTrainArgs a) {
+  const SfDev& m = m0;
   extern __shared__ float lds_all[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, h = lane >> 5;
@@ -243,7 +244,8 @@ __global__ __launch_bounds__(128, 2) void k_maf_train(SfDev m, SfTrainArgs a) {
   using Ops = MafOps<HT, 1>;
 
   // ------------------------------------------------------------------ forward (with stash)
-  for (int t = 0; t < m.T; ++t) {
+  for (int t = 0; t < m0.T; ++t) {
+    const SfDev m = sf_iter_view(m0);  // loop bounds opaque per iteration: predicates are not hoisted and spilled
     const float* tp = m.packed + (size_t)t * m.t_stride;
     {
       f32x16 ut;
@@ -315,7 +317,8 @@ __global__ __launch_bounds__(128, 2) void k_maf_train(SfDev m, SfTrainArgs a) {
   }
 
   // ------------------------------------------------------------------ backward
-  for (int t = m.T - 1; t >= 0; --t) {
+  for (int t = m0.T - 1; t >= 0; --t) {
+    const SfDev m = sf_iter_view(m0);
     const float* tp = m.packed + (size_t)t * m.t_stride;
     const float* tpT = m.packedT + (size_t)t * m.tT_stride;
     float* gp = gimg_x + (size_t)t * m.t_stride;
@@ -429,7 +432,8 @@ struct SfNsfLds {  // transposed tiles needed at once by sf_grad_w
 };
 
 template <int HT, int PT>
-__global__ __launch_bounds__(128) void k_nsf_train(SfDev m, SfTrainArgs a) {
+__global__ __launch_bounds__(128) void k_nsf_train(SfDev m0, SfTrainArgs a) {
+  const SfDev& m = m0;
   extern __shared__ float lds_all[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, h = lane >> 5;
@@ -472,7 +476,8 @@ __global__ __launch_bounds__(128) void k_nsf_train(SfDev m, SfTrainArgs a) {
   };
 
   // ------------------------------------------------------------------ forward (with stash)
-  for (int t = 0; t < m.T; ++t) {
+  for (int t = 0; t < m0.T; ++t) {
+    const SfDev m = sf_iter_view(m0);  // loop bounds opaque per iteration: predicates are not hoisted and spilled
     const float* tp = m.packed + (size_t)t * m.t_stride;
     const int sb = t * TPT;
     store_u(sb);
@@ -539,7 +544,8 @@ __global__ __launch_bounds__(128) void k_nsf_train(SfDev m, SfTrainArgs a) {
   }
 
   // ------------------------------------------------------------------ backward
-  for (int t = m.T - 1; t >= 0; --t) {
+  for (int t = m0.T - 1; t >= 0; --t) {
+    const SfDev m = sf_iter_view(m0);
     const float* tp = m.packed + (size_t)t * m.t_stride;
     const float* tpT = m.packedT + (size_t)t * m.tT_stride;
     float* gp = gimg_x + (size_t)t * m.t_stride;
