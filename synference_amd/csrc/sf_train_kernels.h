@@ -432,7 +432,7 @@ struct SfNsfLds {  // transposed tiles needed at once by sf_grad_w
 };
 
 template <int HT, int PT>
-__global__ __launch_bounds__(128) void k_nsf_train(SfDev m0, SfTrainArgs a) {
+__global__ __launch_bounds__(128, 2) void k_nsf_train(SfDev m0, SfTrainArgs a) {
   const SfDev& m = m0;
   extern __shared__ float lds_all[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
