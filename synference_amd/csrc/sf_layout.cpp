@@ -349,7 +349,7 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
       // ---- 16-row-granular image for the incremental inverse ------------------------------------
       if (v.m16_ok) {
         auto push16 = [&](int32_t a, int32_t b) { L.src16a.push_back(a); L.src16b.push_back(b); };
-        while (L.src16a.size() % 64) push16(-1, -1);
+        while (L.src16a.size() % 1024) push16(-1, -1);  // whole 4 KiB groups: the staging loop copies 4 x 1 KiB per address
         const int64_t tb16 = (int64_t)L.src16a.size();
         if (t == 1) v.t16_stride = (int)tb16;
         auto here = [&]() { return (int)((int64_t)L.src16a.size() - tb16); };
@@ -542,7 +542,7 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
   E.pad_to(64);
   ET.pad_to(64);
   while (L.srcB.size() % 64) L.srcB.push_back(-1);
-  while (L.src16a.size() % 64) { L.src16a.push_back(-1); L.src16b.push_back(-1); }
+  while (L.src16a.size() % 1024) { L.src16a.push_back(-1); L.src16b.push_back(-1); }
   if (T == 1) {
     v.t_stride = (int)E.cur; v.tT_stride = (int)ET.cur; v.tB_stride = (int)L.srcB.size();
     v.t16_stride = (int)L.src16a.size();

@@ -183,11 +183,19 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16(SfDev m, SfSampleArgsHost 
       float4* __restrict__ d4 = reinterpret_cast<float4*>(sf_lds16);
       const int n4 = m.t16_stride >> 2;
       // direct global -> LDS copies (global_load_lds_dwordx4): no staging registers, no ds_write; the LDS
-      // destination of a wave-instruction is its (wave-uniform) base + lane * 16 bytes
+      // destination of a wave-instruction is its (wave-uniform) base + lane * 16 bytes.  The image is padded to whole
+      // 4 KiB groups (sf_layout.cpp): a wave copies a group with ONE address and four immediate offsets
+      // (the immediate applies to the global and to the LDS address alike).
       const int lane_ = threadIdx.x & 63;
-      for (int i = threadIdx.x; i < n4; i += 256)
-        __builtin_amdgcn_global_load_lds((const void*)(s4 + i),
-                                         (void __attribute__((address_space(3)))*)(d4 + (i - lane_)), 16, 0, 0);
+      const int ngroups = n4 >> 8;
+      for (int gi = __builtin_amdgcn_readfirstlane(wave); gi < ngroups; gi += 4) {
+        const float4* g = s4 + gi * 256 + lane_;
+        float4* l = d4 + gi * 256;
+        __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 1024, 0);
+        __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 3072, 0);
+      }
       __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0), other counters untouched: the copies have landed
     }
     __syncthreads();
