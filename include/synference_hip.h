@@ -107,6 +107,9 @@ int sf_flow_get_params(sf_flow* f, float* flat, int64_t n, int is_device, void* 
 /* Host-only helpers (no GPU needed; used by the CPU test-suite):
  * src1/src2[i] = logical index feeding packed float i (or -1); packed = sum of both. */
 int sf_flow_pack_table(const sf_flow* f, int32_t* src1, int32_t* src2, int64_t n_packed);
+/* the same for the 16-row image of the incremental MAF sampler (size 0 when the flow has none) */
+int64_t sf_flow_packed16_size(const sf_flow* f);
+int sf_flow_pack_table16(const sf_flow* f, int32_t* src1, int32_t* src2, int64_t n_packed16);
 /* byte-for-byte description of the packed image for diagnostics (JSON, NUL-terminated) */
 int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen);
 

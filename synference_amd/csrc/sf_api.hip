@@ -112,6 +112,16 @@ int sf_flow_pack_table(const sf_flow* f, int32_t* src1, int32_t* src2, int64_t n
   return SF_OK;
 }
 
+int64_t sf_flow_packed16_size(const sf_flow* f) { return (f && f->L.dev.m16_ok) ? f->L.n_packed16 : 0; }
+
+int sf_flow_pack_table16(const sf_flow* f, int32_t* src1, int32_t* src2, int64_t n_packed16) {
+  if (!f || !src1 || !src2) return fail(SF_ERR_INVALID, "null argument");
+  if (!f->L.dev.m16_ok || n_packed16 != f->L.n_packed16) return fail(SF_ERR_INVALID, "no 16-row image or size mismatch");
+  std::memcpy(src1, f->L.src16a.data(), (size_t)n_packed16 * sizeof(int32_t));
+  std::memcpy(src2, f->L.src16b.data(), (size_t)n_packed16 * sizeof(int32_t));
+  return SF_OK;
+}
+
 int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen) {
   if (!f || !buf) return fail(SF_ERR_INVALID, "null argument");
   const SfDev& v = f->L.dev;
@@ -140,6 +150,9 @@ int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen) {
     sf_ctab_shape(vv, R, NV);
     add("ctab_floats_per_galaxy", (long)v.T * NV * R);
   }
+  add("o16_w0", v.o16_w0); add("o16_wc", v.o16_wc); add("o16_b0", v.o16_b0); add("o16_wk0", v.o16_wk[0]);
+  add("o16_wk1", v.o16_wk[1]); add("o16_bk0", v.o16_bk[0]); add("o16_bk1", v.o16_bk[1]); add("o16_hv", v.o16_hv);
+  add("o16_hvb", v.o16_hvb);
   add("m16_ok", v.m16_ok); add("nT16", v.nT16); add("nC16", v.nC16); add("t16_stride", v.t16_stride);
   s += "\"g16_tile\": [";
   for (int i = 0; i < SF_DMAX; ++i) s += std::to_string(v.g16_tile[i]) + (i + 1 < SF_DMAX ? ", " : "], ");

@@ -83,6 +83,16 @@ class HipFlow:
                                                s2.ctypes.data_as(_lib.c_i32p), n))
         return s1, s2
 
+    def pack_table16(self) -> Tuple[np.ndarray, np.ndarray]:
+        """Gather tables of the 16-row sampler image (empty arrays when the flow has none)."""
+        n = int(self.lib.sf_flow_packed16_size(self.handle))
+        s1 = np.empty(n, np.int32)
+        s2 = np.empty(n, np.int32)
+        if n:
+            _lib.check(self.lib.sf_flow_pack_table16(self.handle, s1.ctypes.data_as(_lib.c_i32p),
+                                                     s2.ctypes.data_as(_lib.c_i32p), n))
+        return s1, s2
+
     def describe(self) -> dict:
         buf = C.create_string_buffer(1 << 16)
         _lib.check(self.lib.sf_flow_describe(self.handle, buf, len(buf)))

@@ -66,6 +66,28 @@ def test_packer_plus_wave_model_reproduce_oracle(name):
     assert np.abs(got - ref).max() < 5e-6
 
 
+@pytest.mark.parametrize("name", ["maf_cfg1", "maf_small", "maf_sig2"])
+def test_16_row_image_plus_wave_model_reproduce_the_oracle_inverse(name):
+    """sf_layout.cpp's image for the 16-row sampler (degree groups packed into 16-row tiles, per-tile weight
+    fragments of v_mfma_f32_16x16x4_f32, head rows for the per-lane dot product) drives a numpy model of
+    sf_maf16.hip's incremental inverse to the oracle's theta = inverse(z | x)."""
+    import torch
+    from oracle import flows as OF
+    from synference_amd.engine import HipFlow
+    ospec, spec, flat, theta, x = make_case(name, B=16)
+    hf = HipFlow(spec)
+    d = hf.describe()
+    if not d["m16_ok"]:
+        pytest.skip("no 16-row image for this shape")
+    s1, s2 = hf.pack_table16()
+    assert len(s1) == d["t16_stride"] * d["T"] and d["t16_stride"] % 1024 == 0
+    packed = ws.pack(flat.astype(np.float64), s1, s2)
+    z = np.random.default_rng(4).normal(size=(16, spec.D))
+    got = ws.maf_inverse16(d, packed, z, x.astype(np.float64))
+    ref, _ = OF.inverse_transform(ospec, torch.as_tensor(flat, dtype=torch.float64), torch.as_tensor(z), torch.as_tensor(x).double())
+    assert np.abs(got - ref.numpy()).max() < 5e-6 * max(1.0, np.abs(ref.numpy()).max())   # fp32 constants image
+
+
 def test_masked_made_entries_are_not_in_the_image():
     from oracle import flows as OF
     from synference_amd.engine import HipFlow

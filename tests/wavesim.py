@@ -221,3 +221,98 @@ def nsf_logprob(d, packed, theta32, x32):
 def pack(flat, s1, s2):
     f = np.concatenate([np.asarray(flat, dtype=np.float64), [0.0]])
     return f[s1] + f[s2]  # index -1 hits the appended zero
+
+
+# ---------------------------------------------------------------------------------------------------
+# 16-row engine (synference_amd/csrc/sf_maf16.hip): v_mfma_f32_16x16x4_f32 lane maps, the packed16 image and the
+# incremental autoregressive inverse, one 16-draw tile
+# ---------------------------------------------------------------------------------------------------
+S16 = LANES & 15
+G4 = LANES >> 4
+
+
+def mfma16(a_lane, b_lane, acc4, r_unused=None):
+    """v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D: lane (j=l&15, g=l>>4), reg r = row 4g+r."""
+    A = a_lane.reshape(4, 16).T
+    Bm = b_lane.reshape(4, 16)
+    Dm = A @ Bm
+    for r in range(4):
+        acc4[r] += Dm[4 * G4 + r, S16]
+
+
+def mma16(packed, woff, IT, ot, it, tile_in, acc4):
+    base = woff + ((ot * IT + it) * 64 + LANES) * 4
+    for r in range(4):
+        mfma16(packed[base + r], tile_in[r], acc4)
+
+
+def maf_inverse16(d, packed, z16, x16):
+    """z16 [16,D] base noise, x16 [16,C] context rows -> theta [16,D] through the 16-row image (table-free path)."""
+    cst = np.asarray(d["cst"])
+    D, T, NB, NT, C = d["D"], d["T"], d["NB"], d["nT16"], d["C"]
+    # draw in tile layout: lane (s, g4), reg r = physical slot 4*g4 + r
+    u = np.zeros((4, 64))
+    for r in range(4):
+        p = 4 * G4 + r
+        u[r] = np.where(p < D, z16[S16, np.minimum(p, D - 1)], 0.0)
+    # standardised context tiles
+    def ctx_tile(ic):
+        ct = np.zeros((4, 64))
+        for r in range(4):
+            rho = ic * 16 + 4 * G4 + r
+            ok = rho < C
+            rr = np.where(ok, rho, 0)
+            ct[r] = np.where(ok, (x16[S16, rr] - cst[d["c_xmean"] + rr]) / cst[d["c_xstd"] + rr], 0.0)
+        return ct
+    def slot_val(t4, sl):
+        v = t4[sl & 3]
+        return v[(LANES & 15) + 16 * (sl >> 2)]
+    def scale(a):
+        return (softplus(a) if d.get("scale_fn", 0) == 0 else 1 / (1 + np.exp(-(a + 2.0)))) + 1e-3
+    for t in range(T - 1, -1, -1):
+        tp = t * d["t16_stride"]
+        c0 = np.zeros((NT, 4, 64))
+        for ot in range(NT):
+            for r in range(4):
+                c0[ot, r] = packed[tp + d["o16_b0"] + (ot * 4 + G4) * 4 + r]
+            for ic in range(d["nC16"]):
+                mma16(packed, tp + d["o16_wc"], d["nC16"], ot, ic, ctx_tile(ic), c0[ot])
+        act = np.zeros((3, NT, 4, 64))
+        ut = np.zeros((4, 64))
+        for p in range(1, D + 1):
+            sl = int(cst[d["c_dslot"] + t * 16 + (p - 1)])
+            pa = np.zeros(64); pm = np.zeros(64)
+            if p >= 2:
+                ot = d["g16_tile"][p - 1]
+                act[0, ot] = c0[ot]
+                mma16(packed, tp + d["o16_w0"], 1, ot, 0, ut, act[0, ot])
+                for k in range(NB):
+                    b = np.zeros((4, 64))
+                    for r in range(4):
+                        b[r] = packed[tp + d[f"o16_bk{k}"] + (ot * 4 + G4) * 4 + r]
+                    for it in range(ot + 1):
+                        mma16(packed, tp + d[f"o16_wk{k}"], NT, ot, it, act[k, it], b)
+                    act[k + 1, ot] = np.tanh(b)
+                hv = tp + d["o16_hv"] + sl * 128 + G4 * 16
+                for tl in range(ot + 1):
+                    for r in range(4):
+                        pa += packed[hv + tl * 4 + r] * act[NB, tl, r]
+                        pm += packed[hv + 64 + tl * 4 + r] * act[NB, tl, r]
+            def sum4(v):
+                v = v + v[LANES ^ 16]
+                return v + v[LANES ^ 32]
+            av = packed[tp + d["o16_hvb"] + 2 * sl] + sum4(pa)
+            mv = packed[tp + d["o16_hvb"] + 2 * sl + 1] + sum4(pm)
+            wv = (slot_val(u, sl) - mv) / scale(av)
+            for r in range(4):
+                ut[r] = np.where((G4 == (sl >> 2)) & (r == (sl & 3)), wv, ut[r])
+        u = ut
+    th = np.zeros((16, D))
+    for r in range(4):
+        for g in range(4):
+            p = 4 * g + r
+            if p < D:
+                td = int(cst[d["c_tdim"] + p])
+                lanes = np.arange(16) + 16 * g
+                th[:, td] = (u[r][lanes] - cst[d["c_pshift"] + p]) / cst[d["c_pscale"] + p]
+    return th
