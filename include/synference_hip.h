@@ -284,9 +284,10 @@ int sf_flux_to_asinh(const float* flux_njy, const float* err_njy, int64_t N, int
 
 /* Depth-noise scatter of library photometry: out[(i*n_scatters + s), c] = flux[i,c] + sigma_ic * N(0,1),
  * sigma_ic = max(sigma[c], |flux[i,c]| * min_flux_pc_error / 100); err_out (may be NULL) receives sigma_ic.
- * sigma [C] device = depth / depth_sigma in the units of flux.  Noise from the Philox stream (seed, stream 2).
- * Replaces ref: sbi_runner.py:580-691 (_apply_depths, 0-D / 1-D depths). */
-int sf_scatter_depths(const float* flux /*[N,C]*/, int64_t N, int32_t C, const float* sigma /*[C]*/,
+ * sigma [n_sigma_rows, C] device = depth / depth_sigma in the units of flux; n_sigma_rows = 1 (one depth per band)
+ * or n_scatters (a depth set chosen per band and scatter copy: the reference's 2-D depths, the choice is the caller's).
+ * Noise from the Philox stream (seed, stream 2).  Replaces ref: sbi_runner.py:580-691 (_apply_depths). */
+int sf_scatter_depths(const float* flux /*[N,C]*/, int64_t N, int32_t C, const float* sigma, int32_t n_sigma_rows,
                       int32_t n_scatters, float min_flux_pc_error, uint64_t seed,
                       float* out /*[N*n_scatters,C]*/, float* err_out, void* stream);
 

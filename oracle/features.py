@@ -27,9 +27,12 @@ def flux_to_asinh(flux_njy, f_b_njy, err_njy=None):
 def scatter_depths(flux, depths, n_scatters=5, depth_sigma=5.0, min_flux_pc_error=0.0, seed=0):
     f = np.asarray(flux, dtype=np.float64)
     N, C = f.shape
-    sg = np.broadcast_to(np.asarray(depths, dtype=np.float64) / depth_sigma, (C,))
+    sg = np.asarray(depths, dtype=np.float64) / depth_sigma
+    # sigma rows: one for all scatter copies, or one per scatter copy ([n_scatters, C], the 2-D depths case after the
+    # caller has drawn a depth set per band and scatter)
+    sg = np.broadcast_to(sg, (C,))[None, :] if sg.ndim < 2 else sg
     rep = np.repeat(f, n_scatters, axis=0)
-    sigma = np.maximum(sg[None, :], np.abs(rep) * min_flux_pc_error / 100.0)
+    sigma = np.maximum(np.tile(sg, (N, 1)) if sg.shape[0] == n_scatters and n_scatters > 1 else sg[:1], np.abs(rep) * min_flux_pc_error / 100.0)
     z = philox.normal(seed, np.arange(N * n_scatters, dtype=np.uint64), 0, C, stream=2).astype(np.float64)
     return rep + sigma * z, sigma
 

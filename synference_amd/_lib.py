@@ -57,7 +57,7 @@ PROTOTYPES = {
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sf_flux_to_asinh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
-    "sf_scatter_depths": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_uint64,
+    "sf_scatter_depths": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_uint64,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "sf_pit_ranks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "sf_flow_packed16_size": (C.c_int64, [C.c_void_p]),

@@ -162,7 +162,7 @@ extern "C" int sf_flux_to_asinh(const float* flux_njy, const float* err_njy, int
 // (seed, stream 2; counter = (out_row, band block)), so a catalogue is reproducible and independent of launch shape
 // (the reference draws from numpy's global generator).
 // ---------------------------------------------------------------------------------------------
-__global__ void k_scatter_depths(const float* __restrict__ flux, long N, int C, const float* __restrict__ sigma,
+__global__ void k_scatter_depths(const float* __restrict__ flux, long N, int C, const float* __restrict__ sigma, int n_sig,
                                  int n_scatters, float min_pc, uint32_t k0, uint32_t k1, float* __restrict__ out,
                                  float* __restrict__ err_out) {
   const int CB = (C + 3) / 4;
@@ -172,6 +172,7 @@ __global__ void k_scatter_depths(const float* __restrict__ flux, long N, int C, 
     const long orow = i / CB;
     const int cb = (int)(i % CB);
     const long row = orow / n_scatters;
+    const float* sg = sigma + (size_t)((orow % n_scatters) % n_sig) * C;  // one sigma row, or one per scatter copy
     float z[4];
     sf_normal4(k0, k1, (uint64_t)orow, 0u, (uint32_t)cb, z);
 #pragma unroll
@@ -179,7 +180,7 @@ __global__ void k_scatter_depths(const float* __restrict__ flux, long N, int C, 
       const int c = cb * 4 + j;
       if (c < C) {
         const float f = flux[row * C + c];
-        const float s = fmaxf(sigma[c], fabsf(f) * min_pc * 0.01f);
+        const float s = fmaxf(sg[c], fabsf(f) * min_pc * 0.01f);
         out[orow * C + c] = f + s * z[j];
         if (err_out) err_out[orow * C + c] = s;
       }
@@ -187,17 +188,21 @@ __global__ void k_scatter_depths(const float* __restrict__ flux, long N, int C, 
   }
 }
 
-extern "C" int sf_scatter_depths(const float* flux, int64_t N, int32_t C, const float* sigma, int32_t n_scatters,
-                                 float min_flux_pc_error, uint64_t seed, float* out, float* err_out, void* stream) {
+extern "C" int sf_scatter_depths(const float* flux, int64_t N, int32_t C, const float* sigma, int32_t n_sigma_rows,
+                                 int32_t n_scatters, float min_flux_pc_error, uint64_t seed, float* out, float* err_out,
+                                 void* stream) {
   if (N == 0) return SF_OK;
   if (!flux || !sigma || !out) { sf_set_error("null argument"); return SF_ERR_INVALID; }
-  if (N < 0 || C < 1 || n_scatters < 1) { sf_set_error("sf_scatter_depths: bad shape"); return SF_ERR_INVALID; }
+  if (N < 0 || C < 1 || n_scatters < 1 || (n_sigma_rows != 1 && n_sigma_rows != n_scatters)) {
+    sf_set_error("sf_scatter_depths: bad shape (sigma rows must be 1 or n_scatters)");
+    return SF_ERR_INVALID;
+  }
   const long total = (long)N * n_scatters * ((C + 3) / 4);
   long blocks = (total + 255) / 256;
   blocks = blocks > 8192 ? 8192 : blocks;
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ 2u;
   hipLaunchKernelGGL(k_scatter_depths, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, flux, (long)N, (int)C, sigma,
-                     (int)n_scatters, min_flux_pc_error, k0, k1, out, err_out);
+                     (int)n_sigma_rows, (int)n_scatters, min_flux_pc_error, k0, k1, out, err_out);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { sf_set_error(std::string("k_scatter_depths: ") + hipGetErrorString(e)); return SF_ERR_HIP; }
   return SF_OK;

@@ -62,20 +62,30 @@ def flux_to_asinh(flux_njy: torch.Tensor, f_b_njy, err_njy: Optional[torch.Tenso
 def scatter_depths(flux: torch.Tensor, depths, n_scatters: int = 5, depth_sigma: float = 5.0,
                    min_flux_pc_error: float = 0.0, seed: int = 0, return_errors: bool = False):
     """(N,C) library photometry -> (N*n_scatters, C) noisy copies, sigma = depths / depth_sigma per band
-    (``depths`` scalar or [C], same units as ``flux``); row i*n_scatters + s is scatter s of row i."""
+    (``depths`` scalar, [C], or [k, C] = k depth sets: as in the reference, one set is then drawn per band and
+    scatter copy, from a generator seeded with ``seed``); row i*n_scatters + s is scatter s of row i."""
     if flux.device.type != "cuda":
         raise RuntimeError("scatter_depths runs on the GPU (no CPU fallback)")
     f = flux.contiguous().float()
     N, Cb = f.shape
-    sg = torch.as_tensor(depths, dtype=torch.float32, device=f.device).reshape(-1) / float(depth_sigma)
-    if sg.numel() == 1:
-        sg = sg.expand(Cb)
-    if sg.numel() != Cb:
-        raise ValueError(f"Mismatch in dimensions: photometry has {Cb} bands but depths has {sg.numel()} elements")
+    dep = torch.as_tensor(depths, dtype=torch.float32, device=f.device)
+    if dep.dim() == 2:  # (k, C) depth sets: depths[idx[c, s], c] per band and scatter (sbi_runner.py:636-649)
+        if dep.shape[1] != Cb:
+            raise ValueError(f"Mismatch in dimensions: photometry has {Cb} bands but depths has {dep.shape[1]} columns")
+        g = torch.Generator().manual_seed(int(seed) & 0x7FFFFFFF)
+        idx = torch.randint(0, dep.shape[0], (n_scatters, Cb), generator=g).to(f.device)
+        sg = dep.gather(0, idx) / float(depth_sigma)                       # [n_scatters, C]
+    else:
+        sg = dep.reshape(-1) / float(depth_sigma)
+        if sg.numel() == 1:
+            sg = sg.expand(Cb)
+        if sg.numel() != Cb:
+            raise ValueError(f"Mismatch in dimensions: photometry has {Cb} bands but depths has {sg.numel()} elements")
+        sg = sg.reshape(1, Cb)
     sg = sg.contiguous()
     out = torch.empty((N * n_scatters, Cb), dtype=torch.float32, device=f.device)
     err = torch.empty_like(out) if return_errors else None
-    _lib.check(_lib.load().sf_scatter_depths(_p(f), N, Cb, _p(sg), n_scatters, C.c_float(min_flux_pc_error),
+    _lib.check(_lib.load().sf_scatter_depths(_p(f), N, Cb, _p(sg), sg.shape[0], n_scatters, C.c_float(min_flux_pc_error),
                                              C.c_uint64(seed & (2 ** 64 - 1)), _p(out), _p(err), _stream(f.device)))
     return (out, err) if return_errors else out
 

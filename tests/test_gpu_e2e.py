@@ -259,3 +259,20 @@ def test_calculate_pit_matches_reference_definition(fitted):
     assert pit.shape == (64,) and np.abs(pit - ref).max() < 1e-6
     m = f.evaluate_model(X_test=X, y_test=y, num_samples=200, seed=11)
     assert len(m["pit_mean"]) == y.shape[1] and all(0.0 <= v <= 1.0 for v in m["pit_mean"])
+
+
+def test_scatter_depths_with_depth_sets():
+    """2-D depths (k sets x C bands): one set per band and scatter copy (sbi_runner.py:636-649)."""
+    from oracle import features as OF
+    from synference_amd.features import scatter_depths
+    rng = np.random.default_rng(5)
+    f = rng.uniform(1, 100, size=(200, 6)).astype(np.float32)
+    sets = rng.uniform(1, 40, size=(4, 6)).astype(np.float32)
+    out, err = scatter_depths(torch.as_tensor(f).cuda(), sets, n_scatters=3, depth_sigma=5.0, seed=9, return_errors=True)
+    err = err.cpu().numpy().reshape(200, 3, 6)
+    assert np.allclose(err, err[0][None])                             # same choice for every object
+    for s in range(3):
+        for c in range(6):
+            assert np.isclose(sets[:, c] / 5.0, err[0, s, c], rtol=1e-6).any()     # each sigma is one of the k sets
+    ro, _ = OF.scatter_depths(f, err[0] * 5.0, 3, 5.0, 0.0, 9)        # oracle with the same per-scatter sigma rows
+    assert np.abs(out.cpu().double().numpy() - ro).max() < 2e-4
