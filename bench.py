@@ -280,6 +280,27 @@ def main():
     barrier_sync(world)
     t_train = max_over_ranks(time.perf_counter() - t0, world, dev)
     pairs = world * tsteps * B / t_train
+    # strong scaling: the GLOBAL batch stays at --train-batch, each rank takes 1/world of it
+    Bs = max(32, B // world)
+    sidx = [torch.randint(0, len(tr), (Bs,), generator=g2).to(dev) for _ in range(4)]
+    gs = 1.0 / (Bs * world)
+
+    def strong_step(k):
+        bi = sidx[k % 4]
+        flow.loss_grad(flat, Ttr[bi], Xtr[bi], gs, grad_out=grad)
+        if world > 1:
+            dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+        opt2.step(grad, 5.0)
+
+    for k in range(max(a.warmup, 1)):
+        strong_step(k)
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for k in range(tsteps):
+        strong_step(k)
+    barrier_sync(world)
+    t_strong = max_over_ranks(time.perf_counter() - t0, world, dev)
+    pairs_strong = world * tsteps * Bs / t_strong
     # reference-default batch (64): 200 steps in one library call (what train_flow does per epoch on one device)
     order64 = torch.randint(0, len(tr), (200 * 64,), generator=g2).to(dev)
     tl64 = torch.zeros((), dtype=torch.float64, device=dev)
@@ -336,7 +357,9 @@ def main():
         "train": {"metric": "flow-train theta.x pairs/sec (fwd+bwd+allreduce+clip+Adam)", "value": pairs,
                   "unit": "pairs/s", "per_gpu_batch": B, "steps": tsteps, "ms_per_step": 1e3 * t_train / tsteps,
                   "achieved_tflops": pairs * 3 * wl["f_lp"] / 1e12,
-                  "batch64_pairs_per_s_1gpu": pairs64},
+                  "batch64_pairs_per_s_1gpu": pairs64,
+                  "strong_scaling": {"global_batch": Bs * world, "per_gpu_batch": Bs, "value": pairs_strong,
+                                     "ms_per_step": 1e3 * t_strong / tsteps}},
     }
     if world == 1 and not a.no_cpu_baseline:
         rec["cpu_baseline"] = cpu_baseline(est.spec, flat.cpu().numpy(), x_test, prior.low.numpy(),
