@@ -265,8 +265,7 @@ def main():
     bidx = [torch.randint(0, len(tr), (B,), generator=g2).to(dev) for _ in range(4)]
 
     def train_step(k):
-        bi = bidx[k % 4]
-        flow.loss_grad(flat, Ttr[bi], Xtr[bi], gscale, grad_out=grad)
+        flow.loss_grad_rows(flat, Ttr, Xtr, bidx[k % 4], gscale, grad)   # row gather fused into the kernel
         if world > 1:
             dist.all_reduce(grad, op=dist.ReduceOp.SUM)
         opt2.step(grad, 5.0)
@@ -286,8 +285,7 @@ def main():
     gs = 1.0 / (Bs * world)
 
     def strong_step(k):
-        bi = sidx[k % 4]
-        flow.loss_grad(flat, Ttr[bi], Xtr[bi], gs, grad_out=grad)
+        flow.loss_grad_rows(flat, Ttr, Xtr, sidx[k % 4], gs, grad)
         if world > 1:
             dist.all_reduce(grad, op=dist.ReduceOp.SUM)
         opt2.step(grad, 5.0)

@@ -205,6 +205,21 @@ class HipFlow:
             _ptr(exp_avg), _ptr(exp_avg_sq), C.byref(adam_desc), step0, C.c_float(max_norm), _ptr(scratch), _ptr(grad),
             _ptr(loss_sum), _stream(self.device)))
 
+    def loss_grad_rows(self, flat: torch.Tensor, theta: torch.Tensor, x: torch.Tensor, rows: torch.Tensor,
+                       grad_scale: float, grad_out: torch.Tensor, loss_sum: Optional[torch.Tensor] = None,
+                       loss_out: Optional[torch.Tensor] = None) -> None:
+        """loss_grad over the batch ``theta[rows], x[rows]`` with the gather fused into the kernel
+        (sf_flow_loss_grad_rows); ``loss_sum``: optional float64 device scalar accumulating sum_b (-log p_b)."""
+        self._dev()
+        for t in (flat, theta, x, grad_out):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
+                raise ValueError("loss_grad_rows needs contiguous float32 tensors on the flow's device")
+        if rows.dtype != torch.int64 or not rows.is_contiguous():
+            raise ValueError("rows must be a contiguous int64 tensor")
+        _lib.check(self.lib.sf_flow_loss_grad_rows(self.handle, _ptr(flat), _ptr(theta), _ptr(x), _ptr(rows), rows.numel(),
+                                                   C.c_float(grad_scale), None, _ptr(loss_out), _ptr(loss_sum),
+                                                   _ptr(grad_out), None, _stream(self.device)))
+
     def loss_grad(self, flat: torch.Tensor, theta, x, grad_scale: float,
                   grad_out: Optional[torch.Tensor] = None, weights: Optional[torch.Tensor] = None,
                   dctx_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:

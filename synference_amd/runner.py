@@ -150,6 +150,10 @@ class HipTrainOps:
     def loss_grad(self, flat, theta, x, scale, grad_out):
         return self.flow.loss_grad(flat, theta, x, scale, grad_out=grad_out)[0]
 
+    def loss_grad_rows(self, flat, theta, x, rows, scale, grad_out, loss_sum):
+        """Batch = rows of the training arrays, gathered inside the kernel; the loss is summed into ``loss_sum``."""
+        self.flow.loss_grad_rows(flat, theta, x, rows, scale, grad_out, loss_sum=loss_sum)
+
     def train_epoch(self, flat, theta, x, order, n_batches, batch, scale, opt, max_norm, grad, loss_sum):
         """All steps of an epoch in one library call (no host round trip per step); single device only."""
         self.flow.train_epoch(flat, theta, x, order, n_batches, batch, scale, opt.exp_avg, opt.exp_avg_sq, opt.desc,
@@ -233,9 +237,9 @@ def train_flow(estimator: FlowEstimator, theta: torch.Tensor, x: torch.Tensor, *
     grad = torch.empty_like(flat.data)
     gscale = 1.0 / (bs_tr * world)
     # single device, flow-only parameters, library optimiser: run each epoch's batch loop inside the library
-    fused_epoch = (world == 1 and not embedded and hasattr(ops, "train_epoch") and isinstance(opt, HipAdam)
-                   and theta.dtype == torch.float32 and x.dtype == torch.float32
-                   and theta.is_contiguous() and x.is_contiguous())
+    plain_f32 = (theta.dtype == torch.float32 and x.dtype == torch.float32 and theta.is_contiguous() and x.is_contiguous())
+    fused_epoch = world == 1 and not embedded and hasattr(ops, "train_epoch") and isinstance(opt, HipAdam) and plain_f32
+    fused_rows = not fused_epoch and not embedded and hasattr(ops, "loss_grad_rows") and plain_f32
 
     best_val, since, best_state = float("inf"), 0, None
     train_log, val_log, epoch = [], [], 0
@@ -264,6 +268,14 @@ def train_flow(estimator: FlowEstimator, theta: torch.Tensor, x: torch.Tensor, *
         if fused_epoch:
             # the whole batch loop in one library call: row gather fused into the kernel, loss summed on the device
             ops.train_epoch(flat.data, theta, x, order.contiguous(), nb_tr, bs_tr, gscale, opt, clip_max_norm, grad, tl)
+        elif fused_rows:
+            # data parallel: fused-gather loss_grad, ONE all-reduce of the flat gradient, identical step on every rank
+            order = order.contiguous()
+            for b in range(nb_tr):
+                ops.loss_grad_rows(flat.data, theta, x, order[b * bs_tr:(b + 1) * bs_tr], gscale, grad, tl)
+                if world > 1:
+                    dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+                opt.step(grad, clip_max_norm)
         else:
             for b in range(nb_tr):
                 idx = order[b * bs_tr:(b + 1) * bs_tr]
