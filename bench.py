@@ -57,7 +57,8 @@ def executed_mfma_flops_per_draw(d):
     if d.get("m16_ok") and not d["hidden_bf16"]:
         # 16-row incremental inverse (sf_maf16.hip): per pass p>=2 one 16-row tile of every layer:
         # 4 MFMAs for W0 u, 4 per input tile <= the pass's tile per hidden block; 16x16x4 MACs x 2 / 16 draws
-        n = sum(4 + NB * 4 * (d["g16_tile"][p - 1] + 1) for p in range(2, D + 1))
+        lo = d.get("g16_lo", d["g16_tile"])   # groups that straddle tiles recompute every tile they touch
+        n = sum((d["g16_tile"][p - 1] - lo[p - 1] + 1) * (4 + NB * 4 * (d["g16_tile"][p - 1] + 1)) for p in range(2, D + 1))
         return T * n * (16 * 16 * 4) * 2 / 16.0
     if d["inc_ok"] and NB <= 2:
         steps = HT * d["nGc"]                                           # hoisted context product

@@ -156,6 +156,8 @@ int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen) {
   add("m16_ok", v.m16_ok); add("nT16", v.nT16); add("nC16", v.nC16); add("t16_stride", v.t16_stride);
   s += "\"g16_tile\": [";
   for (int i = 0; i < SF_DMAX; ++i) s += std::to_string(v.g16_tile[i]) + (i + 1 < SF_DMAX ? ", " : "], ");
+  s += "\"g16_lo\": [";
+  for (int i = 0; i < SF_DMAX; ++i) s += std::to_string(v.g16_lo[i]) + (i + 1 < SF_DMAX ? ", " : "], ");
   s += "\"g_kend\": [";
   for (int i = 0; i < SF_DMAX; ++i) s += std::to_string(v.g_kend[i]) + (i + 1 < SF_DMAX ? ", " : "], ");
   s += "\"g_tile\": [";

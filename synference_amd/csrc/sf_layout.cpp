@@ -158,6 +158,21 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
         used16 += n;
         v.g16_tile[g + mn] = tile16;
       }
+      for (int g = 0; g < G; ++g) v.g16_lo[g + mn] = v.g16_tile[g + mn];
+      if (!ok16 && D >= 2 && NB <= 2 && H <= 64) {
+        // whole groups do not fit four tiles: pack the degree-sorted units contiguously; a group may then straddle
+        // tiles and its pass recomputes every tile it touches (sf_pass16_span)
+        h16row.assign(4 * 16, -1);
+        int r = 0;
+        for (int g = 0; g < G; ++g) {
+          v.g16_lo[g + mn] = r / 16;
+          for (int j : grp[g]) h16row[r++] = j;
+          v.g16_tile[g + mn] = (r - 1) / 16;
+        }
+        tile16 = (H - 1) / 16;
+        ok16 = true;
+        v.m16_span = 1;
+      }
       v.m16_ok = ok16 ? 1 : 0;
       v.nT16 = ok16 ? tile16 + 1 : 0;
       v.nC16 = ceil_div(C, 16);

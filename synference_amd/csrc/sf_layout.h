@@ -70,8 +70,10 @@ struct SfDev {
   //   into <= 4 tiles of 16 rows.  m16_ok = 0 when that packing does not exist (then the 32-row path is used).
   const float* packed16;
   int m16_ok, nT16, nC16, t16_stride;
+  int m16_span;  // 1: contiguous packing, degree groups may straddle tiles (g16_lo < g16_tile)
   int o16_w0, o16_wc, o16_b0, o16_wk[2], o16_bk[2], o16_hv, o16_hvb;
-  int g16_tile[SF_DMAX];  // tile that holds the hidden units of MADE degree g
+  int g16_tile[SF_DMAX];  // LAST tile that holds hidden units of MADE degree g ...
+  int g16_lo[SF_DMAX];    // ... and the FIRST one (== g16_tile when every degree group sits inside one tile)
   // per-galaxy context table (sampling only; sf_flow_prepare_context): everything that depends on the context
   // row alone, evaluated once per galaxy instead of once per draw.  [gal][t][v][row], row in tile order:
   //   MAF (16-row path): v = 0: b0 + bc + Wc e(x)                                   R = nT16*16

@@ -108,6 +108,45 @@ __device__ __forceinline__ void sf_pass16(const SfDev& m, const float* tp, SfPas
   for (int r = 0; r < 4; ++r) S.ut[r] = (g4 == (sl >> 2) && r == (sl & 3)) ? wv : S.ut[r];
 }
 
+// Same pass when the degree group straddles tiles LO..HI (contiguous packing, sf_layout.cpp): every layer is
+// recomputed for all of those tiles before the next layer starts (units of one degree feed each other), over the
+// input tiles 0..HI; rows of later groups inside these tiles get provisional values that nothing unmasked reads
+// and that their own pass overwrites.
+template <int LO, int HI, int NB>
+__device__ __forceinline__ void sf_pass16_span(const SfDev& m, const float* tp, SfPass16& S, int NT, int sl, float u_sl,
+                                               int lane, int g4) {
+  const float* hv = tp + m.o16_hv + sl * 128 + g4 * 16;
+#pragma unroll
+  for (int ot = LO; ot <= HI; ++ot) S.act[0][ot] = sf_mma16(sf_w16(tp + m.o16_w0, 1, ot, 0, lane), S.ut, S.c0[ot]);
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+#pragma unroll
+    for (int ot = LO; ot <= HI; ++ot) {
+      f32x4 b = sf_ld4(tp + m.o16_bk[k] + (ot * 4 + g4) * 4);
+#pragma unroll
+      for (int it = 0; it <= HI; ++it) b = sf_mma16(sf_w16(tp + m.o16_wk[k], NT, ot, it, lane), S.act[k][it], b);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S.act[k + 1][ot][r] = sf_tanh(b[r]);
+    }
+  }
+  float pa = 0.f, pm = 0.f;
+#pragma unroll
+  for (int tl = 0; tl <= HI; ++tl) {
+    const float4 ha = *reinterpret_cast<const float4*>(hv + tl * 4);
+    const float4 hm = *reinterpret_cast<const float4*>(hv + 64 + tl * 4);
+    const f32x4& av = S.act[NB][tl];
+    pa += ha.x * av[0] + ha.y * av[1] + ha.z * av[2] + ha.w * av[3];
+    pm += hm.x * av[0] + hm.y * av[1] + hm.z * av[2] + hm.w * av[3];
+  }
+  const float av = tp[m.o16_hvb + 2 * sl] + sf_sum4groups(pa);
+  const float mv = tp[m.o16_hvb + 2 * sl + 1] + sf_sum4groups(pm);
+  const float sc = (m.scale_fn == 0 ? sf_softplus(av) : sf_sigmoid(av + 2.0f)) + m.eps;
+  const float wv = sf_div(u_sl - mv, sc);
+  S.ldl += sf_log(sc);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) S.ut[r] = (g4 == (sl >> 2) && r == (sl & 3)) ? wv : S.ut[r];
+}
+
 // value of physical slot sl from a tile-layout register quad, broadcast to every row group
 __device__ __forceinline__ float sf_slot16(const f32x4& t, int sl, int lane) {
   const int r = sl & 3;
@@ -115,7 +154,7 @@ __device__ __forceinline__ float sf_slot16(const f32x4& t, int sl, int lane) {
   return __shfl(v, (lane & 15) + 16 * (sl >> 2), 64);
 }
 
-template <int NB>
+template <int NB, bool SPAN>
 __global__ __launch_bounds__(256, 3) void k_maf_inv16(SfDev m, SfSampleArgsHost a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int s = lane & 15, g4 = lane >> 4;
@@ -172,9 +211,12 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16(SfDev m, SfSampleArgsHost 
     for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
       for (int r = 0; r < 4; ++r) S.act[k][ot][r] = 0.f;
-  uint32_t tile_bits = 0;  // g16_tile packed 2 bits per degree (static indexing keeps the argument in SGPRs)
+  uint32_t tile_bits = 0, lo_bits = 0;  // g16_tile / g16_lo packed 2 bits per degree (static indexing keeps them in SGPRs)
 #pragma unroll
-  for (int q = 0; q < SF_DMAX; ++q) tile_bits |= (uint32_t)(m.g16_tile[q] & 3) << (2 * q);
+  for (int q = 0; q < SF_DMAX; ++q) {
+    tile_bits |= (uint32_t)(m.g16_tile[q] & 3) << (2 * q);
+    lo_bits |= (uint32_t)(m.g16_lo[q] & 3) << (2 * q);
+  }
   for (int t = m.T - 1; t >= 0; --t) {
     // ---- stage this transform's 16-row image (direct-to-LDS loads)
     __syncthreads();
@@ -237,11 +279,20 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16(SfDev m, SfSampleArgsHost 
     for (int p = 2; p <= m.D; ++p) {
       const int sl = __builtin_amdgcn_readlane(dsl, p - 1);
       const float u_sl = sf_slot16(u, sl, lane);
-      switch ((tile_bits >> (2 * (p - 1))) & 3u) {
+      const uint32_t hi_t = (tile_bits >> (2 * (p - 1))) & 3u;
+      const uint32_t lo_t = SPAN ? (lo_bits >> (2 * (p - 1))) & 3u : hi_t;  // (the aligned-packing kernel has no span code)
+      switch (lo_t * 4 + hi_t) {
         case 0: sf_pass16<0, NB>(m, tp, S, NT, sl, u_sl, lane, g4); break;
-        case 1: sf_pass16<1, NB>(m, tp, S, NT, sl, u_sl, lane, g4); break;
-        case 2: sf_pass16<2, NB>(m, tp, S, NT, sl, u_sl, lane, g4); break;
-        default: sf_pass16<3, NB>(m, tp, S, NT, sl, u_sl, lane, g4); break;
+        case 5: sf_pass16<1, NB>(m, tp, S, NT, sl, u_sl, lane, g4); break;
+        case 10: sf_pass16<2, NB>(m, tp, S, NT, sl, u_sl, lane, g4); break;
+        case 15: sf_pass16<3, NB>(m, tp, S, NT, sl, u_sl, lane, g4); break;
+        // degree groups that straddle tiles (contiguous packing)
+        case 1: if (SPAN) sf_pass16_span<0, 1, NB>(m, tp, S, NT, sl, u_sl, lane, g4); break;
+        case 2: if (SPAN) sf_pass16_span<0, 2, NB>(m, tp, S, NT, sl, u_sl, lane, g4); break;
+        case 3: if (SPAN) sf_pass16_span<0, 3, NB>(m, tp, S, NT, sl, u_sl, lane, g4); break;
+        case 6: if (SPAN) sf_pass16_span<1, 2, NB>(m, tp, S, NT, sl, u_sl, lane, g4); break;
+        case 7: if (SPAN) sf_pass16_span<1, 3, NB>(m, tp, S, NT, sl, u_sl, lane, g4); break;
+        default: if (SPAN) sf_pass16_span<2, 3, NB>(m, tp, S, NT, sl, u_sl, lane, g4); break;
       }
     }
     logdet -= S.ldl;
@@ -357,19 +408,20 @@ bool sf_maf16_enabled(const SfDev& m, const SfSampleArgsHost& a) {
          a.attempts_per_slot <= 16;
 }
 
-template <int NB>
+template <int NB, bool SPAN>
 static hipError_t sf_launch16(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
   static bool attr = false;
   const size_t sh = (size_t)m.t16_stride * sizeof(float);
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_maf_inv16<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)k_maf_inv16<NB, SPAN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr = true;
   }
   const long per_block = 4L * 16;
-  hipLaunchKernelGGL(k_maf_inv16<NB>, dim3((unsigned)((a.n_items + per_block - 1) / per_block)), dim3(256), sh, st, m, a);
+  hipLaunchKernelGGL((k_maf_inv16<NB, SPAN>), dim3((unsigned)((a.n_items + per_block - 1) / per_block)), dim3(256), sh, st, m, a);
   return hipGetLastError();
 }
 hipError_t sf_launch_maf_inv16(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
-  return m.NB == 1 ? sf_launch16<1>(m, a, st) : sf_launch16<2>(m, a, st);
+  if (m.m16_span) return m.NB == 1 ? sf_launch16<1, true>(m, a, st) : sf_launch16<2, true>(m, a, st);
+  return m.NB == 1 ? sf_launch16<1, false>(m, a, st) : sf_launch16<2, false>(m, a, st);
 }

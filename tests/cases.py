@@ -19,6 +19,10 @@ CASES = {
     "maf_nb3": ("maf", 4, 6, 24, 2, 10, dict(NB=3)),            # num_blocks=3 -> full-pass inverse fallback
     "nsf_nb1": ("nsf", 4, 6, 24, 2, 5, dict(NB=1)),             # num_blocks=1, K=5
     "maf_sig2": ("maf", 3, 5, 20, 2, 10, dict(scale_fn="sigmoid2")),  # nflows<=0.13 scale parametrisation
+    # 16-row sampler with degree groups that straddle tiles (contiguous packing, sf_pass16_span)
+    "maf_span6": ("maf", 6, 10, 50, 3, 10),    # 5 groups of 10 in 4 tiles
+    "maf_span_h64": ("maf", 8, 12, 64, 2, 10), # the example CLI width: 7 groups of 9-10
+    "maf_d2_span": ("maf", 2, 4, 40, 2, 10),   # one group of 40 units over 3 tiles
 }
 
 

@@ -283,18 +283,23 @@ def maf_inverse16(d, packed, z16, x16):
             sl = int(cst[d["c_dslot"] + t * 16 + (p - 1)])
             pa = np.zeros(64); pm = np.zeros(64)
             if p >= 2:
-                ot = d["g16_tile"][p - 1]
-                act[0, ot] = c0[ot]
-                mma16(packed, tp + d["o16_w0"], 1, ot, 0, ut, act[0, ot])
+                lo, hi = d["g16_lo"][p - 1], d["g16_tile"][p - 1]     # tiles holding the group of degree p-1
+                for ot in range(lo, hi + 1):
+                    act[0, ot] = c0[ot]
+                    mma16(packed, tp + d["o16_w0"], 1, ot, 0, ut, act[0, ot])
                 for k in range(NB):
-                    b = np.zeros((4, 64))
-                    for r in range(4):
-                        b[r] = packed[tp + d[f"o16_bk{k}"] + (ot * 4 + G4) * 4 + r]
-                    for it in range(ot + 1):
-                        mma16(packed, tp + d[f"o16_wk{k}"], NT, ot, it, act[k, it], b)
-                    act[k + 1, ot] = np.tanh(b)
+                    new = {}
+                    for ot in range(lo, hi + 1):
+                        b = np.zeros((4, 64))
+                        for r in range(4):
+                            b[r] = packed[tp + d[f"o16_bk{k}"] + (ot * 4 + G4) * 4 + r]
+                        for it in range(hi + 1):
+                            mma16(packed, tp + d[f"o16_wk{k}"], NT, ot, it, act[k, it], b)
+                        new[ot] = np.tanh(b)
+                    for ot, v in new.items():
+                        act[k + 1, ot] = v
                 hv = tp + d["o16_hv"] + sl * 128 + G4 * 16
-                for tl in range(ot + 1):
+                for tl in range(hi + 1):
                     for r in range(4):
                         pa += packed[hv + tl * 4 + r] * act[NB, tl, r]
                         pm += packed[hv + 64 + tl * 4 + r] * act[NB, tl, r]
