@@ -129,6 +129,10 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
       gt[g] = tile;
       gend[g] = tile * 32 + used;  // exclusive end row of degrees <= this one
     }
+    // aligned placement costs extra tiles when the groups pack badly (H = 64, D = 8: 3 tiles instead of 2, i.e.
+    // 1.5x the MFMA work of log_prob and training).  The 16-row sampler covers every H <= 64 by itself, so there the
+    // 32-row image only takes the aligned form when it is free.
+    if (ok && H <= 64 && NB <= 2 && D >= 2 && !d.hidden_bf16 && tile + 1 > ceil_div(H, 32)) ok = false;
     if (ok && D <= SF_DMAX) {
       hrow_full = rows;
       v.HT = std::max(v.HT, tile + 1);
@@ -189,6 +193,20 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
       for (int g = 0; g < G; ++g)
         if (v.g_tile[g + mn] == mt) k = std::max(k, v.g_kend[g + mn]);
       if (k > 0) v.mt_kend[mt] = k;
+    }
+  } else if (d.kind == SF_MAF && D >= 2 && H <= 128) {
+    // contiguous degree-sorted rows: output tile mt holds degrees <= that of its last row and needs the input
+    // groups that cover all units of those degrees (block-triangular skipping still applies)
+    const int mx = std::max(1, D - 1);
+    std::vector<int> cnt(mx, 0);
+    for (int j = 0; j < H; ++j) ++cnt[j % mx];
+    std::vector<int> endrow(mx, 0);
+    for (int g = 0, r = 0; g < mx; ++g) { r += cnt[g]; endrow[g] = r; }
+    for (int mt = 0; mt < v.HT; ++mt) {
+      const int last = std::min(H, (mt + 1) * 32) - 1;   // last occupied row of the tile
+      int g = 0;
+      while (g < mx - 1 && endrow[g] <= last) ++g;        // degree group of that row
+      v.mt_kend[mt] = std::min(v.nGh, ceil_div(endrow[g], 8));
     }
   }
   const std::vector<int> hrow_out(hrow_full.begin(), hrow_full.begin() + HT * 32);

@@ -157,7 +157,9 @@ __global__ void k_grad_gather(const float* __restrict__ gimg, long stride, const
 __global__ void k_train_prep(const float* __restrict__ flat, const int32_t* __restrict__ s1, const int32_t* __restrict__ s2,
                              float* __restrict__ packed, long n1, const int32_t* __restrict__ t1,
                              const int32_t* __restrict__ t2, float* __restrict__ packedT, long n2,
-                             float* __restrict__ gimg, float* __restrict__ dctx, long n4) {
+                             float* __restrict__ gimg, float* __restrict__ dctx, long n4,
+                             const int32_t* __restrict__ u1, const int32_t* __restrict__ u2, float* __restrict__ packed16,
+                             long n5) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n1) {
     const int a = s1[i], b = s2[i];
@@ -179,7 +181,15 @@ __global__ void k_train_prep(const float* __restrict__ flat, const int32_t* __re
     return;
   }
   i -= n2;
-  if (i < n4) dctx[i] = 0.f;
+  if (i < n4) { dctx[i] = 0.f; return; }
+  i -= n4;
+  if (i < n5) {  // 16-row sampler image (so that sampling right after a training step needs no set_params)
+    const int a = u1[i], b = u2[i];
+    float v = 0.f;
+    if (a >= 0) v = flat[a];
+    if (b >= 0) v += flat[b];
+    packed16[i] = v;
+  }
 }
 
 #define SF_TDECL(H)                                                                         \
@@ -225,14 +235,14 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
   }
   {
     const long n4 = (dctx && B > 0) ? B * (long)L.dev.C : 0;
-    const long tot = (long)L.n_packed + (long)L.n_packedT + n4;
+    const long n5 = f->d_packed16 ? (long)L.n_packed16 : 0;
+    const long tot = (long)L.n_packed + (long)L.n_packedT + n4 + n5;
     hipLaunchKernelGGL(k_train_prep, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, flat, f->d_s1, f->d_s2, f->d_packed,
-                       (long)L.n_packed, f->d_t1, f->d_t2, f->d_packedT, (long)L.n_packedT, f->d_gpacked, dctx, n4);
+                       (long)L.n_packed, f->d_t1, f->d_t2, f->d_packedT, (long)L.n_packedT, f->d_gpacked, dctx, n4,
+                       f->d_s16a, f->d_s16b, f->d_packed16, n5);
     SF_TRY(hipGetLastError());
   }
-  // the 16-row sampler image is not needed for training: it is refreshed by the next sf_flow_set_params, and until
-  // then the sampler uses the 32-row kernel on the (fresh) forward image
-  f->packed16_stale = f->d_packed16 != nullptr;
+  f->packed16_stale = false;
   if (L.n_packedB > 0) SF_TRY(sf_launch_pack_bf16(flat, f->d_bsrc, f->d_packedB, (long)L.n_packedB, st));
   if (B > 0) {
     SfTrainArgs a;
