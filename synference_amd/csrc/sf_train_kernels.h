@@ -204,7 +204,7 @@ __device__ __forceinline__ void sf_ctx_grad(const SfDev& m, const f32x16 (&delta
 }
 
 template <int HT>
-__global__ __launch_bounds__(128, 2) void k_maf_train(SfDev m0, SfTrainArgs a) {
+__global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, SfTrainArgs a) {
   const SfDev& m = m0;
   extern __shared__ float lds_all[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -432,7 +432,7 @@ struct SfNsfLds {  // transposed tiles needed at once by sf_grad_w
 };
 
 template <int HT, int PT>
-__global__ __launch_bounds__(128, 2) void k_nsf_train(SfDev m0, SfTrainArgs a) {
+__global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_nsf_train(SfDev m0, SfTrainArgs a) {
   const SfDev& m = m0;
   extern __shared__ float lds_all[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
