@@ -421,13 +421,14 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
           if (t == 0) v.o16_bk[k] = here();
           bias16(NT, h16row, lbk[k], -1);
         }
-        // head rows for the per-lane dot product: [slot][a|m][g4][tile (4)][r]
+        // head rows for the per-lane dot product: [slot][g4][tile (4)][r][a|m]  (a and m interleaved: one packed
+        // v_pk_fma_f32 updates both partial sums)
         if (t == 0) v.o16_hv = here();
         for (int q = 0; q < D; ++q)
-          for (int ab = 0; ab < 2; ++ab)
-            for (int g4 = 0; g4 < 4; ++g4)
-              for (int tl = 0; tl < 4; ++tl)
-                for (int r = 0; r < 4; ++r) {
+          for (int g4 = 0; g4 < 4; ++g4)
+            for (int tl = 0; tl < 4; ++tl)
+              for (int r = 0; r < 4; ++r)
+                for (int ab = 0; ab < 2; ++ab) {
                   const int unit = tl < NT ? h16row[tl * 16 + 4 * g4 + r] : -1;
                   const int orow_l = 2 * sinv[q] + ab;
                   const bool on = unit >= 0 && (orow_l / 2 + 1) > deg_h(unit);

@@ -18,6 +18,7 @@
 #include "sf_rng.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define SF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ float sf_sum4groups(float v) {  // sum over the 4 row groups of a sample
@@ -30,6 +31,14 @@ __device__ __forceinline__ f32x4 sf_mma16(float4 w, const f32x4& in, f32x4 acc) 
   acc = SF_MFMA16(w.y, in[1], acc);
   acc = SF_MFMA16(w.z, in[2], acc);
   acc = SF_MFMA16(w.w, in[3], acc);
+  return acc;
+}
+// head rows of one tile for this lane: (a0,m0,a1,m1), (a2,m2,a3,m3); acc = (sum a_r v_r, sum m_r v_r) as packed FMAs
+__device__ __forceinline__ f32x2 sf_head_acc(f32x2 acc, const float4& h01, const float4& h23, const f32x4& v) {
+  acc += f32x2{h01.x, h01.y} * f32x2{v[0], v[0]};
+  acc += f32x2{h01.z, h01.w} * f32x2{v[1], v[1]};
+  acc += f32x2{h23.x, h23.y} * f32x2{v[2], v[2]};
+  acc += f32x2{h23.z, h23.w} * f32x2{v[3], v[3]};
   return acc;
 }
 __device__ __forceinline__ f32x4 sf_ld4(const float* p) {
@@ -58,11 +67,11 @@ template <int OT, int NB>
 __device__ __forceinline__ void sf_pass16(const SfDev& m, const float* tp, SfPass16& S, int NT, int sl, float u_sl,
                                           int lane, int g4) {
   // everything that does not depend on this pass's new dimension first: weight fragments, partial sums
-  const float* hv = tp + m.o16_hv + sl * 128 + g4 * 16;
+  const float* hv = tp + m.o16_hv + sl * 128 + g4 * 32;
   float4 w0 = sf_w16(tp + m.o16_w0, 1, OT, 0, lane);
   float4 wk[2][OT + 1];
   f32x4 bk[2];
-  float4 ha[OT + 1], hm[OT + 1];
+  float4 h01[OT + 1], h23[OT + 1];
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
     bk[k] = sf_ld4(tp + m.o16_bk[k] + (OT * 4 + g4) * 4);
@@ -71,17 +80,13 @@ __device__ __forceinline__ void sf_pass16(const SfDev& m, const float* tp, SfPas
   }
 #pragma unroll
   for (int tl = 0; tl <= OT; ++tl) {
-    ha[tl] = *reinterpret_cast<const float4*>(hv + tl * 4);
-    hm[tl] = *reinterpret_cast<const float4*>(hv + 64 + tl * 4);
+    h01[tl] = *reinterpret_cast<const float4*>(hv + tl * 8);
+    h23[tl] = *reinterpret_cast<const float4*>(hv + tl * 8 + 4);
   }
   const float ba = tp[m.o16_hvb + 2 * sl], bm = tp[m.o16_hvb + 2 * sl + 1];
-  float pa = 0.f, pm = 0.f;
+  f32x2 pam = {0.f, 0.f};
 #pragma unroll
-  for (int tl = 0; tl < OT; ++tl) {
-    const f32x4& av = S.act[NB][tl];
-    pa += ha[tl].x * av[0] + ha[tl].y * av[1] + ha[tl].z * av[2] + ha[tl].w * av[3];
-    pm += hm[tl].x * av[0] + hm[tl].y * av[1] + hm[tl].z * av[2] + hm[tl].w * av[3];
-  }
+  for (int tl = 0; tl < OT; ++tl) pam = sf_head_acc(pam, h01[tl], h23[tl], S.act[NB][tl]);
 #pragma unroll
   for (int k = 0; k < NB; ++k)
 #pragma unroll
@@ -94,13 +99,9 @@ __device__ __forceinline__ void sf_pass16(const SfDev& m, const float* tp, SfPas
 #pragma unroll
     for (int r = 0; r < 4; ++r) S.act[k + 1][OT][r] = sf_tanh(b[r]);
   }
-  {
-    const f32x4& av = S.act[NB][OT];
-    pa += ha[OT].x * av[0] + ha[OT].y * av[1] + ha[OT].z * av[2] + ha[OT].w * av[3];
-    pm += hm[OT].x * av[0] + hm[OT].y * av[1] + hm[OT].z * av[2] + hm[OT].w * av[3];
-  }
-  const float av = ba + sf_sum4groups(pa);
-  const float mv = bm + sf_sum4groups(pm);
+  pam = sf_head_acc(pam, h01[OT], h23[OT], S.act[NB][OT]);
+  const float av = ba + sf_sum4groups(pam[0]);
+  const float mv = bm + sf_sum4groups(pam[1]);
   const float sc = (m.scale_fn == 0 ? sf_softplus(av) : sf_sigmoid(av + 2.0f)) + m.eps;
   const float wv = sf_div(u_sl - mv, sc);
   S.ldl += sf_log(sc);
@@ -115,7 +116,7 @@ __device__ __forceinline__ void sf_pass16(const SfDev& m, const float* tp, SfPas
 template <int LO, int HI, int NB>
 __device__ __forceinline__ void sf_pass16_span(const SfDev& m, const float* tp, SfPass16& S, int NT, int sl, float u_sl,
                                                int lane, int g4) {
-  const float* hv = tp + m.o16_hv + sl * 128 + g4 * 16;
+  const float* hv = tp + m.o16_hv + sl * 128 + g4 * 32;
 #pragma unroll
   for (int ot = LO; ot <= HI; ++ot) S.act[0][ot] = sf_mma16(sf_w16(tp + m.o16_w0, 1, ot, 0, lane), S.ut, S.c0[ot]);
 #pragma unroll
@@ -129,17 +130,13 @@ __device__ __forceinline__ void sf_pass16_span(const SfDev& m, const float* tp, 
       for (int r = 0; r < 4; ++r) S.act[k + 1][ot][r] = sf_tanh(b[r]);
     }
   }
-  float pa = 0.f, pm = 0.f;
+  f32x2 pam = {0.f, 0.f};
 #pragma unroll
-  for (int tl = 0; tl <= HI; ++tl) {
-    const float4 ha = *reinterpret_cast<const float4*>(hv + tl * 4);
-    const float4 hm = *reinterpret_cast<const float4*>(hv + 64 + tl * 4);
-    const f32x4& av = S.act[NB][tl];
-    pa += ha.x * av[0] + ha.y * av[1] + ha.z * av[2] + ha.w * av[3];
-    pm += hm.x * av[0] + hm.y * av[1] + hm.z * av[2] + hm.w * av[3];
-  }
-  const float av = tp[m.o16_hvb + 2 * sl] + sf_sum4groups(pa);
-  const float mv = tp[m.o16_hvb + 2 * sl + 1] + sf_sum4groups(pm);
+  for (int tl = 0; tl <= HI; ++tl)
+    pam = sf_head_acc(pam, *reinterpret_cast<const float4*>(hv + tl * 8), *reinterpret_cast<const float4*>(hv + tl * 8 + 4),
+                      S.act[NB][tl]);
+  const float av = tp[m.o16_hvb + 2 * sl] + sf_sum4groups(pam[0]);
+  const float mv = tp[m.o16_hvb + 2 * sl + 1] + sf_sum4groups(pam[1]);
   const float sc = (m.scale_fn == 0 ? sf_softplus(av) : sf_sigmoid(av + 2.0f)) + m.eps;
   const float wv = sf_div(u_sl - mv, sc);
   S.ldl += sf_log(sc);

@@ -298,11 +298,11 @@ def maf_inverse16(d, packed, z16, x16):
                         new[ot] = np.tanh(b)
                     for ot, v in new.items():
                         act[k + 1, ot] = v
-                hv = tp + d["o16_hv"] + sl * 128 + G4 * 16
+                hv = tp + d["o16_hv"] + sl * 128 + G4 * 32          # [slot][g4][tile][r][a|m]
                 for tl in range(hi + 1):
                     for r in range(4):
-                        pa += packed[hv + tl * 4 + r] * act[NB, tl, r]
-                        pm += packed[hv + 64 + tl * 4 + r] * act[NB, tl, r]
+                        pa += packed[hv + tl * 8 + 2 * r] * act[NB, tl, r]
+                        pm += packed[hv + tl * 8 + 2 * r + 1] * act[NB, tl, r]
             def sum4(v):
                 v = v + v[LANES ^ 16]
                 return v + v[LANES ^ 32]
