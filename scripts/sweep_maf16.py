@@ -1,0 +1,34 @@
+"""One-off randomized sweep of the 16-row MAF sampler against the oracle (many (D, H, NB, T, C) shapes)."""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import flows as OF
+from synference_amd.spec import FlowSpec
+from synference_amd.engine import HipFlow
+rng = np.random.default_rng(77)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+worst = 0.0; nspan = 0
+for i in range(n):
+    D = int(rng.integers(2, 17)); H = int(rng.integers(2, 65)); NB = int(rng.integers(1, 3)); T = int(rng.integers(1, 4))
+    C = int(rng.choice([1, 5, 16, 17, 40])); seed = 1000 + i
+    perms = OF.random_perms(D, T, seed)
+    st = dict(theta_mean=rng.normal(size=D).astype(np.float32), theta_std=rng.uniform(0.5, 2, size=D).astype(np.float32),
+              x_mean=rng.normal(size=C).astype(np.float32), x_std=rng.uniform(0.5, 2, size=C).astype(np.float32))
+    ospec = OF.FlowSpec(kind="maf", D=D, C=C, H=H, T=T, NB=NB, perms=perms, **{k: v.astype(np.float64) for k, v in st.items()})
+    spec = FlowSpec(kind="maf", D=D, C=C, H=H, T=T, NB=NB, perms=perms, **st)
+    flat = OF.init_params(ospec, seed + 1)
+    flat = (flat + 0.4 * rng.normal(size=flat.shape) * np.abs(flat).mean()).astype(np.float32)
+    B = 37
+    x = (rng.normal(size=(B, C)) * st["x_std"] + st["x_mean"]).astype(np.float32)
+    z = rng.normal(size=(B, D)).astype(np.float32)
+    f = HipFlow(spec, "cuda:0"); f.set_params(torch.as_tensor(flat))
+    d = f.describe(); nspan += int(d.get("m16_span", 0) if "m16_span" in d else d["g16_lo"] != d["g16_tile"])
+    th, ld = f.inverse(z, x)
+    th_ref, ld_ref = OF.inverse_transform(ospec, torch.as_tensor(flat, dtype=torch.float64), torch.as_tensor(z).double(), torch.as_tensor(x).double())
+    scale = np.maximum(np.abs(th_ref.numpy()), st["theta_std"])
+    e = float(np.abs((th.cpu().double().numpy() - th_ref.numpy()) / scale).max()); e2 = float(np.abs(ld.cpu().double().numpy() - ld_ref.numpy()).max())
+    worst = max(worst, e, e2 / max(1.0, D / 4))
+    if e > 5e-4 or e2 > 5e-4 * max(1.0, D / 4) or not d["m16_ok"]:
+        print("BAD" if d["m16_ok"] else "no-m16", dict(D=D, H=H, NB=NB, T=T, C=C), e, e2)
+print(f"{n} shapes, {nspan} with straddling groups, worst relative error {worst:.2e}")
