@@ -63,7 +63,7 @@ def test_tiny_and_empty_batches():
     assert f.log_prob(theta[:0], x[:0]).numel() == 0
 
 
-@pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "nsf_odd"])
+@pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "nsf_odd", "maf_span6", "maf_d2_span"])
 def test_sampler_matches_oracle_draw_for_draw(name):
     ospec, spec, flat, theta, x = make_case(name, B=6, spread=0.2)
     S, seed = 257, 2025
@@ -100,7 +100,7 @@ def test_sampler_unbounded_and_acceptance():
     assert np.abs(acc - racc).max() < 2e-3, (acc, racc)
 
 
-@pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "nsf_odd", "maf_wide", "nsf_nb1"])
+@pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "nsf_odd", "maf_wide", "nsf_nb1", "maf_span6", "maf_span_h64"])
 def test_context_table_round_equals_per_draw_round(name):
     """sf_flow_prepare_context only moves the context products out of the per-draw work: a dense round and a
     retry round over a slot list give the same draws and the same rejected set with and without the table.
