@@ -60,7 +60,8 @@ struct sf_flow {
   int32_t *d_s16a = nullptr, *d_s16b = nullptr;
   int32_t *d_s1 = nullptr, *d_s2 = nullptr, *d_t1 = nullptr, *d_t2 = nullptr;
   float* d_flat = nullptr;      // staging for host-sourced parameters
-  float* d_gpacked = nullptr;   // gradient image (atomic accumulation target)
+  float* d_gpacked = nullptr;   // gradient image replicas (accumulation target)
+  size_t gpacked_cap = 0;       // floats
   int32_t* d_gdst = nullptr;    // logical parameter -> gradient image index
   float* d_act = nullptr;       // activation stash (training)
   size_t act_cap = 0;           // floats

@@ -5,6 +5,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "sf_internal.h"
 #include "sf_train_args.h"
 
@@ -139,15 +141,14 @@ hipError_t sf_launch_adam(float* params, const float* grad, float* m, float* v, 
 //                      they are added to the gradient image with 256-byte-contiguous f32 atomics
 //   bias gradients   : row sums of the delta tile, taken from the B operands already read
 // ---------------------------------------------------------------------------------------------
-__global__ void k_grad_gather(const float* __restrict__ gimg, long stride, const int32_t* __restrict__ gdst,
+__global__ void k_grad_gather(const float* __restrict__ gimg, long stride, int copies, const int32_t* __restrict__ gdst,
                               float* __restrict__ grad, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int g = gdst[i];
   float v = 0.f;
   if (g >= 0) {
-#pragma unroll
-    for (int c = 0; c < SF_GCOPIES; ++c) v += gimg[(size_t)c * stride + g];  // fixed order over the replicas
+    for (int c = 0; c < copies; ++c) v += gimg[(size_t)c * stride + g];  // fixed order over the replicas
   }
   grad[i] = v;
 }
@@ -157,7 +158,7 @@ __global__ void k_grad_gather(const float* __restrict__ gimg, long stride, const
 __global__ void k_train_prep(const float* __restrict__ flat, const int32_t* __restrict__ s1, const int32_t* __restrict__ s2,
                              float* __restrict__ packed, long n1, const int32_t* __restrict__ t1,
                              const int32_t* __restrict__ t2, float* __restrict__ packedT, long n2,
-                             float* __restrict__ gimg, float* __restrict__ dctx, long n4,
+                             float* __restrict__ gimg, int copies, float* __restrict__ dctx, long n4,
                              const int32_t* __restrict__ u1, const int32_t* __restrict__ u2, float* __restrict__ packed16,
                              long n5) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -167,8 +168,7 @@ __global__ void k_train_prep(const float* __restrict__ flat, const int32_t* __re
     if (a >= 0) v = flat[a];
     if (b >= 0) v += flat[b];
     packed[i] = v;
-#pragma unroll
-    for (int c = 0; c < SF_GCOPIES; ++c) gimg[(size_t)c * n1 + i] = 0.f;
+    for (int c = 0; c < copies; ++c) gimg[(size_t)c * n1 + i] = 0.f;
     return;
   }
   i -= n1;
@@ -218,6 +218,7 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
     SF_TRY(hipMemcpy(f->d_t1, L.srcT1.data(), (size_t)L.n_packedT * sizeof(int32_t), hipMemcpyHostToDevice));
     SF_TRY(hipMemcpy(f->d_t2, L.srcT2.data(), (size_t)L.n_packedT * sizeof(int32_t), hipMemcpyHostToDevice));
     SF_TRY(hipMalloc(&f->d_gpacked, (size_t)SF_GCOPIES * L.n_packed * sizeof(float)));
+    f->gpacked_cap = (size_t)SF_GCOPIES * L.n_packed;
     SF_TRY(hipMalloc(&f->d_gdst, (size_t)L.n_params * sizeof(int32_t)));
     SF_TRY(hipMemcpy(f->d_gdst, L.gdst.data(), (size_t)L.n_params * sizeof(int32_t), hipMemcpyHostToDevice));
   }
@@ -233,12 +234,25 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
     SF_TRY(hipMalloc(&f->d_act, need * sizeof(float)));
     f->act_cap = need;
   }
+  // gradient accumulation: one replica per tile + plain stores (bitwise reproducible, and cheaper than atomics) up to
+  // 16 tiles (batch 512: the reference's batch sizes), or whenever SF_DETERMINISTIC=1 and the replicas fit 2 GiB
+  // (batch 2048: +15 % step time for zeroing and summing 64 replicas); else per-XCD replicas + f32 atomics
+  static int force_det = -1;
+  if (force_det < 0) { const char* e = std::getenv("SF_DETERMINISTIC"); force_det = e ? std::atoi(e) : 0; }
+  const bool det = waves > 0 && (waves <= 16 || (force_det == 1 && (size_t)waves * L.n_packed * sizeof(float) <= ((size_t)2 << 30)));
+  const int copies = det ? (int)waves : SF_GCOPIES;
+  if ((size_t)copies * L.n_packed > f->gpacked_cap) {
+    SF_TRY(hipFree(f->d_gpacked));
+    f->d_gpacked = nullptr; f->gpacked_cap = 0;
+    SF_TRY(hipMalloc(&f->d_gpacked, (size_t)copies * L.n_packed * sizeof(float)));
+    f->gpacked_cap = (size_t)copies * L.n_packed;
+  }
   {
     const long n4 = (dctx && B > 0) ? B * (long)L.dev.C : 0;
     const long n5 = f->d_packed16 ? (long)L.n_packed16 : 0;
     const long tot = (long)L.n_packed + (long)L.n_packedT + n4 + n5;
     hipLaunchKernelGGL(k_train_prep, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, flat, f->d_s1, f->d_s2, f->d_packed,
-                       (long)L.n_packed, f->d_t1, f->d_t2, f->d_packedT, (long)L.n_packedT, f->d_gpacked, dctx, n4,
+                       (long)L.n_packed, f->d_t1, f->d_t2, f->d_packedT, (long)L.n_packedT, f->d_gpacked, copies, dctx, n4,
                        f->d_s16a, f->d_s16b, f->d_packed16, n5);
     SF_TRY(hipGetLastError());
   }
@@ -246,7 +260,7 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
   if (L.n_packedB > 0) SF_TRY(sf_launch_pack_bf16(flat, f->d_bsrc, f->d_packedB, (long)L.n_packedB, st));
   if (B > 0) {
     SfTrainArgs a;
-    a.theta = theta; a.x = x; a.idx = idx; a.loss_sum = loss_sum; a.B = B; a.w = grad_scale; a.wts = weights; a.loss = loss; a.dctx = dctx; a.gimg = f->d_gpacked; a.gimg_stride = (long)L.n_packed;
+    a.theta = theta; a.x = x; a.idx = idx; a.loss_sum = loss_sum; a.B = B; a.w = grad_scale; a.wts = weights; a.loss = loss; a.dctx = dctx; a.gimg = f->d_gpacked; a.gimg_stride = (long)L.n_packed; a.det = det ? 1 : 0;
     a.act = reinterpret_cast<float4*>(f->d_act); a.act_per_wave = act_per_wave;
     const SfDev m = f->dev();
     const bool maf = m.kind == SF_MAF;
@@ -259,7 +273,7 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
     }
   }
   hipLaunchKernelGGL(k_grad_gather, dim3((unsigned)((L.n_params + 255) / 256)), dim3(256), 0, st,
-                     f->d_gpacked, (long)L.n_packed, f->d_gdst, grad, (long)L.n_params);
+                     f->d_gpacked, (long)L.n_packed, copies, f->d_gdst, grad, (long)L.n_params);
   SF_TRY(hipGetLastError());
   return SF_OK;
 }

@@ -14,8 +14,9 @@ struct SfTrainArgs {
   double* loss_sum;  // optional device scalar: += sum_b loss_b (unweighted), one f64 atomic per tile
   float* loss;       // [B] or null
   float* dctx;       // [B,C] or null: += d(sum_b w_b loss_b)/d x[b,:] (context gradient, raw x units)
-  float* gimg;       // gradient image: SF_GCOPIES replicas of gimg_stride floats (one per XCD, summed by the gather)
-  long gimg_stride;
+  float* gimg;       // gradient image replicas of gimg_stride floats, summed in fixed order by the gather:
+  long gimg_stride;  //   det == 0: SF_GCOPIES replicas, one per XCD, f32 atomics
+  int det;           //   det == 1: one replica per 32-sample tile, plain stores -> bitwise reproducible gradients
   float4* act;       // activation stash
   long act_per_wave; // float4 per wave
 };

@@ -46,6 +46,7 @@ struct SfGradPipe {
   float* lds;   // two buffers of `stride` floats
   int stride;
   int i;
+  int det;      // 1: the consumer stores into this tile's own replica instead of atomically adding to a shared one
 };
 
 template <int OT, int IT, bool RELU_IN = false>
@@ -66,6 +67,7 @@ __device__ __forceinline__ void sf_grad_w(SfGradPipe& P, const f32x16 (&delta)[O
     d[6] = (int)(unsigned)pw; d[7] = (int)(unsigned)(pw >> 32);
     d[8] = (int)(unsigned)pb; d[9] = (int)(unsigned)(pb >> 32);
     d[10] = lim.v[0]; d[11] = lim.v[1]; d[12] = lim.v[2]; d[13] = lim.v[3];  // per-output-tile group limit (masked layers)
+    d[14] = P.det;
   }
   __syncthreads();
   ++P.i;
@@ -89,6 +91,7 @@ __device__ __forceinline__ void sf_grad_consumer(float* __restrict__ lds, int st
     const int OT = __builtin_amdgcn_readfirstlane(d[0]), IT = __builtin_amdgcn_readfirstlane(d[1]);
     const int nGtot = __builtin_amdgcn_readfirstlane(d[2]), kg0 = __builtin_amdgcn_readfirstlane(d[3]);
     const int ng = __builtin_amdgcn_readfirstlane(d[4]);
+    const bool det = __builtin_amdgcn_readfirstlane(d[14]) != 0;
     float* gw = reinterpret_cast<float*>((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(d[6]) |
                                          ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(d[7]) << 32));
     float* gb = reinterpret_cast<float*>((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(d[8]) |
@@ -116,8 +119,11 @@ __device__ __forceinline__ void sf_grad_consumer(float* __restrict__ lds, int st
           for (int g = 0; g < 4; ++g)
             if (kt * 4 + g < ngm) {
               float* dst = gw + (((size_t)mt * nGtot + kg0 + kt * 4 + g) * 4) * 64 + lane;
-              // padded output rows are exact zeros in all four values: no atomic traffic for those lanes
-              if ((acc[4 * g] != 0.f) | (acc[4 * g + 1] != 0.f) | (acc[4 * g + 2] != 0.f) | (acc[4 * g + 3] != 0.f)) {
+              if (det) {  // this tile owns the replica (pre-zeroed): plain stores, summed later in tile order
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[j * 64] = acc[4 * g + j];
+              } else if ((acc[4 * g] != 0.f) | (acc[4 * g + 1] != 0.f) | (acc[4 * g + 2] != 0.f) | (acc[4 * g + 3] != 0.f)) {
+                // padded output rows are exact zeros in all four values: no atomic traffic for those lanes
 #pragma unroll
                 for (int j = 0; j < 4; ++j) atomicAdd(dst + j * 64, acc[4 * g + j]);
               }
@@ -126,7 +132,10 @@ __device__ __forceinline__ void sf_grad_consumer(float* __restrict__ lds, int st
       }
       if (gb) {
         bsum += sf_xhalf(bsum);
-        if (h == 0) atomicAdd(gb + mt * 32 + c, bsum);
+        if (h == 0) {
+          if (det) gb[mt * 32 + c] = bsum;
+          else atomicAdd(gb + mt * 32 + c, bsum);
+        }
       }
     }
   }
@@ -220,7 +229,8 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, 
   // gradient-image replica of this XCD: f32 atomics from different XCDs then never meet on an address
   int xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-  float* gimg_x = a.gimg + (size_t)(xcc & (SF_GCOPIES - 1)) * a.gimg_stride;
+  float* gimg_x = a.gimg + (size_t)(a.det ? wid : (long)(xcc & (SF_GCOPIES - 1))) * a.gimg_stride;
+  lds.det = a.det;
   float4* stash = a.act + wid * a.act_per_wave;
   const int TPT = (m.NB + 1) * HT + 1;  // stash tiles per transform: u, h0, a_1..a_NB
 
@@ -312,7 +322,8 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, 
       float t = (valid && h == 0) ? nll : 0.f;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-      if (lane == 0) atomicAdd(a.loss_sum, (double)t);
+      // values on a 2^-20 grid add exactly in double: the sum does not depend on the order of the atomics
+      if (lane == 0) atomicAdd(a.loss_sum, (double)rintf(t * 1048576.0f) * (1.0 / 1048576.0));
     }
   }
 
@@ -448,7 +459,8 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_nsf_train(SfDev m0, 
   // gradient-image replica of this XCD: f32 atomics from different XCDs then never meet on an address
   int xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-  float* gimg_x = a.gimg + (size_t)(xcc & (SF_GCOPIES - 1)) * a.gimg_stride;
+  float* gimg_x = a.gimg + (size_t)(a.det ? wid : (long)(xcc & (SF_GCOPIES - 1))) * a.gimg_stride;
+  lds.det = a.det;
   float4* stash = a.act + wid * a.act_per_wave;
   // stash tiles per transform: [0] u_in, [1..HT] h_0, per block k: t1, t2, h_{k+1} (HT each), last: u'
   const int TPT = 2 + (3 * m.NB + 1) * HT;
@@ -539,7 +551,8 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_nsf_train(SfDev m0, 
       float t = (valid && h == 0) ? nll : 0.f;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-      if (lane == 0) atomicAdd(a.loss_sum, (double)t);
+      // values on a 2^-20 grid add exactly in double: the sum does not depend on the order of the atomics
+      if (lane == 0) atomicAdd(a.loss_sum, (double)rintf(t * 1048576.0f) * (1.0 / 1048576.0));
     }
   }
 

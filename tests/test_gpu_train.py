@@ -248,3 +248,22 @@ def test_loss_grad_rows_equals_gathered_loss_grad():
     assert torch.allclose(loss, loss_ref, atol=1e-6)
     assert abs(float(lsum.item()) - float(loss_ref.double().sum().item())) < 1e-3
     assert (grad - grad_ref).abs().max().item() < 1e-5 * max(1.0, grad_ref.abs().max().item())
+
+
+@pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3"])
+def test_small_batch_gradients_are_bitwise_reproducible(name):
+    """Up to 16 tiles (batch 512) every tile owns a gradient-image replica that the gather sums in tile order:
+    the same inputs give the same bits, call after call (larger batches use f32 atomics unless SF_DETERMINISTIC=1)."""
+    from synference_amd.engine import HipFlow
+    ospec, spec, flat, theta, x = make_case(name, B=500)
+    f = HipFlow(spec, "cuda:0")
+    fl = torch.as_tensor(flat)
+    l0, g0 = f.loss_grad(fl, theta, x, 1.0 / 500)
+    g0 = g0.clone(); l0 = l0.clone()
+    for _ in range(3):
+        l1, g1 = f.loss_grad(fl, theta, x, 1.0 / 500)
+        assert torch.equal(g0, g1) and torch.equal(l0, l1)
+    # and they are right
+    rloss, rgrad = oracle_loss_grad(ospec, flat, theta[:300], x[:300])
+    _, g300 = f.loss_grad(fl, theta[:300], x[:300], 1.0 / 300)
+    assert np.abs(g300.cpu().double().numpy() - rgrad).max() < 2e-4 * np.abs(rgrad).max()
