@@ -276,3 +276,20 @@ def test_scatter_depths_with_depth_sets():
             assert np.isclose(sets[:, c] / 5.0, err[0, s, c], rtol=1e-6).any()     # each sigma is one of the k sets
     ro, _ = OF.scatter_depths(f, err[0] * 5.0, 3, 5.0, 0.0, 9)        # oracle with the same per-scatter sigma rows
     assert np.abs(out.cpu().double().numpy() - ro).max() < 2e-4
+
+
+def test_default_batch_training_is_reproducible_run_to_run():
+    """At the reference's batch sizes (<= 512) a seeded run_single_sbi reproduces itself bit for bit: the gradient is
+    summed in tile order, the clip norm and Adam in a fixed order, the shuffles come from the seeded generator."""
+    from synference_amd import SBI_Fitter
+    from synference_amd.synthetic import make_catalogue
+    x, theta, names = make_catalogue(1500, 10, 5, seed=2)
+    outs = []
+    for _ in range(2):
+        f = SBI_Fitter("rep", names, [f"F{i}" for i in range(10)], feature_array=x, parameter_array=theta)
+        post, stats = f.run_single_sbi(model_type="nsf", hidden_features=32, num_transforms=2, training_batch_size=64,
+                                       learning_rate=1e-3, stop_after_epochs=2, max_num_epochs=4, random_seed=5,
+                                       save_model=False, verbose=False, plot=False)
+        outs.append((post.posteriors[0].posterior_estimator.flat.detach().cpu().clone(), stats[0]["training_loss"]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert outs[0][1] == outs[1][1]
