@@ -160,6 +160,8 @@ int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen) {
   for (int i = 0; i < SF_DMAX; ++i) s += std::to_string(v.g16_lo[i]) + (i + 1 < SF_DMAX ? ", " : "], ");
   s += "\"g_kend\": [";
   for (int i = 0; i < SF_DMAX; ++i) s += std::to_string(v.g_kend[i]) + (i + 1 < SF_DMAX ? ", " : "], ");
+  s += "\"g_lo\": [";
+  for (int i = 0; i < SF_DMAX; ++i) s += std::to_string(v.g_lo[i]) + (i + 1 < SF_DMAX ? ", " : "], ");
   s += "\"g_tile\": [";
   for (int i = 0; i < SF_DMAX; ++i) s += std::to_string(v.g_tile[i]) + (i + 1 < SF_DMAX ? ", " : "], ");
   s += "\"mt_kend\": [";

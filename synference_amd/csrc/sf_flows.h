@@ -181,19 +181,27 @@ struct MafOps {
       for (int ns = 0; ns < NS; ++ns) ldl[ns] = 0.f;
       for (int p = 1; p <= m.D; ++p) {
         if (p >= 2) {
-          const int tile = m.g_tile[p - 1];
+          // the degree group of this pass occupies tiles lo..hi (one tile when the layout is aligned, several when
+          // the units are packed contiguously); every layer is recomputed for all of them before the next layer
+          // starts -- units of one degree feed each other -- over the input groups of degree <= p-1
+          const int hi = m.g_tile[p - 1], lo = m.g_lo[p - 1];
           const int kend = m.g_kend[p - 1];
           f32x16 ut[1][NS];
           sf_build_u_tile<NS>(ut, w, h);
 #pragma unroll
           for (int mt = 0; mt < HT; ++mt) {
-            if (mt == tile) {
+            if (mt >= lo && mt <= hi) {
 #pragma unroll
               for (int ns = 0; ns < NS; ++ns) act[0][mt][ns] = c0[mt][ns];
               sf_mm_acc_tile<NS, 1, false>(act[0][mt], ut, tp + m.o_w0, m.nGu, mt, m.nGu, lane);
+            }
+          }
 #pragma unroll
-              for (int k = 0; k < 2; ++k) {
-                if (k < m.NB) {
+          for (int k = 0; k < 2; ++k) {
+            if (k < m.NB) {
+#pragma unroll
+              for (int mt = 0; mt < HT; ++mt) {
+                if (mt >= lo && mt <= hi) {
                   f32x16 b[NS];
                   sf_init_bias_tile<NS>(b, tp + m.o_bk[k], mt, h);
                   if (BF)

@@ -129,10 +129,19 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
       gt[g] = tile;
       gend[g] = tile * 32 + used;  // exclusive end row of degrees <= this one
     }
-    // aligned placement costs extra tiles when the groups pack badly (H = 64, D = 8: 3 tiles instead of 2, i.e.
-    // 1.5x the MFMA work of log_prob and training).  The 16-row sampler covers every H <= 64 by itself, so there the
-    // 32-row image only takes the aligned form when it is free.
-    if (ok && H <= 64 && NB <= 2 && D >= 2 && !d.hidden_bf16 && tile + 1 > ceil_div(H, 32)) ok = false;
+    // Aligned placement (one pass = one tile) costs extra tiles when the groups pack badly (H = 64, D = 8: 3 tiles
+    // instead of 2, i.e. 1.5x the MFMA work of log_prob and training) and extra input groups, which can push the
+    // transform's image out of the LDS.  Contiguous placement (a group may straddle tiles, its pass recomputes
+    // every tile it touches) is taken instead when it saves a tile or is the only one of the two that fits the LDS.
+    if (ok && D >= 2) {
+      const int nGu_e = ceil_div(D, 8), nGc_e = ceil_div(C, 8);
+      auto image_floats = [&](int ht, int ngh) {
+        return 256L * (ht * (nGu_e + nGc_e) + (long)NB * ht * ngh + ngh) + 64L * D * ht + 64L * (NB + 1) * ht;
+      };
+      const long lds_floats = 156L * 1024 / 4;
+      const int ht_a = tile + 1, ngh_a = ceil_div(gend[G - 1], 8), ht_c = ceil_div(H, 32), ngh_c = ceil_div(H, 8);
+      if (ht_a > ht_c || (image_floats(ht_a, ngh_a) > lds_floats && image_floats(ht_c, ngh_c) <= lds_floats)) ok = false;
+    }
     if (ok && D <= SF_DMAX) {
       hrow_full = rows;
       v.HT = std::max(v.HT, tile + 1);
@@ -140,13 +149,19 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
       for (int g = 0; g < G; ++g) {
         // degree value (g + mn) is stored at index (g + mn); index 0 unused when mn == 1
         v.g_tile[g + mn] = gt[g];
+        v.g_lo[g + mn] = gt[g];
         v.g_kend[g + mn] = ceil_div(gend[g], 8);
       }
       v.nGh = ceil_div(gend[G - 1], 8);
-    } else {  // degree-sorted but unaligned: plain contiguous rows
+    } else {  // degree-sorted, contiguous rows: a degree group may straddle tiles (g_lo < g_tile)
       int r = 0;
-      for (int g = 0; g < G; ++g)
+      for (int g = 0; g < G; ++g) {
+        v.g_lo[g + mn] = r / 32;
         for (int j : grp[g]) hrow_full[r++] = j;
+        v.g_tile[g + mn] = (r - 1) / 32;
+        v.g_kend[g + mn] = ceil_div(r, 8);
+      }
+      v.inc_ok = (D >= 2 && D <= SF_DMAX && H <= 128) ? 1 : 0;
     }
     // 16-row tiles for the 16x16x4 incremental inverse: whole degree groups, at most 4 tiles
     {
@@ -191,7 +206,7 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
     for (int mt = 0; mt < 4; ++mt) {
       int k = 0;
       for (int g = 0; g < G; ++g)
-        if (v.g_tile[g + mn] == mt) k = std::max(k, v.g_kend[g + mn]);
+        if (v.g_lo[g + mn] <= mt && mt <= v.g_tile[g + mn]) k = std::max(k, v.g_kend[g + mn]);  // groups with rows in mt
       if (k > 0) v.mt_kend[mt] = k;
     }
   } else if (d.kind == SF_MAF && D >= 2 && H <= 128) {

@@ -59,7 +59,8 @@ struct SfDev {
   // rows of ONE tile g_tile[g]; covering every unit of degree <= g takes g_kend[g] input groups.
   // inc_ok = 1 when no degree group straddles a tile (enables the incremental inverse).
   int inc_ok;
-  int g_tile[SF_DMAX], g_kend[SF_DMAX];
+  int g_tile[SF_DMAX], g_kend[SF_DMAX];  // g_tile = LAST tile of the group
+  int g_lo[SF_DMAX];                      // FIRST tile of the group (== g_tile for aligned layouts)
   int mt_kend[4];  // input groups needed by hidden output tile mt (== nGh when not degree-sorted)
   // bf16 operand image of the hidden HxH layers (inference, opt-in): [mt][ks][lane][8] bf16, ks = 16-row steps
   const unsigned short* packedB;
