@@ -153,7 +153,7 @@ def test_sampler_exhausted_attempts_give_nan_rows():
 # ---------------------------------------------------------------------------------------------------
 # opt-in bf16 mode (BASELINE configs[4]): hidden H x H layers with bf16 MFMA operands, fp32 accumulate
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "nsf_odd", "maf_small"])
+@pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "nsf_odd", "maf_small", "maf_span_h64", "maf_span6"])
 def test_bf16_hidden_mode_matches_bf16_emulating_oracle(name):
     """Tight: against the oracle with the SAME operand rounding (weights and hidden activations of the
     H x H layers rounded to bf16, wide accumulation).  Loose: the stated distance to the fp32 flow."""
