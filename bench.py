@@ -8,8 +8,10 @@ Workload (BASELINE.json configs[1]): NPE MAF (5 transforms, 50 hidden) on the 10
 NIRCam-like mock; one "step" = ``sample_posterior`` over the 2 000-galaxy test catalogue with
 1 000 accepted draws per galaxy (the reference's published benchmark loop, ref:
 src/synference/sbi_runner.py:6438-6442, S=1000 as in examples/paper/model_testing.ipynb:1543-1554),
-prior-box rejection included.  value = accepted posterior samples / s over all ranks (each rank owns
-its own 2 000-galaxy shard: weak scaling, no data-path collective).  The flow-train theta.x pairs/s leg
+prior-box rejection included, driven by the library's own sampler (sf_flow_sample: per-galaxy context table, dense
+round 0, retry rounds; round 0 is bracketed by HIP events on the launch stream inside the library and read back
+through sf_flow_sample_stats for the roofline).  value = accepted posterior samples / s over all ranks (each rank
+owns its own 2 000-galaxy shard: weak scaling, no data-path collective).  The flow-train theta.x pairs/s leg
 (forward+backward+RCCL all-reduce+clip+Adam) is timed right after with the same barrier protocol and
 reported in the "train" object of the same JSON line.
 
