@@ -2,25 +2,35 @@
 """bench.py -- headline benchmark of the amortised-posterior flow path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): NPE MAF (5 transforms, 50 hidden) on the 10k-galaxy 10-filter
-NIRCam-like mock; one "step" = ``sample_posterior`` over the 2 000-galaxy test catalogue with
-1 000 accepted draws per galaxy (the reference's published benchmark loop, ref:
-src/synference/sbi_runner.py:6438-6442, S=1000 as in examples/paper/model_testing.ipynb:1543-1554),
-prior-box rejection included, driven by the library's own sampler (sf_flow_sample: per-galaxy context table, dense
-round 0, retry rounds; round 0 is bracketed by HIP events on the launch stream inside the library and read back
-through sf_flow_sample_stats for the roofline).  value = accepted posterior samples / s over all ranks (each rank
-owns its own 2 000-galaxy shard: weak scaling, no data-path collective).  The flow-train theta.x pairs/s leg
-(forward+backward+RCCL all-reduce+clip+Adam) is timed right after with the same barrier protocol and
-reported in the "train" object of the same JSON line.
+With ``--gpus N > 1`` and no launcher environment (WORLD_SIZE unset) the script starts the N ranks itself
+(``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`` as a child process,
+before this process touches the GPU) and forwards rank 0's JSON line; started under ``torch.distributed.run`` it is one
+rank.  Either way it asserts that the process group really has ``--gpus`` ranks and reports that number.
 
-Inputs are synthetic (synference_amd/synthetic.py) and resident in HBM before the
-timed region; weights are random-init + a short seeded warm-up fit so the posterior is non-trivial.
+Workload (BASELINE.json configs[1]): NPE MAF (5 transforms, 50 hidden) on the 10k-galaxy 10-filter NIRCam-like mock;
+one "step" = ``sample_posterior`` over the 2 000-galaxy test catalogue with 1 000 accepted draws per galaxy (the
+reference's published benchmark loop, ref: src/synference/sbi_runner.py:6438-6442, S=1000 as in
+examples/paper/model_testing.ipynb:1543-1554), prior-box rejection included, driven by the library's own sampler
+(sf_flow_sample: per-galaxy context table + ONE persistent launch that works first attempts and retries to the end; the
+launch is bracketed by HIP events on its stream inside the library and read back through sf_flow_sample_stats).
+value = ACCEPTED posterior samples / s over all ranks (slots that end as NaN rows are not counted); each rank owns its
+own 2 000-galaxy shard: weak scaling, no data-path collective.  The flow-train theta.x pairs/s leg
+(forward+backward+RCCL all-reduce+clip+Adam) is timed right after with the same barrier protocol ("train" object).
+
+roofline.frac is a hardware fraction (<= 1): USEFUL work -- the mask-aware FLOPs of one conditioner evaluation per
+transform for every ACCEPTED draw, the least any algorithm needs (rejected draws are overhead) -- over
+the measured kernel time, against the fp32 MFMA peak.  The MFMA FLOPs the kernel actually issued (padding and
+rejected evaluations included) and the SURVEY 8d contract figure (the reference's D-pass algorithm) are named extras.
+
+Inputs are synthetic (synference_amd/synthetic.py) and resident in HBM before the timed region; weights
+are random-init + a short seeded warm-up fit so the posterior is non-trivial.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -47,9 +57,8 @@ WORKLOADS = {
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA (= vector) dense peak
 
 
-def executed_mfma_flops_per_draw(d):
-    """FLOPs the MAF sampler kernel actually issues on the MFMA pipe per draw (dense padded tiles of
-    the incremental inverse): group-steps x 4 MFMAs x 32x32x2 MACs x 2 / 32 samples."""
+def executed_mfma_flops_per_eval(d):
+    """FLOPs the sampler kernel issues on the MFMA pipe per flow evaluation (dense padded tiles)."""
     D, T, NB, HT = d["D"], d["T"], d["NB"], d["HT"]
     if d["kind"] == 1:  # NSF: conditioner + spline head per transform (context products come from the galaxy table)
         steps = HT * d["nGu"] + NB * (2 * HT * d["nGh"])
@@ -65,22 +74,23 @@ def executed_mfma_flops_per_draw(d):
     if d["inc_ok"] and NB <= 2:
         steps = HT * d["nGc"]                                           # hoisted context product
         steps += sum(d["nGu"] + NB * d["g_kend"][p - 1] for p in range(2, D + 1))   # one hidden tile per pass
-        # (the two head rows per pass are VALU dot products, not MFMA)
     else:
         steps = D * (HT * (d["nGu"] + d["nGc"]) + NB * sum(d["mt_kend"][:HT]) + d["nGh"])
     return T * steps * 4 * (32 * 32 * 2) * 2 / 32.0
 
 
-def pmc_traffic():
-    """HBM bytes per dense round-0 launch from the committed rocprofv3 PMC passes (profiles/), collected
-    with the same command; None when no summary is committed."""
+def pmc_traffic(tag):
+    """HBM bytes per launch from the newest committed rocprofv3 PMC summary (profiles/rNN_pmc_summary.json) collected
+    with this command; None when there is none for this kernel."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary.json")))
     if not files:
         return None, None
     with open(files[-1]) as fh:
         d = json.load(fh)
-    return d.get("hbm_bytes_per_launch"), os.path.basename(files[-1])
+    if tag == "sample":
+        return d.get("hbm_bytes_per_launch"), os.path.basename(files[-1])
+    return d.get("train", {}).get("hbm_bytes_per_launch"), os.path.basename(files[-1])
 
 
 def parse():
@@ -98,8 +108,35 @@ def parse():
     ap.add_argument("--hidden-bf16", action="store_true",
                     help="opt-in bf16 MFMA operands for the hidden HxH layers of the sampler (BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the sampling leg of the CPU baseline")
     return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# N ranks
+# ---------------------------------------------------------------------------------------------------------------
+def spawn_ranks(a):
+    """Start ``--gpus`` ranks as ONE child process tree (torch.distributed.run) and forward its output.  Runs before
+    this process has initialised the GPU (nothing here calls into torch.cuda)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    p = subprocess.run(cmd, env=env)
+    return p.returncode
+
+
+def all_reduce_(t, op, gloo):
+    if gloo and t.device.type == "cuda":   # rehearsal backend: stage device tensors through the host
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
 
 
 def barrier_sync(world):
@@ -109,55 +146,132 @@ def barrier_sync(world):
     torch.cuda.synchronize()
 
 
-def max_over_ranks(t, world, dev):
+def max_over_ranks(t, world, dev, gloo):
     if world == 1:
         return t
     v = torch.tensor([t], dtype=torch.float64, device=dev)
-    dist.all_reduce(v, op=dist.ReduceOp.MAX)
+    all_reduce_(v, dist.ReduceOp.MAX, gloo)
     return float(v.item())
 
 
-def cpu_baseline(spec, flat, x_rows, lo, hi, S, budget_s):
-    """Reference-style CPU path: the oracle restatement driven one galaxy at a time, S accepted draws
-    each with prior-box rejection (SURVEY.md 8d / BASELINE.md B1), one thread, bounded wall time."""
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1 only): the oracle driven the way the reference drives sbi
+# ---------------------------------------------------------------------------------------------------------------
+def host_cpu():
+    model, cores = "unknown", os.cpu_count() or 1
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        for line in out.splitlines():
+            if line.startswith("Model name:"):
+                model = line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else cores
+    return model, cores, usable
+
+
+def cpu_baseline(spec, flat, x_rows, th_rows, lo, hi, S, budget_s, train_theta, train_x):
+    """BASELINE.md section 3, B1-B4, on a bounded sample (about 25-30 s of CPU work in total):
+    B1 per-object sampling, one galaxy per call, 1 thread (mirrors sbi_runner.py:6438-6442; the statistic of log_times);
+    B2 batched sampling on all usable cores; B3 log_prob per row (sbi_runner.py:7193-7196, raw density) and batched;
+    B4 the epoch loop of custom_runner.py:580-618 (Adam, clip 5.0) at batch 64 and at the GPU leg's batch."""
     from oracle import flows as OF
     from oracle import posterior as OP
-    torch.set_num_threads(1)
+    model, cores, usable = host_cpu()
     ospec = OF.FlowSpec(kind=spec.kind, D=spec.D, C=spec.C, H=spec.H, T=spec.T, K=spec.K, NB=spec.NB,
                         perms=spec.perms, theta_mean=spec.theta_mean.astype(np.float64),
                         theta_std=spec.theta_std.astype(np.float64), x_mean=spec.x_mean.astype(np.float64),
                         x_std=spec.x_std.astype(np.float64))
     fl = torch.as_tensor(flat, dtype=torch.float32)
-    times = []
+    # ---- B1
+    torch.set_num_threads(1)
+    times, g = [], 0
     t_all = time.perf_counter()
-    g = 0
     while g < len(x_rows) and (time.perf_counter() - t_all) < budget_s:
         t0 = time.perf_counter()
         OP.sample(ospec, fl, x_rows[g:g + 1], S, 2025 + g, lo, hi, dtype=torch.float32)
         times.append(time.perf_counter() - t0)
         g += 1
     med = float(np.median(times))
-    # batched CPU number on all host cores so the GPU ratio is not credited for removing the loop
-    ncores = min(16, os.cpu_count() or 1)  # the box's CPU share for one GPU
-    torch.set_num_threads(ncores)
+    # ---- B3 (1 thread): per row, then batched
+    xt, tt = torch.as_tensor(x_rows), torch.as_tensor(th_rows, dtype=torch.float32)
+    n_rows, t0 = 0, time.perf_counter()
+    with torch.no_grad():
+        while n_rows < len(x_rows) and time.perf_counter() - t0 < 3.0:
+            OF.log_prob(ospec, fl, tt[n_rows:n_rows + 1], xt[n_rows:n_rows + 1])
+            n_rows += 1
+    lp_row = n_rows / (time.perf_counter() - t0)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 2.0:
+            OF.log_prob(ospec, fl, tt, xt)
+            reps += 1
+    lp_batched_1 = reps * len(xt) / (time.perf_counter() - t0)
+
+    # ---- B4 (1 thread, then all cores): Adam + clip_grad_norm_(5.0), loss = mean(-log_prob) via torch.autograd
+    def train_rate(batch, seconds):
+        p = torch.nn.Parameter(fl.clone())
+        opt = torch.optim.Adam([p], lr=1e-4)
+        rs = np.random.RandomState(0)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            idx = rs.randint(0, len(train_x), size=batch)
+            opt.zero_grad(set_to_none=True)
+            loss = -OF.log_prob(ospec, p, torch.as_tensor(train_theta[idx], dtype=torch.float32),
+                                torch.as_tensor(train_x[idx])).mean()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_([p], 5.0)
+            opt.step()
+            n += batch
+        return n / (time.perf_counter() - t0)
+
+    tr64_1 = train_rate(64, 3.0)
+    # ---- all usable cores
+    torch.set_num_threads(usable)
     nb = min(len(x_rows), 64)
     OP.sample(ospec, fl, x_rows[:4], S, 6, lo, hi, dtype=torch.float32)  # thread-pool warm-up
     t0 = time.perf_counter()
     OP.sample(ospec, fl, x_rows[:nb], S, 7, lo, hi, dtype=torch.float32)
     tb = time.perf_counter() - t0
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 2.0:
+            OF.log_prob(ospec, fl, tt, xt)
+            reps += 1
+    lp_batched_all = reps * len(xt) / (time.perf_counter() - t0)
+    tr64_all = train_rate(64, 2.0)
+    trbig_all = train_rate(16384, 4.0)
     return {"value": S / med, "unit": "samples/s", "cores": 1, "kind": "port",
+            "cpu_model": model, "host_cores": cores, "usable_cores": usable,
             "sample": f"{len(times)} galaxies x {S} accepted draws, one galaxy per call (oracle/posterior.py, "
                       f"torch fp32, 1 thread); median {med:.4f} s/object "
                       f"(16-84%: {np.percentile(times, 16):.4f}-{np.percentile(times, 84):.4f})",
-            "batched_all_cores": {"value": nb * S / tb, "cores": ncores,
-                                  "sample": f"{nb} galaxies x {S} draws in one call"}}
+            "batched_all_cores": {"value": nb * S / tb, "unit": "samples/s", "cores": usable,
+                                  "sample": f"{nb} galaxies x {S} draws in one call"},
+            "log_prob": {"per_row_1thread": {"value": lp_row, "unit": "rows/s", "cores": 1,
+                                             "sample": f"{n_rows} rows, one row per call (sbi_runner.py:7193-7196 loop, raw density)"},
+                         "batched_1thread": {"value": lp_batched_1, "unit": "rows/s", "cores": 1,
+                                             "sample": f"{len(xt)} rows per call"},
+                         "batched_all_cores": {"value": lp_batched_all, "unit": "rows/s", "cores": usable,
+                                               "sample": f"{len(xt)} rows per call"}},
+            "train": {"batch64_1thread": {"value": tr64_1, "unit": "pairs/s", "cores": 1,
+                                          "sample": "3 s of Adam steps at batch 64 (custom_runner.py:580-618 loop, torch autograd on the oracle)"},
+                      "batch64_all_cores": {"value": tr64_all, "unit": "pairs/s", "cores": usable, "sample": "2 s at batch 64"},
+                      "batch16384_all_cores": {"value": trbig_all, "unit": "pairs/s", "cores": usable,
+                                               "sample": "4 s at batch 16384"}}}
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP flow engine has no CPU fallback)")
     # rehearsal knobs (never set by the driver): all ranks on one device / gloo instead of RCCL
@@ -165,18 +279,17 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = os.environ.get("SF_BENCH_BACKEND", "nccl")
+    gloo = backend != "nccl"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("SF_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+        assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
 
-    from synference_amd.engine import retry_width
     from synference_amd.estimator import build_flow
-    from synference_amd.posterior import FlowPosterior
     from synference_amd.priors import prior_from_parameters
     from synference_amd.runner import HipAdam
     from synference_amd.synthetic import make_catalogue
@@ -215,50 +328,50 @@ def main():
         if it == a.fit_steps - 1:
             fit_loss = float(lossv.mean().item())
     flow.set_params(flat)
-    post = FlowPosterior(est, prior.to(dev), seed=2025)
     lo, hi = prior.low.to(dev), prior.high.to(dev)
     X = torch.as_tensor(x_test).to(dev)
     M, S = X.shape[0], a.draws
     out = torch.empty((M, S, D), dtype=torch.float32, device=dev)
-    dense_ms = []
-    drawn = [0]
-    rounds = [0]
-    rej0 = [0]
+    kernel_ms, evals, launches, rej0 = [], [0.0], [0], [0]
 
     def sample_step(k, timed):
         """sample_posterior over the catalogue through the library's own sampler (sf_flow_sample): per-galaxy context
-        table, dense round 0, retry rounds until every slot is filled -- exactly what FlowPosterior.sample_catalogue
-        runs.  The library brackets round 0 with HIP events on this stream (sf_flow_sample_stats)."""
-        flow.sample(X, S, lo, hi, seed=1000 + k, max_attempts=64, out=out)
+        table + the persistent launch -- exactly what FlowPosterior.sample_catalogue runs (no attempt ceiling)."""
+        flow.sample(X, S, lo, hi, seed=1000 + k, out=out)
         st = flow.last_sample_stats
         if timed:
-            dense_ms.append(st["dense_ms"])
-        drawn[0] += st["evaluations"]
-        rounds[0] += st["rounds"]
-        rej0[0] += st["rejected_round0"]
+            kernel_ms.append(st["dense_ms"])
+            evals[0] += st["evaluations"]
+            launches[0] += st["rounds"]
+            rej0[0] += st["rejected_round0"]
         return flow.last_unfilled
 
     for k in range(a.warmup):
         sample_step(0, False)
-    drawn[0] = 0
-    rounds[0] = 0
-    rej0[0] = 0
     barrier_sync(world)
     t0 = time.perf_counter()
     unfilled = 0
     for k in range(a.steps):
         unfilled += sample_step(k, True)
     barrier_sync(world)
-    t_samp = max_over_ranks(time.perf_counter() - t0, world, dev)
-    k0_ms = float(np.mean(dense_ms))
+    t_samp = max_over_ranks(time.perf_counter() - t0, world, dev, gloo)
+    k_ms = float(np.mean(kernel_ms))
     accept = 1.0 - rej0[0] / float(a.steps * M * S)
-    value = world * a.steps * (M * S - 0) / t_samp
-    flops_launch = wl["f_draw"] * M * S   # the per-galaxy part (f_gal * M) runs once per step in the context-table kernel
-    achieved = flops_launch / (k0_ms * 1e-3) / 1e12
-    traffic, traffic_src = pmc_traffic() if a.workload == "maf_cfg2" and M == 2000 and S == 1000 else (None, None)
-    exe_per_draw = executed_mfma_flops_per_draw(flow.describe())
-    executed = exe_per_draw * M * S / (k0_ms * 1e-3) / 1e12
-    minimal = (wl["f_lp"] if wl["kind"] == "maf" else wl["f_draw"]) * M * S / (k0_ms * 1e-3) / 1e12
+    if world > 1:
+        u = torch.tensor([float(unfilled)], dtype=torch.float64, device=dev)
+        all_reduce_(u, dist.ReduceOp.SUM, gloo)
+        unfilled_all = int(u.item())
+    else:
+        unfilled_all = unfilled
+    value = (world * a.steps * M * S - unfilled_all) / t_samp
+    desc = flow.describe()
+    accepted_per_launch = M * S - unfilled / float(a.steps)
+    evals_per_launch = evals[0] / float(a.steps)
+    f_min = wl["f_lp"] if wl["kind"] == "maf" else wl["f_draw"]   # one conditioner evaluation per transform
+    useful = f_min * accepted_per_launch / (k_ms * 1e-3) / 1e12
+    executed = executed_mfma_flops_per_eval(desc) * evals_per_launch / (k_ms * 1e-3) / 1e12
+    contract = wl["f_draw"] * accepted_per_launch / (k_ms * 1e-3) / 1e12
+    traffic, traffic_src = pmc_traffic("sample") if a.workload == "maf_cfg2" and M == 2000 and S == 1000 else (None, None)
 
     # ---------------- train leg: fwd+bwd (+ all-reduce) + clip + Adam at the per-GPU batch
     tsteps = a.train_steps or a.steps
@@ -270,7 +383,7 @@ def main():
     def train_step(k):
         flow.loss_grad_rows(flat, Ttr, Xtr, bidx[k % 4], gscale, grad)   # row gather fused into the kernel
         if world > 1:
-            dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+            all_reduce_(grad, dist.ReduceOp.SUM, gloo)
         opt2.step(grad, 5.0)
 
     for k in range(max(a.warmup, 1)):
@@ -280,8 +393,16 @@ def main():
     for k in range(tsteps):
         train_step(k)
     barrier_sync(world)
-    t_train = max_over_ranks(time.perf_counter() - t0, world, dev)
+    t_train = max_over_ranks(time.perf_counter() - t0, world, dev, gloo)
     pairs = world * tsteps * B / t_train
+    # kernel time of the forward+backward flow kernel alone (HIP events on its stream, inside the library)
+    flow.set_profiling(True)
+    tk = []
+    for k in range(min(tsteps, 10)):
+        train_step(k)
+        tk.append(flow.train_kernel_ms())
+    flow.set_profiling(False)
+    train_kernel_ms = float(np.mean(tk))
     # strong scaling: the GLOBAL batch stays at --train-batch, each rank takes 1/world of it
     Bs = max(32, B // world)
     sidx = [torch.randint(0, len(tr), (Bs,), generator=g2).to(dev) for _ in range(4)]
@@ -290,7 +411,7 @@ def main():
     def strong_step(k):
         flow.loss_grad_rows(flat, Ttr, Xtr, sidx[k % 4], gs, grad)
         if world > 1:
-            dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+            all_reduce_(grad, dist.ReduceOp.SUM, gloo)
         opt2.step(grad, 5.0)
 
     for k in range(max(a.warmup, 1)):
@@ -300,7 +421,7 @@ def main():
     for k in range(tsteps):
         strong_step(k)
     barrier_sync(world)
-    t_strong = max_over_ranks(time.perf_counter() - t0, world, dev)
+    t_strong = max_over_ranks(time.perf_counter() - t0, world, dev, gloo)
     pairs_strong = world * tsteps * Bs / t_strong
     # reference-default batch (64): 200 steps in one library call (what train_flow does per epoch on one device)
     order64 = torch.randint(0, len(tr), (200 * 64,), generator=g2).to(dev)
@@ -314,15 +435,32 @@ def main():
                      5.0, opt2.scratch, grad, tl64)
     opt2.step_count += 200
     torch.cuda.synchronize()
-    pairs64 = 200 * 64 / (time.perf_counter() - t0)
+    t64 = time.perf_counter() - t0
+    pairs64 = 200 * 64 / t64
+    # log_prob throughput (BASELINE.md B3 counterpart): rows/s over the test catalogue, raw density
+    Tt = torch.as_tensor(th_test, dtype=torch.float32).to(dev)
+    reps_lp = max(1, 200_000 // max(M, 1))
+    Xl, Tl = X.repeat(reps_lp, 1), Tt.repeat(reps_lp, 1)
+    flow.log_prob(Tl, Xl)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        flow.log_prob(Tl, Xl)
+    torch.cuda.synchronize()
+    lp_rows = 10 * Xl.shape[0] / (time.perf_counter() - t0)
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
+    f_train = 3.0 * wl["f_lp"]   # a training step costs 3x the log_prob figure per row
+    train_tf = f_train * B / (train_kernel_ms * 1e-3) / 1e12
+    ttraffic, ttraffic_src = pmc_traffic("train") if a.workload == "maf_cfg2" else (None, None)
+    kname = (("k_maf_samp16<NB,SPAN>" if desc.get("m16_ok") and not a.hidden_bf16 else "k_sample_persist<MafOps>")
+             if wl["kind"] == "maf" else "k_sample_persist<NsfOps>")
     rec = {
         "metric": "posterior samples/sec (accepted, prior-box rejection included)",
-        "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "value": value, "unit": "samples/s", "n_gpus": world, "rccl_ranks": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * t_samp / a.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32" if not a.hidden_bf16 else "bf16 hidden-layer MFMA operands, f32 elsewhere",
         "data": "synthetic",
@@ -330,42 +468,46 @@ def main():
                    "name": a.workload,
                    "galaxies_per_gpu": M, "draws_per_galaxy": S, "theta_dim": D, "filters": C,
                    "parallelism": f"rows sharded over {world} GPU(s), no collective",
-                   "acceptance": accept, "fit_steps": a.fit_steps, "fit_final_loss": fit_loss, "rounds_per_step": rounds[0] / a.steps,
-                   "unfilled_slots": unfilled},
-        "roofline": {"bound": "mfma", "kernel": (("k_maf_inv16<NB>" if flow.describe().get("m16_ok") and not a.hidden_bf16 else "k_inverse<MafOps<HT,1,LDS>>")
-                                           if wl["kind"] == "maf" else "k_inverse<NsfOps<HT,PT,1,LDS>>")
-                               + " (dense round 0)",
-                     "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                   "backend": "rccl" if not gloo else backend,
+                   "first_attempt_acceptance": accept, "fit_steps": a.fit_steps, "fit_final_loss": fit_loss,
+                   "launches_per_step": launches[0] / a.steps, "unfilled_slots": unfilled_all,
+                   "flow_evaluations_per_step": evals_per_launch},
+        "roofline": {"bound": "mfma", "kernel": kname + " (persistent: first attempts + retries in one launch)",
+                     "achieved": useful, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": useful / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": 4.0 * D * M * S + 4.0 * C * M,
-                     "launch_ms": k0_ms, "flops_per_launch": flops_launch,
-                     "note": ("achieved = SURVEY 8d contract FLOPs of the REFERENCE algorithm (D full MADE passes per "
-                              "transform: 175150 mask-aware FLOP/draw; the 5000 FLOP/galaxy context part runs once per "
-                              "step in the context-table kernel) / measured launch time. The kernel produces the same "
-                              "draws with an incremental inverse that needs ~1/3 of those FLOPs, so frac can exceed 1: "
-                              "it is an algorithmic speed-up, not hardware utilisation. Hardware utilisation is "
-                              "executed_mfma_frac (dense padded MFMA FLOPs actually issued / fp32 MFMA peak); fp32 MFMA "
-                              "and VALU do not co-execute on gfx950 (SQ_VALU_MFMA_COEXEC_CYCLES = 0, profiles/), so the "
-                              "ceiling for this kernel is MFMA-busy + VALU-busy <= 1 (profiles/*_pmc_summary.json). "
-                              "minimal_* = mask-aware FLOPs of one MADE evaluation per transform (40030/draw).")
-                     if wl["kind"] == "maf" else
-                             "achieved uses the SURVEY 8d figure 148640 FLOP/draw (the 30000 FLOP/galaxy context part "
-                             "runs once per step in the context-table kernel); executed_* = dense padded MFMA FLOPs "
-                             "actually issued",
-                     "executed_mfma_flop_per_draw": exe_per_draw, "executed_mfma_tflops": executed,
+                     "launch_ms": k_ms, "flops_per_launch": f_min * accepted_per_launch,
+                     "accepted_draws_per_launch": accepted_per_launch,
+                     "note": "achieved = USEFUL work / measured kernel time: mask-aware FLOPs of ONE conditioner evaluation per "
+                             "transform (SURVEY 8d; MAF cfg1 40030 FLOP/draw -- the least any algorithm needs; the "
+                             "reference's D-pass inverse spends 175150) x ACCEPTED draws; rejected evaluations, tile "
+                             "padding and the per-galaxy context kernel are overhead.  executed_mfma_* = dense padded "
+                             "MFMA FLOPs the kernel issued over ALL evaluations; contract_* = SURVEY 8d's figure for the "
+                             "reference algorithm x accepted draws (an algorithmic ratio, can exceed 1).",
+                     "executed_mfma_flop_per_eval": executed_mfma_flops_per_eval(desc), "executed_mfma_tflops": executed,
                      "executed_mfma_frac": executed / PEAK_FP32_TFLOPS,
-                     "minimal_algorithm_tflops": minimal, "minimal_algorithm_frac": minimal / PEAK_FP32_TFLOPS},
+                     "contract_tflops": contract, "contract_ratio": contract / PEAK_FP32_TFLOPS},
+        "roofline_train": {"bound": "mfma", "kernel": "k_maf_train<HT>" if wl["kind"] == "maf" else "k_nsf_train<HT,PT>",
+                           "achieved": train_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                           "frac": train_tf / PEAK_FP32_TFLOPS, "traffic": ttraffic, "traffic_source": ttraffic_src,
+                           "launch_ms": train_kernel_ms, "rows_per_launch": B, "flops_per_launch": f_train * B,
+                           "algorithmic_bytes_per_launch": 4.0 * (D + C) * B + 4.0 * 2 * flat.numel(),
+                           "note": "3 x the log_prob figure per row (SURVEY 8d: forward + 2 x backward) / the flow kernel's "
+                                   "duration (HIP events on its stream, sf_flow_train_stats); prep / gather / Adam launches "
+                                   "are in train.ms_per_step, not here"},
         "train": {"metric": "flow-train theta.x pairs/sec (fwd+bwd+allreduce+clip+Adam)", "value": pairs,
                   "unit": "pairs/s", "per_gpu_batch": B, "steps": tsteps, "ms_per_step": 1e3 * t_train / tsteps,
-                  "achieved_tflops": pairs * 3 * wl["f_lp"] / 1e12,
-                  "batch64_pairs_per_s_1gpu": pairs64,
+                  "achieved_tflops": pairs * f_train / 1e12,
+                  "batch64_pairs_per_s_1gpu": pairs64, "batch64_ms_per_step": 1e3 * t64 / 200,
                   "strong_scaling": {"global_batch": Bs * world, "per_gpu_batch": Bs, "value": pairs_strong,
                                      "ms_per_step": 1e3 * t_strong / tsteps}},
+        "log_prob": {"value": lp_rows, "unit": "rows/s", "rows_per_call": int(Xl.shape[0]),
+                     "achieved_tflops": lp_rows * wl["f_lp"] / 1e12},
     }
     if world == 1 and not a.no_cpu_baseline:
-        rec["cpu_baseline"] = cpu_baseline(est.spec, flat.cpu().numpy(), x_test, prior.low.numpy(),
-                                           prior.high.numpy(), S, a.cpu_seconds)
-    print(json.dumps(rec))
+        rec["cpu_baseline"] = cpu_baseline(est.spec, flat.cpu().numpy(), x_test, th_test, prior.low.numpy(),
+                                           prior.high.numpy(), S, a.cpu_seconds, th_lib[tr], x_lib[tr])
+    print(json.dumps(rec), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

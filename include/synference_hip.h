@@ -155,17 +155,33 @@ int sf_flow_sample_round(sf_flow* f, const float* x /*[M,C]*/, int64_t S,
 int sf_flow_prepare_context(sf_flow* f, const float* x /*[M,C]*/, int64_t M, void* stream);
 int sf_flow_release_context(sf_flow* f);
 
-/* Whole sampler: runs rounds until every slot of x[0..M) x S is filled or max_attempts
- * rounds were used; unfilled rows are NaN (sbi_runner.py:6458-6460 convention).
- * Synchronises the stream between rounds (reads one counter).  n_drawn [M] may be NULL.
- * Returns the number of unfilled slots through *n_unfilled (host). */
+/* Whole sampler: ONE persistent launch works the catalogue's M*S output slots to the end -- first attempts and the
+ * retries of rejected slots go through a device-side work queue (no host round trip per rejection round).  Slots that
+ * are still empty after 64 attempts are continued in further launches with the attempt windows [64, 1024),
+ * [1024, 16384), ...:
+ *   max_attempts > 0 : hard ceiling; a slot that used max_attempts attempts becomes a NaN row
+ *                      (failure convention of ref: sbi_runner.py:6458-6460).
+ *   max_attempts <= 0: no ceiling, like [UPSTREAM] accept_reject_sample, which keeps drawing until S draws are kept:
+ *                      a slot is retried for as long as its galaxy still gets draws accepted; the open slots of a galaxy
+ *                      that got NOT ONE draw accepted during a whole window (acceptance zero to within
+ *                      1 / (window x open slots)) become NaN rows.
+ * The host synchronises the stream once per launch (one pinned read-back).  n_drawn [M] may be NULL: attempts consumed
+ * per galaxy.  *n_unfilled (host): number of NaN slots. */
 int sf_flow_sample(sf_flow* f, const float* x /*[M,C]*/, int64_t M, int64_t S,
                    const float* lo, const float* hi, uint64_t seed, int32_t max_attempts,
                    float* out /*[M,S,D]*/, int32_t* n_drawn /*[M]*/, int64_t* n_unfilled /*host*/,
                    void* stream);
 
-/* Figures of the last sf_flow_sample call (host [4]): duration of its dense round 0 in ms (HIP events on the call's
- * stream), number of rounds, slots rejected by round 0, flow evaluations over all rounds. */
+/* The same over an explicit list of output slots (slot = g*S + p; DEVICE uint32 [n_slots], each slot once): only those
+ * slots of out are written.  This is what an ensemble member runs on its share of every row's draws
+ * ([UPSTREAM] sbi EnsemblePosterior.sample, built at ref: custom_runner.py:278-283). */
+int sf_flow_sample_slots(sf_flow* f, const float* x /*[M,C]*/, int64_t M, int64_t S,
+                         const uint32_t* slots, int64_t n_slots, const float* lo, const float* hi, uint64_t seed,
+                         int32_t max_attempts, float* out /*[M,S,D]*/, int64_t* n_unfilled /*host*/, void* stream);
+
+/* Figures of the last sf_flow_sample / sf_flow_sample_slots call (host [4]): duration in ms of its first persistent
+ * launch (HIP events on the call's stream; the only launch unless some slot needed more than 64 attempts), number of
+ * launches, slots whose FIRST attempt was rejected, flow evaluations over all launches. */
 int sf_flow_sample_stats(const sf_flow* f, float* stats4);
 
 /* Accepted fraction of n unconstrained draws per row (stream_id 1): count[g] of n.
@@ -203,6 +219,12 @@ int sf_flow_loss_grad_rows(sf_flow* f, const float* flat, const float* theta /*[
 int sf_flow_loss_grad_weighted(sf_flow* f, const float* flat, const float* theta, const float* x,
                                int64_t B, float grad_scale, const float* weights /*[B]*/,
                                float* loss, float* grad, float* dctx /*[B,C]*/, void* stream);
+
+/* Measurement hook (bench.py's roofline_train): with profiling on, every sf_flow_loss_grad* call brackets its
+ * forward+backward flow kernel with HIP events on the call's stream; sf_flow_train_stats waits for the last such call
+ * and returns that kernel's duration in ms.  Off by default (two event records per step are not free at batch 64). */
+int sf_flow_set_profiling(sf_flow* f, int on);
+int sf_flow_train_stats(sf_flow* f, float* kernel_ms /*host*/);
 
 /* Fused global-norm clip + Adam / AdamW step on flat vectors.
  * Replaces: clip_grad_norm_(max_norm) + optimizer.step() (custom_runner.py:613-618). */
@@ -270,8 +292,9 @@ int sf_quantiles(const float* samples /*[N,S,D]*/, int64_t N, int64_t S, int32_t
                  const float* q /*[Q]*/, int32_t Q, float* out /*[N,D,Q]*/, void* stream);
 
 /* ---- feature transform on the device ------------------------------------------------------
- * mag = -2.5 log10(flux_nJy / 1000) + 23.9 ; negative flux or NaN -> mag_limit ; mag > mag_limit -> mag_limit
- * optional: mag_err = 2.5 err / (ln 10 flux).  All buffers [n] device, 16-byte aligned; err / mag_err may be NULL.
+ * mag = -2.5 log10(flux_nJy / 1000) + 23.9 ; negative flux -> mag_limit ; mag > mag_limit -> mag_limit ; NaN flux -> NaN
+ * optional: mag_err = 2.5 err / (ln 10 flux) exactly as the reference computes it (inf for flux == 0, negative for
+ * negative flux: the reference does not special-case them either).  All buffers [n] device, 16-byte aligned; err / mag_err may be NULL.
  * Replaces the numpy pass at ref: sbi_runner.py:1698-1716 (AB branch) and 1927-1932 (faint limit). */
 int sf_flux_to_abmag(const float* flux_njy, const float* err_njy, int64_t n, float mag_limit,
                      float* mag, float* mag_err, void* stream);

@@ -6,12 +6,16 @@ src/synference/sbi_runner.py:6438-6442 (sample) and :7193-7196 (log_prob), with 
 in-tree box predicate ``Interval.check`` (src/synference/custom_runner.py:982-987:
 ``low <= v <= high`` on every dimension).
 
-Schedule difference, stated once: sbi draws whole batches per galaxy and keeps the
-accepted rows until S are collected; here every output slot (galaxy g, draw p) is
-its own rejection sampler on the counter stream (slot, attempt=0,1,2,...).  Both
-deliver i.i.d. draws from the flow restricted to the prior box; the per-slot form
-is independent of batching, which is what lets the HIP sampler and this oracle
-agree draw for draw.
+Two samplers live here.
+``accept_reject_sample`` restates sbi's batch loop itself (first batch min(S, 10 000)
+proposals, later batches resized to 1.5 x remaining / acceptance, accepted rows kept in
+order until S are collected) on torch's own noise: the reference-shaped sampler that the
+distributional tests (two-sample KS, PIT) compare the HIP sampler with.
+``sample_slots`` / ``sample`` restate the product's schedule: every output slot
+(galaxy g, draw p) is its own rejection sampler on the counter stream
+(slot, attempt=0,1,2,...).  Both deliver i.i.d. draws from the flow restricted to the
+prior box; the per-slot form is independent of batching, which is what lets the HIP
+sampler and this oracle agree draw for draw.
 """
 from __future__ import annotations
 
@@ -33,12 +37,16 @@ def in_box(theta: np.ndarray, lo: Optional[np.ndarray], hi: Optional[np.ndarray]
 
 
 def sample_slots(spec: flows.FlowSpec, flat: torch.Tensor, x: np.ndarray, slots: np.ndarray,
-                 S: int, seed: int, lo=None, hi=None, max_attempts: int = 64, stream: int = 0,
+                 S: int, seed: int, lo=None, hi=None, max_attempts: Optional[int] = None, stream: int = 0,
                  dtype=torch.float32) -> Tuple[np.ndarray, np.ndarray]:
     """Draw one accepted sample for each slot id (slot = g*S + p).
 
-    Returns (theta[len(slots), D], attempts_used[len(slots)]); rows that exhaust
-    ``max_attempts`` are NaN (the reference's failure convention, sbi_runner.py:6458-6460).
+    ``max_attempts`` an integer: hard ceiling, rows that exhaust it are NaN (the reference's failure
+    convention, sbi_runner.py:6458-6460).  ``None``: no ceiling, as in [UPSTREAM] accept_reject_sample
+    -- with the product's progress rule (include/synference_hip.h, sf_flow_sample): attempts go in the
+    windows [0,64), [64,1024), [1024,16384), ...; after a window past the first, the open slots of a
+    galaxy that got no draw accepted during that window become NaN rows.
+    Returns (theta[len(slots), D], attempts_used[len(slots)]).
     """
     slots = np.asarray(slots, dtype=np.uint64)
     out = np.full((len(slots), spec.D), np.nan, dtype=np.float64)
@@ -47,24 +55,62 @@ def sample_slots(spec: flows.FlowSpec, flat: torch.Tensor, x: np.ndarray, slots:
     flat = flat.to(dtype)
     lo_ = None if lo is None else np.asarray(lo, dtype=np.float32)
     hi_ = None if hi is None else np.asarray(hi, dtype=np.float32)
-    for attempt in range(max_attempts):
-        if len(pending) == 0:
-            break
-        sl = slots[pending]
-        g = (sl // np.uint64(S)).astype(np.int64)
-        z = philox.normal(seed, sl, attempt, spec.D, stream=stream)
-        with torch.no_grad():
-            th, _ = flows.inverse_transform(spec, flat, torch.as_tensor(z).to(dtype),
-                                            torch.as_tensor(np.asarray(x)[g]).to(dtype))
-        th32 = th.to(torch.float32).numpy()
-        ok = in_box(th32, lo_, hi_)
-        out[pending[ok]] = th.numpy()[ok]
-        used[pending] += 1
-        pending = pending[~ok]
+    ceiling = int(max_attempts) if max_attempts else 1 << 30
+    attempt, limit, stage = 0, min(64, ceiling), 0
+    xs = np.asarray(x)
+    while len(pending) and attempt < ceiling:
+        progressed = set()
+        while attempt < limit and len(pending):
+            sl = slots[pending]
+            g = (sl // np.uint64(S)).astype(np.int64)
+            z = philox.normal(seed, sl, attempt, spec.D, stream=stream)
+            with torch.no_grad():
+                th, _ = flows.inverse_transform(spec, flat, torch.as_tensor(z).to(dtype),
+                                                torch.as_tensor(xs[g]).to(dtype))
+            ok = in_box(th.to(torch.float32).numpy(), lo_, hi_)
+            out[pending[ok]] = th.numpy()[ok]
+            used[pending] += 1
+            progressed.update(g[ok].tolist())
+            pending = pending[~ok]
+            attempt += 1
+        if not max_attempts and stage >= 1 and len(pending):
+            g = (slots[pending] // np.uint64(S)).astype(np.int64)
+            pending = pending[np.isin(g, list(progressed))]
+        stage += 1
+        limit = min(ceiling, limit * 16)
     return out, used
 
 
-def sample(spec, flat, x, S, seed, lo=None, hi=None, max_attempts=64, dtype=torch.float32):
+def accept_reject_sample(spec: flows.FlowSpec, flat: torch.Tensor, x_row: np.ndarray, S: int, lo, hi,
+                         generator: torch.Generator, max_sampling_batch_size: int = 10_000,
+                         warn_acceptance: float = 0.01, dtype=torch.float32):
+    """[UPSTREAM] sbi ``accept_reject_sample`` as ``DirectPosterior.sample((S,), x=x_row)`` runs it (reached from
+    ref: sbi_runner.py:6442; box predicate custom_runner.py:982-987): propose ``flow.sample(b, context=x_row)``
+    in batches, keep the rows inside the prior box, first batch min(S, 10 000), then
+    ``min(10 000, max(int(1.5 * remaining / acceptance), 100))``, until S are kept; the first S kept rows are
+    returned.  Returns (samples[S, D] float64, acceptance_rate, low_acceptance_warned)."""
+    flat = flat.to(dtype)
+    lo_ = np.asarray(lo, dtype=np.float32)
+    hi_ = np.asarray(hi, dtype=np.float32)
+    xr = torch.as_tensor(np.asarray(x_row)).to(dtype).reshape(1, -1)
+    kept, n_kept, n_total, warned = [], 0, 0, False
+    bs = min(S, max_sampling_batch_size)
+    while n_kept < S:
+        z = torch.randn(bs, spec.D, generator=generator, dtype=torch.float64).to(dtype)
+        with torch.no_grad():
+            th, _ = flows.inverse_transform(spec, flat, z, xr.expand(bs, -1))
+        ok = in_box(th.to(torch.float32).numpy(), lo_, hi_)
+        kept.append(th.double().numpy()[ok])
+        n_kept += int(ok.sum())
+        n_total += bs
+        rate = n_kept / n_total
+        bs = min(max_sampling_batch_size, max(int(1.5 * (S - n_kept) / max(rate, 1e-12)), 100))
+        if n_total > 1000 and rate < warn_acceptance:
+            warned = True
+    return np.concatenate(kept, 0)[:S], n_kept / n_total, warned
+
+
+def sample(spec, flat, x, S, seed, lo=None, hi=None, max_attempts=None, dtype=torch.float32):
     """``posterior.sample((S,), x=x[g])`` for every row g -> (samples[M,S,D], n_drawn[M])."""
     M = len(x)
     th, used = sample_slots(spec, flat, x, np.arange(M * S, dtype=np.uint64), S, seed, lo, hi,

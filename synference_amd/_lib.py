@@ -68,6 +68,8 @@ PROTOTYPES = {
     "sf_flow_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                  C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64),
                                  C.c_void_p]),
+    "sf_flow_sample_slots": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                       C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
     "sf_flow_sample_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "sf_flow_acceptance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                      C.c_uint64, C.c_void_p, C.c_void_p]),
@@ -82,6 +84,8 @@ PROTOTYPES = {
     "sf_flow_loss_grad_weighted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                              C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p]),
+    "sf_flow_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "sf_flow_train_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "sf_opt_create": (C.c_int, [C.c_int64, C.POINTER(sf_adam_desc), C.POINTER(C.c_void_p)]),
     "sf_opt_destroy": (None, [C.c_void_p]),
     "sf_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),

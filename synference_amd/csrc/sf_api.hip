@@ -92,10 +92,11 @@ void sf_flow_destroy(sf_flow* f) {
   if (!f) return;
   if (f->dev_ready) {
     (void)hipFree(f->d_packed); (void)hipFree(f->d_packedT); (void)hipFree(f->d_cst); (void)hipFree(f->d_packedB); (void)hipFree(f->d_bsrc);
-    (void)hipHostFree(f->h_cnt); if (f->ev_dense[0]) (void)hipEventDestroy(f->ev_dense[0]); if (f->ev_dense[1]) (void)hipEventDestroy(f->ev_dense[1]);
+    (void)hipHostFree(f->h_cnt); if (f->ev_train[0]) (void)hipEventDestroy(f->ev_train[0]); if (f->ev_train[1]) (void)hipEventDestroy(f->ev_train[1]); if (f->ev_dense[0]) (void)hipEventDestroy(f->ev_dense[0]); if (f->ev_dense[1]) (void)hipEventDestroy(f->ev_dense[1]);
     (void)hipFree(f->d_ctab); (void)hipFree(f->d_packed16); (void)hipFree(f->d_s16a); (void)hipFree(f->d_s16b);
     (void)hipFree(f->d_s1); (void)hipFree(f->d_s2); (void)hipFree(f->d_t1); (void)hipFree(f->d_t2);
     (void)hipFree(f->d_flat); (void)hipFree(f->d_gpacked); (void)hipFree(f->d_gdst);
+    (void)hipFree(f->d_queue); (void)hipFree(f->d_ring); (void)hipFree(f->d_galacc); (void)hipHostFree(f->h_queue);
     (void)hipFree(f->d_act); (void)hipFree(f->d_rej[0]); (void)hipFree(f->d_rej[1]); (void)hipFree(f->d_cnt);
   }
   delete f;
@@ -313,6 +314,112 @@ int sf_flow_sample_round(sf_flow* f, const float* x, int64_t S, const uint32_t* 
   return SF_OK;
 }
 
+// ---- persistent sampler ------------------------------------------------------------------------
+// Stages of one sampling call.  Stage 1 resolves the dense slot list (first attempts and their retries, attempts
+// [0, 64)) in ONE persistent launch; slots that are still empty afterwards ("survivors": the flow's mass for that
+// galaxy lies almost entirely outside the prior box) go through further launches with the attempt window
+// [64, 1024), [1024, 16384), ... until they are filled, the caller's ceiling `max_attempts` is reached, or -- when
+// the caller set no ceiling (max_attempts <= 0) -- a galaxy got NOT ONE draw accepted during a whole window: its
+// acceptance is then zero to within 1 / (window x open slots) and its open slots become NaN rows, which is what the
+// reference's timeout / error path produces (ref: sbi_runner.py:6443-6460); [UPSTREAM] accept_reject_sample itself
+// would loop forever on such a galaxy.
+static int ensure_queue(sf_flow* f, int64_t n_slots, int64_t M) {
+  if (!f->d_queue) SF_HIP(hipMalloc(&f->d_queue, sizeof(SfQueue)));
+  if (!f->h_queue) SF_HIP(hipHostMalloc((void**)&f->h_queue, sizeof(SfQueue), hipHostMallocDefault));
+  uint64_t cap = 1u << 16;
+  while (cap < (uint64_t)n_slots) cap <<= 1;
+  if (f->ring_cap < cap) {
+    (void)hipFree(f->d_ring);
+    f->d_ring = nullptr; f->ring_cap = 0;
+    SF_HIP(hipMalloc(&f->d_ring, cap * sizeof(unsigned long long)));
+    SF_HIP(hipMemset(f->d_ring, 0, cap * sizeof(unsigned long long)));  // consumers clear what they take: stays zero
+    f->ring_cap = cap;
+  }
+  if (f->rej_cap < (size_t)n_slots) {
+    (void)hipFree(f->d_rej[0]); (void)hipFree(f->d_rej[1]);
+    f->d_rej[0] = f->d_rej[1] = nullptr; f->rej_cap = 0;
+    SF_HIP(hipMalloc(&f->d_rej[0], (size_t)n_slots * sizeof(uint32_t)));
+    SF_HIP(hipMalloc(&f->d_rej[1], (size_t)n_slots * sizeof(uint32_t)));
+    f->rej_cap = (size_t)n_slots;
+  }
+  if (f->galacc_cap < (size_t)M) {
+    (void)hipFree(f->d_galacc);
+    f->d_galacc = nullptr; f->galacc_cap = 0;
+    SF_HIP(hipMalloc(&f->d_galacc, (size_t)M * sizeof(int32_t)));
+    f->galacc_cap = (size_t)M;
+  }
+  return SF_OK;
+}
+
+// x [M,C]; slots: device list of n_slots output slots (NULL = all of 0 .. M*S-1); see sf_flow_sample_slots
+static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, const uint32_t* slots, int64_t n_slots,
+                             const float* lo, const float* hi, uint64_t seed, int32_t max_attempts, float* out,
+                             int32_t* n_drawn, int64_t* n_unfilled, hipStream_t st) {
+  if (n_unfilled) *n_unfilled = 0;
+  if (n_slots == 0) return SF_OK;
+  if ((uint64_t)(M * S) > 0xfff00000ull) return fail(SF_ERR_INVALID, "M*S must stay below 2^32 - 2^20: split the catalogue");
+  int rc = ensure_queue(f, n_slots, M);
+  if (rc) return rc;
+  const bool capped = max_attempts > 0;
+  const uint32_t ceiling = capped ? (uint32_t)max_attempts : 0x40000000u;
+  {
+    rc = sf_flow_prepare_context(f, x, M, (void*)st);
+    if (rc) return rc;
+  }
+  const SfDev m = sampler_dev(f, x);
+  SfSampleArgsHost a;
+  a.x = x; a.S = (long)S; seed_keys(seed, 0, a.k0, a.k1);
+  a.lo = lo; a.hi = hi; a.out = out; a.n_drawn = n_drawn;
+  a.q = f->d_queue; a.ring = f->d_ring; a.ring_mask = (uint32_t)(f->ring_cap - 1);
+  const uint32_t* cur = slots;
+  int64_t pending = n_slots;
+  uint32_t attempt = 0, limit = ceiling < 64u ? ceiling : 64u;
+  int buf = 0, stage = 0;
+  double evals = 0.0;
+  float rej0 = 0.f;
+  int64_t dropped = 0;
+  while (pending > 0) {
+    SF_HIP(hipMemsetAsync(f->d_queue, 0, sizeof(SfQueue), st));
+    const bool progress_rule = !capped && stage >= 1;
+    if (progress_rule) SF_HIP(hipMemsetAsync(f->d_galacc, 0, (size_t)M * sizeof(int32_t), st));
+    a.slots = cur; a.slot_base = 0; a.n_items = (long)pending; a.n_total = (uint32_t)pending;
+    a.attempt = attempt; a.attempt_limit = limit; a.attempts_per_slot = 1;
+    a.rejected = f->d_rej[buf];
+    a.gal_acc = progress_rule ? f->d_galacc : nullptr;
+    if (stage == 0) SF_HIP(hipEventRecord(f->ev_dense[0], st));
+    hipError_t e = sf_launch_inverse(m, a, st);
+    if (e != hipSuccess) { f->ctab_x = nullptr; return hip_fail(e, "persistent sampler launch"); }
+    if (stage == 0) SF_HIP(hipEventRecord(f->ev_dense[1], st));
+    if (progress_rule)  // drop the open slots of galaxies that made no progress in this window (NaN rows), in place
+      SF_HIP(sf_launch_filter_survivors(f->d_rej[buf], &f->d_queue->n_surv, (long)S, f->d_galacc, out, f->L.dev.D, st));
+    SF_HIP(hipMemcpyAsync(f->h_queue, f->d_queue, sizeof(SfQueue), hipMemcpyDeviceToHost, st));  // pinned
+    SF_HIP(hipStreamSynchronize(st));
+    if (f->h_queue->error) {
+      f->ctab_x = nullptr;
+      return fail(SF_ERR_STATE, "persistent sampler: a device-side wait exceeded its bound (work queue inconsistent)");
+    }
+    evals += (double)f->h_queue->evals;
+    dropped += (int64_t)f->h_queue->dropped;
+    if (stage == 0) rej0 = (float)f->h_queue->rej0;
+    pending = (int64_t)f->h_queue->n_surv;
+    cur = f->d_rej[buf];
+    buf ^= 1;
+    ++stage;
+    attempt = limit;
+    if (limit >= ceiling) break;
+    limit = (limit > ceiling / 16u) ? ceiling : limit * 16u;
+  }
+  {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, f->ev_dense[0], f->ev_dense[1]) != hipSuccess) ms = 0.f;
+    f->last_stats[0] = ms; f->last_stats[1] = (float)stage; f->last_stats[2] = rej0; f->last_stats[3] = (float)evals;
+  }
+  f->ctab_x = nullptr;
+  if (pending > 0) SF_HIP(sf_launch_fill_nan_rows(out, cur, (long)pending, f->L.dev.D, st));
+  if (n_unfilled) *n_unfilled = pending + dropped;
+  return SF_OK;
+}
+
 int sf_flow_sample(sf_flow* f, const float* x, int64_t M, int64_t S, const float* lo, const float* hi,
                    uint64_t seed, int32_t max_attempts, float* out, int32_t* n_drawn, int64_t* n_unfilled,
                    void* stream) {
@@ -322,70 +429,24 @@ int sf_flow_sample(sf_flow* f, const float* x, int64_t M, int64_t S, const float
   if (!x || !out) return fail(SF_ERR_INVALID, "null argument");
   if (!f->params_set) return fail(SF_ERR_STATE, "sf_flow_set_params has not been called");
   if (M < 0 || S < 1) return fail(SF_ERR_INVALID, "bad M or S");
-  if (max_attempts < 1) max_attempts = 1;
-  const int64_t total = M * S;
-  if (n_unfilled) *n_unfilled = 0;
-  if (total == 0) return SF_OK;
-  if ((uint64_t)total > 0xffffffffull) return fail(SF_ERR_INVALID, "M*S must fit 32 bits: split the catalogue");
+  if ((lo == nullptr) != (hi == nullptr)) return fail(SF_ERR_INVALID, "lo and hi must be given together");
   hipStream_t st = (hipStream_t)stream;
-  // Rejected-slot lists: sized for the worst case of round 0 lazily -- start at total/4 and fall
-  // back to a full-size list only when a round would overflow it.
-  size_t need = (size_t)total;
-  if (f->rej_cap < need) {
-    (void)hipFree(f->d_rej[0]); (void)hipFree(f->d_rej[1]);
-    f->d_rej[0] = f->d_rej[1] = nullptr;
-    SF_HIP(hipMalloc(&f->d_rej[0], need * sizeof(uint32_t)));
-    SF_HIP(hipMalloc(&f->d_rej[1], need * sizeof(uint32_t)));
-    f->rej_cap = need;
-  }
   if (n_drawn) SF_HIP(sf_launch_fill_i32(n_drawn, (long)M, (int32_t)S, st));
-  {
-    int rc = sf_flow_prepare_context(f, x, M, stream);
-    if (rc) return rc;
-  }
-  int64_t pending = total;
-  const uint32_t* cur = nullptr;
-  int buf = 0;
-  int attempt = 0;
-  int round = 0;
-  double items = 0.0;
-  float rej0 = 0.f;
-  SF_HIP(hipMemsetAsync(f->d_cnt, 0, SF_MAX_ROUNDS * sizeof(uint32_t), st));  // one counter per round
-  while (attempt < max_attempts && pending > 0) {
-    // round 0: one attempt per slot; retry rounds: several attempts per pending slot (at most 16: the 16-row
-    // kernel resolves a slot inside one 16-draw tile) so that the tail needs only a few launches; the
-    // speculation budget is the work a latency-bound round can absorb
-    int A = 1;
-    if (attempt > 0) {
-      const int64_t budget = 262144;
-      while (A < 16 && (int64_t)(2 * A) * pending <= budget && attempt + 2 * A <= max_attempts) A *= 2;
-    }
-    uint32_t* cnt = f->d_cnt + (round % SF_MAX_ROUNDS);
-    if (round > 0 && round % SF_MAX_ROUNDS == 0) SF_HIP(hipMemsetAsync(f->d_cnt, 0, SF_MAX_ROUNDS * sizeof(uint32_t), st));
-    if (round == 0) SF_HIP(hipEventRecord(f->ev_dense[0], st));
-    int rc = sf_flow_sample_round(f, x, S, cur, 0, pending, (uint32_t)attempt, A, seed, 0, lo, hi, out,
-                                  f->d_rej[buf], cnt, n_drawn, stream);
-    if (rc) { f->ctab_x = nullptr; return rc; }
-    if (round == 0) SF_HIP(hipEventRecord(f->ev_dense[1], st));
-    SF_HIP(hipMemcpyAsync(f->h_cnt, cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, st));  // pinned: no staging copy
-    SF_HIP(hipStreamSynchronize(st));
-    items += (double)pending * A;
-    pending = f->h_cnt[0];
-    if (round == 0) rej0 = (float)pending;
-    cur = f->d_rej[buf];
-    buf ^= 1;
-    attempt += A;
-    ++round;
-  }
-  {
-    float ms = 0.f;
-    if (round > 0 && hipEventElapsedTime(&ms, f->ev_dense[0], f->ev_dense[1]) != hipSuccess) ms = 0.f;
-    f->last_stats[0] = ms; f->last_stats[1] = (float)round; f->last_stats[2] = rej0; f->last_stats[3] = (float)items;
-  }
-  f->ctab_x = nullptr;
-  if (pending > 0) SF_HIP(sf_launch_fill_nan_rows(out, cur, (long)pending, f->L.dev.D, st));
-  if (n_unfilled) *n_unfilled = pending;
-  return SF_OK;
+  return sample_persistent(f, x, M, S, nullptr, M * S, lo, hi, seed, max_attempts, out, n_drawn, n_unfilled, st);
+}
+
+int sf_flow_sample_slots(sf_flow* f, const float* x, int64_t M, int64_t S, const uint32_t* slots, int64_t n_slots,
+                         const float* lo, const float* hi, uint64_t seed, int32_t max_attempts, float* out,
+                         int64_t* n_unfilled, void* stream) {
+  if (!f) return fail(SF_ERR_INVALID, "null handle");
+  if (n_unfilled) *n_unfilled = 0;
+  if (n_slots == 0) return SF_OK;
+  if (!x || !out || !slots) return fail(SF_ERR_INVALID, "null argument");
+  if (!f->params_set) return fail(SF_ERR_STATE, "sf_flow_set_params has not been called");
+  if (M < 1 || S < 1 || n_slots < 0 || n_slots > M * S) return fail(SF_ERR_INVALID, "bad M, S or n_slots");
+  if ((lo == nullptr) != (hi == nullptr)) return fail(SF_ERR_INVALID, "lo and hi must be given together");
+  return sample_persistent(f, x, M, S, slots, n_slots, lo, hi, seed, max_attempts, out, nullptr, n_unfilled,
+                           (hipStream_t)stream);
 }
 
 int sf_flow_sample_stats(const sf_flow* f, float* stats4) {
@@ -469,6 +530,21 @@ int sf_flow_train_epoch(sf_flow* f, float* flat, const float* theta, const float
   return SF_OK;
 }
 
+int sf_flow_set_profiling(sf_flow* f, int on) {
+  if (!f) return fail(SF_ERR_INVALID, "null handle");
+  f->profiling = on != 0;
+  f->ev_train_valid = false;
+  return SF_OK;
+}
+
+int sf_flow_train_stats(sf_flow* f, float* kernel_ms) {
+  if (!f || !kernel_ms) return fail(SF_ERR_INVALID, "null argument");
+  if (!f->profiling || !f->ev_train_valid) return fail(SF_ERR_STATE, "no profiled training call yet (sf_flow_set_profiling)");
+  SF_HIP(hipEventSynchronize(f->ev_train[1]));
+  SF_HIP(hipEventElapsedTime(kernel_ms, f->ev_train[0], f->ev_train[1]));
+  return SF_OK;
+}
+
 int sf_flow_loss_grad(sf_flow* f, const float* flat, const float* theta, const float* x, int64_t B,
                       float grad_scale, float* loss, float* grad, void* stream) {
   return sf_flow_loss_grad_weighted(f, flat, theta, x, B, grad_scale, nullptr, loss, grad, nullptr, stream);
@@ -487,6 +563,7 @@ struct sf_opt {
   int64_t step = 0;
 };
 
+void sf_opt_destroy(sf_opt* o);
 int sf_opt_create(int64_t n, const sf_adam_desc* d, sf_opt** out) {
   if (n < 1 || !d || !out) return fail(SF_ERR_INVALID, "bad argument");
   int nd = 0;
@@ -494,11 +571,15 @@ int sf_opt_create(int64_t n, const sf_adam_desc* d, sf_opt** out) {
   sf_opt* o = new sf_opt();
   o->n = n;
   o->d = *d;
-  SF_HIP(hipMalloc(&o->m, (size_t)n * sizeof(float)));
-  SF_HIP(hipMalloc(&o->v, (size_t)n * sizeof(float)));
-  SF_HIP(hipMalloc(&o->norm, sizeof(float)));
-  SF_HIP(hipMemset(o->m, 0, (size_t)n * sizeof(float)));
-  SF_HIP(hipMemset(o->v, 0, (size_t)n * sizeof(float)));
+  hipError_t e = hipMalloc(&o->m, (size_t)n * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&o->v, (size_t)n * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&o->norm, sizeof(float));
+  if (e == hipSuccess) e = hipMemset(o->m, 0, (size_t)n * sizeof(float));
+  if (e == hipSuccess) e = hipMemset(o->v, 0, (size_t)n * sizeof(float));
+  if (e != hipSuccess) {
+    sf_opt_destroy(o);
+    return hip_fail(e, "sf_opt_create");
+  }
   *out = o;
   return SF_OK;
 }

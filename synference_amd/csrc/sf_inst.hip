@@ -25,17 +25,58 @@ static inline int sf_lds_wpb(size_t shmem_bytes) {
 }
 
 template <class K>
-static hipError_t set_shmem(K kernel, size_t bytes, bool& done) {
-  if (done) return hipSuccess;
+static hipError_t set_shmem(K kernel, size_t bytes, SfAttrCache& done) {
+  int dev;
+  if (!done.need(dev)) return hipSuccess;
   hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess) done = true;
+  if (e == hipSuccess) done.set(dev);
   return e;
+}
+
+
+// ---- persistent sampler launches (a.q != nullptr): grid = what the chip holds at once ------------------------
+static int sf_cu_count() {
+  int dev = 0;
+  hipDeviceProp_t pr;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+    return pr.multiProcessorCount;
+  return 256;
+}
+template <class Ops, int NS, bool LDSW, int WPB>
+static hipError_t launch_persist_w(const SfDev& m, const SfSampleArgsHost& a, size_t image_bytes, hipStream_t st) {
+  static SfAttrCache attr;
+  static int resident = 0;
+  constexpr int IPW = WPB * 32 * NS;
+  const size_t sh = image_bytes + SF_Q_WORDS(IPW) * sizeof(unsigned int);
+  hipError_t e = set_shmem(k_sample_persist<Ops, NS, LDSW, WPB>, sh, attr);
+  if (e != hipSuccess) return e;
+  if (!resident) {
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_sample_persist<Ops, NS, LDSW, WPB>, 64 * WPB, sh) !=
+            hipSuccess || occ < 1)
+      occ = 1;
+    resident = sf_cu_count() * occ;
+  }
+  long grid = (a.n_items + IPW - 1) / IPW;
+  if (grid > resident) grid = resident;
+  SfSampArgs args;
+  args.m = m;
+  args.a = a;
+  hipLaunchKernelGGL((k_sample_persist<Ops, NS, LDSW, WPB>), dim3((unsigned)grid), dim3(64 * WPB), sh, st, args,
+                     (int)(image_bytes / sizeof(float)));
+  return hipGetLastError();
+}
+template <class OpsL>
+static hipError_t launch_persist_lds(const SfDev& m, const SfSampleArgsHost& a, size_t image_bytes, hipStream_t st) {
+  image_bytes = (image_bytes + 15) & ~(size_t)15;
+  if (sf_lds_wpb(image_bytes + SF_Q_WORDS(128) * sizeof(unsigned int)) == 4) return launch_persist_w<OpsL, 1, true, 4>(m, a, image_bytes, st);
+  return launch_persist_w<OpsL, 1, true, 8>(m, a, image_bytes, st);
 }
 
 template <class OpsB>
 static hipError_t launch_logprob_bf16(const SfDev& m, const float* theta, const float* x, long B, float* out,
                                       hipStream_t st) {
-  static bool attr = false;
+  static SfAttrCache attr;
   const size_t sh = (size_t)m.part_max * sizeof(float) + (size_t)m.tB_stride * sizeof(unsigned short);
   hipError_t e = set_shmem(k_logprob<OpsB, 1, true>, sh, attr);
   if (e != hipSuccess) return e;
@@ -46,8 +87,9 @@ static hipError_t launch_logprob_bf16(const SfDev& m, const float* theta, const 
 }
 template <class OpsB>
 static hipError_t launch_inverse_bf16(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
-  static bool attr = false;
+  static SfAttrCache attr;
   const size_t sh = (size_t)m.part_max * sizeof(float) + (size_t)m.tB_stride * sizeof(unsigned short);
+  if (a.q) return launch_persist_lds<OpsB>(m, a, sh, st);
   hipError_t e = set_shmem(k_inverse<OpsB, 1, true>, sh, attr);
   if (e != hipSuccess) return e;
   const int wpb = sf_lds_wpb(sh);
@@ -60,7 +102,7 @@ template <class OpsG, class OpsL, int NS>
 static hipError_t launch_logprob(const SfDev& m, const float* theta, const float* x, long B, float* out,
                                  hipStream_t st) {
   if (sf_fits_lds(m)) {
-    static bool attr = false;
+    static SfAttrCache attr;
     const size_t sh = (size_t)m.part_max * sizeof(float);
     hipError_t e = set_shmem(k_logprob<OpsL, NS, true>, sh, attr);
     if (e != hipSuccess) return e;
@@ -77,8 +119,14 @@ static hipError_t launch_logprob(const SfDev& m, const float* theta, const float
 }
 template <class OpsG, class OpsL, int NS>
 static hipError_t launch_inverse(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
+  if constexpr (NS == 1) {
+    if (a.q) {  // persistent sampler (one 32-sample tile per wave)
+      if (sf_fits_lds(m)) return launch_persist_lds<OpsL>(m, a, (size_t)m.part_max * sizeof(float), st);
+      return launch_persist_w<OpsG, 1, false, 4>(m, a, 0, st);
+    }
+  }
   if (sf_fits_lds(m)) {
-    static bool attr = false;
+    static SfAttrCache attr;
     const size_t sh = (size_t)m.part_max * sizeof(float);
     hipError_t e = set_shmem(k_inverse<OpsL, NS, true>, sh, attr);
     if (e != hipSuccess) return e;
@@ -134,7 +182,7 @@ hipError_t SF_CAT(sf_launch_inverse_k, SF_KIND, _h, SF_HT)(const SfDev& m, int n
                                                            hipStream_t st) {
   if (m.hidden_bf16) SF_BF_SWITCH(launch_inverse_bf16, m, a, st)
 #if SF_HT <= 2
-  if (ns == 2) SF_PT_SWITCH(2, launch_inverse, m, a, st)
+  if (ns == 2 && !a.q) SF_PT_SWITCH(2, launch_inverse, m, a, st)
 #endif
   SF_PT_SWITCH(1, launch_inverse, m, a, st)
 }

@@ -168,6 +168,132 @@ __global__ __launch_bounds__(LDSW ? 512 : 256) void k_inverse(SfDev m, SfSampleA
 
 
 // ---------------------------------------------------------------------------------------------
+// Persistent sampler on the 32-row engine (NSF; MAF shapes the 16-row kernel does not take): the tile pipeline of
+// k_inverse driven by the device work queue (sf_queue.h) -- ONE launch resolves every slot, first attempts and
+// retries.  Sampler only.  Argument blocks are read through the laundered kernarg pointer (see k_maf_samp16).
+// ---------------------------------------------------------------------------------------------
+struct SfSampArgs {
+  SfDev m;
+  SfSampleArgsHost a;
+};
+
+template <class Ops, int NS, bool LDSW, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_sample_persist(SfSampArgs args_in, int ctrl_off) {
+  constexpr int IPW = WPB * 32 * NS;
+  const int wave = threadIdx.x >> 6;
+  unsigned int* ctrl = reinterpret_cast<unsigned int*>(sf_lds_image + ctrl_off);
+  if (threadIdx.x < SF_Q_HDR) ctrl[threadIdx.x] = 0u;
+  for (;;) {
+    const SfSampArgs* ap;
+    {
+      auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(kp));
+      ap = (const SfSampArgs*)kp;
+    }
+    const SfDev& m = ap->m;
+    const SfSampleArgsHost& a = ap->a;
+    const int lane = (threadIdx.x & 63) + sf_opaque_zero();
+    const int c = lane & 31, h = lane >> 5;
+    if (!sf_q_fetch<IPW, 32>(a, ctrl)) break;
+    float u[NS][SF_DMAX];
+    const float* xr[NS];
+    float logdet[NS];
+    const float* cg[NS];
+    const bool use_tab = m.ctab != nullptr;
+    {
+      const unsigned int n_ent = ctrl[0];
+      const int lgA = (int)ctrl[1];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        const int wi = (wave * NS + ns) * 32 + c;
+        const unsigned int e = (unsigned)wi >> lgA;
+        const unsigned int ee = e < n_ent ? e : 0u;
+        const uint32_t slot = ctrl[SF_Q_HDR + ee];
+        const uint32_t att = ctrl[SF_Q_HDR + IPW + ee] + ((unsigned)wi & ((1u << lgA) - 1u));
+        const long gal = (long)(slot / (uint32_t)a.S);
+        logdet[ns] = 0.f;
+#pragma unroll
+        for (int p = 0; p < SF_DMAX; ++p) u[ns][p] = 0.f;
+#pragma unroll
+        for (int blk = 0; blk < SF_DMAX / 4; ++blk)
+          if (blk * 4 < m.D) {
+            float z4[4];
+            sf_normal4(a.k0, a.k1, (uint64_t)slot, att, (uint32_t)blk, z4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u[ns][blk * 4 + j] = (blk * 4 + j < m.D) ? z4[j] : 0.f;
+          }
+        xr[ns] = a.x + gal * m.C;
+        cg[ns] = use_tab ? m.ctab + (size_t)gal * m.T * m.ctab_NV * m.ctab_R : nullptr;
+      }
+    }
+    Ops::inverse(m, u, xr, logdet, lane, sf_lds_image, use_tab ? &cg : nullptr);
+    const unsigned int n_ent = ctrl[0];
+    const int lgA = (int)ctrl[1];
+    const int A = 1 << lgA;
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+      float th[SF_DMAX];
+      bool ok = true;
+#pragma unroll
+      for (int p = 0; p < SF_DMAX; ++p)
+        if (p < m.D) {
+          const int td = (int)m.cst[m.c_tdim + p];
+          th[p] = (u[ns][p] - m.cst[m.c_pshift + p]) / m.cst[m.c_pscale + p];
+          ok = ok && (fabsf(th[p]) <= 3.0e38f);  // finite (NaN compares false)
+          if (a.lo) ok = ok && (th[p] >= a.lo[td]) && (th[p] <= a.hi[td]);
+        }
+      const int wi = (wave * NS + ns) * 32 + c;
+      const unsigned int e = (unsigned)wi >> lgA;
+      const bool entry_ok = e < n_ent;
+      const unsigned int ee = entry_ok ? e : 0u;
+      const uint32_t slot = ctrl[SF_Q_HDR + ee];
+      const uint32_t att_base = ctrl[SF_Q_HDR + IPW + ee];
+      const uint32_t att = att_base + ((unsigned)wi & ((1u << lgA) - 1u));
+      const bool valid = entry_ok && att < a.attempt_limit;
+      // A consecutive lanes hold attempts att_base .. att_base+A-1 of one slot: the lowest accepted one wins
+      const unsigned long long bal = __ballot(valid && h == 0 && ok);
+      const int grp0 = (c / A) * A;
+      const uint32_t gmask = (uint32_t)((bal >> grp0) & ((A >= 32) ? 0xffffffffull : ((1ull << A) - 1ull)));
+      const int first = gmask ? (int)__builtin_ctz(gmask) : -1;
+      const int me = c - grp0;
+      if (valid && h == 0 && ok && me == first) {
+#pragma unroll
+        for (int p = 0; p < SF_DMAX; ++p)
+          if (p < m.D) a.out[(size_t)slot * m.D + (int)m.cst[m.c_tdim + p]] = th[p];
+      }
+      const bool leader = entry_ok && h == 0 && me == 0;
+      const uint32_t room = a.attempt_limit > att_base ? a.attempt_limit - att_base : 0u;
+      const uint32_t tried = room < (uint32_t)A ? room : (uint32_t)A;
+      const bool hit = leader && first >= 0;
+      const bool retry = leader && first < 0 && att_base + (uint32_t)A < a.attempt_limit;
+      const bool surv = leader && first < 0 && !retry;
+      if (leader && (a.n_drawn || a.gal_acc)) {
+        const long gal = (long)(slot / (uint32_t)a.S);
+        if (a.n_drawn && att_base > 0) atomicAdd(&a.n_drawn[gal], first >= 0 ? first + 1 : (int)tried);
+        if (hit && a.gal_acc) atomicAdd(&a.gal_acc[gal], 1);
+      }
+      if (retry) {
+        const unsigned int pos = atomicAdd(&ctrl[2], 1u);
+        ctrl[SF_Q_HDR + 2 * IPW + pos] = slot;
+        ctrl[SF_Q_HDR + 3 * IPW + pos] = att_base + (uint32_t)A;
+      }
+      if (surv) {
+        const unsigned int pos = atomicAdd(&ctrl[3], 1u);
+        ctrl[SF_Q_HDR + 4 * IPW + pos] = slot;
+      }
+      const unsigned int n_res = (unsigned)__popcll(__ballot(hit || surv));
+      const unsigned int n_ev = (unsigned)__popcll(__ballot(valid && h == 0));
+      const unsigned int n_r0 = (unsigned)__popcll(__ballot(leader && first < 0 && att_base == 0u));
+      if ((threadIdx.x & 63) == 0) {
+        if (n_res) atomicAdd(&ctrl[4], n_res);
+        if (n_ev) atomicAdd(&ctrl[5], n_ev);
+        if (n_r0) atomicAdd(&ctrl[6], n_r0);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // NSF per-galaxy context table (sf_flow_prepare_context): tab[gal][t][v][row], rows in tile order
 //   v = 0: bin + Win_c e(x);  v = 1+k: bg_k + Wg_k e(x)     (SfDev::ctab)
 // One wave = 32 galaxies; weights stream from the global operand image (tiny kernel).

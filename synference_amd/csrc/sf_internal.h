@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "sf_layout.h"
+#include "sf_queue.h"
 
 struct SfSampleArgsHost {
   const float* x = nullptr;
@@ -23,6 +24,13 @@ struct SfSampleArgsHost {
   uint32_t* n_rejected = nullptr;
   int32_t* n_drawn = nullptr;
   int32_t* count = nullptr;
+  // persistent mode (q != nullptr): one launch works the dense list AND its retries to the end (sf_queue.h)
+  struct SfQueue* q = nullptr;
+  unsigned long long* ring = nullptr;  // retry ring, ring_mask + 1 entries
+  uint32_t ring_mask = 0;
+  uint32_t attempt_limit = 0xffffffffu;  // attempts [attempt, attempt_limit) are tried by this launch; then -> rejected[]
+  uint32_t n_total = 0;                // slots of the dense list (== n_items)
+  int32_t* gal_acc = nullptr;          // optional [M]: += 1 per accepted slot of the galaxy (progress test between stages)
 };
 
 hipError_t sf_launch_logprob(const SfDev& m, const float* theta, const float* x, long B, float* out,
@@ -39,8 +47,22 @@ hipError_t sf_launch_pack(const float* flat, const int32_t* s1, const int32_t* s
 hipError_t sf_launch_pack_bf16(const float* flat, const int32_t* src, unsigned short* out, long n, hipStream_t st);
 hipError_t sf_launch_fill_nan_rows(float* out, const uint32_t* slots, long n, int D, hipStream_t st);
 hipError_t sf_launch_fill_i32(int32_t* p, long n, int32_t v, hipStream_t st);
+// survivors of galaxies with gal_acc == 0 become NaN rows; the others are compacted in place; *n_surv updated
+hipError_t sf_launch_filter_survivors(uint32_t* list, unsigned int* n_surv, long S, const int32_t* gal_acc, float* out,
+                                      int D, hipStream_t st);
 
 #include <string>
+// per-device "attribute already set" cache for hipFuncSetAttribute(MaxDynamicSharedMemorySize): function attributes are
+// per device, so a process that launches on a second device must set them there too
+struct SfAttrCache {
+  bool done[16] = {false};
+  bool need(int& dev) {
+    dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return true;
+    return !done[dev];
+  }
+  void set(int dev) { if (dev >= 0 && dev < 16) done[dev] = true; }
+};
 void sf_set_error(const std::string& msg);  // thread-local message behind sf_last_error()
 
 // ---- the handle (shared by sf_api.hip and sf_train.hip) -------------------------------------
@@ -49,6 +71,7 @@ struct sf_flow {
   SfLayout L;
   bool dev_ready = false;
   bool params_set = false;
+  bool train_ready = false;     // every lazily built training buffer exists (sf_train.hip)
   bool flat_valid = false;      // d_flat holds the vector last given to sf_flow_set_params
   float* d_packed = nullptr;    // forward operand image
   float* d_packedT = nullptr;   // transposed operand image (training, lazily built)
@@ -67,8 +90,17 @@ struct sf_flow {
   size_t act_cap = 0;           // floats
   uint32_t* d_rej[2] = {nullptr, nullptr};
   size_t rej_cap = 0;
+  SfQueue* d_queue = nullptr;    // work-queue words of the persistent sampler (sf_queue.h)
+  SfQueue* h_queue = nullptr;    // pinned host mirror, read once per stage
+  unsigned long long* d_ring = nullptr;  // retry ring
+  uint64_t ring_cap = 0;         // entries (power of two)
+  int32_t* d_galacc = nullptr;   // per-galaxy accepted-slot counter of a stage (progress rule)
+  size_t galacc_cap = 0;
   uint32_t* d_cnt = nullptr;     // SF_MAX_ROUNDS rejected-slot counters (one per round of a sf_flow_sample call)
   uint32_t* h_cnt = nullptr;     // pinned host mirror for the per-round read-back
+  bool profiling = false;         // sf_flow_set_profiling: bracket the training flow kernel with HIP events
+  hipEvent_t ev_train[2] = {nullptr, nullptr};
+  bool ev_train_valid = false;
   hipEvent_t ev_dense[2] = {nullptr, nullptr};  // brackets round 0 of the last sf_flow_sample call
   float last_stats[4] = {0.f, 0.f, 0.f, 0.f};   // dense-round ms, rounds, rejected after round 0, items evaluated
   float* d_ctab = nullptr;       // per-galaxy context table (sf_flow_prepare_context)

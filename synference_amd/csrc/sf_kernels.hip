@@ -35,6 +35,48 @@ __global__ void k_fill_nan_rows(float* __restrict__ out, const uint32_t* __restr
   for (int d = 0; d < D; ++d) out[(long)slots[i] * D + d] = __builtin_nanf("");
 }
 
+// Progress rule between the stages of an uncapped sampling call (sf_api.hip): one workgroup walks the survivor list;
+// slots of galaxies that got no draw accepted in the stage are written as NaN rows, the rest are compacted in place
+// (stable order), and the survivor count is updated.  The list is short (it is what more than 64 attempts left over).
+__global__ __launch_bounds__(1024) void k_filter_survivors(uint32_t* __restrict__ list, unsigned int* __restrict__ n_surv,
+                                                          long S, const int32_t* __restrict__ gal_acc,
+                                                          float* __restrict__ out, int D) {
+  __shared__ unsigned int warp_cnt[16];
+  __shared__ unsigned int base_s;
+  const unsigned int n = *n_surv;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base_s = 0;
+  __syncthreads();
+  for (unsigned int i0 = 0; i0 < n; i0 += 1024) {
+    const unsigned int i = i0 + threadIdx.x;
+    uint32_t slot = 0;
+    bool keep = false;
+    if (i < n) {
+      slot = list[i];
+      keep = gal_acc[(long)(slot / (uint32_t)S)] > 0;
+      if (!keep)
+        for (int d = 0; d < D; ++d) out[(size_t)slot * D + d] = __builtin_nanf("");
+    }
+    const unsigned long long bal = __ballot(keep);
+    if (lane == 0) warp_cnt[w] = (unsigned)__popcll(bal);
+    __syncthreads();  // every read of this chunk of the list has happened
+    unsigned int off = base_s;
+    for (int q = 0; q < w; ++q) off += warp_cnt[q];
+    if (keep) list[off + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = slot;  // off + rank <= i: never ahead of the reads
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned int t = 0;
+      for (int q = 0; q < 16; ++q) t += warp_cnt[q];
+      base_s += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    n_surv[1] = n - base_s;  // SfQueue::dropped sits right behind n_surv
+    *n_surv = base_s;
+  }
+}
+
 __global__ void k_fill_i32(int32_t* p, long n, int32_t v) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -141,6 +183,11 @@ hipError_t sf_launch_pack_bf16(const float* flat, const int32_t* src, unsigned s
 hipError_t sf_launch_fill_nan_rows(float* out, const uint32_t* slots, long n, int D, hipStream_t st) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_fill_nan_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, slots, n, D);
+  return hipGetLastError();
+}
+hipError_t sf_launch_filter_survivors(uint32_t* list, unsigned int* n_surv, long S, const int32_t* gal_acc, float* out,
+                                      int D, hipStream_t st) {
+  hipLaunchKernelGGL(k_filter_survivors, dim3(1), dim3(1024), 0, st, list, n_surv, S, gal_acc, out, D);
   return hipGetLastError();
 }
 hipError_t sf_launch_fill_i32(int32_t* p, long n, int32_t v, hipStream_t st) {

@@ -138,7 +138,7 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
       auto image_floats = [&](int ht, int ngh) {
         return 256L * (ht * (nGu_e + nGc_e) + (long)NB * ht * ngh + ngh) + 64L * D * ht + 64L * (NB + 1) * ht;
       };
-      const long lds_floats = 156L * 1024 / 4;
+      const long lds_floats = 152L * 1024 / 4;
       const int ht_a = tile + 1, ngh_a = ceil_div(gend[G - 1], 8), ht_c = ceil_div(H, 32), ngh_c = ceil_div(H, 8);
       if (ht_a > ht_c || (image_floats(ht_a, ngh_a) > lds_floats && image_floats(ht_c, ngh_c) <= lds_floats)) ok = false;
     }
@@ -597,11 +597,11 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
     v.t16_stride = (int)L.src16a.size();
   }
   L.n_packed16 = (int64_t)L.src16a.size();
-  if (v.m16_ok && (size_t)v.t16_stride * sizeof(float) > 156 * 1024) v.m16_ok = 0;
+  if (v.m16_ok && (size_t)v.t16_stride * sizeof(float) > 152 * 1024) v.m16_ok = 0;
   L.n_packedB = (int64_t)L.srcB.size();
-  // ---- LDS staging plan (budget: 156 KiB of the 160 KiB LDS) ---------------------------------
+  // ---- LDS staging plan (budget: 152 KiB of the 160 KiB LDS; the rest holds the persistent sampler's control block) ---------------------------------
   {
-    const int budget = 156 * 1024 / 4;
+    const int budget = 152 * 1024 / 4;
     std::vector<int> cuts;  // block boundaries (float offsets) in execution order, first = 0, last = end
     if (d.kind == SF_MAF) {
       cuts = {0, v.t_stride};
@@ -640,7 +640,7 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
     if (v.hidden_bf16) {
       const int need = v.t_stride + (v.tB_stride + 1) / 2;  // floats: fp32 image + bf16 image of one transform
       if (v.n_parts != 1 || need > budget)
-        return fail("hidden_bf16: one transform's fp32 + bf16 operand images must fit the 156 KiB LDS budget");
+        return fail("hidden_bf16: one transform's fp32 + bf16 operand images must fit the 152 KiB LDS budget");
     }
   }
   L.n_packed = E.cur;

@@ -63,7 +63,7 @@ struct SfPass16 {
 
 // One autoregressive pass with the degree group in (static) tile OT: recompute that tile of every hidden
 // layer from the finished dimensions, then the (a, m) head rows of physical slot sl as per-lane dot products.
-template <int OT, int NB>
+template <int OT, int NB, bool LD = true>
 __device__ __forceinline__ void sf_pass16(const SfDev& m, const float* tp, SfPass16& S, int NT, int sl, float u_sl,
                                           int lane, int g4) {
   // everything that does not depend on this pass's new dimension first: weight fragments, partial sums
@@ -104,7 +104,7 @@ __device__ __forceinline__ void sf_pass16(const SfDev& m, const float* tp, SfPas
   const float mv = bm + sf_sum4groups(pam[1]);
   const float sc = (m.scale_fn == 0 ? sf_softplus(av) : sf_sigmoid(av + 2.0f)) + m.eps;
   const float wv = sf_div(u_sl - mv, sc);
-  S.ldl += sf_log(sc);
+  if (LD) S.ldl += sf_log(sc);  // (the sampler does not need the log-determinant)
 #pragma unroll
   for (int r = 0; r < 4; ++r) S.ut[r] = (g4 == (sl >> 2) && r == (sl & 3)) ? wv : S.ut[r];
 }
@@ -113,7 +113,7 @@ __device__ __forceinline__ void sf_pass16(const SfDev& m, const float* tp, SfPas
 // recomputed for all of those tiles before the next layer starts (units of one degree feed each other), over the
 // input tiles 0..HI; rows of later groups inside these tiles get provisional values that nothing unmasked reads
 // and that their own pass overwrites.
-template <int LO, int HI, int NB>
+template <int LO, int HI, int NB, bool LD = true>
 __device__ __forceinline__ void sf_pass16_span(const SfDev& m, const float* tp, SfPass16& S, int NT, int sl, float u_sl,
                                                int lane, int g4) {
   const float* hv = tp + m.o16_hv + sl * 128 + g4 * 32;
@@ -139,7 +139,7 @@ __device__ __forceinline__ void sf_pass16_span(const SfDev& m, const float* tp, 
   const float mv = tp[m.o16_hvb + 2 * sl + 1] + sf_sum4groups(pam[1]);
   const float sc = (m.scale_fn == 0 ? sf_softplus(av) : sf_sigmoid(av + 2.0f)) + m.eps;
   const float wv = sf_div(u_sl - mv, sc);
-  S.ldl += sf_log(sc);
+  if (LD) S.ldl += sf_log(sc);  // (the sampler does not need the log-determinant)
 #pragma unroll
   for (int r = 0; r < 4; ++r) S.ut[r] = (g4 == (sl >> 2) && r == (sl & 3)) ? wv : S.ut[r];
 }
@@ -351,6 +351,226 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16(SfDev m, SfSampleArgsHost 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent sampler: the same tile pipeline as k_maf_inv16, driven by the device work queue of sf_queue.h.  One
+// launch resolves every slot of the dense list (first attempts AND retries); sampler only (no parity hook, no
+// acceptance mode, no log-determinant).
+// The two argument blocks are read through the kernarg segment pointer, laundered once per iteration: descriptor
+// fields and table entries are then loaded where they are used (scalar-cache hits) instead of being hoisted out of
+// the persistent loop and kept in registers for the life of the kernel -- with them live the pass functions spill.
+// ---------------------------------------------------------------------------------------------------------------
+struct SfSamp16Args {
+  SfDev m;
+  SfSampleArgsHost a;
+};
+
+template <int NB, bool SPAN>
+__global__ __launch_bounds__(256, 3) void k_maf_samp16(SfSamp16Args args_in) {
+  const int wave = threadIdx.x >> 6;
+  unsigned int* ctrl = reinterpret_cast<unsigned int*>(sf_lds16 + args_in.m.t16_stride);
+  if (threadIdx.x < SF_Q_HDR) ctrl[threadIdx.x] = 0u;
+  for (;;) {
+    const SfSamp16Args* ap;
+    {
+      auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(kp));
+      ap = (const SfSamp16Args*)kp;
+    }
+    const SfDev& m = ap->m;
+    const SfSampleArgsHost& a = ap->a;
+    const int lane = (threadIdx.x & 63) + sf_opaque_zero();  // lane-derived addresses are recomputed per iteration
+    const int s = lane & 15, g4 = lane >> 4;
+    if (!sf_q_fetch<64, 16>(a, ctrl)) break;
+    const int wi = wave * 16 + s;
+    const int NT = m.nT16;
+    f32x4 u;
+    const float* xr;
+    const float* ctg;
+    {
+      const unsigned int n_ent = ctrl[0];
+      const int lgA = (int)ctrl[1];
+      const unsigned int e = (unsigned)wi >> lgA;
+      const unsigned int ee = e < n_ent ? e : 0u;
+      const uint32_t slot = ctrl[SF_Q_HDR + ee];
+      const uint32_t att = ctrl[SF_Q_HDR + 64 + ee] + ((unsigned)wi & ((1u << lgA) - 1u));
+      const long gal = (long)(slot / (uint32_t)a.S);
+      float z4[4];
+      sf_normal4(a.k0, a.k1, (uint64_t)slot, att, (uint32_t)g4, z4);  // Philox block g4 = dimensions 4*g4 .. 4*g4+3
+#pragma unroll
+      for (int r = 0; r < 4; ++r) u[r] = (4 * g4 + r < m.D) ? z4[r] : 0.f;
+      xr = a.x + gal * m.C;
+      ctg = m.ctab ? m.ctab + (size_t)gal * m.T * m.ctab_R : nullptr;  // wave-uniform choice
+    }
+    auto ctx_tile = [&](int ic) {
+      f32x4 ct;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rho = ic * 16 + 4 * g4 + r;
+        const bool ok = rho < m.C;
+        const int rr = ok ? rho : 0;
+        const float v = sf_div(xr[rr] - m.cst[m.c_xmean + rr], m.cst[m.c_xstd + rr]);
+        ct[r] = ok ? v : 0.f;
+      }
+      return ct;
+    };
+    f32x4 ct0;
+    if (!ctg) ct0 = ctx_tile(0);
+    uint32_t tile_bits = 0, lo_bits = 0;  // g16_tile / g16_lo packed 2 bits per degree
+#pragma unroll
+    for (int q = 0; q < SF_DMAX; ++q) {
+      tile_bits |= (uint32_t)(m.g16_tile[q] & 3) << (2 * q);
+      lo_bits |= (uint32_t)(m.g16_lo[q] & 3) << (2 * q);
+    }
+    // cleared per tile of draws: a non-finite value left behind by one draw must not reach the next one through a
+    // structural zero (see k_maf_inv16 for why once per tile is enough)
+    SfPass16 S;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S.act[k][ot][r] = 0.f;
+    for (int t = m.T - 1; t >= 0; --t) {
+      __syncthreads();
+      {
+        const float4* __restrict__ s4 = reinterpret_cast<const float4*>(m.packed16 + (size_t)t * m.t16_stride);
+        float4* __restrict__ d4 = reinterpret_cast<float4*>(sf_lds16);
+        const int n4 = m.t16_stride >> 2;
+        const int lane_ = threadIdx.x & 63;
+        const int ngroups = n4 >> 8;
+        for (int gi = __builtin_amdgcn_readfirstlane(wave); gi < ngroups; gi += 4) {
+          const float4* g = s4 + gi * 256 + lane_;
+          float4* l = d4 + gi * 256;
+          __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 1024, 0);
+          __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 2048, 0);
+          __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 3072, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the copies have landed
+      }
+      __syncthreads();
+      const float* tp = sf_lds16;
+      if (ctg) {
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot)
+          if (ot < NT) S.c0[ot] = *reinterpret_cast<const f32x4*>(ctg + (size_t)t * m.ctab_R + ot * 16 + 4 * g4);
+      } else {
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot)
+          if (ot < NT) {
+            S.c0[ot] = sf_ld4(tp + m.o16_b0 + (ot * 4 + g4) * 4);
+            S.c0[ot] = sf_mma16(sf_w16(tp + m.o16_wc, m.nC16, ot, 0, lane), ct0, S.c0[ot]);
+          }
+        for (int ic = 1; ic < m.nC16; ++ic) {
+          const f32x4 ct = ctx_tile(ic);
+#pragma unroll
+          for (int ot = 0; ot < 4; ++ot)
+            if (ot < NT) S.c0[ot] = sf_mma16(sf_w16(tp + m.o16_wc, m.nC16, ot, ic, lane), ct, S.c0[ot]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S.ut[r] = 0.f;
+      S.ldl = 0.f;
+      const int dsl = (int)m.cst[m.c_dslot + t * SF_DMAX + s];
+      {
+        const int sl = __builtin_amdgcn_readlane(dsl, 0);
+        const float av = tp[m.o16_hvb + 2 * sl], mv = tp[m.o16_hvb + 2 * sl + 1];
+        const float sc = (m.scale_fn == 0 ? sf_softplus(av) : sf_sigmoid(av + 2.0f)) + m.eps;
+        const float wv = sf_div(sf_slot16(u, sl, lane) - mv, sc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S.ut[r] = (g4 == (sl >> 2) && r == (sl & 3)) ? wv : S.ut[r];
+      }
+      for (int p = 2; p <= m.D; ++p) {
+        const int sl = __builtin_amdgcn_readlane(dsl, p - 1);
+        const float u_sl = sf_slot16(u, sl, lane);
+        const uint32_t hi_t = (tile_bits >> (2 * (p - 1))) & 3u;
+        const uint32_t lo_t = SPAN ? (lo_bits >> (2 * (p - 1))) & 3u : hi_t;
+        switch (lo_t * 4 + hi_t) {
+          case 0: sf_pass16<0, NB, false>(m, tp, S, NT, sl, u_sl, lane, g4); break;
+          case 5: sf_pass16<1, NB, false>(m, tp, S, NT, sl, u_sl, lane, g4); break;
+          case 10: sf_pass16<2, NB, false>(m, tp, S, NT, sl, u_sl, lane, g4); break;
+          case 15: sf_pass16<3, NB, false>(m, tp, S, NT, sl, u_sl, lane, g4); break;
+          case 1: if (SPAN) sf_pass16_span<0, 1, NB, false>(m, tp, S, NT, sl, u_sl, lane, g4); break;
+          case 2: if (SPAN) sf_pass16_span<0, 2, NB, false>(m, tp, S, NT, sl, u_sl, lane, g4); break;
+          case 3: if (SPAN) sf_pass16_span<0, 3, NB, false>(m, tp, S, NT, sl, u_sl, lane, g4); break;
+          case 6: if (SPAN) sf_pass16_span<1, 2, NB, false>(m, tp, S, NT, sl, u_sl, lane, g4); break;
+          case 7: if (SPAN) sf_pass16_span<1, 3, NB, false>(m, tp, S, NT, sl, u_sl, lane, g4); break;
+          default: if (SPAN) sf_pass16_span<2, 3, NB, false>(m, tp, S, NT, sl, u_sl, lane, g4); break;
+        }
+      }
+      u = S.ut;
+    }
+    // ---------------------------------------------------------------- un-standardise, box test, outputs
+    float th[4];
+    bool ok = true;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int p = 4 * g4 + r;
+      th[r] = 0.f;
+      if (p < m.D) {
+        const int td = (int)m.cst[m.c_tdim + p];
+        th[r] = sf_div(u[r] - m.cst[m.c_pshift + p], m.cst[m.c_pscale + p]);
+        ok = ok && (fabsf(th[r]) <= 3.0e38f);  // finite (NaN compares false)
+        if (a.lo) ok = ok && (th[r] >= a.lo[td]) && (th[r] <= a.hi[td]);
+      }
+    }
+    // the work words are still in LDS: nothing about the item had to stay in registers through the flow
+    const unsigned int n_ent = ctrl[0];
+    const int lgA = (int)ctrl[1];
+    const unsigned int e = (unsigned)wi >> lgA;
+    const bool entry_ok = e < n_ent;
+    const unsigned int ee = entry_ok ? e : 0u;
+    const uint32_t slot = ctrl[SF_Q_HDR + ee];
+    const uint32_t att_base = ctrl[SF_Q_HDR + 64 + ee];
+    const uint32_t att = att_base + ((unsigned)wi & ((1u << lgA) - 1u));
+    const bool valid = entry_ok && att < a.attempt_limit;
+    const unsigned long long okb = __ballot(ok);
+    const uint32_t acc16 = (uint32_t)(okb & (okb >> 16) & (okb >> 32) & (okb >> 48) & 0xffffull) &
+                           (uint32_t)(__ballot(valid) & 0xffffull);
+    // A <= 16 consecutive items hold attempts att_base .. att_base+A-1 of one slot: the lowest accepted one wins
+    const int A = 1 << lgA;
+    const int grp0 = (s / A) * A;
+    const uint32_t gmask = (acc16 >> grp0) & ((1u << A) - 1u);
+    const int first = gmask ? (int)__builtin_ctz(gmask) : -1;
+    const int me = s - grp0;
+    if (valid && me == first) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * g4 + r < m.D) a.out[(size_t)slot * m.D + (int)m.cst[m.c_tdim + 4 * g4 + r]] = th[r];
+    }
+    // accepted -> resolved; rejected -> staged for the retry ring, or for the survivor list once the launch's attempt
+    // limit is reached; wave 0 publishes everything the workgroup staged at the top of the next sf_q_fetch
+    const bool leader = entry_ok && g4 == 0 && me == 0;
+    const uint32_t room = a.attempt_limit > att_base ? a.attempt_limit - att_base : 0u;
+    const uint32_t tried = room < (uint32_t)A ? room : (uint32_t)A;  // attempts of this entry evaluated here
+    const bool hit = leader && first >= 0;
+    const bool retry = leader && first < 0 && att_base + (uint32_t)A < a.attempt_limit;
+    const bool surv = leader && first < 0 && !retry;
+    if (leader && (a.n_drawn || a.gal_acc)) {
+      const long gal = (long)(slot / (uint32_t)a.S);
+      if (a.n_drawn && att_base > 0) atomicAdd(&a.n_drawn[gal], first >= 0 ? first + 1 : (int)tried);
+      if (hit && a.gal_acc) atomicAdd(&a.gal_acc[gal], 1);
+    }
+    if (retry) {
+      const unsigned int pos = atomicAdd(&ctrl[2], 1u);
+      ctrl[SF_Q_HDR + 2 * 64 + pos] = slot;
+      ctrl[SF_Q_HDR + 3 * 64 + pos] = att_base + (uint32_t)A;
+    }
+    if (surv) {
+      const unsigned int pos = atomicAdd(&ctrl[3], 1u);
+      ctrl[SF_Q_HDR + 4 * 64 + pos] = slot;
+    }
+    const unsigned int n_res = (unsigned)__popcll(__ballot(hit || surv));
+    const unsigned int n_ev = (unsigned)__popcll(__ballot(valid && g4 == 0));
+    const unsigned int n_r0 = (unsigned)__popcll(__ballot(leader && first < 0 && att_base == 0u));
+    if ((threadIdx.x & 63) == 0) {
+      if (n_res) atomicAdd(&ctrl[4], n_res);
+      if (n_ev) atomicAdd(&ctrl[5], n_ev);
+      if (n_r0) atomicAdd(&ctrl[6], n_r0);
+    }
+  }
+}
+
 // Per-galaxy context table of the 16-row path: tab[gal][t][row] = b0 + bc + Wc e(x_gal), rows in tile order.
 // One wave = 16 galaxies; same MFMA sequence as the in-kernel evaluation, so the sampler's draws do not change.
 __global__ __launch_bounds__(256) void k_maf_ctab16(SfDev m, const float* __restrict__ x, long M, float* __restrict__ tab) {
@@ -405,14 +625,46 @@ bool sf_maf16_enabled(const SfDev& m, const SfSampleArgsHost& a) {
          a.attempts_per_slot <= 16;
 }
 
+// workgroups that fit the chip at once (persistent launches): 3 per CU by registers and LDS
+static int sf_resident_blocks16(const void* fn, size_t sh) {
+  int dev = 0, cus = 256, per = 3;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+  }
+  int occ = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, sh) == hipSuccess && occ > 0) per = occ < 3 ? occ : 3;
+  return cus * per;
+}
+
 template <int NB, bool SPAN>
 static hipError_t sf_launch16(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
-  static bool attr = false;
+  if (a.q) {  // persistent sampler: no more workgroups than the chip holds (more would only queue behind the spinning ones)
+    static SfAttrCache attr;
+    static int resident = 0;
+    const size_t sh = (size_t)m.t16_stride * sizeof(float) + SF_Q_WORDS(64) * sizeof(unsigned int);
+    int attr_dev;
+    if (attr.need(attr_dev)) {
+      hipError_t e = hipFuncSetAttribute((const void*)k_maf_samp16<NB, SPAN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      attr.set(attr_dev);
+    }
+    if (!resident) resident = sf_resident_blocks16((const void*)k_maf_samp16<NB, SPAN>, sh);
+    long grid = (a.n_items + 63) / 64;
+    if (grid > resident) grid = resident;
+    SfSamp16Args args;
+    args.m = m;
+    args.a = a;
+    hipLaunchKernelGGL((k_maf_samp16<NB, SPAN>), dim3((unsigned)grid), dim3(256), sh, st, args);
+    return hipGetLastError();
+  }
+  static SfAttrCache attr;
   const size_t sh = (size_t)m.t16_stride * sizeof(float);
-  if (!attr) {
+  int attr_dev;
+  if (attr.need(attr_dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)k_maf_inv16<NB, SPAN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr = true;
+    attr.set(attr_dev);
   }
   const long per_block = 4L * 16;
   hipLaunchKernelGGL((k_maf_inv16<NB, SPAN>), dim3((unsigned)((a.n_items + per_block - 1) / per_block)), dim3(256), sh, st, m, a);

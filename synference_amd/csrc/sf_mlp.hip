@@ -220,11 +220,12 @@ template <int HT>
 hipError_t launch_bwd(const SfMlpDev& d, const SfMlpArgs& a, hipStream_t st) {
   const long grid = ((a.B + 31) / 32 + 3) / 4;
   const size_t shmem = (size_t)4 * (2 * HT) * SF_TL * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
+  static SfAttrCache attr;
+  int attr_dev;
+  if (attr.need(attr_dev)) {
     hipError_t e = hipFuncSetAttribute((const void*)k_mlp_bwd<HT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
-    attr = true;
+    attr.set(attr_dev);
   }
   hipLaunchKernelGGL((k_mlp_bwd<HT>), dim3((unsigned)grid), dim3(256), shmem, st, d, a);
   return hipGetLastError();

@@ -75,13 +75,16 @@ extern "C" int sf_quantiles(const float* samples, int64_t N, int64_t S, int32_t 
 
 // ---------------------------------------------------------------------------------------------
 // Feature transform on the device: fluxes in nJy -> AB magnitudes,
-//   mag = -2.5 log10(f / 1000) + 23.9 ; f < 0 (or non-finite result) -> mag_limit ; mag > mag_limit -> mag_limit
+//   mag = -2.5 log10(f / 1000) + 23.9 ; f < 0 -> mag_limit ; mag > mag_limit (incl. f == 0 -> +inf) -> mag_limit ;
+//   a NaN flux stays NaN (the reference only replaces negative fluxes, sbi_runner.py:1706-1714, so that rows with a
+//   missing band are still recognised and masked downstream)
 // and, optionally, flux errors -> magnitude errors  2.5 sigma / (ln 10 f).
 // Replaces the host numpy pass at ref: src/synference/sbi_runner.py:1698-1716, 1927-1932.  HBM-bound, float4 I/O.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sf_abmag(float f_njy, float lim) {
+  if (f_njy != f_njy) return f_njy;  // missing band: NaN propagates
   float m = -2.5f * log10f(f_njy * 1.0e-3f) + 23.9f;
-  if (!(f_njy >= 0.f) || !(m == m) || m > lim) m = lim;  // negative flux, NaN and the faint limit
+  if (f_njy < 0.f || m > lim) m = lim;  // negative flux and the faint limit (f == 0 gives +inf > lim)
   return m;
 }
 __global__ void k_flux_to_abmag(const float* __restrict__ flux, const float* __restrict__ err, long n, float lim,

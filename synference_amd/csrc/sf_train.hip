@@ -211,16 +211,33 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
                        hipStream_t st, std::string& err) {
   const SfLayout& L = f->L;
   // ---- lazily built training state
-  if (!f->d_packedT) {
-    SF_TRY(hipMalloc(&f->d_packedT, (size_t)L.n_packedT * sizeof(float)));
-    SF_TRY(hipMalloc(&f->d_t1, (size_t)L.n_packedT * sizeof(int32_t)));
-    SF_TRY(hipMalloc(&f->d_t2, (size_t)L.n_packedT * sizeof(int32_t)));
-    SF_TRY(hipMemcpy(f->d_t1, L.srcT1.data(), (size_t)L.n_packedT * sizeof(int32_t), hipMemcpyHostToDevice));
-    SF_TRY(hipMemcpy(f->d_t2, L.srcT2.data(), (size_t)L.n_packedT * sizeof(int32_t), hipMemcpyHostToDevice));
-    SF_TRY(hipMalloc(&f->d_gpacked, (size_t)SF_GCOPIES * L.n_packed * sizeof(float)));
+  if (!f->train_ready) {
+    // all-or-nothing: a failed allocation frees what was already taken, so that the next call starts over instead of
+    // launching kernels on half-built state
+    auto undo = [&]() {
+      (void)hipFree(f->d_packedT); (void)hipFree(f->d_t1); (void)hipFree(f->d_t2); (void)hipFree(f->d_gpacked); (void)hipFree(f->d_gdst);
+      f->d_packedT = nullptr; f->d_t1 = f->d_t2 = nullptr; f->d_gpacked = nullptr; f->d_gdst = nullptr; f->gpacked_cap = 0;
+    };
+#define SF_TRY_U(call)                                                       \
+  do {                                                                       \
+    hipError_t e_ = (call);                                                  \
+    if (e_ != hipSuccess) {                                                  \
+      err = std::string(#call) + ": " + hipGetErrorString(e_);               \
+      undo();                                                                \
+      return SF_ERR_HIP;                                                     \
+    }                                                                        \
+  } while (0)
+    SF_TRY_U(hipMalloc(&f->d_packedT, (size_t)L.n_packedT * sizeof(float)));
+    SF_TRY_U(hipMalloc(&f->d_t1, (size_t)L.n_packedT * sizeof(int32_t)));
+    SF_TRY_U(hipMalloc(&f->d_t2, (size_t)L.n_packedT * sizeof(int32_t)));
+    SF_TRY_U(hipMemcpy(f->d_t1, L.srcT1.data(), (size_t)L.n_packedT * sizeof(int32_t), hipMemcpyHostToDevice));
+    SF_TRY_U(hipMemcpy(f->d_t2, L.srcT2.data(), (size_t)L.n_packedT * sizeof(int32_t), hipMemcpyHostToDevice));
+    SF_TRY_U(hipMalloc(&f->d_gpacked, (size_t)SF_GCOPIES * L.n_packed * sizeof(float)));
     f->gpacked_cap = (size_t)SF_GCOPIES * L.n_packed;
-    SF_TRY(hipMalloc(&f->d_gdst, (size_t)L.n_params * sizeof(int32_t)));
-    SF_TRY(hipMemcpy(f->d_gdst, L.gdst.data(), (size_t)L.n_params * sizeof(int32_t), hipMemcpyHostToDevice));
+    SF_TRY_U(hipMalloc(&f->d_gdst, (size_t)L.n_params * sizeof(int32_t)));
+    SF_TRY_U(hipMemcpy(f->d_gdst, L.gdst.data(), (size_t)L.n_params * sizeof(int32_t), hipMemcpyHostToDevice));
+#undef SF_TRY_U
+    f->train_ready = true;
   }
   const SfDev& v = L.dev;
   const long waves = (B + 31) / 32;
@@ -264,12 +281,20 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
     a.act = reinterpret_cast<float4*>(f->d_act); a.act_per_wave = act_per_wave;
     const SfDev m = f->dev();
     const bool maf = m.kind == SF_MAF;
+    if (f->profiling) {
+      if (!f->ev_train[0]) { SF_TRY(hipEventCreate(&f->ev_train[0])); SF_TRY(hipEventCreate(&f->ev_train[1])); }
+      SF_TRY(hipEventRecord(f->ev_train[0], st));
+    }
     switch (m.HT) {
       case 1: SF_TRY(maf ? sf_launch_maf_train_h1(m, a, st) : sf_launch_nsf_train_h1(m, a, st)); break;
       case 2: SF_TRY(maf ? sf_launch_maf_train_h2(m, a, st) : sf_launch_nsf_train_h2(m, a, st)); break;
       case 3: SF_TRY(maf ? sf_launch_maf_train_h3(m, a, st) : sf_launch_nsf_train_h3(m, a, st)); break;
       case 4: SF_TRY(maf ? sf_launch_maf_train_h4(m, a, st) : sf_launch_nsf_train_h4(m, a, st)); break;
       default: err = "bad HT"; return SF_ERR_INVALID;
+    }
+    if (f->profiling) {
+      SF_TRY(hipEventRecord(f->ev_train[1], st));
+      f->ev_train_valid = true;
     }
   }
   hipLaunchKernelGGL(k_grad_gather, dim3((unsigned)((L.n_params + 255) / 256)), dim3(256), 0, st,

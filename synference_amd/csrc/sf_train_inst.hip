@@ -15,11 +15,12 @@ static hipError_t set_shmem(K kernel, size_t bytes) {
 hipError_t SF_CAT(sf_launch_maf_train_h, SF_HT)(const SfDev& m, const SfTrainArgs& a, hipStream_t st) {
   const long grid = (a.B + 31) / 32;  // one workgroup (producer + consumer wave) per 32-sample tile
   const size_t shmem = (size_t)2 * (SF_JOB_HDR + (2 * SF_HT) * SF_TL) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
+  static SfAttrCache attr;
+  int attr_dev;
+  if (attr.need(attr_dev)) {
     hipError_t e = set_shmem(k_maf_train<SF_HT>, shmem);
     if (e != hipSuccess) return e;
-    attr = true;
+    attr.set(attr_dev);
   }
   hipLaunchKernelGGL((k_maf_train<SF_HT>), dim3((unsigned)grid), dim3(128), shmem, st, m, a);
   return hipGetLastError();
@@ -29,11 +30,12 @@ template <int PT>
 static hipError_t launch_nsf(const SfDev& m, const SfTrainArgs& a, hipStream_t st) {
   const long grid = (a.B + 31) / 32;
   const size_t shmem = (size_t)2 * (SF_JOB_HDR + SfNsfLds<SF_HT, PT>::tiles * SF_TL) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
+  static SfAttrCache attr;
+  int attr_dev;
+  if (attr.need(attr_dev)) {
     hipError_t e = set_shmem(k_nsf_train<SF_HT, PT>, shmem);
     if (e != hipSuccess) return e;
-    attr = true;
+    attr.set(attr_dev);
   }
   hipLaunchKernelGGL((k_nsf_train<SF_HT, PT>), dim3((unsigned)grid), dim3(128), shmem, st, m, a);
   return hipGetLastError();

@@ -139,9 +139,11 @@ class HipFlow:
                                                        _stream(self.device)))
         return th, ld
 
-    def sample(self, x, S: int, lo=None, hi=None, seed: int = 0, max_attempts: int = 64,
+    def sample(self, x, S: int, lo=None, hi=None, seed: int = 0, max_attempts: Optional[int] = None,
                out: Optional[torch.Tensor] = None, return_counts: bool = False):
-        """samples[M,S,D] (NaN rows where ``max_attempts`` rounds did not fill a slot)."""
+        """samples[M,S,D].  ``max_attempts`` None / 0: no ceiling -- a slot is retried while its galaxy still gets
+        draws accepted (sf_flow_sample); a positive value is a hard ceiling per slot, after which the slot is a NaN row."""
+        max_attempts = int(max_attempts or 0)
         self._dev()
         x = _f32c(x, self.device)
         M = x.shape[0]
@@ -161,6 +163,38 @@ class HipFlow:
         _lib.check(self.lib.sf_flow_sample_stats(self.handle, st4))
         self.last_sample_stats = dict(dense_ms=st4[0], rounds=int(st4[1]), rejected_round0=int(st4[2]), evaluations=st4[3])
         return (out, nd) if return_counts else out
+
+    def sample_slots(self, x, S: int, slots: torch.Tensor, out: torch.Tensor, lo=None, hi=None, seed: int = 0,
+                     max_attempts: Optional[int] = None) -> int:
+        """Fill the listed output slots (slot = g*S + p; int32 / uint32 device tensor) of ``out`` [M,S,D] in place
+        (sf_flow_sample_slots); returns the number of slots left as NaN rows."""
+        self._dev()
+        x = _f32c(x, self.device)
+        if x.dim() != 2 or x.shape[1] != self.spec.C:
+            raise ValueError(f"x must be (M,{self.spec.C})")
+        M = x.shape[0]
+        if out.shape != (M, S, self.spec.D) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("out must be a contiguous float32 (M,S,D) tensor on the flow's device")
+        if slots.dtype not in (torch.int32, torch.uint32) or not slots.is_contiguous() or slots.device != self.device:
+            raise ValueError("slots must be a contiguous 32-bit integer tensor on the flow's device")
+        lo_t = None if lo is None else _f32c(lo, self.device)
+        hi_t = None if hi is None else _f32c(hi, self.device)
+        unfilled = C.c_int64(0)
+        _lib.check(self.lib.sf_flow_sample_slots(self.handle, _ptr(x), M, S, _ptr(slots), slots.numel(), _ptr(lo_t), _ptr(hi_t),
+                                                 C.c_uint64(seed & (2 ** 64 - 1)), int(max_attempts or 0), _ptr(out),
+                                                 C.byref(unfilled), _stream(self.device)))
+        self.last_unfilled = int(unfilled.value)
+        return self.last_unfilled
+
+    def set_profiling(self, on: bool) -> None:
+        """Bracket the training flow kernel of later loss_grad calls with HIP events (sf_flow_set_profiling)."""
+        _lib.check(self.lib.sf_flow_set_profiling(self.handle, 1 if on else 0))
+
+    def train_kernel_ms(self) -> float:
+        """Duration of the flow kernel of the last profiled loss_grad call (sf_flow_train_stats)."""
+        ms = C.c_float(0.0)
+        _lib.check(self.lib.sf_flow_train_stats(self.handle, C.byref(ms)))
+        return float(ms.value)
 
     def prepare_context(self, x) -> None:
         """Per-galaxy context table for the sample_round calls that follow with this same tensor ``x``."""

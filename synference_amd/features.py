@@ -22,8 +22,11 @@ def flux_to_abmag(flux_njy: torch.Tensor, err_njy: Optional[torch.Tensor] = None
     """(N,C) fluxes in nJy on the GPU -> AB magnitudes (and magnitude errors when ``err_njy`` is given)."""
     if flux_njy.device.type != "cuda":
         raise RuntimeError("flux_to_abmag runs on the GPU (no CPU fallback)")
-    f = flux_njy.contiguous().float()
-    e = None if err_njy is None else err_njy.contiguous().float()
+    def _aligned(t):  # the kernel moves float4: a contiguous view that starts off a 16-byte boundary is copied
+        t = t.contiguous().float()
+        return t if t.data_ptr() % 16 == 0 else t.clone()
+    f = _aligned(flux_njy)
+    e = None if err_njy is None else _aligned(err_njy)
     mag = torch.empty_like(f)
     mag_err = None if e is None else torch.empty_like(f)
     p = lambda t: None if t is None else C.c_void_p(t.data_ptr())

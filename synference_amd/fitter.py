@@ -113,8 +113,38 @@ class SBI_Fitter:
                        name_append: str = "timestamp", set_self: bool = True, learning_type: str = "offline",
                        override_prior_ranges: dict = {}, evaluate_model: bool = False,
                        num_posterior_draws_per_sample: int = 1000, embedding_net=None,
-                       max_num_epochs: Optional[int] = None, **unused) -> tuple:
-        """Train an ensemble of n_nets flows; returns (posteriors, stats) like the reference."""
+                       max_num_epochs: Optional[int] = None, custom_config_yaml: Optional[str] = None,
+                       optimizer_choice: str = "Adam", **unused) -> tuple:
+        """Train an ensemble of n_nets flows; returns (posteriors, stats) like the reference.
+
+        ``custom_config_yaml`` (ref: sbi_runner.py:4570-4597, custom_runner.py:226-244, 298-365): a YAML file whose
+        ``train_args`` has ``skip_optimization: True`` and ``fixed_params`` (``model_choice``, ``optimizer_choice``,
+        ``learning_rate``, ``training_batch_size``, ``stop_after_epochs``, ``clip_max_norm`` and the model's own
+        ``<model>_hidden_features`` / ``<model>_num_transforms`` / ``<model>_num_bins`` ...) trains ONE model with those
+        values, ``validation_fraction`` from ``train_args`` (default 0.1); the Optuna search branch is out of scope."""
+        if custom_config_yaml is not None:
+            import yaml
+            with open(custom_config_yaml) as fh:
+                ta = yaml.safe_load(fh)["train_args"]
+            if not ta.get("skip_optimization", False):
+                raise ValueError("custom_config_yaml without skip_optimization asks for the Optuna hyper-parameter search, "
+                                 "which is outside the HIP path: set train_args.skip_optimization and fixed_params")
+            fp = ta.get("fixed_params")
+            if not fp or "model_choice" not in fp:  # custom_runner.py:229-233
+                raise ValueError("`skip_optimization` is True, but `fixed_params` (including 'model_choice') "
+                                 "are not defined in `train_args`.")
+            model_type = fp["model_choice"]
+            n_nets = 1
+            margs = {k.split("_", 1)[1]: v for k, v in fp.items() if k.startswith(model_type + "_")}
+            hidden_features = int(margs.pop("hidden_features", hidden_features))
+            num_transforms = int(margs.pop("num_transforms", num_transforms))
+            additional_model_args = {**additional_model_args, **margs}
+            optimizer_choice = fp.get("optimizer_choice", "Adam")
+            learning_rate = fp["learning_rate"]
+            training_batch_size = fp.get("training_batch_size", 32)
+            stop_after_epochs = fp.get("stop_after_epochs", 20)
+            clip_max_norm = fp.get("clip_max_norm", 5.0)
+            validation_fraction = ta.get("validation_fraction", 0.1)
         if backend != "hip":
             raise ValueError(f"backend '{backend}' is not available in synference_amd: use backend='hip'")
         if learning_type != "offline":
@@ -136,11 +166,9 @@ class SBI_Fitter:
         y_train = self.fitted_parameter_array[train_indices]
         X_test = self.feature_array[test_indices] if test_indices is not None else None
         y_test = self.fitted_parameter_array[test_indices] if test_indices is not None else None
-        saved = self.fitted_parameter_array
-        try:  # priors span the TRAINING parameters like the reference (sbi_runner.py:3519-3520 on the grid)
-            prior = self.create_priors(override_prior_ranges, verbose=verbose)
-        finally:
-            self.fitted_parameter_array = saved
+        # the prior box spans the WHOLE parameter array (train + test rows), as in the reference's create_priors
+        # (sbi_runner.py:3519-3520)
+        prior = self.create_priors(override_prior_ranges, verbose=verbose)
         nets = []
         for i in range(n_nets):
             args = dict(hidden_features=hf[i], num_transforms=nt[i])
@@ -148,7 +176,8 @@ class SBI_Fitter:
             nets.append(load_nde_hip(engines[i], model=models[i], embedding_net=embedding_net, **args))
         train_args = dict(training_batch_size=training_batch_size, learning_rate=learning_rate,
                           validation_fraction=validation_fraction, stop_after_epochs=stop_after_epochs,
-                          clip_max_norm=clip_max_norm, log_every=1 if verbose else 0)
+                          clip_max_norm=clip_max_norm, log_every=1 if verbose else 0,
+                          optimizer_choice=optimizer_choice)
         if max_num_epochs is not None:
             train_args["max_num_epochs"] = max_num_epochs
         stamp = time.strftime("%Y%m%d_%H%M%S") if name_append == "timestamp" else str(name_append)
@@ -190,22 +219,35 @@ class SBI_Fitter:
         single = X.ndim == 1 or (X.ndim == 2 and X.shape[0] == 1)
         if X.ndim == 1:
             X = X[None, :]
-        t0 = time.time()
-        try:
-            s = posteriors.sample_catalogue(torch.as_tensor(X), num_samples, seed)
-            # D2H in float32 through a pinned buffer (half the PCIe bytes of a device-side .double()),
-            # widened to the reference's float64 container on the host
-            host = torch.empty(s.shape, dtype=torch.float32, pin_memory=True)
-            host.copy_(s, non_blocking=True)
-            torch.cuda.current_stream(s.device).synchronize()
-            samples = host.double().numpy()
-        except Exception as e:
-            logger.error(f"Error occurred while sampling: {e}")
-            samples = np.full((len(X), num_samples, len(self.fitted_parameter_names)), np.nan)
-        if log_times and len(X):
-            per = (time.time() - t0) / len(X)
-            logger.info(f"Median time per sample: {per:.5f} seconds (catalogue call, {len(X)} objects).")
-            self.last_time_per_object = per
+        # log_times: the reference times every object (sbi_runner.py:6438-6469: median and 16th-84th percentile of the
+        # per-object wall time); the catalogue call is timed in chunks instead and each chunk's time is shared equally
+        # by its objects, so the three statistics keep their meaning without a per-galaxy host loop
+        n_chunks = min(len(X), 16) if log_times else 1
+        bounds = np.linspace(0, len(X), n_chunks + 1).astype(int)
+        samples = np.full((len(X), num_samples, len(self.fitted_parameter_names)), np.nan)
+        times = []
+        for ci in range(n_chunks):
+            a, b = int(bounds[ci]), int(bounds[ci + 1])
+            if b <= a:
+                continue
+            t0 = time.time()
+            try:
+                sub_seed = None if seed is None else int(seed) + 0x9E3779B1 * ci
+                s = posteriors.sample_catalogue(torch.as_tensor(X[a:b]), num_samples, sub_seed)
+                # D2H in float32 through a pinned buffer (half the PCIe bytes of a device-side .double()),
+                # widened to the reference's float64 container on the host
+                host = torch.empty(s.shape, dtype=torch.float32, pin_memory=True)
+                host.copy_(s, non_blocking=True)
+                torch.cuda.current_stream(s.device).synchronize()
+                samples[a:b] = host.double().numpy()
+            except Exception as e:  # sbi_runner.py:6458-6460: failed objects are NaN rows
+                logger.error(f"Error occurred while sampling objects {a}..{b}: {e}")
+            times.extend([(time.time() - t0) / (b - a)] * (b - a))
+        if log_times and times:
+            self.last_times_per_object = np.asarray(times)
+            self.last_time_per_object = float(np.median(times))
+            logger.info(f"Median time per sample: {np.median(times):.5f} seconds."
+                        f"16th-84th: {np.percentile(times, 16):.5f}-{np.percentile(times, 84):.5f}s.")
         return np.squeeze(samples, 0) if single else samples
 
     def log_prob(self, X: np.ndarray, y: np.ndarray, posteriors: object = None, verbose=True,

@@ -42,10 +42,14 @@ class FlowPosterior:
     """q(theta | x) restricted to the prior support ([UPSTREAM] sbi DirectPosterior)."""
 
     def __init__(self, posterior_estimator: FlowEstimator, prior: Optional[CustomIndependentUniform] = None,
-                 max_sampling_attempts: int = 64, seed: int = 0):
+                 max_sampling_attempts: Optional[int] = None, seed: int = 0):
+        """``max_sampling_attempts``: None (default) = no ceiling, like [UPSTREAM] accept_reject_sample, which draws
+        until S samples are kept: a slot is retried for as long as its galaxy still gets draws accepted (see
+        sf_flow_sample); an integer is a hard ceiling on the attempts per output slot, after which the slot is a NaN
+        row (the reference's failure convention, sbi_runner.py:6458-6460)."""
         self.posterior_estimator = posterior_estimator
         self.prior = prior
-        self.max_sampling_attempts = int(max_sampling_attempts)
+        self.max_sampling_attempts = None if not max_sampling_attempts else int(max_sampling_attempts)
         self._seed = int(seed)
         self._calls = 0
         self.name = ""
@@ -114,12 +118,22 @@ class FlowPosterior:
             counts[r0:r1] = c
             unfilled += est.flow.last_unfilled
         self.last_acceptance = (S / counts.float().clamp_min(1)).mean().item() if N else None
+        self.last_unfilled = unfilled
         if unfilled:
-            logger.error(f"{unfilled} posterior draws could not be placed inside the prior support after "
-                         f"{self.max_sampling_attempts} attempts; those rows are NaN.")
-        if self.last_acceptance is not None and self.last_acceptance < 0.01:
-            logger.warning(f"Only {self.last_acceptance * 100:.3f}% of the proposed samples were accepted: "
-                           "the posterior mass is largely outside the prior support.")
+            why = (f"after {self.max_sampling_attempts} attempts" if self.max_sampling_attempts
+                   else "(their galaxies' acceptance rate is zero to sampling precision)")
+            logger.error(f"{unfilled} posterior draws could not be placed inside the prior support {why}; "
+                         "those rows are NaN.")
+        if N:
+            # [UPSTREAM] accept_reject_sample warns per observation once its acceptance rate drops below 1 %
+            # ("... It may take a long time to collect the remaining samples"); the in-tree diagnostics of
+            # custom_runner.py:1131-1186 name the offending parameters -- CustomIndependentUniform.acceptance_report
+            acc_g = S / counts.float().clamp_min(1)
+            n_low = int((acc_g < 0.01).sum().item())
+            self.last_low_acceptance = n_low
+            if n_low:
+                logger.warning(f"Only {float(acc_g.min()) * 100:.3f}% of the proposed samples were accepted for the worst of "
+                               f"{n_low} observation(s) below 1 %: their posterior mass is largely outside the prior support.")
         return (out, counts) if return_counts else out
 
     def log_prob_catalogue(self, theta, X, norm_posterior: bool = True, num_rejection_samples: int = 10000,
@@ -141,7 +155,18 @@ class FlowPosterior:
             lp = torch.where(inside, lp, torch.full_like(lp, float("-inf")))
             if norm_posterior:
                 ux, inv = torch.unique(X, dim=0, return_inverse=True)
-                acc = est.flow.acceptance(ux, int(num_rejection_samples), lo, hi, seed=self._next_seed(seed))
+                n_rej = int(num_rejection_samples)
+                # one acceptance launch numbers its draws with 32 bits (and its context table is capped at 2 GiB):
+                # chunk the distinct rows; the chunk index is folded into the seed so that streams stay distinct
+                rows_per = max(1, min(_MAX_SLOTS_PER_CALL // max(n_rej, 1), 1 << 20))
+                per_gal = 4 * int(est.flow.describe().get("ctab_floats_per_galaxy", 0))
+                if per_gal > 0:
+                    rows_per = max(1, min(rows_per, (2 << 30) // per_gal))
+                s0 = self._next_seed(seed)
+                acc = torch.empty(ux.shape[0], dtype=torch.float32, device=self.device)
+                for ci, r0 in enumerate(range(0, ux.shape[0], rows_per)):
+                    r1 = min(ux.shape[0], r0 + rows_per)
+                    acc[r0:r1] = est.flow.acceptance(ux[r0:r1], n_rej, lo, hi, seed=s0 + 0x632BE59BD9B4E019 * ci)
                 lp = lp - torch.log(acc.clamp_min(1e-30))[inv]
         return lp
 
@@ -286,33 +311,15 @@ def device_quantiles(samples: torch.Tensor, quantiles) -> torch.Tensor:
 
 
 def _sample_slot_list(post: FlowPosterior, X, S: int, slots: torch.Tensor, seed: int, out: torch.Tensor):
-    """Rejection rounds over an explicit slot list (ensemble members own disjoint slot sets)."""
+    """One member's share of an ensemble draw: the persistent sampler over an explicit slot list
+    (sf_flow_sample_slots; ensemble members own disjoint slot sets of every row)."""
     n = int(slots.numel())
     if n == 0:
         return
     est = post.posterior_estimator
     est._sync_params()
     lo, hi = post._box()
-    dev = X.device
-    rej = [torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)]
-    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
-    cur, pending, attempt, k = slots.contiguous(), n, 0, 0
-    from .engine import retry_width
-    est.flow.prepare_context(X)
-    try:
-        while attempt < post.max_sampling_attempts:
-            A = retry_width(pending, attempt, post.max_sampling_attempts, n)
-            cnt.zero_()
-            est.flow.sample_round(X, S, cur, 0, pending, attempt, seed, lo, hi, out, rej[k & 1], cnt,
-                                  attempts_per_slot=A)
-            pending = int(cnt.item())
-            cur = rej[k & 1]
-            attempt += A
-            k += 1
-            if pending == 0:
-                return
-    finally:
-        est.flow.release_context()
-    bad = cur[:pending].long()
-    out.reshape(-1, out.shape[-1])[bad] = float("nan")
-    logger.error(f"{pending} posterior draws could not be placed inside the prior support.")
+    unfilled = est.flow.sample_slots(X, S, slots.contiguous(), out, lo, hi, seed=seed,
+                                     max_attempts=post.max_sampling_attempts)
+    if unfilled:
+        logger.error(f"{unfilled} posterior draws could not be placed inside the prior support; those rows are NaN.")

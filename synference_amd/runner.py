@@ -124,9 +124,13 @@ class TorchEmbeddingTrainOps:
 
             def step(s, grad, max_norm):  # grads live on the parameters (autograd); `grad` is unused
                 _, world = _dist_info()
-                if world > 1:
+                if world > 1:  # ONE collective over the concatenated gradients (latency-bound message)
+                    flatg = torch.cat([p.grad.reshape(-1) for p in ops.params])
+                    dist_all_reduce(flatg)
+                    off = 0
                     for p in ops.params:
-                        dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+                        p.grad.copy_(flatg[off:off + p.numel()].view_as(p.grad))
+                        off += p.numel()
                 if max_norm:
                     torch.nn.utils.clip_grad_norm_(ops.params, max_norm)
                 s.o.step()
@@ -189,6 +193,31 @@ def _dist_info():
     return 0, 1
 
 
+def _host_staged(t: torch.Tensor) -> bool:
+    """gloo (CPU rehearsals, several ranks on one GPU) is only relied on for host tensors: device tensors are staged
+    through the host; RCCL (backend "nccl") takes them as they are."""
+    return t.device.type == "cuda" and dist.get_backend() == "gloo"
+
+
+def dist_all_reduce(t: torch.Tensor, op=None) -> None:
+    op = dist.ReduceOp.SUM if op is None else op
+    if _host_staged(t):
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+
+
+def dist_broadcast(t: torch.Tensor, src: int = 0) -> None:
+    if _host_staged(t):
+        h = t.detach().cpu()
+        dist.broadcast(h, src=src)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src)
+
+
 def split_indices(n: int, validation_fraction: float, generator: torch.Generator):
     """custom_runner.py:337-343: ``num_val = int(f*n)``; random_split of range(n)."""
     num_val = int(validation_fraction * n)
@@ -208,7 +237,15 @@ def train_flow(estimator: FlowEstimator, theta: torch.Tensor, x: torch.Tensor, *
     embedded = bool(getattr(estimator, "has_embedding", False))
     if ops is None:
         ops = TorchEmbeddingTrainOps(estimator) if embedded else HipTrainOps(estimator)
-    gen = torch.Generator().manual_seed(seed if seed is not None else int(time.time()))
+    if seed is None:
+        seed = int(time.time())
+    if world > 1:
+        # every rank must draw the SAME train/validation split and the same epoch orders: rank 0's seed wins
+        # (a per-rank time() seed would make shards overlap and leak validation rows into training)
+        sd = torch.tensor([int(seed)], dtype=torch.int64, device=dev)
+        dist_broadcast(sd, src=0)
+        seed = int(sd.item())
+    gen = torch.Generator().manual_seed(int(seed))
     N = theta.shape[0]
     if val_theta is None:
         tr_idx, va_idx = split_indices(N, validation_fraction, gen)
@@ -217,8 +254,13 @@ def train_flow(estimator: FlowEstimator, theta: torch.Tensor, x: torch.Tensor, *
     else:
         tr_idx = torch.arange(N, device=dev)
         val_theta_t, val_x_t = val_theta, val_x
-    if world > 1:  # identical start + disjoint shards of equal size
-        dist.broadcast(flat.data, src=0)
+    if world > 1:  # identical start (flow, embedding net, buffers) + disjoint shards of equal size
+        seen = set()
+        for t in list(estimator.parameters()) + list(estimator.buffers()):
+            if t.data_ptr() in seen:
+                continue
+            seen.add(t.data_ptr())
+            dist_broadcast(t.data, src=0)
         per = tr_idx.numel() // world
         tr_idx = tr_idx[rank * per:(rank + 1) * per]
         vper = val_theta_t.shape[0] // world
@@ -244,8 +286,15 @@ def train_flow(estimator: FlowEstimator, theta: torch.Tensor, x: torch.Tensor, *
     best_val, since, best_state = float("inf"), 0, None
     train_log, val_log, epoch = [], [], 0
     ckpt = f"{save_dir}checkpoint_posterior.pt" if save_dir else None
-    if ckpt and os.path.exists(ckpt):  # custom_runner.py:559-573
-        ck = torch.load(ckpt, map_location="cpu")
+    resume = bool(ckpt and rank == 0 and os.path.exists(ckpt))
+    ck = torch.load(ckpt, map_location="cpu") if resume else None
+    if world > 1:
+        # rank 0 decides (storage need not be shared) and hands the checkpoint to the others, so that every rank
+        # resumes at the same epoch and the collectives stay in step
+        box = [ck]
+        dist.broadcast_object_list(box, src=0)
+        ck = box[0]
+    if ck is not None:  # custom_runner.py:559-573
         if embedded:
             estimator.load_state_dict(ck["model_state_dict"])
         else:
@@ -274,14 +323,14 @@ def train_flow(estimator: FlowEstimator, theta: torch.Tensor, x: torch.Tensor, *
             for b in range(nb_tr):
                 ops.loss_grad_rows(flat.data, theta, x, order[b * bs_tr:(b + 1) * bs_tr], gscale, grad, tl)
                 if world > 1:
-                    dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+                    dist_all_reduce(grad)
                 opt.step(grad, clip_max_norm)
         else:
             for b in range(nb_tr):
                 idx = order[b * bs_tr:(b + 1) * bs_tr]
                 loss = ops.loss_grad(flat.data, theta[idx], x[idx], gscale, grad)
                 if world > 1 and not embedded:
-                    dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+                    dist_all_reduce(grad)
                 opt.step(grad, clip_max_norm)
                 tl += loss.double().sum()
         rows_seen += nb_tr * bs_tr * world
@@ -294,7 +343,7 @@ def train_flow(estimator: FlowEstimator, theta: torch.Tensor, x: torch.Tensor, *
             vl = -ops.log_prob(val_theta_t[vorder], val_x_t[vorder]).double().sum()
         acc[0], acc[1] = tl, vl
         if world > 1:
-            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+            dist_all_reduce(acc)
         tsum, vsum = acc.tolist()
         train_avg = tsum / (nb_tr * bs_tr * world)
         val_avg = vsum / (nb_va * bs_va * world) if nb_va > 0 else float("nan")

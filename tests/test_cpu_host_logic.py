@@ -192,3 +192,153 @@ def test_sharded_gradient_sum_equals_full_batch_gradient():
     g = torch.empty_like(flat)
     OracleOps(o).loss_grad(flat, th, x, 1.0 / 128, g)
     assert (ret[0] - g).abs().max() < 1e-6 and torch.equal(ret[0], ret[1])
+
+
+# ------------------------------------------------------------------------------------------------
+# round 2: seed / parameter / resume agreement across ranks, rejection schedules of the oracle
+# ------------------------------------------------------------------------------------------------
+def _dp_seed_worker(rank, world, port, ret, ckpt_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    th, x = _toy(400, seed=3)
+    s, o = _specs(th, x)
+    est = _Est(s)
+    seen = []
+
+    class SpyOps(OracleOps):
+        def loss_grad(self, flat, theta, x, scale, grad_out):
+            seen.append(theta.clone())
+            return super().loss_grad(flat, theta, x, scale, grad_out)
+
+    # seed=None on rank 1 (a per-rank time() seed in round 1), a fixed seed on rank 0: rank 0's must win.
+    # Only rank 0 can see the checkpoint directory: the resume decision must be rank 0's for everybody.
+    out = train_flow(est, th, x, batch_size=32, learning_rate=5e-3, validation_fraction=0.25, stop_after_epochs=50,
+                     max_num_epochs=3, seed=(77 if rank == 0 else None), ops=SpyOps(o), log_every=0,
+                     save_dir=(ckpt_dir if rank == 0 else ckpt_dir + "_not_there/"))
+    rows = torch.cat(seen)
+    ret[rank] = (rows, out["epochs_trained"][0], est.flat.detach().clone())
+    dist.destroy_process_group()
+
+
+def test_data_parallel_ranks_share_split_seed_and_resume_decision(tmp_path):
+    th, x = _toy(400, seed=3)
+    s, o = _specs(th, x)
+    # a checkpoint only rank 0 can see: epoch 3 of a previous run
+    ck = str(tmp_path) + "/m_"
+    flat = init_params(s, torch.Generator().manual_seed(9))
+    torch.save({"epoch": 3, "model_state_dict": {"flat": flat}, "optimizer_state_dict": {"exp_avg": torch.zeros(1),
+                "exp_avg_sq": torch.zeros(1), "step": 0}, "train_loss": [3.0, 2.0, 1.5], "val_loss": [3.0, 2.0, 1.6],
+                "epochs_since_improvement": 0, "best_val_loss": 1.6, "best_model_state_dict": {"flat": flat}},
+               ck + "checkpoint_posterior.pt")
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dp_seed_worker, args=(2, 33500 + (os.getpid() % 2000), ret, ck), nprocs=2, join=True)
+    (rows0, ep0, f0), (rows1, ep1, f1) = ret[0], ret[1]
+    assert ep0 == ep1 == 4                      # both resumed at epoch 3 and ran one more
+    assert torch.equal(f0, f1)
+    # same split on both ranks (rank 0's seed): the training rows the two ranks saw are disjoint, and none of them is
+    # a validation row of that split
+    g = torch.Generator().manual_seed(77)
+    tr, va = split_indices(400, 0.25, g)
+    as_set = lambda t: {tuple(np.round(r, 6)) for r in t.numpy().tolist()}
+    s0, s1, sva = as_set(rows0), as_set(rows1), as_set(th[va])
+    assert not (s0 & s1) and not (s0 & sva) and not (s1 & sva)
+    assert len(s0) + len(s1) <= len(tr)
+
+
+def test_oracle_batch_accept_reject_sampler_and_uncapped_slot_schedule():
+    from oracle import posterior as OP
+    th, x = _toy(50, seed=1)
+    s, o = _specs(th, x)
+    flat = init_params(s, torch.Generator().manual_seed(4))
+    free, _ = OP.sample(o, flat, x[:3].numpy(), 500, 3)
+    lo = np.quantile(free.reshape(-1, 2), 0.3, axis=0).astype(np.float32)
+    hi = np.quantile(free.reshape(-1, 2), 0.7, axis=0).astype(np.float32)
+    # sbi-shaped batch loop: exactly S rows, all inside the box, acceptance consistent with the box's mass
+    gen = torch.Generator().manual_seed(0)
+    smp, rate, warned = OP.accept_reject_sample(o, flat, x[0].numpy(), 700, lo, hi, gen)
+    assert smp.shape == (700, 2) and ((smp >= lo) & (smp <= hi)).all() and 0.05 < rate < 0.5 and not warned
+    # per-slot schedule without a ceiling: everything is filled, attempts follow a geometric law with that rate
+    out, used = OP.sample_slots(o, flat, x[:1].numpy(), np.arange(400, dtype=np.uint64), 400, 7, lo, hi)
+    assert np.isfinite(out).all() and used.max() > 8
+    assert abs(400.0 / used.sum() - rate) < 0.05
+    # both samplers target the same distribution
+    from scipy import stats
+    assert min(stats.ks_2samp(out[:, d], smp[:, d]).pvalue for d in range(2)) > 1e-3
+    # the progress rule: a dead galaxy (NaN context) ends as NaN rows after the window [64, 1024); a ceiling is a ceiling
+    xx = x[:2].numpy().copy()
+    xx[1] = np.nan
+    out, used = OP.sample_slots(o, flat, xx, np.arange(20, dtype=np.uint64), 10, 7, lo, hi)
+    assert np.isfinite(out[:10]).all() and np.isnan(out[10:]).all() and (used[10:] == 1024).all()
+    out, used = OP.sample_slots(o, flat, xx, np.arange(20, dtype=np.uint64), 10, 7, lo, hi, max_attempts=5)
+    assert np.isnan(out[10:]).all() and used.max() <= 5
+
+
+def test_bench_starts_its_own_ranks_when_asked_for_several_gpus(monkeypatch):
+    """bench.py --gpus N without a launcher environment must start N ranks through torch.distributed.run (and never
+    report n_gpus = 1 for it, as round 1 did)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec_ = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(bench)
+    calls = {}
+
+    def fake_run(cmd, env=None, **kw):
+        calls["cmd"], calls["env"] = cmd, env
+
+        class R:
+            returncode = 0
+        return R()
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = calls["cmd"]
+    assert "torch.distributed.run" in cmd and "--nproc-per-node=4" in cmd and "--master-addr" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "2"]
+    assert calls["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # under a launcher whose world size disagrees with --gpus the script refuses instead of mis-reporting
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=2" in str(e.value.code)
+
+
+def test_custom_config_yaml_maps_fixed_params(tmp_path, monkeypatch):
+    """ref: sbi_runner.py:4570-4597 + custom_runner.py:298-365: train_args.fixed_params drive one training run."""
+    from synference_amd import SBI_Fitter
+    import synference_amd.fitter as fitter_mod
+    cfg = tmp_path / "best.yaml"
+    cfg.write_text("train_args:\n  skip_optimization: True\n  validation_fraction: 0.1\n  fixed_params:\n"
+                   "    model_choice: \"nsf\"\n    optimizer_choice: \"AdamW\"\n    learning_rate: 0.0003\n"
+                   "    training_batch_size: 52\n    stop_after_epochs: 47\n    clip_max_norm: 4.7\n"
+                   "    nsf_hidden_features: 69\n    nsf_num_transforms: 15\n    nsf_num_bins: 8\n")
+    seen = {}
+
+    class FakeRunner:
+        @classmethod
+        def load(cls, **kw):
+            seen.update(kw)
+            return cls()
+
+        def __call__(self, loader, seed=None):
+            return "posterior", [{"ok": True}]
+
+    monkeypatch.setattr(fitter_mod, "HIPRunner", FakeRunner)
+    rng = np.random.default_rng(0)
+    f = SBI_Fitter("y", ["a", "b"], ["F0", "F1", "F2"], feature_array=rng.normal(size=(50, 3)),
+                   parameter_array=rng.normal(size=(50, 2)))
+    post, stats = f.run_single_sbi(custom_config_yaml=str(cfg), verbose=False, save_model=False, random_seed=1)
+    ta = seen["train_args"]
+    assert ta["training_batch_size"] == 52 and ta["stop_after_epochs"] == 47 and ta["optimizer_choice"] == "AdamW"
+    assert abs(ta["learning_rate"] - 3e-4) < 1e-12 and abs(ta["clip_max_norm"] - 4.7) < 1e-12 and ta["validation_fraction"] == 0.1
+    net = seen["nets"][0]
+    assert net.model == "nsf" and net.model_args == dict(hidden_features=69, num_transforms=15, num_bins=8)
+    bad = tmp_path / "search.yaml"
+    bad.write_text("train_args:\n  optuna: {n_trials: 3}\n")
+    with pytest.raises(ValueError, match="Optuna"):
+        f.run_single_sbi(custom_config_yaml=str(bad), verbose=False)

@@ -197,10 +197,18 @@ def test_flux_to_abmag_matches_reference_formula():
     with np.errstate(all="ignore"):
         ref = -2.5 * np.log10(f.astype(np.float64) / 1000.0) + 23.9      # sbi_runner.py:1705
         ref[f < 0] = 50.0                                                  # :1706, :1714
-        ref[~np.isfinite(ref)] = 50.0
-        ref[ref > 50.0] = 50.0                                             # :1932
+        ref[ref > 50.0] = 50.0                                             # :1932 (f == 0 -> +inf -> limit)
         rerr = 2.5 * e.astype(np.float64) / (np.log(10) * f.astype(np.float64))
-    assert np.abs(mag.cpu().double().numpy() - ref).max() < 2e-5
+    got = mag.cpu().double().numpy()
+    assert np.isnan(got[5, 0]) and np.isnan(ref[5, 0])                     # a missing band stays NaN (masked downstream)
+    fin = np.isfinite(ref)
+    assert fin.sum() == ref.size - 1 and np.abs(got[fin] - ref[fin]).max() < 2e-5
+    # contiguous but 16-byte-misaligned views are accepted (copied)
+    base = torch.as_tensor(np.concatenate([[0.0], f.reshape(-1)]).astype(np.float32)).cuda()
+    mis = base[1:].reshape(f.shape)
+    assert mis.data_ptr() % 16 != 0
+    got2 = flux_to_abmag(mis, None, 50.0).cpu().double().numpy()
+    assert np.array_equal(np.isnan(got2), np.isnan(got)) and np.abs(got2[fin] - got[fin]).max() == 0
     ok = np.isfinite(rerr) & (f > 0)
     assert np.abs(merr.cpu().double().numpy()[ok] - rerr[ok]).max() < 1e-4 * np.abs(rerr[ok]).max()
 
