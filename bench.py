@@ -263,6 +263,12 @@ def cpu_baseline(spec, flat, x_rows, th_rows, lo, hi, S, budget_s, train_theta, 
                                                "sample": "4 s at batch 16384"}}}
 
 
+def note(msg):
+    """progress line on stderr (rank 0): long runs must show signs of life"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -328,6 +334,7 @@ def main():
         if it == a.fit_steps - 1:
             fit_loss = float(lossv.mean().item())
     flow.set_params(flat)
+    note(f"warm-up fit done (loss {fit_loss:.3f}); sampling {a.warmup}+{a.steps} steps")
     lo, hi = prior.low.to(dev), prior.high.to(dev)
     X = torch.as_tensor(x_test).to(dev)
     M, S = X.shape[0], a.draws
@@ -373,6 +380,7 @@ def main():
     contract = wl["f_draw"] * accepted_per_launch / (k_ms * 1e-3) / 1e12
     traffic, traffic_src = pmc_traffic("sample") if a.workload == "maf_cfg2" and M == 2000 and S == 1000 else (None, None)
 
+    note(f"sampling done: {1e3 * t_samp / a.steps:.3f} ms/step, kernel {k_ms:.3f} ms, unfilled {unfilled_all}")
     # ---------------- train leg: fwd+bwd (+ all-reduce) + clip + Adam at the per-GPU batch
     tsteps = a.train_steps or a.steps
     B = a.train_batch
@@ -504,6 +512,7 @@ def main():
         "log_prob": {"value": lp_rows, "unit": "rows/s", "rows_per_call": int(Xl.shape[0]),
                      "achieved_tflops": lp_rows * wl["f_lp"] / 1e12},
     }
+    note("GPU legs done; CPU baseline (about 30 s)" if world == 1 and not a.no_cpu_baseline else "GPU legs done")
     if world == 1 and not a.no_cpu_baseline:
         rec["cpu_baseline"] = cpu_baseline(est.spec, flat.cpu().numpy(), x_test, th_test, prior.low.numpy(),
                                            prior.high.numpy(), S, a.cpu_seconds, th_lib[tr], x_lib[tr])

@@ -44,8 +44,8 @@ def sample_slots(spec: flows.FlowSpec, flat: torch.Tensor, x: np.ndarray, slots:
     ``max_attempts`` an integer: hard ceiling, rows that exhaust it are NaN (the reference's failure
     convention, sbi_runner.py:6458-6460).  ``None``: no ceiling, as in [UPSTREAM] accept_reject_sample
     -- with the product's progress rule (include/synference_hip.h, sf_flow_sample): attempts go in the
-    windows [0,64), [64,1024), [1024,16384), ...; after a window past the first, the open slots of a
-    galaxy that got no draw accepted during that window become NaN rows.
+    windows [0,1024), [1024,16384), ...; after a window, the open slots of a galaxy that got no draw
+    accepted between its 64th attempt and the end of that window become NaN rows.
     Returns (theta[len(slots), D], attempts_used[len(slots)]).
     """
     slots = np.asarray(slots, dtype=np.uint64)
@@ -56,7 +56,7 @@ def sample_slots(spec: flows.FlowSpec, flat: torch.Tensor, x: np.ndarray, slots:
     lo_ = None if lo is None else np.asarray(lo, dtype=np.float32)
     hi_ = None if hi is None else np.asarray(hi, dtype=np.float32)
     ceiling = int(max_attempts) if max_attempts else 1 << 30
-    attempt, limit, stage = 0, min(64, ceiling), 0
+    attempt, limit = 0, min(1024, ceiling)
     xs = np.asarray(x)
     while len(pending) and attempt < ceiling:
         progressed = set()
@@ -70,13 +70,13 @@ def sample_slots(spec: flows.FlowSpec, flat: torch.Tensor, x: np.ndarray, slots:
             ok = in_box(th.to(torch.float32).numpy(), lo_, hi_)
             out[pending[ok]] = th.numpy()[ok]
             used[pending] += 1
-            progressed.update(g[ok].tolist())
+            if attempt >= 64:
+                progressed.update(g[ok].tolist())
             pending = pending[~ok]
             attempt += 1
-        if not max_attempts and stage >= 1 and len(pending):
+        if not max_attempts and len(pending):
             g = (slots[pending] // np.uint64(S)).astype(np.int64)
             pending = pending[np.isin(g, list(progressed))]
-        stage += 1
         limit = min(ceiling, limit * 16)
     return out, used
 

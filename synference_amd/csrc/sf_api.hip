@@ -315,14 +315,14 @@ int sf_flow_sample_round(sf_flow* f, const float* x, int64_t S, const uint32_t* 
 }
 
 // ---- persistent sampler ------------------------------------------------------------------------
-// Stages of one sampling call.  Stage 1 resolves the dense slot list (first attempts and their retries, attempts
-// [0, 64)) in ONE persistent launch; slots that are still empty afterwards ("survivors": the flow's mass for that
-// galaxy lies almost entirely outside the prior box) go through further launches with the attempt window
-// [64, 1024), [1024, 16384), ... until they are filled, the caller's ceiling `max_attempts` is reached, or -- when
-// the caller set no ceiling (max_attempts <= 0) -- a galaxy got NOT ONE draw accepted during a whole window: its
-// acceptance is then zero to within 1 / (window x open slots) and its open slots become NaN rows, which is what the
-// reference's timeout / error path produces (ref: sbi_runner.py:6443-6460); [UPSTREAM] accept_reject_sample itself
-// would loop forever on such a galaxy.
+// Launches of one sampling call.  The first persistent launch resolves the dense slot list -- first attempts and
+// retries -- up to 1024 attempts per slot (or the caller's ceiling).  Slots that are still empty afterwards
+// ("survivors": the flow's mass for that galaxy lies almost entirely outside the prior box) go through further
+// launches with the attempt windows [1024, 16384), [16384, 262144), ... until they are filled, the caller's ceiling
+// `max_attempts` is reached, or -- when the caller set no ceiling (max_attempts <= 0) -- a galaxy got NOT ONE draw
+// accepted between its 64th attempt and the end of a window: its acceptance is then zero to within
+// 1 / (window x open slots) and its open slots become NaN rows, which is what the reference's timeout / error path
+// produces (ref: sbi_runner.py:6443-6460); [UPSTREAM] accept_reject_sample itself would loop forever on such a galaxy.
 static int ensure_queue(sf_flow* f, int64_t n_slots, int64_t M) {
   if (!f->d_queue) SF_HIP(hipMalloc(&f->d_queue, sizeof(SfQueue)));
   if (!f->h_queue) SF_HIP(hipHostMalloc((void**)&f->h_queue, sizeof(SfQueue), hipHostMallocDefault));
@@ -371,16 +371,20 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
   a.x = x; a.S = (long)S; seed_keys(seed, 0, a.k0, a.k1);
   a.lo = lo; a.hi = hi; a.out = out; a.n_drawn = n_drawn;
   a.q = f->d_queue; a.ring = f->d_ring; a.ring_mask = (uint32_t)(f->ring_cap - 1);
+  a.out_slots = (uint32_t)(M * S);
   const uint32_t* cur = slots;
   int64_t pending = n_slots;
-  uint32_t attempt = 0, limit = ceiling < 64u ? ceiling : 64u;
+  uint32_t attempt = 0, limit = ceiling < 1024u ? ceiling : 1024u;
   int buf = 0, stage = 0;
   double evals = 0.0;
   float rej0 = 0.f;
   int64_t dropped = 0;
   while (pending > 0) {
     SF_HIP(hipMemsetAsync(f->d_queue, 0, sizeof(SfQueue), st));
-    const bool progress_rule = !capped && stage >= 1;
+#ifdef SF_Q_STATS
+    SF_HIP(hipMemsetAsync(&f->d_queue->stats[10], 0xff, sizeof(unsigned long long), st));  // atomicMin target
+#endif
+    const bool progress_rule = !capped;
     if (progress_rule) SF_HIP(hipMemsetAsync(f->d_galacc, 0, (size_t)M * sizeof(int32_t), st));
     a.slots = cur; a.slot_base = 0; a.n_items = (long)pending; a.n_total = (uint32_t)pending;
     a.attempt = attempt; a.attempt_limit = limit; a.attempts_per_slot = 1;
@@ -396,9 +400,24 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
     SF_HIP(hipStreamSynchronize(st));
     if (f->h_queue->error) {
       f->ctab_x = nullptr;
-      return fail(SF_ERR_STATE, "persistent sampler: a device-side wait exceeded its bound (work queue inconsistent)");
+      return fail(SF_ERR_STATE, "persistent sampler: work queue inconsistent (code " + std::to_string(f->h_queue->error) +
+                                    ": 1 = a device-side wait exceeded its bound, 2 = foreign ring entry, 3 = survivor "
+                                    "list overflow, 4 = listed slot outside M*S, 5 = claimed entry never arrived, 6/7 = "
+                                    "claim contention); head " + std::to_string(f->h_queue->head) + " reserve " +
+                                    std::to_string(f->h_queue->reserve) + " resolved " + std::to_string(f->h_queue->resolved) +
+                                    " of " + std::to_string((unsigned)pending) + " survivors " + std::to_string(f->h_queue->n_surv) +
+                                    " dense_next " + std::to_string(f->h_queue->dense_next));
     }
     evals += (double)f->h_queue->evals;
+    if (std::getenv("SF_Q_STATS")) {
+      const unsigned long long* q = f->h_queue->stats;
+      std::fprintf(stderr, "[sf_queue] stage %d: entry-barrier %.3e cyc, serial %.3e cyc, exit-barrier %.3e cyc, idle %.3e cyc in %llu "
+                   "episodes, %llu donations, iterations dense %llu tail %llu, entries %llu, evals %llu, resolved %u/%u\n", stage,
+                   (double)q[0], (double)q[1], (double)q[2], (double)q[3], q[4], q[5], q[6], q[7], q[8],
+                   (unsigned long long)f->h_queue->evals, f->h_queue->resolved, (unsigned)a.n_total);
+      std::fprintf(stderr, "[sf_queue]   max iterations of a workgroup %llu; last flow evaluation ended %.1f us, last exit %.1f us after the first start\n",
+                   q[11], ((double)q[12] - (double)q[10]) * 0.01, ((double)q[13] - (double)q[10]) * 0.01);
+    }
     dropped += (int64_t)f->h_queue->dropped;
     if (stage == 0) rej0 = (float)f->h_queue->rej0;
     pending = (int64_t)f->h_queue->n_surv;

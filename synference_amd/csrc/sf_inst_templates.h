@@ -182,7 +182,8 @@ __global__ __launch_bounds__(64 * WPB) void k_sample_persist(SfSampArgs args_in,
   constexpr int IPW = WPB * 32 * NS;
   const int wave = threadIdx.x >> 6;
   unsigned int* ctrl = reinterpret_cast<unsigned int*>(sf_lds_image + ctrl_off);
-  if (threadIdx.x < SF_Q_HDR) ctrl[threadIdx.x] = 0u;
+  unsigned int pf;
+  sf_q_begin<IPW>(args_in.a, ctrl, pf);
   for (;;) {
     const SfSampArgs* ap;
     {
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(64 * WPB) void k_sample_persist(SfSampArgs args_in,
     const SfSampleArgsHost& a = ap->a;
     const int lane = (threadIdx.x & 63) + sf_opaque_zero();
     const int c = lane & 31, h = lane >> 5;
-    if (!sf_q_fetch<IPW, 32>(a, ctrl)) break;
+    if (!sf_q_fetch<IPW, 32>(a, ctrl, pf)) break;
     float u[NS][SF_DMAX];
     const float* xr[NS];
     float logdet[NS];
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(64 * WPB) void k_sample_persist(SfSampArgs args_in,
       if (leader && (a.n_drawn || a.gal_acc)) {
         const long gal = (long)(slot / (uint32_t)a.S);
         if (a.n_drawn && att_base > 0) atomicAdd(&a.n_drawn[gal], first >= 0 ? first + 1 : (int)tried);
-        if (hit && a.gal_acc) atomicAdd(&a.gal_acc[gal], 1);
+        if (hit && a.gal_acc && att_base >= 64u) atomicAdd(&a.gal_acc[gal], 1);  // progress past the 64th attempt
       }
       if (retry) {
         const unsigned int pos = atomicAdd(&ctrl[2], 1u);

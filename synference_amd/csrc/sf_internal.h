@@ -30,6 +30,7 @@ struct SfSampleArgsHost {
   uint32_t ring_mask = 0;
   uint32_t attempt_limit = 0xffffffffu;  // attempts [attempt, attempt_limit) are tried by this launch; then -> rejected[]
   uint32_t n_total = 0;                // slots of the dense list (== n_items)
+  uint32_t out_slots = 0;              // M * S: every slot id must be below this
   int32_t* gal_acc = nullptr;          // optional [M]: += 1 per accepted slot of the galaxy (progress test between stages)
 };
 

@@ -368,7 +368,13 @@ template <int NB, bool SPAN>
 __global__ __launch_bounds__(256, 3) void k_maf_samp16(SfSamp16Args args_in) {
   const int wave = threadIdx.x >> 6;
   unsigned int* ctrl = reinterpret_cast<unsigned int*>(sf_lds16 + args_in.m.t16_stride);
-  if (threadIdx.x < SF_Q_HDR) ctrl[threadIdx.x] = 0u;
+  unsigned int pf;
+  sf_q_begin<64>(args_in.a, ctrl, pf);
+#ifdef SF_Q_STATS
+  const unsigned long long qs_k0 = __builtin_amdgcn_s_memtime();
+  unsigned long long qs_iters = 0, qs_last_work = 0;
+  if (threadIdx.x == 0) atomicMin(&args_in.a.q->stats[10], __builtin_amdgcn_s_memrealtime());  // first start (100 MHz)
+#endif
   for (;;) {
     const SfSamp16Args* ap;
     {
@@ -380,7 +386,20 @@ __global__ __launch_bounds__(256, 3) void k_maf_samp16(SfSamp16Args args_in) {
     const SfSampleArgsHost& a = ap->a;
     const int lane = (threadIdx.x & 63) + sf_opaque_zero();  // lane-derived addresses are recomputed per iteration
     const int s = lane & 15, g4 = lane >> 4;
-    if (!sf_q_fetch<64, 16>(a, ctrl)) break;
+    if (!sf_q_fetch<64, 16>(a, ctrl, pf)) {
+#ifdef SF_Q_STATS
+      if (threadIdx.x == 0) {
+        atomicAdd(&a.q->stats[9], __builtin_amdgcn_s_memtime() - qs_k0);  // workgroup lifetime
+        atomicMax(&a.q->stats[11], qs_iters);                              // most iterations of one workgroup
+        atomicMax(&a.q->stats[12], qs_last_work);                          // end of the last flow evaluation (100 MHz)
+        atomicMax(&a.q->stats[13], __builtin_amdgcn_s_memrealtime());      // last exit
+      }
+#endif
+      break;
+    }
+#ifdef SF_Q_STATS
+    ++qs_iters;
+#endif
     const int wi = wave * 16 + s;
     const int NT = m.nT16;
     f32x4 u;
@@ -549,7 +568,7 @@ __global__ __launch_bounds__(256, 3) void k_maf_samp16(SfSamp16Args args_in) {
     if (leader && (a.n_drawn || a.gal_acc)) {
       const long gal = (long)(slot / (uint32_t)a.S);
       if (a.n_drawn && att_base > 0) atomicAdd(&a.n_drawn[gal], first >= 0 ? first + 1 : (int)tried);
-      if (hit && a.gal_acc) atomicAdd(&a.gal_acc[gal], 1);
+      if (hit && a.gal_acc && att_base >= 64u) atomicAdd(&a.gal_acc[gal], 1);  // progress past the 64th attempt
     }
     if (retry) {
       const unsigned int pos = atomicAdd(&ctrl[2], 1u);
@@ -568,6 +587,9 @@ __global__ __launch_bounds__(256, 3) void k_maf_samp16(SfSamp16Args args_in) {
       if (n_ev) atomicAdd(&ctrl[5], n_ev);
       if (n_r0) atomicAdd(&ctrl[6], n_r0);
     }
+#ifdef SF_Q_STATS
+    qs_last_work = __builtin_amdgcn_s_memrealtime();
+#endif
   }
 }
 

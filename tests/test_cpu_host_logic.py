@@ -265,7 +265,7 @@ def test_oracle_batch_accept_reject_sampler_and_uncapped_slot_schedule():
     # both samplers target the same distribution
     from scipy import stats
     assert min(stats.ks_2samp(out[:, d], smp[:, d]).pvalue for d in range(2)) > 1e-3
-    # the progress rule: a dead galaxy (NaN context) ends as NaN rows after the window [64, 1024); a ceiling is a ceiling
+    # the progress rule: a dead galaxy (NaN context) ends as NaN rows after the window [0, 1024); a ceiling is a ceiling
     xx = x[:2].numpy().copy()
     xx[1] = np.nan
     out, used = OP.sample_slots(o, flat, xx, np.arange(20, dtype=np.uint64), 10, 7, lo, hi)
