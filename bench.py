@@ -158,16 +158,36 @@ def max_over_ranks(t, world, dev, gloo):
 # CPU baseline (rank 0, N = 1 only): the oracle driven the way the reference drives sbi
 # ---------------------------------------------------------------------------------------------------------------
 def host_cpu():
+    """(CPU model, logical cores of the host, cores this process may actually use): the last is the smaller of the
+    affinity mask and the cgroup CPU quota -- on a shared GPU box the mask shows every core of the host while the quota
+    grants a share, and a thread pool sized by the mask would mostly wait for its quota."""
     model, cores = "unknown", os.cpu_count() or 1
     try:
-        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
-        for line in out.splitlines():
-            if line.startswith("Model name:"):
-                model = line.split(":", 1)[1].strip()
-    except Exception:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
         pass
     usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else cores
-    return model, cores, usable
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:            # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = fh.read().split()[:2]
+            if q != "max":
+                quota = int(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, per = int(fq.read()), int(fp.read())
+                if q > 0:
+                    quota = q / float(per)
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        usable = max(1, min(usable, int(quota + 0.5)))
+    return model, cores, usable, quota
 
 
 def cpu_baseline(spec, flat, x_rows, th_rows, lo, hi, S, budget_s, train_theta, train_x):
@@ -177,22 +197,26 @@ def cpu_baseline(spec, flat, x_rows, th_rows, lo, hi, S, budget_s, train_theta, 
     B4 the epoch loop of custom_runner.py:580-618 (Adam, clip 5.0) at batch 64 and at the GPU leg's batch."""
     from oracle import flows as OF
     from oracle import posterior as OP
-    model, cores, usable = host_cpu()
+    model, cores, usable, quota = host_cpu()
+    usable = min(usable, 32)   # torch CPU ops of this size stop scaling long before that
+    note(f"CPU baseline on {model}: host {cores} logical cores, cgroup quota {quota}, using {usable} threads")
     ospec = OF.FlowSpec(kind=spec.kind, D=spec.D, C=spec.C, H=spec.H, T=spec.T, K=spec.K, NB=spec.NB,
                         perms=spec.perms, theta_mean=spec.theta_mean.astype(np.float64),
                         theta_std=spec.theta_std.astype(np.float64), x_mean=spec.x_mean.astype(np.float64),
                         x_std=spec.x_std.astype(np.float64))
     fl = torch.as_tensor(flat, dtype=torch.float32)
-    # ---- B1
+    # ---- B1: the reference's own schedule -- sbi's batch accept/reject loop, one galaxy per call
     torch.set_num_threads(1)
+    gen = torch.Generator().manual_seed(2025)
     times, g = [], 0
     t_all = time.perf_counter()
     while g < len(x_rows) and (time.perf_counter() - t_all) < budget_s:
         t0 = time.perf_counter()
-        OP.sample(ospec, fl, x_rows[g:g + 1], S, 2025 + g, lo, hi, dtype=torch.float32)
+        OP.accept_reject_sample(ospec, fl, x_rows[g], S, lo, hi, gen)
         times.append(time.perf_counter() - t0)
         g += 1
     med = float(np.median(times))
+    note(f"B1 done: {len(times)} galaxies, median {med:.4f} s/object")
     # ---- B3 (1 thread): per row, then batched
     xt, tt = torch.as_tensor(x_rows), torch.as_tensor(th_rows, dtype=torch.float32)
     n_rows, t0 = 0, time.perf_counter()
@@ -226,13 +250,15 @@ def cpu_baseline(spec, flat, x_rows, th_rows, lo, hi, S, budget_s, train_theta, 
             n += batch
         return n / (time.perf_counter() - t0)
 
+    note("B3 (1 thread) done")
     tr64_1 = train_rate(64, 3.0)
+    note("B4 (1 thread) done")
     # ---- all usable cores
     torch.set_num_threads(usable)
     nb = min(len(x_rows), 64)
-    OP.sample(ospec, fl, x_rows[:4], S, 6, lo, hi, dtype=torch.float32)  # thread-pool warm-up
+    OP.sample(ospec, fl, x_rows[:4], S, 6, lo, hi, max_attempts=64, dtype=torch.float32)  # thread-pool warm-up
     t0 = time.perf_counter()
-    OP.sample(ospec, fl, x_rows[:nb], S, 7, lo, hi, dtype=torch.float32)
+    OP.sample(ospec, fl, x_rows[:nb], S, 7, lo, hi, max_attempts=64, dtype=torch.float32)
     tb = time.perf_counter() - t0
     with torch.no_grad():
         t0 = time.perf_counter()
@@ -241,15 +267,16 @@ def cpu_baseline(spec, flat, x_rows, th_rows, lo, hi, S, budget_s, train_theta, 
             OF.log_prob(ospec, fl, tt, xt)
             reps += 1
     lp_batched_all = reps * len(xt) / (time.perf_counter() - t0)
+    note("B2/B3 (all cores) done")
     tr64_all = train_rate(64, 2.0)
     trbig_all = train_rate(16384, 4.0)
     return {"value": S / med, "unit": "samples/s", "cores": 1, "kind": "port",
-            "cpu_model": model, "host_cores": cores, "usable_cores": usable,
-            "sample": f"{len(times)} galaxies x {S} accepted draws, one galaxy per call (oracle/posterior.py, "
-                      f"torch fp32, 1 thread); median {med:.4f} s/object "
+            "cpu_model": model, "host_cores": cores, "usable_cores": usable, "cgroup_cpu_quota": quota,
+            "sample": f"{len(times)} galaxies x {S} accepted draws, one galaxy per call (oracle/posterior.py "
+                      f"accept_reject_sample = sbi's batch loop, torch fp32, 1 thread); median {med:.4f} s/object "
                       f"(16-84%: {np.percentile(times, 16):.4f}-{np.percentile(times, 84):.4f})",
             "batched_all_cores": {"value": nb * S / tb, "unit": "samples/s", "cores": usable,
-                                  "sample": f"{nb} galaxies x {S} draws in one call"},
+                                  "sample": f"{nb} galaxies x {S} draws in one call (per-slot schedule, ceiling 64 attempts)"},
             "log_prob": {"per_row_1thread": {"value": lp_row, "unit": "rows/s", "cores": 1,
                                              "sample": f"{n_rows} rows, one row per call (sbi_runner.py:7193-7196 loop, raw density)"},
                          "batched_1thread": {"value": lp_batched_1, "unit": "rows/s", "cores": 1,

@@ -31,11 +31,13 @@ torch.cuda.synchronize(); note("fit done")
 flow.set_params(flat)
 lo, hi = prior.low.to(dev), prior.high.to(dev)
 X = torch.as_tensor(x_test).to(dev); S = 1000
-for m in (4, 64, 500, 2000):
-    for cap in (1, 8, 64):
+for m in (2000,):
+    for cap in (1, 64, 1024, None):
         out = torch.empty((m, S, D), dtype=torch.float32, device=dev)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        flow.sample(X[:m], S, lo, hi, seed=1000, max_attempts=cap, out=out)
+        o, nd = flow.sample(X[:m], S, lo, hi, seed=1000, max_attempts=cap, out=out, return_counts=True)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         st = flow.last_sample_stats
+        acc = (S / nd.float().clamp_min(1)).sort().values
+        note(f"lowest acceptances: {[round(float(v), 5) for v in acc[:6]]}")
         note(f"sample M={m} cap={cap}: {dt*1e3:.2f} ms kernel={st['dense_ms']:.3f} ms launches={st['rounds']} unfilled={flow.last_unfilled} evals={st['evaluations']:.3e}")

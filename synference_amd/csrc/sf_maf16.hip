@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256, 3) void k_maf_samp16(SfSamp16Args args_in) {
     const SfSampleArgsHost& a = ap->a;
     const int lane = (threadIdx.x & 63) + sf_opaque_zero();  // lane-derived addresses are recomputed per iteration
     const int s = lane & 15, g4 = lane >> 4;
-    if (!sf_q_fetch<64, 16>(a, ctrl, pf)) {
+    if (!sf_q_fetch<64, 64>(a, ctrl, pf)) {
 #ifdef SF_Q_STATS
       if (threadIdx.x == 0) {
         atomicAdd(&a.q->stats[9], __builtin_amdgcn_s_memtime() - qs_k0);  // workgroup lifetime
@@ -546,12 +546,28 @@ __global__ __launch_bounds__(256, 3) void k_maf_samp16(SfSamp16Args args_in) {
     const unsigned long long okb = __ballot(ok);
     const uint32_t acc16 = (uint32_t)(okb & (okb >> 16) & (okb >> 32) & (okb >> 48) & 0xffffull) &
                            (uint32_t)(__ballot(valid) & 0xffffull);
-    // A <= 16 consecutive items hold attempts att_base .. att_base+A-1 of one slot: the lowest accepted one wins
+    // A consecutive items hold attempts att_base .. att_base+A-1 of one slot: the lowest accepted one wins.
+    // A <= 16: the group sits inside this wave's tile.  A = 32 / 64 (the last few slots of a catalogue, each tried by
+    // half of / the whole workgroup at once): the waves of the group combine through four LDS words.
     const int A = 1 << lgA;
-    const int grp0 = (s / A) * A;
-    const uint32_t gmask = (acc16 >> grp0) & ((1u << A) - 1u);
-    const int first = gmask ? (int)__builtin_ctz(gmask) : -1;
-    const int me = s - grp0;
+    int first, me;
+    if (lgA <= 4) {
+      const int grp0 = (s / A) * A;
+      const uint32_t gmask = (acc16 >> grp0) & ((1u << A) - 1u);
+      first = gmask ? (int)__builtin_ctz(gmask) : -1;
+      me = s - grp0;
+    } else {
+      if ((threadIdx.x & 63) == 0) ctrl[20 + wave] = acc16 ? (unsigned)__builtin_ctz(acc16) : 16u;
+      __syncthreads();  // (lgA is the same for the whole workgroup)
+      const int gw0 = (int)((e << lgA) >> 4), gwn = A >> 4;  // first wave of the group, waves per group
+      first = -1;
+#pragma unroll
+      for (int w = 3; w >= 0; --w) {
+        const unsigned int cw = ctrl[20 + w];
+        if (w >= gw0 && w < gw0 + gwn && cw < 16u) first = (w - gw0) * 16 + (int)cw;
+      }
+      me = wi - (int)(e << lgA);
+    }
     if (valid && me == first) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)

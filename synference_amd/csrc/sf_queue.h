@@ -38,9 +38,10 @@ struct SfQueue {  // device memory owned by the handle; zeroed before each persi
 // control block of a workgroup in LDS (uint32 words), IPW = items per workgroup iteration
 //   [0] entries fetched (0 = exit)  [1] log2(attempts per entry)  [2] retry entries staged  [3] survivors staged
 //   [4] resolved  [5] evaluations  [6] first-attempt rejections  [7],[8] the workgroup's current range of the dense
-//   list  [9] dense list exhausted  [10] tickets held  [12..19] their ring positions
+//   list  [9] dense list exhausted  [10] tickets held  [12..19] their ring positions  [20..23] per-wave candidates of
+//   a speculation group that spans waves
 //   then slot[IPW] att[IPW] push_slot[IPW] push_att[IPW] surv_slot[IPW]
-#define SF_Q_HDR 20
+#define SF_Q_HDR 24
 #define SF_Q_WORDS(IPW) (SF_Q_HDR + 5 * (IPW))
 
 __device__ __forceinline__ unsigned int sf_q_ld(const unsigned int* p) {
@@ -104,33 +105,37 @@ __device__ __forceinline__ bool sf_q_fetch(const Args& a, unsigned int* ctrl, un
       w_slot[i] = p_slot[i];
       w_att[i] = p_att[i];
     }
-    // ---- top up from the workgroup's range of the dense list; ranges are reserved one iteration ahead
+    // ---- top up from the workgroup's range of the dense list; ranges are reserved one iteration ahead.  A top-up
+    // may end one range and begin the next (two segments at most: a range holds IPW items)
     unsigned int dcur = ctrl[7], dend = ctrl[8], dense_done = ctrl[9];
-    unsigned int nd = 0, dbase = dcur;
-    if (!dense_done && dcur >= dend) {  // range used up: look at the reserved one (its atomic was issued an iteration ago)
-      const unsigned int nb = __shfl(pf, 0, 64);
-      if (nb >= a.n_total) {
-        dense_done = 1u;  // (also found out by a workgroup whose own retries fill the whole iteration)
-      } else if (n < (unsigned)IPW) {
+    if (!dense_done && n >= (unsigned)IPW && dcur >= dend) {
+      // own retries fill the whole iteration: still find out when the dense list has run dry (tail mode shares work)
+      if (__shfl(pf, 0, 64) >= a.n_total) dense_done = 1u;
+    }
+#pragma unroll 1
+    for (int seg = 0; seg < 2; ++seg) {
+      if (dense_done || n >= (unsigned)IPW) break;  // (a full iteration never touches `pf`: it may have just been issued)
+      if (dcur >= dend) {  // range used up: adopt the reserved one (its atomic was issued an iteration ago)
+        const unsigned int nb = __shfl(pf, 0, 64);
+        if (nb >= a.n_total) {
+          dense_done = 1u;
+          break;
+        }
         dcur = nb;
         dend = a.n_total - nb < (unsigned)IPW ? a.n_total : nb + (unsigned)IPW;
         if (lane == 0) pf = atomicAdd(&q->dense_next, (unsigned)IPW);  // for a later iteration: not waited for here
-        dbase = dcur;
       }
-    }
-    if (!dense_done && dcur < dend && n < (unsigned)IPW) {
       const unsigned int want = (unsigned)IPW - n;
-      nd = dend - dcur < want ? dend - dcur : want;
-      dbase = dcur;
+      const unsigned int nd = dend - dcur < want ? dend - dcur : want;
+      for (unsigned int i = lane; i < nd; i += 64) {
+        unsigned int sl = a.slots ? a.slots[dcur + i] : (unsigned int)a.slot_base + dcur + i;
+        if (sl >= a.out_slots) { atomicExch(&q->error, 4u); sl = 0u; }  // a listed slot outside out[M*S]
+        w_slot[n + i] = sl;
+        w_att[n + i] = a.attempt;
+      }
+      n += nd;
       dcur += nd;
     }
-    for (unsigned int i = lane; i < nd; i += 64) {
-      unsigned int sl = a.slots ? a.slots[dbase + i] : (unsigned int)a.slot_base + dbase + i;
-      if (sl >= a.out_slots) { atomicExch(&q->error, 4u); sl = 0u; }  // a listed slot outside out[M*S]
-      w_slot[n + i] = sl;
-      w_att[n + i] = a.attempt;
-    }
-    n += nd;
     unsigned int lg = 0;
     if (dense_done) {  // ---- tail mode
       if (lane == 0) {
