@@ -110,6 +110,10 @@ int sf_flow_pack_table(const sf_flow* f, int32_t* src1, int32_t* src2, int64_t n
 /* the same for the 16-row image of the incremental MAF sampler (size 0 when the flow has none) */
 int64_t sf_flow_packed16_size(const sf_flow* f);
 int sf_flow_pack_table16(const sf_flow* f, int32_t* src1, int32_t* src2, int64_t n_packed16);
+/* split-bf16 image of the hidden blocks of the persistent 16-row sampler: src[i] = logical index | (part << 30) for
+ * bf16 element i (part 0: hi = bf16(w), part 1: lo = bf16(w - hi)), -1 = zero; size 0 when the flow has none */
+int64_t sf_flow_packed16b_size(const sf_flow* f);
+int sf_flow_pack_table16b(const sf_flow* f, int32_t* src, int64_t n);
 /* byte-for-byte description of the packed image for diagnostics (JSON, NUL-terminated) */
 int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen);
 

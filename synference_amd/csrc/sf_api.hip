@@ -50,6 +50,12 @@ static int ensure_device(sf_flow* f) {
     SF_HIP(hipMemcpy(f->d_s16a, f->L.src16a.data(), n16 * sizeof(int32_t), hipMemcpyHostToDevice));
     SF_HIP(hipMemcpy(f->d_s16b, f->L.src16b.data(), n16 * sizeof(int32_t), hipMemcpyHostToDevice));
   }
+  if (f->L.dev.m16_ok && f->L.n_packed16B > 0) {
+    const size_t nB = (size_t)f->L.n_packed16B;
+    SF_HIP(hipMalloc(&f->d_packed16B, nB * sizeof(unsigned short)));
+    SF_HIP(hipMalloc(&f->d_s16B, nB * sizeof(int32_t)));
+    SF_HIP(hipMemcpy(f->d_s16B, f->L.src16B.data(), nB * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   if (f->L.n_packedB > 0) {
     SF_HIP(hipMalloc(&f->d_packedB, (size_t)f->L.n_packedB * sizeof(unsigned short)));
     SF_HIP(hipMalloc(&f->d_bsrc, (size_t)f->L.n_packedB * sizeof(int32_t)));
@@ -93,7 +99,7 @@ void sf_flow_destroy(sf_flow* f) {
   if (f->dev_ready) {
     (void)hipFree(f->d_packed); (void)hipFree(f->d_packedT); (void)hipFree(f->d_cst); (void)hipFree(f->d_packedB); (void)hipFree(f->d_bsrc);
     (void)hipHostFree(f->h_cnt); if (f->ev_train[0]) (void)hipEventDestroy(f->ev_train[0]); if (f->ev_train[1]) (void)hipEventDestroy(f->ev_train[1]); if (f->ev_dense[0]) (void)hipEventDestroy(f->ev_dense[0]); if (f->ev_dense[1]) (void)hipEventDestroy(f->ev_dense[1]);
-    (void)hipFree(f->d_ctab); (void)hipFree(f->d_packed16); (void)hipFree(f->d_s16a); (void)hipFree(f->d_s16b);
+    (void)hipFree(f->d_ctab); (void)hipFree(f->d_packed16B); (void)hipFree(f->d_s16B); (void)hipFree(f->d_packed16); (void)hipFree(f->d_s16a); (void)hipFree(f->d_s16b);
     (void)hipFree(f->d_s1); (void)hipFree(f->d_s2); (void)hipFree(f->d_t1); (void)hipFree(f->d_t2);
     (void)hipFree(f->d_flat); (void)hipFree(f->d_gpacked); (void)hipFree(f->d_gdst);
     (void)hipFree(f->d_queue); (void)hipFree(f->d_ring); (void)hipFree(f->d_galacc); (void)hipHostFree(f->h_queue);
@@ -120,6 +126,15 @@ int sf_flow_pack_table16(const sf_flow* f, int32_t* src1, int32_t* src2, int64_t
   if (!f->L.dev.m16_ok || n_packed16 != f->L.n_packed16) return fail(SF_ERR_INVALID, "no 16-row image or size mismatch");
   std::memcpy(src1, f->L.src16a.data(), (size_t)n_packed16 * sizeof(int32_t));
   std::memcpy(src2, f->L.src16b.data(), (size_t)n_packed16 * sizeof(int32_t));
+  return SF_OK;
+}
+
+int64_t sf_flow_packed16b_size(const sf_flow* f) { return (f && f->L.dev.m16_ok) ? f->L.n_packed16B : 0; }
+
+int sf_flow_pack_table16b(const sf_flow* f, int32_t* src, int64_t n) {
+  if (!f || !src) return fail(SF_ERR_INVALID, "null argument");
+  if (!f->L.dev.m16_ok || n != f->L.n_packed16B) return fail(SF_ERR_INVALID, "no split-bf16 image or size mismatch");
+  std::memcpy(src, f->L.src16B.data(), (size_t)n * sizeof(int32_t));
   return SF_OK;
 }
 
@@ -154,6 +169,7 @@ int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen) {
   add("o16_w0", v.o16_w0); add("o16_wc", v.o16_wc); add("o16_b0", v.o16_b0); add("o16_wk0", v.o16_wk[0]);
   add("o16_wk1", v.o16_wk[1]); add("o16_bk0", v.o16_bk[0]); add("o16_bk1", v.o16_bk[1]); add("o16_hv", v.o16_hv);
   add("o16_hvb", v.o16_hvb);
+  add("t16_a", v.t16_a); add("t16B_stride", v.t16B_stride); add("nP16", v.nP16); add("o16B_wk0", v.o16B_wk[0]); add("o16B_wk1", v.o16B_wk[1]);
   add("m16_ok", v.m16_ok); add("nT16", v.nT16); add("nC16", v.nC16); add("t16_stride", v.t16_stride);
   s += "\"g16_tile\": [";
   for (int i = 0; i < SF_DMAX; ++i) s += std::to_string(v.g16_tile[i]) + (i + 1 < SF_DMAX ? ", " : "], ");
@@ -191,6 +207,7 @@ int sf_flow_set_params(sf_flow* f, const float* flat, int64_t n, int is_device, 
   f->flat_valid = true;
   SF_HIP(sf_launch_pack(src, f->d_s1, f->d_s2, f->d_packed, (long)f->L.n_packed, st));
   if (f->d_packed16) SF_HIP(sf_launch_pack(src, f->d_s16a, f->d_s16b, f->d_packed16, (long)f->L.n_packed16, st));
+  if (f->d_packed16B) SF_HIP(sf_launch_pack_bf16_split(src, f->d_s16B, f->d_packed16B, (long)f->L.n_packed16B, st));
   f->packed16_stale = false;
   if (f->L.n_packedB > 0) SF_HIP(sf_launch_pack_bf16(src, f->d_bsrc, f->d_packedB, (long)f->L.n_packedB, st));
   f->params_set = true;

@@ -46,6 +46,7 @@ hipError_t sf_launch_maf_ctab16(const SfDev& m, const float* x, long M, float* t
 hipError_t sf_launch_pack(const float* flat, const int32_t* s1, const int32_t* s2, float* packed, long n,
                           hipStream_t st);
 hipError_t sf_launch_pack_bf16(const float* flat, const int32_t* src, unsigned short* out, long n, hipStream_t st);
+hipError_t sf_launch_pack_bf16_split(const float* flat, const int32_t* src, unsigned short* out, long n, hipStream_t st);
 hipError_t sf_launch_fill_nan_rows(float* out, const uint32_t* slots, long n, int D, hipStream_t st);
 hipError_t sf_launch_fill_i32(int32_t* p, long n, int32_t v, hipStream_t st);
 // survivors of galaxies with gal_acc == 0 become NaN rows; the others are compacted in place; *n_surv updated
@@ -81,6 +82,8 @@ struct sf_flow {
   int32_t* d_bsrc = nullptr;
   float* d_packed16 = nullptr;          // 16-row image of the incremental MAF inverse (sf_maf16.hip)
   bool packed16_stale = false;          // loss_grad refreshed only the forward image
+  unsigned short* d_packed16B = nullptr;  // split-bf16 hidden blocks of the 16-row sampler (sf_layout.h)
+  int32_t* d_s16B = nullptr;
   int32_t *d_s16a = nullptr, *d_s16b = nullptr;
   int32_t *d_s1 = nullptr, *d_s2 = nullptr, *d_t1 = nullptr, *d_t2 = nullptr;
   float* d_flat = nullptr;      // staging for host-sourced parameters
@@ -115,6 +118,7 @@ struct sf_flow {
     v.cst = d_cst;
     v.packedB = d_packedB;
     v.packed16 = packed16_stale ? nullptr : d_packed16;
+    v.packed16B = reinterpret_cast<const uint32_t*>(d_packed16B);
     v.ctab = nullptr;  // set per launch by the sampler entry points
     return v;
   }

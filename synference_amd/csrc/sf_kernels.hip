@@ -29,6 +29,22 @@ __global__ void k_pack_bf16(const float* __restrict__ flat, const int32_t* __res
   out[i] = __builtin_bit_cast(unsigned short, v);
 }
 
+// split-bf16 pack: src = logical index | (part << 30); part 0 -> hi = bf16(w) (round to nearest even), part 1 ->
+// lo = bf16(w - hi).  Two bf16 per 32-bit word of the image.
+__global__ void k_pack_bf16_split(const float* __restrict__ flat, const int32_t* __restrict__ src,
+                                  unsigned short* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int a = src[i];
+  unsigned short r = 0;
+  if (a >= 0) {
+    const float w = flat[a & 0x3fffffff];
+    const __bf16 hi = (__bf16)w;
+    r = __builtin_bit_cast(unsigned short, (a >> 30) & 1 ? (__bf16)(w - (float)hi) : hi);
+  }
+  out[i] = r;
+}
+
 __global__ void k_fill_nan_rows(float* __restrict__ out, const uint32_t* __restrict__ slots, long n, int D) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -178,6 +194,11 @@ hipError_t sf_launch_pack(const float* flat, const int32_t* s1, const int32_t* s
 hipError_t sf_launch_pack_bf16(const float* flat, const int32_t* src, unsigned short* out, long n, hipStream_t st) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_pack_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, flat, src, out, n);
+  return hipGetLastError();
+}
+hipError_t sf_launch_pack_bf16_split(const float* flat, const int32_t* src, unsigned short* out, long n, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_pack_bf16_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, flat, src, out, n);
   return hipGetLastError();
 }
 hipError_t sf_launch_fill_nan_rows(float* out, const uint32_t* slots, long n, int D, hipStream_t st) {

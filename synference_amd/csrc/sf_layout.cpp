@@ -424,6 +424,7 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
         for (int p = 0; p < D; ++p) u16[p] = sinv[p];
         const std::vector<int> c16 = iota_rows(C, v.nC16 * 16);
         const int NT = v.nT16;
+        // part A (everything but the hidden H x H blocks; staged by both sampler kernels)
         if (t == 0) v.o16_w0 = here();
         linear16(NT, 1, h16row, u16, lW0, D, [&](int j, int i) { return deg_h(j) >= i + 1; });
         if (t == 0) v.o16_wc = here();
@@ -431,8 +432,6 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
         if (t == 0) v.o16_b0 = here();
         bias16(NT, h16row, lb0, lbc);
         for (int k = 0; k < NB && k < 2; ++k) {
-          if (t == 0) v.o16_wk[k] = here();
-          linear16(NT, NT, h16row, h16row, lWk[k], H, [&](int j, int i) { return deg_h(j) >= deg_h(i); });
           if (t == 0) v.o16_bk[k] = here();
           bias16(NT, h16row, lbk[k], -1);
         }
@@ -452,6 +451,39 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
         if (t == 0) v.o16_hvb = here();
         for (int q = 0; q < D; ++q)
           for (int ab = 0; ab < 2; ++ab) push16((int32_t)(lbf + 2 * sinv[q] + ab), -1);
+        while (L.src16a.size() % 1024) push16(-1, -1);
+        if (t == 0) v.t16_a = here();
+        // part B: the hidden blocks in fp32 (k_maf_inv16: parity hook, acceptance counts, explicit rounds)
+        for (int k = 0; k < NB && k < 2; ++k) {
+          if (t == 0) v.o16_wk[k] = here();
+          linear16(NT, NT, h16row, h16row, lWk[k], H, [&](int j, int i) { return deg_h(j) >= deg_h(i); });
+        }
+        // ---- split-bf16 image of the hidden blocks (k_maf_samp16): per block [ot][pair][hi|lo][64 lanes][8 bf16];
+        // element j of lane l is W[out row ot*16 + (l&15)][in row 16*(2*pair + (j>>2)) + 4*(l>>4) + (j&3)] -- the k order
+        // in which two 16-row activation tiles (4 registers each, lane = sample + 16 * row group) form the B operand
+        // of v_mfma_f32_16x16x32_bf16 without moving between lanes.  hi = bf16(w), lo = bf16(w - hi): three products
+        // hi.hi + hi.lo + lo.hi reproduce the fp32 product to ~2^-17 relative.
+        {
+          while (L.src16B.size() % 2048) L.src16B.push_back(-1);  // whole 4 KiB groups (2 bf16 per 32-bit word)
+          const int64_t tbB = (int64_t)L.src16B.size();
+          if (t == 1) v.t16B_stride = (int)(tbB / 2);
+          const int NP = (NT + 1) / 2;
+          v.nP16 = NP;
+          for (int k = 0; k < NB && k < 2; ++k) {
+            if (t == 0) v.o16B_wk[k] = (int)(((int64_t)L.src16B.size() - tbB) / 2);
+            for (int ot = 0; ot < NT; ++ot)
+              for (int pr = 0; pr < NP; ++pr)
+                for (int part = 0; part < 2; ++part)
+                  for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                      const int it = 2 * pr + (j >> 2);
+                      const int oo = h16row[ot * 16 + (l & 15)];
+                      const int ii = it < NT ? h16row[it * 16 + 4 * (l >> 4) + (j & 3)] : -1;
+                      const bool on = oo >= 0 && ii >= 0 && deg_h(oo) >= deg_h(ii);
+                      L.src16B.push_back(on ? (int32_t)((lWk[k] + (int64_t)oo * H + ii) | ((int64_t)part << 30)) : -1);
+                    }
+          }
+        }
       }
     }
   } else {
@@ -597,6 +629,10 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
     v.t16_stride = (int)L.src16a.size();
   }
   L.n_packed16 = (int64_t)L.src16a.size();
+  while (L.src16B.size() % 2048) L.src16B.push_back(-1);
+  if (T == 1) v.t16B_stride = (int)(L.src16B.size() / 2);
+  L.n_packed16B = (int64_t)L.src16B.size();
+  if (!v.m16_ok) { L.src16B.clear(); L.n_packed16B = 0; }
   if (v.m16_ok && (size_t)v.t16_stride * sizeof(float) > 152 * 1024) v.m16_ok = 0;
   L.n_packedB = (int64_t)L.srcB.size();
   // ---- LDS staging plan (budget: 152 KiB of the 160 KiB LDS; the rest holds the persistent sampler's control block) ---------------------------------

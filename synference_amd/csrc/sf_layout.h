@@ -71,6 +71,10 @@ struct SfDev {
   //   into <= 4 tiles of 16 rows.  m16_ok = 0 when that packing does not exist (then the 32-row path is used).
   const float* packed16;
   int m16_ok, nT16, nC16, t16_stride;
+  int t16_a;     // floats of part A of the 16-row image (everything but the fp32 hidden blocks): what k_maf_samp16 stages
+  // split-bf16 hidden blocks of the 16-row sampler: 32-bit words (2 bf16 each), [ot][pair][hi|lo][64 lanes][4 words]
+  const uint32_t* packed16B;
+  int t16B_stride, nP16, o16B_wk[2];  // words per transform, in-tile pairs, block offsets in words
   int m16_span;  // 1: contiguous packing, degree groups may straddle tiles (g16_lo < g16_tile)
   int o16_w0, o16_wc, o16_b0, o16_wk[2], o16_bk[2], o16_hv, o16_hvb;
   int g16_tile[SF_DMAX];  // LAST tile that holds hidden units of MADE degree g ...
@@ -101,6 +105,9 @@ struct SfLayout {
   std::vector<int32_t> gdst;
   std::vector<int32_t> srcB;          // bf16 hidden image gather table (one entry per bf16 element)
   std::vector<int32_t> src16a, src16b;  // 16-row image gather table (sum of two sources, like src1/src2)
+  std::vector<int32_t> src16B;          // split-bf16 hidden blocks of the 16-row sampler: per bf16 element, logical index |
+                                        // (part << 30), part 0 = hi = bf16(w), 1 = lo = bf16(w - hi); -1 = zero
+  int64_t n_packed16B = 0;
   int64_t n_packed16 = 0;
   int64_t n_packedB = 0;
   std::vector<float> cst;             // constants image

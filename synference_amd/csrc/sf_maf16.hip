@@ -352,9 +352,181 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16(SfDev m, SfSampleArgsHost 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Split-bf16 hidden blocks (k_maf_samp16 only).  The H x H blocks carry ~2/3 of a pass's MACs; on fp32 MFMA
+// (v_mfma_f32_16x16x4_f32: 32 cycles for K = 4) they take as long as the same MACs on the vector pipe.  Here every
+// operand is split into hi = bf16(v) and lo = bf16(v - hi) and the product is hi.hi + hi.lo + lo.hi on
+// v_mfma_f32_16x16x32_bf16 (16 cycles for K = 32, fp32 accumulation): ~2^-17 relative per product -- the draws still
+// meet the oracle at the fp32 tolerance of the parity tests -- at a fifth of the matrix-pipe time.
+// Operand order: two 16-row activation tiles (4 registers per lane each, lane = sample + 16 * row group) ARE the B
+// operand of one K = 32 step: element j of lane l is row 16*(2*pair + (j>>2)) + 4*(l>>4) + (j&3); the weight image
+// (sf_layout.cpp, src16B) stores the A operand in the same k order, hi and lo parts as separate 16-byte fragments.
+// ---------------------------------------------------------------------------------------------------------------
+typedef __bf16 sf_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 sf_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define SF_MFMA16B(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+struct SfSplit2 {  // two activation values' worth of split operands for one 16-row tile: hi/lo packed bf16 pairs
+  unsigned int hi[2], lo[2];
+};
+__device__ __forceinline__ SfSplit2 sf_split16(const f32x4& v) {
+  SfSplit2 t;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const sf_bf16x2 h = {(__bf16)v[2 * q], (__bf16)v[2 * q + 1]};
+    const unsigned int hw = __builtin_bit_cast(unsigned int, h);
+    const float r0 = v[2 * q] - __builtin_bit_cast(float, hw << 16);
+    const float r1 = v[2 * q + 1] - __builtin_bit_cast(float, hw & 0xffff0000u);
+    const sf_bf16x2 l = {(__bf16)r0, (__bf16)r1};
+    t.hi[q] = hw;
+    t.lo[q] = __builtin_bit_cast(unsigned int, l);
+  }
+  return t;
+}
+// acc += W[ot, pair] . (the pair's two tiles)   (three bf16 products; bh / bl ARE the B operands, no moves)
+__device__ __forceinline__ f32x4 sf_mma16x3(const u32x4& w_hi, const u32x4& w_lo, const u32x4& bh, const u32x4& bl, f32x4 acc) {
+  const sf_bf16x8 Ah = __builtin_bit_cast(sf_bf16x8, w_hi), Al = __builtin_bit_cast(sf_bf16x8, w_lo);
+  const sf_bf16x8 Bh = __builtin_bit_cast(sf_bf16x8, bh), Bl = __builtin_bit_cast(sf_bf16x8, bl);
+  acc = SF_MFMA16B(Al, Bh, acc);
+  acc = SF_MFMA16B(Ah, Bl, acc);
+  acc = SF_MFMA16B(Ah, Bh, acc);
+  return acc;
+}
+// fragment of block k: (out tile ot, in-tile pair pr, part 0 = hi / 1 = lo); wB = base of the block in 32-bit words
+__device__ __forceinline__ u32x4 sf_w16b(const unsigned int* wB, int NP, int ot, int pr, int part, int lane) {
+  return reinterpret_cast<const u32x4*>(wB)[((ot * NP + pr) * 2 + part) * 64 + lane];
+}
+
+struct SfPass16B {
+  // split inputs of hidden block k ([0] = initial layer, [1] = output of block 0), held per PAIR of tiles exactly as
+  // the MFMA wants its B operand: components 0,1 = tile 2p (rows 0,1 | rows 2,3), components 2,3 = tile 2p+1
+  u32x4 ph[2][2], pl[2][2];
+  f32x4 head[4];       // output of the last block (fp32: the head rows are per-lane dot products); [tile]
+  f32x4 ut;            // finished dimensions of this transform, tile layout: slot 4*g4 + r
+  const float* c0p;    // this draw's context-table row for the transform (b0 + bc + Wc e(x), tile order), or nullptr
+  const float* xr;     // the draw's context row (no-table path: c0 is evaluated where it is needed)
+};
+// c0 of tile ot = b0 + bc + Wc e(x): from the per-galaxy table, else evaluated on the spot (rare: tables above the
+// size cap); either way it is not kept in registers across the passes
+__device__ __forceinline__ f32x4 sf_c0_16(const SfDev& m, const float* tp, const SfPass16B& S, int ot, int lane, int g4) {
+  if (S.c0p) return *reinterpret_cast<const f32x4*>(S.c0p + ot * 16 + 4 * g4);
+  f32x4 c = sf_ld4(tp + m.o16_b0 + (ot * 4 + g4) * 4);
+  for (int ic = 0; ic < m.nC16; ++ic) {
+    f32x4 ct;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rho = ic * 16 + 4 * g4 + r;
+      const bool ok = rho < m.C;
+      const int rr = ok ? rho : 0;
+      const float v = sf_div(S.xr[rr] - m.cst[m.c_xmean + rr], m.cst[m.c_xstd + rr]);
+      ct[r] = ok ? v : 0.f;
+    }
+    c = sf_mma16(sf_w16(tp + m.o16_wc, m.nC16, ot, ic, lane), ct, c);
+  }
+  return c;
+}
+template <int TILE>
+__device__ __forceinline__ void sf_put16b(SfPass16B& S, int k, const f32x4& v) {  // k is a static loop index at every call
+  const SfSplit2 t = sf_split16(v);
+  S.ph[k][TILE >> 1][(TILE & 1) * 2] = t.hi[0];
+  S.ph[k][TILE >> 1][(TILE & 1) * 2 + 1] = t.hi[1];
+  S.pl[k][TILE >> 1][(TILE & 1) * 2] = t.lo[0];
+  S.pl[k][TILE >> 1][(TILE & 1) * 2 + 1] = t.lo[1];
+}
+
+// One autoregressive pass with the degree group in (static) tile OT (see sf_pass16); hidden blocks on split bf16.
+template <int OT, int NB>
+__device__ __forceinline__ void sf_pass16b(const SfDev& m, const float* tp, const unsigned int* tpB, SfPass16B& S, int NT, int sl,
+                                           float u_sl, int lane, int g4) {
+  constexpr int PR = OT >> 1;  // the pair that holds tile OT; pairs below it are complete
+  const int NP = m.nP16;
+  const float* hv = tp + m.o16_hv + sl * 128 + g4 * 32;
+  const float4 w0 = sf_w16(tp + m.o16_w0, 1, OT, 0, lane);
+  // head rows of the tiles finished in earlier passes: partial sums first (nothing here depends on this pass)
+  f32x2 pam = {0.f, 0.f};
+#pragma unroll
+  for (int tl = 0; tl < OT; ++tl)
+    pam = sf_head_acc(pam, *reinterpret_cast<const float4*>(hv + tl * 8), *reinterpret_cast<const float4*>(hv + tl * 8 + 4), S.head[tl]);
+  // initial layer of tile OT (the start of the dependent chain)
+  sf_put16b<OT>(S, 0, sf_mma16(w0, S.ut, sf_c0_16(m, tp, S, OT, lane, g4)));
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    __builtin_amdgcn_sched_barrier(0);  // keep one block's fragments in flight at a time (registers)
+    f32x4 b = sf_ld4(tp + m.o16_bk[k] + (OT * 4 + g4) * 4);
+    // complete pairs, then the pair of tile OT: its other tile is either final (OT odd) or one that masked weights
+    // never read (OT even)
+#pragma unroll
+    for (int pr = 0; pr <= PR; ++pr)
+      b = sf_mma16x3(sf_w16b(tpB + m.o16B_wk[k], NP, OT, pr, 0, lane), sf_w16b(tpB + m.o16B_wk[k], NP, OT, pr, 1, lane),
+                     S.ph[k][pr], S.pl[k][pr], b);
+    f32x4 th;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) th[r] = sf_tanh(b[r]);
+    if (k + 1 < NB) sf_put16b<OT>(S, k + 1, th);
+    else S.head[OT] = th;
+  }
+  pam = sf_head_acc(pam, *reinterpret_cast<const float4*>(hv + OT * 8), *reinterpret_cast<const float4*>(hv + OT * 8 + 4), S.head[OT]);
+  const float av = tp[m.o16_hvb + 2 * sl] + sf_sum4groups(pam[0]);
+  const float mv = tp[m.o16_hvb + 2 * sl + 1] + sf_sum4groups(pam[1]);
+  const float sc = (m.scale_fn == 0 ? sf_softplus(av) : sf_sigmoid(av + 2.0f)) + m.eps;
+  const float wv = sf_div(u_sl - mv, sc);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) S.ut[r] = (g4 == (sl >> 2) && r == (sl & 3)) ? wv : S.ut[r];
+}
+
+// The same pass when the degree group straddles tiles LO..HI (contiguous packing; see sf_pass16_span).
+template <int LO, int HI, int NB>
+__device__ __forceinline__ void sf_pass16b_span(const SfDev& m, const float* tp, const unsigned int* tpB, SfPass16B& S, int NT,
+                                                int sl, float u_sl, int lane, int g4) {
+  constexpr int PH = HI >> 1;
+  const int NP = m.nP16;
+  const float* hv = tp + m.o16_hv + sl * 128 + g4 * 32;
+  auto put = [&](int k, int ot, const f32x4& v) {  // (k, ot are unrolled loop indices: static after unrolling)
+    const SfSplit2 t = sf_split16(v);
+    S.ph[k][ot >> 1][(ot & 1) * 2] = t.hi[0];
+    S.ph[k][ot >> 1][(ot & 1) * 2 + 1] = t.hi[1];
+    S.pl[k][ot >> 1][(ot & 1) * 2] = t.lo[0];
+    S.pl[k][ot >> 1][(ot & 1) * 2 + 1] = t.lo[1];
+  };
+#pragma unroll
+  for (int ot = LO; ot <= HI; ++ot) put(0, ot, sf_mma16(sf_w16(tp + m.o16_w0, 1, ot, 0, lane), S.ut, sf_c0_16(m, tp, S, ot, lane, g4)));
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    f32x4 nb[HI - LO + 1];
+#pragma unroll
+    for (int ot = LO; ot <= HI; ++ot) {
+      f32x4 b = sf_ld4(tp + m.o16_bk[k] + (ot * 4 + g4) * 4);
+#pragma unroll
+      for (int pr = 0; pr <= PH; ++pr)
+        b = sf_mma16x3(sf_w16b(tpB + m.o16B_wk[k], NP, ot, pr, 0, lane), sf_w16b(tpB + m.o16B_wk[k], NP, ot, pr, 1, lane),
+                       S.ph[k][pr], S.pl[k][pr], b);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) nb[ot - LO][r] = sf_tanh(b[r]);
+    }
+#pragma unroll
+    for (int ot = LO; ot <= HI; ++ot) {
+      if (k + 1 < NB) put(k + 1, ot, nb[ot - LO]);
+      else S.head[ot] = nb[ot - LO];
+    }
+  }
+  f32x2 pam = {0.f, 0.f};
+#pragma unroll
+  for (int tl = 0; tl <= HI; ++tl)
+    pam = sf_head_acc(pam, *reinterpret_cast<const float4*>(hv + tl * 8), *reinterpret_cast<const float4*>(hv + tl * 8 + 4),
+                      S.head[tl]);
+  const float av = tp[m.o16_hvb + 2 * sl] + sf_sum4groups(pam[0]);
+  const float mv = tp[m.o16_hvb + 2 * sl + 1] + sf_sum4groups(pam[1]);
+  const float sc = (m.scale_fn == 0 ? sf_softplus(av) : sf_sigmoid(av + 2.0f)) + m.eps;
+  const float wv = sf_div(u_sl - mv, sc);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) S.ut[r] = (g4 == (sl >> 2) && r == (sl & 3)) ? wv : S.ut[r];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Persistent sampler: the same tile pipeline as k_maf_inv16, driven by the device work queue of sf_queue.h.  One
 // launch resolves every slot of the dense list (first attempts AND retries); sampler only (no parity hook, no
 // acceptance mode, no log-determinant).
+// Hidden H x H blocks run on split-bf16 MFMA (sf_pass16b); the rest of the arithmetic is fp32 as in k_maf_inv16.
 // The two argument blocks are read through the kernarg segment pointer, laundered once per iteration: descriptor
 // fields and table entries are then loaded where they are used (scalar-cache hits) instead of being hoisted out of
 // the persistent loop and kept in registers for the life of the kernel -- with them live the pass functions spill.
@@ -367,7 +539,7 @@ struct SfSamp16Args {
 template <int NB, bool SPAN>
 __global__ __launch_bounds__(256, 3) void k_maf_samp16(SfSamp16Args args_in) {
   const int wave = threadIdx.x >> 6;
-  unsigned int* ctrl = reinterpret_cast<unsigned int*>(sf_lds16 + args_in.m.t16_stride);
+  unsigned int* ctrl = reinterpret_cast<unsigned int*>(sf_lds16 + args_in.m.t16_a + args_in.m.t16B_stride);
   unsigned int pf;
   sf_q_begin<64>(args_in.a, ctrl, pf);
 #ifdef SF_Q_STATS
@@ -420,20 +592,6 @@ __global__ __launch_bounds__(256, 3) void k_maf_samp16(SfSamp16Args args_in) {
       xr = a.x + gal * m.C;
       ctg = m.ctab ? m.ctab + (size_t)gal * m.T * m.ctab_R : nullptr;  // wave-uniform choice
     }
-    auto ctx_tile = [&](int ic) {
-      f32x4 ct;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rho = ic * 16 + 4 * g4 + r;
-        const bool ok = rho < m.C;
-        const int rr = ok ? rho : 0;
-        const float v = sf_div(xr[rr] - m.cst[m.c_xmean + rr], m.cst[m.c_xstd + rr]);
-        ct[r] = ok ? v : 0.f;
-      }
-      return ct;
-    };
-    f32x4 ct0;
-    if (!ctg) ct0 = ctx_tile(0);
     uint32_t tile_bits = 0, lo_bits = 0;  // g16_tile / g16_lo packed 2 bits per degree
 #pragma unroll
     for (int q = 0; q < SF_DMAX; ++q) {
@@ -442,23 +600,29 @@ __global__ __launch_bounds__(256, 3) void k_maf_samp16(SfSamp16Args args_in) {
     }
     // cleared per tile of draws: a non-finite value left behind by one draw must not reach the next one through a
     // structural zero (see k_maf_inv16 for why once per tile is enough)
-    SfPass16 S;
+    SfPass16B S;
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < 2; ++k)
 #pragma unroll
-      for (int ot = 0; ot < 4; ++ot)
+      for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) S.act[k][ot][r] = 0.f;
+        for (int c = 0; c < 4; ++c) { S.ph[k][pr][c] = 0u; S.pl[k][pr][c] = 0u; }
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S.head[ot][r] = 0.f;
     for (int t = m.T - 1; t >= 0; --t) {
       __syncthreads();
       {
-        const float4* __restrict__ s4 = reinterpret_cast<const float4*>(m.packed16 + (size_t)t * m.t16_stride);
-        float4* __restrict__ d4 = reinterpret_cast<float4*>(sf_lds16);
-        const int n4 = m.t16_stride >> 2;
+        // part A of the fp32 image (input / context layers, biases, head rows) and the split-bf16 hidden blocks, one
+        // behind the other in LDS: direct global -> LDS copies, 4 KiB groups (ONE address, four immediate offsets)
         const int lane_ = threadIdx.x & 63;
-        const int ngroups = n4 >> 8;
-        for (int gi = __builtin_amdgcn_readfirstlane(wave); gi < ngroups; gi += 4) {
-          const float4* g = s4 + gi * 256 + lane_;
+        const int ga = m.t16_a >> 10, gb = m.t16B_stride >> 10;
+        const float4* __restrict__ sa = reinterpret_cast<const float4*>(m.packed16 + (size_t)t * m.t16_stride);
+        const float4* __restrict__ sb = reinterpret_cast<const float4*>(m.packed16B + (size_t)t * m.t16B_stride);
+        float4* __restrict__ d4 = reinterpret_cast<float4*>(sf_lds16);
+        for (int gi = __builtin_amdgcn_readfirstlane(wave); gi < ga + gb; gi += 4) {
+          const float4* g = (gi < ga ? sa + gi * 256 : sb + (gi - ga) * 256) + lane_;
           float4* l = d4 + gi * 256;
           __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 0, 0);
           __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 1024, 0);
@@ -469,27 +633,11 @@ __global__ __launch_bounds__(256, 3) void k_maf_samp16(SfSamp16Args args_in) {
       }
       __syncthreads();
       const float* tp = sf_lds16;
-      if (ctg) {
-#pragma unroll
-        for (int ot = 0; ot < 4; ++ot)
-          if (ot < NT) S.c0[ot] = *reinterpret_cast<const f32x4*>(ctg + (size_t)t * m.ctab_R + ot * 16 + 4 * g4);
-      } else {
-#pragma unroll
-        for (int ot = 0; ot < 4; ++ot)
-          if (ot < NT) {
-            S.c0[ot] = sf_ld4(tp + m.o16_b0 + (ot * 4 + g4) * 4);
-            S.c0[ot] = sf_mma16(sf_w16(tp + m.o16_wc, m.nC16, ot, 0, lane), ct0, S.c0[ot]);
-          }
-        for (int ic = 1; ic < m.nC16; ++ic) {
-          const f32x4 ct = ctx_tile(ic);
-#pragma unroll
-          for (int ot = 0; ot < 4; ++ot)
-            if (ot < NT) S.c0[ot] = sf_mma16(sf_w16(tp + m.o16_wc, m.nC16, ot, ic, lane), ct, S.c0[ot]);
-        }
-      }
+      const unsigned int* tpB = reinterpret_cast<const unsigned int*>(sf_lds16 + m.t16_a);
+      S.c0p = ctg ? ctg + (size_t)t * m.ctab_R : nullptr;
+      S.xr = xr;
 #pragma unroll
       for (int r = 0; r < 4; ++r) S.ut[r] = 0.f;
-      S.ldl = 0.f;
       const int dsl = (int)m.cst[m.c_dslot + t * SF_DMAX + s];
       {
         const int sl = __builtin_amdgcn_readlane(dsl, 0);
@@ -505,16 +653,16 @@ __global__ __launch_bounds__(256, 3) void k_maf_samp16(SfSamp16Args args_in) {
         const uint32_t hi_t = (tile_bits >> (2 * (p - 1))) & 3u;
         const uint32_t lo_t = SPAN ? (lo_bits >> (2 * (p - 1))) & 3u : hi_t;
         switch (lo_t * 4 + hi_t) {
-          case 0: sf_pass16<0, NB, false>(m, tp, S, NT, sl, u_sl, lane, g4); break;
-          case 5: sf_pass16<1, NB, false>(m, tp, S, NT, sl, u_sl, lane, g4); break;
-          case 10: sf_pass16<2, NB, false>(m, tp, S, NT, sl, u_sl, lane, g4); break;
-          case 15: sf_pass16<3, NB, false>(m, tp, S, NT, sl, u_sl, lane, g4); break;
-          case 1: if (SPAN) sf_pass16_span<0, 1, NB, false>(m, tp, S, NT, sl, u_sl, lane, g4); break;
-          case 2: if (SPAN) sf_pass16_span<0, 2, NB, false>(m, tp, S, NT, sl, u_sl, lane, g4); break;
-          case 3: if (SPAN) sf_pass16_span<0, 3, NB, false>(m, tp, S, NT, sl, u_sl, lane, g4); break;
-          case 6: if (SPAN) sf_pass16_span<1, 2, NB, false>(m, tp, S, NT, sl, u_sl, lane, g4); break;
-          case 7: if (SPAN) sf_pass16_span<1, 3, NB, false>(m, tp, S, NT, sl, u_sl, lane, g4); break;
-          default: if (SPAN) sf_pass16_span<2, 3, NB, false>(m, tp, S, NT, sl, u_sl, lane, g4); break;
+          case 0: sf_pass16b<0, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+          case 5: sf_pass16b<1, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+          case 10: sf_pass16b<2, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+          case 15: sf_pass16b<3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+          case 1: if (SPAN) sf_pass16b_span<0, 1, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+          case 2: if (SPAN) sf_pass16b_span<0, 2, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+          case 3: if (SPAN) sf_pass16b_span<0, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+          case 6: if (SPAN) sf_pass16b_span<1, 2, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+          case 7: if (SPAN) sf_pass16b_span<1, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+          default: if (SPAN) sf_pass16b_span<2, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
         }
       }
       u = S.ut;
@@ -680,7 +828,7 @@ static hipError_t sf_launch16(const SfDev& m, const SfSampleArgsHost& a, hipStre
   if (a.q) {  // persistent sampler: no more workgroups than the chip holds (more would only queue behind the spinning ones)
     static SfAttrCache attr;
     static int resident = 0;
-    const size_t sh = (size_t)m.t16_stride * sizeof(float) + SF_Q_WORDS(64) * sizeof(unsigned int);
+    const size_t sh = ((size_t)m.t16_a + (size_t)m.t16B_stride) * sizeof(float) + SF_Q_WORDS(64) * sizeof(unsigned int);
     int attr_dev;
     if (attr.need(attr_dev)) {
       hipError_t e = hipFuncSetAttribute((const void*)k_maf_samp16<NB, SPAN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -160,7 +160,7 @@ __global__ void k_train_prep(const float* __restrict__ flat, const int32_t* __re
                              const int32_t* __restrict__ t2, float* __restrict__ packedT, long n2,
                              float* __restrict__ gimg, int copies, float* __restrict__ dctx, long n4,
                              const int32_t* __restrict__ u1, const int32_t* __restrict__ u2, float* __restrict__ packed16,
-                             long n5) {
+                             long n5, const int32_t* __restrict__ sB, unsigned short* __restrict__ packed16B, long n6) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n1) {
     const int a = s1[i], b = s2[i];
@@ -189,6 +189,18 @@ __global__ void k_train_prep(const float* __restrict__ flat, const int32_t* __re
     if (a >= 0) v = flat[a];
     if (b >= 0) v += flat[b];
     packed16[i] = v;
+    return;
+  }
+  i -= n5;
+  if (i < n6) {  // split-bf16 hidden blocks of the persistent sampler (k_pack_bf16_split)
+    const int a = sB[i];
+    unsigned short r = 0;
+    if (a >= 0) {
+      const float w = flat[a & 0x3fffffff];
+      const __bf16 hi = (__bf16)w;
+      r = __builtin_bit_cast(unsigned short, (a >> 30) & 1 ? (__bf16)(w - (float)hi) : hi);
+    }
+    packed16B[i] = r;
   }
 }
 
@@ -267,10 +279,11 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
   {
     const long n4 = (dctx && B > 0) ? B * (long)L.dev.C : 0;
     const long n5 = f->d_packed16 ? (long)L.n_packed16 : 0;
-    const long tot = (long)L.n_packed + (long)L.n_packedT + n4 + n5;
+    const long n6 = f->d_packed16B ? (long)L.n_packed16B : 0;
+    const long tot = (long)L.n_packed + (long)L.n_packedT + n4 + n5 + n6;
     hipLaunchKernelGGL(k_train_prep, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, flat, f->d_s1, f->d_s2, f->d_packed,
                        (long)L.n_packed, f->d_t1, f->d_t2, f->d_packedT, (long)L.n_packedT, f->d_gpacked, copies, dctx, n4,
-                       f->d_s16a, f->d_s16b, f->d_packed16, n5);
+                       f->d_s16a, f->d_s16b, f->d_packed16, n5, f->d_s16B, f->d_packed16B, n6);
     SF_TRY(hipGetLastError());
   }
   f->packed16_stale = false;

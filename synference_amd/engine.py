@@ -93,6 +93,15 @@ class HipFlow:
                                                      s2.ctypes.data_as(_lib.c_i32p), n))
         return s1, s2
 
+    def pack_table16b(self) -> np.ndarray:
+        """Gather table of the split-bf16 hidden blocks of the persistent 16-row sampler (empty when the flow has none):
+        entry i = logical index | (part << 30), part 0 = hi, 1 = lo; -1 = zero."""
+        n = int(self.lib.sf_flow_packed16b_size(self.handle))
+        s = np.empty(n, np.int32)
+        if n:
+            _lib.check(self.lib.sf_flow_pack_table16b(self.handle, s.ctypes.data_as(_lib.c_i32p), n))
+        return s
+
     def describe(self) -> dict:
         buf = C.create_string_buffer(1 << 16)
         _lib.check(self.lib.sf_flow_describe(self.handle, buf, len(buf)))

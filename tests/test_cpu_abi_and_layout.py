@@ -140,3 +140,51 @@ def test_product_never_imports_the_oracle():
     for p in (ROOT / "synference_amd").rglob("*.py"):
         txt = p.read_text()
         assert "import oracle" not in txt and "from oracle" not in txt, p
+
+
+@pytest.mark.parametrize("name", ["maf_cfg1", "maf_small", "maf_span6", "maf_span_h64"])
+def test_split_bf16_table_of_the_16_row_sampler_reconstructs_the_masked_hidden_weights(name):
+    """sf_layout.cpp's split-bf16 image (src16B): per hidden block [ot][pair][hi|lo][64 lanes][8]; element j of lane l is
+    W[out row ot*16 + (l&15)][in row 16*(2*pair + (j>>2)) + 4*(l>>4) + (j&3)] in the 16-row unit order, masked entries
+    zero; hi + lo (bf16 round-to-nearest-even of w and of w - hi) equals w to 2^-16 relative."""
+    from oracle import flows as OF
+    from synference_amd.engine import HipFlow
+    ospec, spec, flat, theta, x = make_case(name, B=4)
+    hf = HipFlow(spec)
+    d = hf.describe()
+    if not d["m16_ok"]:
+        pytest.skip("no 16-row image for this shape")
+    tab = hf.pack_table16b()
+    assert len(tab) == 2 * d["t16B_stride"] * d["T"] and d["t16B_stride"] % 1024 == 0 and d["t16_a"] % 1024 == 0
+    idx, part = tab & 0x3FFFFFFF, (tab >> 30) & 1
+    on = tab >= 0
+    w = np.where(on, np.asarray(flat, np.float32)[np.where(on, idx, 0)], np.float32(0))
+
+    def bf16(v):  # round to nearest even
+        u = np.asarray(v, np.float32).view(np.uint32).astype(np.uint64)
+        r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32) << 16
+        return r.astype(np.uint32).view(np.float32)
+    hi = bf16(w)
+    val = np.where(part == 1, bf16(w - hi), hi)
+    NT, NP, NB, T = d["nT16"], d["nP16"], d["NB"], d["T"]
+    # unit order of the 16-row tiles from the fp32 image's W0 block: not exported directly, so check via reconstruction:
+    # every (hi, lo) pair of the same element reconstructs the same masked weight, and each block's set of non-zero
+    # weights equals the oracle's masked block
+    M0, Mh, Mf = OF.made_masks(spec.D, spec.H)
+    lay = {n: (s_, o) for n, s_, o in OF.param_layout(ospec)}
+    for t in range(T):
+        for k in range(min(NB, 2)):
+            base = 2 * (t * d["t16B_stride"] + d[f"o16B_wk{k}"])
+            blk = val[base: base + NT * NP * 2 * 64 * 8].reshape(NT, NP, 2, 64, 8)
+            ib = idx[base: base + NT * NP * 2 * 64 * 8].reshape(NT, NP, 2, 64, 8)
+            ob = on[base: base + NT * NP * 2 * 64 * 8].reshape(NT, NP, 2, 64, 8)
+            assert np.array_equal(ib[:, :, 0], ib[:, :, 1]) and np.array_equal(ob[:, :, 0], ob[:, :, 1])
+            rec = blk[:, :, 0].astype(np.float64) + blk[:, :, 1].astype(np.float64)
+            shape, off = lay[f"t{t}.W{k + 1}"]
+            W = np.asarray(flat, np.float64)[off: off + spec.H * spec.H].reshape(spec.H, spec.H)
+            ref = np.where(ob[:, :, 0], np.asarray(flat, np.float64)[np.where(ob[:, :, 0], ib[:, :, 0], 0)], 0.0)
+            assert np.abs(rec - ref).max() <= 2.0 ** -16 * max(np.abs(W).max(), 1e-30)
+            # the block holds exactly the unmasked entries of W_k, each once
+            used = np.unique(ib[:, :, 0][ob[:, :, 0]]) - off
+            assert len(used) == int(Mh.sum()) and np.array_equal(np.sort(used), np.flatnonzero(Mh.reshape(-1)))
+            assert ob[:, :, 0].sum() == int(Mh.sum())
