@@ -18,7 +18,7 @@ raw, tag = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(list); name = None; durs = []
 for f in glob.glob(raw + '/p*/*/*_counter_collection.csv'):
     for r in csv.DictReader(open(f)):
-        if ('k_inverse' in r['Kernel_Name'] or 'k_maf_inv16' in r['Kernel_Name'] or 'k_logprob' in r['Kernel_Name']) and int(r['Grid_Size']) > 1000000:
+        if ('k_maf_samp16' in r['Kernel_Name'] or 'k_sample_persist' in r['Kernel_Name']) or (('k_inverse' in r['Kernel_Name'] or 'k_maf_inv16' in r['Kernel_Name'] or 'k_logprob' in r['Kernel_Name']) and int(r['Grid_Size']) > 1000000):
             acc[r['Counter_Name']].append(float(r['Counter_Value'])); name = r['Kernel_Name']
             durs.append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
             regs = (r.get('VGPR_Count'), r.get('Accum_VGPR_Count'), r.get('LDS_Block_Size'), r.get('Scratch_Size'), r['Grid_Size'], r['Workgroup_Size'])
