@@ -1,0 +1,88 @@
+#!/usr/bin/env python
+"""OFF-BOX tool: emit tests/golden/upstream_<model>.npz from a real sbi / nflows flow.
+
+Run this where ``sbi`` is installed (it is NOT in the build image, and the GPU boxes have no network):
+
+    pip install "sbi>=0.22"            # pulls pyknos / nflows
+    python scripts/export_upstream_golden.py --out tests/golden
+
+For each of {maf, nsf} it builds the estimator exactly the way the reference does
+(ref: src/synference/sbi_runner.py:5123-5146 -> ili.utils.load_nde_sbi -> sbi ``posterior_nn(model, hidden_features,
+num_transforms, ...)``; ref: src/synference/custom_runner.py:320-326 ``estimator_builder(batch_x=, batch_theta=)``),
+perturbs the weights away from their initial values (so that splines / LU are not the identity), and stores
+
+    sd/<name>            every tensor of ``estimator.state_dict()``
+    theta, x             evaluation batch (float32)
+    log_prob             estimator log-density of (theta | x)                       [UPSTREAM arithmetic]
+    z, theta_from_z      base noise and  transform.inverse(z, context=embedding(x)) [UPSTREAM arithmetic]
+    logabsdet_inv        its log |det|
+    meta                 json: model, sbi / nflows versions, builder kwargs
+
+``tests/test_golden.py::test_upstream_golden_*`` picks these files up when they exist: the state dict is mapped by
+``synference_amd.importer`` onto the flat vector, and both the CPU oracle (always) and the HIP kernels (on a GPU box)
+must reproduce ``log_prob`` to 1e-4 and ``theta_from_z`` to fp32 tolerance.  That is the only route from
+"parity unpinned" to pinned parity: nothing in this repository can stand in for running upstream code.
+"""
+import argparse
+import json
+import os
+
+import numpy as np
+import torch
+
+
+def build(model, theta, x, hidden_features, num_transforms, num_bins):
+    try:
+        from sbi.neural_nets import posterior_nn          # sbi >= 0.23
+    except ImportError:
+        from sbi.utils import posterior_nn                # sbi 0.22
+    kw = dict(model=model, hidden_features=hidden_features, num_transforms=num_transforms,
+              z_score_theta="independent", z_score_x="independent")
+    if model == "nsf":
+        kw["num_bins"] = num_bins
+    est = posterior_nn(**kw)(theta, x)
+    return est, kw
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="tests/golden")
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    import sbi
+    try:
+        import pyknos.nflows as nf
+        nfv = getattr(nf, "__version__", "pyknos")
+    except ImportError:
+        import nflows as nf
+        nfv = getattr(nf, "__version__", "nflows")
+    for model, D, C, H, T, K in (("maf", 5, 10, 50, 5, 10), ("nsf", 8, 20, 50, 5, 8)):
+        torch.manual_seed(a.seed)
+        rng = np.random.default_rng(a.seed)
+        theta = torch.as_tensor(rng.normal(size=(2000, D)) * rng.uniform(0.5, 2.0, size=D) + rng.normal(size=D), dtype=torch.float32)
+        x = torch.as_tensor(rng.normal(size=(2000, C)) * rng.uniform(0.5, 2.0, size=C) + rng.normal(size=C), dtype=torch.float32)
+        est, kw = build(model, theta, x, H, T, K)
+        flow = getattr(est, "net", est)                    # sbi >= 0.23 wraps the nflows Flow in NFlowsFlow(net=...)
+        with torch.no_grad():
+            for p in flow.parameters():                    # away from the init (identity splines / LU, tiny last layers)
+                p.add_(0.3 * p.abs().mean().clamp_min(0.05) * torch.randn_like(p))
+        flow.eval()
+        te, xe = theta[:256], x[:256]
+        z = torch.randn(256, D)
+        with torch.no_grad():
+            lp = flow.log_prob(te, context=xe)
+            emb = flow._embedding_net(xe)
+            th, lad = flow._transform.inverse(z, context=emb)
+        out = {"sd/" + k: v.detach().cpu().numpy() for k, v in flow.state_dict().items()}
+        out.update(theta=te.numpy(), x=xe.numpy(), log_prob=lp.numpy().astype(np.float64), z=z.numpy(),
+                   theta_from_z=th.numpy().astype(np.float64), logabsdet_inv=lad.numpy().astype(np.float64),
+                   meta=np.array(json.dumps(dict(model=model, sbi=sbi.__version__, nflows=str(nfv), builder_kwargs=kw,
+                                                 wrapper=type(est).__name__))))
+        os.makedirs(a.out, exist_ok=True)
+        path = os.path.join(a.out, f"upstream_{model}.npz")
+        np.savez_compressed(path, **out)
+        print("wrote", path, "log_prob[:3] =", lp[:3].tolist())
+
+
+if __name__ == "__main__":
+    main()

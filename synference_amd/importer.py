@@ -1,0 +1,213 @@
+"""Import an upstream (sbi / pyknos-nflows) MAF or NSF into the HIP engine's flat parameter vector.
+
+SURVEY.md 8f row f4.  The reference stores trained posteriors as sbi pickles
+(ref: src/synference/sbi_runner.py:7436-7485, ``load_model_from_pkl``); opening one needs sbi, which this
+build never imports.  What crosses the boundary instead is the estimator's ``state_dict()`` -- a plain
+``{name: array}`` mapping that ``scripts/export_upstream_golden.py`` (run off-box, where sbi is installed)
+writes into an ``.npz`` -- and this module maps it, by module path, onto ``FlowSpec`` + the flat vector
+documented in include/synference_hip.h.  No dependency beyond numpy / torch.
+
+Module paths follow pyknos-nflows 0.14 / sbi 0.22-0.23:
+
+    [net.]_transform._transforms.0._shift / ._scale                      z-score of theta (AffineTransform)
+    [net.]_embedding_net.0._mean / ._std                                 z-score of x (Standardize)
+  MAF, block i = 2t (transform) and 2t+1 (permutation) of  _transform._transforms.1._transforms:
+    .{2t}.autoregressive_net.initial_layer.{weight,bias}                 W0, b0          (mask: buffer, ignored)
+    .{2t}.autoregressive_net.context_layer.{weight,bias}                 Wc, bc
+    .{2t}.autoregressive_net.blocks.{k}.linear.{weight,bias}             W{k+1}, b{k+1}
+    .{2t}.autoregressive_net.final_layer.{weight,bias}                   Wf, bf
+    .{2t+1}._permutation                                                 perms[t]
+  NSF, block i = 2t (coupling) and 2t+1 (LULinear; absent when D == 1):
+    .{2t}.transform_net.initial_layer.{weight,bias}                      Win [H, d_id + C], bin
+    .{2t}.transform_net.blocks.{k}.context_layer.{weight,bias}           Wg, bg
+    .{2t}.transform_net.blocks.{k}.linear_layers.{0,1}.{weight,bias}     W1, b1, W2, b2
+    .{2t}.transform_net.final_layer.{weight,bias}                        Wout, bout
+    .{2t+1}.{lower_entries,upper_entries,unconstrained_upper_diag,bias}  lu.*
+
+Names are matched by SUFFIX after the transform index, so wrapper prefixes of other sbi versions
+(``net.``, ``_neural_net.``, ``posterior_estimator.``) do not matter.  Anything that cannot be mapped raises
+``KeyError`` naming what is missing -- nothing is guessed.
+"""
+from __future__ import annotations
+
+import re
+from typing import Dict, Mapping, Optional, Tuple
+
+import numpy as np
+
+from .spec import FlowSpec, num_params, param_layout
+
+
+def _np(v) -> np.ndarray:
+    if hasattr(v, "detach"):
+        v = v.detach().cpu().numpy()
+    return np.asarray(v)
+
+
+def _strip(sd: Mapping[str, object]) -> Dict[str, np.ndarray]:
+    """name -> array with any wrapper prefix in front of ``_transform`` / ``_embedding_net`` removed."""
+    out = {}
+    for k, v in sd.items():
+        m = re.search(r"(_transform\.|_embedding_net\.|_distribution\.)", k)
+        out[k[m.start():] if m else k] = _np(v)
+    return out
+
+
+def _blocks(sd: Dict[str, np.ndarray]) -> Dict[int, Dict[str, np.ndarray]]:
+    """{i: {suffix: array}} for the entries of the inner CompositeTransform (``_transform._transforms.1._transforms.i.*``;
+    without a theta z-score the chain sits directly under ``_transform._transforms.i.*``)."""
+    pat_inner = re.compile(r"^_transform\._transforms\.1\._transforms\.(\d+)\.(.+)$")
+    pat_flat = re.compile(r"^_transform\._transforms\.(\d+)\.(.+)$")
+    inner = any(pat_inner.match(k) for k in sd)
+    out: Dict[int, Dict[str, np.ndarray]] = {}
+    for k, v in sd.items():
+        m = (pat_inner if inner else pat_flat).match(k)
+        if m and not (not inner and m.group(2) in ("_shift", "_scale")):
+            out.setdefault(int(m.group(1)), {})[m.group(2)] = v
+    return out
+
+
+def spec_and_flat_from_state_dict(state_dict: Mapping[str, object], num_bins: Optional[int] = None,
+                                  **spec_overrides) -> Tuple[FlowSpec, np.ndarray]:
+    """(FlowSpec, flat float32 vector) of an upstream MAF / NSF ``state_dict``.
+
+    ``num_bins`` is needed for NSF only when it cannot be inferred (it is: final_layer rows = d_tr * (3K - 1)).
+    ``spec_overrides``: constants that the state dict does not carry (``tail_bound``, ``scale_fn`` ...)."""
+    sd = _strip(state_dict)
+    blocks = _blocks(sd)
+    if not blocks:
+        raise KeyError("no '_transform._transforms.*' entries: this is not an nflows Flow state_dict")
+    kind = "maf" if any("autoregressive_net.initial_layer.weight" in b for b in blocks.values()) else \
+           "nsf" if any("transform_net.initial_layer.weight" in b for b in blocks.values()) else None
+    if kind is None:
+        raise KeyError("neither MaskedAffineAutoregressiveTransform nor PiecewiseRationalQuadraticCouplingTransform "
+                       "parameters found")
+    # ---- z-score buffers (sbi standardizing_transform: scale = 1/std, shift = -mean/std)
+    if "_transform._transforms.0._scale" in sd:
+        scale = sd["_transform._transforms.0._scale"].reshape(-1).astype(np.float64)
+        shift = sd["_transform._transforms.0._shift"].reshape(-1).astype(np.float64)
+        theta_std, theta_mean = 1.0 / scale, -shift / scale
+    else:
+        theta_std = theta_mean = None
+    x_mean = sd.get("_embedding_net.0._mean")
+    x_std = sd.get("_embedding_net.0._std")
+    extra = [k for k in sd if k.startswith("_embedding_net.") and not k.startswith("_embedding_net.0.")]
+    if extra:
+        raise KeyError(f"the estimator has a trainable embedding net ({extra[0]} ...): import it separately and pass its "
+                       "output width as the context")
+    if kind == "maf":
+        tidx = sorted(i for i, b in blocks.items() if "autoregressive_net.initial_layer.weight" in b)
+        T = len(tidx)
+        b0 = blocks[tidx[0]]
+        H, D = b0["autoregressive_net.initial_layer.weight"].shape
+        C = b0["autoregressive_net.context_layer.weight"].shape[1]
+        NB = len({int(m.group(1)) for k in b0 for m in [re.match(r"autoregressive_net\.blocks\.(\d+)\.linear\.weight", k)] if m})
+        perms = []
+        for i in tidx:
+            p = blocks.get(i + 1, {}).get("_permutation")
+            perms.append(np.arange(D) if p is None else p.astype(np.int64))
+        spec = FlowSpec(kind="maf", D=D, C=C, H=H, T=T, NB=NB, perms=np.stack(perms).astype(np.int32),
+                        theta_mean=theta_mean, theta_std=theta_std, x_mean=x_mean, x_std=x_std, **spec_overrides)
+        names = {"W0": "autoregressive_net.initial_layer.weight", "b0": "autoregressive_net.initial_layer.bias",
+                 "Wc": "autoregressive_net.context_layer.weight", "bc": "autoregressive_net.context_layer.bias",
+                 "Wf": "autoregressive_net.final_layer.weight", "bf": "autoregressive_net.final_layer.bias"}
+        for k in range(NB):
+            names[f"W{k + 1}"] = f"autoregressive_net.blocks.{k}.linear.weight"
+            names[f"b{k + 1}"] = f"autoregressive_net.blocks.{k}.linear.bias"
+        src = {t: (blocks[i], names) for t, i in enumerate(tidx)}
+    else:
+        tidx = sorted(i for i, b in blocks.items() if "transform_net.initial_layer.weight" in b)
+        T = len(tidx)
+        b0 = blocks[tidx[0]]
+        H, win = b0["transform_net.initial_layer.weight"].shape
+        lu0 = blocks.get(tidx[0] + 1, {})
+        if "unconstrained_upper_diag" in lu0:
+            D = lu0["unconstrained_upper_diag"].shape[0]
+        elif theta_std is not None:
+            D = len(theta_std)
+        else:
+            raise KeyError("cannot infer the theta dimension (no LULinear block and no z-score buffers)")
+        d_id0 = D // 2                      # block 0 transforms dims 0,2,4,...: identity dims = floor(D/2)
+        C = win - d_id0
+        d_tr0 = D - d_id0
+        nout = b0["transform_net.final_layer.weight"].shape[0]
+        K = num_bins if num_bins is not None else (nout // d_tr0 + 1) // 3
+        if d_tr0 * (3 * K - 1) != nout:
+            raise KeyError(f"final_layer has {nout} rows: not d_tr * (3K - 1) for d_tr = {d_tr0}, K = {K}")
+        NB = len({int(m.group(1)) for k in b0 for m in [re.match(r"transform_net\.blocks\.(\d+)\.context_layer\.weight", k)] if m})
+        spec = FlowSpec(kind="nsf", D=D, C=C, H=H, T=T, K=K, NB=NB, theta_mean=theta_mean, theta_std=theta_std,
+                        x_mean=x_mean, x_std=x_std, **spec_overrides)
+        names = {"Win": "transform_net.initial_layer.weight", "bin": "transform_net.initial_layer.bias",
+                 "Wout": "transform_net.final_layer.weight", "bout": "transform_net.final_layer.bias"}
+        for k in range(NB):
+            names[f"blk{k}.Wg"] = f"transform_net.blocks.{k}.context_layer.weight"
+            names[f"blk{k}.bg"] = f"transform_net.blocks.{k}.context_layer.bias"
+            names[f"blk{k}.W1"] = f"transform_net.blocks.{k}.linear_layers.0.weight"
+            names[f"blk{k}.b1"] = f"transform_net.blocks.{k}.linear_layers.0.bias"
+            names[f"blk{k}.W2"] = f"transform_net.blocks.{k}.linear_layers.1.weight"
+            names[f"blk{k}.b2"] = f"transform_net.blocks.{k}.linear_layers.1.bias"
+        lun = {"lu.lower": "lower_entries", "lu.upper": "upper_entries", "lu.udiag": "unconstrained_upper_diag",
+               "lu.bias": "bias"}
+        src = {}
+        for t, i in enumerate(tidx):
+            merged = dict(blocks[i])
+            merged.update({"__lu__." + k: v for k, v in blocks.get(i + 1, {}).items()})
+            nm = dict(names)
+            nm.update({k: "__lu__." + v for k, v in lun.items()})
+            src[t] = (merged, nm)
+    flat = np.zeros(num_params(spec), dtype=np.float32)
+    for name, shape, off in param_layout(spec):
+        t = int(name[1:name.index(".")])
+        leaf = name[name.index(".") + 1:]
+        blk, nm = src[t]
+        key = nm.get(leaf)
+        if key is None or key not in blk:
+            raise KeyError(f"upstream tensor for '{name}' ({key}) not found in transform {t}")
+        arr = blk[key]
+        n = int(np.prod(shape))
+        if arr.size != n:
+            raise KeyError(f"'{key}' of transform {t} has {arr.size} elements, the layout expects {shape}")
+        flat[off:off + n] = arr.reshape(-1).astype(np.float32)
+    return spec, flat
+
+
+def state_dict_from_flat(spec: FlowSpec, flat, prefix: str = "") -> Dict[str, np.ndarray]:
+    """The inverse mapping (upstream module paths; used to hand weights back to an sbi estimator off-box, and by the
+    tests to round-trip the importer)."""
+    flat = _np(flat).astype(np.float32)
+    out: Dict[str, np.ndarray] = {}
+    p = prefix + "_transform._transforms."
+    out[p + "0._scale"] = (1.0 / spec.theta_std.astype(np.float64)).astype(np.float32)
+    out[p + "0._shift"] = (-spec.theta_mean.astype(np.float64) / spec.theta_std.astype(np.float64)).astype(np.float32)
+    out[prefix + "_embedding_net.0._mean"] = spec.x_mean.copy()
+    out[prefix + "_embedding_net.0._std"] = spec.x_std.copy()
+    inv = {}
+    if spec.kind == "maf":
+        inv = {"W0": "autoregressive_net.initial_layer.weight", "b0": "autoregressive_net.initial_layer.bias",
+               "Wc": "autoregressive_net.context_layer.weight", "bc": "autoregressive_net.context_layer.bias",
+               "Wf": "autoregressive_net.final_layer.weight", "bf": "autoregressive_net.final_layer.bias"}
+        for k in range(spec.NB):
+            inv[f"W{k + 1}"] = f"autoregressive_net.blocks.{k}.linear.weight"
+            inv[f"b{k + 1}"] = f"autoregressive_net.blocks.{k}.linear.bias"
+    else:
+        inv = {"Win": "transform_net.initial_layer.weight", "bin": "transform_net.initial_layer.bias",
+               "Wout": "transform_net.final_layer.weight", "bout": "transform_net.final_layer.bias",
+               "lu.lower": "+lower_entries", "lu.upper": "+upper_entries", "lu.udiag": "+unconstrained_upper_diag",
+               "lu.bias": "+bias"}
+        for k in range(spec.NB):
+            inv[f"blk{k}.Wg"] = f"transform_net.blocks.{k}.context_layer.weight"
+            inv[f"blk{k}.bg"] = f"transform_net.blocks.{k}.context_layer.bias"
+            inv[f"blk{k}.W1"] = f"transform_net.blocks.{k}.linear_layers.0.weight"
+            inv[f"blk{k}.b1"] = f"transform_net.blocks.{k}.linear_layers.0.bias"
+            inv[f"blk{k}.W2"] = f"transform_net.blocks.{k}.linear_layers.1.weight"
+            inv[f"blk{k}.b2"] = f"transform_net.blocks.{k}.linear_layers.1.bias"
+    for name, shape, off in param_layout(spec):
+        t = int(name[1:name.index(".")])
+        leaf = name[name.index(".") + 1:]
+        key = inv[leaf]
+        i = 2 * t + (1 if key.startswith("+") else 0)
+        out[f"{p}1._transforms.{i}.{key.lstrip('+')}"] = flat[off:off + int(np.prod(shape))].reshape(shape).copy()
+    if spec.kind == "maf":
+        for t in range(spec.T):
+            out[f"{p}1._transforms.{2 * t + 1}._permutation"] = spec.perms[t].astype(np.int64)
+    return out

@@ -342,3 +342,31 @@ def test_custom_config_yaml_maps_fixed_params(tmp_path, monkeypatch):
     bad.write_text("train_args:\n  optuna: {n_trials: 3}\n")
     with pytest.raises(ValueError, match="Optuna"):
         f.run_single_sbi(custom_config_yaml=str(bad), verbose=False)
+
+
+@pytest.mark.parametrize("kind,D,C,K,NB", [("maf", 5, 10, 10, 2), ("nsf", 8, 20, 8, 2), ("nsf", 5, 3, 10, 1), ("maf", 3, 4, 10, 3)])
+def test_upstream_state_dict_importer_round_trip(kind, D, C, K, NB):
+    """synference_amd.importer maps nflows module paths onto the flat vector: a state dict laid out
+    with those paths -- under an arbitrary wrapper prefix, with the mask buffers nflows also stores -- comes back as the
+    same FlowSpec and flat vector, and the oracle evaluates both identically."""
+    from synference_amd.importer import spec_and_flat_from_state_dict, state_dict_from_flat
+    rng = np.random.default_rng(1)
+    g = torch.Generator().manual_seed(3)
+    perms = np.stack([rng.permutation(D) for _ in range(3)]) if kind == "maf" else None
+    s = FlowSpec(kind=kind, D=D, C=C, H=24, T=3, K=K, NB=NB, perms=perms, theta_mean=rng.normal(size=D),
+                 theta_std=rng.uniform(0.5, 2, size=D), x_mean=rng.normal(size=C), x_std=rng.uniform(0.5, 2, size=C))
+    flat = init_params(s, g).numpy() + 0.05 * rng.normal(size=num_params(s)).astype(np.float32)
+    sd = state_dict_from_flat(s, flat, prefix="posterior_estimator.net.")
+    if kind == "maf":   # buffers a real state dict carries besides the parameters
+        sd["posterior_estimator.net._transform._transforms.1._transforms.0.autoregressive_net.initial_layer.mask"] = np.ones((24, D))
+    sd["posterior_estimator.net._distribution._log_z"] = np.zeros(1)
+    s2, flat2 = spec_and_flat_from_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    assert (s2.kind, s2.D, s2.C, s2.H, s2.T, s2.NB) == (kind, D, C, 24, 3, NB) and (kind == "maf" or s2.K == K)
+    assert np.array_equal(flat2, flat.astype(np.float32))
+    assert np.allclose(s2.theta_mean, s.theta_mean, rtol=1e-6) and np.allclose(s2.theta_std, s.theta_std, rtol=1e-6)
+    assert np.allclose(s2.x_mean, s.x_mean) and np.allclose(s2.x_std, s.x_std)
+    if kind == "maf":
+        assert np.array_equal(s2.perms, s.perms)
+    with pytest.raises(KeyError, match="not found|expects"):
+        bad = {k: v for k, v in sd.items() if not k.endswith("final_layer.bias")}
+        spec_and_flat_from_state_dict(bad)

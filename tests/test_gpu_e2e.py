@@ -301,3 +301,20 @@ def test_default_batch_training_is_reproducible_run_to_run():
         outs.append((post.posteriors[0].posterior_estimator.flat.detach().cpu().clone(), stats[0]["training_loss"]))
     assert torch.equal(outs[0][0], outs[1][0])
     assert outs[0][1] == outs[1][1]
+
+
+def test_batched_posterior_api_of_sbi_023(fitted):
+    """sbi >= 0.23 surface the reference probes for (ref: custom_runner.py:441-452, 489-493):
+    ``sample_batched((S,), x=X)`` -> (S, N, D) and ``log_prob_batched(theta (S,N,D), x (N,C))`` -> (S, N)."""
+    f, post, _, _ = fitted
+    X = torch.as_tensor(f._X_test[:7])
+    p0 = post.posteriors[0]
+    s = p0.sample_batched((33,), x=X, seed=4)
+    assert s.shape == (33, 7, 5)
+    assert torch.equal(s.permute(1, 0, 2).contiguous(), p0.sample_catalogue(X, 33, seed=4))
+    lp = p0.log_prob_batched(s, X, norm_posterior=False)
+    assert lp.shape == (33, 7) and torch.isfinite(lp).all()
+    ref = p0.log_prob_catalogue(s[5], X, norm_posterior=False)          # draw 5 of every observation
+    assert torch.allclose(lp[5], ref, atol=1e-5)
+    es = post.sample_batched((16,), x=X, seed=2)                        # the ensemble offers the same surface
+    assert es.shape == (16, 7, 5) and torch.isfinite(es).all()
