@@ -159,18 +159,22 @@ int sf_flow_sample_round(sf_flow* f, const float* x /*[M,C]*/, int64_t S,
 int sf_flow_prepare_context(sf_flow* f, const float* x /*[M,C]*/, int64_t M, void* stream);
 int sf_flow_release_context(sf_flow* f);
 
-/* Whole sampler: ONE persistent launch works the catalogue's M*S output slots to the end -- first attempts and the
- * retries of rejected slots are scheduled on the device (no host round trip per rejection round), up to 1024 attempts
- * per slot.  Slots that are still empty then are continued in further launches with the attempt windows
- * [1024, 16384), [16384, 262144), ...:
+/* Whole sampler.  ONE persistent launch works the catalogue's M*S output slots -- first attempts and the retries of
+ * rejected slots are scheduled on the device (no host round trip per rejection round) -- up to 1024 attempts per slot
+ * (256 on the 32-row kernels).  The few slots that are still empty then (their galaxy accepts less than about one draw
+ * in a thousand) are continued chip-wide: a "find" launch evaluates a whole range of attempts of every open slot side by
+ * side and records the lowest accepted one, a "resolve" launch re-evaluates exactly that attempt and writes the draw.
+ * Every slot keeps the LOWEST accepted attempt of its Philox stream (slot, attempt): the draws do not depend on how the
+ * work was scheduled.
  *   max_attempts > 0 : hard ceiling; a slot that used max_attempts attempts becomes a NaN row
  *                      (failure convention of ref: sbi_runner.py:6458-6460).
  *   max_attempts <= 0: no ceiling, like [UPSTREAM] accept_reject_sample, which keeps drawing until S draws are kept:
- *                      a slot is retried for as long as its galaxy still gets draws accepted; the open slots of a galaxy
- *                      that got NOT ONE draw accepted between its 64th attempt and the end of a window (acceptance zero
- *                      to within 1 / (window x open slots)) become NaN rows.
- * The host synchronises the stream once per launch (one pinned read-back).  n_drawn [M] may be NULL: attempts consumed
- * per galaxy.  *n_unfilled (host): number of NaN slots. */
+ *                      a slot is retried for as long as its galaxy still gets draws accepted.  Where an attempt window
+ *                      ends (1024, 16384, 262144, ...), and once the galaxy's open slots have used 1e5 attempts since
+ *                      the last look, the open slots of a galaxy that got NOT ONE draw accepted since then (counted
+ *                      from its 64th attempt on) become NaN rows.
+ * The host synchronises the stream once per launch pair (one pinned read-back).  n_drawn [M] may be NULL: attempts
+ * consumed per galaxy.  *n_unfilled (host): number of NaN slots. */
 int sf_flow_sample(sf_flow* f, const float* x /*[M,C]*/, int64_t M, int64_t S,
                    const float* lo, const float* hi, uint64_t seed, int32_t max_attempts,
                    float* out /*[M,S,D]*/, int32_t* n_drawn /*[M]*/, int64_t* n_unfilled /*host*/,
@@ -184,7 +188,7 @@ int sf_flow_sample_slots(sf_flow* f, const float* x /*[M,C]*/, int64_t M, int64_
                          int32_t max_attempts, float* out /*[M,S,D]*/, int64_t* n_unfilled /*host*/, void* stream);
 
 /* Figures of the last sf_flow_sample / sf_flow_sample_slots call (host [4]): duration in ms of its first persistent
- * launch (HIP events on the call's stream; the only launch unless some slot needed more than 1024 attempts), number of
+ * launch (HIP events on the call's stream; the only launch unless some slot needed more than 1024 / 256 attempts), number of
  * launches, slots whose FIRST attempt was rejected, flow evaluations over all launches. */
 int sf_flow_sample_stats(const sf_flow* f, float* stats4);
 

@@ -43,9 +43,10 @@ def sample_slots(spec: flows.FlowSpec, flat: torch.Tensor, x: np.ndarray, slots:
 
     ``max_attempts`` an integer: hard ceiling, rows that exhaust it are NaN (the reference's failure
     convention, sbi_runner.py:6458-6460).  ``None``: no ceiling, as in [UPSTREAM] accept_reject_sample
-    -- with the product's progress rule (include/synference_hip.h, sf_flow_sample): attempts go in the
-    windows [0,1024), [1024,16384), ...; after a window, the open slots of a galaxy that got no draw
-    accepted between its 64th attempt and the end of that window become NaN rows.
+    -- with the product's progress rule (include/synference_hip.h, sf_flow_sample): the rule is looked at
+    where a window ends (attempts 1024, 16384, 262144, ...) once the open slots have seen at least 1e5
+    attempts (window length x S) since the last look; the open slots of a galaxy that got no draw
+    accepted since then (counting from the 64th attempt) become NaN rows.
     Returns (theta[len(slots), D], attempts_used[len(slots)]).
     """
     slots = np.asarray(slots, dtype=np.uint64)
@@ -56,11 +57,11 @@ def sample_slots(spec: flows.FlowSpec, flat: torch.Tensor, x: np.ndarray, slots:
     lo_ = None if lo is None else np.asarray(lo, dtype=np.float32)
     hi_ = None if hi is None else np.asarray(hi, dtype=np.float32)
     ceiling = int(max_attempts) if max_attempts else 1 << 30
-    attempt, limit = 0, min(1024, ceiling)
+    attempt, window_end, acc_from = 0, min(1024, ceiling), 64
     xs = np.asarray(x)
+    progressed = set()
     while len(pending) and attempt < ceiling:
-        progressed = set()
-        while attempt < limit and len(pending):
+        while attempt < window_end and len(pending):
             sl = slots[pending]
             g = (sl // np.uint64(S)).astype(np.int64)
             z = philox.normal(seed, sl, attempt, spec.D, stream=stream)
@@ -74,10 +75,11 @@ def sample_slots(spec: flows.FlowSpec, flat: torch.Tensor, x: np.ndarray, slots:
                 progressed.update(g[ok].tolist())
             pending = pending[~ok]
             attempt += 1
-        if not max_attempts and len(pending):
+        if not max_attempts and len(pending) and (attempt - acc_from) * S >= 100000:
             g = (slots[pending] // np.uint64(S)).astype(np.int64)
             pending = pending[np.isin(g, list(progressed))]
-        limit = min(ceiling, limit * 16)
+            progressed, acc_from = set(), attempt
+        window_end = min(ceiling, window_end * 16)
     return out, used
 
 

@@ -102,7 +102,7 @@ void sf_flow_destroy(sf_flow* f) {
     (void)hipFree(f->d_ctab); (void)hipFree(f->d_packed16B); (void)hipFree(f->d_s16B); (void)hipFree(f->d_packed16); (void)hipFree(f->d_s16a); (void)hipFree(f->d_s16b);
     (void)hipFree(f->d_s1); (void)hipFree(f->d_s2); (void)hipFree(f->d_t1); (void)hipFree(f->d_t2);
     (void)hipFree(f->d_flat); (void)hipFree(f->d_gpacked); (void)hipFree(f->d_gdst);
-    (void)hipFree(f->d_queue); (void)hipFree(f->d_ring); (void)hipFree(f->d_galacc); (void)hipHostFree(f->h_queue);
+    (void)hipFree(f->d_queue); (void)hipFree(f->d_ring); (void)hipFree(f->d_galacc); (void)hipFree(f->d_best); (void)hipHostFree(f->h_queue);
     (void)hipFree(f->d_act); (void)hipFree(f->d_rej[0]); (void)hipFree(f->d_rej[1]); (void)hipFree(f->d_cnt);
   }
   delete f;
@@ -391,28 +391,41 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
   a.out_slots = (uint32_t)(M * S);
   const uint32_t* cur = slots;
   int64_t pending = n_slots;
-  uint32_t attempt = 0, limit = ceiling < 1024u ? ceiling : 1024u;
+  // the 16-row MAF kernel tries a slot 64 times per workgroup iteration, the 32-row kernels 32 times per tile: the
+  // first (persistent) launch goes as deep as a short sequential chain allows, the windows beyond are chip-wide
+  const bool fast16 = m.kind == SF_MAF && m.m16_ok && !m.hidden_bf16 && m.packed16 != nullptr;
+  const uint32_t first_window = fast16 ? 1024u : 256u;
+  uint32_t attempt = 0, limit = ceiling < first_window ? ceiling : first_window;
   int buf = 0, stage = 0;
   double evals = 0.0;
   float rej0 = 0.f;
   int64_t dropped = 0;
-  while (pending > 0) {
+  const bool progress_rule = !capped;
+  // The progress rule is looked at where a window ends (attempts 1024, 16384, 262144, ...), and only once the galaxy's
+  // open slots have seen enough attempts since the last look for "no draw accepted" to mean something (1e5 attempts
+  // over S slots: acceptance below ~3e-5 at 95 %); otherwise the counters carry over into the next window.
+  uint32_t acc_from = 64;
+  auto rule_due = [&](uint32_t att_now) { return progress_rule && (uint64_t)(att_now - acc_from) * (uint64_t)S >= 100000ull; };
+  // ---- launch 1: the persistent kernel -- first attempts and retries of every slot, attempts [0, limit)
+  {
     SF_HIP(hipMemsetAsync(f->d_queue, 0, sizeof(SfQueue), st));
 #ifdef SF_Q_STATS
     SF_HIP(hipMemsetAsync(&f->d_queue->stats[10], 0xff, sizeof(unsigned long long), st));  // atomicMin target
 #endif
-    const bool progress_rule = !capped;
     if (progress_rule) SF_HIP(hipMemsetAsync(f->d_galacc, 0, (size_t)M * sizeof(int32_t), st));
     a.slots = cur; a.slot_base = 0; a.n_items = (long)pending; a.n_total = (uint32_t)pending;
-    a.attempt = attempt; a.attempt_limit = limit; a.attempts_per_slot = 1;
+    a.attempt = 0; a.attempt_limit = limit; a.attempts_per_slot = 1;
     a.rejected = f->d_rej[buf];
     a.gal_acc = progress_rule ? f->d_galacc : nullptr;
-    if (stage == 0) SF_HIP(hipEventRecord(f->ev_dense[0], st));
+    SF_HIP(hipEventRecord(f->ev_dense[0], st));
     hipError_t e = sf_launch_inverse(m, a, st);
     if (e != hipSuccess) { f->ctab_x = nullptr; return hip_fail(e, "persistent sampler launch"); }
-    if (stage == 0) SF_HIP(hipEventRecord(f->ev_dense[1], st));
-    if (progress_rule)  // drop the open slots of galaxies that made no progress in this window (NaN rows), in place
+    SF_HIP(hipEventRecord(f->ev_dense[1], st));
+    if (limit >= 1024u && rule_due(limit)) {  // drop the open slots of galaxies that made no progress (NaN rows), in place
       SF_HIP(sf_launch_filter_survivors(f->d_rej[buf], &f->d_queue->n_surv, (long)S, f->d_galacc, out, f->L.dev.D, st));
+      SF_HIP(hipMemsetAsync(f->d_galacc, 0, (size_t)M * sizeof(int32_t), st));
+      acc_from = limit;
+    }
     SF_HIP(hipMemcpyAsync(f->h_queue, f->d_queue, sizeof(SfQueue), hipMemcpyDeviceToHost, st));  // pinned
     SF_HIP(hipStreamSynchronize(st));
     if (f->h_queue->error) {
@@ -426,6 +439,7 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
                                     " dense_next " + std::to_string(f->h_queue->dense_next));
     }
     evals += (double)f->h_queue->evals;
+    dropped += (int64_t)f->h_queue->dropped;
     if (std::getenv("SF_Q_STATS")) {
       const unsigned long long* q = f->h_queue->stats;
       std::fprintf(stderr, "[sf_queue] stage %d: entry-barrier %.3e cyc, serial %.3e cyc, exit-barrier %.3e cyc, idle %.3e cyc in %llu "
@@ -435,15 +449,63 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
       std::fprintf(stderr, "[sf_queue]   max iterations of a workgroup %llu; last flow evaluation ended %.1f us, last exit %.1f us after the first start\n",
                    q[11], ((double)q[12] - (double)q[10]) * 0.01, ((double)q[13] - (double)q[10]) * 0.01);
     }
-    dropped += (int64_t)f->h_queue->dropped;
-    if (stage == 0) rej0 = (float)f->h_queue->rej0;
+    rej0 = (float)f->h_queue->rej0;
     pending = (int64_t)f->h_queue->n_surv;
     cur = f->d_rej[buf];
     buf ^= 1;
-    ++stage;
+    stage = 1;
     attempt = limit;
-    if (limit >= ceiling) break;
-    limit = (limit > ceiling / 16u) ? ceiling : limit * 16u;
+  }
+  // ---- deep tail: the few slots that used up `limit` attempts (their galaxies accept less than ~1 draw in a
+  // thousand).  One slot's attempts are now spread over the whole chip instead of over one workgroup: a FIND launch
+  // evaluates attempts [a_lo, a_lo + A) of every survivor side by side (plain kernel, an accepted attempt only lowers
+  // best[i] with an atomic min), a RESOLVE launch re-evaluates exactly attempt best[i] and writes the draw -- the
+  // slot still keeps its LOWEST accepted attempt, so the result does not depend on A or on the schedule.
+  if (pending > 0 && attempt < ceiling) {
+    if (f->best_cap < (size_t)pending) {
+      (void)hipFree(f->d_best);
+      f->d_best = nullptr; f->best_cap = 0;
+      SF_HIP(hipMalloc(&f->d_best, (size_t)pending * sizeof(uint32_t)));
+      f->best_cap = (size_t)pending;
+    }
+    SfSampleArgsHost p = a;  // plain launches
+    p.q = nullptr; p.ring = nullptr; p.gal_acc = nullptr; p.n_drawn = nullptr;
+    uint32_t window_end = attempt < 1024u ? 1024u : ((attempt > ceiling / 16u) ? ceiling : attempt * 16u);
+    if (window_end > ceiling) window_end = ceiling;
+    while (pending > 0 && attempt < ceiling) {
+      uint32_t A = 32;
+      while ((uint64_t)(2u * A) * (uint64_t)pending <= (1ull << 22) && 2u * A <= 65536u) A *= 2;
+      while (A > 1 && (uint64_t)attempt + A > (uint64_t)window_end) A /= 2;  // windows (and the caller's ceiling) are exact
+      SF_HIP(hipMemsetAsync(f->d_best, 0xff, (size_t)pending * sizeof(uint32_t), st));
+      p.slots = cur; p.slot_base = 0; p.n_items = (long)pending * A; p.attempts_per_slot = (int)A; p.attempt = attempt;
+      p.best = f->d_best; p.att_list = nullptr; p.rejected = nullptr; p.n_rejected = nullptr;
+      hipError_t e = sf_launch_inverse(m, p, st);
+      if (e != hipSuccess) { f->ctab_x = nullptr; return hip_fail(e, "find launch"); }
+      SF_HIP(sf_launch_account_window(cur, f->d_best, (long)pending, (long)S, attempt, A, n_drawn,
+                                      progress_rule ? f->d_galacc : nullptr, st));
+      SF_HIP(hipMemsetAsync(&f->d_queue->n_surv, 0, 2 * sizeof(unsigned int), st));  // n_surv, dropped
+      p.n_items = (long)pending; p.attempts_per_slot = 1; p.best = nullptr; p.att_list = f->d_best;
+      p.rejected = f->d_rej[buf]; p.n_rejected = &f->d_queue->n_surv;
+      e = sf_launch_inverse(m, p, st);
+      if (e != hipSuccess) { f->ctab_x = nullptr; return hip_fail(e, "resolve launch"); }
+      evals += (double)pending * A + (double)pending;
+      attempt += A;
+      const bool window_done = attempt >= window_end || attempt >= ceiling;
+      const bool look = window_done && rule_due(attempt);
+      if (look) {
+        SF_HIP(sf_launch_filter_survivors(f->d_rej[buf], &f->d_queue->n_surv, (long)S, f->d_galacc, out, f->L.dev.D, st));
+        SF_HIP(hipMemsetAsync(f->d_galacc, 0, (size_t)M * sizeof(int32_t), st));
+        acc_from = attempt;
+      }
+      SF_HIP(hipMemcpyAsync(f->h_queue, f->d_queue, sizeof(SfQueue), hipMemcpyDeviceToHost, st));
+      SF_HIP(hipStreamSynchronize(st));
+      if (look) dropped += (int64_t)f->h_queue->dropped;
+      if (window_done) window_end = (window_end > ceiling / 16u) ? ceiling : window_end * 16u;
+      pending = (int64_t)f->h_queue->n_surv;
+      cur = f->d_rej[buf];
+      buf ^= 1;
+      ++stage;
+    }
   }
   {
     float ms = 0.f;

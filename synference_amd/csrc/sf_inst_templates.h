@@ -77,9 +77,11 @@ __global__ __launch_bounds__(LDSW ? 512 : 256) void k_inverse(SfDev m, SfSampleA
   float logdet[NS];
   long item[NS];
   uint64_t slot[NS];
-  long gal[NS];
+  long gal[NS], ps_idx[NS];
+  uint32_t att_mine[NS];
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) {
+    ps_idx[ns] = 0; att_mine[ns] = 0;
     item[ns] = base + ns * 32 + c;
     const long it = item[ns] < a.n_items ? item[ns] : a.n_items - 1;
     logdet[ns] = 0.f;
@@ -93,9 +95,11 @@ __global__ __launch_bounds__(LDSW ? 512 : 256) void k_inverse(SfDev m, SfSampleA
         if (p < m.D) u[ns][p] = a.z_in[it * m.D + p];
     } else {
       const long ps = it >> a.log2_attempts;  // listed slot; A (a power of two) consecutive items share it
+      ps_idx[ns] = ps;
       slot[ns] = a.slots ? (uint64_t)a.slots[ps] : (uint64_t)(a.slot_base + ps);
       gal[ns] = (long)((uint32_t)slot[ns] / (uint32_t)a.S);  // slot ids fit 32 bits (checked by the API)
-      const uint32_t att = a.attempt + (uint32_t)(it & (long)(a.attempts_per_slot - 1));
+      const uint32_t att = a.att_list ? a.att_list[ps] : a.attempt + (uint32_t)(it & ((1L << a.log2_attempts) - 1));
+      att_mine[ns] = att;
 #pragma unroll
       for (int blk = 0; blk < SF_DMAX / 4; ++blk)
         if (blk * 4 < m.D) {
@@ -126,6 +130,7 @@ __global__ __launch_bounds__(LDSW ? 512 : 256) void k_inverse(SfDev m, SfSampleA
         ok = ok && (fabsf(th[p]) <= 3.0e38f);  // finite (NaN compares false)
         if (a.lo) ok = ok && (th[p] >= a.lo[td]) && (th[p] <= a.hi[td]);
       }
+    if (a.att_list && att_mine[ns] == 0xffffffffu) ok = false;  // no attempt to resolve: straight to the rejected list
     if (a.z_in) {
       if (valid && h == 0) {
 #pragma unroll
@@ -133,6 +138,8 @@ __global__ __launch_bounds__(LDSW ? 512 : 256) void k_inverse(SfDev m, SfSampleA
           if (p < m.D) a.out[item[ns] * m.D + (int)m.cst[m.c_tdim + p]] = th[p];
         if (a.logdet_out) a.logdet_out[item[ns]] = logdet[ns] - m.logdet0;
       }
+    } else if (a.best) {
+      if (valid && h == 0 && ok) atomicMin(&a.best[ps_idx[ns]], att_mine[ns]);
     } else if (a.count) {
       const bool hit = valid && h == 0 && ok;
       const unsigned long long bal = __ballot(hit);
@@ -270,7 +277,9 @@ __global__ __launch_bounds__(64 * WPB) void k_sample_persist(SfSampArgs args_in,
       const bool surv = leader && first < 0 && !retry;
       if (leader && (a.n_drawn || a.gal_acc)) {
         const long gal = (long)(slot / (uint32_t)a.S);
-        if (a.n_drawn && att_base > 0) atomicAdd(&a.n_drawn[gal], first >= 0 ? first + 1 : (int)tried);
+        // (the caller pre-counts ONE attempt per slot; a first attempt that ran with speculation may have used more)
+      const int used = (first >= 0 ? first + 1 : (int)tried) - (att_base == 0u ? 1 : 0);
+      if (a.n_drawn && used > 0) atomicAdd(&a.n_drawn[gal], used);
         if (hit && a.gal_acc && att_base >= 64u) atomicAdd(&a.gal_acc[gal], 1);  // progress past the 64th attempt
       }
       if (retry) {

@@ -24,6 +24,11 @@ struct SfSampleArgsHost {
   uint32_t* n_rejected = nullptr;
   int32_t* n_drawn = nullptr;
   int32_t* count = nullptr;
+  // find mode (plain kernels): listed slot i = item >> log2_attempts (any power of two of attempts per slot); an accepted
+  // attempt only lowers best[i] (atomic min), nothing else is written.  att_list (sampling mode, attempts_per_slot 1):
+  // listed slot i tries attempt att_list[i] instead of `attempt` (0xffffffff = none: goes straight to the rejected list)
+  uint32_t* best = nullptr;
+  const uint32_t* att_list = nullptr;
   // persistent mode (q != nullptr): one launch works the dense list AND its retries to the end (sf_queue.h)
   struct SfQueue* q = nullptr;
   unsigned long long* ring = nullptr;  // retry ring, ring_mask + 1 entries
@@ -49,6 +54,8 @@ hipError_t sf_launch_pack_bf16(const float* flat, const int32_t* src, unsigned s
 hipError_t sf_launch_pack_bf16_split(const float* flat, const int32_t* src, unsigned short* out, long n, hipStream_t st);
 hipError_t sf_launch_fill_nan_rows(float* out, const uint32_t* slots, long n, int D, hipStream_t st);
 hipError_t sf_launch_fill_i32(int32_t* p, long n, int32_t v, hipStream_t st);
+hipError_t sf_launch_account_window(const uint32_t* list, const uint32_t* best, long n, long S, uint32_t a_lo, uint32_t A,
+                                    int32_t* n_drawn, int32_t* gal_acc, hipStream_t st);
 // survivors of galaxies with gal_acc == 0 become NaN rows; the others are compacted in place; *n_surv updated
 hipError_t sf_launch_filter_survivors(uint32_t* list, unsigned int* n_surv, long S, const int32_t* gal_acc, float* out,
                                       int D, hipStream_t st);
@@ -99,6 +106,8 @@ struct sf_flow {
   unsigned long long* d_ring = nullptr;  // retry ring
   uint64_t ring_cap = 0;         // entries (power of two)
   int32_t* d_galacc = nullptr;   // per-galaxy accepted-slot counter of a stage (progress rule)
+  uint32_t* d_best = nullptr;    // deep-tail windows: lowest accepted attempt per survivor (find launch -> resolve launch)
+  size_t best_cap = 0;
   size_t galacc_cap = 0;
   uint32_t* d_cnt = nullptr;     // SF_MAX_ROUNDS rejected-slot counters (one per round of a sf_flow_sample call)
   uint32_t* h_cnt = nullptr;     // pinned host mirror for the per-round read-back

@@ -93,6 +93,18 @@ __global__ __launch_bounds__(1024) void k_filter_survivors(uint32_t* __restrict_
   }
 }
 
+// Bookkeeping between the find and the resolve launch of a deep-tail window (sf_api.hip): attempts consumed per galaxy
+// and the per-galaxy progress counter.
+__global__ void k_account_window(const uint32_t* __restrict__ list, const uint32_t* __restrict__ best, long n, long S,
+                                 uint32_t a_lo, uint32_t A, int32_t* __restrict__ n_drawn, int32_t* __restrict__ gal_acc) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long g = (long)(list[i] / (uint32_t)S);
+  const uint32_t b = best[i];
+  if (n_drawn) atomicAdd(&n_drawn[g], b != 0xffffffffu ? (int)(b - a_lo + 1u) : (int)A);
+  if (gal_acc && b != 0xffffffffu) atomicAdd(&gal_acc[g], 1);
+}
+
 __global__ void k_fill_i32(int32_t* p, long n, int32_t v) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -209,6 +221,12 @@ hipError_t sf_launch_fill_nan_rows(float* out, const uint32_t* slots, long n, in
 hipError_t sf_launch_filter_survivors(uint32_t* list, unsigned int* n_surv, long S, const int32_t* gal_acc, float* out,
                                       int D, hipStream_t st) {
   hipLaunchKernelGGL(k_filter_survivors, dim3(1), dim3(1024), 0, st, list, n_surv, S, gal_acc, out, D);
+  return hipGetLastError();
+}
+hipError_t sf_launch_account_window(const uint32_t* list, const uint32_t* best, long n, long S, uint32_t a_lo, uint32_t A,
+                                    int32_t* n_drawn, int32_t* gal_acc, hipStream_t st) {
+  if (n <= 0 || (!n_drawn && !gal_acc)) return hipSuccess;
+  hipLaunchKernelGGL(k_account_window, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, list, best, n, S, a_lo, A, n_drawn, gal_acc);
   return hipGetLastError();
 }
 hipError_t sf_launch_fill_i32(int32_t* p, long n, int32_t v, hipStream_t st) {

@@ -162,7 +162,8 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16(SfDev m, SfSampleArgsHost 
   // tile layout: this lane holds physical slots 4*g4 .. 4*g4+3 of sample s
   f32x4 u;
   uint64_t slot;
-  long gal;
+  long gal, ps_idx = 0;
+  uint32_t att_mine = 0;
   if (a.z_in) {
     slot = (uint64_t)it;
     gal = it;
@@ -170,9 +171,11 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16(SfDev m, SfSampleArgsHost 
     for (int r = 0; r < 4; ++r) u[r] = (4 * g4 + r < m.D) ? a.z_in[it * m.D + 4 * g4 + r] : 0.f;
   } else {
     const long ps = it >> a.log2_attempts;  // listed slot; A (a power of two) consecutive items share it
+    ps_idx = ps;
     slot = a.slots ? (uint64_t)a.slots[ps] : (uint64_t)(a.slot_base + ps);
     gal = (long)((uint32_t)slot / (uint32_t)a.S);  // slot ids fit 32 bits (checked by the API)
-    const uint32_t att = a.attempt + (uint32_t)(it & (long)(a.attempts_per_slot - 1));
+    const uint32_t att = a.att_list ? a.att_list[ps] : a.attempt + (uint32_t)(it & ((1L << a.log2_attempts) - 1));
+    att_mine = att;
     float z4[4];
     sf_normal4(a.k0, a.k1, slot, att, (uint32_t)g4, z4);  // Philox block g4 = dimensions 4*g4 .. 4*g4+3
 #pragma unroll
@@ -311,6 +314,7 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16(SfDev m, SfSampleArgsHost 
       if (a.lo) ok = ok && (th[r] >= a.lo[td]) && (th[r] <= a.hi[td]);
     }
   }
+  if (a.att_list && att_mine == 0xffffffffu) ok = false;  // no attempt to resolve: straight to the rejected list
   const unsigned long long okb = __ballot(ok);
   const uint32_t acc16 = (uint32_t)(okb & (okb >> 16) & (okb >> 32) & (okb >> 48) & 0xffffull) &
                          (uint32_t)(__ballot(valid) & 0xffffull);
@@ -322,6 +326,8 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16(SfDev m, SfSampleArgsHost 
         if (4 * g4 + r < m.D) a.out[item * m.D + (int)m.cst[m.c_tdim + 4 * g4 + r]] = th[r];
       if (a.logdet_out && g4 == 0) a.logdet_out[item] = logdet - m.logdet0;
     }
+  } else if (a.best) {
+    if (accepted && g4 == 0) atomicMin(&a.best[ps_idx], att_mine);
   } else if (a.count) {
     const long g_first = __shfl(gal, 0, 64);
     const long g_last = __shfl(gal, 15, 64);
@@ -731,7 +737,9 @@ __global__ __launch_bounds__(256, 3) void k_maf_samp16(SfSamp16Args args_in) {
     const bool surv = leader && first < 0 && !retry;
     if (leader && (a.n_drawn || a.gal_acc)) {
       const long gal = (long)(slot / (uint32_t)a.S);
-      if (a.n_drawn && att_base > 0) atomicAdd(&a.n_drawn[gal], first >= 0 ? first + 1 : (int)tried);
+      // (the caller pre-counts ONE attempt per slot; a first attempt that ran with speculation may have used more)
+      const int used = (first >= 0 ? first + 1 : (int)tried) - (att_base == 0u ? 1 : 0);
+      if (a.n_drawn && used > 0) atomicAdd(&a.n_drawn[gal], used);
       if (hit && a.gal_acc && att_base >= 64u) atomicAdd(&a.gal_acc[gal], 1);  // progress past the 64th attempt
     }
     if (retry) {
@@ -808,7 +816,7 @@ bool sf_maf16_enabled(const SfDev& m, const SfSampleArgsHost& a) {
     env = e ? std::atoi(e) : 1;
   }
   return env != 0 && m.kind == SF_MAF && m.m16_ok && !m.hidden_bf16 && m.packed16 != nullptr &&
-         a.attempts_per_slot <= 16;
+         (a.attempts_per_slot <= 16 || a.best != nullptr);  // (find mode has no in-tile attempt groups)
 }
 
 // workgroups that fit the chip at once (persistent launches): 3 per CU by registers and LDS

@@ -268,8 +268,8 @@ def test_oracle_batch_accept_reject_sampler_and_uncapped_slot_schedule():
     # the progress rule: a dead galaxy (NaN context) ends as NaN rows after the window [0, 1024); a ceiling is a ceiling
     xx = x[:2].numpy().copy()
     xx[1] = np.nan
-    out, used = OP.sample_slots(o, flat, xx, np.arange(20, dtype=np.uint64), 10, 7, lo, hi)
-    assert np.isfinite(out[:10]).all() and np.isnan(out[10:]).all() and (used[10:] == 1024).all()
+    out, used = OP.sample_slots(o, flat, xx, np.arange(240, dtype=np.uint64), 120, 7, lo, hi)
+    assert np.isfinite(out[:120]).all() and np.isnan(out[120:]).all() and (used[120:] == 1024).all()
     out, used = OP.sample_slots(o, flat, xx, np.arange(20, dtype=np.uint64), 10, 7, lo, hi, max_attempts=5)
     assert np.isnan(out[10:]).all() and used.max() <= 5
 
