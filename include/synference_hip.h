@@ -180,6 +180,11 @@ int sf_flow_sample(sf_flow* f, const float* x /*[M,C]*/, int64_t M, int64_t S,
                    float* out /*[M,S,D]*/, int32_t* n_drawn /*[M]*/, int64_t* n_unfilled /*host*/,
                    void* stream);
 
+/* Wall-clock ceiling of later sf_flow_sample / sf_flow_sample_slots calls on this handle (seconds; <= 0 = none, the
+ * default): once it is exceeded no further attempt window is opened and the slots still empty become NaN rows.
+ * Replaces: the per-object timeout of sample_posterior (timeout_seconds_per_test, ref: sbi_runner.py:6358, 6443-6452). */
+int sf_flow_set_sample_time_limit(sf_flow* f, double seconds);
+
 /* The same over an explicit list of output slots (slot = g*S + p; DEVICE uint32 [n_slots], each slot once): only those
  * slots of out are written.  This is what an ensemble member runs on its share of every row's draws
  * ([UPSTREAM] sbi EnsemblePosterior.sample, built at ref: custom_runner.py:278-283). */

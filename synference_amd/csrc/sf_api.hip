@@ -1,6 +1,7 @@
 // sf_api.hip -- the C ABI (include/synference_hip.h): handle management and call sequencing.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -391,6 +392,11 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
   a.out_slots = (uint32_t)(M * S);
   const uint32_t* cur = slots;
   int64_t pending = n_slots;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto out_of_time = [&]() {
+    return f->sample_time_limit_s > 0.0 &&
+           std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > f->sample_time_limit_s;
+  };
   // the 16-row MAF kernel tries a slot 64 times per workgroup iteration, the 32-row kernels 32 times per tile: the
   // first (persistent) launch goes as deep as a short sequential chain allows, the windows beyond are chip-wide
   const bool fast16 = m.kind == SF_MAF && m.m16_ok && !m.hidden_bf16 && m.packed16 != nullptr;
@@ -472,7 +478,7 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
     p.q = nullptr; p.ring = nullptr; p.gal_acc = nullptr; p.n_drawn = nullptr;
     uint32_t window_end = attempt < 1024u ? 1024u : ((attempt > ceiling / 16u) ? ceiling : attempt * 16u);
     if (window_end > ceiling) window_end = ceiling;
-    while (pending > 0 && attempt < ceiling) {
+    while (pending > 0 && attempt < ceiling && !out_of_time()) {
       uint32_t A = 32;
       while ((uint64_t)(2u * A) * (uint64_t)pending <= (1ull << 22) && 2u * A <= 65536u) A *= 2;
       while (A > 1 && (uint64_t)attempt + A > (uint64_t)window_end) A /= 2;  // windows (and the caller's ceiling) are exact
@@ -625,6 +631,12 @@ int sf_flow_train_epoch(sf_flow* f, float* flat, const float* theta, const float
     rc = sf_adam_apply(flat, grad, exp_avg, exp_avg_sq, f->L.n_params, d, step0 + b + 1, max_norm, scratch, stream);
     if (rc) return rc;
   }
+  return SF_OK;
+}
+
+int sf_flow_set_sample_time_limit(sf_flow* f, double seconds) {
+  if (!f) return fail(SF_ERR_INVALID, "null handle");
+  f->sample_time_limit_s = seconds > 0.0 ? seconds : 0.0;
   return SF_OK;
 }
 

@@ -111,6 +111,7 @@ struct sf_flow {
   size_t galacc_cap = 0;
   uint32_t* d_cnt = nullptr;     // SF_MAX_ROUNDS rejected-slot counters (one per round of a sf_flow_sample call)
   uint32_t* h_cnt = nullptr;     // pinned host mirror for the per-round read-back
+  double sample_time_limit_s = 0.0;  // > 0: sf_flow_sample* stop opening new attempt windows after this much wall time
   bool profiling = false;         // sf_flow_set_profiling: bracket the training flow kernel with HIP events
   hipEvent_t ev_train[2] = {nullptr, nullptr};
   bool ev_train_valid = false;

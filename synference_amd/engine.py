@@ -195,6 +195,10 @@ class HipFlow:
         self.last_unfilled = int(unfilled.value)
         return self.last_unfilled
 
+    def set_sample_time_limit(self, seconds: Optional[float]) -> None:
+        """Wall-clock ceiling of later sample() / sample_slots() calls (None / 0 = none); see sf_flow_set_sample_time_limit."""
+        _lib.check(self.lib.sf_flow_set_sample_time_limit(self.handle, C.c_double(float(seconds or 0.0))))
+
     def set_profiling(self, on: bool) -> None:
         """Bracket the training flow kernel of later loss_grad calls with HIP events (sf_flow_set_profiling)."""
         _lib.check(self.lib.sf_flow_set_profiling(self.handle, 1 if on else 0))

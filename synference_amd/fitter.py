@@ -233,7 +233,9 @@ class SBI_Fitter:
             t0 = time.time()
             try:
                 sub_seed = None if seed is None else int(seed) + 0x9E3779B1 * ci
-                s = posteriors.sample_catalogue(torch.as_tensor(X[a:b]), num_samples, sub_seed)
+                # the reference's per-object timeout (sbi_runner.py:6358) becomes the wall-clock ceiling of the chunk
+                tmo = float(timeout_seconds_per_test) * (b - a) if timeout_seconds_per_test else None
+                s = posteriors.sample_catalogue(torch.as_tensor(X[a:b]), num_samples, sub_seed, timeout_seconds=tmo)
                 # D2H in float32 through a pinned buffer (half the PCIe bytes of a device-side .double()),
                 # widened to the reference's float64 container on the host
                 host = torch.empty(s.shape, dtype=torch.float32, pin_memory=True)

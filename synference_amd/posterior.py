@@ -94,11 +94,14 @@ class FlowPosterior:
         return (self._seed * 0x9E3779B97F4A7C15 + self._calls) & (2 ** 63 - 1)
 
     # ---- catalogue-wide fast paths ----------------------------------------------------------
-    def sample_catalogue(self, X, num_samples: int, seed: Optional[int] = None, return_counts=False):
-        """(N,S,D) float32 device tensor of accepted draws for every row of X (NaN rows on failure)."""
+    def sample_catalogue(self, X, num_samples: int, seed: Optional[int] = None, return_counts=False,
+                         timeout_seconds: Optional[float] = None):
+        """(N,S,D) float32 device tensor of accepted draws for every row of X (NaN rows on failure).
+        ``timeout_seconds``: wall-clock ceiling of the call (the reference's ``timeout_seconds_per_test`` x objects)."""
         est = self.posterior_estimator
         X = self._embed(X)
         est._sync_params()
+        est.flow.set_sample_time_limit(timeout_seconds)
         lo, hi = self._box()
         seed = self._next_seed(seed)
         N, S = X.shape[0], int(num_samples)
@@ -242,10 +245,12 @@ class EnsemblePosterior:
         self._calls += 1
         return (self._seed * 0x9E3779B97F4A7C15 + 0x51ED27 + self._calls) & (2 ** 63 - 1)
 
-    def sample_catalogue(self, X, num_samples: int, seed: Optional[int] = None):
+    def sample_catalogue(self, X, num_samples: int, seed: Optional[int] = None, timeout_seconds: Optional[float] = None):
         """Per row: multinomial(weights, S) split; member e fills positions [cum_{e-1}, cum_e)."""
         if len(self.posteriors) == 1:
-            return self.posteriors[0].sample_catalogue(X, num_samples, self._next_seed(seed))
+            return self.posteriors[0].sample_catalogue(X, num_samples, self._next_seed(seed), timeout_seconds=timeout_seconds)
+        for p in self.posteriors:
+            p.posterior_estimator.flow.set_sample_time_limit(timeout_seconds)
         p0 = self.posteriors[0]
         dev, D, S = p0.device, p0.spec.D, int(num_samples)
         X = torch.as_tensor(X, dtype=torch.float32, device=dev)
