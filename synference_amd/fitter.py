@@ -38,9 +38,15 @@ class SBI_Fitter:
                  library_path: str = None, supplementary_parameters: np.ndarray = None,
                  supplementary_parameter_names: list = None, supplementary_parameter_units: list = None,
                  device: str = "cuda", observation_type: str = "photometry") -> None:
-        if simulator is not None or library_path is not None:
-            raise ValueError("the HIP backend starts from a feature array and a parameter array; library "
-                             "loading and online simulators are outside the accelerated path")
+        if simulator is not None:
+            raise ValueError("online simulators are outside the accelerated path: the HIP backend trains on a library "
+                             "(init_from_hdf5) or on a feature array + parameter array")
+        self.library_path = library_path
+        self.raw_observation_grid = None if raw_observation_grid is None else np.asarray(raw_observation_grid)
+        self.raw_observation_units = raw_observation_units
+        self.supplementary_parameters = supplementary_parameters
+        self.supplementary_parameter_names = supplementary_parameter_names
+        self.supplementary_parameter_units = supplementary_parameter_units
         self.name = name
         self.parameter_names = list(parameter_names)
         self.fitted_parameter_names = list(parameter_names)
@@ -71,6 +77,50 @@ class SBI_Fitter:
         self.fitted_model_name = None
 
     # ---------------------------------------------------------------------------------------
+    @classmethod
+    def init_from_hdf5(cls, model_name: str, hdf5_path: str, return_output: bool = False, **kwargs):
+        """ref: sbi_runner.py:309-405 -- a fitter on top of a library file (``Grid/Photometry`` (C,N) in nJy,
+        ``Grid/Parameters`` (D,N), root attributes ``FilterCodes`` / ``ParameterNames`` / units), read by
+        ``synference_amd.library.load_library_from_hdf5`` (no h5py needed)."""
+        from .library import load_library_from_hdf5
+        output = load_library_from_hdf5(hdf5_path)
+        if return_output:
+            return output
+        if "photometry" in output:
+            grid, otype = output["photometry"], "photometry"
+        elif "spectra" in output:
+            grid, otype = output["spectra"], "spectra"
+        else:
+            raise ValueError("HDF5 file must contain 'photometry' or 'spectra' data.")
+        return cls(name=model_name, raw_observation_grid=grid, raw_observation_names=list(output["filter_codes"]),
+                   parameter_array=output["parameters"].T, parameter_names=list(output["parameter_names"]),
+                   parameter_units=None if output["parameter_units"] is None else list(output["parameter_units"]),
+                   raw_observation_units=output["photometry_units"], library_path=hdf5_path,
+                   supplementary_parameters=output.get("supplementary_parameters"),
+                   supplementary_parameter_names=list(output.get("supplementary_parameter_names", [])),
+                   supplementary_parameter_units=list(output.get("supplementary_parameter_units", [])),
+                   observation_type=otype, **kwargs)
+
+    def create_feature_array_from_raw_photometry(self, normed_flux_units: str = "AB", norm_mag_limit: float = 50.0,
+                                                 extra_features: list = None, normalize_method=None, **unused):
+        """The AB-magnitude branch of the reference's feature engineering (ref: sbi_runner.py:1698-1716, 1927-1932,
+        2150) on the device: the library's (C, N) fluxes in nJy become the (N, C) float32 feature array.  Extra feature
+        columns, normalisation to a reference band and noise models stay outside the accelerated path."""
+        if self.raw_observation_grid is None:
+            raise ValueError("no raw observation grid: build the fitter with init_from_hdf5 or pass feature_array")
+        if extra_features or normalize_method is not None or normed_flux_units != "AB":
+            raise ValueError("only normed_flux_units='AB' without extra features / normalisation is on the HIP path")
+        from .features import flux_to_abmag
+        flux = torch.as_tensor(np.ascontiguousarray(self.raw_observation_grid.T), dtype=torch.float32)
+        if not torch.cuda.is_available():
+            raise RuntimeError("create_feature_array_from_raw_photometry runs on the GPU (no CPU fallback)")
+        mag = flux_to_abmag(flux.cuda(), None, norm_mag_limit)
+        self.feature_array = np.ascontiguousarray(mag.cpu().numpy().astype(np.float32))
+        self.feature_names = list(self.raw_observation_names)
+        self.feature_units = ["AB"] * self.feature_array.shape[1]
+        self.has_features = True
+        return self.feature_array, self.feature_names
+
     def split_dataset(self, train_fraction: float = 0.8, random_seed: int = None, verbose: bool = True) -> tuple:
         if random_seed is not None:
             np.random.seed(random_seed)

@@ -1,0 +1,79 @@
+"""Library files without h5py: synference_amd.hdf5_lite against byte-level fixtures assembled from
+the HDF5 File Format Specification (tests/helpers/hdf5_fixture.py), and the reference's load_library_from_hdf5 contract
+(ref: src/synference/utils.py:37-112)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "helpers"))
+from hdf5_fixture import Writer, write_library  # noqa: E402
+
+from synference_amd.hdf5_lite import File, Hdf5Error  # noqa: E402
+from synference_amd.library import load_library_from_hdf5  # noqa: E402
+
+
+@pytest.mark.parametrize("gzip,shuffle,chunks", [(4, False, None), (9, True, (3, 700)), (0, False, (10, 128)), (1, True, (1, 4096))])
+def test_library_round_trip(tmp_path, gzip, shuffle, chunks):
+    rng = np.random.default_rng(0)
+    C, D, N = 10, 5, 3001                                        # ragged against every chunk shape
+    phot = rng.lognormal(size=(C, N)) * 100.0
+    par = rng.normal(size=(D, N))
+    supp = rng.normal(size=(2, N))
+    codes = [f"JWST/NIRCam.F{115 + 35 * i}W" for i in range(C)]
+    names = ["log_mass", "tau_v", "log_zmet", "peak_age", "tau"]
+    p = str(tmp_path / "grid.hdf5")
+    write_library(p, phot, par, codes, names, ["Msun", "mag", "", "Myr", "dimensionless"], supp, ["mwa", "sfr"], ["Myr", "Msun/yr"],
+                  chunks=chunks, gzip=gzip, shuffle=shuffle)
+    out = load_library_from_hdf5(p)
+    assert np.array_equal(out["photometry"], phot) and np.array_equal(out["parameters"], par)      # bit-exact
+    assert out["photometry"].dtype == np.float64 and out["photometry"].shape == (C, N)
+    assert list(out["filter_codes"]) == codes and list(out["parameter_names"]) == names
+    assert out["photometry_units"] == "nJy" and list(out["parameter_units"])[-1] == "dimensionless"
+    assert np.array_equal(out["supplementary_parameters"], supp) and list(out["supplementary_parameter_names"]) == ["mwa", "sfr"]
+    assert "spectra" not in out
+    with File(p) as f:
+        assert "Grid/Photometry" in f and "Grid/Nope" not in f and sorted(f["Grid"].keys()) == ["Parameters", "Photometry", "SupplementaryParameters"]
+        assert f.attrs["CreationDT"] == "20260101_000000"
+        assert np.array_equal(f["Grid/Parameters"][:, 5:9], par[:, 5:9])
+
+
+def test_contiguous_float32_dataset_fixed_strings_and_numeric_attributes(tmp_path):
+    w = Writer()
+    a = np.arange(24, dtype=np.float32).reshape(4, 6)
+    d = w.dataset(a, chunks=None, attrs={"scale": np.array([1.5, 2.5]), "tags": np.array([b"ab", b"cde"], dtype="S3")})
+    g, _, _ = w.group({"A": d}, attrs={"note": "inner"})
+    p = str(tmp_path / "x.h5")
+    w.finish({"G": g}, {"Title": "tést", "Names": ["a", "", "θ"]}, p)
+    with File(p) as f:
+        ds = f["G/A"]
+        assert np.array_equal(ds[:], a) and ds[:].dtype == np.float32
+        assert np.array_equal(ds.attrs["scale"], [1.5, 2.5]) and list(ds.attrs["tags"]) == ["ab", "cde"]
+        assert f["G"].attrs["note"] == "inner" and f.attrs["Title"] == "tést" and list(f.attrs["Names"]) == ["a", "", "θ"]
+        with pytest.raises(KeyError):
+            f["G/B"]
+
+
+def test_not_hdf5_and_missing_file(tmp_path):
+    p = tmp_path / "junk.h5"
+    p.write_bytes(b"not an hdf5 file" * 100)
+    with pytest.raises(Hdf5Error):
+        File(str(p))
+    with pytest.raises(FileNotFoundError, match="HDF5 file not found"):
+        load_library_from_hdf5(str(tmp_path / "absent.hdf5"))
+
+
+def test_fitter_from_library_file(tmp_path):
+    """SBI_Fitter.init_from_hdf5 (ref: sbi_runner.py:309-405): arrays in the reference's orientation."""
+    from synference_amd import SBI_Fitter
+    rng = np.random.default_rng(1)
+    phot, par = rng.lognormal(size=(4, 50)), rng.normal(size=(3, 50))
+    p = str(tmp_path / "lib.hdf5")
+    write_library(p, phot, par, ["F1", "F2", "F3", "F4"], ["a", "b", "c"], ["", "", ""])
+    f = SBI_Fitter.init_from_hdf5("m", p)
+    assert f.fitted_parameter_array.shape == (50, 3) and np.array_equal(f.fitted_parameter_array, par.T)
+    assert f.raw_observation_grid.shape == (4, 50) and f.raw_observation_names == ["F1", "F2", "F3", "F4"]
+    assert f.parameter_names == ["a", "b", "c"] and f.library_path == p and not f.has_features
+    out = SBI_Fitter.init_from_hdf5("m", p, return_output=True)
+    assert set(out) >= {"parameters", "photometry", "filter_codes", "parameter_names", "photometry_units", "parameter_units"}

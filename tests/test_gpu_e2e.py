@@ -318,3 +318,26 @@ def test_batched_posterior_api_of_sbi_023(fitted):
     assert torch.allclose(lp[5], ref, atol=1e-5)
     es = post.sample_batched((16,), x=X, seed=2)                        # the ensemble offers the same surface
     assert es.shape == (16, 7, 5) and torch.isfinite(es).all()
+
+
+def test_library_file_to_trained_posterior(tmp_path):
+    """f1 + f2 + the hot path: a library file in the reference's HDF5 layout (ref: library.py:4074-4153) -> device
+    feature transform (nJy -> AB magnitudes) -> training -> sampling, without h5py."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "helpers"))
+    from hdf5_fixture import write_library
+    from synference_amd import SBI_Fitter
+    from synference_amd.synthetic import make_catalogue
+    x, theta, names = make_catalogue(3000, 10, 5, seed=9)              # x: AB-magnitude-like features (N, C)
+    flux_njy = 10.0 ** ((23.9 - x.astype(np.float64)) / 2.5) * 1000.0  # the fluxes behind those magnitudes
+    p = str(tmp_path / "grid.hdf5")
+    write_library(p, flux_njy.T, theta.T, [f"JWST/NIRCam.F{i}" for i in range(10)], names, [""] * 5)
+    f = SBI_Fitter.init_from_hdf5("lib", p)
+    feats, fnames = f.create_feature_array_from_raw_photometry(normed_flux_units="AB", norm_mag_limit=50.0)
+    assert feats.shape == (3000, 10) and feats.dtype == np.float32 and np.abs(feats - np.minimum(x, 50.0)).max() < 2e-3
+    post, stats = f.run_single_sbi(model_type="maf", hidden_features=32, num_transforms=3, training_batch_size=256,
+                                   learning_rate=2e-3, stop_after_epochs=2, max_num_epochs=6, random_seed=1,
+                                   save_model=False, verbose=False)
+    assert stats[0]["training_loss"][-1] < stats[0]["training_loss"][0]
+    s = f.sample_posterior(f._X_test[:6], num_samples=50, seed=2)
+    assert s.shape == (6, 50, 5) and np.isfinite(s).all()
