@@ -313,7 +313,7 @@ struct SfSpline {
         e[k] = sf_exp(e[k] - mx);
         sum += e[k];
       }
-    const float scale = (1.0f - min_size * (float)K);
+    const float scale = (1.0f - min_size * (float)K) * __builtin_amdgcn_rcpf(sum);  // (one reciprocal per family)
     float cs = 0.f, c_lo = -B;
     left = -B;
     size = 1.f;
@@ -321,7 +321,7 @@ struct SfSpline {
 #pragma unroll
     for (int k = 0; k < KM; ++k)
       if (k < K) {
-        cs += min_size + scale * sf_div(e[k], sum);
+        cs += min_size + scale * e[k];
         const float c_hi = (k == K - 1) ? B : (2.0f * B * cs - B);
         const bool sel = BY_VALUE ? (v >= c_lo) : (k == idx);
         if (sel) {
@@ -349,16 +349,17 @@ struct SfSpline {
       knots<NS, KM, true>(m, q, ns, m.min_h, vc, idx, y_k, h_k);
       knots<NS, 0, false>(m, q, ns, m.min_w, vc, idx, x_k, w_k);
     }
-    // derivatives at the bin's two knots (boundary knots use the padded constant)
-    const float d_edge = m.min_d + sf_softplus(m.deriv_const);
-    float d_k = d_edge, d_k1 = d_edge;
+    // derivatives at the bin's two knots (boundary knots use the padded constant): pick the two raw values first,
+    // then ONE softplus each -- not a softplus (exp + log) per interior knot of which K-3 are thrown away
+    float r_k = m.deriv_const, r_k1 = m.deriv_const;
 #pragma unroll
     for (int j = 1; j < KM; ++j)
       if (j < K) {
-        const float dj = m.min_d + sf_softplus(Q<NS>(q, ns, 2 * KM + j - 1));
-        d_k = (j == idx) ? dj : d_k;
-        d_k1 = (j == idx + 1) ? dj : d_k1;
+        const float rj = Q<NS>(q, ns, 2 * KM + j - 1);
+        r_k = (j == idx) ? rj : r_k;
+        r_k1 = (j == idx + 1) ? rj : r_k1;
       }
+    const float d_k = m.min_d + sf_softplus(r_k), d_k1 = m.min_d + sf_softplus(r_k1);
     const float s_k = sf_div(h_k, w_k);
     float xi;
     if (!inverse) {
@@ -477,15 +478,15 @@ struct SfSplineBwd {
     float pw[KM], ph[KM];
     family_fwd<NS, 0, true>(m, q, ns, m.min_w, vc, idx, x_k, w_k, pw);
     family_fwd<NS, KM, false>(m, q, ns, m.min_h, vc, idx, y_k, h_k, ph);
-    const float d_edge = m.min_d + sf_softplus(m.deriv_const);
-    float d_k = d_edge, d_k1 = d_edge;
+    float r_k = m.deriv_const, r_k1 = m.deriv_const;  // raw derivative parameters of the bin's two knots
 #pragma unroll
     for (int j = 1; j < KM; ++j)
       if (j < K) {
-        const float dj = m.min_d + sf_softplus(SfSpline<PT>::template Q<NS>(q, ns, 2 * KM + j - 1));
-        d_k = (j == idx) ? dj : d_k;
-        d_k1 = (j == idx + 1) ? dj : d_k1;
+        const float rj = SfSpline<PT>::template Q<NS>(q, ns, 2 * KM + j - 1);
+        r_k = (j == idx) ? rj : r_k;
+        r_k1 = (j == idx + 1) ? rj : r_k1;
       }
+    const float d_k = m.min_d + sf_softplus(r_k), d_k1 = m.min_d + sf_softplus(r_k1);
     const float s = h_k / w_k;
     const float xi = (vc - x_k) / w_k;
     const float om = xi * (1.f - xi);
@@ -517,13 +518,12 @@ struct SfSplineBwd {
     dv = inside ? L_xi * inv_w : Go;
     family_bwd<NS, 0>(m, pw, idx, L_x, L_w, m.min_w, dq, ns);
     family_bwd<NS, KM>(m, ph, idx, L_y, L_h, m.min_h, dq, ns);
+    // d softplus / d raw = sigmoid(raw): only the bin's two knots carry gradient -- two sigmoids, not K-1
+    const float g_k = L_dk * sf_sigmoid(r_k), g_k1 = L_dk1 * sf_sigmoid(r_k1);
 #pragma unroll
     for (int j = 1; j < KM; ++j)
-      if (j < K) {
-        const float raw = SfSpline<PT>::template Q<NS>(q, ns, 2 * KM + j - 1);
-        const float g = ((j == idx) ? L_dk : 0.f) + ((j == idx + 1) ? L_dk1 : 0.f);
-        dq[(2 * KM + j - 1) >> 4][ns][(2 * KM + j - 1) & 15] = g * sf_sigmoid(raw);
-      }
+      if (j < K)
+        dq[(2 * KM + j - 1) >> 4][ns][(2 * KM + j - 1) & 15] = ((j == idx) ? g_k : 0.f) + ((j == idx + 1) ? g_k1 : 0.f);
   }
 };
 

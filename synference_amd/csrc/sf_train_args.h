@@ -19,4 +19,17 @@ struct SfTrainArgs {
   int det;           //   det == 1: one replica per 32-sample tile, plain stores -> bitwise reproducible gradients
   float4* act;       // activation stash
   long act_per_wave; // float4 per wave
+#ifdef SF_TRAIN_TRACE
+  unsigned long long* trace;  // developer build only: [2 waves][128] time stamps of one workgroup (scripts/train_trace.sh)
+#endif
 };
+
+#ifdef SF_TRAIN_TRACE
+#define SF_TR(slot)                                                                                                   \
+  do {                                                                                                                \
+    if (a.trace && blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0)                                            \
+      a.trace[(threadIdx.x >> 6) * 128 + (slot)] = __builtin_readcyclecounter();                                      \
+  } while (0)
+#else
+#define SF_TR(slot) do { } while (0)
+#endif

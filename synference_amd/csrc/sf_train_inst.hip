@@ -1,5 +1,6 @@
 // sf_train_inst.hip -- one translation unit per SF_HT: instantiates the training kernels.
 #include "sf_train_kernels.h"
+#include <cstdio>
 
 #ifndef SF_HT
 #error "compile with -DSF_HT=1..4"
@@ -22,6 +23,30 @@ hipError_t SF_CAT(sf_launch_maf_train_h, SF_HT)(const SfDev& m, const SfTrainArg
     if (e != hipSuccess) return e;
     attr.set(attr_dev);
   }
+#ifdef SF_TRAIN_TRACE
+  {  // developer build: time stamps of the middle workgroup, printed as microsecond deltas (100 MHz counter)
+    static unsigned long long* d_tr = nullptr;
+    if (!d_tr && hipMalloc(&d_tr, 256 * 8) != hipSuccess) return hipErrorOutOfMemory;
+    (void)hipMemsetAsync(d_tr, 0, 256 * 8, st);
+    SfTrainArgs b = a;
+    b.trace = d_tr;
+    hipLaunchKernelGGL((k_maf_train<SF_HT>), dim3((unsigned)grid), dim3(128), shmem, st, m, b);
+    (void)hipStreamSynchronize(st);
+    unsigned long long h[256];
+    (void)hipMemcpy(h, d_tr, sizeof(h), hipMemcpyDeviceToHost);
+    static int calls = 0;
+    if (++calls % 8 == 0) {
+      fprintf(stderr, "[train trace] B=%ld grid=%ld\n", a.B, grid);
+      for (int w = 0; w < 2; ++w) {
+        fprintf(stderr, "  wave %d:", w);
+        for (int i = 0; i < 128; ++i)
+          if (h[w * 128 + i]) fprintf(stderr, " %d:%.2f", i, (double)(h[w * 128 + i] - h[0]) * 0.01);
+        fprintf(stderr, "\n");
+      }
+    }
+    return hipGetLastError();
+  }
+#endif
   hipLaunchKernelGGL((k_maf_train<SF_HT>), dim3((unsigned)grid), dim3(128), shmem, st, m, a);
   return hipGetLastError();
 }

@@ -80,11 +80,13 @@ __device__ __forceinline__ void sf_grad_stop(SfGradPipe& P, int lane) {
 }
 
 // the consumer wave: runs until the stop descriptor
-__device__ __forceinline__ void sf_grad_consumer(float* __restrict__ lds, int stride, int lane) {
+__device__ __forceinline__ void sf_grad_consumer(float* __restrict__ lds, int stride, int lane, const SfTrainArgs& a) {
   const int c = lane & 31, h = lane >> 5;
   const int rd = c * 33 + h;
   for (int i = 0;; ++i) {
+    SF_TR(2 * (i < 60 ? i : 60) + 1);
     __syncthreads();
+    SF_TR(2 * (i < 60 ? i : 60) + 2);
     const float* buf = lds + (i & 1) * stride;
     const int* d = reinterpret_cast<const int*>(buf);
     if (__builtin_amdgcn_readfirstlane(d[5])) break;
@@ -222,8 +224,9 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, 
   const long base = wid * 32;
   if (base >= a.B) return;
   SfGradPipe lds = {lds_all, SF_JOB_HDR + (2 * HT) * SF_TL, 0};
+  SF_TR(0);
   if (wave == 1) {
-    sf_grad_consumer(lds_all, lds.stride, lane);
+    sf_grad_consumer(lds_all, lds.stride, lane, a);
     return;
   }
   // gradient-image replica of this XCD: f32 atomics from different XCDs then never meet on an address
@@ -252,6 +255,7 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, 
     }
   }
   using Ops = MafOps<HT, 1>;
+  SF_TR(1);
 
   // ------------------------------------------------------------------ forward (with stash)
   for (int t = 0; t < m0.T; ++t) {
@@ -303,6 +307,7 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, 
       }
     }
     logdet[0] += ld + sf_xhalf(ld);
+    SF_TR(2 + t);
   }
   float G[SF_DMAX];  // dL/d(output of the current transform), replicated in both halves
   const float w = valid ? (a.wts ? a.w * a.wts[row] : a.w) : 0.f;
@@ -347,6 +352,7 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, 
     f32x16 fin[1][1];
     sf_init_bias<1, 1>(fin, tp + m.o_bf, h);
     sf_mm_acc<1, 1, HT, false, false, true>(fin, ak, tp + m.o_wf, m.nGh, 0, m.nGh, lane);
+    SF_TR(20 + 10 * (m0.T - 1 - t) + 0);
     f32x16 dfin[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) dfin[0][0][r] = 0.f;
@@ -369,13 +375,16 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, 
       }
     }
     // head: dWf, dbf ; delta_h = Wf^T dfin
+    SF_TR(20 + 10 * (m0.T - 1 - t) + 1);
     sf_grad_w<1, HT>(lds, dfin, ak, gp + m.o_wf, gp + m.o_bf, m.nGh, 0, m.nGh, lane);
+    SF_TR(20 + 10 * (m0.T - 1 - t) + 2);
     f32x16 dh[HT][1];
 #pragma unroll
     for (int mt = 0; mt < HT; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dh[mt][0][r] = 0.f;
     sf_mm_acc<HT, 1, 1, false, false, true>(dh, dfin, tpT + m.oT_wf, m.nGf, 0, m.nGf, lane);
+    SF_TR(20 + 10 * (m0.T - 1 - t) + 3);
 #pragma unroll
     for (int kk = 0; kk < SF_NBMAX; ++kk) {
       const int k = SF_NBMAX - 1 - kk;
@@ -389,11 +398,13 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, 
         for (int mt = 0; mt < HT; ++mt) sf_stash_load(stash, t * TPT + 1 + k * HT + mt, ak[mt][0], lane);
         sf_grad_w<HT, HT>(lds, dpre, ak, gp + m.o_wk[k], gp + m.o_bk[k], m.nGh, 0, m.nGh, lane,
                           SfKLim{{m.mt_kend[0], m.mt_kend[1], m.mt_kend[2], m.mt_kend[3]}});
+        SF_TR(20 + 10 * (m0.T - 1 - t) + 4 + 2 * kk);
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) dh[mt][0][r] = 0.f;
         sf_mm_acc<HT, 1, HT, false, false, true>(dh, dpre, tpT + m.oT_wk[k], m.nGh, 0, m.nGh, lane);
+        SF_TR(20 + 10 * (m0.T - 1 - t) + 5 + 2 * kk);
       }
     }
     // initial layer: dW0 (u tile), dWc (context tiles), d(b0+bc)
@@ -408,6 +419,7 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, 
       else sf_build_ctx_tile<1>(ct, xr, m, kt, h);
       sf_grad_w<HT, 1>(lds, dh, ct, gp + m.o_wc, nullptr, m.nGc, kt * 4, min(4, m.nGc - kt * 4), lane);
     }
+    SF_TR(20 + 10 * (m0.T - 1 - t) + 8);
     if (a.dctx) sf_ctx_grad<HT>(m, dh, tpT + m.oT_wc, a.dctx + ii * m.C, valid, lane);
     // delta_u = W0^T delta_h0
     f32x16 du[1][1];
@@ -422,8 +434,10 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, 
         G[p] = Gd[p] + ((h == ((p >> 2) & 1)) ? v : oth);
       }
     }
+    SF_TR(20 + 10 * (m0.T - 1 - t) + 9);
   }
   sf_grad_stop(lds, lane);
+  SF_TR(8);
 }
 
 
@@ -453,7 +467,7 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_nsf_train(SfDev m0, 
   if (base >= a.B) return;
   SfGradPipe lds = {lds_all, SF_JOB_HDR + SfNsfLds<HT, PT>::tiles * SF_TL, 0};
   if (wave == 1) {
-    sf_grad_consumer(lds_all, lds.stride, lane);
+    sf_grad_consumer(lds_all, lds.stride, lane, a);
     return;
   }
   // gradient-image replica of this XCD: f32 atomics from different XCDs then never meet on an address
