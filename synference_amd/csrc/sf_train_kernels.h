@@ -6,13 +6,25 @@
 #include "sf_internal.h"
 #include "sf_train_args.h"
 
-#define SF_TL 1056  // floats per transposed tile in LDS: 32 rows x 33
+// Transposed tile in LDS: 32 rows x 36 floats; sample s of a row sits at (s & 1) * 16 + (s >> 1), so that the 16 values an
+// MFMA lane needs over the 16 k-steps (samples 2k + h) are contiguous: four ds_read_b128 instead of 16 ds_read_b32.
+#define SF_TLR 36
+#define SF_TL (32 * SF_TLR)
 
 
 template <bool RELU = false>
 __device__ __forceinline__ void sf_tile_to_lds(float* __restrict__ dst, const f32x16& t, int c, int h) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) dst[sf_row(r, h) * 33 + c] = RELU ? fmaxf(t[r], 0.f) : t[r];
+  for (int r = 0; r < 16; ++r) dst[sf_row(r, h) * SF_TLR + (c & 1) * 16 + (c >> 1)] = RELU ? fmaxf(t[r], 0.f) : t[r];
+}
+// the 16 k-step operands of lane (c, h) from a transposed tile
+__device__ __forceinline__ void sf_tile_row16(const float* __restrict__ tile, int c, int h, float (&v)[16]) {
+  const float4* p = reinterpret_cast<const float4*>(tile + c * SF_TLR + h * 16);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 t = p[q];
+    v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+  }
 }
 __device__ __forceinline__ void sf_stash_store(float4* __restrict__ base, int tile, const f32x16& t, int lane) {
 #pragma unroll
@@ -26,6 +38,19 @@ __device__ __forceinline__ void sf_stash_load(const float4* __restrict__ base, i
     t[4 * q] = v.x; t[4 * q + 1] = v.y; t[4 * q + 2] = v.z; t[4 * q + 3] = v.w;
   }
 }
+
+// Wave-private staging of an operand image into LDS (direct global -> LDS loads, no registers): only the producer wave
+// reads weights, so no workgroup barrier is involved -- the wave waits for its own loads and goes on.  With the
+// operands in LDS a layer no longer starts with an L2 round trip (1-2 k cycles each, twelve per transform and
+// direction), and the wave's outstanding stash stores no longer sit in front of weight loads in the vmcnt queue.
+__device__ __forceinline__ void sf_wave_stage(const float* __restrict__ src, float* __restrict__ lds, int nfloats, int lane) {
+  const float4* __restrict__ s4 = reinterpret_cast<const float4*>(src);
+  float4* __restrict__ d4 = reinterpret_cast<float4*>(lds);
+  const int n4 = nfloats >> 2;
+  for (int i = lane; i < n4; i += 64)
+    __builtin_amdgcn_global_load_lds((const void*)(s4 + i), (void __attribute__((address_space(3)))*)(d4 + (i - lane)), 16, 0, 0);
+}
+__device__ __forceinline__ void sf_wave_stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---------------------------------------------------------------------------------------------
 // Weight gradients: producer / consumer wave pair.
@@ -82,7 +107,6 @@ __device__ __forceinline__ void sf_grad_stop(SfGradPipe& P, int lane) {
 // the consumer wave: runs until the stop descriptor
 __device__ __forceinline__ void sf_grad_consumer(float* __restrict__ lds, int stride, int lane, const SfTrainArgs& a) {
   const int c = lane & 31, h = lane >> 5;
-  const int rd = c * 33 + h;
   for (int i = 0;; ++i) {
     SF_TR(2 * (i < 60 ? i : 60) + 1);
     __syncthreads();
@@ -101,22 +125,23 @@ __device__ __forceinline__ void sf_grad_consumer(float* __restrict__ lds, int st
     const float* tiles = buf + SF_JOB_HDR;
     for (int mt = 0; mt < OT; ++mt) {
       float bsum = 0.f;
-      const float* ld = tiles + (IT + mt) * SF_TL + rd;
+      float bv[16];
+      sf_tile_row16(tiles + (IT + mt) * SF_TL, c, h, bv);
+      if (gb) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) bsum += bv[k];
+      }
       // groups past the limit are structurally masked weights (block-triangular MADE layers): no gradient needed
       const int ngm = min(ng, __builtin_amdgcn_readfirstlane(d[10 + mt]) - kg0);
       for (int kt = 0; kt < IT; ++kt) {
-        if (kt * 4 < ngm || (kt == 0 && gb)) {
-          const float* li = tiles + kt * SF_TL + rd;
+        if (kt * 4 < ngm) {
+          float av[16];
+          sf_tile_row16(tiles + kt * SF_TL, c, h, av);
           f32x16 acc;
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-          for (int k = 0; k < 16; ++k) {
-            const float a = li[2 * k];
-            const float b = ld[2 * k];
-            if (kt == 0) bsum += b;
-            acc = SF_MFMA(a, b, acc);
-          }
+          for (int k = 0; k < 16; ++k) acc = SF_MFMA(av[k], bv[k], acc);
 #pragma unroll
           for (int g = 0; g < 4; ++g)
             if (kt * 4 + g < ngm) {
@@ -159,25 +184,23 @@ __device__ __forceinline__ void sf_grad_w_local(float* __restrict__ lds, const f
   for (int mt = 0; mt < OT; ++mt) sf_tile_to_lds<false>(lds + (IT + mt) * SF_TL, delta[mt][0], c, h);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  const int rd = c * 33 + h;
 #pragma unroll
   for (int mt = 0; mt < OT; ++mt) {
     float bsum = 0.f;
-    const float* ld = lds + (IT + mt) * SF_TL + rd;
+    float bv[16];
+    sf_tile_row16(lds + (IT + mt) * SF_TL, c, h, bv);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) bsum += bv[k];
 #pragma unroll
     for (int kt = 0; kt < IT; ++kt) {
       if (kt * 4 < ng) {
-        const float* li = lds + kt * SF_TL + rd;
+        float av[16];
+        sf_tile_row16(lds + kt * SF_TL, c, h, av);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const float a = li[2 * k];
-          const float b = ld[2 * k];
-          if (kt == 0) bsum += b;
-          acc = SF_MFMA(a, b, acc);
-        }
+        for (int k = 0; k < 16; ++k) acc = SF_MFMA(av[k], bv[k], acc);
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           if (kt * 4 + g < ng) {
@@ -214,7 +237,9 @@ __device__ __forceinline__ void sf_ctx_grad(const SfDev& m, const f32x16 (&delta
   }
 }
 
-template <int HT>
+// LDSW: the producer keeps the operand image of the current transform (forward: [0, o_hv); backward: the transposed
+// image up to the context block) in LDS behind the two job buffers.
+template <int HT, bool LDSW>
 __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, SfTrainArgs a) {
   const SfDev& m = m0;
   extern __shared__ float lds_all[];
@@ -236,6 +261,7 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, 
   lds.det = a.det;
   float4* stash = a.act + wid * a.act_per_wave;
   const int TPT = (m.NB + 1) * HT + 1;  // stash tiles per transform: u, h0, a_1..a_NB
+  float* wlds = lds_all + 2 * lds.stride;  // LDSW: operand image of the current transform
 
   const long row = base + c;
   const bool valid = row < a.B;
@@ -261,12 +287,17 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, 
   for (int t = 0; t < m0.T; ++t) {
     const SfDev m = sf_iter_view(m0);  // loop bounds opaque per iteration: predicates are not hoisted and spilled
     const float* tp = m.packed + (size_t)t * m.t_stride;
+    if (LDSW) {
+      sf_wave_stage(tp, wlds, m.o_hv, lane);
+      tp = wlds;
+    }
     {
       f32x16 ut;
 #pragma unroll
       for (int p = 0; p < SF_DMAX; ++p) ut[p] = u[0][p];
       sf_stash_store(stash, t * TPT, ut, lane);
     }
+    if (LDSW) sf_wave_stage_wait();
     f32x16 act[HT][1];
     sf_init_bias<HT, 1>(act, tp + m.o_b0, h);
     {
@@ -336,7 +367,12 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, 
   for (int t = m0.T - 1; t >= 0; --t) {
     const SfDev m = sf_iter_view(m0);
     const float* tp = m.packed + (size_t)t * m.t_stride;
-    const float* tpT = m.packedT + (size_t)t * m.tT_stride;
+    const float* tpTg = m.packedT + (size_t)t * m.tT_stride;
+    const float* tpT = tpTg;
+    if (LDSW) {  // in flight behind the stash loads and the head recomputation (which reads its operands from L2)
+      sf_wave_stage(tpTg, wlds, m.oT_wc, lane);
+      tpT = wlds;
+    }
     float* gp = gimg_x + (size_t)t * m.t_stride;
     float uin[1][SF_DMAX];
     {
@@ -383,6 +419,7 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, 
     for (int mt = 0; mt < HT; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dh[mt][0][r] = 0.f;
+    if (LDSW) sf_wave_stage_wait();
     sf_mm_acc<HT, 1, 1, false, false, true>(dh, dfin, tpT + m.oT_wf, m.nGf, 0, m.nGf, lane);
     SF_TR(20 + 10 * (m0.T - 1 - t) + 3);
 #pragma unroll
@@ -420,7 +457,7 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, 
       sf_grad_w<HT, 1>(lds, dh, ct, gp + m.o_wc, nullptr, m.nGc, kt * 4, min(4, m.nGc - kt * 4), lane);
     }
     SF_TR(20 + 10 * (m0.T - 1 - t) + 8);
-    if (a.dctx) sf_ctx_grad<HT>(m, dh, tpT + m.oT_wc, a.dctx + ii * m.C, valid, lane);
+    if (a.dctx) sf_ctx_grad<HT>(m, dh, tpTg + m.oT_wc, a.dctx + ii * m.C, valid, lane);
     // delta_u = W0^T delta_h0
     f32x16 du[1][1];
 #pragma unroll
