@@ -57,28 +57,6 @@ WORKLOADS = {
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA (= vector) dense peak
 
 
-def executed_mfma_flops_per_eval(d):
-    """FLOPs the sampler kernel issues on the MFMA pipe per flow evaluation (dense padded tiles)."""
-    D, T, NB, HT = d["D"], d["T"], d["NB"], d["HT"]
-    if d["kind"] == 1:  # NSF: conditioner + spline head per transform (context products come from the galaxy table)
-        steps = HT * d["nGu"] + NB * (2 * HT * d["nGh"])
-        d_tr = [(D - (t & 1) + 1) // 2 for t in range(T)]
-        heads = sum(((dt + 1) // 2) * d["PT"] * d["nGh"] for dt in d_tr)
-        return (T * steps + heads) * 4 * (32 * 32 * 2) * 2 / 32.0
-    if d.get("m16_ok") and not d["hidden_bf16"]:
-        # 16-row incremental inverse (sf_maf16.hip): per pass p>=2 one 16-row tile of every layer:
-        # 4 MFMAs for W0 u, 4 per input tile <= the pass's tile per hidden block; 16x16x4 MACs x 2 / 16 draws
-        lo = d.get("g16_lo", d["g16_tile"])   # groups that straddle tiles recompute every tile they touch
-        n = sum((d["g16_tile"][p - 1] - lo[p - 1] + 1) * (4 + NB * 4 * (d["g16_tile"][p - 1] + 1)) for p in range(2, D + 1))
-        return T * n * (16 * 16 * 4) * 2 / 16.0
-    if d["inc_ok"] and NB <= 2:
-        steps = HT * d["nGc"]                                           # hoisted context product
-        steps += sum(d["nGu"] + NB * d["g_kend"][p - 1] for p in range(2, D + 1))   # one hidden tile per pass
-    else:
-        steps = D * (HT * (d["nGu"] + d["nGc"]) + NB * sum(d["mt_kend"][:HT]) + d["nGh"])
-    return T * steps * 4 * (32 * 32 * 2) * 2 / 32.0
-
-
 def pmc_traffic(tag):
     """HBM bytes per launch from the newest committed rocprofv3 PMC summary (profiles/rNN_pmc_summary.json) collected
     with this command; None when there is none for this kernel."""
@@ -90,6 +68,9 @@ def pmc_traffic(tag):
         d = json.load(fh)
     if tag == "sample":
         return d.get("hbm_bytes_per_launch"), os.path.basename(files[-1])
+    if tag == "sample_busy":   # issue-slot occupancy of the sampler kernel (SQ counters of the same summary)
+        keys = ("mfma_busy_frac", "valu_busy_frac", "wait_frac_of_wave_cycles")
+        return ({k: d[k] for k in keys if k in d} or None), os.path.basename(files[-1])
     return d.get("train", {}).get("hbm_bytes_per_launch"), os.path.basename(files[-1])
 
 
@@ -403,9 +384,10 @@ def main():
     evals_per_launch = evals[0] / float(a.steps)
     f_min = wl["f_lp"] if wl["kind"] == "maf" else wl["f_draw"]   # one conditioner evaluation per transform
     useful = f_min * accepted_per_launch / (k_ms * 1e-3) / 1e12
-    executed = executed_mfma_flops_per_eval(desc) * evals_per_launch / (k_ms * 1e-3) / 1e12
     contract = wl["f_draw"] * accepted_per_launch / (k_ms * 1e-3) / 1e12
-    traffic, traffic_src = pmc_traffic("sample") if a.workload == "maf_cfg2" and M == 2000 and S == 1000 else (None, None)
+    default_wl = a.workload == "maf_cfg2" and M == 2000 and S == 1000
+    traffic, traffic_src = pmc_traffic("sample") if default_wl else (None, None)
+    busy, _ = pmc_traffic("sample_busy") if default_wl else (None, None)
 
     note(f"sampling done: {1e3 * t_samp / a.steps:.3f} ms/step, kernel {k_ms:.3f} ms, unfilled {unfilled_all}")
     # ---------------- train leg: fwd+bwd (+ all-reduce) + clip + Adam at the per-GPU batch
@@ -516,11 +498,11 @@ def main():
                      "note": "achieved = USEFUL work / measured kernel time: mask-aware FLOPs of ONE conditioner evaluation per "
                              "transform (SURVEY 8d; MAF cfg1 40030 FLOP/draw -- the least any algorithm needs; the "
                              "reference's D-pass inverse spends 175150) x ACCEPTED draws; rejected evaluations, tile "
-                             "padding and the per-galaxy context kernel are overhead.  executed_mfma_* = dense padded "
-                             "MFMA FLOPs the kernel issued over ALL evaluations; contract_* = SURVEY 8d's figure for the "
-                             "reference algorithm x accepted draws (an algorithmic ratio, can exceed 1).",
-                     "executed_mfma_flop_per_eval": executed_mfma_flops_per_eval(desc), "executed_mfma_tflops": executed,
-                     "executed_mfma_frac": executed / PEAK_FP32_TFLOPS,
+                             "padding and the per-galaxy context kernel are overhead.  issue_busy = SQ counters "
+                             "of the committed PMC summary (the hidden blocks run as three bf16 MFMAs, so MFMA FLOPs are no "
+                             "longer comparable with the fp32 peak; what binds is VALU issue + latency); contract_* = SURVEY "
+                             "8d's figure for the reference algorithm x accepted draws (an algorithmic ratio, can exceed 1).",
+                     "issue_busy": busy,
                      "contract_tflops": contract, "contract_ratio": contract / PEAK_FP32_TFLOPS},
         "roofline_train": {"bound": "mfma", "kernel": "k_maf_train<HT>" if wl["kind"] == "maf" else "k_nsf_train<HT,PT>",
                            "achieved": train_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
