@@ -171,7 +171,7 @@ int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen) {
   add("o16_wk1", v.o16_wk[1]); add("o16_bk0", v.o16_bk[0]); add("o16_bk1", v.o16_bk[1]); add("o16_hv", v.o16_hv);
   add("o16_hvb", v.o16_hvb);
   add("t16_a", v.t16_a); add("t16B_stride", v.t16B_stride); add("nP16", v.nP16); add("o16B_wk0", v.o16B_wk[0]); add("o16B_wk1", v.o16B_wk[1]);
-  add("m16_ok", v.m16_ok); add("nT16", v.nT16); add("nC16", v.nC16); add("t16_stride", v.t16_stride);
+  add("m16_ok", v.m16_ok); add("m16_span", v.m16_span); add("nT16", v.nT16); add("nC16", v.nC16); add("t16_stride", v.t16_stride);
   s += "\"g16_tile\": [";
   for (int i = 0; i < SF_DMAX; ++i) s += std::to_string(v.g16_tile[i]) + (i + 1 < SF_DMAX ? ", " : "], ");
   s += "\"g16_lo\": [";

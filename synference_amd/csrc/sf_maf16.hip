@@ -399,8 +399,11 @@ __device__ __forceinline__ f32x4 sf_mma16x3(const u32x4& w_hi, const u32x4& w_lo
   return acc;
 }
 // fragment of block k: (out tile ot, in-tile pair pr, part 0 = hi / 1 = lo); wB = base of the block in 32-bit words
+// CP: aligned placement stores only the pairs a tile can read (sf_layout.cpp): entry ot + (ot == 3) + pr
+template <bool CP>
 __device__ __forceinline__ u32x4 sf_w16b(const unsigned int* wB, int NP, int ot, int pr, int part, int lane) {
-  return reinterpret_cast<const u32x4*>(wB)[((ot * NP + pr) * 2 + part) * 64 + lane];
+  const int e = CP ? ot + (ot == 3 ? 1 : 0) + pr : ot * NP + pr;
+  return reinterpret_cast<const u32x4*>(wB)[(e * 2 + part) * 64 + lane];
 }
 
 struct SfPass16B {
@@ -441,7 +444,7 @@ __device__ __forceinline__ void sf_put16b(SfPass16B& S, int k, const f32x4& v) {
 }
 
 // One autoregressive pass with the degree group in (static) tile OT (see sf_pass16); hidden blocks on split bf16.
-template <int OT, int NB>
+template <int OT, int NB, bool CP>
 __device__ __forceinline__ void sf_pass16b(const SfDev& m, const float* tp, const unsigned int* tpB, SfPass16B& S, int NT, int sl,
                                            float u_sl, int lane, int g4) {
   constexpr int PR = OT >> 1;  // the pair that holds tile OT; pairs below it are complete
@@ -463,7 +466,7 @@ __device__ __forceinline__ void sf_pass16b(const SfDev& m, const float* tp, cons
     // never read (OT even)
 #pragma unroll
     for (int pr = 0; pr <= PR; ++pr)
-      b = sf_mma16x3(sf_w16b(tpB + m.o16B_wk[k], NP, OT, pr, 0, lane), sf_w16b(tpB + m.o16B_wk[k], NP, OT, pr, 1, lane),
+      b = sf_mma16x3(sf_w16b<CP>(tpB + m.o16B_wk[k], NP, OT, pr, 0, lane), sf_w16b<CP>(tpB + m.o16B_wk[k], NP, OT, pr, 1, lane),
                      S.ph[k][pr], S.pl[k][pr], b);
     f32x4 th;
 #pragma unroll
@@ -504,7 +507,7 @@ __device__ __forceinline__ void sf_pass16b_span(const SfDev& m, const float* tp,
       f32x4 b = sf_ld4(tp + m.o16_bk[k] + (ot * 4 + g4) * 4);
 #pragma unroll
       for (int pr = 0; pr <= PH; ++pr)
-        b = sf_mma16x3(sf_w16b(tpB + m.o16B_wk[k], NP, ot, pr, 0, lane), sf_w16b(tpB + m.o16B_wk[k], NP, ot, pr, 1, lane),
+        b = sf_mma16x3(sf_w16b<false>(tpB + m.o16B_wk[k], NP, ot, pr, 0, lane), sf_w16b<false>(tpB + m.o16B_wk[k], NP, ot, pr, 1, lane),
                        S.ph[k][pr], S.pl[k][pr], b);
 #pragma unroll
       for (int r = 0; r < 4; ++r) nb[ot - LO][r] = sf_tanh(b[r]);
@@ -543,7 +546,7 @@ struct SfSamp16Args {
 };
 
 template <int NB, bool SPAN>
-__global__ __launch_bounds__(256, 3) void k_maf_samp16(SfSamp16Args args_in) {
+__global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args args_in) {
   const int wave = threadIdx.x >> 6;
   unsigned int* ctrl = reinterpret_cast<unsigned int*>(sf_lds16 + args_in.m.t16_a + args_in.m.t16B_stride);
   unsigned int pf;
@@ -659,10 +662,10 @@ __global__ __launch_bounds__(256, 3) void k_maf_samp16(SfSamp16Args args_in) {
         const uint32_t hi_t = (tile_bits >> (2 * (p - 1))) & 3u;
         const uint32_t lo_t = SPAN ? (lo_bits >> (2 * (p - 1))) & 3u : hi_t;
         switch (lo_t * 4 + hi_t) {
-          case 0: sf_pass16b<0, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
-          case 5: sf_pass16b<1, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
-          case 10: sf_pass16b<2, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
-          case 15: sf_pass16b<3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+          case 0: sf_pass16b<0, NB, !SPAN>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+          case 5: sf_pass16b<1, NB, !SPAN>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+          case 10: sf_pass16b<2, NB, !SPAN>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+          case 15: sf_pass16b<3, NB, !SPAN>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
           case 1: if (SPAN) sf_pass16b_span<0, 1, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
           case 2: if (SPAN) sf_pass16b_span<0, 2, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
           case 3: if (SPAN) sf_pass16b_span<0, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
@@ -819,15 +822,16 @@ bool sf_maf16_enabled(const SfDev& m, const SfSampleArgsHost& a) {
          (a.attempts_per_slot <= 16 || a.best != nullptr);  // (find mode has no in-tile attempt groups)
 }
 
-// workgroups that fit the chip at once (persistent launches): 3 per CU by registers and LDS
-static int sf_resident_blocks16(const void* fn, size_t sh) {
-  int dev = 0, cus = 256, per = 3;
+// workgroups that fit the chip at once (persistent launches): `cap` per CU by registers and LDS (4 with the compact
+// image of the aligned placement at 128 VGPRs, 3 for the contiguous one)
+static int sf_resident_blocks16(const void* fn, size_t sh, int cap) {
+  int dev = 0, cus = 256, per = cap;
   if (hipGetDevice(&dev) == hipSuccess) {
     hipDeviceProp_t pr;
     if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
   }
   int occ = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, sh) == hipSuccess && occ > 0) per = occ < 3 ? occ : 3;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, 256, sh) == hipSuccess && occ > 0) per = occ < cap ? occ : cap;
   return cus * per;
 }
 
@@ -843,7 +847,7 @@ static hipError_t sf_launch16(const SfDev& m, const SfSampleArgsHost& a, hipStre
       if (e != hipSuccess) return e;
       attr.set(attr_dev);
     }
-    if (!resident) resident = sf_resident_blocks16((const void*)k_maf_samp16<NB, SPAN>, sh);
+    if (!resident) resident = sf_resident_blocks16((const void*)k_maf_samp16<NB, SPAN>, sh, SPAN ? 3 : 4);
     long grid = (a.n_items + 63) / 64;
     if (grid > resident) grid = resident;
     SfSamp16Args args;
