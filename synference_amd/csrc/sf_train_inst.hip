@@ -14,33 +14,34 @@ static hipError_t set_shmem(K kernel, size_t bytes) {
   return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <bool LDSW>
+template <int NBUF, int NC, int DM>
 static hipError_t launch_maf(const SfDev& m, const SfTrainArgs& a, size_t shmem, hipStream_t st) {
-  const long grid = (a.B + 31) / 32;  // one workgroup (producer + consumer wave) per 32-sample tile
+  const long grid = (a.B + 31) / 32;  // one workgroup (producer + consumer waves) per 32-sample tile
   static SfAttrCache attr;
   static size_t attr_bytes = 0;
   int attr_dev;
   if (attr.need(attr_dev) || shmem > attr_bytes) {
-    hipError_t e = set_shmem(k_maf_train<SF_HT, LDSW>, shmem);
+    hipError_t e = set_shmem(k_maf_train<SF_HT, NBUF, NC, DM>, shmem);
     if (e != hipSuccess) return e;
     attr.set(attr_dev);
     attr_bytes = shmem;
   }
+  const dim3 block(64 * (1 + NC));
 #ifdef SF_TRAIN_TRACE
   {  // developer build: time stamps of the middle workgroup, printed in units of 100 shader cycles
     static unsigned long long* d_tr = nullptr;
-    if (!d_tr && hipMalloc(&d_tr, 256 * 8) != hipSuccess) return hipErrorOutOfMemory;
-    (void)hipMemsetAsync(d_tr, 0, 256 * 8, st);
+    if (!d_tr && hipMalloc(&d_tr, 384 * 8) != hipSuccess) return hipErrorOutOfMemory;
+    (void)hipMemsetAsync(d_tr, 0, 384 * 8, st);
     SfTrainArgs b = a;
     b.trace = d_tr;
-    hipLaunchKernelGGL((k_maf_train<SF_HT, LDSW>), dim3((unsigned)grid), dim3(128), shmem, st, m, b);
+    hipLaunchKernelGGL((k_maf_train<SF_HT, NBUF, NC, DM>), dim3((unsigned)grid), block, shmem, st, m, b);
     (void)hipStreamSynchronize(st);
-    unsigned long long h[256];
+    unsigned long long h[384];
     (void)hipMemcpy(h, d_tr, sizeof(h), hipMemcpyDeviceToHost);
     static int calls = 0;
     if (++calls % 8 == 0) {
-      fprintf(stderr, "[train trace] B=%ld grid=%ld ldsw=%d shmem=%zu\n", a.B, grid, (int)LDSW, shmem);
-      for (int w = 0; w < 2; ++w) {
+      fprintf(stderr, "[train trace] B=%ld grid=%ld nbuf=%d nc=%d shmem=%zu\n", a.B, grid, NBUF, NC, shmem);
+      for (int w = 0; w < 1 + NC; ++w) {
         fprintf(stderr, "  wave %d:", w);
         for (int i = 0; i < 128; ++i)
           if (h[w * 128 + i]) fprintf(stderr, " %d:%.2f", i, (double)(long long)(h[w * 128 + i] - h[0]) * 0.01);
@@ -50,29 +51,30 @@ static hipError_t launch_maf(const SfDev& m, const SfTrainArgs& a, size_t shmem,
     return hipGetLastError();
   }
 #endif
-  hipLaunchKernelGGL((k_maf_train<SF_HT, LDSW>), dim3((unsigned)grid), dim3(128), shmem, st, m, a);
+  hipLaunchKernelGGL((k_maf_train<SF_HT, NBUF, NC, DM>), dim3((unsigned)grid), block, shmem, st, m, a);
   return hipGetLastError();
 }
 
 hipError_t SF_CAT(sf_launch_maf_train_h, SF_HT)(const SfDev& m, const SfTrainArgs& a, hipStream_t st) {
-  const size_t pipe = (size_t)2 * (SF_JOB_HDR + (2 * SF_HT) * SF_TL) * sizeof(float);
-  // Operands of one transform in LDS (forward image without the sampler-only head rows, transposed image without the
-  // context block) when two workgroups still fit a CU (80 KiB each) AND the whole batch is resident at that
-  // occupancy (512 tiles = batch 16 384): measured 3 % at batch 64 and 2 % at 16 384 (the forward sweep of a
-  // transform 24.0 -> 21.6 k cycles); at 65 536 rows the halved occupancy costs 8 %, so larger batches keep streaming
-  // operands from L2 with four workgroups per CU.
-  const size_t wimg = (size_t)(m.o_hv > m.oT_wc ? m.o_hv : m.oT_wc) * sizeof(float);
-  static int use_lds = -1;
-  if (use_lds < 0) { const char* e = std::getenv("SF_TRAIN_LDSW"); use_lds = e ? std::atoi(e) : 1; }
-  if (use_lds && (a.B + 31) / 32 <= 512 && (m.o_hv & 3) == 0 && (m.oT_wc & 3) == 0 && pipe + wimg <= (size_t)80 * 1024)
-    return launch_maf<true>(m, a, pipe + wimg, st);
-  return launch_maf<false>(m, a, pipe, st);
+  const size_t buf = (size_t)(SF_JOB_HDR + (2 * SF_HT) * SF_TL) * sizeof(float), ctl = SF_PIPE_CTL * sizeof(int);
+  const long tiles = (a.B + 31) / 32;
+  static int two = -1;  // SF_TRAIN_CONSUMERS=1 keeps one consumer / two buffers at every batch size
+  if (two < 0) { const char* e = std::getenv("SF_TRAIN_CONSUMERS"); two = e ? (std::atoi(e) >= 2) : 1; }
+  // While the whole batch is resident with two workgroups per CU (512 tiles = batch 16 384) LDS is plentiful: four job
+  // buffers and TWO consumer waves, so that the producer never waits at a hand-over (with one consumer and two buffers
+  // it stalled at every job: the consumer is busy 75 % of the backward sweep).  Measured: 182 -> 172 us at batch
+  // 16 384; the sweep is then bound by the producer's own chain.  Larger batches keep two buffers and one consumer:
+  // four workgroups per CU matter more there (65 536 rows: 562 vs 577 us).
+  const bool d8 = m.D <= 8;  // (every BASELINE shape; D up to 16 runs the same code with longer theta loops)
+  if (two && tiles <= 512 && ctl + 4 * buf <= (size_t)80 * 1024)
+    return d8 ? launch_maf<4, 2, 8>(m, a, ctl + 4 * buf, st) : launch_maf<4, 2, SF_DMAX>(m, a, ctl + 4 * buf, st);
+  return d8 ? launch_maf<2, 1, 8>(m, a, ctl + 2 * buf, st) : launch_maf<2, 1, SF_DMAX>(m, a, ctl + 2 * buf, st);
 }
 
 template <int PT>
 static hipError_t launch_nsf(const SfDev& m, const SfTrainArgs& a, hipStream_t st) {
   const long grid = (a.B + 31) / 32;
-  const size_t shmem = (size_t)2 * (SF_JOB_HDR + SfNsfLds<SF_HT, PT>::tiles * SF_TL) * sizeof(float);
+  const size_t shmem = SF_PIPE_CTL * sizeof(int) + (size_t)2 * (SF_JOB_HDR + SfNsfLds<SF_HT, PT>::tiles * SF_TL) * sizeof(float);
   static SfAttrCache attr;
   int attr_dev;
   if (attr.need(attr_dev)) {

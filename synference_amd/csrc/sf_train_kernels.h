@@ -39,47 +39,63 @@ __device__ __forceinline__ void sf_stash_load(const float4* __restrict__ base, i
   }
 }
 
-// Wave-private staging of an operand image into LDS (direct global -> LDS loads, no registers): only the producer wave
-// reads weights, so no workgroup barrier is involved -- the wave waits for its own loads and goes on.  With the
-// operands in LDS a layer no longer starts with an L2 round trip (1-2 k cycles each, twelve per transform and
-// direction), and the wave's outstanding stash stores no longer sit in front of weight loads in the vmcnt queue.
-__device__ __forceinline__ void sf_wave_stage(const float* __restrict__ src, float* __restrict__ lds, int nfloats, int lane) {
-  const float4* __restrict__ s4 = reinterpret_cast<const float4*>(src);
-  float4* __restrict__ d4 = reinterpret_cast<float4*>(lds);
-  const int n4 = nfloats >> 2;
-  for (int i = lane; i < n4; i += 64)
-    __builtin_amdgcn_global_load_lds((const void*)(s4 + i), (void __attribute__((address_space(3)))*)(d4 + (i - lane)), 16, 0, 0);
-}
-__device__ __forceinline__ void sf_wave_stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
 // ---------------------------------------------------------------------------------------------
-// Weight gradients: producer / consumer wave pair.
+// Weight gradients: one producer wave, NC consumer waves.
 //   gw block [mt][kg][j][lane] += sum_s in[i][s] * delta[o][s]
-// A workgroup is TWO waves that own one 32-sample tile.  Wave 0 (producer) runs forward + backward; whenever a
-// layer's delta tile is ready it drops (in tiles, delta tiles, job descriptor) transposed into one of two LDS
-// buffers and passes a workgroup barrier.  Wave 1 (consumer) sits in a loop: barrier, read the descriptor, do the
-// MFMAs over the 32 samples and the f32 atomics into the gradient image.  The consumer interprets descriptors, so
-// the two waves cannot disagree on the job sequence; the producer ends with a stop descriptor.  Effect: the ~50 %
-// of a tile's MFMA work that is weight gradients leaves the latency chain of the data path and runs on another
-// SIMD (the waves of a workgroup are spread over the SIMDs of a CU).
-//   barrier protocol: job i lives in buffer i&1; the producer arrives at barrier i after writing it, the consumer
-//   arrives at barrier i before reading it, hence at barrier i+1 only after finishing job i -- which is what the
-//   producer waits for before it may overwrite buffer i&1 with job i+2.
+// A workgroup owns one 32-sample tile.  Wave 0 (producer) runs forward + backward; whenever a layer's delta tile is
+// ready it drops (in tiles, delta tiles, job descriptor) transposed into the next of NBUF LDS buffers.  Waves 1..NC
+// (consumers; job i belongs to consumer i % NC) read the descriptor, do the MFMAs over the 32 samples and the f32
+// atomics into the gradient image.  The consumers interpret descriptors, so the waves cannot disagree on the job
+// sequence; the producer ends with one stop descriptor per consumer.  Effect: the ~50 % of a tile's MFMA work that
+// is weight gradients leaves the latency chain of the data path and runs on other SIMDs (the waves of a workgroup
+// are spread over the SIMDs of a CU).
+//   hand-over: two sequence words per buffer in LDS -- ready[b] = i + 1 once job i is complete in buffer b (release
+//   store after the wave's LDS writes), done[b] = i + 1 once its consumer has read everything it needs; the producer
+//   re-uses buffer b for job i + NBUF after done[b] == i + 1.  No workgroup barrier: round 1's two-buffer barrier
+//   protocol made the producer wait at EVERY job for the consumer to finish the job before last (the consumer is
+//   busy 75 % of the backward sweep), and with a barrier a second consumer cannot work across hand-overs.
 // ---------------------------------------------------------------------------------------------
 #define SF_JOB_HDR 16  // floats reserved for the descriptor in front of the tiles
+#define SF_PIPE_CTL 32  // ints in front of the buffers: ready[0..7], done[8..15]
 struct SfGradPipe {
-  float* lds;   // two buffers of `stride` floats
+  float* lds;   // NBUF buffers of `stride` floats (behind the control words)
   int stride;
   int i;
   int det;      // 1: the consumer stores into this tile's own replica instead of atomically adding to a shared one
+  int* ctl;
 };
+// The sequence words and the data they guard are all LDS, and a wave's LDS instructions are executed in order: the
+// hand-over needs "my LDS accesses are done" (s_waitcnt lgkmcnt(0)) and compiler barriers, NOT a workgroup-scope
+// fence -- that one would also wait for the consumer's outstanding global atomics (vmcnt(0), microseconds).
+__device__ __forceinline__ int sf_pipe_load(const int* p) {
+  const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+  return v;
+}
+__device__ __forceinline__ void sf_pipe_store(int* p, int v, bool writer) {  // called by the whole wave; `writer` lane stores
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (writer) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// producer: buffer of job P.i, free to be written
+template <int NBUF>
+__device__ __forceinline__ float* sf_pipe_acquire(SfGradPipe& P) {
+  const int b = P.i & (NBUF - 1);
+  if (P.i >= NBUF)
+    while (sf_pipe_load(P.ctl + 8 + b) != P.i - NBUF + 1) __builtin_amdgcn_s_sleep(1);
+  return P.lds + b * P.stride;
+}
+template <int NBUF>
+__device__ __forceinline__ void sf_pipe_publish(SfGradPipe& P, int lane) {
+  sf_pipe_store(P.ctl + (P.i & (NBUF - 1)), P.i + 1, lane == 0);
+  ++P.i;
+}
 
-template <int OT, int IT, bool RELU_IN = false>
+template <int NBUF, int OT, int IT, bool RELU_IN = false>
 __device__ __forceinline__ void sf_grad_w(SfGradPipe& P, const f32x16 (&delta)[OT][1], const f32x16 (&in)[IT][1],
                                           float* __restrict__ gw, float* __restrict__ gb, int nGtot, int kg0, int ng,
                                           int lane, SfKLim lim = SfKLim{{1 << 20, 1 << 20, 1 << 20, 1 << 20}}) {
   const int c = lane & 31, h = lane >> 5;
-  float* buf = P.lds + (P.i & 1) * P.stride;
+  float* buf = sf_pipe_acquire<NBUF>(P);
   float* tiles = buf + SF_JOB_HDR;
 #pragma unroll
   for (int kt = 0; kt < IT; ++kt) sf_tile_to_lds<RELU_IN>(tiles + kt * SF_TL, in[kt][0], c, h);
@@ -94,24 +110,30 @@ __device__ __forceinline__ void sf_grad_w(SfGradPipe& P, const f32x16 (&delta)[O
     d[10] = lim.v[0]; d[11] = lim.v[1]; d[12] = lim.v[2]; d[13] = lim.v[3];  // per-output-tile group limit (masked layers)
     d[14] = P.det;
   }
-  __syncthreads();
-  ++P.i;
+  sf_pipe_publish<NBUF>(P, lane);
 }
 
+template <int NBUF, int NC>
 __device__ __forceinline__ void sf_grad_stop(SfGradPipe& P, int lane) {
-  if (lane == 0) reinterpret_cast<int*>(P.lds + (P.i & 1) * P.stride)[5] = 1;
-  __syncthreads();
-  ++P.i;
+#pragma unroll
+  for (int q = 0; q < NC; ++q) {  // consecutive jobs go to different consumers: one stop descriptor each
+    float* buf = sf_pipe_acquire<NBUF>(P);
+    if (lane == 0) reinterpret_cast<int*>(buf)[5] = 1;
+    sf_pipe_publish<NBUF>(P, lane);
+  }
 }
 
 // the consumer wave: runs until the stop descriptor
-__device__ __forceinline__ void sf_grad_consumer(float* __restrict__ lds, int stride, int lane, const SfTrainArgs& a) {
+template <int NBUF, int NC>
+__device__ __forceinline__ void sf_grad_consumer(float* __restrict__ lds, int* __restrict__ ctl, int stride, int lane, int me,
+                                                 const SfTrainArgs& a) {
   const int c = lane & 31, h = lane >> 5;
-  for (int i = 0;; ++i) {
+  for (int i = me;; i += NC) {
+    const int bsel = i & (NBUF - 1);
     SF_TR(2 * (i < 60 ? i : 60) + 1);
-    __syncthreads();
+    while (sf_pipe_load(ctl + bsel) != i + 1) __builtin_amdgcn_s_sleep(1);
     SF_TR(2 * (i < 60 ? i : 60) + 2);
-    const float* buf = lds + (i & 1) * stride;
+    const float* buf = lds + bsel * stride;
     const int* d = reinterpret_cast<const int*>(buf);
     if (__builtin_amdgcn_readfirstlane(d[5])) break;
     const int OT = __builtin_amdgcn_readfirstlane(d[0]), IT = __builtin_amdgcn_readfirstlane(d[1]);
@@ -165,6 +187,7 @@ __device__ __forceinline__ void sf_grad_consumer(float* __restrict__ lds, int st
         }
       }
     }
+    sf_pipe_store(ctl + 8 + bsel, i + 1, lane == 0);  // every operand of the job has been read: the buffer is free
   }
 }
 
@@ -237,10 +260,9 @@ __device__ __forceinline__ void sf_ctx_grad(const SfDev& m, const f32x16 (&delta
   }
 }
 
-// LDSW: the producer keeps the operand image of the current transform (forward: [0, o_hv); backward: the transposed
-// image up to the context block) in LDS behind the two job buffers.
-template <int HT, bool LDSW>
-__global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, SfTrainArgs a) {
+// DM: static bound of the theta loops (8 when D <= 8: the upper half of the u / G register arrays is then dead)
+template <int HT, int NBUF, int NC, int DM>
+__global__ __launch_bounds__(64 * (1 + NC), (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, SfTrainArgs a) {
   const SfDev& m = m0;
   extern __shared__ float lds_all[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -248,10 +270,13 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, 
   const long wid = (long)blockIdx.x;  // one 32-sample tile per workgroup: wave 0 producer, wave 1 weight-gradient consumer
   const long base = wid * 32;
   if (base >= a.B) return;
-  SfGradPipe lds = {lds_all, SF_JOB_HDR + (2 * HT) * SF_TL, 0};
+  int* ctl = reinterpret_cast<int*>(lds_all);
+  SfGradPipe lds = {lds_all + SF_PIPE_CTL, SF_JOB_HDR + (2 * HT) * SF_TL, 0, 0, ctl};
+  if (threadIdx.x < SF_PIPE_CTL) ctl[threadIdx.x] = 0;
+  __syncthreads();  // (the only workgroup barrier of the kernel)
   SF_TR(0);
-  if (wave == 1) {
-    sf_grad_consumer(lds_all, lds.stride, lane, a);
+  if (wave >= 1) {
+    sf_grad_consumer<NBUF, NC>(lds.lds, ctl, lds.stride, lane, wave - 1, a);
     return;
   }
   // gradient-image replica of this XCD: f32 atomics from different XCDs then never meet on an address
@@ -261,7 +286,6 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, 
   lds.det = a.det;
   float4* stash = a.act + wid * a.act_per_wave;
   const int TPT = (m.NB + 1) * HT + 1;  // stash tiles per transform: u, h0, a_1..a_NB
-  float* wlds = lds_all + 2 * lds.stride;  // LDSW: operand image of the current transform
 
   const long row = base + c;
   const bool valid = row < a.B;
@@ -273,7 +297,9 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, 
   float u[1][SF_DMAX];
   float logdet[1] = {m.logdet0};
 #pragma unroll
-  for (int p = 0; p < SF_DMAX; ++p) {
+  for (int p = DM; p < SF_DMAX; ++p) u[0][p] = 0.f;
+#pragma unroll
+  for (int p = 0; p < DM; ++p) {
     u[0][p] = 0.f;
     if (p < m.D) {
       const int td = (int)m.cst[m.c_tdim + p];
@@ -287,17 +313,12 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, 
   for (int t = 0; t < m0.T; ++t) {
     const SfDev m = sf_iter_view(m0);  // loop bounds opaque per iteration: predicates are not hoisted and spilled
     const float* tp = m.packed + (size_t)t * m.t_stride;
-    if (LDSW) {
-      sf_wave_stage(tp, wlds, m.o_hv, lane);
-      tp = wlds;
-    }
     {
       f32x16 ut;
 #pragma unroll
-      for (int p = 0; p < SF_DMAX; ++p) ut[p] = u[0][p];
+      for (int p = 0; p < DM; ++p) ut[p] = u[0][p];
       sf_stash_store(stash, t * TPT, ut, lane);
     }
-    if (LDSW) sf_wave_stage_wait();
     f32x16 act[HT][1];
     sf_init_bias<HT, 1>(act, tp + m.o_b0, h);
     {
@@ -327,7 +348,7 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, 
     sf_mm_acc<1, 1, HT, false, false, true>(fin, act, tp + m.o_wf, m.nGh, 0, m.nGh, lane);
     float ld = 0.f;
 #pragma unroll
-    for (int p = 0; p < SF_DMAX; ++p) {
+    for (int p = 0; p < DM; ++p) {
       if (p < m.D) {
         const float s = Ops::scale(m, fin[0][0][2 * (p >> 1)]);
         const float val = s * u[0][p] + fin[0][0][2 * (p >> 1) + 1];
@@ -345,7 +366,7 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, 
   {
     float ss = 0.f;
 #pragma unroll
-    for (int p = 0; p < SF_DMAX; ++p) {
+    for (int p = 0; p < DM; ++p) {
       G[p] = 0.f;
       if (p < m.D) {
         ss += u[0][p] * u[0][p];
@@ -364,37 +385,42 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, 
   }
 
   // ------------------------------------------------------------------ backward
+  // Activations come back from the stash one layer AHEAD of their use: a_j lives in register set (NB - j) & 1, so the
+  // load of a layer's input is issued while the previous layer's data-gradient MFMAs run, and the first two loads of a
+  // transform (a_NB and u) are issued before the last product of the transform above it.  (An HBM / L2 round trip per
+  // layer used to sit in the dependent chain: four per transform.)
+  f32x16 aset[2][HT][1];
+  f32x16 utile;
+  {
+    const int t = m0.T - 1;
+#pragma unroll
+    for (int mt = 0; mt < HT; ++mt) sf_stash_load(stash, t * TPT + 1 + m.NB * HT + mt, aset[0][mt][0], lane);
+    sf_stash_load(stash, t * TPT, utile, lane);
+  }
   for (int t = m0.T - 1; t >= 0; --t) {
     const SfDev m = sf_iter_view(m0);
     const float* tp = m.packed + (size_t)t * m.t_stride;
-    const float* tpTg = m.packedT + (size_t)t * m.tT_stride;
-    const float* tpT = tpTg;
-    if (LDSW) {  // in flight behind the stash loads and the head recomputation (which reads its operands from L2)
-      sf_wave_stage(tpTg, wlds, m.oT_wc, lane);
-      tpT = wlds;
-    }
+    const float* tpT = m.packedT + (size_t)t * m.tT_stride;
     float* gp = gimg_x + (size_t)t * m.t_stride;
     float uin[1][SF_DMAX];
-    {
-      f32x16 ut;
-      sf_stash_load(stash, t * TPT, ut, lane);
 #pragma unroll
-      for (int p = 0; p < SF_DMAX; ++p) uin[0][p] = ut[p];
+    for (int p = 0; p < SF_DMAX; ++p) uin[0][p] = p < DM ? utile[p] : 0.f;
+    // input of the top block, needed after the head: in flight behind the head recomputation
+    if (m.NB >= 1) {
+#pragma unroll
+      for (int mt = 0; mt < HT; ++mt) sf_stash_load(stash, t * TPT + 1 + (m.NB - 1) * HT + mt, aset[1][mt][0], lane);
     }
-    f32x16 ak[HT][1];  // activation feeding the layer whose gradient is being formed
-#pragma unroll
-    for (int mt = 0; mt < HT; ++mt) sf_stash_load(stash, t * TPT + 1 + m.NB * HT + mt, ak[mt][0], lane);
     // recompute the head
     f32x16 fin[1][1];
     sf_init_bias<1, 1>(fin, tp + m.o_bf, h);
-    sf_mm_acc<1, 1, HT, false, false, true>(fin, ak, tp + m.o_wf, m.nGh, 0, m.nGh, lane);
+    sf_mm_acc<1, 1, HT, false, false, true>(fin, aset[0], tp + m.o_wf, m.nGh, 0, m.nGh, lane);
     SF_TR(20 + 10 * (m0.T - 1 - t) + 0);
     f32x16 dfin[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) dfin[0][0][r] = 0.f;
     float Gd[SF_DMAX];
 #pragma unroll
-    for (int p = 0; p < SF_DMAX; ++p) {
+    for (int p = 0; p < DM; ++p) {
       Gd[p] = 0.f;
       if (p < m.D) {
         const float av = fin[0][0][2 * (p >> 1)];
@@ -412,59 +438,78 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, 
     }
     // head: dWf, dbf ; delta_h = Wf^T dfin
     SF_TR(20 + 10 * (m0.T - 1 - t) + 1);
-    sf_grad_w<1, HT>(lds, dfin, ak, gp + m.o_wf, gp + m.o_bf, m.nGh, 0, m.nGh, lane);
+    sf_grad_w<NBUF, 1, HT>(lds, dfin, aset[0], gp + m.o_wf, gp + m.o_bf, m.nGh, 0, m.nGh, lane);
     SF_TR(20 + 10 * (m0.T - 1 - t) + 2);
     f32x16 dh[HT][1];
 #pragma unroll
     for (int mt = 0; mt < HT; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dh[mt][0][r] = 0.f;
-    if (LDSW) sf_wave_stage_wait();
     sf_mm_acc<HT, 1, 1, false, false, true>(dh, dfin, tpT + m.oT_wf, m.nGf, 0, m.nGf, lane);
     SF_TR(20 + 10 * (m0.T - 1 - t) + 3);
 #pragma unroll
-    for (int kk = 0; kk < SF_NBMAX; ++kk) {
-      const int k = SF_NBMAX - 1 - kk;
-      if (k < m.NB) {
+    for (int d = 0; d < SF_NBMAX; ++d) {  // d = distance from the top block: block k = NB - 1 - d
+      if (d < m.NB) {
+        const int k = m.NB - 1 - d;
+        // the descriptor arrays are indexed with select chains (a dynamic index would put the descriptor in scratch)
+        int o_wk = m.o_wk[0], o_bk = m.o_bk[0], oT_wk = m.oT_wk[0];
+#pragma unroll
+        for (int q = 1; q < SF_NBMAX; ++q) {
+          o_wk = (k == q) ? m.o_wk[q] : o_wk;
+          o_bk = (k == q) ? m.o_bk[q] : o_bk;
+          oT_wk = (k == q) ? m.oT_wk[q] : oT_wk;
+        }
+        f32x16 (&aout)[HT][1] = aset[d & 1];       // a_{k+1}: output of block k
+        f32x16 (&ain)[HT][1] = aset[(d + 1) & 1];  // a_k: its input (loaded one step ago)
         f32x16 dpre[HT][1];
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) dpre[mt][0][r] = dh[mt][0][r] * (1.0f - ak[mt][0][r] * ak[mt][0][r]);
+          for (int r = 0; r < 16; ++r) dpre[mt][0][r] = dh[mt][0][r] * (1.0f - aout[mt][0][r] * aout[mt][0][r]);
+        sf_grad_w<NBUF, HT, HT>(lds, dpre, ain, gp + o_wk, gp + o_bk, m.nGh, 0, m.nGh, lane,
+                                SfKLim{{m.mt_kend[0], m.mt_kend[1], m.mt_kend[2], m.mt_kend[3]}});
+        // a_{k+1} is dead now: its registers take the input of the block below (or, after the bottom block, the top
+        // activation of the next transform), in flight during this block's data-gradient product
+        if (k >= 1) {
 #pragma unroll
-        for (int mt = 0; mt < HT; ++mt) sf_stash_load(stash, t * TPT + 1 + k * HT + mt, ak[mt][0], lane);
-        sf_grad_w<HT, HT>(lds, dpre, ak, gp + m.o_wk[k], gp + m.o_bk[k], m.nGh, 0, m.nGh, lane,
-                          SfKLim{{m.mt_kend[0], m.mt_kend[1], m.mt_kend[2], m.mt_kend[3]}});
-        SF_TR(20 + 10 * (m0.T - 1 - t) + 4 + 2 * kk);
+          for (int mt = 0; mt < HT; ++mt) sf_stash_load(stash, t * TPT + 1 + (k - 1) * HT + mt, aout[mt][0], lane);
+        }
+        SF_TR(20 + 10 * (m0.T - 1 - t) + 4);
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) dh[mt][0][r] = 0.f;
-        sf_mm_acc<HT, 1, HT, false, false, true>(dh, dpre, tpT + m.oT_wk[k], m.nGh, 0, m.nGh, lane);
-        SF_TR(20 + 10 * (m0.T - 1 - t) + 5 + 2 * kk);
+        sf_mm_acc<HT, 1, HT, false, false, true>(dh, dpre, tpT + oT_wk, m.nGh, 0, m.nGh, lane);
+        SF_TR(20 + 10 * (m0.T - 1 - t) + 5);
       }
     }
     // initial layer: dW0 (u tile), dWc (context tiles), d(b0+bc)
     {
       f32x16 ut[1][1];
       sf_build_u_tile<1>(ut, uin, h);
-      sf_grad_w<HT, 1>(lds, dh, ut, gp + m.o_w0, gp + m.o_b0, m.nGu, 0, m.nGu, lane);
+      sf_grad_w<NBUF, HT, 1>(lds, dh, ut, gp + m.o_w0, gp + m.o_b0, m.nGu, 0, m.nGu, lane);
     }
     for (int kt = 0; kt * 4 < m.nGc; ++kt) {
       f32x16 ct[1][1];
       if (kt == 0) ct[0][0] = ct0[0][0];
       else sf_build_ctx_tile<1>(ct, xr, m, kt, h);
-      sf_grad_w<HT, 1>(lds, dh, ct, gp + m.o_wc, nullptr, m.nGc, kt * 4, min(4, m.nGc - kt * 4), lane);
+      sf_grad_w<NBUF, HT, 1>(lds, dh, ct, gp + m.o_wc, nullptr, m.nGc, kt * 4, min(4, m.nGc - kt * 4), lane);
+    }
+    // first loads of the transform above: in flight during the last products of this one
+    if (t >= 1) {
+#pragma unroll
+      for (int mt = 0; mt < HT; ++mt) sf_stash_load(stash, (t - 1) * TPT + 1 + m.NB * HT + mt, aset[0][mt][0], lane);
+      sf_stash_load(stash, (t - 1) * TPT, utile, lane);
     }
     SF_TR(20 + 10 * (m0.T - 1 - t) + 8);
-    if (a.dctx) sf_ctx_grad<HT>(m, dh, tpTg + m.oT_wc, a.dctx + ii * m.C, valid, lane);
+    if (a.dctx) sf_ctx_grad<HT>(m, dh, tpT + m.oT_wc, a.dctx + ii * m.C, valid, lane);
     // delta_u = W0^T delta_h0
     f32x16 du[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) du[0][0][r] = 0.f;
     sf_mm_acc<1, 1, HT, false, false, true>(du, dh, tpT + m.oT_w0, m.nGh, 0, m.nGh, lane);
 #pragma unroll
-    for (int p = 0; p < SF_DMAX; ++p) {
+    for (int p = 0; p < DM; ++p) {
       if (p < m.D) {
         const float v = du[0][0][(p & 3) + 4 * (p >> 3)];
         const float oth = sf_xhalf(v);
@@ -473,7 +518,7 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_maf_train(SfDev m0, 
     }
     SF_TR(20 + 10 * (m0.T - 1 - t) + 9);
   }
-  sf_grad_stop(lds, lane);
+  sf_grad_stop<NBUF, NC>(lds, lane);
   SF_TR(8);
 }
 
@@ -502,9 +547,13 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_nsf_train(SfDev m0, 
   const long wid = (long)blockIdx.x;  // one 32-sample tile per workgroup: wave 0 producer, wave 1 weight-gradient consumer
   const long base = wid * 32;
   if (base >= a.B) return;
-  SfGradPipe lds = {lds_all, SF_JOB_HDR + SfNsfLds<HT, PT>::tiles * SF_TL, 0};
-  if (wave == 1) {
-    sf_grad_consumer(lds_all, lds.stride, lane, a);
+  constexpr int NBUF = 2, NC = 1;
+  int* ctl = reinterpret_cast<int*>(lds_all);
+  SfGradPipe lds = {lds_all + SF_PIPE_CTL, SF_JOB_HDR + SfNsfLds<HT, PT>::tiles * SF_TL, 0, 0, ctl};
+  if (threadIdx.x < SF_PIPE_CTL) ctl[threadIdx.x] = 0;
+  __syncthreads();
+  if (wave >= 1) {
+    sf_grad_consumer<NBUF, NC>(lds.lds, ctl, lds.stride, lane, wave - 1, a);
     return;
   }
   // gradient-image replica of this XCD: f32 atomics from different XCDs then never meet on an address
@@ -730,7 +779,7 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_nsf_train(SfDev m0, 
           G[p] = (have && p == tgt) ? dv : G[p];
           G[p] = (have_o && p == tgt_o) ? dvo : G[p];
         }
-        sf_grad_w<PT, HT>(lds, dq, hN, gp + m.o_wout + jp * PT * m.nGh * 256, gp + m.o_bout + jp * PT * 32,
+        sf_grad_w<NBUF, PT, HT>(lds, dq, hN, gp + m.o_wout + jp * PT * m.nGh * 256, gp + m.o_bout + jp * PT * 32,
                           m.nGh, 0, m.nGh, lane);
         sf_mm_acc<HT, 1, PT, false, false, true>(dh, dq, tpT + m.oT_wout + jp * HT * (PT * 4) * 256, PT * 4, 0, PT * 4, lane);
       }
@@ -762,7 +811,7 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_nsf_train(SfDev m0, 
             f32x16 ct[1][1];
             if (kt == 0) ct[0][0] = ct0[0][0];
             else sf_build_ctx_tile<1>(ct, xr, m, kt, h);
-            sf_grad_w<HT, 1>(lds, dgate, ct, gp + m.o_wg[k], kt == 0 ? gp + m.o_bg[k] : nullptr, m.nGc, kt * 4,
+            sf_grad_w<NBUF, HT, 1>(lds, dgate, ct, gp + m.o_wg[k], kt == 0 ? gp + m.o_bg[k] : nullptr, m.nGc, kt * 4,
                              min(4, m.nGc - kt * 4), lane);
           }
           if (a.dctx) sf_ctx_grad<HT>(m, dgate, tpT + m.oT_wg[k], a.dctx + ii * m.C, valid, lane);
@@ -770,7 +819,7 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_nsf_train(SfDev m0, 
         f32x16 t1[HT][1];
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt) sf_stash_load(stash, bb + mt, t1[mt][0], lane);
-        sf_grad_w<HT, HT, true>(lds, dt2, t1, gp + m.o_w2[k], gp + m.o_b2[k], m.nGh, 0, m.nGh, lane);
+        sf_grad_w<NBUF, HT, HT, true>(lds, dt2, t1, gp + m.o_w2[k], gp + m.o_b2[k], m.nGh, 0, m.nGh, lane);
         f32x16 dt1[HT][1];
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt)
@@ -786,7 +835,7 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_nsf_train(SfDev m0, 
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt)
           sf_stash_load(stash, k == 0 ? sb + 1 + mt : sb + 1 + HT + (k - 1) * 3 * HT + 2 * HT + mt, hk[mt][0], lane);
-        sf_grad_w<HT, HT, true>(lds, dt1, hk, gp + m.o_w1[k], gp + m.o_b1[k], m.nGh, 0, m.nGh, lane);
+        sf_grad_w<NBUF, HT, HT, true>(lds, dt1, hk, gp + m.o_w1[k], gp + m.o_b1[k], m.nGh, 0, m.nGh, lane);
         f32x16 dr0[HT][1];
 #pragma unroll
         for (int mt = 0; mt < HT; ++mt)
@@ -803,13 +852,13 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_nsf_train(SfDev m0, 
     {
       f32x16 ut[1][1];
       sf_build_u_tile<1>(ut, uin, h);
-      sf_grad_w<HT, 1>(lds, dh, ut, gp + m.o_winu, gp + m.o_bin, m.nGu, 0, m.nGu, lane);
+      sf_grad_w<NBUF, HT, 1>(lds, dh, ut, gp + m.o_winu, gp + m.o_bin, m.nGu, 0, m.nGu, lane);
     }
     for (int kt = 0; kt * 4 < m.nGc; ++kt) {
       f32x16 ct[1][1];
       if (kt == 0) ct[0][0] = ct0[0][0];
       else sf_build_ctx_tile<1>(ct, xr, m, kt, h);
-      sf_grad_w<HT, 1>(lds, dh, ct, gp + m.o_winc, nullptr, m.nGc, kt * 4, min(4, m.nGc - kt * 4), lane);
+      sf_grad_w<NBUF, HT, 1>(lds, dh, ct, gp + m.o_winc, nullptr, m.nGc, kt * 4, min(4, m.nGc - kt * 4), lane);
     }
     if (a.dctx) sf_ctx_grad<HT>(m, dh, tpT + m.oT_wc, a.dctx + ii * m.C, valid, lane);
     f32x16 du[1][1];
@@ -825,5 +874,5 @@ __global__ __launch_bounds__(128, (HT <= 2 ? 2 : 1)) void k_nsf_train(SfDev m0, 
       }
     }
   }
-  sf_grad_stop(lds, lane);
+  sf_grad_stop<NBUF, NC>(lds, lane);
 }
