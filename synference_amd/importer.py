@@ -12,7 +12,7 @@ Module paths follow pyknos-nflows 0.14 / sbi 0.22-0.23 (SURVEY.md Appendix B.1-B
     [net.]_transform._transforms.0._shift / ._scale                      z-score of theta (AffineTransform)
     [net.]_embedding_net.0._mean / ._std                                 z-score of x (Standardize)
   MAF, block i = 2t (transform) and 2t+1 (permutation) of  _transform._transforms.1._transforms:
-    .{2t}.autoregressive_net.initial_layer.{weight,bias}                 W0, b0          (mask: buffer, ignored)
+    .{2t}.autoregressive_net.initial_layer.{weight,bias}                 W0, b0          (+ .mask buffers, see below)
     .{2t}.autoregressive_net.context_layer.{weight,bias}                 Wc, bc
     .{2t}.autoregressive_net.blocks.{k}.linear.{weight,bias}             W{k+1}, b{k+1}
     .{2t}.autoregressive_net.final_layer.{weight,bias}                   Wf, bf
@@ -23,6 +23,12 @@ Module paths follow pyknos-nflows 0.14 / sbi 0.22-0.23 (SURVEY.md Appendix B.1-B
     .{2t}.transform_net.blocks.{k}.linear_layers.{0,1}.{weight,bias}     W1, b1, W2, b2
     .{2t}.transform_net.final_layer.{weight,bias}                        Wout, bout
     .{2t+1}.{lower_entries,upper_entries,unconstrained_upper_diag,bias}  lu.*
+
+nflows keeps its MADE masks (``*.mask``) and the coupling split (``transform_features`` / ``identity_features``) as
+BUFFERS, so a real checkpoint carries upstream's own connectivity.  The importer compares them with the connectivity
+this engine builds from (D, H) alone -- degrees ``j % max(1, D-1) + min(1, D-1)``, ``>=`` in hidden layers, strict at
+the output, even dimensions transformed by even coupling blocks -- and raises ``ValueError`` on the first difference:
+a checkpoint cannot be imported into a flow that would wire it differently.
 
 Names are matched by SUFFIX after the transform index, so wrapper prefixes of other sbi versions
 (``net.``, ``_neural_net.``, ``posterior_estimator.``) do not matter.  Anything that cannot be mapped raises
@@ -65,6 +71,50 @@ def _blocks(sd: Dict[str, np.ndarray]) -> Dict[int, Dict[str, np.ndarray]]:
         if m and not (not inner and m.group(2) in ("_shift", "_scale")):
             out.setdefault(int(m.group(1)), {})[m.group(2)] = v
     return out
+
+
+def made_masks(D: int, H: int):
+    """(M0 [H, D], Mh [H, H], Mf [2D, H]) boolean MADE masks of this engine (sf_layout.cpp; [UPSTREAM] nflows
+    MaskedLinear._get_mask_and_degrees with sequential degrees and output multiplier 2)."""
+    mx, mn = max(1, D - 1), min(1, D - 1)
+    deg_in = np.arange(1, D + 1)
+    deg_h = np.arange(H) % mx + mn
+    M0 = deg_h[:, None] >= deg_in[None, :]
+    Mh = deg_h[:, None] >= deg_h[None, :]
+    deg_out = np.repeat(deg_in, 2)                 # rows (a_0, m_0, a_1, m_1, ...)
+    Mf = deg_out[:, None] > deg_h[None, :]
+    return M0, Mh, Mf
+
+
+def _check_connectivity(kind: str, D: int, H: int, NB: int, blocks, tidx) -> int:
+    """Compare upstream's connectivity buffers, where the state dict has them, with this engine's; returns how many
+    buffers were checked."""
+    n = 0
+    if kind == "maf":
+        M0, Mh, Mf = made_masks(D, H)
+        want = {"autoregressive_net.initial_layer.mask": M0, "autoregressive_net.final_layer.mask": Mf}
+        for k in range(NB):
+            want[f"autoregressive_net.blocks.{k}.linear.mask"] = Mh
+        for t, i in enumerate(tidx):
+            for key, ours in want.items():
+                got = blocks[i].get(key)
+                if got is None:
+                    continue
+                n += 1
+                if got.shape != ours.shape or not np.array_equal(got != 0, ours):
+                    raise ValueError(f"transform {t}: upstream '{key}' differs from this engine's MADE mask "
+                                     f"({int(((got != 0) != ours).sum()) if got.shape == ours.shape else 'shape'} entries): "
+                                     "the checkpoint was built with a different degree assignment")
+    else:
+        for t, i in enumerate(tidx):
+            ours_tr = np.arange(D)[np.arange(D) % 2 == t % 2]     # even dims in even blocks (sbi: mask = alternating +-1)
+            got = blocks[i].get("transform_features")
+            if got is not None:
+                n += 1
+                if not np.array_equal(np.sort(got.reshape(-1)), ours_tr):
+                    raise ValueError(f"coupling block {t}: upstream transforms dimensions {got.reshape(-1).tolist()}, this engine "
+                                     f"{ours_tr.tolist()}")
+    return n
 
 
 def spec_and_flat_from_state_dict(state_dict: Mapping[str, object], num_bins: Optional[int] = None,
@@ -115,6 +165,7 @@ def spec_and_flat_from_state_dict(state_dict: Mapping[str, object], num_bins: Op
             names[f"W{k + 1}"] = f"autoregressive_net.blocks.{k}.linear.weight"
             names[f"b{k + 1}"] = f"autoregressive_net.blocks.{k}.linear.bias"
         src = {t: (blocks[i], names) for t, i in enumerate(tidx)}
+        _check_connectivity("maf", D, H, NB, blocks, tidx)
     else:
         tidx = sorted(i for i, b in blocks.items() if "transform_net.initial_layer.weight" in b)
         T = len(tidx)
@@ -146,6 +197,7 @@ def spec_and_flat_from_state_dict(state_dict: Mapping[str, object], num_bins: Op
             names[f"blk{k}.b1"] = f"transform_net.blocks.{k}.linear_layers.0.bias"
             names[f"blk{k}.W2"] = f"transform_net.blocks.{k}.linear_layers.1.weight"
             names[f"blk{k}.b2"] = f"transform_net.blocks.{k}.linear_layers.1.bias"
+        _check_connectivity("nsf", D, H, NB, blocks, tidx)
         lun = {"lu.lower": "lower_entries", "lu.upper": "upper_entries", "lu.udiag": "unconstrained_upper_diag",
                "lu.bias": "bias"}
         src = {}
@@ -208,6 +260,17 @@ def state_dict_from_flat(spec: FlowSpec, flat, prefix: str = "") -> Dict[str, np
         i = 2 * t + (1 if key.startswith("+") else 0)
         out[f"{p}1._transforms.{i}.{key.lstrip('+')}"] = flat[off:off + int(np.prod(shape))].reshape(shape).copy()
     if spec.kind == "maf":
+        M0, Mh, Mf = made_masks(spec.D, spec.H)
         for t in range(spec.T):
             out[f"{p}1._transforms.{2 * t + 1}._permutation"] = spec.perms[t].astype(np.int64)
+            q = f"{p}1._transforms.{2 * t}.autoregressive_net."
+            out[q + "initial_layer.mask"] = M0.astype(np.float32)
+            out[q + "final_layer.mask"] = Mf.astype(np.float32)
+            for k in range(spec.NB):
+                out[q + f"blocks.{k}.linear.mask"] = Mh.astype(np.float32)
+    else:
+        for t in range(spec.T):
+            d = np.arange(spec.D)
+            out[f"{p}1._transforms.{2 * t}.transform_features"] = d[d % 2 == t % 2].astype(np.int64)
+            out[f"{p}1._transforms.{2 * t}.identity_features"] = d[d % 2 != t % 2].astype(np.int64)
     return out

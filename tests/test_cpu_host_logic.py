@@ -356,9 +356,7 @@ def test_upstream_state_dict_importer_round_trip(kind, D, C, K, NB):
     s = FlowSpec(kind=kind, D=D, C=C, H=24, T=3, K=K, NB=NB, perms=perms, theta_mean=rng.normal(size=D),
                  theta_std=rng.uniform(0.5, 2, size=D), x_mean=rng.normal(size=C), x_std=rng.uniform(0.5, 2, size=C))
     flat = init_params(s, g).numpy() + 0.05 * rng.normal(size=num_params(s)).astype(np.float32)
-    sd = state_dict_from_flat(s, flat, prefix="posterior_estimator.net.")
-    if kind == "maf":   # buffers a real state dict carries besides the parameters
-        sd["posterior_estimator.net._transform._transforms.1._transforms.0.autoregressive_net.initial_layer.mask"] = np.ones((24, D))
+    sd = state_dict_from_flat(s, flat, prefix="posterior_estimator.net.")   # (with the connectivity buffers nflows stores)
     sd["posterior_estimator.net._distribution._log_z"] = np.zeros(1)
     s2, flat2 = spec_and_flat_from_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
     assert (s2.kind, s2.D, s2.C, s2.H, s2.T, s2.NB) == (kind, D, C, 24, 3, NB) and (kind == "maf" or s2.K == K)
@@ -370,3 +368,20 @@ def test_upstream_state_dict_importer_round_trip(kind, D, C, K, NB):
     with pytest.raises(KeyError, match="not found|expects"):
         bad = {k: v for k, v in sd.items() if not k.endswith("final_layer.bias")}
         spec_and_flat_from_state_dict(bad)
+    # upstream's own connectivity buffers are compared with the engine's: a checkpoint wired differently is refused
+    from oracle import flows as OF
+    if kind == "maf":
+        from synference_amd.importer import made_masks
+        for ours, ref in zip(made_masks(D, 24), OF.made_masks(D, 24)):
+            assert np.array_equal(ours, np.asarray(ref) != 0)           # importer's rule == the oracle's masks
+        key = "posterior_estimator.net._transform._transforms.1._transforms.2.autoregressive_net.blocks.0.linear.mask"
+        tampered = dict(sd)
+        tampered[key] = np.tril(np.ones((24, 24), np.float32))
+        with pytest.raises(ValueError, match="MADE mask"):
+            spec_and_flat_from_state_dict(tampered)
+    else:
+        key = "posterior_estimator.net._transform._transforms.1._transforms.0.transform_features"
+        tampered = dict(sd)
+        tampered[key] = np.arange(1, D, 2)
+        with pytest.raises(ValueError, match="transforms dimensions"):
+            spec_and_flat_from_state_dict(tampered)
