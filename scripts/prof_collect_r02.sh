@@ -22,9 +22,10 @@ with open(out + '/kernels.txt', 'w') as f:
     # the timed sampling steps are the launches over the full 2e6-slot catalogue; the 20 timed + 3 warm-up ones come first
     block(f, "sampler (persistent, one launch per bench step)", lambda r: 'k_maf_samp16' in r['Kernel_Name'])
     block(f, "context table", lambda r: 'ctab' in r['Kernel_Name'])
-    block(f, "train fwd+bwd at batch 16384", lambda r: 'k_maf_train' in r['Kernel_Name'] and int(r['Grid_Size_X']) == 512 * 128)
-    block(f, "train fwd+bwd at batch 2048 (warm-up fit)", lambda r: 'k_maf_train' in r['Kernel_Name'] and int(r['Grid_Size_X']) == 64 * 128)
-    block(f, "train fwd+bwd at batch 64", lambda r: 'k_maf_train' in r['Kernel_Name'] and int(r['Grid_Size_X']) == 2 * 128)
+    tiles = lambda r: int(r['Grid_Size_X']) // int(r['Workgroup_Size_X'])   # one workgroup (1 + NC waves) per 32-row tile
+    block(f, "train fwd+bwd at batch 16384", lambda r: 'k_maf_train' in r['Kernel_Name'] and tiles(r) == 512)
+    block(f, "train fwd+bwd at batch 2048 (warm-up fit)", lambda r: 'k_maf_train' in r['Kernel_Name'] and tiles(r) == 64)
+    block(f, "train fwd+bwd at batch 64", lambda r: 'k_maf_train' in r['Kernel_Name'] and tiles(r) == 2)
     block(f, "log_prob 200k rows", lambda r: 'k_logprob' in r['Kernel_Name'])
     block(f, "clip + Adam", lambda r: 'k_adam' in r['Kernel_Name'])
     block(f, "train prep (re-tile + zero)", lambda r: 'k_train_prep' in r['Kernel_Name'])
@@ -37,7 +38,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFM
 import csv, glob, sys
 allr = list(csv.DictReader(open(glob.glob(sys.argv[1] + '/*/*_counter_collection.csv')[0])))
 for tag, sel in (("sampler", lambda r: 'k_maf_samp16' in r['Kernel_Name']),
-                 ("train16384", lambda r: 'k_maf_train' in r['Kernel_Name'] and int(r['Grid_Size']) == 512 * 128)):
+                 ("train16384", lambda r: 'k_maf_train' in r['Kernel_Name'] and int(r['Grid_Size']) // int(r['Workgroup_Size']) == 512)):
     rows = [r for r in allr if sel(r)]
     if rows:
         w = csv.DictWriter(open(f"{sys.argv[2]}_{tag}.csv", 'w'), fieldnames=rows[0].keys()); w.writeheader(); w.writerows(rows)
