@@ -583,6 +583,9 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
 #endif
     const int wi = wave * 16 + s;
     const int NT = m.nT16;
+    // a wave whose 16 lanes hold no item (tail iterations with few entries) only takes part in the staging: its issue
+    // slots go to the other workgroups of the CU
+    const bool wave_has_work = (unsigned)(wave * 16) < (ctrl[0] << ctrl[1]);
     f32x4 u;
     const float* xr;
     const float* ctg;
@@ -647,6 +650,7 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
       S.xr = xr;
 #pragma unroll
       for (int r = 0; r < 4; ++r) S.ut[r] = 0.f;
+      if (!wave_has_work) continue;
       const int dsl = (int)m.cst[m.c_dslot + t * SF_DMAX + s];
       {
         const int sl = __builtin_amdgcn_readlane(dsl, 0);

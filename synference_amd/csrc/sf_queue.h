@@ -223,7 +223,20 @@ __device__ __forceinline__ bool sf_q_fetch(const Args& a, unsigned int* ctrl, un
           SF_QS_ADD(5, 1);                // donations
         }
       }
-      if (n) while ((2u << lg) * n <= (unsigned)IPW && (2u << lg) <= (unsigned)AMAX) ++lg;
+      if (n) {
+        // Speculation fills lanes that would idle, but the waves it keeps busy share their SIMDs with three other
+        // workgroups: entries that have only just been rejected (a first retry is accepted 9 times out of 10 on a
+        // trained posterior) get A = 2, and A grows with the attempt number the entries have reached.
+        unsigned int mn = 0xffffffffu;
+        for (unsigned int i = lane; i < n; i += 64) mn = w_att[i] < mn ? w_att[i] : mn;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const unsigned int ot = (unsigned int)__shfl_xor((int)mn, o, 64);
+          mn = ot < mn ? ot : mn;
+        }
+        const unsigned int amax_now = mn < 4u ? 2u : (mn < (unsigned)AMAX ? mn : (unsigned)AMAX);
+        while ((2u << lg) * n <= (unsigned)IPW && (2u << lg) <= amax_now) ++lg;
+      }
       if (lane == 0) ctrl[10] = nt;
     }
     if (lane == 0) {
