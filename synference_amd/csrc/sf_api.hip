@@ -400,7 +400,12 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
   // the 16-row MAF kernel tries a slot 64 times per workgroup iteration, the 32-row kernels 32 times per tile: the
   // first (persistent) launch goes as deep as a short sequential chain allows, the windows beyond are chip-wide
   const bool fast16 = m.kind == SF_MAF && m.m16_ok && !m.hidden_bf16 && m.packed16 != nullptr;
-  const uint32_t first_window = fast16 ? 1024u : 256u;
+  uint32_t first_window = fast16 ? 1024u : 256u;
+  {
+    static int env_w = -1;  // developer knob: SF_FIRST_WINDOW=<attempts> (power of two)
+    if (env_w < 0) { const char* e = std::getenv("SF_FIRST_WINDOW"); env_w = e ? std::atoi(e) : 0; }
+    if (env_w >= 64) first_window = (uint32_t)env_w;
+  }
   uint32_t attempt = 0, limit = ceiling < first_window ? ceiling : first_window;
   int buf = 0, stage = 0;
   double evals = 0.0;
