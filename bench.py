@@ -51,9 +51,25 @@ WORKLOADS = {
                      f_lp=178_640.0, label="BASELINE configs[2]: NPE NSF T=5 H=50 K=8 on 100k-galaxy 20-filter mock"),
     # the reference's own production model (examples/sbi/configs/best_params.yaml: NSF, 15 transforms, 69 hidden;
     # the model behind the published 0.047 s/object H100 timing) on the cfg3-shaped mock
-    "nsf_prod": dict(kind="nsf", D=8, C=20, K=10, n_lib=100_000, galaxies=1000, f_draw=0.0, f_gal=0.0, f_lp=0.0,
-                     H=69, T=15, label="reference production NSF (T=15, H=69, K=10) on the 20-filter mock"),
+    "nsf_prod": dict(kind="nsf", D=8, C=20, K=10, n_lib=100_000, galaxies=1000, H=69, T=15,
+                     label="reference production NSF (T=15, H=69, K=10) on the 20-filter mock"),
 }
+
+
+def nsf_flops(D, C, H, T, K, NB=2):
+    """(per draw, per galaxy) FLOPs of the coupling NSF, counted as SURVEY.md 8(d) counts cfg3 (MACs x 2; the context
+    products Win_c e(x), Wg e(x) are per galaxy): reproduces 148 640 / 30 000 for D=8, C=20, H=50, T=5, K=8."""
+    draw = gal = 0
+    for t in range(T):
+        d_tr = (D - (t & 1) + 1) // 2
+        d_id = D - d_tr
+        draw += H * d_id + NB * 2 * H * H + d_tr * (3 * K - 1) * H + D * D     # Win_u, W1 + W2, Wout, LU
+        gal += H * C + NB * H * C                                               # Win_c, gates
+    return 2.0 * draw, 2.0 * gal
+
+
+_d, _g = nsf_flops(8, 20, 69, 15, 10)
+WORKLOADS["nsf_prod"].update(f_draw=_d, f_gal=_g, f_lp=_d + _g)
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA (= vector) dense peak
 
 

@@ -385,3 +385,16 @@ def test_upstream_state_dict_importer_round_trip(kind, D, C, K, NB):
         tampered[key] = np.arange(1, D, 2)
         with pytest.raises(ValueError, match="transforms dimensions"):
             spec_and_flat_from_state_dict(tampered)
+
+
+def test_bench_flop_model_reproduces_the_survey_figures():
+    """bench.py's analytic NSF FLOP count (used for workloads SURVEY.md 8(d) does not list) must give the survey's own
+    figures for cfg3: 148 640 per draw + 30 000 per galaxy."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.nsf_flops(8, 20, 50, 5, 8) == (148640.0, 30000.0)
+    w = b.WORKLOADS["nsf_cfg3"]
+    assert (w["f_draw"], w["f_gal"], w["f_lp"]) == (148640.0, 30000.0, 178640.0)
+    assert b.WORKLOADS["nsf_prod"]["f_lp"] == b.WORKLOADS["nsf_prod"]["f_draw"] + b.WORKLOADS["nsf_prod"]["f_gal"] > 9e5
