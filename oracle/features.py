@@ -7,6 +7,8 @@ Follows, as plain numpy float64:
                           comes from the build's Philox stream (seed, stream 2; counter = output row) instead of
                           numpy's global generator
   * pit_ranks:            ref src/synference/sbi_runner.py:7153-7158
+  * feature_array_ab:     ref src/synference/sbi_runner.py:1566-1589, 1629-1655, 1698-1716, 1783-1834, 1917-1932,
+                          1936-2027, 2084-2099 (the AB branch of create_feature_array_from_raw_photometry)
 """
 import numpy as np
 
@@ -43,3 +45,56 @@ def pit_ranks(samples, truth):
     valid = np.isfinite(s).sum(1)
     with np.errstate(invalid="ignore", divide="ignore"):
         return np.where(valid > 0, (s < t).sum(1) / valid, np.nan)
+
+
+def feature_array_ab(grid_njy, names, normalize_method=None, normalization_unit="AB", scatter_fluxes=0, depths=None,
+                     include_errors=False, min_flux_pc_error=0.0, norm_mag_limit=50.0, photometry_to_remove=(),
+                     remove_nan_inf=True, drop_dropouts=False, drop_dropout_fraction=1.0, seed=0):
+    """(feature_array [N', F] float64, feature_names, deleted row indices) from a (C, N) library grid in nJy."""
+    names = list(names)
+    grid = np.asarray(grid_njy, dtype=np.float64)
+    if photometry_to_remove:
+        rm = [i for i, n in enumerate(names) if n in photometry_to_remove]
+        grid = np.delete(grid, rm, axis=0)
+        names = [n for i, n in enumerate(names) if i not in rm]
+    phot, err = grid.T, None                                           # (N, C)
+    if scatter_fluxes:
+        phot, err = scatter_depths(phot, depths, scatter_fluxes, 5.0, min_flux_pc_error, seed)
+        err = np.broadcast_to(err, phot.shape) if err.shape[0] == 1 else err
+    with np.errstate(all="ignore"):
+        mag = -2.5 * np.log10(phot / 1000.0) + 23.9                    # :1705 (nJy -> uJy)
+        mag_err = None if err is None else 2.5 * err / (np.log(10) * phot)   # :1699-1702
+    mag[phot < 0] = norm_mag_limit                                     # :1706, :1714
+    norm_col = None
+    zero = np.zeros(len(mag), bool)
+    if normalize_method is not None:
+        j = names.index(normalize_method)
+        ref = mag[:, j]
+        orig = grid[j] if not scatter_fluxes else np.repeat(grid[j], scatter_fluxes)
+        mag = np.delete(mag, j, axis=1) - ref[:, None]                 # :1793-1797 (norm_func = np.subtract)
+        if mag_err is not None:
+            mag_err = np.delete(mag_err, j, axis=1)
+        with np.errstate(all="ignore"):
+            if normalization_unit == "AB":
+                norm_col = -2.5 * np.log10(orig / 1000.0) + 23.9       # :1807-1818
+            else:
+                norm_col = np.log10(orig)                              # "log10 nJy": :1827-1830
+                norm_col[np.isinf(norm_col)] = 0.0
+        zero = ref == 0.0                                              # :1917-1925
+        names = [n for i, n in enumerate(names) if i != j]
+    mag[mag > norm_mag_limit] = norm_mag_limit                         # :1927-1932
+    cols, fnames = [mag], list(names)
+    if mag_err is not None and include_errors:
+        cols.append(mag_err)
+        fnames += [f"unc_{n}" for n in names]
+    if norm_col is not None:
+        cols.append(norm_col[:, None])
+        fnames.append(f"norm_{normalize_method}_{normalization_unit}")
+    feat = np.concatenate(cols, axis=1)
+    delete = zero.copy()
+    if remove_nan_inf:
+        delete |= ~np.isfinite(feat).all(axis=1)                       # :2084-2094
+    if drop_dropouts:
+        nb = len(names)
+        delete |= (np.abs(feat[:, :nb]) >= norm_mag_limit).sum(axis=1) >= nb * drop_dropout_fraction   # :2096-2113
+    return feat[~delete], fnames, np.nonzero(delete)[0]

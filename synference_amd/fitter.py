@@ -64,7 +64,10 @@ class SBI_Fitter:
             # reference: feature_array.astype(np.float32), (N, C) (sbi_runner.py:2150)
             self.feature_array = np.ascontiguousarray(np.asarray(feature_array).astype(np.float32))
             self.has_features = True
+        self.parameter_array = None
+        self.parameter_units = parameter_units
         if parameter_array is not None:
+            self.parameter_array = np.asarray(parameter_array)
             self.fitted_parameter_array = np.asarray(parameter_array)
             if self.fitted_parameter_array.shape[1] != len(self.parameter_names):
                 raise ValueError("parameter_array must be (N, len(parameter_names))")
@@ -101,25 +104,189 @@ class SBI_Fitter:
                    supplementary_parameter_units=list(output.get("supplementary_parameter_units", [])),
                    observation_type=otype, **kwargs)
 
-    def create_feature_array_from_raw_photometry(self, normed_flux_units: str = "AB", norm_mag_limit: float = 50.0,
-                                                 extra_features: list = None, normalize_method=None, **unused):
-        """The AB-magnitude branch of the reference's feature engineering (ref: sbi_runner.py:1698-1716, 1927-1932,
-        2150) on the device: the library's (C, N) fluxes in nJy become the (N, C) float32 feature array.  Extra feature
-        columns, normalisation to a reference band and noise models stay outside the accelerated path."""
+    def create_feature_array_from_raw_photometry(self, normalize_method: Optional[str] = None, extra_features: list = None,
+                                                 normed_flux_units: str = "AB", normalization_unit: str = "AB",
+                                                 verbose: bool = True, scatter_fluxes: Union[int, bool] = False,
+                                                 empirical_noise_models=None, depths=None,
+                                                 include_errors_in_feature_array: bool = False,
+                                                 min_flux_pc_error: float = 0.0, simulate_missing_fluxes: bool = False,
+                                                 norm_mag_limit: float = 50.0, remove_nan_inf: bool = True,
+                                                 parameters_to_remove: Optional[list] = None,
+                                                 photometry_to_remove: Optional[list] = None,
+                                                 parameters_to_add: Optional[list] = None, drop_dropouts: bool = False,
+                                                 drop_dropout_fraction: float = 1.0, max_rows: int = -1,
+                                                 parameter_transformations: Optional[dict] = None, seed: int = 0,
+                                                 **unused):
+        """The AB-magnitude branch of the reference's feature engineering (ref: sbi_runner.py:1429-2222) with the
+        arithmetic on the device: the library's (C, N) fluxes in nJy become the (N', F) float32 feature array.
+
+        Same argument names and meaning as the reference for what is supported:
+          * ``photometry_to_remove`` (1566-1589), ``scatter_fluxes`` + ``depths`` (array, or dict by filter name; same
+            unit as the grid) + ``min_flux_pc_error`` (1629-1655, ``_apply_depths`` 580-691; ``sf_scatter_depths``),
+            ``include_errors_in_feature_array`` (magnitude errors 2.5 e / (ln 10 f), 1698-1702, columns ``unc_<filter>``);
+          * nJy -> AB with negative fluxes and anything fainter set to ``norm_mag_limit`` (1704-1716, 1927-1932;
+            ``sf_flux_to_abmag``);
+          * ``normalize_method`` = a filter name (1783-1834): that band is removed, the others become colours relative
+            to it, and the band itself -- the UNSCATTERED library flux, as ``normalization_unit`` "AB" or "log10 nJy"
+            -- is the last column ``norm_<filter>_<unit>`` (2002-2027);
+          * ``remove_nan_inf``, ``drop_dropouts`` / ``drop_dropout_fraction``, ``max_rows`` (2084-2140), and the
+            parameter bookkeeping of ``update_parameter_array`` (476-578: ``parameters_to_remove``,
+            ``parameters_to_add`` from the supplementary parameters, repetition per scatter copy, deleted rows,
+            ``parameter_transformations``).
+        Outside the accelerated path (``ValueError``): asinh / other flux units, extra feature expressions, empirical noise
+        models, simulated missing fluxes, normalisation by a supplementary parameter.  ``seed`` replaces numpy's global
+        generator for the scatter noise and the ``max_rows`` draw."""
         if self.raw_observation_grid is None:
             raise ValueError("no raw observation grid: build the fitter with init_from_hdf5 or pass feature_array")
-        if extra_features or normalize_method is not None or normed_flux_units != "AB":
-            raise ValueError("only normed_flux_units='AB' without extra features / normalisation is on the HIP path")
-        from .features import flux_to_abmag
-        flux = torch.as_tensor(np.ascontiguousarray(self.raw_observation_grid.T), dtype=torch.float32)
+        if extra_features or normed_flux_units != "AB" or empirical_noise_models is not None or simulate_missing_fluxes:
+            raise ValueError("only normed_flux_units='AB' without extra features, empirical noise models or simulated "
+                             "missing fluxes is on the HIP path")
         if not torch.cuda.is_available():
             raise RuntimeError("create_feature_array_from_raw_photometry runs on the GPU (no CPU fallback)")
-        mag = flux_to_abmag(flux.cuda(), None, norm_mag_limit)
-        self.feature_array = np.ascontiguousarray(mag.cpu().numpy().astype(np.float32))
-        self.feature_names = list(self.raw_observation_names)
-        self.feature_units = ["AB"] * self.feature_array.shape[1]
-        self.has_features = True
+        from .features import flux_to_abmag, scatter_depths
+        names = [str(n_) for n_ in self.raw_observation_names]
+        grid = np.asarray(self.raw_observation_grid)                                    # (C, N)
+        photometry_to_remove = list(photometry_to_remove or [])
+        if photometry_to_remove:
+            rm = [i for i, n_ in enumerate(names) if n_ in photometry_to_remove]
+            if not rm:
+                raise ValueError(f"No matching photometry filters found in the raw photometry names: {photometry_to_remove}")
+            grid = np.delete(grid, rm, axis=0)
+            names = [n_ for i, n_ in enumerate(names) if i not in rm]
+            if not names:
+                raise ValueError("No photometry filters left after removing the specified ones.")
+        n_sc = int(scatter_fluxes) if scatter_fluxes else 0
+        flux = torch.as_tensor(np.ascontiguousarray(grid.T), dtype=torch.float32).cuda()  # (N, C) on the device
+        err = None
+        if n_sc:
+            if depths is None:
+                raise ValueError("If scattering fluxes, depths or empirical noise models must be provided.")
+            if isinstance(depths, dict):
+                depths = np.asarray([depths[n_] for n_ in names], dtype=np.float32)
+            self.phot_depths, self.min_flux_pc_error = depths, min_flux_pc_error
+            flux, err = scatter_depths(flux, depths, n_sc, 5.0, min_flux_pc_error, seed=seed, return_errors=True)
+        mag, mag_err = flux_to_abmag(flux, err, norm_mag_limit) if err is not None else (flux_to_abmag(flux, None, norm_mag_limit), None)
+        norm_col, norm_name = None, None
+        if normalize_method is not None:
+            if normalize_method not in names:
+                raise NotImplementedError("Normalization method not implemented.\n                    Please use a filter name for normalization.")
+            j = names.index(normalize_method)
+            keep = [i for i in range(len(names)) if i != j]
+            ref = mag[:, j:j + 1]
+            orig = torch.as_tensor(np.ascontiguousarray(grid[j]), dtype=torch.float64).cuda()   # unscattered library flux (nJy)
+            if n_sc:
+                orig = orig.repeat_interleave(n_sc)
+            mag = mag[:, keep] - ref                                                   # colours (norm_func = np.subtract)
+            if mag_err is not None:
+                mag_err = mag_err[:, keep]
+            if normalization_unit == "AB":
+                norm_col = -2.5 * torch.log10(orig * 1e-3) + 23.9
+            elif normalization_unit.startswith("log10 "):
+                if normalization_unit.split(" ")[1] != "nJy":
+                    raise ValueError("normalization_unit: 'AB' or 'log10 nJy' on the HIP path")
+                norm_col = torch.log10(orig)
+                norm_col[torch.isinf(norm_col)] = 0.0
+            else:
+                raise ValueError("normalization_unit: 'AB' or 'log10 nJy' on the HIP path")
+            zero_norm = (ref.reshape(-1) == 0)
+            names = [names[i] for i in keep]
+            norm_name = f"norm_{normalize_method}_{normalization_unit}"
+        mag = torch.where(mag > norm_mag_limit, torch.full_like(mag, norm_mag_limit), mag)   # 1927-1932
+        cols, feature_names, units = [mag], list(names), ["AB"] * len(names)
+        error_names = [f"unc_{n_}" for n_ in names] if mag_err is not None else []
+        if mag_err is not None and include_errors_in_feature_array:
+            cols.append(mag_err)
+            feature_names += error_names
+            units += ["AB"] * len(error_names)
+        if norm_col is not None:
+            cols.append(norm_col.float().reshape(-1, 1))
+            feature_names.append(norm_name)
+            units.append(normalization_unit)
+        feat = torch.cat(cols, dim=1)
+        delete = torch.zeros(feat.shape[0], dtype=torch.bool, device=feat.device)
+        if norm_col is not None:
+            delete |= zero_norm                                                        # 1917-1925
+        if remove_nan_inf:
+            bad = ~torch.isfinite(feat).all(dim=1)
+            if verbose and int(bad.sum()):
+                logger.warning(f"Warning: Deleting {int(bad.sum())} rows with NaN or Inf\n                    values in the feature array.")
+            delete |= bad
+        if drop_dropouts:
+            nb = len(names)
+            drop = (feat[:, :nb].abs() >= norm_mag_limit).sum(dim=1) >= nb * drop_dropout_fraction
+            if verbose and int(drop.sum()):
+                logger.warning(f"Warning: Dropping {int(drop.sum())} dropouts where more than\n                    "
+                               f"{drop_dropout_fraction * 100}% of bands are at the norm_mag_limit.")
+            delete |= drop
+        delete_rows = torch.nonzero(delete).reshape(-1).cpu().numpy()
+        if max_rows > 0 and feat.shape[0] - len(delete_rows) > max_rows:
+            options = np.setdiff1d(np.arange(feat.shape[0]), delete_rows)
+            chosen = np.random.default_rng(seed).choice(options, size=max_rows, replace=False)
+            delete_rows = np.concatenate([delete_rows, np.setdiff1d(options, chosen)])
+        keep_rows = np.setdiff1d(np.arange(feat.shape[0]), delete_rows)
+        if keep_rows.size == 0:
+            raise ValueError("All rows in the feature array were deleted. Please check the input parameters.")
+        feat = feat[torch.as_tensor(keep_rows, device=feat.device)]
+        self.feature_array = np.ascontiguousarray(feat.cpu().numpy().astype(np.float32))
+        self.feature_names, self.feature_units, self.has_features = feature_names, units, True
+        self.feature_array_flags = dict(normalize_method=normalize_method, extra_features=extra_features,
+                                        normed_flux_units=normed_flux_units, normalization_unit=normalization_unit,
+                                        scatter_fluxes=scatter_fluxes, depths=depths,
+                                        include_errors_in_feature_array=include_errors_in_feature_array,
+                                        min_flux_pc_error=min_flux_pc_error, norm_mag_limit=norm_mag_limit,
+                                        remove_nan_inf=remove_nan_inf, parameters_to_remove=parameters_to_remove,
+                                        photometry_to_remove=photometry_to_remove, parameters_to_add=parameters_to_add,
+                                        drop_dropouts=drop_dropouts, drop_dropout_fraction=drop_dropout_fraction,
+                                        raw_observation_names=names, error_names=error_names, norm_name=norm_name)
+        self.update_parameter_array(parameters_to_remove=list(parameters_to_remove or []), delete_rows=np.sort(delete_rows),
+                                    n_scatters=max(n_sc, 1), parameters_to_add=list(parameters_to_add or []),
+                                    parameter_transformations=parameter_transformations)
         return self.feature_array, self.feature_names
+
+    def update_parameter_array(self, parameters_to_remove: list = [], delete_rows=[], n_scatters: int = 1,
+                               parameters_to_add: list = [], parameter_transformations: dict = None) -> None:
+        """ref: sbi_runner.py:476-578 -- the fitted parameter array that goes with the feature array: columns removed /
+        added (from the supplementary parameters), rows repeated per scatter copy, deleted rows dropped, optional
+        per-parameter transformations (the column is renamed ``<fn>_<name>``)."""
+        if getattr(self, "parameter_array", None) is None:
+            raise ValueError("no parameter array: build the fitter from a library or pass parameter_array")
+        arr = np.array(self.parameter_array, copy=True)
+        pnames = [str(n_) for n_ in self.parameter_names]
+        punits = None if self.parameter_units is None else list(self.parameter_units)
+        for prm in np.unique(list(parameters_to_remove)):
+            if prm in pnames:
+                i = pnames.index(prm)
+                arr = np.delete(arr, i, axis=1)
+                pnames.pop(i)
+                if punits is not None:
+                    punits.pop(i)
+        for prm in parameters_to_add:
+            sn = [str(n_) for n_ in (self.supplementary_parameter_names or [])]
+            if prm not in sn:
+                raise ValueError(f"Can't add {prm} to parameter array - not found in supplementary parameters. "
+                                 f"Available parameters: {self.supplementary_parameter_names}")
+            i = sn.index(prm)
+            arr = np.column_stack((arr, np.asarray(self.supplementary_parameters)[i]))
+            pnames.append(prm)
+            if punits is not None and self.supplementary_parameter_units is not None:
+                punits.append(self.supplementary_parameter_units[i])
+        if n_scatters > 1:
+            arr = np.repeat(arr, n_scatters, axis=0)
+        if len(delete_rows) > 0:
+            arr = np.delete(arr, np.asarray(delete_rows, dtype=np.int64), axis=0)
+        if parameter_transformations is not None:
+            for prm, fn in parameter_transformations.items():
+                if prm not in pnames:
+                    raise ValueError(f"Parameter {prm} not found in fitted parameter names for transformation.")
+                i = pnames.index(prm)
+                arr[:, i] = fn(arr[:, i])
+                pnames[i] = f"{fn.__name__}_{prm}"
+                if punits is not None and punits[i] is not None and str(punits[i]) != "dimensionless":
+                    punits[i] = f"{fn.__name__}({punits[i]})"
+        self.fitted_parameter_array = arr
+        self.fitted_parameter_names = pnames
+        self.simple_fitted_parameter_names = [n_.split("/")[-1] for n_ in pnames]
+        self.fitted_parameter_units = punits
 
     def split_dataset(self, train_fraction: float = 0.8, random_seed: int = None, verbose: bool = True) -> tuple:
         if random_seed is not None:

@@ -341,3 +341,79 @@ def test_library_file_to_trained_posterior(tmp_path):
     assert stats[0]["training_loss"][-1] < stats[0]["training_loss"][0]
     s = f.sample_posterior(f._X_test[:6], num_samples=50, seed=2)
     assert s.shape == (6, 50, 5) and np.isfinite(s).all()
+
+
+def _library_fitter(C=6, N=400, D=3, seed=4):
+    from synference_amd import SBI_Fitter
+    rng = np.random.default_rng(seed)
+    grid = (10 ** rng.uniform(0.5, 4.5, size=(C, N))).astype(np.float64)           # nJy
+    grid[1, 5] = -3.0; grid[2, 6] = 0.0; grid[0, 7] = np.nan
+    grid[:, 9] = 1e-40                                                              # a dropout row: every band at the limit
+    params = rng.normal(size=(N, D))
+    supp = rng.uniform(1, 2, size=(2, N))
+    names = [f"F{i}" for i in range(C)]
+    f = SBI_Fitter("lib", [f"p{i}" for i in range(D)], raw_observation_names=names, raw_observation_grid=grid,
+                   parameter_array=params, parameter_units=["u"] * D, raw_observation_units="nJy",
+                   supplementary_parameters=supp, supplementary_parameter_names=["mass", "sfr"],
+                   supplementary_parameter_units=["Msun", "Msun/yr"])
+    return f, grid, names, params, supp
+
+
+@pytest.mark.parametrize("opts", [
+    dict(),
+    dict(scatter_fluxes=3, depths=np.array([30., 40., 50., 60., 70., 80.]), include_errors_in_feature_array=True, min_flux_pc_error=5.0),
+    dict(normalize_method="F2", normalization_unit="AB", photometry_to_remove=["F5"]),
+    dict(normalize_method="F0", normalization_unit="log10 nJy", scatter_fluxes=2, depths={f"F{i}": 20.0 + i for i in range(6)},
+         include_errors_in_feature_array=True, drop_dropouts=True, drop_dropout_fraction=0.8),
+])
+def test_feature_array_from_raw_photometry_matches_the_oracle_restatement(opts):
+    """ref: sbi_runner.py:1429-2222 (AB branch): scatter by depths, magnitudes + errors, colours relative to a filter, the
+    normalisation column, row deletions, and the parameter array that goes with it (update_parameter_array, 476-578)."""
+    from oracle import features as OFE
+    f, grid, names, params, supp = _library_fitter()
+    feat, fnames = f.create_feature_array_from_raw_photometry(seed=11, verbose=False, parameters_to_remove=["p1"],
+                                                             parameters_to_add=["sfr"],
+                                                             parameter_transformations={"p0": np.tanh}, **opts)
+    o = dict(opts)
+    dep = o.pop("depths", None)
+    if isinstance(dep, dict):
+        dep = np.array([dep[n] for n in names if n not in o.get("photometry_to_remove", [])])
+    ref, rnames, deleted = OFE.feature_array_ab(grid, names, normalize_method=o.get("normalize_method"),
+                                                normalization_unit=o.get("normalization_unit", "AB"),
+                                                scatter_fluxes=o.get("scatter_fluxes", 0), depths=dep,
+                                                include_errors=o.get("include_errors_in_feature_array", False),
+                                                min_flux_pc_error=o.get("min_flux_pc_error", 0.0),
+                                                photometry_to_remove=o.get("photometry_to_remove", ()),
+                                                drop_dropouts=o.get("drop_dropouts", False),
+                                                drop_dropout_fraction=o.get("drop_dropout_fraction", 1.0), seed=11)
+    assert list(fnames) == rnames and feat.dtype == np.float32 and feat.shape == ref.shape
+    assert len(deleted) >= 1 and 7 * max(int(opts.get("scatter_fluxes", 0)), 1) in deleted     # the NaN band row is gone
+    scale = np.maximum(1.0, np.abs(ref))
+    err = np.abs((feat - ref) / scale)
+    # (a scattered flux that lands near zero loses float32 digits to cancellation before the logarithm: rare, bounded)
+    assert np.quantile(err, 0.999) < 2e-5 and err.max() < 2e-3, (np.quantile(err, 0.999), err.max())
+    # the parameter array that goes with it
+    n_sc = max(int(o.get("scatter_fluxes", 0)), 1)
+    want = np.column_stack((np.delete(params, 1, axis=1), supp[1]))
+    want = np.delete(np.repeat(want, n_sc, axis=0), deleted, axis=0)
+    want[:, 0] = np.tanh(want[:, 0])
+    assert f.fitted_parameter_names == ["tanh_p0", "p2", "sfr"] and f.fitted_parameter_units == ["tanh(u)", "u", "Msun/yr"]
+    assert f.fitted_parameter_array.shape == (feat.shape[0], 3) and np.allclose(f.fitted_parameter_array, want)
+    nb = len(f.feature_array_flags["raw_observation_names"])
+    assert f.feature_units[:nb] == ["AB"] * nb and len(f.feature_units) == feat.shape[1]
+
+
+def test_feature_array_argument_errors_follow_the_reference():
+    f, grid, names, params, supp = _library_fitter()
+    with pytest.raises(ValueError, match="No matching photometry filters"):
+        f.create_feature_array_from_raw_photometry(photometry_to_remove=["nope"])
+    with pytest.raises(ValueError, match="depths or empirical noise models must be provided"):
+        f.create_feature_array_from_raw_photometry(scatter_fluxes=2)
+    with pytest.raises(NotImplementedError, match="filter name"):
+        f.create_feature_array_from_raw_photometry(normalize_method="mass")
+    with pytest.raises(ValueError, match="not found in supplementary parameters"):
+        f.create_feature_array_from_raw_photometry(parameters_to_add=["age"])
+    with pytest.raises(ValueError, match="HIP path"):
+        f.create_feature_array_from_raw_photometry(normed_flux_units="asinh")
+    feat, _ = f.create_feature_array_from_raw_photometry(max_rows=50, seed=2, verbose=False)
+    assert feat.shape == (50, 6) and f.fitted_parameter_array.shape == (50, 3)
