@@ -480,16 +480,115 @@ class SBI_Fitter:
                                            norm_posterior, num_rejection_samples)
         return lp.double().cpu().numpy()
 
+    def create_features_from_observations(self, observations, columns_to_feature_names: dict = None, flux_units=None,
+                                          missing_data_flag=-99, override_transformations: dict = {},
+                                          ignore_missing: bool = False):
+        """ref: sbi_runner.py:2473-2937 -- the observed catalogue as the (N', F) float32 feature array the model was
+        trained on, plus the mask of removed rows, from the transformations recorded by
+        ``create_feature_array_from_raw_photometry`` (``self.feature_array_flags``).
+
+        As in the reference the photometry columns must ALREADY be in the training units (``flux_units`` has to equal
+        ``normed_flux_units``, an assertion there too); what happens here is column mapping and validation (every
+        filter, every ``unc_`` column when errors were features, the ``norm_<filter>_<unit>`` column), the error-NaN
+        check, the normalisation step exactly as the reference writes it (2844-2865), removal of rows that carry the
+        missing-data flag, the ``norm_mag_limit`` clip and inf -> NaN.  Empirical noise models, flags and simulated
+        missing fluxes are outside the HIP path."""
+        import pandas as pd
+        flags = dict(getattr(self, "feature_array_flags", None) or {})
+        if len(flags) == 0:
+            raise ValueError("No feature array flags found. Please create the feature array first.")
+        flags.update(override_transformations)
+        if not isinstance(observations, pd.DataFrame):
+            raise TypeError("Observations must be a pandas DataFrame or an astropy Table.")
+        if columns_to_feature_names is None:
+            columns_to_feature_names = {col: col for col in observations.columns}
+        feature_names_to_columns = {v: k for k, v in columns_to_feature_names.items()}
+        for name in flags["raw_observation_names"]:
+            if name not in feature_names_to_columns:
+                raise ValueError(f"Column '{name}' not found in observations. Please provide a mapping for all photometry filters.")
+        if flags.get("include_errors_in_feature_array"):
+            for name in flags["error_names"]:
+                if name not in feature_names_to_columns:
+                    raise ValueError(f"Column '{name}' not found in observations. Please provide a mapping for all errors.")
+        if flags.get("norm_name") is not None and flags["norm_name"] not in feature_names_to_columns:
+            raise ValueError(f"Column '{flags['norm_name']}' not found in\n                observations. "
+                             "Please provide a mapping for the normalization factor.")
+        training_flux_units = flags["normed_flux_units"]
+        assert flux_units == training_flux_units, (f"Flux units '{flux_units}' do not match\n                    "
+                                                   f"training data units '{training_flux_units}'.")
+        fnames = list(self.feature_names)
+        nrows, ncols = observations.shape[0], np.shape(self.feature_array)[1]
+        fa = np.zeros((ncols, nrows), dtype=np.float32)
+        photometry_columns = [feature_names_to_columns[name] for name in flags["raw_observation_names"]]
+        for col in photometry_columns:
+            if col not in observations.columns:
+                raise ValueError(f"Column '{col}' not found in observations.\n                    "
+                                 "Please provide a mapping for all photometry filters.")
+            fa[fnames.index(columns_to_feature_names[col]), :] = observations[col].values
+        err_names = flags["error_names"] if flags.get("include_errors_in_feature_array") else []
+        for col in err_names:
+            ocol = feature_names_to_columns[col]
+            if ocol not in observations.columns:
+                raise ValueError(f"Column '{ocol}' not found in observations.\n                    "
+                                 "Please provide a mapping for all errors.")
+            fa[fnames.index(col), :] = observations[ocol].values
+        for col in err_names:
+            ev, fv = fa[fnames.index(col), :], fa[fnames.index(col.replace("unc_", "")), :]
+            bad = np.isnan(ev) & ~np.isnan(fv)
+            if np.sum(bad) > 0:
+                raise ValueError(f"Error column '{col}' contains NaN values where the\n                    corresponding flux "
+                                 f"column '{col.replace('unc_', '')}' does not.{np.sum(bad)} NaN values found.")
+        if flags.get("norm_name") is not None:
+            ncol = feature_names_to_columns[flags["norm_name"]]
+            if ncol not in observations.columns:
+                raise ValueError(f"Column '{flags['norm_name']}'\n                    not found in observations.\n"
+                                 "                    Please provide a mapping for the normalization factor.")
+            fa[fnames.index(flags["norm_name"]), :] = observations[ncol].values
+        if flags.get("normalize_method") is not None:
+            nf = fa[fnames.index(flags["norm_name"]), :]
+            # exactly as the reference writes it (2847-2849): the AB column goes back to a uJy flux and is SUBTRACTED
+            nf = 10 ** ((23.9 - nf) / 2.5)
+            for col in photometry_columns:
+                i = fnames.index(columns_to_feature_names[col])
+                fa[i, :] = np.subtract(fa[i, :], nf)
+        removed = np.zeros(nrows, dtype=bool)
+        missing = np.isnan(fa) if (isinstance(missing_data_flag, float) and np.isnan(missing_data_flag)) else (fa == missing_data_flag)
+        if not ignore_missing:
+            if missing.sum() > 0:
+                logger.info(f"Removing {int(missing.sum())} observations with missing data.")
+            removed[missing.any(axis=0)] = True
+        fa, missing = fa[:, ~removed], missing[:, ~removed]
+        clip = (fa > flags["norm_mag_limit"]) & ~missing
+        fa[clip] = flags["norm_mag_limit"]
+        fa[~np.isfinite(fa)] = np.nan
+        return fa.T, removed
+
     def fit_catalogue(self, observations, columns_to_feature_names: dict = None, num_samples: int = 1000,
                       quantiles=(0.16, 0.5, 0.84), sample_method: str = "direct", append_to_input: bool = True,
                       return_samples: bool = False, log_times: bool = False, seed: Optional[int] = None,
-                      device_quantiles: bool = True, **unused):
+                      device_quantiles: bool = True, flux_units=None, missing_data_flag=-99,
+                      override_transformations: dict = {}, **unused):
         """Sampling + quantile section of the reference's fit_catalogue (sbi_runner.py:3230-3282).
 
-        ``observations`` is a pandas DataFrame / dict of columns / (N, C) array already expressed in the
-        feature space the model was trained on (the flux -> feature conversion of lines 3061-3068 is
-        outside the accelerated path).  Rows containing NaN are masked and get NaN quantiles."""
+        ``observations`` is a pandas DataFrame / dict of columns / (N, C) array.  With ``flux_units`` given and a feature
+        array that was built by ``create_feature_array_from_raw_photometry`` the table goes through
+        ``create_features_from_observations`` first (3061-3068: column mapping, normalisation, missing-data rows);
+        otherwise its columns are taken as the model's feature columns.  Masked rows get NaN quantiles."""
         import pandas as pd
+        if flux_units is not None and getattr(self, "feature_array_flags", None):
+            df0 = pd.DataFrame(observations) if isinstance(observations, dict) else observations
+            feats_ok, removed = self.create_features_from_observations(df0, columns_to_feature_names, flux_units,
+                                                                       missing_data_flag, override_transformations)
+            full = np.full((len(df0), feats_ok.shape[1]), np.nan, dtype=np.float32)
+            full[~removed] = feats_ok
+            out = self.fit_catalogue(full, None, num_samples, quantiles, sample_method, False, return_samples, log_times,
+                                     seed, device_quantiles)
+            qt = out[0] if return_samples else out
+            table = df0.copy() if append_to_input else pd.DataFrame({"ID": np.arange(len(df0)) + 1})
+            for c in qt.columns:
+                if c != "ID":
+                    table[c] = qt[c].to_numpy()
+            return (table, out[1]) if return_samples else table
         if isinstance(observations, np.ndarray):
             df = pd.DataFrame(observations, columns=list(self.feature_names)[: observations.shape[1]])
         elif isinstance(observations, dict):

@@ -341,6 +341,19 @@ def test_library_file_to_trained_posterior(tmp_path):
     assert stats[0]["training_loss"][-1] < stats[0]["training_loss"][0]
     s = f.sample_posterior(f._X_test[:6], num_samples=50, seed=2)
     assert s.shape == (6, 50, 5) and np.isfinite(s).all()
+    # an observed catalogue in the training units goes through create_features_from_observations (sbi_runner.py:3061-3068):
+    # short column names mapped to the filter codes, one row with the missing-data flag
+    import pandas as pd
+    obs = pd.DataFrame({f"F{i}": f._X_test[:8, i].astype(np.float64) for i in range(10)})
+    obs.loc[3, "F4"] = -99.0
+    cmap = {f"F{i}": f"JWST/NIRCam.F{i}" for i in range(10)}
+    table = f.fit_catalogue(obs, columns_to_feature_names=cmap, flux_units="AB", num_samples=200, seed=5)
+    direct = f.fit_catalogue(f._X_test[:8], num_samples=200, seed=5, append_to_input=False)
+    qcols = [c for c in table.columns if c.endswith(("_16", "_50", "_84"))]
+    assert len(qcols) == 15 and list(table.columns[:10]) == list(obs.columns)
+    assert table.loc[3, qcols].isna().all() and table.drop(index=3)[qcols].notna().all().all()
+    # rows 0-2 sit at the same catalogue positions in both calls: same slots, same draws, same quantiles
+    assert np.allclose(table.loc[:2, qcols].to_numpy(float), direct.loc[:2, qcols].to_numpy(float), rtol=1e-6)
 
 
 def _library_fitter(C=6, N=400, D=3, seed=4):
