@@ -412,6 +412,17 @@ class SBI_Fitter:
             self._train_indices, self._test_indices = train_indices, test_indices
             self._X_train, self._y_train, self._X_test, self._y_test = X_train, y_train, X_test, y_test
             self.fitted_model_name = run_name
+        if save_model and out_dir is not None:  # sbi_runner.py:4973-5014: the fitter's state next to the posterior pickle
+            prior_was = self._prior
+            self._prior = prior
+            try:
+                self.save_state(out_dir=out_dir, name_append=stamp, has_grid=True, engine=engine, learning_type=learning_type,
+                                ensemble_model_types=list(models), ensemble_model_args=[dict(hidden_features=hf[i],
+                                num_transforms=nt[i], **additional_model_args) for i in range(n_nets)], n_nets=n_nets,
+                                train_args=train_args, stats=stats, training_time=self.training_time,
+                                train_fraction=train_test_fraction, test_indices=test_indices, train_indices=train_indices)
+            finally:
+                self._prior = prior_was if not set_self else prior
         if evaluate_model and X_test is not None:
             self.evaluate_model(posteriors=posteriors, X_test=X_test, y_test=y_test,
                                 num_samples=num_posterior_draws_per_sample)
@@ -479,6 +490,122 @@ class SBI_Fitter:
                                            torch.as_tensor(np.asarray(X, dtype=np.float32)),
                                            norm_posterior, num_rejection_samples)
         return lp.double().cpu().numpy()
+
+    def save_state(self, out_dir, name_append: str = "", save_method: str = "joblib", has_grid: bool = True, **extras):
+        """ref: sbi_runner.py:693-830 -- what a later session needs next to ``{name}_{append}_posterior.pkl``: feature /
+        parameter names and units, the prior, the feature-array flags and (``has_grid``) the feature and parameter
+        arrays, plus ``extras`` (train arguments, split indices, stats ...), as ``{name}{_append}_params.pkl``
+        (``save_method`` 'joblib' -- the reference's default --, 'pickle' or 'torch'); ``stats`` also go to
+        ``{name}{_append}_summary.json`` with the scalar entries of the dictionary appended."""
+        import json
+        import pickle
+        os.makedirs(out_dir, exist_ok=True)
+        param_dict = {"feature_names": self.feature_names, "feature_units": self.feature_units,
+                      "fitted_parameter_units": self.fitted_parameter_units,
+                      "fitted_parameter_names": self.fitted_parameter_names,
+                      "timestamp": time.strftime("%Y%m%d_%H%M%S"), "prior": self._prior,
+                      "library_path": self.library_path, "name": self.name, "has_simulator": self.has_simulator}
+        if len(name_append) > 0 and name_append[0] != "_":
+            name_append = f"_{name_append}"
+        save_path = f"{out_dir}/{self.name}{name_append}_params.pkl"
+        param_dict.update(extras)
+        if has_grid:
+            param_dict["feature_array_flags"] = getattr(self, "feature_array_flags", {})
+            param_dict["feature_array"] = self.feature_array
+            param_dict["parameter_array"] = self.fitted_parameter_array
+        if "stats" in param_dict:
+            summary = list(param_dict["stats"]) + [{k: v for k, v in param_dict.items()
+                                                    if isinstance(v, (list, str, float, int, bool)) and k != "stats"}]
+            try:
+                with open(f"{out_dir}/{self.name}{name_append}_summary.json", "w") as fh:
+                    json.dump(summary, fh, indent=4, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
+            except Exception as e:  # (the reference logs and goes on)
+                logger.error(f"Error saving stats: {e}")
+        if save_method == "joblib":
+            from joblib import dump
+            dump(param_dict, save_path, compress=3)
+        elif save_method == "pickle":
+            with open(save_path, "wb") as fh:
+                pickle.dump(param_dict, fh, protocol=pickle.HIGHEST_PROTOCOL)
+        elif save_method == "torch":
+            torch.save(param_dict, save_path)
+        else:
+            raise ValueError("save_method: 'joblib', 'pickle' or 'torch' on the HIP path")
+        return save_path
+
+    def load_model_from_pkl(self, model_file: str, set_self: bool = True, load_arrays: bool = True):
+        """ref: sbi_runner.py:7401-7633 -- (posteriors, stats, params) of a model trained by THIS backend: ``model_file`` is
+        the ``*_posterior.pkl`` or the directory that holds exactly one; ``*_summary.json`` and ``*_params.pkl`` next to
+        it are read when present and, with ``set_self``, put back on the fitter (names, units, flags, prior, arrays,
+        the train / test split).  sbi's own pickles need sbi and stay outside the build (see ``importer.py`` for their
+        weights)."""
+        import glob
+        import json
+        import pickle
+        if not os.path.exists(model_file):
+            raise ValueError(f"Model file {model_file} does not exist.")
+        if os.path.isdir(model_file):
+            files = glob.glob(os.path.join(model_file, "*_posterior.pkl"))
+            if len(files) == 0:
+                raise ValueError(f"No parameter files found in {model_file}.")
+            if len(files) > 1:
+                raise ValueError(f"Multiple parameter files found in {model_file}.\n                    Please specify a single file.")
+            model_file = files[0]
+        with open(model_file, "rb") as fh:
+            posteriors = pickle.load(fh)
+        stats = None
+        sfile = model_file.replace("posterior.pkl", "summary.json")
+        if os.path.exists(sfile):
+            with open(sfile, "r", encoding="utf-8") as fh:
+                stats = json.load(fh)
+            if set_self:
+                self.stats = stats
+        else:
+            logger.info(f"Warning: No summary file found for {model_file}.")
+        if hasattr(posteriors, "to"):
+            posteriors = posteriors.to(self.device) or posteriors
+        if set_self:
+            self.posteriors = posteriors
+        pfile = model_file.replace("posterior.pkl", "params.pkl")
+        params = None
+        if os.path.exists(pfile):
+            try:
+                from joblib import load as jl_load
+                params = jl_load(pfile)
+            except Exception:
+                try:
+                    with open(pfile, "rb") as fh:
+                        params = pickle.load(fh)
+                except Exception:
+                    params = torch.load(pfile, map_location="cpu", weights_only=False)
+            if set_self:
+                self.fitted_parameter_names = list(params["fitted_parameter_names"])
+                self.simple_fitted_parameter_names = [str(i).split("/")[-1] for i in self.fitted_parameter_names]
+                self.fitted_parameter_units = params.get("fitted_parameter_units", self.parameter_units)
+                self.feature_names = params["feature_names"]
+                self.feature_units = params.get("feature_units", None)
+                if "feature_array_flags" in params:
+                    self.feature_array_flags = params["feature_array_flags"]
+                    self.has_features = True
+                if load_arrays and params.get("feature_array") is not None:
+                    self.fitted_parameter_array = params["parameter_array"]
+                    self.feature_array = params["feature_array"]
+                    self.has_features = True
+                    self._train_indices = params.get("train_indices")
+                    self._test_indices = params.get("test_indices")
+                    self._train_fraction = params.get("train_fraction")
+                    if self._train_indices is not None and self._test_indices is not None:
+                        self._X_test = self.feature_array[self._test_indices]
+                        self._y_test = self.fitted_parameter_array[self._test_indices]
+                        self._X_train = self.feature_array[self._train_indices]
+                        self._y_train = self.fitted_parameter_array[self._train_indices]
+                self._train_args = params.get("train_args")
+                self._prior = params.get("prior")
+                self._ensemble_model_types = params.get("ensemble_model_types")
+                self._ensemble_model_args = params.get("ensemble_model_args")
+        else:
+            logger.warning(f"No parameter file found for {model_file}.")
+        return posteriors, stats, params
 
     def create_features_from_observations(self, observations, columns_to_feature_names: dict = None, flux_units=None,
                                           missing_data_flag=-99, override_transformations: dict = {},

@@ -97,6 +97,33 @@ def test_posterior_pickle_roundtrip(fitted):
     assert np.array_equal(a, b)
 
 
+def test_saved_state_reloads_into_a_fresh_fitter(fitted):
+    """ref: sbi_runner.py:693-830 (save_state), 7401-7633 (load_model_from_pkl): the directory written by
+    run_single_sbi(save_model=True) is everything a later session needs -- posterior, stats, names, prior, arrays, split."""
+    from synference_amd import SBI_Fitter
+    f, post, stats, out = fitted
+    assert (out / "e2e_t_params.pkl").exists() and (out / "e2e_t_summary.json").exists()
+    g = SBI_Fitter("e2e", list(f.parameter_names))
+    p2, stats2, params = g.load_model_from_pkl(str(out))                      # the directory holds exactly one model
+    assert params["n_nets"] == len(post.posteriors) and params["train_args"]["training_batch_size"] > 0
+    assert list(g.feature_names) == list(f.feature_names) and g.fitted_parameter_names == list(f.fitted_parameter_names)
+    assert np.array_equal(g.feature_array, f.feature_array) and np.array_equal(g._X_test, f._X_test)
+    assert np.allclose(g._prior.low.cpu(), f._prior.low.cpu()) and len(stats2) == len(stats) + 1   # + the scalar summary
+    X = f._X_test[:5]
+    a = f.sample_posterior(X, num_samples=40, seed=3)
+    b = g.sample_posterior(X, num_samples=40, seed=3)
+    assert np.array_equal(a, b)
+    t1 = f.fit_catalogue(X, num_samples=100, seed=4, append_to_input=False)
+    t2 = g.fit_catalogue(X, num_samples=100, seed=4, append_to_input=False)
+    assert np.allclose(t1.to_numpy(float), t2.to_numpy(float), equal_nan=True)
+    with pytest.raises(ValueError, match="does not exist"):
+        g.load_model_from_pkl(str(out / "nope"))
+    (out / "second_posterior.pkl").write_bytes(b"x")
+    with pytest.raises(ValueError, match="Multiple parameter files"):
+        g.load_model_from_pkl(str(out))
+    (out / "second_posterior.pkl").unlink()
+
+
 def test_unsupported_requests_fail_loudly(fitted):
     f, *_ = fitted
     with pytest.raises(ValueError):
