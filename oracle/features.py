@@ -49,8 +49,9 @@ def pit_ranks(samples, truth):
 
 def feature_array_ab(grid_njy, names, normalize_method=None, normalization_unit="AB", scatter_fluxes=0, depths=None,
                      include_errors=False, min_flux_pc_error=0.0, norm_mag_limit=50.0, photometry_to_remove=(),
-                     remove_nan_inf=True, drop_dropouts=False, drop_dropout_fraction=1.0, seed=0):
-    """(feature_array [N', F] float64, feature_names, deleted row indices) from a (C, N) library grid in nJy."""
+                     remove_nan_inf=True, drop_dropouts=False, drop_dropout_fraction=1.0, seed=0, asinh_f_b=None):
+    """(feature_array [N', F] float64, feature_names, deleted row indices) from a (C, N) library grid in nJy.
+    ``asinh_f_b`` (per-filter softening in nJy): the asinh branch (1718-1732) instead of AB magnitudes."""
     names = list(names)
     grid = np.asarray(grid_njy, dtype=np.float64)
     if photometry_to_remove:
@@ -61,6 +62,18 @@ def feature_array_ab(grid_njy, names, normalize_method=None, normalization_unit=
     if scatter_fluxes:
         phot, err = scatter_depths(phot, depths, scatter_fluxes, 5.0, min_flux_pc_error, seed)
         err = np.broadcast_to(err, phot.shape) if err.shape[0] == 1 else err
+    if asinh_f_b is not None:
+        mag = flux_to_asinh(phot, asinh_f_b) if err is None else None
+        mag_err = None
+        if err is not None:
+            mag, mag_err = flux_to_asinh(phot, asinh_f_b, err)
+        cols, fnames = [mag], list(names)
+        if mag_err is not None and include_errors:
+            cols.append(mag_err)
+            fnames += [f"unc_{n}" for n in names]
+        feat = np.concatenate(cols, axis=1)
+        delete = ~np.isfinite(feat).all(axis=1) if remove_nan_inf else np.zeros(len(feat), bool)
+        return feat[~delete], fnames, np.nonzero(delete)[0]
     with np.errstate(all="ignore"):
         mag = -2.5 * np.log10(phot / 1000.0) + 23.9                    # :1705 (nJy -> uJy)
         mag_err = None if err is None else 2.5 * err / (np.log(10) * phot)   # :1699-1702

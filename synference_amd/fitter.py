@@ -115,8 +115,8 @@ class SBI_Fitter:
                                                  photometry_to_remove: Optional[list] = None,
                                                  parameters_to_add: Optional[list] = None, drop_dropouts: bool = False,
                                                  drop_dropout_fraction: float = 1.0, max_rows: int = -1,
-                                                 parameter_transformations: Optional[dict] = None, seed: int = 0,
-                                                 **unused):
+                                                 parameter_transformations: Optional[dict] = None,
+                                                 asinh_softening_parameters=None, seed: int = 0, **unused):
         """The AB-magnitude branch of the reference's feature engineering (ref: sbi_runner.py:1429-2222) with the
         arithmetic on the device: the library's (C, N) fluxes in nJy become the (N', F) float32 feature array.
 
@@ -133,17 +133,25 @@ class SBI_Fitter:
             parameter bookkeeping of ``update_parameter_array`` (476-578: ``parameters_to_remove``,
             ``parameters_to_add`` from the supplementary parameters, repetition per scatter copy, deleted rows,
             ``parameter_transformations``).
-        Outside the accelerated path (``ValueError``): asinh / other flux units, extra feature expressions, empirical noise
-        models, simulated missing fluxes, normalisation by a supplementary parameter.  ``seed`` replaces numpy's global
-        generator for the scatter noise and the ``max_rows`` draw."""
+          * ``normed_flux_units="asinh"`` (1591-1627, 1718-1732; utils.py:647-704; ``sf_flux_to_asinh``): softening
+            ``asinh_softening_parameters`` per filter in the grid's unit -- an array, a dict by filter name, or
+            ``"SNR_<k>"`` = k x depth / 5 when scattering with depths; no magnitude-limit clip there, as in the reference.
+        Outside the accelerated path (``ValueError``): other flux units, extra feature expressions, empirical noise
+        models, simulated missing fluxes, normalisation by a supplementary parameter or of asinh magnitudes.  ``seed``
+        replaces numpy's global generator for the scatter noise and the ``max_rows`` draw."""
         if self.raw_observation_grid is None:
             raise ValueError("no raw observation grid: build the fitter with init_from_hdf5 or pass feature_array")
-        if extra_features or normed_flux_units != "AB" or empirical_noise_models is not None or simulate_missing_fluxes:
-            raise ValueError("only normed_flux_units='AB' without extra features, empirical noise models or simulated "
-                             "missing fluxes is on the HIP path")
+        if extra_features or normed_flux_units not in ("AB", "asinh") or empirical_noise_models is not None or simulate_missing_fluxes:
+            raise ValueError("only normed_flux_units='AB' / 'asinh' without extra features, empirical noise models or "
+                             "simulated missing fluxes is on the HIP path")
+        asinh = normed_flux_units == "asinh"
+        if asinh and normalize_method is not None:
+            raise ValueError("normalisation of asinh magnitudes is outside the HIP path")
+        if asinh:
+            assert asinh_softening_parameters is not None, "asinh_softening_parameters must be provided for asinh normalization."
         if not torch.cuda.is_available():
             raise RuntimeError("create_feature_array_from_raw_photometry runs on the GPU (no CPU fallback)")
-        from .features import flux_to_abmag, scatter_depths
+        from .features import flux_to_abmag, flux_to_asinh, scatter_depths
         names = [str(n_) for n_ in self.raw_observation_names]
         grid = np.asarray(self.raw_observation_grid)                                    # (C, N)
         photometry_to_remove = list(photometry_to_remove or [])
@@ -165,7 +173,22 @@ class SBI_Fitter:
                 depths = np.asarray([depths[n_] for n_ in names], dtype=np.float32)
             self.phot_depths, self.min_flux_pc_error = depths, min_flux_pc_error
             flux, err = scatter_depths(flux, depths, n_sc, 5.0, min_flux_pc_error, seed=seed, return_errors=True)
-        mag, mag_err = flux_to_abmag(flux, err, norm_mag_limit) if err is not None else (flux_to_abmag(flux, None, norm_mag_limit), None)
+        if asinh:
+            if isinstance(asinh_softening_parameters, str):
+                assert asinh_softening_parameters.startswith("SNR_"), "If a string, asinh_softening_parameters must start with 'SNR_'."
+                assert n_sc and depths is not None, ("If setting asinh_softening_parameters from noise models, "
+                                                     "depths or empirical_noise_models must be provided.")
+                fb = float(asinh_softening_parameters.split("_")[-1]) * np.asarray(depths, dtype=np.float64).reshape(-1) / 5.0
+            elif isinstance(asinh_softening_parameters, dict):
+                fb = np.asarray([asinh_softening_parameters[n_] for n_ in names], dtype=np.float64)
+            else:
+                fb = np.asarray(asinh_softening_parameters, dtype=np.float64).reshape(-1)
+            if fb.size not in (1, len(names)):
+                raise AssertionError("asinh_softening_parameter must be a list of the same length as the number of photometry filters.")
+            fb = np.broadcast_to(fb, (len(names),)).astype(np.float32)
+            mag, mag_err = flux_to_asinh(flux, fb, err) if err is not None else (flux_to_asinh(flux, fb, None), None)
+        else:
+            mag, mag_err = flux_to_abmag(flux, err, norm_mag_limit) if err is not None else (flux_to_abmag(flux, None, norm_mag_limit), None)
         norm_col, norm_name = None, None
         if normalize_method is not None:
             if normalize_method not in names:
@@ -191,13 +214,14 @@ class SBI_Fitter:
             zero_norm = (ref.reshape(-1) == 0)
             names = [names[i] for i in keep]
             norm_name = f"norm_{normalize_method}_{normalization_unit}"
-        mag = torch.where(mag > norm_mag_limit, torch.full_like(mag, norm_mag_limit), mag)   # 1927-1932
-        cols, feature_names, units = [mag], list(names), ["AB"] * len(names)
+        if not asinh:
+            mag = torch.where(mag > norm_mag_limit, torch.full_like(mag, norm_mag_limit), mag)   # 1927-1932 (AB only)
+        cols, feature_names, units = [mag], list(names), [normed_flux_units] * len(names)
         error_names = [f"unc_{n_}" for n_ in names] if mag_err is not None else []
         if mag_err is not None and include_errors_in_feature_array:
             cols.append(mag_err)
             feature_names += error_names
-            units += ["AB"] * len(error_names)
+            units += [normed_flux_units] * len(error_names)
         if norm_col is not None:
             cols.append(norm_col.float().reshape(-1, 1))
             feature_names.append(norm_name)

@@ -405,6 +405,9 @@ def _library_fitter(C=6, N=400, D=3, seed=4):
     dict(normalize_method="F2", normalization_unit="AB", photometry_to_remove=["F5"]),
     dict(normalize_method="F0", normalization_unit="log10 nJy", scatter_fluxes=2, depths={f"F{i}": 20.0 + i for i in range(6)},
          include_errors_in_feature_array=True, drop_dropouts=True, drop_dropout_fraction=0.8),
+    dict(normed_flux_units="asinh", asinh_softening_parameters="SNR_2", scatter_fluxes=2,
+         depths=np.array([30., 40., 50., 60., 70., 80.]), include_errors_in_feature_array=True),
+    dict(normed_flux_units="asinh", asinh_softening_parameters={f"F{i}": 5.0 + i for i in range(6)}),
 ])
 def test_feature_array_from_raw_photometry_matches_the_oracle_restatement(opts):
     """ref: sbi_runner.py:1429-2222 (AB branch): scatter by depths, magnitudes + errors, colours relative to a filter, the
@@ -418,7 +421,12 @@ def test_feature_array_from_raw_photometry_matches_the_oracle_restatement(opts):
     dep = o.pop("depths", None)
     if isinstance(dep, dict):
         dep = np.array([dep[n] for n in names if n not in o.get("photometry_to_remove", [])])
-    ref, rnames, deleted = OFE.feature_array_ab(grid, names, normalize_method=o.get("normalize_method"),
+    fb = o.get("asinh_softening_parameters")
+    if isinstance(fb, str):
+        fb = float(fb.split("_")[-1]) * np.asarray(dep) / 5.0
+    elif isinstance(fb, dict):
+        fb = np.array([fb[n] for n in names])
+    ref, rnames, deleted = OFE.feature_array_ab(grid, names, asinh_f_b=fb, normalize_method=o.get("normalize_method"),
                                                 normalization_unit=o.get("normalization_unit", "AB"),
                                                 scatter_fluxes=o.get("scatter_fluxes", 0), depths=dep,
                                                 include_errors=o.get("include_errors_in_feature_array", False),
@@ -440,7 +448,7 @@ def test_feature_array_from_raw_photometry_matches_the_oracle_restatement(opts):
     assert f.fitted_parameter_names == ["tanh_p0", "p2", "sfr"] and f.fitted_parameter_units == ["tanh(u)", "u", "Msun/yr"]
     assert f.fitted_parameter_array.shape == (feat.shape[0], 3) and np.allclose(f.fitted_parameter_array, want)
     nb = len(f.feature_array_flags["raw_observation_names"])
-    assert f.feature_units[:nb] == ["AB"] * nb and len(f.feature_units) == feat.shape[1]
+    assert f.feature_units[:nb] == [opts.get("normed_flux_units", "AB")] * nb and len(f.feature_units) == feat.shape[1]
 
 
 def test_feature_array_argument_errors_follow_the_reference():
@@ -454,6 +462,8 @@ def test_feature_array_argument_errors_follow_the_reference():
     with pytest.raises(ValueError, match="not found in supplementary parameters"):
         f.create_feature_array_from_raw_photometry(parameters_to_add=["age"])
     with pytest.raises(ValueError, match="HIP path"):
+        f.create_feature_array_from_raw_photometry(normed_flux_units="log10 nJy")
+    with pytest.raises(AssertionError, match="asinh_softening_parameters must be provided"):
         f.create_feature_array_from_raw_photometry(normed_flux_units="asinh")
     feat, _ = f.create_feature_array_from_raw_photometry(max_rows=50, seed=2, verbose=False)
     assert feat.shape == (50, 6) and f.fitted_parameter_array.shape == (50, 3)
