@@ -785,26 +785,50 @@ class SBI_Fitter:
         return (table, samples) if return_samples else table
 
     def evaluate_model(self, posteriors=None, X_test=None, y_test=None, num_samples: int = 1000,
-                       independent_metrics: bool = True, seed: Optional[int] = None, **unused) -> dict:
-        """Flow-derived metrics of the reference's evaluate_model (sbi_runner.py:6484-6735): per-parameter
-        MSE / RMSE / R^2 of the posterior mean, mean log-prob, PIT (7128-7160)."""
+                       independent_metrics: bool = True, seed: Optional[int] = None, samples=None,
+                       verbose: bool = False, **unused) -> dict:
+        """The reference's evaluate_model for flow posteriors (sbi_runner.py:6484-6735), same keys and arithmetic:
+        ``MSE``, ``RMSE``, ``mean_ae``, ``median_ae``, ``R_squared`` (total sum of squares about the GLOBAL mean of
+        y_test, as there), ``RMSE_norm`` / ``mean_ae_norm`` (divided by the global std), ``log_dpit_max``
+        (-0.5 log max |PIT - uniform|, 6613-6616) and ``mean_log_prob``; per parameter with ``independent_metrics``, else
+        pooled.  ``tarp`` needs the third-party ``tarp`` package and is left out.  The draws stay on the device: means,
+        medians and PIT ranks are reduced there and only (N, D) summaries cross PCIe."""
         posteriors = posteriors if posteriors is not None else self.posteriors
         X_test = self._X_test if X_test is None else X_test
         y_test = self._y_test if y_test is None else y_test
-        # draws stay on the device: only (N, D) summaries cross PCIe
-        X32 = torch.as_tensor(np.asarray(X_test, dtype=np.float32))
-        sd = posteriors.sample_catalogue(X32, num_samples, seed)
-        mean = torch.nanmean(sd, dim=1).double().cpu().numpy()
+        if isinstance(samples, str):
+            samples = np.load(samples)
+        if samples is not None:
+            if samples.shape[1] != num_samples:
+                raise ValueError(f"Samples must have {num_samples} samples per test sample, but got {samples.shape[1]}.")
+            sd = torch.as_tensor(np.asarray(samples, dtype=np.float32)).to(self.device)
+        else:
+            sd = posteriors.sample_catalogue(torch.as_tensor(np.asarray(X_test, dtype=np.float32)), num_samples, seed)
+        mean_pred = torch.nanmean(sd, dim=1).double().cpu().numpy()
+        from .posterior import device_quantiles as _dq
+        median_pred = _dq(sd, (0.5,)).double().cpu().numpy()[:, :, 0]       # numpy's rule (sf_quantiles), NaN-aware
         y = np.asarray(y_test, dtype=np.float64)
-        mse = np.nanmean((mean - y) ** 2, 0)
-        ss_tot = np.sum((y - y.mean(0)) ** 2, 0)
-        r2 = 1.0 - np.nansum((mean - y) ** 2, 0) / np.where(ss_tot > 0, ss_tot, np.nan)
-        lp = self.log_prob(X_test, y_test, posteriors=posteriors, norm_posterior=False)
-        from .features import pit_ranks
-        pit = pit_ranks(sd, torch.as_tensor(y, dtype=torch.float32)).double().cpu().numpy()
-        metrics = {"mse": mse.tolist(), "rmse": np.sqrt(mse).tolist(), "r_squared": r2.tolist(),
-                   "mean_log_prob": float(np.mean(lp[np.isfinite(lp)])) if np.isfinite(lp).any() else float("nan"),
-                   "pit_mean": np.nanmean(pit, 0).tolist(), "pit_std": np.nanstd(pit, 0).tolist()}
+        axis = 0 if independent_metrics else None
+        ss_res = np.sum((y - mean_pred) ** 2, axis=axis)
+        ss_tot = np.sum((y - np.mean(y)) ** 2, axis=axis)
+        pit = self.calculate_PIT(X_test, y, samples=sd, posteriors=posteriors)
+        dpit_max = np.max(np.abs(pit - np.linspace(0, 1, len(pit))))
+        metrics = {"MSE": np.mean((y - mean_pred) ** 2, axis=axis),
+                   "RMSE": np.sqrt(np.mean((y - mean_pred) ** 2, axis=axis)),
+                   "mean_ae": np.mean(np.abs(y - mean_pred), axis=axis),
+                   "median_ae": np.median(np.abs(y - median_pred), axis=axis),
+                   "R_squared": 1 - (ss_res / ss_tot),
+                   "RMSE_norm": np.sqrt(np.mean((y - mean_pred) ** 2, axis=axis)) / np.std(y),
+                   "mean_ae_norm": np.mean(np.abs(y - mean_pred), axis=axis) / np.std(y),
+                   "log_dpit_max": float(-0.5 * np.log(dpit_max))}
+        try:
+            metrics["mean_log_prob"] = float(np.mean(self.log_prob(X_test, y_test, posteriors=posteriors)))
+        except Exception:
+            pass
+        metrics = {k: (v.tolist() if isinstance(v, np.ndarray) else float(v)) for k, v in metrics.items()}
+        if verbose:
+            for k, v in metrics.items():
+                logger.info(f"{k}: {v}")
         self.last_metrics = metrics
         return metrics
 
@@ -817,6 +841,8 @@ class SBI_Fitter:
         posteriors = posteriors if posteriors is not None else self.posteriors
         if samples is None:
             sd = posteriors.sample_catalogue(torch.as_tensor(np.asarray(X, dtype=np.float32)), num_samples, seed)
+        elif isinstance(samples, torch.Tensor):
+            sd = samples.to(self.device).float()
         else:
             sd = torch.as_tensor(np.asarray(samples, dtype=np.float32)).to(self.device)
         y2 = np.asarray(y, dtype=np.float32).reshape(sd.shape[0], -1)

@@ -292,8 +292,22 @@ def test_calculate_pit_matches_reference_definition(fitted):
     ref = np.sort(np.array([np.mean(s[i] < y[i]) for i in range(len(y))]))     # sbi_runner.py:7153-7158
     ref = ref / ref[-1]
     assert pit.shape == (64,) and np.abs(pit - ref).max() < 1e-6
-    m = f.evaluate_model(X_test=X, y_test=y, num_samples=200, seed=11)
-    assert len(m["pit_mean"]) == y.shape[1] and all(0.0 <= v <= 1.0 for v in m["pit_mean"])
+    # evaluate_model: the reference's keys and arithmetic (sbi_runner.py:6596-6639) on the same draws
+    m = f.evaluate_model(X_test=X, y_test=y, num_samples=200, samples=s)
+    mean_pred, median_pred = s.mean(1), np.median(s, 1)
+    ss_res, ss_tot = np.sum((y - mean_pred) ** 2, 0), np.sum((y - np.mean(y)) ** 2, 0)
+    want = {"MSE": np.mean((y - mean_pred) ** 2, 0), "RMSE": np.sqrt(np.mean((y - mean_pred) ** 2, 0)),
+            "mean_ae": np.mean(np.abs(y - mean_pred), 0), "median_ae": np.median(np.abs(y - median_pred), 0),
+            "R_squared": 1 - ss_res / ss_tot, "RMSE_norm": np.sqrt(np.mean((y - mean_pred) ** 2, 0)) / np.std(y),
+            "mean_ae_norm": np.mean(np.abs(y - mean_pred), 0) / np.std(y)}
+    for k, v in want.items():
+        assert np.allclose(m[k], v, rtol=2e-5, atol=1e-6), k
+    assert abs(m["log_dpit_max"] + 0.5 * np.log(np.max(np.abs(ref - np.linspace(0, 1, 64))))) < 1e-5
+    assert np.isfinite(m["mean_log_prob"]) and "tarp" not in m
+    pooled = f.evaluate_model(X_test=X, y_test=y, num_samples=200, samples=s, independent_metrics=False)
+    assert isinstance(pooled["MSE"], float) and abs(pooled["MSE"] / np.mean((y - mean_pred) ** 2) - 1.0) < 1e-5
+    with pytest.raises(ValueError, match="Samples must have 100 samples"):
+        f.evaluate_model(X_test=X, y_test=y, num_samples=100, samples=s)
 
 
 def test_scatter_depths_with_depth_sets():
