@@ -104,6 +104,15 @@ class SBI_Fitter:
                    supplementary_parameter_units=list(output.get("supplementary_parameter_units", [])),
                    observation_type=otype, **kwargs)
 
+    def create_feature_array(self, flux_units: str = "AB", extra_features: list = None, **kwargs):
+        """ref: sbi_runner.py:1065-1094 -- the simple wrapper: no noise, every filter of the library."""
+        if self.observation_type == "photometry":
+            return self.create_feature_array_from_raw_photometry(normed_flux_units=flux_units, extra_features=extra_features,
+                                                                 **kwargs)
+        if self.observation_type == "spectra":
+            raise ValueError("feature arrays from raw spectra are outside the HIP path")
+        raise ValueError(f"Observation type {self.observation_type} not supported. Please use 'photometry' or 'spectra'.")
+
     def create_feature_array_from_raw_photometry(self, normalize_method: Optional[str] = None, extra_features: list = None,
                                                  normed_flux_units: str = "AB", normalization_unit: str = "AB",
                                                  verbose: bool = True, scatter_fluxes: Union[int, bool] = False,

@@ -481,3 +481,5 @@ def test_feature_array_argument_errors_follow_the_reference():
         f.create_feature_array_from_raw_photometry(normed_flux_units="asinh")
     feat, _ = f.create_feature_array_from_raw_photometry(max_rows=50, seed=2, verbose=False)
     assert feat.shape == (50, 6) and f.fitted_parameter_array.shape == (50, 3)
+    feat2, names2 = f.create_feature_array(flux_units="AB", verbose=False)      # the simple wrapper (sbi_runner.py:1065-1094)
+    assert feat2.shape[1] == 6 and names2 == [f"F{i}" for i in range(6)]
