@@ -727,22 +727,29 @@ class SBI_Fitter:
                       quantiles=(0.16, 0.5, 0.84), sample_method: str = "direct", append_to_input: bool = True,
                       return_samples: bool = False, log_times: bool = False, seed: Optional[int] = None,
                       device_quantiles: bool = True, flux_units=None, missing_data_flag=-99,
-                      override_transformations: dict = {}, **unused):
+                      override_transformations: dict = {}, timeout_seconds_per_row: float = 5,
+                      return_feature_array: bool = False, return_full_samples: bool = False, **unused):
         """Sampling + quantile section of the reference's fit_catalogue (sbi_runner.py:3230-3282).
 
         ``observations`` is a pandas DataFrame / dict of columns / (N, C) array.  With ``flux_units`` given and a feature
         array that was built by ``create_feature_array_from_raw_photometry`` the table goes through
         ``create_features_from_observations`` first (3061-3068: column mapping, normalisation, missing-data rows);
-        otherwise its columns are taken as the model's feature columns.  Masked rows get NaN quantiles."""
+        otherwise its columns are taken as the model's feature columns.  Masked rows get NaN quantiles.
+        ``timeout_seconds_per_row`` (reference default 5 s) x rows is the wall-clock ceiling of the catalogue call
+        (sbi_runner.py:3246-3253); ``return_feature_array`` returns (feature_array, mask) like line 3092-3094;
+        ``return_full_samples`` is the reference's name for ``return_samples``."""
         import pandas as pd
+        return_samples = return_samples or return_full_samples
         if flux_units is not None and getattr(self, "feature_array_flags", None):
             df0 = pd.DataFrame(observations) if isinstance(observations, dict) else observations
             feats_ok, removed = self.create_features_from_observations(df0, columns_to_feature_names, flux_units,
                                                                        missing_data_flag, override_transformations)
+            if return_feature_array:
+                return feats_ok, removed
             full = np.full((len(df0), feats_ok.shape[1]), np.nan, dtype=np.float32)
             full[~removed] = feats_ok
             out = self.fit_catalogue(full, None, num_samples, quantiles, sample_method, False, return_samples, log_times,
-                                     seed, device_quantiles)
+                                     seed, device_quantiles, timeout_seconds_per_row=timeout_seconds_per_row)
             qt = out[0] if return_samples else out
             table = df0.copy() if append_to_input else pd.DataFrame({"ID": np.arange(len(df0)) + 1})
             for c in qt.columns:
@@ -763,6 +770,9 @@ class SBI_Fitter:
             raise ValueError(f"observations lack the feature columns {missing}")
         feats = df[cols].to_numpy(dtype=np.float32)
         obs_mask = ~np.isfinite(feats).all(1)
+        if return_feature_array:
+            return feats[~obs_mask], obs_mask
+        tmo = float(timeout_seconds_per_row) * max(1, int((~obs_mask).sum())) if timeout_seconds_per_row else None
         if device_quantiles and not return_samples and num_samples <= 8192:
             # f3: quantiles reduced on the GPU; only (N, D, Q) floats cross PCIe
             from .posterior import device_quantiles as _dq
@@ -771,7 +781,8 @@ class SBI_Fitter:
             if (~obs_mask).any():
                 if sample_method != "direct":
                     raise ValueError("Invalid sample method for the HIP backend. Use 'direct'.")
-                s_dev = self.posteriors.sample_catalogue(torch.as_tensor(feats[~obs_mask]), num_samples, seed)
+                s_dev = self.posteriors.sample_catalogue(torch.as_tensor(feats[~obs_mask]), num_samples, seed,
+                                                         timeout_seconds=tmo)
                 qarr[~obs_mask] = _dq(s_dev, quantiles).double().cpu().numpy()
             for i, param in enumerate(self.simple_fitted_parameter_names):
                 for j, qv in enumerate(quantiles):
@@ -780,7 +791,8 @@ class SBI_Fitter:
         samples = np.full((len(df), num_samples, len(self.fitted_parameter_names)), np.nan)
         if (~obs_mask).any():
             samples[~obs_mask] = self.sample_posterior(feats[~obs_mask], sample_method=sample_method,
-                                                       num_samples=num_samples, log_times=log_times, seed=seed)
+                                                       num_samples=num_samples, log_times=log_times, seed=seed,
+                                                       timeout_seconds_per_test=timeout_seconds_per_row)
         samples_quant = samples.transpose(2, 0, 1)
         table = df.copy() if append_to_input else pd.DataFrame({"ID": np.arange(len(df)) + 1})
         for i, param in enumerate(self.simple_fitted_parameter_names):

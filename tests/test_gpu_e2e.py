@@ -395,6 +395,11 @@ def test_library_file_to_trained_posterior(tmp_path):
     assert table.loc[3, qcols].isna().all() and table.drop(index=3)[qcols].notna().all().all()
     # rows 0-2 sit at the same catalogue positions in both calls: same slots, same draws, same quantiles
     assert np.allclose(table.loc[:2, qcols].to_numpy(float), direct.loc[:2, qcols].to_numpy(float), rtol=1e-6)
+    fa, mask = f.fit_catalogue(obs, columns_to_feature_names=cmap, flux_units="AB", return_feature_array=True)
+    assert fa.shape == (7, 10) and mask.tolist() == [False, False, False, True, False, False, False, False]
+    tq, full = f.fit_catalogue(obs, columns_to_feature_names=cmap, flux_units="AB", num_samples=64, seed=5,
+                               return_full_samples=True, timeout_seconds_per_row=30)
+    assert full.shape == (8, 64, 5) and np.isnan(full[3]).all() and np.isfinite(np.delete(full, 3, axis=0)).all()
 
 
 def _library_fitter(C=6, N=400, D=3, seed=4):
