@@ -748,8 +748,10 @@ class SBI_Fitter:
                 return feats_ok, removed
             full = np.full((len(df0), feats_ok.shape[1]), np.nan, dtype=np.float32)
             full[~removed] = feats_ok
-            out = self.fit_catalogue(full, None, num_samples, quantiles, sample_method, False, return_samples, log_times,
-                                     seed, device_quantiles, timeout_seconds_per_row=timeout_seconds_per_row)
+            out = self.fit_catalogue(full, columns_to_feature_names=None, num_samples=num_samples, quantiles=quantiles,
+                                     sample_method=sample_method, append_to_input=False, return_samples=return_samples,
+                                     log_times=log_times, seed=seed, device_quantiles=device_quantiles,
+                                     timeout_seconds_per_row=timeout_seconds_per_row)
             qt = out[0] if return_samples else out
             table = df0.copy() if append_to_input else pd.DataFrame({"ID": np.arange(len(df0)) + 1})
             for c in qt.columns:
