@@ -114,6 +114,13 @@ int sf_flow_pack_table16(const sf_flow* f, int32_t* src1, int32_t* src2, int64_t
  * bf16 element i (part 0: hi = bf16(w), part 1: lo = bf16(w - hi)), -1 = zero; size 0 when the flow has none */
 int64_t sf_flow_packed16b_size(const sf_flow* f);
 int sf_flow_pack_table16b(const sf_flow* f, int32_t* src, int64_t n);
+/* cooperative 16-row training image (MAF, num_blocks 2, D <= 8; csrc/sf_layout.h SfTrcDev): sizes (0 when the flow has
+ * none), gather table, logical parameter -> gradient-partial index, and the descriptor as int32 words in declaration order */
+int64_t sf_flow_trainc_size(const sf_flow* f);
+int64_t sf_flow_trainc_grad_size(const sf_flow* f);
+int sf_flow_trainc_table(const sf_flow* f, int32_t* src1, int32_t* src2, int64_t n, int32_t* gdst, int64_t n_params,
+                         int32_t* desc /*[64]*/, float* cst, int64_t n_cst);
+int64_t sf_flow_cst_size(const sf_flow* f);
 /* byte-for-byte description of the packed image for diagnostics (JSON, NUL-terminated) */
 int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen);
 

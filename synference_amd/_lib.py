@@ -63,6 +63,11 @@ PROTOTYPES = {
     "sf_flow_packed16_size": (C.c_int64, [C.c_void_p]),
     "sf_flow_pack_table16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "sf_flow_packed16b_size": (C.c_int64, [C.c_void_p]),
+    "sf_flow_trainc_size": (C.c_int64, [C.c_void_p]),
+    "sf_flow_trainc_grad_size": (C.c_int64, [C.c_void_p]),
+    "sf_flow_cst_size": (C.c_int64, [C.c_void_p]),
+    "sf_flow_trainc_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                       C.c_void_p, C.c_int64]),
     "sf_flow_pack_table16b": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "sf_flow_get_params": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "sf_flow_prepare_context": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

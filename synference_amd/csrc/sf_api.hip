@@ -103,6 +103,7 @@ void sf_flow_destroy(sf_flow* f) {
     (void)hipFree(f->d_ctab); (void)hipFree(f->d_packed16B); (void)hipFree(f->d_s16B); (void)hipFree(f->d_packed16); (void)hipFree(f->d_s16a); (void)hipFree(f->d_s16b);
     (void)hipFree(f->d_s1); (void)hipFree(f->d_s2); (void)hipFree(f->d_t1); (void)hipFree(f->d_t2);
     (void)hipFree(f->d_flat); (void)hipFree(f->d_gpacked); (void)hipFree(f->d_gdst);
+    (void)hipFree(f->d_imgC); (void)hipFree(f->d_sC1); (void)hipFree(f->d_sC2); (void)hipFree(f->d_gdstC); (void)hipFree(f->d_gpartC);
     (void)hipFree(f->d_queue); (void)hipFree(f->d_ring); (void)hipFree(f->d_galacc); (void)hipFree(f->d_best); (void)hipHostFree(f->h_queue);
     (void)hipFree(f->d_act); (void)hipFree(f->d_rej[0]); (void)hipFree(f->d_rej[1]); (void)hipFree(f->d_cnt);
   }
@@ -136,6 +137,24 @@ int sf_flow_pack_table16b(const sf_flow* f, int32_t* src, int64_t n) {
   if (!f || !src) return fail(SF_ERR_INVALID, "null argument");
   if (!f->L.dev.m16_ok || n != f->L.n_packed16B) return fail(SF_ERR_INVALID, "no split-bf16 image or size mismatch");
   std::memcpy(src, f->L.src16B.data(), (size_t)n * sizeof(int32_t));
+  return SF_OK;
+}
+
+int64_t sf_flow_trainc_size(const sf_flow* f) { return (f && f->L.trc.ok) ? f->L.n_imgC : 0; }
+int64_t sf_flow_trainc_grad_size(const sf_flow* f) { return (f && f->L.trc.ok) ? f->L.n_gradC : 0; }
+int64_t sf_flow_cst_size(const sf_flow* f) { return f ? (int64_t)f->L.cst.size() : 0; }
+int sf_flow_trainc_table(const sf_flow* f, int32_t* src1, int32_t* src2, int64_t n, int32_t* gdst, int64_t n_params,
+                         int32_t* desc, float* cst, int64_t n_cst) {
+  if (!f || !src1 || !src2 || !gdst || !desc || !cst) return fail(SF_ERR_INVALID, "null argument");
+  if (!f->L.trc.ok || n != f->L.n_imgC || n_params != f->L.n_params || n_cst != (int64_t)f->L.cst.size())
+    return fail(SF_ERR_INVALID, "no cooperative training image or size mismatch");
+  static_assert(sizeof(SfTrcDev) <= 64 * sizeof(int32_t), "descriptor words");
+  std::memcpy(src1, f->L.srcC1.data(), (size_t)n * sizeof(int32_t));
+  std::memcpy(src2, f->L.srcC2.data(), (size_t)n * sizeof(int32_t));
+  std::memcpy(gdst, f->L.gdstC.data(), (size_t)n_params * sizeof(int32_t));
+  std::memset(desc, 0, 64 * sizeof(int32_t));
+  std::memcpy(desc, &f->L.trc, sizeof(SfTrcDev));
+  std::memcpy(cst, f->L.cst.data(), (size_t)n_cst * sizeof(float));
   return SF_OK;
 }
 

@@ -97,6 +97,12 @@ struct sf_flow {
   float* d_gpacked = nullptr;   // gradient image replicas (accumulation target)
   size_t gpacked_cap = 0;       // floats
   int32_t* d_gdst = nullptr;    // logical parameter -> gradient image index
+  // cooperative 16-row training path (sf_trainc.hip): operand image, its gather table, gradient partials
+  float* d_imgC = nullptr;
+  int32_t *d_sC1 = nullptr, *d_sC2 = nullptr, *d_gdstC = nullptr;
+  float* d_gpartC = nullptr;
+  size_t gpartC_cap = 0;        // floats
+  bool trainc_ready = false;
   float* d_act = nullptr;       // activation stash (training)
   size_t act_cap = 0;           // floats
   uint32_t* d_rej[2] = {nullptr, nullptr};

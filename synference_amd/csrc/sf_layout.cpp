@@ -90,6 +90,7 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
   const int D = d.D, C = d.C, H = d.H, T = d.T, NB = d.NB, K = d.K;
   SfDev& v = L.dev;
   std::memset(&v, 0, sizeof(v));
+  std::memset(&L.trc, 0, sizeof(L.trc));
   v.kind = d.kind; v.D = D; v.C = C; v.H = H; v.T = T; v.K = K; v.NB = NB;
   v.scale_fn = d.scale_fn;
   v.HT = ceil_div(H, 32);
@@ -490,6 +491,149 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
           }
         }
       }
+      // ---- cooperative 16-row training image (sf_layout.h, SfTrcDev; sf_trainc.hip) -------------------------
+      if (v.m16_ok && NB == 2 && D <= 8) {
+        SfTrcDev& c = L.trc;
+        const int NT = v.nT16;
+        if (t == 0) {
+          c.ok = 1;
+          c.NT = NT;
+          // rows of the input tiles: slot rows first (fixed), context features fill what is left
+          std::vector<int> insrc(16, -1);
+          int f = 0;
+          for (int rho = 0; rho < 16 && f < C; ++rho) {
+            const bool slot_row = (rho & 3) < 2 && 2 * (rho >> 2) + (rho & 3) < D;
+            if (!slot_row) insrc[rho] = f++;
+          }
+          while (f < C) {
+            for (int rho = 0; rho < 16; ++rho) insrc.push_back(f < C ? f++ : -1);
+          }
+          c.NI = (int)insrc.size() / 16;
+          c.c_insrc = (int)L.cst.size();
+          for (int q : insrc) L.cst.push_back((float)q);
+          // unmasked hidden blocks and the tile bounds they imply
+          for (int ot = 0; ot < 4; ++ot) { c.kend[ot] = 0; c.kbeg[ot] = NT > 0 ? NT - 1 : 0; }
+          c.c_jobs = (int)L.cst.size();
+          c.n_jobs = 0;
+          for (int ot = 0; ot < NT; ++ot)
+            for (int it = 0; it < NT; ++it) {
+              bool any = false;
+              for (int ro = 0; ro < 16 && !any; ++ro)
+                for (int ri = 0; ri < 16 && !any; ++ri) {
+                  const int oo = h16row[ot * 16 + ro], ii = h16row[it * 16 + ri];
+                  any = oo >= 0 && ii >= 0 && deg_h(oo) >= deg_h(ii);
+                }
+              if (any) {
+                c.kend[ot] = std::max(c.kend[ot], it);
+                c.kbeg[it] = std::min(c.kbeg[it], ot);
+                L.cst.push_back((float)(ot * 4 + it));
+                ++c.n_jobs;
+              }
+            }
+          while (L.cst.size() % 4) L.cst.push_back(0.f);
+        }
+        const int NI = c.NI;
+        auto insrc_at = [&](int it, int rho) { return (int)L.cst[c.c_insrc + it * 16 + rho]; };
+        auto pushC = [&](int32_t a, int32_t b) { L.srcC1.push_back(a); L.srcC2.push_back(b); };
+        while (L.srcC1.size() % 256) pushC(-1, -1);
+        const int64_t tbC = (int64_t)L.srcC1.size();
+        if (t == 1) c.t_stride = (int)tbC;
+        auto hereC = [&]() { return (int)((int64_t)L.srcC1.size() - tbC); };
+        int64_t gcur = 0;                                  // cursor in this transform's gradient partial
+        const int64_t gbase_t = (int64_t)t * c.g_stride;   // (g_stride is known from t = 0 on)
+        // logical index of W[(to, ro)][(ti, ri)] for every layer, -1 = structural zero
+        auto w_in = [&](int to, int ro, int ti, int ri) -> int64_t {
+          const int oo = h16row[to * 16 + ro];
+          if (oo < 0) return -1;
+          if (ti == 0 && (ri & 3) < 2) {
+            const int p = 2 * (ri >> 2) + (ri & 3);
+            if (p < D) return deg_h(oo) >= sinv[p] + 1 ? lW0 + (int64_t)oo * D + sinv[p] : -1;
+          }
+          const int fsrc = insrc_at(ti, ri);
+          return fsrc >= 0 ? lWc + (int64_t)oo * C + fsrc : -1;
+        };
+        auto w_hid = [&](int64_t base) {
+          return [&, base](int to, int ro, int ti, int ri) -> int64_t {
+            const int oo = h16row[to * 16 + ro], ii = h16row[ti * 16 + ri];
+            return (oo >= 0 && ii >= 0 && deg_h(oo) >= deg_h(ii)) ? base + (int64_t)oo * H + ii : -1;
+          };
+        };
+        auto head_row = [&](int ro) -> int {  // logical output row of head-tile row ro, -1 = padding
+          const int p = 2 * (ro >> 2) + (ro & 1);
+          if (p >= D) return -1;
+          return 2 * sinv[p] + ((ro & 3) >= 2 ? 1 : 0);
+        };
+        auto w_head = [&](int /*to*/, int ro, int ti, int ri) -> int64_t {
+          const int orow_l = head_row(ro), ii = h16row[ti * 16 + ri];
+          return (orow_l >= 0 && ii >= 0 && (orow_l / 2 + 1) > deg_h(ii)) ? lWf + (int64_t)orow_l * H + ii : -1;
+        };
+        using WFn = std::function<int64_t(int, int, int, int)>;
+        auto fwd_block = [&](int OT, int IT, const WFn& fn, int64_t g_off) {
+          for (int ot = 0; ot < OT; ++ot)
+            for (int it = 0; it < IT; ++it)
+              for (int l = 0; l < 64; ++l)
+                for (int r = 0; r < 4; ++r) {
+                  const int ro = l & 15, ri = 4 * (l >> 4) + r;
+                  const int64_t idx = fn(ot, ro, it, ri);
+                  pushC((int32_t)idx, -1);
+                  if (idx >= 0) L.gdstC[(size_t)idx] = (int32_t)(gbase_t + g_off + ((int64_t)ot * IT + it) * 256 + (ro & 3) * 64 + (ro >> 2) * 16 + ri);
+                }
+        };
+        auto tr_block = [&](int ITr, int OTk, const WFn& fn) {  // rows = forward input tiles, K = forward output tiles
+          for (int it = 0; it < ITr; ++it)
+            for (int ot = 0; ot < OTk; ++ot)
+              for (int l = 0; l < 64; ++l)
+                for (int r = 0; r < 4; ++r) pushC((int32_t)fn(ot, 4 * (l >> 4) + r, it, l & 15), -1);
+        };
+        auto bias_block = [&](int OT, const std::function<int64_t(int, int)>& f1, const std::function<int64_t(int, int)>& f2,
+                              int64_t g_off) {
+          for (int ot = 0; ot < OT; ++ot)
+            for (int ro = 0; ro < 16; ++ro) {
+              const int64_t a1 = f1(ot, ro), a2 = f2 ? f2(ot, ro) : -1;
+              pushC((int32_t)a1, (int32_t)a2);
+              const int32_t g = (int32_t)(gbase_t + g_off + ot * 16 + ro);
+              if (a1 >= 0) L.gdstC[(size_t)a1] = g;
+              if (a2 >= 0) L.gdstC[(size_t)a2] = g;
+            }
+        };
+        auto hid_bias = [&](int64_t base) {
+          return [&, base](int ot, int ro) -> int64_t { const int oo = h16row[ot * 16 + ro]; return oo >= 0 ? base + oo : -1; };
+        };
+        if (t == 0) L.gdstC.assign((size_t)0, -1);
+        if (L.gdstC.size() < (size_t)P) L.gdstC.resize((size_t)P, -1);   // P = end of this transform's logical block
+        // ---- forward blocks
+        int o; int64_t g;
+        o = hereC(); g = gcur; gcur += (int64_t)NT * NI * 256; fwd_block(NT, NI, w_in, g);
+        if (t == 0) { c.o_win = o; c.g_win = (int)g; }
+        o = hereC(); g = gcur; gcur += NT * 16; bias_block(NT, hid_bias(lb0), hid_bias(lbc), g);
+        if (t == 0) { c.o_b0 = o; c.g_b0 = (int)g; }
+        o = hereC(); g = gcur; gcur += (int64_t)NT * NT * 256; fwd_block(NT, NT, w_hid(lWk[0]), g);
+        if (t == 0) { c.o_w1 = o; c.g_w1 = (int)g; }
+        o = hereC(); g = gcur; gcur += NT * 16; bias_block(NT, hid_bias(lbk[0]), nullptr, g);
+        if (t == 0) { c.o_b1 = o; c.g_b1 = (int)g; }
+        o = hereC(); g = gcur; gcur += (int64_t)NT * NT * 256; fwd_block(NT, NT, w_hid(lWk[1]), g);
+        if (t == 0) { c.o_w2 = o; c.g_w2 = (int)g; }
+        o = hereC(); g = gcur; gcur += NT * 16; bias_block(NT, hid_bias(lbk[1]), nullptr, g);
+        if (t == 0) { c.o_b2 = o; c.g_b2 = (int)g; }
+        o = hereC(); g = gcur; gcur += (int64_t)NT * 256; fwd_block(1, NT, w_head, g);
+        if (t == 0) { c.o_wf = o; c.g_wf = (int)g; }
+        o = hereC(); g = gcur; gcur += 16;
+        bias_block(1, [&](int, int ro) -> int64_t { const int r_ = head_row(ro); return r_ >= 0 ? lbf + r_ : -1; }, nullptr, g);
+        if (t == 0) { c.o_bf = o; c.g_bf = (int)g; }
+        // ---- transposed blocks (data gradients)
+        o = hereC(); tr_block(NT, 1, w_head);
+        if (t == 0) c.o_wfT = o;
+        o = hereC(); tr_block(NT, NT, w_hid(lWk[1]));
+        if (t == 0) c.o_w2T = o;
+        o = hereC(); tr_block(NT, NT, w_hid(lWk[0]));
+        if (t == 0) c.o_w1T = o;
+        o = hereC(); tr_block(NI, NT, w_in);
+        if (t == 0) c.o_winT = o;
+        if (t == 0) {
+          c.g_stride = (int)((gcur + 63) / 64 * 64);
+          // (the gdstC entries written above used g_stride = 0 for t = 0: gbase_t = 0 either way)
+        }
+      }
     }
   } else {
     v.PT = K <= 11 ? 2 : 3;  // PT=1 (K<=5) is not instantiated: K<=11 shares the 2-tile layout
@@ -683,6 +827,13 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
       if (v.n_parts != 1 || need > budget)
         return fail("hidden_bf16: one transform's fp32 + bf16 operand images must fit the 152 KiB LDS budget");
     }
+  }
+  if (L.trc.ok) {
+    while (L.srcC1.size() % 256) { L.srcC1.push_back(-1); L.srcC2.push_back(-1); }
+    if (T == 1) L.trc.t_stride = (int)L.srcC1.size();
+    L.n_imgC = (int64_t)L.srcC1.size();
+    L.n_gradC = (int64_t)T * L.trc.g_stride;
+    L.gdstC.resize((size_t)P, -1);
   }
   L.n_packed = E.cur;
   L.n_packedT = ET.cur;

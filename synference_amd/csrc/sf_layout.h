@@ -92,8 +92,37 @@ struct SfDev {
   float tail_bound, min_w, min_h, min_d, eps, lu_eps, inv_sqrt_h, deriv_const;
 };
 
+// ---- cooperative 16-row training image (sf_trainc.hip; MAF, num_blocks = 2, D <= 8, <= 4 hidden tiles of 16 rows) ----
+// One workgroup = 8 waves = 64 samples; wave (grp, j) owns hidden tile j (grp 0) / NT-1-j (grp 1) of its group's 32
+// samples, the waves exchange activation tiles through LDS at every layer.  Tile = 16 rows x 16 samples in 4 VGPRs
+// (lane l: sample l & 15, rows 4*(l >> 4) + r), as in sf_maf16.hip.
+//   input tile 0, row 4*g4 + r:  r < 2 and 2*g4 + r < D -> physical slot 2*g4 + r of u; every other row of tile 0 and
+//                                all rows of tiles 1.. hold context features in increasing order (c_insrc, -1 = none)
+//   head tile (one 16-row output tile), row 4*g4 + r: r < 2 -> a of slot 2*g4 + r, r >= 2 -> m of slot 2*g4 + r - 2:
+//                                a lane's head outputs are exactly the (a, m) of the two slots it holds of u
+//   forward block   [ot][it][64 lanes][4]: lane l, component r = W[ot*16 + (l & 15)][it*16 + 4*(l >> 4) + r]
+//   transposed block[it][ot][64 lanes][4]: lane l, component r = W[ot*16 + 4*(l >> 4) + r][it*16 + (l & 15)]
+//   gradient block  [ot][it][4 regs][64 lanes]: the accumulator of dW = delta . in^T as it stands
+//                   (element (ro, ri) at (ro & 3) * 64 + (ro >> 2) * 16 + ri); bias gradients [tile*16 + row]
+struct SfTrcDev {
+  int ok;
+  int NT, NI;                    // hidden tiles, input tiles
+  int t_stride, g_stride;        // floats per transform: operand image / gradient partial
+  int o_win, o_b0, o_w1, o_b1, o_w2, o_b2, o_wf, o_bf;   // forward blocks (offsets from the transform base)
+  int o_wfT, o_w2T, o_w1T, o_winT;                       // transposed blocks
+  int g_win, g_b0, g_w1, g_b1, g_w2, g_b2, g_wf, g_bf;   // gradient partial
+  int kend[4];   // hidden output tile ot multiplies input tiles 0..kend[ot] (MADE masks; NT-1 = dense)
+  int kbeg[4];   // hidden input tile it receives gradient from output tiles kbeg[it]..NT-1
+  int c_insrc;   // constants image: [NI*16] float-encoded context feature of each input-tile row, -1 = none / slot row
+  int c_jobs, n_jobs;  // constants image: [n_jobs] float-encoded (ot*4 + it) of the unmasked hidden weight blocks
+};
+
 struct SfLayout {
   SfDev dev;  // pointers left null
+  SfTrcDev trc;                       // trc.ok == 0: no cooperative training image for this flow
+  std::vector<int32_t> srcC1, srcC2;  // its gather table (sum of two sources, like src1/src2)
+  std::vector<int32_t> gdstC;         // logical parameter -> index in a gradient partial (or -1)
+  int64_t n_imgC = 0, n_gradC = 0;
   int64_t n_params = 0;
   int64_t n_packed = 0;  // floats in packed (== floats in packedT)
   std::vector<int32_t> src1, src2;    // forward image gather table

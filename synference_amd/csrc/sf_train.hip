@@ -9,6 +9,7 @@
 
 #include "sf_internal.h"
 #include "sf_train_args.h"
+#include "sf_trainc.h"
 
 // ---------------------------------------------------------------------------------------------
 // clip_grad_norm_ + Adam
@@ -160,7 +161,8 @@ __global__ void k_train_prep(const float* __restrict__ flat, const int32_t* __re
                              const int32_t* __restrict__ t2, float* __restrict__ packedT, long n2,
                              float* __restrict__ gimg, int copies, float* __restrict__ dctx, long n4,
                              const int32_t* __restrict__ u1, const int32_t* __restrict__ u2, float* __restrict__ packed16,
-                             long n5, const int32_t* __restrict__ sB, unsigned short* __restrict__ packed16B, long n6) {
+                             long n5, const int32_t* __restrict__ sB, unsigned short* __restrict__ packed16B, long n6,
+                             const int32_t* __restrict__ c1, const int32_t* __restrict__ c2, float* __restrict__ imgC, long n7) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n1) {
     const int a = s1[i], b = s2[i];
@@ -201,6 +203,15 @@ __global__ void k_train_prep(const float* __restrict__ flat, const int32_t* __re
       r = __builtin_bit_cast(unsigned short, (a >> 30) & 1 ? (__bf16)(w - (float)hi) : hi);
     }
     packed16B[i] = r;
+    return;
+  }
+  i -= n6;
+  if (i < n7) {  // cooperative training image (sf_trainc.hip)
+    const int a = c1[i], b = c2[i];
+    float v = 0.f;
+    if (a >= 0) v = flat[a];
+    if (b >= 0) v += flat[b];
+    imgC[i] = v;
   }
 }
 
@@ -222,6 +233,75 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
                        float grad_scale, const float* weights, float* loss, double* loss_sum, float* grad, float* dctx,
                        hipStream_t st, std::string& err) {
   const SfLayout& L = f->L;
+  // ---- cooperative 16-row kernel (sf_trainc.hip): MAF, two blocks, D <= 8, T <= SF_TRC_TS, <= 4 hidden tiles
+  if (B > 0 && sf_trainc_eligible(L, dctx != nullptr)) {
+    if (!f->trainc_ready) {
+      auto undo = [&]() {
+        (void)hipFree(f->d_imgC); (void)hipFree(f->d_sC1); (void)hipFree(f->d_sC2); (void)hipFree(f->d_gdstC);
+        f->d_imgC = nullptr; f->d_sC1 = f->d_sC2 = f->d_gdstC = nullptr;
+      };
+#define SF_TRY_C(call)                                                       \
+  do {                                                                       \
+    hipError_t e_ = (call);                                                  \
+    if (e_ != hipSuccess) {                                                  \
+      err = std::string(#call) + ": " + hipGetErrorString(e_);               \
+      undo();                                                                \
+      return SF_ERR_HIP;                                                     \
+    }                                                                        \
+  } while (0)
+      SF_TRY_C(hipMalloc(&f->d_imgC, (size_t)L.n_imgC * sizeof(float)));
+      SF_TRY_C(hipMalloc(&f->d_sC1, (size_t)L.n_imgC * sizeof(int32_t)));
+      SF_TRY_C(hipMalloc(&f->d_sC2, (size_t)L.n_imgC * sizeof(int32_t)));
+      SF_TRY_C(hipMemcpy(f->d_sC1, L.srcC1.data(), (size_t)L.n_imgC * sizeof(int32_t), hipMemcpyHostToDevice));
+      SF_TRY_C(hipMemcpy(f->d_sC2, L.srcC2.data(), (size_t)L.n_imgC * sizeof(int32_t), hipMemcpyHostToDevice));
+      SF_TRY_C(hipMalloc(&f->d_gdstC, (size_t)L.n_params * sizeof(int32_t)));
+      SF_TRY_C(hipMemcpy(f->d_gdstC, L.gdstC.data(), (size_t)L.n_params * sizeof(int32_t), hipMemcpyHostToDevice));
+#undef SF_TRY_C
+      f->trainc_ready = true;
+    }
+    const int grid = sf_trainc_grid(B);
+    const size_t need = (size_t)grid * (size_t)L.n_gradC;
+    if (need > f->gpartC_cap) {
+      if (f->d_gpartC) SF_TRY(hipFree(f->d_gpartC));
+      f->d_gpartC = nullptr; f->gpartC_cap = 0;
+      SF_TRY(hipMalloc(&f->d_gpartC, need * sizeof(float)));
+      f->gpartC_cap = need;
+    }
+    {
+      const long n4 = dctx ? B * (long)L.dev.C : 0;
+      const long n5 = f->d_packed16 ? (long)L.n_packed16 : 0;
+      const long n6 = f->d_packed16B ? (long)L.n_packed16B : 0;
+      const long n7 = (long)L.n_imgC;
+      const long tot = (long)L.n_packed + n4 + n5 + n6 + n7;
+      hipLaunchKernelGGL(k_train_prep, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, flat, f->d_s1, f->d_s2, f->d_packed,
+                         (long)L.n_packed, (const int32_t*)nullptr, (const int32_t*)nullptr, (float*)nullptr, 0L, (float*)nullptr, 0,
+                         dctx, n4, f->d_s16a, f->d_s16b, f->d_packed16, n5, f->d_s16B, f->d_packed16B, n6, f->d_sC1, f->d_sC2,
+                         f->d_imgC, n7);
+      SF_TRY(hipGetLastError());
+    }
+    f->packed16_stale = false;
+    if (L.n_packedB > 0) SF_TRY(sf_launch_pack_bf16(flat, f->d_bsrc, f->d_packedB, (long)L.n_packedB, st));
+    SfTrcArgs a;
+    a.c = L.trc;
+    a.img = f->d_imgC; a.cst = f->d_cst;
+    a.D = L.dev.D; a.C = L.dev.C; a.T = L.dev.T; a.scale_fn = L.dev.scale_fn;
+    a.eps = L.dev.eps; a.logdet0 = L.dev.logdet0;
+    a.c_pscale = L.dev.c_pscale; a.c_pshift = L.dev.c_pshift; a.c_tdim = L.dev.c_tdim; a.c_xmean = L.dev.c_xmean; a.c_xstd = L.dev.c_xstd;
+    a.theta = theta; a.x = x; a.idx = idx; a.wts = weights; a.B = B; a.n_chunks = (B + 63) / 64; a.w = grad_scale;
+    a.loss = loss; a.loss_sum = loss_sum; a.dctx = dctx;
+    a.gpart = f->d_gpartC; a.gpart_stride = (long)L.n_gradC;
+    if (f->profiling) {
+      if (!f->ev_train[0]) { SF_TRY(hipEventCreate(&f->ev_train[0])); SF_TRY(hipEventCreate(&f->ev_train[1])); }
+      SF_TRY(hipEventRecord(f->ev_train[0], st));
+    }
+    SF_TRY(sf_launch_maf_trainc(a, grid, st));
+    if (f->profiling) {
+      SF_TRY(hipEventRecord(f->ev_train[1], st));
+      f->ev_train_valid = true;
+    }
+    SF_TRY(sf_launch_gather_c(f->d_gpartC, (long)L.n_gradC, grid, f->d_gdstC, grad, (long)L.n_params, st));
+    return SF_OK;
+  }
   // ---- lazily built training state
   if (!f->train_ready) {
     // all-or-nothing: a failed allocation frees what was already taken, so that the next call starts over instead of
@@ -283,7 +363,8 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
     const long tot = (long)L.n_packed + (long)L.n_packedT + n4 + n5 + n6;
     hipLaunchKernelGGL(k_train_prep, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, flat, f->d_s1, f->d_s2, f->d_packed,
                        (long)L.n_packed, f->d_t1, f->d_t2, f->d_packedT, (long)L.n_packedT, f->d_gpacked, copies, dctx, n4,
-                       f->d_s16a, f->d_s16b, f->d_packed16, n5, f->d_s16B, f->d_packed16B, n6);
+                       f->d_s16a, f->d_s16b, f->d_packed16, n5, f->d_s16B, f->d_packed16B, n6, (const int32_t*)nullptr,
+                       (const int32_t*)nullptr, (float*)nullptr, 0L);
     SF_TRY(hipGetLastError());
   }
   f->packed16_stale = false;

@@ -1,0 +1,34 @@
+// sf_trainc.h -- cooperative 16-row MAF training kernel (sf_trainc.hip): argument block and launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sf_layout.h"
+
+#define SF_TRC_TS 5  // transforms whose a1 / a2 tiles a wave keeps in registers (flows with more take k_maf_train)
+
+struct SfTrcArgs {
+  SfTrcDev c;
+  const float* img;   // cooperative operand image (SfLayout::srcC1/2), all transforms
+  const float* cst;   // constants image (sf_layout.cpp)
+  int D, C, T, scale_fn;
+  float eps, logdet0;
+  int c_pscale, c_pshift, c_tdim, c_xmean, c_xstd;
+  const float* theta;
+  const float* x;
+  const long long* idx;  // optional [B]: batch row b reads library row idx[b]
+  const float* wts;      // optional per-sample weights [B] (multiplied by w)
+  long B, n_chunks;      // n_chunks = ceil(B / 64)
+  float w;
+  float* loss;           // [B] or null
+  double* loss_sum;      // optional device scalar
+  float* dctx;           // [B, C] or null (only with one input tile)
+  float* gpart;          // [grid] gradient partials of gpart_stride floats; plain stores, summed by k_gather_c
+  long gpart_stride;
+};
+
+size_t sf_trainc_lds_bytes(const SfTrcDev& c, int TS);
+bool sf_trainc_eligible(const SfLayout& L, bool want_dctx);
+int sf_trainc_grid(long B);
+hipError_t sf_launch_maf_trainc(const SfTrcArgs& a, int grid, hipStream_t st);
+hipError_t sf_launch_gather_c(const float* gpart, long stride, int nwg, const int32_t* gdst, float* grad, long n, hipStream_t st);

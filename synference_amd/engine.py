@@ -102,6 +102,28 @@ class HipFlow:
             _lib.check(self.lib.sf_flow_pack_table16b(self.handle, s.ctypes.data_as(_lib.c_i32p), n))
         return s
 
+    TRC_FIELDS = ("ok NT NI t_stride g_stride o_win o_b0 o_w1 o_b1 o_w2 o_b2 o_wf o_bf o_wfT o_w2T o_w1T o_winT "
+                  "g_win g_b0 g_w1 g_b1 g_w2 g_b2 g_wf g_bf kend0 kend1 kend2 kend3 kbeg0 kbeg1 kbeg2 kbeg3 c_insrc c_jobs "
+                  "n_jobs").split()
+
+    def trainc_table(self):
+        """Cooperative 16-row training image (csrc/sf_layout.h, SfTrcDev): None when the flow has none, else
+        (src1, src2, gdst, descriptor dict, constants image)."""
+        n = int(self.lib.sf_flow_trainc_size(self.handle))
+        if not n:
+            return None
+        s1 = np.empty(n, np.int32)
+        s2 = np.empty(n, np.int32)
+        gd = np.empty(self.n_params, np.int32)
+        desc = np.zeros(64, np.int32)
+        ncst = int(self.lib.sf_flow_cst_size(self.handle))
+        cst = np.empty(ncst, np.float32)
+        _lib.check(self.lib.sf_flow_trainc_table(self.handle, s1.ctypes.data, s2.ctypes.data, n, gd.ctypes.data, self.n_params,
+                                                 desc.ctypes.data, cst.ctypes.data, ncst))
+        d = {k: int(v) for k, v in zip(self.TRC_FIELDS, desc)}
+        d["n_grad"] = int(self.lib.sf_flow_trainc_grad_size(self.handle))
+        return s1, s2, gd, d, cst
+
     def describe(self) -> dict:
         buf = C.create_string_buffer(1 << 16)
         _lib.check(self.lib.sf_flow_describe(self.handle, buf, len(buf)))
