@@ -25,7 +25,20 @@ struct SfTrcArgs {
   float* dctx;           // [B, C] or null (only with one input tile)
   float* gpart;          // [grid] gradient partials of gpart_stride floats; plain stores, summed by k_gather_c
   long gpart_stride;
+#ifdef SF_TRC_TRACE
+  unsigned long long* trace;  // developer build: [8 waves][256] cycle stamps of workgroup 0
+#endif
 };
+
+#ifdef SF_TRC_TRACE
+#define SF_TC(slot)                                                                                         \
+  do {                                                                                                      \
+    if (a.trace && blockIdx.x == 0 && (threadIdx.x & 63) == 0)                                              \
+      a.trace[(threadIdx.x >> 6) * 256 + (slot)] = __builtin_readcyclecounter();                            \
+  } while (0)
+#else
+#define SF_TC(slot) do { } while (0)
+#endif
 
 size_t sf_trainc_lds_bytes(const SfTrcDev& c, int TS);
 bool sf_trainc_eligible(const SfLayout& L, bool want_dctx);
