@@ -287,7 +287,7 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
     a.D = L.dev.D; a.C = L.dev.C; a.T = L.dev.T; a.scale_fn = L.dev.scale_fn;
     a.eps = L.dev.eps; a.logdet0 = L.dev.logdet0;
     a.c_pscale = L.dev.c_pscale; a.c_pshift = L.dev.c_pshift; a.c_tdim = L.dev.c_tdim; a.c_xmean = L.dev.c_xmean; a.c_xstd = L.dev.c_xstd;
-    a.theta = theta; a.x = x; a.idx = idx; a.wts = weights; a.B = B; a.n_chunks = (B + 63) / 64; a.w = grad_scale;
+    a.theta = theta; a.x = x; a.idx = idx; a.wts = weights; a.B = B; a.n_chunks = (B + 32L * sf_trainc_groups(B) - 1) / (32L * sf_trainc_groups(B)); a.w = grad_scale;
     a.loss = loss; a.loss_sum = loss_sum; a.dctx = dctx;
     a.gpart = f->d_gpartC; a.gpart_stride = (long)L.n_gradC;
     if (f->profiling) {

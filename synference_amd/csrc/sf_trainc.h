@@ -18,7 +18,7 @@ struct SfTrcArgs {
   const float* x;
   const long long* idx;  // optional [B]: batch row b reads library row idx[b]
   const float* wts;      // optional per-sample weights [B] (multiplied by w)
-  long B, n_chunks;      // n_chunks = ceil(B / 64)
+  long B, n_chunks;      // n_chunks = ceil(B / (32 * groups per workgroup))
   float w;
   float* loss;           // [B] or null
   double* loss_sum;      // optional device scalar
@@ -40,7 +40,8 @@ struct SfTrcArgs {
 #define SF_TC(slot) do { } while (0)
 #endif
 
-size_t sf_trainc_lds_bytes(const SfTrcDev& c, int TS);
+size_t sf_trainc_lds_bytes(const SfTrcDev& c, int TS, int NG);
+int sf_trainc_groups(long B);
 bool sf_trainc_eligible(const SfLayout& L, bool want_dctx);
 int sf_trainc_grid(long B);
 hipError_t sf_launch_maf_trainc(const SfTrcArgs& a, int grid, hipStream_t st);

@@ -48,8 +48,11 @@ __device__ __forceinline__ void c_st4(float* p, const f32x4 v) {
   *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }
 // weight fragment of block (a, b) of a [.][nb] block array
+// (block index first, as a wave-uniform 64-bit base; the lane enters as an unsigned 32-bit offset: the load then takes
+//  the SGPR-base + VGPR-offset form and every fragment address shares ONE per-lane register)
 __device__ __forceinline__ float4 c_frag(const float* wp, int nb, int a, int b, int lane) {
-  return reinterpret_cast<const float4*>(wp)[(a * nb + b) * 64 + lane];
+  const float4* base = reinterpret_cast<const float4*>(wp) + (a * nb + b) * 64;
+  return base[(unsigned)lane];
 }
 __device__ __forceinline__ f32x4 c_zero() {
   f32x4 z;
@@ -96,16 +99,17 @@ __device__ __forceinline__ void c_dw_finish(const CJob& J, f32x4 acc, float bs, 
     if (lane < 16) J.gb[J.ot * 16 + lane] = accumulate ? J.gb[J.ot * 16 + lane] + bs : bs;
   }
 }
+template <int NQ>
 __device__ __forceinline__ void c_dw_jobs(const CJob& A, const CJob& B, bool two, bool accumulate, int lane) {
   f32x4 accA = c_zero(), accB = c_zero();
   float bsA = 0.f, bsB = 0.f;
   if (two) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 dA = *reinterpret_cast<const float4*>(A.Td + (A.ot * 4 + q) * 256 + lane * 4);
-      const float4 iA = *reinterpret_cast<const float4*>(A.Ti + (A.it * 4 + q) * 256 + lane * 4);
-      const float4 dB = *reinterpret_cast<const float4*>(B.Td + (B.ot * 4 + q) * 256 + lane * 4);
-      const float4 iB = *reinterpret_cast<const float4*>(B.Ti + (B.it * 4 + q) * 256 + lane * 4);
+    for (int q = 0; q < NQ; ++q) {
+      const float4 dA = *reinterpret_cast<const float4*>(A.Td + (A.ot * NQ + q) * 256 + lane * 4);
+      const float4 iA = *reinterpret_cast<const float4*>(A.Ti + (A.it * NQ + q) * 256 + lane * 4);
+      const float4 dB = *reinterpret_cast<const float4*>(B.Td + (B.ot * NQ + q) * 256 + lane * 4);
+      const float4 iB = *reinterpret_cast<const float4*>(B.Ti + (B.it * NQ + q) * 256 + lane * 4);
       accA = SF_MFMA16(dA.x, iA.x, accA);
       accB = SF_MFMA16(dB.x, iB.x, accB);
       accA = SF_MFMA16(dA.y, iA.y, accA);
@@ -121,9 +125,9 @@ __device__ __forceinline__ void c_dw_jobs(const CJob& A, const CJob& B, bool two
     c_dw_finish(B, accB, bsB, accumulate, lane);
   } else {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 dA = *reinterpret_cast<const float4*>(A.Td + (A.ot * 4 + q) * 256 + lane * 4);
-      const float4 iA = *reinterpret_cast<const float4*>(A.Ti + (A.it * 4 + q) * 256 + lane * 4);
+    for (int q = 0; q < NQ; ++q) {
+      const float4 dA = *reinterpret_cast<const float4*>(A.Td + (A.ot * NQ + q) * 256 + lane * 4);
+      const float4 iA = *reinterpret_cast<const float4*>(A.Ti + (A.it * NQ + q) * 256 + lane * 4);
       accA = SF_MFMA16(dA.x, iA.x, accA);
       accA = SF_MFMA16(dA.y, iA.y, accA);
       accA = SF_MFMA16(dA.z, iA.z, accA);
@@ -158,49 +162,61 @@ __device__ __forceinline__ void c_barrier() {
 __host__ __device__ inline int sf_trc_nbias(int NT) { return 3 * NT * 16 + 16; }
 __host__ __device__ inline int sf_trc_cb_floats(int NT, int NI, int TS) { return TS * sf_trc_nbias(NT) + 16 + NI * 16 * 3 + 8 * 3; }
 
-template <int TS, int NI, int NT>
-__global__ __launch_bounds__(512, 2) void k_maf_trainc(SfTrcArgs a_in) {
+// NG groups of 4 waves per workgroup, 32 samples (two 16-sample subtiles) per group.  Wave (p, qq) of a group owns
+// hidden tiles p and NT-1-p of subtile qq: with the block-triangular MADE layers that is (p + 1) + (NT - p) = NT + 1
+// blocks per layer for EVERY wave (round 3's first version gave wave j tile j for both subtiles: the wave with the
+// last tile ran four blocks while the first ran one, and every barrier waited for it).
+template <int TS, int NI, int NT, int NG>
+__global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
   extern __shared__ float lds[];
+  constexpr int NQ = 2 * NG, NW = 4 * NG, NTH = 256 * NG;
+  constexpr int NP = (NT + 1) / 2;  // wave rows (p) that own tiles
   const SfTrcArgs& a = c_args();
   const SfTrcDev& c = a.c;
   // (the wave index is made visibly wave-uniform: tile indices, buffer bases and fragment bases then live in SGPRs and the
   //  per-lane address part is one register)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int grp = wave >> 2, j = wave & 3;
+  const int grp = wave >> 2, p = (wave >> 1) & 1, qq = wave & 1;
+  const int q = 2 * grp + qq;  // my subtile
   const int s = lane & 15, g4 = lane >> 4;
   const int D = a.D;
-  const int mt_raw = grp == 0 ? j : NT - 1 - j;
-  const bool has = NT == 4 || (mt_raw >= 0 && mt_raw < NT);  // this wave owns hidden tile mt (always, with four tiles)
-  const int mt = has ? mt_raw : 0;
-  int ke = 0, kb = 0;  // tile bounds of my tile (select chains: the descriptor stays in SGPRs)
+  const int tA = p, tB = NT - 1 - p;
+  const bool has0 = tA <= tB, has1 = tA < tB;  // tiles this wave owns: tA, and tB when different
+  const int tB_ = has1 ? tB : tA;
+  int keA = 0, keB = 0, kbA = 0, kbB = 0;  // tile bounds (select chains: the descriptor stays in SGPRs)
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    ke = (q == mt) ? c.kend[q] : ke;
-    kb = (q == mt) ? c.kbeg[q] : kb;
+  for (int i = 0; i < 4; ++i) {
+    keA = (i == tA) ? c.kend[i] : keA;
+    keB = (i == tB_) ? c.kend[i] : keB;
+    kbA = (i == tA) ? c.kbeg[i] : kbA;
+    kbB = (i == tB_) ? c.kbeg[i] : kbB;
   }
+  // block slots of a masked layer: tile A's blocks first, then tile B's (at most 5 in all: sf_trainc_eligible)
+  const int nfA = has0 ? keA + 1 : 0, nfT = nfA + (has1 ? keB + 1 : 0);        // forward: input tiles 0..ke
+  const int nbA = has0 ? NT - kbA : 0, nbT = nbA + (has1 ? NT - kbB : 0);      // backward: output tiles kb..NT-1
   // ---- LDS map (floats)
-  constexpr int HSZ = NT * 1024;         // one hidden-size tensor: NT tiles x 4 subtiles x 256
+  constexpr int HSZ = NT * NQ * 256;     // one hidden-size tensor: NT tiles x NQ subtiles x 256
   float* XBa = lds;                      // B layout: h0 (fwd) / dpre2 (bwd); backward partial sums of du
   float* XBb = XBa + HSZ;                // B layout: a1 (fwd) / dpre1 (bwd)
   float* TB0 = XBb + HSZ;                // T layout x5: TD2, TA2 (later TD0), TH0, TD1, TA1; forward: head partial sums
   float* TD2 = TB0, *TA2 = TB0 + HSZ, *TH0 = TB0 + 2 * HSZ, *TD1 = TB0 + 3 * HSZ, *TA1 = TB0 + 4 * HSZ;
   float* TD0 = TA2;
-  float* PBf = TB0;
-  float* PBb = XBa;
-  float* TDF = TB0 + 5 * HSZ;            // T layout: head delta, 1 tile
-  float* TIN = TDF + 1024;               // T layout: input tiles, NI tiles
-  float* USt = TIN + NI * 1024;          // [TS][64 samples][8]: u entering transform t
-  float* ASt = USt + TS * 512;           // [TS][64][8]: head output a (slots)
+  float* PBf = TB0;                      // [NP][NQ] tiles
+  float* PBb = XBa;                      // [NP][NQ] tiles
+  float* TDF = TB0 + 5 * HSZ;            // T layout: head delta, 1 tile x NQ
+  float* TIN = TDF + NQ * 256;           // T layout: input tiles, NI tiles x NQ
+  float* USt = TIN + NI * NQ * 256;      // [TS][16*NQ samples][8]: u entering transform t
+  float* ASt = USt + TS * NQ * 128;      // [TS][16*NQ][8]: head output a (slots)
   // constants of the whole call: biases of every transform, the weight-gradient block list, per input-row and
   // per-slot standardisation constants (read from LDS in the phases instead of through dependent global loads)
   constexpr int NBIAS = 3 * NT * 16 + 16;
-  float* CBb = ASt + TS * 512;           // [T][b0 NT*16 | b1 | b2 | bf 16]
+  float* CBb = ASt + TS * NQ * 128;      // [T][b0 NT*16 | b1 | b2 | bf 16]
   int* CBj = reinterpret_cast<int*>(CBb + TS * NBIAS);  // [16] (ot * 4 + it)
   float* CBx = reinterpret_cast<float*>(CBj + 16);      // [NI*16][feature, mean, 1/std]
   float* CBs = CBx + NI * 16 * 3;                       // [8 slots][theta column, scale, shift]
   {
     const float* cst = a.cst;
-    for (int i = threadIdx.x; i < a.T * NBIAS; i += 512) {
+    for (int i = threadIdx.x; i < a.T * NBIAS; i += NTH) {
       const int t = i / NBIAS, k = i - t * NBIAS;
       const int sec = k / (NT * 16), kk = k - sec * NT * 16;
       const int off = sec == 0 ? c.o_b0 : (sec == 1 ? c.o_b1 : (sec == 2 ? c.o_b2 : c.o_bf));
@@ -215,39 +231,45 @@ __global__ __launch_bounds__(512, 2) void k_maf_trainc(SfTrcArgs a_in) {
       CBx[threadIdx.x * 3 + 2] = 1.0f / cst[a.c_xstd + ff];
     }
     if (threadIdx.x < 8) {
-      const int p = threadIdx.x < D ? threadIdx.x : 0;
-      CBs[threadIdx.x * 3] = cst[a.c_tdim + p];
-      CBs[threadIdx.x * 3 + 1] = cst[a.c_pscale + p];
-      CBs[threadIdx.x * 3 + 2] = cst[a.c_pshift + p];
+      const int pp = threadIdx.x < D ? threadIdx.x : 0;
+      CBs[threadIdx.x * 3] = cst[a.c_tdim + pp];
+      CBs[threadIdx.x * 3 + 1] = cst[a.c_pscale + pp];
+      CBs[threadIdx.x * 3 + 2] = cst[a.c_pshift + pp];
     }
   }
   __syncthreads();
-  // my two subtiles
-  const int q0 = 2 * grp;
   const bool s0on = 2 * g4 < D, s1on = 2 * g4 + 1 < D;
+  static_assert(NG <= 2, "groups");
+  const bool swapped = NG == 2 ? grp == 1 : (blockIdx.x & 1) != 0;  // (one group: alternate workgroups instead)
+  // slot i of a masked layer -> (which of my tiles, block index); wave-uniform
+  auto fslot_tile = [&](int i) { return i < nfA ? tA : tB_; };
+  auto fslot_it = [&](int i) { const int ii = i < nfT ? i : (nfT > 0 ? nfT - 1 : 0); return ii < nfA ? ii : ii - nfA; };
+  auto bslot_tile = [&](int i) { return i < nbA ? tA : tB_; };
+  auto bslot_ot = [&](int i) { const int ii = i < nbT ? i : (nbT > 0 ? nbT - 1 : 0); return ii < nbA ? kbA + ii : kbB + ii - nbA; };
 
   for (long chunk = blockIdx.x, iter = 0; chunk < a.n_chunks; chunk += gridDim.x, ++iter) {
     const bool accumulate = iter > 0;
     SF_TC(0);
     // first fragments of the forward sweep: in flight behind the input loads
-    float4 pwin[NI];
+    float4 pwin[2][NI];
     {
       const float* tp0 = a.img + sf_opaque_zero();
 #pragma unroll
-      for (int it = 0; it < NI; ++it) pwin[it] = c_frag(tp0 + c.o_win, NI, mt, it, lane);
+      for (int it = 0; it < NI; ++it) {
+        pwin[0][it] = c_frag(tp0 + c.o_win, NI, tA, it, lane);
+        pwin[1][it] = c_frag(tp0 + c.o_win, NI, tB_, it, lane);
+      }
     }
-    // ------------------------------------------------------------------ per-sample inputs
-    bool valid[2];
-    float wgt[2];
-    f32x4 inx[NI][2];  // [input tile][subtile]: context part of the input tiles (slot rows 0 here)
-    float u0[2], u1[2];
-#pragma unroll
-    for (int qq = 0; qq < 2; ++qq) {
-      const long row = chunk * 64 + (q0 + qq) * 16 + s;
-      valid[qq] = row < a.B;
-      const long ii = valid[qq] ? row : a.B - 1;
+    // ------------------------------------------------------------------ per-sample inputs (one subtile per wave)
+    const long row = chunk * (16 * NQ) + q * 16 + s;
+    const bool valid = row < a.B;
+    float wgt;
+    f32x4 inx[NI];  // context part of the input tiles (slot rows 0 here)
+    float u0, u1;
+    {
+      const long ii = valid ? row : a.B - 1;
       const long src = a.idx ? (long)a.idx[ii] : ii;
-      wgt[qq] = valid[qq] ? (a.wts ? a.w * a.wts[row] : a.w) : 0.f;
+      wgt = valid ? (a.wts ? a.w * a.wts[row] : a.w) : 0.f;
       const float* xr = a.x + src * a.C;
 #pragma unroll
       for (int it = 0; it < NI; ++it) {
@@ -256,17 +278,17 @@ __global__ __launch_bounds__(512, 2) void k_maf_trainc(SfTrcArgs a_in) {
           const float* cb = CBx + (it * 16 + 4 * g4 + r) * 3;
           const int f = (int)cb[0];
           const float v = (xr[f >= 0 ? f : 0] - cb[1]) * cb[2];
-          inx[it][qq][r] = f >= 0 ? v : 0.f;
+          inx[it][r] = f >= 0 ? v : 0.f;
         }
       }
       const float* sb = CBs + (2 * g4) * 3;
       // (unconditional loads, selected afterwards: a load under a per-lane condition gets its own wait)
       const float th0 = a.theta[src * D + (int)sb[0]], th1 = a.theta[src * D + (int)sb[3]];
-      u0[qq] = s0on ? th0 * sb[1] + sb[2] : 0.f;
-      u1[qq] = s1on ? th1 * sb[4] + sb[5] : 0.f;
+      u0 = s0on ? th0 * sb[1] + sb[2] : 0.f;
+      u1 = s1on ? th1 * sb[4] + sb[5] : 0.f;
     }
-    float ld[2] = {0.f, 0.f};
-    f32x4 a1s[TS][2], a2s[TS][2];  // the wave's own tile of a1 / a2 for every transform
+    float ld = 0.f;
+    f32x4 a1s[TS][2], a2s[TS][2];  // my two tiles of a1 / a2 for every transform
 
     // ------------------------------------------------------------------ forward
 #pragma unroll
@@ -278,142 +300,137 @@ __global__ __launch_bounds__(512, 2) void k_maf_trainc(SfTrcArgs a_in) {
         const float* cb = CBb + t * NBIAS;
         // F1: h0 = b0 + bc + Win . [u ; e(x)]
         SF_TC(1 + 5 * t);
-        float4 w1f[4], w2f[4];
-        if (has) {
+        float4 w1f[5], w2f[5];
+        if (has0) {
           // next phase's fragments: in flight across the barrier
 #pragma unroll
-          for (int it = 0; it < 4; ++it) w1f[it] = c_frag(tp + c.o_w1, NT, mt, it <= ke ? it : ke, lane);
-          f32x4 h0[2];
-          const f32x4 bv = c_ld4(cb + (mt * 4 + g4) * 4);
-          h0[0] = bv; h0[1] = bv;
+          for (int i = 0; i < 5; ++i) w1f[i] = c_frag(tp + c.o_w1, NT, fslot_tile(i), fslot_it(i), lane);
+          f32x4 in0 = inx[0];
+          in0[0] = s0on ? u0 : in0[0];
+          in0[1] = s1on ? u1 : in0[1];
 #pragma unroll
-          for (int it = 0; it < NI; ++it) {
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-              f32x4 in = inx[it][qq];
-              if (it == 0) {
-                in[0] = s0on ? u0[qq] : in[0];
-                in[1] = s1on ? u1[qq] : in[1];
-              }
-              h0[qq] = c_mma(pwin[it], in, h0[qq]);
+          for (int k = 0; k < 2; ++k) {
+            if (k == 0 || has1) {
+              const int tk = k == 0 ? tA : tB_;
+              f32x4 h0 = c_ld4(cb + (tk * 4 + g4) * 4);
+              h0 = c_mma(pwin[k][0], in0, h0);
+              if constexpr (NI > 1) h0 = c_mma(pwin[k][NI - 1], inx[NI - 1], h0);
+              c_st4(XBa + (tk * NQ + q) * 256 + lane * 4, h0);
             }
           }
-#pragma unroll
-          for (int qq = 0; qq < 2; ++qq) c_st4(XBa + (mt * 4 + q0 + qq) * 256 + lane * 4, h0[qq]);
         }
         SF_TC(2 + 5 * t);
         c_barrier();
         // F2: a1 = tanh(b1 + W1 h0)
-        float4 wff = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (has) {
+        float4 wff[2];
+        if (has0) {
 #pragma unroll
-          for (int it = 0; it < 4; ++it) w2f[it] = c_frag(tp + c.o_w2, NT, mt, it <= ke ? it : ke, lane);
-          wff = c_frag(tp + c.o_wf, NT, 0, mt, lane);
-          const f32x4 b1v = c_ld4(cb + NT * 16 + (mt * 4 + g4) * 4);
-          f32x4 acc[2] = {b1v, b1v};
+          for (int i = 0; i < 5; ++i) w2f[i] = c_frag(tp + c.o_w2, NT, fslot_tile(i), fslot_it(i), lane);
+          wff[0] = c_frag(tp + c.o_wf, NT, 0, tA, lane);
+          wff[1] = c_frag(tp + c.o_wf, NT, 0, tB_, lane);
+          f32x4 accA = c_ld4(cb + NT * 16 + (tA * 4 + g4) * 4), accB = c_ld4(cb + NT * 16 + (tB_ * 4 + g4) * 4);
 #pragma unroll
-          for (int it = 0; it < 4; ++it)
-            if (it <= ke) {
-#pragma unroll
-              for (int qq = 0; qq < 2; ++qq)
-                acc[qq] = c_mma(w1f[it], c_ld4(XBa + (it * 4 + q0 + qq) * 256 + lane * 4), acc[qq]);
+          for (int i = 0; i < 5; ++i) {
+            if (i < nfT) {
+              const f32x4 tv = c_ld4(XBa + (fslot_it(i) * NQ + q) * 256 + lane * 4);
+              if (i < nfA) accA = c_mma(w1f[i], tv, accA);
+              else accB = c_mma(w1f[i], tv, accB);
             }
-#pragma unroll
-          for (int qq = 0; qq < 2; ++qq) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[qq][r] = sf_tanh(acc[qq][r]);
-            a1s[t][qq] = acc[qq];
-            c_st4(XBb + (mt * 4 + q0 + qq) * 256 + lane * 4, acc[qq]);
           }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { accA[r] = sf_tanh(accA[r]); accB[r] = sf_tanh(accB[r]); }
+          a1s[t][0] = accA; a1s[t][1] = accB;
+          c_st4(XBb + (tA * NQ + q) * 256 + lane * 4, accA);
+          if (has1) c_st4(XBb + (tB_ * NQ + q) * 256 + lane * 4, accB);
         }
         SF_TC(3 + 5 * t);
         c_barrier();
-        // F3: a2 = tanh(b2 + W2 a1); head partial sums over my 16 hidden rows
-        if (has) {
+        // F3: a2 = tanh(b2 + W2 a1); head partial sums over my hidden rows
+        if (has0) {
           {  // the next transform's first fragments (the last transform reloads its own: no branch around a load)
             const float* tpn = tp + (t + 1 < a.T ? c.t_stride : 0);
 #pragma unroll
-            for (int it = 0; it < NI; ++it) pwin[it] = c_frag(tpn + c.o_win, NI, mt, it, lane);
-          }
-          const f32x4 b2v = c_ld4(cb + 2 * NT * 16 + (mt * 4 + g4) * 4);
-          f32x4 acc[2] = {b2v, b2v};
-#pragma unroll
-          for (int it = 0; it < 4; ++it)
-            if (it <= ke) {
-#pragma unroll
-              for (int qq = 0; qq < 2; ++qq)
-                acc[qq] = c_mma(w2f[it], c_ld4(XBb + (it * 4 + q0 + qq) * 256 + lane * 4), acc[qq]);
+            for (int it = 0; it < NI; ++it) {
+              pwin[0][it] = c_frag(tpn + c.o_win, NI, tA, it, lane);
+              pwin[1][it] = c_frag(tpn + c.o_win, NI, tB_, it, lane);
             }
-#pragma unroll
-          for (int qq = 0; qq < 2; ++qq) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[qq][r] = sf_tanh(acc[qq][r]);
-            a2s[t][qq] = acc[qq];
-            c_st4(PBf + (mt * 4 + q0 + qq) * 256 + lane * 4, c_mma(wff, acc[qq], c_zero()));
           }
+          f32x4 accA = c_ld4(cb + 2 * NT * 16 + (tA * 4 + g4) * 4), accB = c_ld4(cb + 2 * NT * 16 + (tB_ * 4 + g4) * 4);
+#pragma unroll
+          for (int i = 0; i < 5; ++i) {
+            if (i < nfT) {
+              const f32x4 tv = c_ld4(XBb + (fslot_it(i) * NQ + q) * 256 + lane * 4);
+              if (i < nfA) accA = c_mma(w2f[i], tv, accA);
+              else accB = c_mma(w2f[i], tv, accB);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { accA[r] = sf_tanh(accA[r]); accB[r] = sf_tanh(accB[r]); }
+          a2s[t][0] = accA; a2s[t][1] = accB;
+          f32x4 hp = c_mma(wff[0], accA, c_zero());
+          if (has1) hp = c_mma(wff[1], accB, hp);
+          c_st4(PBf + (p * NQ + q) * 256 + lane * 4, hp);
         }
         SF_TC(4 + 5 * t);
         c_barrier();
         SF_TC(5 + 5 * t);
-        // F4 (every wave, replicated): head = bf + sum of the partial sums; affine update of the two slots of this lane
+        // F4 (both waves of the subtile, replicated): head = bf + partial sums; affine update of this lane's two slots
         {
-          const f32x4 bfv = c_ld4(cb + 3 * NT * 16 + g4 * 4);
+          f32x4 fin = c_ld4(cb + 3 * NT * 16 + g4 * 4);
 #pragma unroll
-          for (int qq = 0; qq < 2; ++qq) {
-            f32x4 fin = bfv;
+          for (int pp = 0; pp < NP; ++pp) {
+            const f32x4 pv = c_ld4(PBf + (pp * NQ + q) * 256 + lane * 4);
 #pragma unroll
-            for (int it = 0; it < 4; ++it)
-              if (it < NT) {
-                const f32x4 pv = c_ld4(PBf + (it * 4 + q0 + qq) * 256 + lane * 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) fin[r] += pv[r];
-              }
-            if (j == 0) {  // one wave per group keeps what the backward sweep needs
-              const int sidx = ((t * 64) + (q0 + qq) * 16 + s) * 8 + 2 * g4;
-              *reinterpret_cast<float2*>(USt + sidx) = make_float2(u0[qq], u1[qq]);
-              *reinterpret_cast<float2*>(ASt + sidx) = make_float2(fin[0], fin[1]);
-            }
-            const float sc0 = c_scale(a.scale_fn, fin[0], a.eps), sc1 = c_scale(a.scale_fn, fin[1], a.eps);
-            u0[qq] = s0on ? sc0 * u0[qq] + fin[2] : 0.f;
-            u1[qq] = s1on ? sc1 * u1[qq] + fin[3] : 0.f;
-            ld[qq] += (s0on ? sf_log(sc0) : 0.f) + (s1on ? sf_log(sc1) : 0.f);
+            for (int r = 0; r < 4; ++r) fin[r] += pv[r];
           }
+          if (p == 0) {  // one wave per subtile keeps what the backward sweep needs
+            const int sidx = ((t * NQ + q) * 16 + s) * 8 + 2 * g4;
+            *reinterpret_cast<float2*>(USt + sidx) = make_float2(u0, u1);
+            *reinterpret_cast<float2*>(ASt + sidx) = make_float2(fin[0], fin[1]);
+          }
+          const float sc0 = c_scale(a.scale_fn, fin[0], a.eps), sc1 = c_scale(a.scale_fn, fin[1], a.eps);
+          u0 = s0on ? sc0 * u0 + fin[2] : 0.f;
+          u1 = s1on ? sc1 * u1 + fin[3] : 0.f;
+          ld += (s0on ? sf_log(sc0) : 0.f) + (s1on ? sf_log(sc1) : 0.f);
         }
       }
     }
     // first fragments of the backward sweep (top transform): in flight behind the loss
-    float4 pwfT, pw2T[4], pwinB[NI];
+    float4 pwfT[2], pw2T[5], pwinB[2][NI];
     {
       const SfTrcArgs& a = c_args();
       const SfTrcDev& c = a.c;
       const float* tpl = a.img + (size_t)(a.T - 1) * c.t_stride + sf_opaque_zero();
-      pwfT = c_frag(tpl + c.o_wfT, 1, mt, 0, lane);
+      pwfT[0] = c_frag(tpl + c.o_wfT, 1, tA, 0, lane);
+      pwfT[1] = c_frag(tpl + c.o_wfT, 1, tB_, 0, lane);
 #pragma unroll
-      for (int it = 0; it < NI; ++it) pwinB[it] = c_frag(tpl + c.o_win, NI, mt, it, lane);
+      for (int it = 0; it < NI; ++it) {
+        pwinB[0][it] = c_frag(tpl + c.o_win, NI, tA, it, lane);
+        pwinB[1][it] = c_frag(tpl + c.o_win, NI, tB_, it, lane);
+      }
 #pragma unroll
-      for (int ot = 0; ot < 4; ++ot) pw2T[ot] = c_frag(tpl + c.o_w2T, NT, mt, (ot >= kb && ot < NT) ? ot : kb, lane);
+      for (int i = 0; i < 5; ++i) pw2T[i] = c_frag(tpl + c.o_w2T, NT, bslot_tile(i), bslot_ot(i), lane);
     }
     // ------------------------------------------------------------------ loss, dL/du_T
-    float G0[2], G1[2];
-#pragma unroll
-    for (int qq = 0; qq < 2; ++qq) {
-      float ss = u0[qq] * u0[qq] + u1[qq] * u1[qq];
-      float lds_ = ld[qq];
+    float G0, G1;
+    {
+      float ss = u0 * u0 + u1 * u1;
+      float lds_ = ld;
       ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
       lds_ += __shfl_xor(lds_, 16, 64); lds_ += __shfl_xor(lds_, 32, 64);
       const float nll = 0.5f * ss + 0.5f * (float)D * 1.8378770664093453f - (a.logdet0 + lds_);
-      if (j == 0) {
-        if (a.loss && valid[qq] && g4 == 0) a.loss[chunk * 64 + (q0 + qq) * 16 + s] = nll;
+      if (p == 0) {
+        if (a.loss && valid && g4 == 0) a.loss[row] = nll;
         if (a.loss_sum) {
-          float tsum = (valid[qq] && g4 == 0) ? nll : 0.f;
+          float tsum = (valid && g4 == 0) ? nll : 0.f;
 #pragma unroll
           for (int o = 8; o > 0; o >>= 1) tsum += __shfl_xor(tsum, o, 64);
           // values on a 2^-20 grid add exactly in double: the sum does not depend on the order of the atomics
           if (lane == 0) atomicAdd(a.loss_sum, (double)rintf(tsum * 1048576.0f) * (1.0 / 1048576.0));
         }
       }
-      G0[qq] = wgt[qq] * u0[qq];
-      G1[qq] = wgt[qq] * u1[qq];
+      G0 = wgt * u0;
+      G1 = wgt * u1;
     }
     SF_TC(39);
     c_barrier();  // the last head sums have been read (PBf is TD2's buffer), the u / a stash is complete
@@ -431,136 +448,162 @@ __global__ __launch_bounds__(512, 2) void k_maf_trainc(SfTrcArgs a_in) {
         float* gp = gpart + (size_t)t * c.g_stride;
         // B1: head backward, delta of block 2, h0 recomputed
         SF_TC(40 + 12 * tt);
-        float Gd0[2], Gd1[2];
+        float Gd0, Gd1;
         {
-          const f32x4 b0v = c_ld4(cb + (mt * 4 + g4) * 4);
+          const int sidx = ((t * NQ + q) * 16 + s) * 8 + 2 * g4;
+          const float2 uu = *reinterpret_cast<const float2*>(USt + sidx);
+          const float2 aa = *reinterpret_cast<const float2*>(ASt + sidx);
+          const float sc0 = c_scale(a.scale_fn, aa.x, a.eps), sc1 = c_scale(a.scale_fn, aa.y, a.eps);
+          f32x4 dfin;
+          dfin[0] = s0on ? (G0 * uu.x - sf_div(wgt, sc0)) * c_dscale(a.scale_fn, aa.x) : 0.f;
+          dfin[1] = s1on ? (G1 * uu.y - sf_div(wgt, sc1)) * c_dscale(a.scale_fn, aa.y) : 0.f;
+          dfin[2] = s0on ? G0 : 0.f;
+          dfin[3] = s1on ? G1 : 0.f;
+          Gd0 = s0on ? G0 * sc0 : 0.f;
+          Gd1 = s1on ? G1 * sc1 : 0.f;
+          // input tiles of this transform (slot rows from the stash)
+          f32x4 in0 = inx[0];
+          in0[0] = s0on ? uu.x : in0[0];
+          in0[1] = s1on ? uu.y : in0[1];
+          if (p == 0) {
+            c_put_T(TDF + q * 256, dfin, s, g4);
+            c_put_T(TIN + q * 256, in0, s, g4);
+            if constexpr (NI > 1) c_put_T(TIN + (NQ + q) * 256, inx[NI - 1], s, g4);
+          }
+          if (has0) {
 #pragma unroll
-          for (int qq = 0; qq < 2; ++qq) {
-            const int sidx = ((t * 64) + (q0 + qq) * 16 + s) * 8 + 2 * g4;
-            const float2 uu = *reinterpret_cast<const float2*>(USt + sidx);
-            const float2 aa = *reinterpret_cast<const float2*>(ASt + sidx);
-            const float sc0 = c_scale(a.scale_fn, aa.x, a.eps), sc1 = c_scale(a.scale_fn, aa.y, a.eps);
-            f32x4 dfin;
-            dfin[0] = s0on ? (G0[qq] * uu.x - sf_div(wgt[qq], sc0)) * c_dscale(a.scale_fn, aa.x) : 0.f;
-            dfin[1] = s1on ? (G1[qq] * uu.y - sf_div(wgt[qq], sc1)) * c_dscale(a.scale_fn, aa.y) : 0.f;
-            dfin[2] = s0on ? G0[qq] : 0.f;
-            dfin[3] = s1on ? G1[qq] : 0.f;
-            Gd0[qq] = s0on ? G0[qq] * sc0 : 0.f;
-            Gd1[qq] = s1on ? G1[qq] * sc1 : 0.f;
-            if (j == 0) c_put_T(TDF + (q0 + qq) * 256, dfin, s, g4);
-            // input tiles of this transform (slot rows from the stash)
-            f32x4 in0 = inx[0][qq];
-            in0[0] = s0on ? uu.x : in0[0];
-            in0[1] = s1on ? uu.y : in0[1];
-            if (j == 0) {
-              c_put_T(TIN + (q0 + qq) * 256, in0, s, g4);
-              if constexpr (NI > 1) c_put_T(TIN + (4 + q0 + qq) * 256, inx[NI - 1][qq], s, g4);
-            }
-            if (has) {
-              f32x4 dp2 = c_mma(pwfT, dfin, c_zero());
+            for (int k = 0; k < 2; ++k) {
+              if (k == 0 || has1) {
+                const int tk = k == 0 ? tA : tB_;
+                f32x4 dp2 = c_mma(pwfT[k], dfin, c_zero());
 #pragma unroll
-              for (int r = 0; r < 4; ++r) dp2[r] *= 1.0f - a2s[t][qq][r] * a2s[t][qq][r];
-              c_st4(XBa + (mt * 4 + q0 + qq) * 256 + lane * 4, dp2);
-              c_put_T(TD2 + (mt * 4 + q0 + qq) * 256, dp2, s, g4);
-              c_put_T(TA2 + (mt * 4 + q0 + qq) * 256, a2s[t][qq], s, g4);
-              f32x4 h0 = c_mma(pwinB[0], in0, b0v);
-              if constexpr (NI > 1) h0 = c_mma(pwinB[NI - 1], inx[NI - 1][qq], h0);
-              c_put_T(TH0 + (mt * 4 + q0 + qq) * 256, h0, s, g4);
+                for (int r = 0; r < 4; ++r) dp2[r] *= 1.0f - a2s[t][k][r] * a2s[t][k][r];
+                c_st4(XBa + (tk * NQ + q) * 256 + lane * 4, dp2);
+                c_put_T(TD2 + (tk * NQ + q) * 256, dp2, s, g4);
+                c_put_T(TA2 + (tk * NQ + q) * 256, a2s[t][k], s, g4);
+                f32x4 h0 = c_mma(pwinB[k][0], in0, c_ld4(cb + (tk * 4 + g4) * 4));
+                if constexpr (NI > 1) h0 = c_mma(pwinB[k][NI - 1], inx[NI - 1], h0);
+                c_put_T(TH0 + (tk * NQ + q) * 256, h0, s, g4);
+              }
             }
           }
         }
         SF_TC(41 + 12 * tt);
         c_barrier();
         SF_TC(42 + 12 * tt);
-        // B2: delta of block 1; weight gradients of the head
-        float4 w1T[4], wiT = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (has) {
+        // B2: delta of block 1; weight gradients of the head.  The two halves of a backward phase (data path, weight-
+        // gradient blocks) are independent: odd groups run them in the opposite order, so that the two waves that share
+        // a SIMD are not in the same kind of work at the same time (MFMA chain + tanh' epilogue vs LDS-fed block products)
+        float4 w1T[5], wiT[2];
+        auto b2_data = [&]() {
+        if (has0) {
 #pragma unroll
-          for (int ot = 0; ot < 4; ++ot) w1T[ot] = c_frag(tp + c.o_w1T, NT, mt, (ot >= kb && ot < NT) ? ot : kb, lane);
-          wiT = c_frag(tp + c.o_winT, NT, 0, mt, lane);
-          f32x4 acc[2] = {c_zero(), c_zero()};
+          for (int i = 0; i < 5; ++i) w1T[i] = c_frag(tp + c.o_w1T, NT, bslot_tile(i), bslot_ot(i), lane);
+          wiT[0] = c_frag(tp + c.o_winT, NT, 0, tA, lane);
+          wiT[1] = c_frag(tp + c.o_winT, NT, 0, tB_, lane);
+          f32x4 accA = c_zero(), accB = c_zero();
 #pragma unroll
-          for (int ot = 0; ot < 4; ++ot)
-            if (ot >= kb && ot < NT) {
-#pragma unroll
-              for (int qq = 0; qq < 2; ++qq)
-                acc[qq] = c_mma(pw2T[ot], c_ld4(XBa + (ot * 4 + q0 + qq) * 256 + lane * 4), acc[qq]);
+          for (int i = 0; i < 5; ++i) {
+            if (i < nbT) {
+              const f32x4 tv = c_ld4(XBa + (bslot_ot(i) * NQ + q) * 256 + lane * 4);
+              if (i < nbA) accA = c_mma(pw2T[i], tv, accA);
+              else accB = c_mma(pw2T[i], tv, accB);
             }
+          }
 #pragma unroll
-          for (int qq = 0; qq < 2; ++qq) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[qq][r] *= 1.0f - a1s[t][qq][r] * a1s[t][qq][r];
-            c_st4(XBb + (mt * 4 + q0 + qq) * 256 + lane * 4, acc[qq]);
-            c_put_T(TD1 + (mt * 4 + q0 + qq) * 256, acc[qq], s, g4);
-            c_put_T(TA1 + (mt * 4 + q0 + qq) * 256, a1s[t][qq], s, g4);
+          for (int r = 0; r < 4; ++r) {
+            accA[r] *= 1.0f - a1s[t][0][r] * a1s[t][0][r];
+            accB[r] *= 1.0f - a1s[t][1][r] * a1s[t][1][r];
+          }
+          c_st4(XBb + (tA * NQ + q) * 256 + lane * 4, accA);
+          c_put_T(TD1 + (tA * NQ + q) * 256, accA, s, g4);
+          c_put_T(TA1 + (tA * NQ + q) * 256, a1s[t][0], s, g4);
+          if (has1) {
+            c_st4(XBb + (tB_ * NQ + q) * 256 + lane * 4, accB);
+            c_put_T(TD1 + (tB_ * NQ + q) * 256, accB, s, g4);
+            c_put_T(TA1 + (tB_ * NQ + q) * 256, a1s[t][1], s, g4);
           }
         }
-        SF_TC(43 + 12 * tt);
-        if (wave < NT) {  // dWf[head tile][hidden tile]; bias with the first block
-          const CJob J = {TDF, TA2, gp + c.g_wf + wave * 256, wave == 0 ? gp + c.g_bf : nullptr, 0, wave};
-          c_dw_jobs(J, J, false, accumulate, lane);
+        };
+        auto b2_jobs = [&]() {
+        for (int n = wave; n < NT; n += 2 * NW) {  // dWf[head tile][hidden tile]; bias with the first block
+          const bool two = n + NW < NT;
+          const int n2 = two ? n + NW : n;
+          const CJob A = {TDF, TA2, gp + c.g_wf + n * 256, n == 0 ? gp + c.g_bf : nullptr, 0, n};
+          const CJob B = {TDF, TA2, gp + c.g_wf + n2 * 256, nullptr, 0, n2};
+          c_dw_jobs<NQ>(A, B, two, accumulate, lane);
         }
+        };
+        if (swapped) { b2_jobs(); SF_TC(43 + 12 * tt); b2_data(); } else { b2_data(); SF_TC(43 + 12 * tt); b2_jobs(); }
         SF_TC(44 + 12 * tt);
         c_barrier();
         SF_TC(45 + 12 * tt);
         // B3: delta of the initial layer, partial sums of W_in^T delta; weight gradients of block 2
-        if (has) {
-          f32x4 acc[2] = {c_zero(), c_zero()};
+        auto b3_data = [&]() {
+        if (has0) {
+          f32x4 accA = c_zero(), accB = c_zero();
 #pragma unroll
-          for (int ot = 0; ot < 4; ++ot)
-            if (ot >= kb && ot < NT) {
-#pragma unroll
-              for (int qq = 0; qq < 2; ++qq)
-                acc[qq] = c_mma(w1T[ot], c_ld4(XBb + (ot * 4 + q0 + qq) * 256 + lane * 4), acc[qq]);
+          for (int i = 0; i < 5; ++i) {
+            if (i < nbT) {
+              const f32x4 tv = c_ld4(XBb + (bslot_ot(i) * NQ + q) * 256 + lane * 4);
+              if (i < nbA) accA = c_mma(w1T[i], tv, accA);
+              else accB = c_mma(w1T[i], tv, accB);
             }
-#pragma unroll
-          for (int qq = 0; qq < 2; ++qq) {
-            c_put_T(TD0 + (mt * 4 + q0 + qq) * 256, acc[qq], s, g4);
-            c_st4(PBb + (mt * 4 + q0 + qq) * 256 + lane * 4, c_mma(wiT, acc[qq], c_zero()));
           }
+          c_put_T(TD0 + (tA * NQ + q) * 256, accA, s, g4);
+          f32x4 dup = c_mma(wiT[0], accA, c_zero());
+          if (has1) {
+            c_put_T(TD0 + (tB_ * NQ + q) * 256, accB, s, g4);
+            dup = c_mma(wiT[1], accB, dup);
+          }
+          c_st4(PBb + (p * NQ + q) * 256 + lane * 4, dup);
         }
-        SF_TC(46 + 12 * tt);
-        {
+        };
+        auto b3_jobs = [&]() {
           const int nj = c.n_jobs;
-          if (wave < nj) {
-            const int cA = CBj[wave], cB = CBj[wave + 8 < nj ? wave + 8 : wave];
+          for (int n = wave; n < nj; n += 2 * NW) {
+            const bool two = n + NW < nj;
+            const int cA = CBj[n], cB = CBj[two ? n + NW : n];
             const CJob A = {TD2, TA1, gp + c.g_w2 + ((cA >> 2) * NT + (cA & 3)) * 256, (cA & 3) == 0 ? gp + c.g_b2 : nullptr, cA >> 2, cA & 3};
             const CJob B = {TD2, TA1, gp + c.g_w2 + ((cB >> 2) * NT + (cB & 3)) * 256, (cB & 3) == 0 ? gp + c.g_b2 : nullptr, cB >> 2, cB & 3};
-            c_dw_jobs(A, B, wave + 8 < nj, accumulate, lane);
+            c_dw_jobs<NQ>(A, B, two, accumulate, lane);
           }
-        }
+        };
+        if (swapped) { b3_jobs(); SF_TC(46 + 12 * tt); b3_data(); } else { b3_data(); SF_TC(46 + 12 * tt); b3_jobs(); }
         SF_TC(47 + 12 * tt);
         c_barrier();
         SF_TC(48 + 12 * tt);
-        // B4 (every wave, replicated): dL/du of the transform below; weight gradients of block 1 and the initial layer
+        // B4 (both waves of the subtile, replicated): dL/du of the transform below; weight gradients of block 1 and
+        // the initial layer
         {  // first fragments of the transform below (the bottom transform reloads its own)
           const float* tpn = tp - (t >= 1 ? c.t_stride : 0);
-          pwfT = c_frag(tpn + c.o_wfT, 1, mt, 0, lane);
+          pwfT[0] = c_frag(tpn + c.o_wfT, 1, tA, 0, lane);
+          pwfT[1] = c_frag(tpn + c.o_wfT, 1, tB_, 0, lane);
 #pragma unroll
-          for (int it = 0; it < NI; ++it) pwinB[it] = c_frag(tpn + c.o_win, NI, mt, it, lane);
+          for (int it = 0; it < NI; ++it) {
+            pwinB[0][it] = c_frag(tpn + c.o_win, NI, tA, it, lane);
+            pwinB[1][it] = c_frag(tpn + c.o_win, NI, tB_, it, lane);
+          }
 #pragma unroll
-          for (int ot = 0; ot < 4; ++ot) pw2T[ot] = c_frag(tpn + c.o_w2T, NT, mt, (ot >= kb && ot < NT) ? ot : kb, lane);
+          for (int i = 0; i < 5; ++i) pw2T[i] = c_frag(tpn + c.o_w2T, NT, bslot_tile(i), bslot_ot(i), lane);
         }
-#pragma unroll
-        for (int qq = 0; qq < 2; ++qq) {
+        {
           f32x4 du = c_zero();
 #pragma unroll
-          for (int it = 0; it < 4; ++it)
-            if (it < NT) {
-              const f32x4 pv = c_ld4(PBb + (it * 4 + q0 + qq) * 256 + lane * 4);
+          for (int pp = 0; pp < NP; ++pp) {
+            const f32x4 pv = c_ld4(PBb + (pp * NQ + q) * 256 + lane * 4);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) du[r] += pv[r];
-            }
-          G0[qq] = Gd0[qq] + (s0on ? du[0] : 0.f);
-          G1[qq] = Gd1[qq] + (s1on ? du[1] : 0.f);
-          if (a.dctx && j == 0 && valid[qq]) {  // context gradient of the rows of input tile 0 that hold features
-            const long brow = chunk * 64 + (q0 + qq) * 16 + s;
+            for (int r = 0; r < 4; ++r) du[r] += pv[r];
+          }
+          G0 = Gd0 + (s0on ? du[0] : 0.f);
+          G1 = Gd1 + (s1on ? du[1] : 0.f);
+          if (a.dctx && p == 0 && valid) {  // context gradient of the rows of input tile 0 that hold features
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float* cbx = CBx + (4 * g4 + r) * 3;
               const int f = (int)cbx[0];
               const bool slot_row = (r == 0 && s0on) || (r == 1 && s1on);
-              if (f >= 0 && !slot_row) a.dctx[brow * a.C + f] += du[r] * cbx[2];
+              if (f >= 0 && !slot_row) a.dctx[row * a.C + f] += du[r] * cbx[2];
             }
           }
         }
@@ -578,10 +621,10 @@ __global__ __launch_bounds__(512, 2) void k_maf_trainc(SfTrcArgs a_in) {
             const int ot = m / NI, it = m - ot * NI;
             return CJob{TD0, TIN, gp + c.g_win + (ot * NI + it) * 256, it == 0 ? gp + c.g_b0 : nullptr, ot, it};
           };
-          for (int n = wave; n < ntot; n += 16) {
-            const bool two = n + 8 < ntot;
-            const CJob A = mk(n), B = mk(two ? n + 8 : n);
-            c_dw_jobs(A, B, two, accumulate, lane);
+          for (int n = wave; n < ntot; n += 2 * NW) {
+            const bool two = n + NW < ntot;
+            const CJob A = mk(n), B = mk(two ? n + NW : n);
+            c_dw_jobs<NQ>(A, B, two, accumulate, lane);
           }
         }
         SF_TC(50 + 12 * tt);
@@ -620,8 +663,21 @@ __global__ __launch_bounds__(256) void k_gather_c(const float* __restrict__ gpar
   if (qy == 0 && i < n) grad[i] = (part[0][px] + part[1][px]) + (part[2][px] + part[3][px]);
 }
 
-size_t sf_trainc_lds_bytes(const SfTrcDev& c, int TS) {
-  return ((size_t)c.NT * 1024 * 7 + 1024 + (size_t)c.NI * 1024 + (size_t)TS * 1024 + (size_t)sf_trc_cb_floats(c.NT, c.NI, TS)) * sizeof(float);
+size_t sf_trainc_lds_bytes(const SfTrcDev& c, int TS, int NG) {
+  const size_t NQ = 2 * (size_t)NG;
+  return ((size_t)c.NT * NQ * 256 * 7 + NQ * 256 + (size_t)c.NI * NQ * 256 + (size_t)TS * NQ * 256 +
+          (size_t)sf_trc_cb_floats(c.NT, c.NI, TS)) * sizeof(float);
+}
+
+// groups of 4 waves (32 samples) per workgroup.  2 = one 8-wave workgroup per CU, weight-gradient products over 64
+// samples, half the gradient partials (batch 16 384: 72 us either way, 37 MB instead of 74 MB of partials); 1 = 4-wave
+// workgroups, taken while the batch leaves CUs idle anyway (<= 8 192 rows: one workgroup per CU, and a 32-sample
+// chain is shorter: batch 64 50 us instead of 63, batch 2 048 56 instead of 66).  SF_TRC_NG=1|2 overrides.
+int sf_trainc_groups(long B) {
+  static int forced = -1;
+  if (forced < 0) { const char* e = std::getenv("SF_TRC_NG"); forced = e ? std::atoi(e) : 0; }
+  if (forced == 1 || forced == 2) return forced;
+  return B <= 8192 ? 1 : 2;
 }
 
 bool sf_trainc_eligible(const SfLayout& L, bool want_dctx) {
@@ -631,7 +687,14 @@ bool sf_trainc_eligible(const SfLayout& L, bool want_dctx) {
   if (!env || !c.ok) return false;
   if (L.dev.T > SF_TRC_TS || c.NI > 2 || c.NT < 1 || c.NT > 4) return false;
   if (want_dctx && c.NI > 1) return false;
-  return sf_trainc_lds_bytes(c, SF_TRC_TS) <= (size_t)160 * 1024;
+  // a wave holds the fragments of tiles p and NT-1-p in five slots per layer (aligned MADE placement: NT + 1 blocks)
+  for (int p = 0; 2 * p < c.NT; ++p) {
+    const int tA = p, tB = c.NT - 1 - p;
+    const int nf = (c.kend[tA] + 1) + (tB > tA ? c.kend[tB] + 1 : 0);
+    const int nb = (c.NT - c.kbeg[tA]) + (tB > tA ? c.NT - c.kbeg[tB] : 0);
+    if (nf > 5 || nb > 5) return false;
+  }
+  return sf_trainc_lds_bytes(c, SF_TRC_TS, 2) <= (size_t)160 * 1024;
 }
 
 int sf_trainc_grid(long B) {
@@ -642,20 +705,22 @@ int sf_trainc_grid(long B) {
     cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
               ? pr.multiProcessorCount : 256;
   }
-  const long chunks = (B + 63) / 64;
-  return (int)(chunks < cus ? chunks : cus);
+  const int ng = sf_trainc_groups(B);
+  const long per = 32L * ng, chunks = (B + per - 1) / per;
+  const long cap = (long)cus * (ng == 1 ? 2 : 1);
+  return (int)(chunks < cap ? chunks : cap);
 }
 
-template <int NI, int NT>
+template <int NI, int NT, int NG>
 static hipError_t c_launch(const SfTrcArgs& a, int grid, hipStream_t st) {
   static SfAttrCache attr;
   int attr_dev;
   if (attr.need(attr_dev)) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_maf_trainc<SF_TRC_TS, NI, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)k_maf_trainc<SF_TRC_TS, NI, NT, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr.set(attr_dev);
   }
-  const size_t sh = sf_trainc_lds_bytes(a.c, SF_TRC_TS);
+  const size_t sh = sf_trainc_lds_bytes(a.c, SF_TRC_TS, NG);
 #ifdef SF_TRC_TRACE
   {
     static unsigned long long* d_tr = nullptr;
@@ -663,14 +728,14 @@ static hipError_t c_launch(const SfTrcArgs& a, int grid, hipStream_t st) {
     (void)hipMemsetAsync(d_tr, 0, 8 * 256 * 8, st);
     SfTrcArgs b = a;
     b.trace = d_tr;
-    hipLaunchKernelGGL((k_maf_trainc<SF_TRC_TS, NI, NT>), dim3((unsigned)grid), dim3(512), sh, st, b);
+    hipLaunchKernelGGL((k_maf_trainc<SF_TRC_TS, NI, NT, NG>), dim3((unsigned)grid), dim3(256 * NG), sh, st, b);
     (void)hipStreamSynchronize(st);
     static unsigned long long h[8 * 256];
     (void)hipMemcpy(h, d_tr, sizeof(h), hipMemcpyDeviceToHost);
     static int calls = 0;
     if (++calls % 8 == 0) {
       fprintf(stderr, "[trainc trace] B=%ld grid=%d (units of 100 cycles since stamp 0 of wave 0)\n", a.B, grid);
-      for (int w = 0; w < 8; ++w) {
+      for (int w = 0; w < 4 * NG; ++w) {
         fprintf(stderr, "  wave %d:", w);
         for (int i = 0; i < 256; ++i)
           if (h[w * 256 + i]) fprintf(stderr, " %d:%.1f", i, (double)(long long)(h[w * 256 + i] - h[0]) * 0.01);
@@ -680,23 +745,28 @@ static hipError_t c_launch(const SfTrcArgs& a, int grid, hipStream_t st) {
     return hipGetLastError();
   }
 #endif
-  hipLaunchKernelGGL((k_maf_trainc<SF_TRC_TS, NI, NT>), dim3((unsigned)grid), dim3(512), sh, st, a);
+  hipLaunchKernelGGL((k_maf_trainc<SF_TRC_TS, NI, NT, NG>), dim3((unsigned)grid), dim3(256 * NG), sh, st, a);
   return hipGetLastError();
 }
 
-hipError_t sf_launch_maf_trainc(const SfTrcArgs& a, int grid, hipStream_t st) {
+template <int NG>
+static hipError_t c_dispatch(const SfTrcArgs& a, int grid, hipStream_t st) {
   const int key = a.c.NI * 10 + a.c.NT;
   switch (key) {
-    case 11: return c_launch<1, 1>(a, grid, st);
-    case 12: return c_launch<1, 2>(a, grid, st);
-    case 13: return c_launch<1, 3>(a, grid, st);
-    case 14: return c_launch<1, 4>(a, grid, st);
-    case 21: return c_launch<2, 1>(a, grid, st);
-    case 22: return c_launch<2, 2>(a, grid, st);
-    case 23: return c_launch<2, 3>(a, grid, st);
-    case 24: return c_launch<2, 4>(a, grid, st);
+    case 11: return c_launch<1, 1, NG>(a, grid, st);
+    case 12: return c_launch<1, 2, NG>(a, grid, st);
+    case 13: return c_launch<1, 3, NG>(a, grid, st);
+    case 14: return c_launch<1, 4, NG>(a, grid, st);
+    case 21: return c_launch<2, 1, NG>(a, grid, st);
+    case 22: return c_launch<2, 2, NG>(a, grid, st);
+    case 23: return c_launch<2, 3, NG>(a, grid, st);
+    case 24: return c_launch<2, 4, NG>(a, grid, st);
   }
   return hipErrorInvalidValue;
+}
+
+hipError_t sf_launch_maf_trainc(const SfTrcArgs& a, int grid, hipStream_t st) {
+  return sf_trainc_groups(a.B) == 1 ? c_dispatch<1>(a, grid, st) : c_dispatch<2>(a, grid, st);
 }
 
 hipError_t sf_launch_gather_c(const float* gpart, long stride, int nwg, const int32_t* gdst, float* grad, long n, hipStream_t st) {
