@@ -329,7 +329,10 @@ def main():
     D, C = wl["D"], wl["C"]
     n_gal = a.galaxies or wl["galaxies"]
     x_lib, th_lib, names = make_catalogue(wl["n_lib"], C, D, seed=1234)
-    x_test, th_test, _ = make_catalogue(n_gal, C, D, seed=4321 + rank)
+    # ONE test catalogue of world x n_gal rows, sharded by rank as contiguous row blocks; weak scaling: the
+    # catalogue grows with the number of ranks, each rank's share stays at n_gal rows
+    x_all, th_all, _ = make_catalogue(n_gal * world, C, D, seed=4321)
+    x_test, th_test = x_all[rank * n_gal:(rank + 1) * n_gal], th_all[rank * n_gal:(rank + 1) * n_gal]
     rs = np.random.RandomState(0)
     idx = rs.permutation(len(x_lib))
     tr = idx[: int(0.8 * len(idx))]
@@ -406,6 +409,28 @@ def main():
     busy, _ = pmc_traffic("sample_busy") if default_wl else (None, None)
 
     note(f"sampling done: {1e3 * t_samp / a.steps:.3f} ms/step, kernel {k_ms:.3f} ms, unfilled {unfilled_all}")
+    # the same step with the all-fp32 sampler kernels (sf_set_sampler_fp32), quoted beside the default: the default MAF
+    # sampler runs its hidden H x H blocks as split-bf16 x3 products with fp32 accumulation
+    fp32_leg = None
+    if wl["kind"] == "maf" and not a.hidden_bf16 and desc.get("m16_ok"):
+        from synference_amd import _lib as _sflib
+        _sflib.load().sf_set_sampler_fp32(1)
+        try:
+            sample_step(0, False)
+            barrier_sync(world)
+            t0 = time.perf_counter()
+            n32 = max(2, min(a.steps, 5))
+            unf32 = 0
+            for k in range(n32):
+                unf32 += sample_step(k, False)
+            barrier_sync(world)
+            t32 = max_over_ranks(time.perf_counter() - t0, world, dev, gloo)
+            fp32_leg = {"kernel": "k_sample_persist<MafOps> (32-row tiles, v_mfma_f32_32x32x2_f32 everywhere)",
+                        "ms_per_step": 1e3 * t32 / n32, "value": (world * n32 * M * S - unf32 * world) / t32,
+                        "unit": "samples/s", "steps": n32}
+        finally:
+            _sflib.load().sf_set_sampler_fp32(0)
+        note(f"fp32 sampler leg: {fp32_leg['ms_per_step']:.3f} ms/step")
     # ---------------- train leg: fwd+bwd (+ all-reduce) + clip + Adam at the per-GPU batch
     tsteps = a.train_steps or a.steps
     B = a.train_batch
@@ -436,6 +461,28 @@ def main():
         tk.append(flow.train_kernel_ms())
     flow.set_profiling(False)
     train_kernel_ms = float(np.mean(tk))
+    # throughput regime: the flow kernel alone at 8 x the batch (one library call per step, no optimiser)
+    Bbig = 8 * B
+    big_idx = torch.randint(0, len(tr), (Bbig,), generator=g2).to(dev)
+    flow.set_profiling(True)
+    tkb = []
+    for k in range(6):
+        flow.loss_grad_rows(flat, Ttr, Xtr, big_idx, 1.0 / Bbig, grad)
+        if k >= 1:
+            tkb.append(flow.train_kernel_ms())
+    flow.set_profiling(False)
+    big_kernel_ms = float(np.mean(tkb))
+    # the bare gradient all-reduce (flat fp32 vector), so that the data-parallel step can be decomposed
+    allreduce_us = None
+    if world > 1:
+        for _ in range(10):
+            all_reduce_(grad, dist.ReduceOp.SUM, gloo)
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        for _ in range(100):
+            all_reduce_(grad, dist.ReduceOp.SUM, gloo)
+        torch.cuda.synchronize()
+        allreduce_us = max_over_ranks((time.perf_counter() - t0) / 100 * 1e6, world, dev, gloo)
     # strong scaling: the GLOBAL batch stays at --train-batch, each rank takes 1/world of it
     Bs = max(32, B // world)
     sidx = [torch.randint(0, len(tr), (Bs,), generator=g2).to(dev) for _ in range(4)]
@@ -491,17 +538,27 @@ def main():
     ttraffic, ttraffic_src = pmc_traffic("train") if a.workload == "maf_cfg2" else (None, None)
     kname = (("k_maf_samp16<NB,SPAN>" if desc.get("m16_ok") and not a.hidden_bf16 else "k_sample_persist<MafOps>")
              if wl["kind"] == "maf" else "k_sample_persist<NsfOps>")
+    split = wl["kind"] == "maf" and desc.get("m16_ok") and not a.hidden_bf16
+    tpath = flow.train_path(B)
+    tkname = ({1: "k_maf_trainc<TS,NI,NT,1> (cooperative 16-row tiles, 4 waves per 32 samples)",
+               2: "k_maf_trainc<TS,NI,NT,2> (cooperative 16-row tiles, 8 waves per 64 samples)"}.get(tpath)
+              or ("k_maf_train<HT>" if wl["kind"] == "maf" else "k_nsf_train<HT,PT>"))
+    observed_world = dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1
+    observed_backend = dist.get_backend() if (world > 1 and dist.is_initialized()) else "none (single process, no process group)"
     rec = {
         "metric": "posterior samples/sec (accepted, prior-box rejection included)",
-        "value": value, "unit": "samples/s", "n_gpus": world, "rccl_ranks": world, "steps": a.steps, "warmup": a.warmup,
+        "value": value, "unit": "samples/s", "n_gpus": world, "rccl_ranks": observed_world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * t_samp / a.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32" if not a.hidden_bf16 else "bf16 hidden-layer MFMA operands, f32 elsewhere",
+        "vs_baseline": None,
+        "dtype": ("bf16 hidden-layer MFMA operands, f32 elsewhere" if a.hidden_bf16 else
+                  ("f32 (sampler hidden HxH blocks: split-bf16 x3, fp32 accumulate; log_prob and training: f32 throughout)"
+                   if split else "f32")),
         "data": "synthetic",
         "config": {"workload": f"{wl['label']}; sample_posterior over {M} test galaxies x {S} draws per GPU",
                    "name": a.workload,
                    "galaxies_per_gpu": M, "draws_per_galaxy": S, "theta_dim": D, "filters": C,
-                   "parallelism": f"rows sharded over {world} GPU(s), no collective",
-                   "backend": "rccl" if not gloo else backend,
+                   "parallelism": f"one catalogue of {world * M} rows sharded over {world} GPU(s) as contiguous row blocks, no collective",
+                   "backend": observed_backend,
                    "first_attempt_acceptance": accept, "fit_steps": a.fit_steps, "fit_final_loss": fit_loss,
                    "launches_per_step": launches[0] / a.steps, "unfilled_slots": unfilled_all,
                    "flow_evaluations_per_step": evals_per_launch},
@@ -518,9 +575,9 @@ def main():
                              "of the committed PMC summary (the hidden blocks run as three bf16 MFMAs, so MFMA FLOPs are no "
                              "longer comparable with the fp32 peak; what binds is VALU issue + latency); contract_* = SURVEY "
                              "8d's figure for the reference algorithm x accepted draws (an algorithmic ratio, can exceed 1).",
-                     "issue_busy": busy,
+                     "issue_busy": busy, "fp32_sampler": fp32_leg,
                      "contract_tflops": contract, "contract_ratio": contract / PEAK_FP32_TFLOPS},
-        "roofline_train": {"bound": "mfma", "kernel": "k_maf_train<HT>" if wl["kind"] == "maf" else "k_nsf_train<HT,PT>",
+        "roofline_train": {"bound": "mfma", "kernel": tkname,
                            "achieved": train_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                            "frac": train_tf / PEAK_FP32_TFLOPS, "traffic": ttraffic, "traffic_source": ttraffic_src,
                            "launch_ms": train_kernel_ms, "rows_per_launch": B, "flops_per_launch": f_train * B,
@@ -532,6 +589,10 @@ def main():
                   "unit": "pairs/s", "per_gpu_batch": B, "steps": tsteps, "ms_per_step": 1e3 * t_train / tsteps,
                   "achieved_tflops": pairs * f_train / 1e12,
                   "batch64_pairs_per_s_1gpu": pairs64, "batch64_ms_per_step": 1e3 * t64 / 200,
+                  "allreduce_us": allreduce_us,
+                  "throughput_regime": {"per_gpu_batch": Bbig, "kernel_ms": big_kernel_ms,
+                                        "achieved_tflops": f_train * Bbig / (big_kernel_ms * 1e-3) / 1e12,
+                                        "frac": f_train * Bbig / (big_kernel_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS},
                   "strong_scaling": {"global_batch": Bs * world, "per_gpu_batch": Bs, "value": pairs_strong,
                                      "ms_per_step": 1e3 * t_strong / tsteps}},
         "log_prob": {"value": lp_rows, "unit": "rows/s", "rows_per_call": int(Xl.shape[0]),

@@ -121,6 +121,9 @@ int64_t sf_flow_trainc_grad_size(const sf_flow* f);
 int sf_flow_trainc_table(const sf_flow* f, int32_t* src1, int32_t* src2, int64_t n, int32_t* gdst, int64_t n_params,
                          int32_t* desc /*[64]*/, float* cst, int64_t n_cst);
 int64_t sf_flow_cst_size(const sf_flow* f);
+/* which kernel sf_flow_loss_grad* runs for a batch of B rows: 0 = one producer wave per 32-sample tile (k_maf_train /
+ * k_nsf_train), 1 / 2 = the cooperative 16-row kernel with 4-wave / 8-wave workgroups (k_maf_trainc) */
+int sf_flow_train_path(const sf_flow* f, int64_t B, int want_dctx);
 /* byte-for-byte description of the packed image for diagnostics (JSON, NUL-terminated) */
 int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen);
 
@@ -135,6 +138,16 @@ int sf_flow_log_prob(sf_flow* f, const float* theta /*[B,D]*/, const float* x /*
 int sf_flow_inverse_from_noise(sf_flow* f, const float* z /*[B,D]*/, const float* x /*[B,C]*/,
                                int64_t B, float* theta /*[B,D]*/, float* logdet /*[B]*/,
                                void* stream);
+/* Parity hook of the SAMPLER's arithmetic: the same inverse from given noise, evaluated by the pass functions the
+ * persistent sampler (sf_flow_sample) runs -- for a MAF with H <= 64 the hidden H x H blocks as split-bf16 x3 products
+ * with fp32 accumulation, everything else fp32.  Returns 0, or 1 when this flow's sampler is the all-fp32 path (then
+ * the result is sf_flow_inverse_from_noise's).  Replaces nothing in the reference: test surface of
+ * posterior.sample's numerics (sbi_runner.py:6442). */
+int sf_flow_inverse_from_noise_sampler(sf_flow* f, const float* z /*[B,D]*/, const float* x /*[B,C]*/, int64_t B,
+                                       float* theta /*[B,D]*/, void* stream);
+/* 1: the persistent sampler takes the all-fp32 kernels (also: environment SF_SAMPLER_FP32=1); 0: default
+ * (split-bf16 x3 hidden blocks where the flow has them).  Process-wide. */
+int sf_set_sampler_fp32(int on);
 
 /* One rejection round over a list of output slots (slot = g*S + p).  For every listed slot the
  * attempts attempt .. attempt+attempts_per_slot-1 are evaluated together (attempts_per_slot a power

@@ -63,6 +63,9 @@ PROTOTYPES = {
     "sf_flow_packed16_size": (C.c_int64, [C.c_void_p]),
     "sf_flow_pack_table16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "sf_flow_packed16b_size": (C.c_int64, [C.c_void_p]),
+    "sf_flow_inverse_from_noise_sampler": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "sf_set_sampler_fp32": (C.c_int, [C.c_int]),
+    "sf_flow_train_path": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
     "sf_flow_trainc_size": (C.c_int64, [C.c_void_p]),
     "sf_flow_trainc_grad_size": (C.c_int64, [C.c_void_p]),
     "sf_flow_cst_size": (C.c_int64, [C.c_void_p]),

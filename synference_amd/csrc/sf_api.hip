@@ -11,6 +11,7 @@
 
 #include "sf_internal.h"
 #include "sf_train.h"
+#include "sf_trainc.h"
 
 namespace {
 thread_local std::string g_err;
@@ -267,6 +268,33 @@ int sf_flow_inverse_from_noise(sf_flow* f, const float* z, const float* x, int64
   a.x = x; a.z_in = z; a.n_items = (long)B; a.out = theta; a.logdet_out = logdet;
   SF_HIP(sf_launch_inverse(f->dev(), a, (hipStream_t)stream));
   return SF_OK;
+}
+
+int sf_flow_inverse_from_noise_sampler(sf_flow* f, const float* z, const float* x, int64_t B, float* theta, void* stream) {
+  if (!f) return fail(SF_ERR_INVALID, "null handle");
+  if (B == 0) return SF_OK;
+  if (!z || !x || !theta) return fail(SF_ERR_INVALID, "null argument");
+  if (!f->params_set) return fail(SF_ERR_STATE, "sf_flow_set_params has not been called");
+  const SfDev m = f->dev();
+  if (!sf_maf16b_available(m) || sf_sampler_fp32_get()) {  // the sampler of this flow is the fp32 path
+    SfSampleArgsHost a;
+    a.x = x; a.z_in = z; a.n_items = (long)B; a.out = theta;
+    SF_HIP(sf_launch_inverse(m, a, (hipStream_t)stream));
+    return 1;  // (positive: "fp32 path", not an error)
+  }
+  SF_HIP(sf_launch_maf_inv16b_hook(m, z, x, (long)B, theta, (hipStream_t)stream));
+  return SF_OK;
+}
+
+int sf_set_sampler_fp32(int on) {
+  sf_sampler_fp32_set(on);
+  return SF_OK;
+}
+
+int sf_flow_train_path(const sf_flow* f, int64_t B, int want_dctx) {
+  if (!f) return fail(SF_ERR_INVALID, "null handle");
+  if (B > 0 && sf_trainc_eligible(f->L, want_dctx != 0)) return sf_trainc_groups((long)B);
+  return 0;
 }
 
 static void seed_keys(uint64_t seed, uint32_t stream_id, uint32_t& k0, uint32_t& k1) {

@@ -44,6 +44,10 @@ hipError_t sf_launch_logprob(const SfDev& m, const float* theta, const float* x,
 hipError_t sf_launch_inverse(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st);
 bool sf_maf16_enabled(const SfDev& m, const SfSampleArgsHost& a);
 hipError_t sf_launch_maf_inv16(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st);
+bool sf_maf16b_available(const SfDev& m);
+hipError_t sf_launch_maf_inv16b_hook(const SfDev& m, const float* z, const float* x, long n, float* out, hipStream_t st);
+void sf_sampler_fp32_set(int on);
+int sf_sampler_fp32_get();
 // per-galaxy context table: rows/variants for this flow (0 = the flow has no table path), builder
 void sf_ctab_shape(const SfDev& m, int& R, int& NV);
 hipError_t sf_launch_ctab(const SfDev& m, const float* x, long M, float* tab, hipStream_t st);

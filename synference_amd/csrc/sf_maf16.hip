@@ -772,6 +772,124 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
   }
 }
 
+// Parity hook of the persistent sampler's ARITHMETIC: theta = inverse(z | x) from GIVEN noise through exactly the pass
+// functions k_maf_samp16 runs (sf_pass16b / sf_pass16b_span: hidden H x H blocks as split-bf16 x3, everything else
+// fp32), so that the sampler's precision can be asserted against the fp64 oracle draw for draw, with no Philox and no
+// rejection in between (sf_flow_inverse_from_noise_sampler; tests/test_gpu_parity.py).  One wave = 16 rows of z.
+template <int NB, bool SPAN>
+__global__ __launch_bounds__(256, 3) void k_maf_inv16b(SfDev m, const float* __restrict__ z, const float* __restrict__ x,
+                                                       long n, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = lane & 15, g4 = lane >> 4;
+  const long item = ((long)blockIdx.x * 4 + wave) * 16 + s;
+  const bool valid = item < n;
+  const long it = valid ? item : n - 1;
+  f32x4 u;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) u[r] = (4 * g4 + r < m.D) ? z[it * m.D + 4 * g4 + r] : 0.f;
+  const int NT = m.nT16;
+  uint32_t tile_bits = 0, lo_bits = 0;
+#pragma unroll
+  for (int q = 0; q < SF_DMAX; ++q) {
+    tile_bits |= (uint32_t)(m.g16_tile[q] & 3) << (2 * q);
+    lo_bits |= (uint32_t)(m.g16_lo[q] & 3) << (2 * q);
+  }
+  SfPass16B S;
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { S.ph[k][pr][c] = 0u; S.pl[k][pr][c] = 0u; }
+#pragma unroll
+  for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S.head[ot][r] = 0.f;
+  for (int t = m.T - 1; t >= 0; --t) {
+    __syncthreads();
+    {
+      const int lane_ = threadIdx.x & 63;
+      const int ga = m.t16_a >> 10, gb = m.t16B_stride >> 10;
+      const float4* __restrict__ sa = reinterpret_cast<const float4*>(m.packed16 + (size_t)t * m.t16_stride);
+      const float4* __restrict__ sb = reinterpret_cast<const float4*>(m.packed16B + (size_t)t * m.t16B_stride);
+      float4* __restrict__ d4 = reinterpret_cast<float4*>(sf_lds16);
+      for (int gi = __builtin_amdgcn_readfirstlane(wave); gi < ga + gb; gi += 4) {
+        const float4* g = (gi < ga ? sa + gi * 256 : sb + (gi - ga) * 256) + lane_;
+        float4* l = d4 + gi * 256;
+        __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 1024, 0);
+        __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 3072, 0);
+      }
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+    }
+    __syncthreads();
+    const float* tp = sf_lds16;
+    const unsigned int* tpB = reinterpret_cast<const unsigned int*>(sf_lds16 + m.t16_a);
+    S.c0p = nullptr;
+    S.xr = x + it * m.C;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S.ut[r] = 0.f;
+    const int dsl = (int)m.cst[m.c_dslot + t * SF_DMAX + s];
+    {
+      const int sl = __builtin_amdgcn_readlane(dsl, 0);
+      const float av = tp[m.o16_hvb + 2 * sl], mv = tp[m.o16_hvb + 2 * sl + 1];
+      const float sc = (m.scale_fn == 0 ? sf_softplus(av) : sf_sigmoid(av + 2.0f)) + m.eps;
+      const float wv = sf_div(sf_slot16(u, sl, lane) - mv, sc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S.ut[r] = (g4 == (sl >> 2) && r == (sl & 3)) ? wv : S.ut[r];
+    }
+    for (int p = 2; p <= m.D; ++p) {
+      const int sl = __builtin_amdgcn_readlane(dsl, p - 1);
+      const float u_sl = sf_slot16(u, sl, lane);
+      const uint32_t hi_t = (tile_bits >> (2 * (p - 1))) & 3u;
+      const uint32_t lo_t = SPAN ? (lo_bits >> (2 * (p - 1))) & 3u : hi_t;
+      switch (lo_t * 4 + hi_t) {
+        case 0: sf_pass16b<0, NB, !SPAN>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+        case 5: sf_pass16b<1, NB, !SPAN>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+        case 10: sf_pass16b<2, NB, !SPAN>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+        case 15: sf_pass16b<3, NB, !SPAN>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+        case 1: if (SPAN) sf_pass16b_span<0, 1, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+        case 2: if (SPAN) sf_pass16b_span<0, 2, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+        case 3: if (SPAN) sf_pass16b_span<0, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+        case 6: if (SPAN) sf_pass16b_span<1, 2, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+        case 7: if (SPAN) sf_pass16b_span<1, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+        default: if (SPAN) sf_pass16b_span<2, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+      }
+    }
+    u = S.ut;
+  }
+  if (valid) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int p = 4 * g4 + r;
+      if (p < m.D) out[item * m.D + (int)m.cst[m.c_tdim + p]] = sf_div(u[r] - m.cst[m.c_pshift + p], m.cst[m.c_pscale + p]);
+    }
+  }
+}
+
+template <int NB, bool SPAN>
+static hipError_t sf_launch16b_hook(const SfDev& m, const float* z, const float* x, long n, float* out, hipStream_t st) {
+  static SfAttrCache attr;
+  const size_t sh = ((size_t)m.t16_a + (size_t)m.t16B_stride) * sizeof(float);
+  int attr_dev;
+  if (attr.need(attr_dev)) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_maf_inv16b<NB, SPAN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr.set(attr_dev);
+  }
+  hipLaunchKernelGGL((k_maf_inv16b<NB, SPAN>), dim3((unsigned)((n + 63) / 64)), dim3(256), sh, st, m, z, x, n, out);
+  return hipGetLastError();
+}
+// false when the flow has no split-bf16 sampler (then the sampler IS the fp32 path and sf_flow_inverse_from_noise covers it)
+bool sf_maf16b_available(const SfDev& m) {
+  return m.kind == SF_MAF && m.m16_ok && !m.hidden_bf16 && m.packed16 != nullptr && m.packed16B != nullptr;
+}
+hipError_t sf_launch_maf_inv16b_hook(const SfDev& m, const float* z, const float* x, long n, float* out, hipStream_t st) {
+  if (m.m16_span) return m.NB == 1 ? sf_launch16b_hook<1, true>(m, z, x, n, out, st) : sf_launch16b_hook<2, true>(m, z, x, n, out, st);
+  return m.NB == 1 ? sf_launch16b_hook<1, false>(m, z, x, n, out, st) : sf_launch16b_hook<2, false>(m, z, x, n, out, st);
+}
+
 // Per-galaxy context table of the 16-row path: tab[gal][t][row] = b0 + bc + Wc e(x_gal), rows in tile order.
 // One wave = 16 galaxies; same MFMA sequence as the in-kernel evaluation, so the sampler's draws do not change.
 __global__ __launch_bounds__(256) void k_maf_ctab16(SfDev m, const float* __restrict__ x, long M, float* __restrict__ tab) {
@@ -816,12 +934,22 @@ hipError_t sf_launch_maf_ctab16(const SfDev& m, const float* x, long M, float* t
 }
 
 // SF_MAF16=0 disables the path (diagnostics / A-B runs).  A = 32 retry rounds stay on the 32-row kernel.
+// SF_SAMPLER_FP32=1 (or sf_set_sampler_fp32(1)): the PERSISTENT sampler takes the all-fp32 32-row kernel
+// (k_sample_persist<MafOps>) instead of k_maf_samp16's split-bf16 hidden blocks -- the pure-fp32 number quoted beside
+// the default one in bench.py.
+static int g_sampler_fp32 = -1;
+void sf_sampler_fp32_set(int on) { g_sampler_fp32 = on ? 1 : 0; }
+int sf_sampler_fp32_get() {
+  if (g_sampler_fp32 < 0) { const char* e = std::getenv("SF_SAMPLER_FP32"); g_sampler_fp32 = (e && std::atoi(e) != 0) ? 1 : 0; }
+  return g_sampler_fp32;
+}
 bool sf_maf16_enabled(const SfDev& m, const SfSampleArgsHost& a) {
   static int env = -1;
   if (env < 0) {
     const char* e = std::getenv("SF_MAF16");
     env = e ? std::atoi(e) : 1;
   }
+  if (a.q && sf_sampler_fp32_get()) return false;
   return env != 0 && m.kind == SF_MAF && m.m16_ok && !m.hidden_bf16 && m.packed16 != nullptr &&
          (a.attempts_per_slot <= 16 || a.best != nullptr);  // (find mode has no in-tile attempt groups)
 }

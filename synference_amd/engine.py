@@ -170,6 +170,25 @@ class HipFlow:
                                                        _stream(self.device)))
         return th, ld
 
+    def inverse_sampler(self, z, x) -> Tuple[torch.Tensor, bool]:
+        """theta = inverse(z | x) through the persistent sampler's own arithmetic (sf_flow_inverse_from_noise_sampler:
+        split-bf16 x3 hidden blocks for a MAF with H <= 64).  Returns (theta, split) -- ``split`` False when this
+        flow's sampler is the all-fp32 path."""
+        self._dev()
+        z, x = _f32c(z, self.device), _f32c(x, self.device)
+        B = z.shape[0]
+        if z.shape != (B, self.spec.D) or x.shape != (B, self.spec.C):
+            raise ValueError("shape mismatch")
+        th = torch.empty_like(z)
+        rc = self.lib.sf_flow_inverse_from_noise_sampler(self.handle, _ptr(z), _ptr(x), B, _ptr(th), _stream(self.device))
+        if rc < 0:
+            _lib.check(rc)
+        return th, rc == 0
+
+    def train_path(self, B: int, want_dctx: bool = False) -> int:
+        """0: one producer wave per 32-sample tile; 1 / 2: cooperative 16-row kernel, 4- / 8-wave workgroups."""
+        return int(self.lib.sf_flow_train_path(self.handle, int(B), 1 if want_dctx else 0))
+
     def sample(self, x, S: int, lo=None, hi=None, seed: int = 0, max_attempts: Optional[int] = None,
                out: Optional[torch.Tensor] = None, return_counts: bool = False):
         """samples[M,S,D].  ``max_attempts`` None / 0: no ceiling -- a slot is retried while its galaxy still gets
