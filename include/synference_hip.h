@@ -200,6 +200,13 @@ int sf_flow_sample(sf_flow* f, const float* x /*[M,C]*/, int64_t M, int64_t S,
                    float* out /*[M,S,D]*/, int32_t* n_drawn /*[M]*/, int64_t* n_unfilled /*host*/,
                    void* stream);
 
+/* Row offset of the NEXT sampling calls on this handle (sf_flow_sample, sf_flow_sample_slots, sf_flow_sample_round,
+ * sf_flow_acceptance): the rows passed are rows [row_offset, row_offset + M) of a larger catalogue.  Only the random
+ * streams see it (Philox counter = (row_offset + g) * S + p): a chunk of a catalogue, or one rank's contiguous shard of it
+ * (rows sharded over GPUs, no collective), then draws exactly what those rows draw in ONE call over the whole
+ * catalogue with the same seed.  Stays in force until changed; 0 after sf_flow_create.
+ * Replaces: nothing in the reference (its per-galaxy loop, sbi_runner.py:6438-6442, has no batching to be independent of). */
+int sf_flow_set_sample_row_offset(sf_flow* f, int64_t row_offset);
 /* Wall-clock ceiling of later sf_flow_sample / sf_flow_sample_slots calls on this handle (seconds; <= 0 = none, the
  * default): once it is exceeded no further attempt window is opened and the slots still empty become NaN rows.
  * Replaces: the per-object timeout of sample_posterior (timeout_seconds_per_test, ref: sbi_runner.py:6358, 6443-6452). */

@@ -38,8 +38,9 @@ def in_box(theta: np.ndarray, lo: Optional[np.ndarray], hi: Optional[np.ndarray]
 
 def sample_slots(spec: flows.FlowSpec, flat: torch.Tensor, x: np.ndarray, slots: np.ndarray,
                  S: int, seed: int, lo=None, hi=None, max_attempts: Optional[int] = None, stream: int = 0,
-                 dtype=torch.float32) -> Tuple[np.ndarray, np.ndarray]:
-    """Draw one accepted sample for each slot id (slot = g*S + p).
+                 dtype=torch.float32, row_offset: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+    """Draw one accepted sample for each slot id (slot = g*S + p).  ``row_offset``: x holds rows [row_offset, ...) of a
+    larger catalogue; the random streams are those of slot (row_offset + g)*S + p (sf_flow_set_sample_row_offset).
 
     ``max_attempts`` an integer: hard ceiling, rows that exhaust it are NaN (the reference's failure
     convention, sbi_runner.py:6458-6460).  ``None``: no ceiling, as in [UPSTREAM] accept_reject_sample
@@ -64,7 +65,7 @@ def sample_slots(spec: flows.FlowSpec, flat: torch.Tensor, x: np.ndarray, slots:
         while attempt < window_end and len(pending):
             sl = slots[pending]
             g = (sl // np.uint64(S)).astype(np.int64)
-            z = philox.normal(seed, sl, attempt, spec.D, stream=stream)
+            z = philox.normal(seed, sl + np.uint64(row_offset * S), attempt, spec.D, stream=stream)
             with torch.no_grad():
                 th, _ = flows.inverse_transform(spec, flat, torch.as_tensor(z).to(dtype),
                                                 torch.as_tensor(xs[g]).to(dtype))
@@ -112,11 +113,11 @@ def accept_reject_sample(spec: flows.FlowSpec, flat: torch.Tensor, x_row: np.nda
     return np.concatenate(kept, 0)[:S], n_kept / n_total, warned
 
 
-def sample(spec, flat, x, S, seed, lo=None, hi=None, max_attempts=None, dtype=torch.float32):
+def sample(spec, flat, x, S, seed, lo=None, hi=None, max_attempts=None, dtype=torch.float32, row_offset=0):
     """``posterior.sample((S,), x=x[g])`` for every row g -> (samples[M,S,D], n_drawn[M])."""
     M = len(x)
     th, used = sample_slots(spec, flat, x, np.arange(M * S, dtype=np.uint64), S, seed, lo, hi,
-                            max_attempts, dtype=dtype)
+                            max_attempts, dtype=dtype, row_offset=row_offset)
     return th.reshape(M, S, spec.D), used.reshape(M, S).sum(1)
 
 

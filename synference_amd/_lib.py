@@ -65,6 +65,7 @@ PROTOTYPES = {
     "sf_flow_packed16b_size": (C.c_int64, [C.c_void_p]),
     "sf_flow_inverse_from_noise_sampler": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "sf_set_sampler_fp32": (C.c_int, [C.c_int]),
+    "sf_flow_set_sample_row_offset": (C.c_int, [C.c_void_p, C.c_int64]),
     "sf_flow_train_path": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
     "sf_flow_trainc_size": (C.c_int64, [C.c_void_p]),
     "sf_flow_trainc_grad_size": (C.c_int64, [C.c_void_p]),

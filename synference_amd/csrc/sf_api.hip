@@ -372,6 +372,7 @@ int sf_flow_sample_round(sf_flow* f, const float* x, int64_t S, const uint32_t* 
   SfSampleArgsHost a;
   a.x = x; a.S = (long)S; a.slots = slots; a.slot_base = (long)slot_base; a.n_items = (long)n_slots * A;
   a.attempts_per_slot = A; a.attempt = attempt; seed_keys(seed, stream_id, a.k0, a.k1);
+  a.rng_slot_offset = (unsigned long long)f->sample_row_offset * (unsigned long long)S;
   a.lo = lo; a.hi = hi; a.out = out; a.rejected = rejected; a.n_rejected = n_rejected; a.n_drawn = n_drawn;
   if (f->ctab_x == x && (uint64_t)(slot_base + n_slots) > (uint64_t)f->ctab_M * (uint64_t)S && slots == nullptr)
     return fail(SF_ERR_INVALID, "slots reach past the rows given to sf_flow_prepare_context");
@@ -399,6 +400,7 @@ static int ensure_queue(sf_flow* f, int64_t n_slots, int64_t M) {
     SF_HIP(hipMalloc(&f->d_ring, cap * sizeof(unsigned long long)));
     SF_HIP(hipMemset(f->d_ring, 0, cap * sizeof(unsigned long long)));  // consumers clear what they take: stays zero
     f->ring_cap = cap;
+    f->ring_dirty = false;
   }
   if (f->rej_cap < (size_t)n_slots) {
     (void)hipFree(f->d_rej[0]); (void)hipFree(f->d_rej[1]);
@@ -434,6 +436,7 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
   const SfDev m = sampler_dev(f, x);
   SfSampleArgsHost a;
   a.x = x; a.S = (long)S; seed_keys(seed, 0, a.k0, a.k1);
+  a.rng_slot_offset = (unsigned long long)f->sample_row_offset * (unsigned long long)S;
   a.lo = lo; a.hi = hi; a.out = out; a.n_drawn = n_drawn;
   a.q = f->d_queue; a.ring = f->d_ring; a.ring_mask = (uint32_t)(f->ring_cap - 1);
   a.out_slots = (uint32_t)(M * S);
@@ -463,9 +466,18 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
   // open slots have seen enough attempts since the last look for "no draw accepted" to mean something (1e5 attempts
   // over S slots: acceptance below ~3e-5 at 95 %); otherwise the counters carry over into the next window.
   uint32_t acc_from = 64;
-  auto rule_due = [&](uint32_t att_now) { return progress_rule && (uint64_t)(att_now - acc_from) * (uint64_t)S >= 100000ull; };
+  // Evidence = attempts since the last look x slots of the galaxy that are actually being worked.  sf_flow_sample works all S
+  // slots of a galaxy; sf_flow_sample_slots (an ensemble member's share) may list ONE slot of a galaxy, so there the rule
+  // counts one slot per galaxy: a listed slot is given up only after ~1e5 attempts of its own (with S in its place a
+  // single-slot galaxy of acceptance 1e-3 was written off after one 1 024-attempt window).
+  const uint64_t S_rule = slots ? 1ull : (uint64_t)S;
+  auto rule_due = [&](uint32_t att_now) { return progress_rule && (uint64_t)(att_now - acc_from) * S_rule >= 100000ull; };
   // ---- launch 1: the persistent kernel -- first attempts and retries of every slot, attempts [0, limit)
   {
+    // The retry ring stays all-zero only while every launch ends cleanly (consumers clear what they take).  A launch that
+    // ended on a queue error, or never completed, may have left donated entries behind: clear the ring before it is reused.
+    if (f->ring_dirty) SF_HIP(hipMemsetAsync(f->d_ring, 0, f->ring_cap * sizeof(unsigned long long), st));
+    f->ring_dirty = true;
     SF_HIP(hipMemsetAsync(f->d_queue, 0, sizeof(SfQueue), st));
 #ifdef SF_Q_STATS
     SF_HIP(hipMemsetAsync(&f->d_queue->stats[10], 0xff, sizeof(unsigned long long), st));  // atomicMin target
@@ -496,6 +508,7 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
                                     " of " + std::to_string((unsigned)pending) + " survivors " + std::to_string(f->h_queue->n_surv) +
                                     " dense_next " + std::to_string(f->h_queue->dense_next));
     }
+    f->ring_dirty = false;  // clean end: every ring entry was consumed
     evals += (double)f->h_queue->evals;
     dropped += (int64_t)f->h_queue->dropped;
     if (std::getenv("SF_Q_STATS")) {
@@ -621,6 +634,7 @@ int sf_flow_acceptance(sf_flow* f, const float* x, int64_t M, int64_t n, const f
   SF_HIP(sf_launch_fill_i32(count, (long)M, 0, st));
   SfSampleArgsHost a;
   a.x = x; a.S = (long)n; a.n_items = (long)(M * n); seed_keys(seed, 1u, a.k0, a.k1);
+  a.rng_slot_offset = (unsigned long long)f->sample_row_offset * (unsigned long long)n;
   a.lo = lo; a.hi = hi; a.count = count;
   {
     int rc = sf_flow_prepare_context(f, x, M, stream);
@@ -683,6 +697,13 @@ int sf_flow_train_epoch(sf_flow* f, float* flat, const float* theta, const float
     rc = sf_adam_apply(flat, grad, exp_avg, exp_avg_sq, f->L.n_params, d, step0 + b + 1, max_norm, scratch, stream);
     if (rc) return rc;
   }
+  return SF_OK;
+}
+
+int sf_flow_set_sample_row_offset(sf_flow* f, int64_t row_offset) {
+  if (!f) return fail(SF_ERR_INVALID, "null handle");
+  if (row_offset < 0) return fail(SF_ERR_INVALID, "row_offset < 0");
+  f->sample_row_offset = (long long)row_offset;
   return SF_OK;
 }
 

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(LDSW ? 512 : 256) void k_inverse(SfDev m, SfSampleA
       for (int blk = 0; blk < SF_DMAX / 4; ++blk)
         if (blk * 4 < m.D) {
           float z4[4];
-          sf_normal4(a.k0, a.k1, slot[ns], att, (uint32_t)blk, z4);
+          sf_normal4(a.k0, a.k1, slot[ns] + a.rng_slot_offset, att, (uint32_t)blk, z4);
 #pragma unroll
           for (int j = 0; j < 4; ++j) u[ns][blk * 4 + j] = (blk * 4 + j < m.D) ? z4[j] : 0.f;
         }
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(64 * WPB) void k_sample_persist(SfSampArgs args_in,
         for (int blk = 0; blk < SF_DMAX / 4; ++blk)
           if (blk * 4 < m.D) {
             float z4[4];
-            sf_normal4(a.k0, a.k1, (uint64_t)slot, att, (uint32_t)blk, z4);
+            sf_normal4(a.k0, a.k1, (uint64_t)slot + a.rng_slot_offset, att, (uint32_t)blk, z4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) u[ns][blk * 4 + j] = (blk * 4 + j < m.D) ? z4[j] : 0.f;
           }

@@ -14,6 +14,9 @@ struct SfSampleArgsHost {
   long slot_base = 0;
   long n_items = 0;
   uint32_t attempt = 0, k0 = 0, k1 = 0;
+  // added to the slot id in the Philox counter only: row_offset * S, so that a block of rows of a larger catalogue
+  // (a chunk, a rank's shard) draws exactly what those rows draw in a single call over the whole catalogue
+  unsigned long long rng_slot_offset = 0;
   int attempts_per_slot = 1;  // A: consecutive attempts evaluated per listed slot (power of two <= 32)
   int log2_attempts = 0;      // log2(A) (set by sf_launch_inverse)
   const float* lo = nullptr;
@@ -115,12 +118,14 @@ struct sf_flow {
   SfQueue* h_queue = nullptr;    // pinned host mirror, read once per stage
   unsigned long long* d_ring = nullptr;  // retry ring
   uint64_t ring_cap = 0;         // entries (power of two)
+  bool ring_dirty = false;       // a persistent launch did not end cleanly: clear the ring before the next one
   int32_t* d_galacc = nullptr;   // per-galaxy accepted-slot counter of a stage (progress rule)
   uint32_t* d_best = nullptr;    // deep-tail windows: lowest accepted attempt per survivor (find launch -> resolve launch)
   size_t best_cap = 0;
   size_t galacc_cap = 0;
   uint32_t* d_cnt = nullptr;     // SF_MAX_ROUNDS rejected-slot counters (one per round of a sf_flow_sample call)
   uint32_t* h_cnt = nullptr;     // pinned host mirror for the per-round read-back
+  long long sample_row_offset = 0;   // sf_flow_set_sample_row_offset: first row of the next sampling calls in its catalogue
   double sample_time_limit_s = 0.0;  // > 0: sf_flow_sample* stop opening new attempt windows after this much wall time
   bool profiling = false;         // sf_flow_set_profiling: bracket the training flow kernel with HIP events
   hipEvent_t ev_train[2] = {nullptr, nullptr};

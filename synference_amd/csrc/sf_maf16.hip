@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16(SfDev m, SfSampleArgsHost 
     const uint32_t att = a.att_list ? a.att_list[ps] : a.attempt + (uint32_t)(it & ((1L << a.log2_attempts) - 1));
     att_mine = att;
     float z4[4];
-    sf_normal4(a.k0, a.k1, slot, att, (uint32_t)g4, z4);  // Philox block g4 = dimensions 4*g4 .. 4*g4+3
+    sf_normal4(a.k0, a.k1, slot + a.rng_slot_offset, att, (uint32_t)g4, z4);  // Philox block g4 = dimensions 4*g4 .. 4*g4+3
 #pragma unroll
     for (int r = 0; r < 4; ++r) u[r] = (4 * g4 + r < m.D) ? z4[r] : 0.f;
   }
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
       const uint32_t att = ctrl[SF_Q_HDR + 64 + ee] + ((unsigned)wi & ((1u << lgA) - 1u));
       const long gal = (long)(slot / (uint32_t)a.S);
       float z4[4];
-      sf_normal4(a.k0, a.k1, (uint64_t)slot, att, (uint32_t)g4, z4);  // Philox block g4 = dimensions 4*g4 .. 4*g4+3
+      sf_normal4(a.k0, a.k1, (uint64_t)slot + a.rng_slot_offset, att, (uint32_t)g4, z4);  // Philox block g4 = dimensions 4*g4 .. 4*g4+3
 #pragma unroll
       for (int r = 0; r < 4; ++r) u[r] = (4 * g4 + r < m.D) ? z4[r] : 0.f;
       xr = a.x + gal * m.C;

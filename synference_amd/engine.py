@@ -185,6 +185,11 @@ class HipFlow:
             _lib.check(rc)
         return th, rc == 0
 
+    def set_sample_row_offset(self, row_offset: int) -> None:
+        """The rows of the next sampling / acceptance calls are rows [row_offset, ...) of a larger catalogue: only the
+        random streams see it (sf_flow_set_sample_row_offset)."""
+        _lib.check(self.lib.sf_flow_set_sample_row_offset(self.handle, int(row_offset)))
+
     def train_path(self, B: int, want_dctx: bool = False) -> int:
         """0: one producer wave per 32-sample tile; 1 / 2: cooperative 16-row kernel, 4- / 8-wave workgroups."""
         return int(self.lib.sf_flow_train_path(self.handle, int(B), 1 if want_dctx else 0))

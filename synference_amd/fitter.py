@@ -480,10 +480,33 @@ class SBI_Fitter:
         single = X.ndim == 1 or (X.ndim == 2 and X.shape[0] == 1)
         if X.ndim == 1:
             X = X[None, :]
+        # Under an initialised process group (one process per GPU) the catalogue is sharded: rank r samples rows
+        # [r N / W, (r+1) N / W) -- rows are independent (ref: sbi_runner.py:6438-6442), weights are replicated, there is no
+        # data-path collective -- and the blocks are gathered so that every rank returns the whole array.  The random
+        # streams are keyed by the row's position in the catalogue: the result is the single-process one, bit for bit.
+        from .posterior import all_gather_rows, broadcast_seed, dist_world, shard_bounds
+        rank, world = dist_world()
+        if world > 1 and len(X) >= world and kwargs.get("shard", True):
+            if seed is None:
+                seed = posteriors._next_seed(None)
+            seed = broadcast_seed(seed)
+            b = shard_bounds(len(X), world)
+            tmo = float(timeout_seconds_per_test) * (b[rank + 1] - b[rank]) if timeout_seconds_per_test else None
+            t0 = time.time()
+            local = posteriors.sample_catalogue(torch.as_tensor(X[b[rank]:b[rank + 1]]), num_samples, seed,
+                                                timeout_seconds=tmo, row_offset=b[rank])
+            if log_times:
+                per = (time.time() - t0) / max(1, b[rank + 1] - b[rank])
+                self.last_times_per_object = np.full(b[rank + 1] - b[rank], per)
+                self.last_time_per_object = float(per)
+            full = all_gather_rows(local, b)
+            return full.double().cpu().numpy()
         # log_times: the reference times every object (sbi_runner.py:6438-6469: median and 16th-84th percentile of the
         # per-object wall time); the catalogue call is timed in chunks instead and each chunk's time is shared equally
         # by its objects, so the three statistics keep their meaning without a per-galaxy host loop
         n_chunks = min(len(X), 16) if log_times else 1
+        if seed is None and n_chunks > 1:
+            seed = posteriors._next_seed(None)
         bounds = np.linspace(0, len(X), n_chunks + 1).astype(int)
         samples = np.full((len(X), num_samples, len(self.fitted_parameter_names)), np.nan)
         times = []
@@ -493,10 +516,10 @@ class SBI_Fitter:
                 continue
             t0 = time.time()
             try:
-                sub_seed = None if seed is None else int(seed) + 0x9E3779B1 * ci
                 # the reference's per-object timeout (sbi_runner.py:6358) becomes the wall-clock ceiling of the chunk
                 tmo = float(timeout_seconds_per_test) * (b - a) if timeout_seconds_per_test else None
-                s = posteriors.sample_catalogue(torch.as_tensor(X[a:b]), num_samples, sub_seed, timeout_seconds=tmo)
+                # (same seed, rows keyed by their position: the draws do not depend on the timing chunks)
+                s = posteriors.sample_catalogue(torch.as_tensor(X[a:b]), num_samples, seed, timeout_seconds=tmo, row_offset=a)
                 # D2H in float32 through a pinned buffer (half the PCIe bytes of a device-side .double()),
                 # widened to the reference's float64 container on the host
                 host = torch.empty(s.shape, dtype=torch.float32, pin_memory=True)
@@ -519,9 +542,36 @@ class SBI_Fitter:
         DirectPosterior default norm_posterior=True -> leakage-corrected)."""
         if posteriors is None:
             posteriors = self.posteriors
-        lp = posteriors.log_prob_catalogue(torch.as_tensor(np.asarray(y, dtype=np.float32)),
-                                           torch.as_tensor(np.asarray(X, dtype=np.float32)),
-                                           norm_posterior, num_rejection_samples)
+        Xt = torch.as_tensor(np.asarray(X, dtype=np.float32))
+        yt = torch.as_tensor(np.asarray(y, dtype=np.float32))
+        from .posterior import all_gather_rows, broadcast_seed, dist_world, shard_bounds
+        rank, world = dist_world()
+        if world > 1 and Xt.dim() == 2 and yt.dim() == 2 and len(Xt) == len(yt) and len(Xt) >= world:
+            # rank-sharded (rows independent, ref: sbi_runner.py:7193-7196): every rank evaluates its row block; the
+            # DISTINCT contexts behind the leakage correction are split over the ranks too and their acceptance rates
+            # gathered, with streams keyed by the position in the sorted list of distinct rows -- same result as one process
+            b = shard_bounds(len(Xt), world)
+            members = getattr(posteriors, "posteriors", [posteriors])
+            acc = None
+            if norm_posterior and posteriors.prior is not None:
+                dev = members[0].device
+                acc = []
+                for mem in members:
+                    E = mem._embed(Xt)
+                    ux, inv = torch.unique(E, dim=0, return_inverse=True)
+                    ub = shard_bounds(ux.shape[0], world)
+                    seed = broadcast_seed(mem._next_seed(None))
+                    part = mem.acceptance_rows(ux[ub[rank]:ub[rank + 1]], num_rejection_samples, seed, row_offset=ub[rank])
+                    acc_all = all_gather_rows(part, ub) if ux.shape[0] >= world else mem.acceptance_rows(ux, num_rejection_samples, seed)
+                    acc.append(acc_all.to(dev)[inv][b[rank]:b[rank + 1]])
+            sl = slice(b[rank], b[rank + 1])
+            if hasattr(posteriors, "posteriors"):
+                lp = posteriors.log_prob_catalogue(yt[sl], Xt[sl], norm_posterior, num_rejection_samples, acc=acc)
+            else:
+                lp = posteriors.log_prob_catalogue(yt[sl], Xt[sl], norm_posterior, num_rejection_samples,
+                                                   **({} if acc is None else {"acc_rows": acc[0]}))
+            return all_gather_rows(lp.contiguous(), b).double().cpu().numpy()
+        lp = posteriors.log_prob_catalogue(yt, Xt, norm_posterior, num_rejection_samples)
         return lp.double().cpu().numpy()
 
     def save_state(self, out_dir, name_append: str = "", save_method: str = "joblib", has_grid: bool = True, **extras):
@@ -783,9 +833,20 @@ class SBI_Fitter:
             if (~obs_mask).any():
                 if sample_method != "direct":
                     raise ValueError("Invalid sample method for the HIP backend. Use 'direct'.")
-                s_dev = self.posteriors.sample_catalogue(torch.as_tensor(feats[~obs_mask]), num_samples, seed,
-                                                         timeout_seconds=tmo)
-                qarr[~obs_mask] = _dq(s_dev, quantiles).double().cpu().numpy()
+                from .posterior import all_gather_rows, broadcast_seed, dist_world, shard_bounds
+                rank, world = dist_world()
+                good = feats[~obs_mask]
+                if world > 1 and len(good) >= world:   # rank r: its row block; only the (n, D, Q) quantiles are gathered
+                    if seed is None:
+                        seed = self.posteriors._next_seed(None)
+                    seed = broadcast_seed(seed)
+                    b = shard_bounds(len(good), world)
+                    s_dev = self.posteriors.sample_catalogue(torch.as_tensor(good[b[rank]:b[rank + 1]]), num_samples, seed,
+                                                             timeout_seconds=tmo, row_offset=b[rank])
+                    qarr[~obs_mask] = all_gather_rows(_dq(s_dev, quantiles).contiguous(), b).double().cpu().numpy()
+                else:
+                    s_dev = self.posteriors.sample_catalogue(torch.as_tensor(good), num_samples, seed, timeout_seconds=tmo)
+                    qarr[~obs_mask] = _dq(s_dev, quantiles).double().cpu().numpy()
             for i, param in enumerate(self.simple_fitted_parameter_names):
                 for j, qv in enumerate(quantiles):
                     table[f"{param}_{int(qv * 100)}"] = qarr[:, i, j]

@@ -95,9 +95,11 @@ class FlowPosterior:
 
     # ---- catalogue-wide fast paths ----------------------------------------------------------
     def sample_catalogue(self, X, num_samples: int, seed: Optional[int] = None, return_counts=False,
-                         timeout_seconds: Optional[float] = None):
+                         timeout_seconds: Optional[float] = None, row_offset: int = 0):
         """(N,S,D) float32 device tensor of accepted draws for every row of X (NaN rows on failure).
-        ``timeout_seconds``: wall-clock ceiling of the call (the reference's ``timeout_seconds_per_test`` x objects)."""
+        ``timeout_seconds``: wall-clock ceiling of the call (the reference's ``timeout_seconds_per_test`` x objects).
+        ``row_offset``: X holds rows [row_offset, row_offset + N) of a larger catalogue (a rank's shard): with the same
+        seed the draws are those of a single call over the whole catalogue, whatever the chunking or the sharding."""
         est = self.posterior_estimator
         X = self._embed(X)
         est._sync_params()
@@ -113,13 +115,17 @@ class FlowPosterior:
         if per_gal > 0:
             rows_per = max(1, min(rows_per, (2 << 30) // per_gal))
         unfilled = 0
-        for r0 in range(0, N, rows_per):
-            r1 = min(N, r0 + rows_per)
-            # slot ids restart per chunk: fold the chunk start into the seed so streams stay distinct
-            o, c = est.flow.sample(X[r0:r1], S, lo, hi, seed=seed + 0x632BE59BD9B4E019 * (r0 // rows_per),
-                                   max_attempts=self.max_sampling_attempts, out=out[r0:r1], return_counts=True)
-            counts[r0:r1] = c
-            unfilled += est.flow.last_unfilled
+        try:
+            for r0 in range(0, N, rows_per):
+                r1 = min(N, r0 + rows_per)
+                # slot ids restart per chunk; the random streams are keyed by the row's position in the whole catalogue
+                est.flow.set_sample_row_offset(int(row_offset) + r0)
+                o, c = est.flow.sample(X[r0:r1], S, lo, hi, seed=seed, max_attempts=self.max_sampling_attempts,
+                                       out=out[r0:r1], return_counts=True)
+                counts[r0:r1] = c
+                unfilled += est.flow.last_unfilled
+        finally:
+            est.flow.set_sample_row_offset(0)
         self.last_acceptance = (S / counts.float().clamp_min(1)).mean().item() if N else None
         self.last_unfilled = unfilled
         if unfilled:
@@ -139,10 +145,32 @@ class FlowPosterior:
                                f"{n_low} observation(s) below 1 %: their posterior mass is largely outside the prior support.")
         return (out, counts) if return_counts else out
 
+    def acceptance_rows(self, ux, num_rejection_samples: int, seed: int, row_offset: int = 0):
+        """Leakage-correction acceptance rate of every row of ``ux`` (rows [row_offset, ...) of a larger list of distinct
+        contexts): chunked, streams keyed by the row's position in the whole list."""
+        est = self.posterior_estimator
+        lo, hi = self._box()
+        n_rej = int(num_rejection_samples)
+        # one acceptance launch numbers its draws with 32 bits (and its context table is capped at 2 GiB)
+        rows_per = max(1, min(_MAX_SLOTS_PER_CALL // max(n_rej, 1), 1 << 20))
+        per_gal = 4 * int(est.flow.describe().get("ctab_floats_per_galaxy", 0))
+        if per_gal > 0:
+            rows_per = max(1, min(rows_per, (2 << 30) // per_gal))
+        acc = torch.empty(ux.shape[0], dtype=torch.float32, device=self.device)
+        try:
+            for r0 in range(0, ux.shape[0], rows_per):
+                r1 = min(ux.shape[0], r0 + rows_per)
+                est.flow.set_sample_row_offset(int(row_offset) + r0)
+                acc[r0:r1] = est.flow.acceptance(ux[r0:r1], n_rej, lo, hi, seed=seed)
+        finally:
+            est.flow.set_sample_row_offset(0)
+        return acc
+
     def log_prob_catalogue(self, theta, X, norm_posterior: bool = True, num_rejection_samples: int = 10000,
-                           seed: Optional[int] = None):
+                           seed: Optional[int] = None, acc_rows=None):
         """[UPSTREAM] DirectPosterior.log_prob for aligned rows: raw density, -inf outside the prior
-        support, minus log(acceptance(x)) when ``norm_posterior``."""
+        support, minus log(acceptance(x)) when ``norm_posterior``.  ``acc_rows``: acceptance rate of
+        every row, computed by the caller (rank-sharded evaluation: the distinct contexts are split over the ranks)."""
         est = self.posterior_estimator
         theta = torch.as_tensor(theta, dtype=torch.float32, device=self.device)
         if theta.dim() == 1:
@@ -156,20 +184,11 @@ class FlowPosterior:
         if lo is not None:
             inside = ((theta >= lo) & (theta <= hi)).all(-1)
             lp = torch.where(inside, lp, torch.full_like(lp, float("-inf")))
-            if norm_posterior:
+            if norm_posterior and acc_rows is not None:
+                lp = lp - torch.log(torch.as_tensor(acc_rows, dtype=torch.float32, device=lp.device).clamp_min(1e-30))
+            elif norm_posterior:
                 ux, inv = torch.unique(X, dim=0, return_inverse=True)
-                n_rej = int(num_rejection_samples)
-                # one acceptance launch numbers its draws with 32 bits (and its context table is capped at 2 GiB):
-                # chunk the distinct rows; the chunk index is folded into the seed so that streams stay distinct
-                rows_per = max(1, min(_MAX_SLOTS_PER_CALL // max(n_rej, 1), 1 << 20))
-                per_gal = 4 * int(est.flow.describe().get("ctab_floats_per_galaxy", 0))
-                if per_gal > 0:
-                    rows_per = max(1, min(rows_per, (2 << 30) // per_gal))
-                s0 = self._next_seed(seed)
-                acc = torch.empty(ux.shape[0], dtype=torch.float32, device=self.device)
-                for ci, r0 in enumerate(range(0, ux.shape[0], rows_per)):
-                    r1 = min(ux.shape[0], r0 + rows_per)
-                    acc[r0:r1] = est.flow.acceptance(ux[r0:r1], n_rej, lo, hi, seed=s0 + 0x632BE59BD9B4E019 * ci)
+                acc = self.acceptance_rows(ux, num_rejection_samples, self._next_seed(seed))
                 lp = lp - torch.log(acc.clamp_min(1e-30))[inv]
         return lp
 
@@ -245,10 +264,13 @@ class EnsemblePosterior:
         self._calls += 1
         return (self._seed * 0x9E3779B97F4A7C15 + 0x51ED27 + self._calls) & (2 ** 63 - 1)
 
-    def sample_catalogue(self, X, num_samples: int, seed: Optional[int] = None, timeout_seconds: Optional[float] = None):
-        """Per row: multinomial(weights, S) split; member e fills positions [cum_{e-1}, cum_e)."""
+    def sample_catalogue(self, X, num_samples: int, seed: Optional[int] = None, timeout_seconds: Optional[float] = None,
+                         row_offset: int = 0):
+        """Per row: multinomial(weights, S) split; member e fills positions [cum_{e-1}, cum_e).  ``row_offset``: X holds
+        rows [row_offset, ...) of a larger catalogue (see FlowPosterior.sample_catalogue)."""
         if len(self.posteriors) == 1:
-            return self.posteriors[0].sample_catalogue(X, num_samples, self._next_seed(seed), timeout_seconds=timeout_seconds)
+            return self.posteriors[0].sample_catalogue(X, num_samples, self._next_seed(seed), timeout_seconds=timeout_seconds,
+                                                       row_offset=row_offset)
         for p in self.posteriors:
             p.posterior_estimator.flow.set_sample_time_limit(timeout_seconds)
         p0 = self.posteriors[0]
@@ -259,7 +281,8 @@ class EnsemblePosterior:
         seed = self._next_seed(seed)
         out = torch.full((N, S, D), float("nan"), dtype=torch.float32, device=dev)
         w = self._weights.double().numpy()
-        counts = np.random.default_rng(seed & 0xFFFFFFFF).multinomial(S, w / w.sum(), size=N)
+        # (the generator fills rows in order: the split of a row depends on its position in the WHOLE catalogue only)
+        counts = np.random.default_rng(seed & 0xFFFFFFFF).multinomial(S, w / w.sum(), size=int(row_offset) + N)[int(row_offset):]
         cum = np.concatenate([np.zeros((N, 1), np.int64), np.cumsum(counts, 1)], 1)
         rows_per = max(1, (_MAX_SLOTS_PER_CALL // 4) // max(S, 1))
         pos = torch.arange(S, device=dev)[None, :]
@@ -269,8 +292,12 @@ class EnsemblePosterior:
             for e, post in enumerate(self.posteriors):
                 mask = (pos >= cum_d[:, e:e + 1]) & (pos < cum_d[:, e + 1:e + 2])
                 slots = torch.nonzero(mask.reshape(-1)).reshape(-1).to(torch.int32)  # bit pattern == uint32
-                _sample_slot_list(post, post._embed(X[r0:r1]), S, slots,
-                                  seed + 0x632BE59BD9B4E019 * (r0 // rows_per), out[r0:r1])
+                flow = post.posterior_estimator.flow
+                try:
+                    flow.set_sample_row_offset(int(row_offset) + r0)
+                    _sample_slot_list(post, post._embed(X[r0:r1]), S, slots, seed, out[r0:r1])
+                finally:
+                    flow.set_sample_row_offset(0)
         return out
 
     def sample(self, sample_shape=(1,), x=None, show_progress_bars=False, seed: Optional[int] = None, **_):
@@ -284,9 +311,11 @@ class EnsemblePosterior:
     def sample_batched(self, sample_shape=(1,), x=None, show_progress_bars=False, seed: Optional[int] = None, **_):
         return self.sample_catalogue(x, int(np.prod(sample_shape)), seed).permute(1, 0, 2).contiguous()
 
-    def log_prob_catalogue(self, theta, X, norm_posterior: bool = True, num_rejection_samples: int = 10000):
-        lps = torch.stack([p.log_prob_catalogue(theta, X, norm_posterior, num_rejection_samples)
-                           for p in self.posteriors], 0)
+    def log_prob_catalogue(self, theta, X, norm_posterior: bool = True, num_rejection_samples: int = 10000, acc=None):
+        """``acc``: optional list (one entry per member) of precomputed acceptance rates per row (rank-sharded callers)."""
+        lps = torch.stack([p.log_prob_catalogue(theta, X, norm_posterior, num_rejection_samples,
+                                                **({} if acc is None else {"acc_rows": acc[i]}))
+                           for i, p in enumerate(self.posteriors)], 0)
         logw = torch.log(self._weights.to(lps.device))[:, None]
         return torch.logsumexp(lps + logw, dim=0)
 
@@ -328,3 +357,49 @@ def _sample_slot_list(post: FlowPosterior, X, S: int, slots: torch.Tensor, seed:
                                      max_attempts=post.max_sampling_attempts)
     if unfilled:
         logger.error(f"{unfilled} posterior draws could not be placed inside the prior support; those rows are NaN.")
+
+
+# ---- rank-sharded catalogue evaluation (contiguous row blocks per GPU, weights replicated, no data-path
+# collective; the blocks are gathered afterwards) -------------------------------------------------------------------------
+def dist_world():
+    """(rank, world) of the initialised default process group, else (0, 1)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_bounds(n: int, world: int):
+    """Contiguous row blocks [b[r], b[r+1]) of n rows over ``world`` ranks."""
+    return [(r * n) // world for r in range(world + 1)]
+
+
+def all_gather_rows(local: torch.Tensor, bounds):
+    """Every rank contributes rows [bounds[r], bounds[r+1]) (``local``: that block); returns the whole array on every
+    rank.  Blocks are padded to the largest one for the collective; NCCL/RCCL takes device tensors, other backends
+    (gloo: CPU tests, single-device rehearsals) are staged through the host."""
+    import torch.distributed as dist
+    rank, world = dist_world()
+    if world == 1:
+        return local
+    sizes = [bounds[r + 1] - bounds[r] for r in range(world)]
+    mx = max(sizes)
+    nccl = dist.get_backend() == "nccl"
+    src = local if nccl else local.cpu()
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=src.device)
+    pad[: sizes[rank]] = src
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    out = torch.cat([parts[r][: sizes[r]] for r in range(world)], 0)
+    return out.to(local.device)
+
+
+def broadcast_seed(seed):
+    """The same seed on every rank (rank 0's: a call with seed=None draws one from the posterior's own counter)."""
+    import torch.distributed as dist
+    rank, world = dist_world()
+    if world == 1:
+        return seed
+    box = [seed]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]

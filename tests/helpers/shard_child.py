@@ -1,0 +1,67 @@
+"""One rank of tests/test_gpu_configs.py::test_rank_sharded_catalogue_evaluation_equals_the_single_process_call.
+
+Started as a fresh child process (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT / SF_DP_OUT in the environment); both
+ranks share cuda:0, so the process group is gloo and the gathers are staged through the host.  Builds the same fitter
+state as the parent (seeded untrained flows + a prior box) and runs the PRODUCT calls under the process group:
+SBI_Fitter.sample_posterior, .log_prob and .fit_catalogue."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def build(kind):
+    """The fitter of the test: deterministic, no training (shared by the parent and the children)."""
+    from synference_amd.estimator import build_flow
+    from synference_amd.fitter import SBI_Fitter
+    from synference_amd.posterior import EnsemblePosterior, FlowPosterior
+    from synference_amd.priors import CustomIndependentUniform
+    from synference_amd.synthetic import make_catalogue
+    C, D = (10, 5) if kind == "maf" else (20, 8)
+    x, theta, names = make_catalogue(3000, C, D, seed=21)
+    dev = torch.device("cuda:0")
+    members = []
+    for i in range(2 if kind == "nsf" else 1):
+        est = build_flow(kind, theta[:2000], x[:2000], hidden_features=50, num_transforms=3, num_bins=8, device=dev,
+                         generator=torch.Generator().manual_seed(5 + i)).to(dev)
+        with torch.no_grad():   # (a random-init flow is nearly the identity: widen it a little so that the box rejects)
+            est.flat.mul_(1.5)
+        lo = (theta[:2000].mean(0) - 2.5 * theta[:2000].std(0)).astype(np.float32)
+        hi = (theta[:2000].mean(0) + 2.5 * theta[:2000].std(0)).astype(np.float32)
+        members.append(FlowPosterior(est, CustomIndependentUniform(lo, hi, device="cuda")))
+    post = EnsemblePosterior(members, weights=[0.6, 0.4][: len(members)]) if len(members) > 1 else EnsemblePosterior(members, weights=[1.0])
+    f = SBI_Fitter("shard", names, [f"F{i}" for i in range(C)], feature_array=x, parameter_array=theta)
+    f.posteriors = post
+    f._prior = members[0].prior
+    return f, x, theta
+
+
+def run(f, x, theta):
+    X, Y = x[2000:2101], theta[2000:2101]            # 101 rows: the blocks of two ranks differ in length
+    s = f.sample_posterior(X, num_samples=64, seed=17)
+    lp = f.log_prob(X, Y, num_rejection_samples=512)
+    import pandas as pd
+    tab = f.fit_catalogue(pd.DataFrame(X, columns=list(f.feature_names)), num_samples=128, seed=9, append_to_input=False)
+    return {"samples": s, "lp": lp, "table": tab.to_numpy(float)}
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {}
+    for kind in ("maf", "nsf"):
+        f, x, theta = build(kind)
+        out[kind] = run(f, x, theta)
+    torch.save(out, os.path.join(os.environ["SF_DP_OUT"], f"shard_rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

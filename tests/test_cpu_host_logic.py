@@ -461,3 +461,48 @@ def test_create_features_from_observations_follows_the_reference_rules():
     assert removed2.tolist() == [False, True, False, False, False]
     feat3, removed3 = g.create_features_from_observations(obs, {"m0": "F0", "m1": "F1"}, flux_units="AB", ignore_missing=True)
     assert not removed3.any() and feat3.shape == (5, 2)
+
+
+# ------------------------------------------------------------------------------------------------
+# round 3: rank-sharded catalogue evaluation (host side: row blocks, gather, seed agreement)
+# ------------------------------------------------------------------------------------------------
+def _shard_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from synference_amd.posterior import all_gather_rows, broadcast_seed, dist_world, shard_bounds
+    assert dist_world() == (rank, world)
+    full = torch.arange(7 * 3 * 2, dtype=torch.float32).reshape(7, 3, 2)      # 7 rows over 2 ranks: blocks of 3 and 4
+    b = shard_bounds(7, world)
+    got = all_gather_rows(full[b[rank]:b[rank + 1]].clone(), b)
+    seed = broadcast_seed(1234 if rank == 0 else 999)
+    vec = all_gather_rows(torch.arange(b[rank], b[rank + 1], dtype=torch.float32), b)  # 1-D payload (log_prob)
+    ret[rank] = (got.clone(), seed, b, vec.clone())
+    dist.destroy_process_group()
+
+
+def test_row_sharding_gathers_uneven_blocks_and_agrees_on_the_seed():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_shard_worker, args=(2, 33500 + (os.getpid() % 2000), ret), nprocs=2, join=True)
+    full = torch.arange(7 * 3 * 2, dtype=torch.float32).reshape(7, 3, 2)
+    for r in range(2):
+        got, seed, b, vec = ret[r]
+        assert b == [0, 3, 7]
+        assert torch.equal(got, full) and seed == 1234
+        assert torch.equal(vec, torch.arange(7, dtype=torch.float32))
+    from synference_amd.posterior import shard_bounds
+    for n, w in ((10, 3), (8, 8), (100001, 8)):
+        b = shard_bounds(n, w)
+        assert b[0] == 0 and b[-1] == n and all(b[i] <= b[i + 1] for i in range(w))
+        assert max(b[i + 1] - b[i] for i in range(w)) - min(b[i + 1] - b[i] for i in range(w)) <= 1
+
+
+def test_oracle_streams_are_keyed_by_the_row_position():
+    """oracle/posterior.py restates sf_flow_set_sample_row_offset: a block of rows with row_offset draws what those rows
+    draw inside the whole catalogue."""
+    from cases import make_case
+    from oracle import posterior as OP
+    ospec, spec, flat, theta, x = make_case("maf_small", B=6, spread=0.2)
+    whole, _ = OP.sample(ospec, torch.as_tensor(flat), x, 9, 5, dtype=torch.float64)
+    part, _ = OP.sample(ospec, torch.as_tensor(flat), x[2:5], 9, 5, dtype=torch.float64, row_offset=2)
+    assert np.array_equal(whole[2:5], part)

@@ -162,6 +162,47 @@ def test_cfg3_data_parallel_training_on_the_hip_kernels(tmp_path):
     assert (r0["grad"] - ref).abs().max() < 1e-5 * max(1.0, ref.abs().max().item())
 
 
+def test_rank_sharded_catalogue_evaluation_equals_the_single_process_call(tmp_path):
+    """catalogue rows are sharded over the ranks as contiguous blocks (no data-path collective) and gathered.
+    Two fresh child ranks (gloo, both on cuda:0) run SBI_Fitter.sample_posterior / log_prob / fit_catalogue under a
+    process group; every rank must return, bit for bit, what this single process returns."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "helpers"))
+    import shard_child
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   SF_DP_OUT=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "helpers", "shard_child.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    r0 = torch.load(tmp_path / "shard_rank0.pt", weights_only=False)
+    r1 = torch.load(tmp_path / "shard_rank1.pt", weights_only=False)
+    for kind in ("maf", "nsf"):
+        f, x, theta = shard_child.build(kind)
+        ref = shard_child.run(f, x, theta)
+        assert np.isfinite(ref["samples"]).all() and np.isfinite(ref["lp"]).any()   # (-inf: theta outside the box)
+        for k in ("samples", "lp", "table"):
+            assert np.array_equal(r0[kind][k], ref[k], equal_nan=True), (kind, k, "rank 0 vs single process")
+            assert np.array_equal(r1[kind][k], ref[k], equal_nan=True), (kind, k, "rank 1 vs single process")
+    # and the draws of a block do not depend on how the catalogue is cut: rows 40..60 alone, keyed by their position
+    f, x, theta = shard_child.build("maf")
+    whole = f.posteriors.sample_catalogue(torch.as_tensor(x[2000:2101]), 64, 17)
+    part = f.posteriors.sample_catalogue(torch.as_tensor(x[2040:2060]), 64, 17, row_offset=40)
+    assert torch.equal(whole[40:60], part)
+
+
 @pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "maf_wide"])
 def test_large_batch_gradient_path_matches_autograd(name):
     """Batches above 512 rows take the many-tiles accumulation path of the training kernels (gradient-image replicas
