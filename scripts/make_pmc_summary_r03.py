@@ -1,0 +1,72 @@
+"""profiles/r03_pmc_summary.json from the per-kernel counter rows written by scripts/prof_collect_r03.sh
+(profiles/r03_pmc_maf.csv: default bench; profiles/r03_pmc_nsf.csv: bench.py --workload nsf_cfg3; four separate
+rocprofv3 --pmc passes each: FETCH_SIZE | WRITE_SIZE | two SQ sets).  Keys of the top level / "train" are the ones
+bench.py reads (hbm_bytes_per_launch, *_busy_frac); "nsf" holds the sampler / log_prob / training kernels of cfg3."""
+import collections, csv, json, os, re, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+
+
+def section(rows, pat, grid=None, alg_bytes=None, note=None):
+    acc = collections.defaultdict(list); dur = {}; kern = None; meta = None
+    for r in rows:
+        if not re.search(pat, r["Kernel_Name"]) or (grid is not None and int(r["Grid_Size"]) != grid):
+            continue
+        acc[r["Counter_Name"]].append(float(r["Counter_Value"])); kern = r["Kernel_Name"]
+        dur[(r["Counter_Name"], r["Dispatch_Id"])] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size")}
+    if not acc:
+        return None
+    m = {k: sum(v) / len(v) for k, v in acc.items()}
+    d_sq = [v for (c, _), v in dur.items() if c == "SQ_WAVE_CYCLES"] or list(dur.values())
+    us = sum(d_sq) / len(d_sq)
+    simd_cycles = 1024 * us * 1e-6 * 2.4e9
+    out = {"kernel": kern, "launch": meta, "launches_averaged": len(d_sq), "kernel_us_under_pmc": us,
+           "FETCH_SIZE_KB_raw": m.get("FETCH_SIZE"), "WRITE_SIZE_KB": m.get("WRITE_SIZE"),
+           "gfx950_correction": "FETCH_SIZE reports 1/2 of wide coalesced reads on gfx950 (MI355X_MICROARCH.md, HBM section): doubled",
+           "hbm_bytes_per_launch": (2 * m.get("FETCH_SIZE", 0.0) + m.get("WRITE_SIZE", 0.0)) * 1024,
+           "algorithmic_bytes_per_launch": alg_bytes}
+    for k in ("SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_VALU_TRANS_F32",
+              "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_VALU_MFMA_COEXEC_CYCLES", "SQ_BUSY_CYCLES", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
+        if k in m:
+            out[k] = m[k]
+    for k in ("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+        if k in m:
+            out[k + "_quad"] = m[k]
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in m:
+        out["mfma_busy_frac"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles
+        out["valu_busy_frac"] = 4 * m["SQ_ACTIVE_INST_VALU"] / simd_cycles
+        out["wait_frac_of_wave_cycles"] = m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"]
+    if "SQ_WAIT_INST_ANY" in m and "SQ_WAVE_CYCLES" in m:
+        out["issue_stall_frac_of_wave_cycles"] = m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]
+        out["issuing_frac_of_wave_cycles"] = m["SQ_ACTIVE_INST_ANY"] / m["SQ_WAVE_CYCLES"]
+    if note:
+        out["note"] = note
+    return out
+
+
+maf = list(csv.DictReader(open(os.path.join(P, f"{tag}_pmc_maf.csv"))))
+M, S, D, C, P_ = 2000, 1000, 5, 10, 32300
+out = section(maf, "k_maf_samp16", alg_bytes=4.0 * D * M * S + 4.0 * C * M)
+out["command"] = ("rocprofv3 --pmc <COUNTERS> --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 "
+                  "--no-cpu-baseline (separate passes: FETCH_SIZE | WRITE_SIZE | SQ_* | SQ_*; scripts/prof_collect_r03.sh)")
+out["note"] = ("busy fractions = counter / (1024 SIMDs x launch time x 2.4 GHz); *_quad counters count quad-cycles.  One sampler "
+               "launch = one whole bench step (2000 galaxies x 1000 accepted draws, first attempts + retries).")
+# training kernel at the bench batch: 16 384 rows = 256 workgroups of 512 threads
+out["train"] = section(maf, "k_maf_trainc", grid=256 * 512, alg_bytes=4.0 * (D + C) * 16384 + 4.0 * 2 * P_,
+                       note="cooperative 16-row kernel, batch 16 384: per-workgroup gradient partials are written with plain stores "
+                            "(256 x 145 KB) and summed by k_gather_c")
+out["train_gather"] = section(maf, "k_gather_c")
+out["train_prep"] = section(maf, "k_train_prep")
+nsf_path = os.path.join(P, f"{tag}_pmc_nsf.csv")
+if os.path.exists(nsf_path):
+    nsf = list(csv.DictReader(open(nsf_path)))
+    Mn, Dn, Cn = 20000, 8, 20
+    out["nsf"] = {
+        "command": "the same passes over  bench.py --workload nsf_cfg3 --steps 2 --warmup 1  (BASELINE configs[2])",
+        "sampler": section(nsf, "k_sample_persist", alg_bytes=4.0 * Dn * Mn * 1000 + 4.0 * Cn * Mn),
+        "log_prob": section(nsf, "k_logprob"),
+        "train16384": section(nsf, "k_nsf_train", grid=512 * 128, alg_bytes=4.0 * (Dn + Cn) * 16384 + 4.0 * 2 * 91570),
+    }
+json.dump(out, open(os.path.join(P, f"{tag}_pmc_summary.json"), "w"), indent=1)
+print(json.dumps(out, indent=1)[:6000])

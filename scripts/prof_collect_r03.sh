@@ -1,0 +1,70 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): everything behind profiles/r03_*.
+#   1. rocprofv3 --kernel-trace --stats of the default bench command          -> kernel_stats.csv, kernels.txt
+#   2. three separate --pmc passes of the default bench (FETCH_SIZE | WRITE_SIZE | SQ_*)  -> per-kernel counter rows
+#   3. the same for the NSF workload of BASELINE configs[2] (bench.py --workload nsf_cfg3)
+#   4. un-profiled bench lines of both workloads
+# Only small summaries are kept (gpurun_out/prof_r03/); scripts/make_pmc_summary_r03.py turns them into
+# profiles/r03_pmc_summary.json, which bench.py reads `traffic` / `issue_busy` from.
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/prof_r03; RAW=/tmp/sfprof3; rm -rf $RAW; mkdir -p $OUT $RAW
+say() { echo "[$(date +%H:%M:%S)] $*" | tee -a $OUT/progress.log; }
+
+trace() {  # tag, bench args
+  rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/stats_$1 -- python3 bench.py $2 --no-cpu-baseline > $OUT/bench_under_rocprof_$1.json 2> $RAW/stats_$1.err
+  cp $RAW/stats_$1/*/*_kernel_stats.csv $OUT/kernel_stats_$1.csv
+  python3 - "$RAW/stats_$1" "$OUT/kernels_$1.txt" <<'PY'
+import csv, glob, sys, statistics, collections
+rows = list(csv.DictReader(open(glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv')[0])))
+dur = lambda r: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+groups = collections.defaultdict(list)
+for r in rows:
+    groups[(r['Kernel_Name'], r['Grid_Size_X'], r['Workgroup_Size_X'])].append(r)
+with open(sys.argv[2], 'w') as f:
+    for key, rs in sorted(groups.items(), key=lambda kv: -sum(map(dur, kv[1]))):
+        d = list(map(dur, rs))
+        if sum(d) < 50: continue
+        f.write(f"{key[0]}\n  grid={key[1]} wg={key[2]} launches n={len(rs)} avg_us={statistics.mean(d):.1f} median_us={statistics.median(d):.1f} "
+                f"min_us={min(d):.1f} max_us={max(d):.1f} total_ms={sum(d)/1e3:.2f}\n"
+                f"  VGPR={rs[0]['VGPR_Count']} AGPR={rs[0]['Accum_VGPR_Count']} SGPR={rs[0]['SGPR_Count']} LDS={rs[0]['LDS_Block_Size']} scratch={rs[0]['Scratch_Size']}\n")
+PY
+}
+
+pmc() {  # tag, bench args, kernel regex
+  for pass in "FETCH_SIZE" "WRITE_SIZE" \
+              "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_ANY" \
+              "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VMEM"; do
+    t=$(echo $pass | cut -d' ' -f1)
+    rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $RAW/pmc_$1_$t -- python3 bench.py $2 --no-cpu-baseline > /dev/null 2> $RAW/pmc_$1_$t.err
+    say "pmc $1 $t done"
+  done
+  python3 - "$RAW" "$1" "$3" "$OUT/pmc_$1.csv" <<'PY'
+import csv, glob, sys, re
+raw, tag, pat, out = sys.argv[1], sys.argv[2], re.compile(sys.argv[3]), sys.argv[4]
+rows = []
+for f in sorted(glob.glob(f"{raw}/pmc_{tag}_*/*/*_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        if pat.search(r['Kernel_Name']):
+            rows.append({k: r[k] for k in ('Dispatch_Id', 'Kernel_Name', 'Grid_Size', 'Workgroup_Size', 'VGPR_Count', 'Accum_VGPR_Count',
+                                           'SGPR_Count', 'LDS_Block_Size', 'Scratch_Size', 'Counter_Name', 'Counter_Value',
+                                           'Start_Timestamp', 'End_Timestamp')})
+w = csv.DictWriter(open(out, 'w'), fieldnames=rows[0].keys()); w.writeheader(); w.writerows(rows)
+print(len(rows), "counter rows ->", out)
+PY
+}
+
+say "kernel trace, default bench"
+trace maf ""
+say "PMC passes, default bench"
+pmc maf "--steps 3 --warmup 1" "k_maf_samp16|k_maf_trainc|k_gather_c|k_train_prep|k_adam|k_logprob"
+say "kernel trace, nsf_cfg3"
+trace nsf "--workload nsf_cfg3 --steps 3 --warmup 1"
+say "PMC passes, nsf_cfg3"
+pmc nsf "--workload nsf_cfg3 --steps 2 --warmup 1" "k_sample_persist|k_logprob|k_nsf_train"
+say "un-profiled bench lines"
+python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+say "default bench done"
+python3 bench.py --workload nsf_cfg3 --no-cpu-baseline > $OUT/bench_nsf_cfg3.json 2> $OUT/bench_nsf_cfg3.err
+say "all done"
+ls -la $OUT
