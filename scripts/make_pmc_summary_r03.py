@@ -8,13 +8,18 @@ P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "p
 
 
 def section(rows, pat, grid=None, alg_bytes=None, note=None):
+    """rows: the aggregated table of prof_collect_r03.sh (one row per kernel x launch shape x counter)."""
     acc = collections.defaultdict(list); dur = {}; kern = None; meta = None
-    for r in rows:
-        if not re.search(pat, r["Kernel_Name"]) or (grid is not None and int(r["Grid_Size"]) != grid):
-            continue
-        acc[r["Counter_Name"]].append(float(r["Counter_Value"])); kern = r["Kernel_Name"]
-        dur[(r["Counter_Name"], r["Dispatch_Id"])] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    # of several launch shapes of one kernel (warm-up fit, bench batch ...) take `grid`, else the one with the longest launches
+    cand = [r for r in rows if re.search(pat, r["Kernel_Name"]) and (grid is None or int(r["Grid_Size"]) == grid)]
+    if cand and grid is None:
+        best = max(cand, key=lambda r: float(r["Mean_us"]))
+        cand = [r for r in cand if r["Grid_Size"] == best["Grid_Size"] and r["Kernel_Name"] == best["Kernel_Name"]]
+    for r in cand:
+        acc[r["Counter_Name"]].append(float(r["Counter_Mean"])); kern = r["Kernel_Name"]
+        dur[(r["Counter_Name"], "all")] = float(r["Mean_us"])
         meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size")}
+        meta["launches_per_counter_pass"] = int(r["Launches"])
     if not acc:
         return None
     m = {k: sum(v) / len(v) for k, v in acc.items()}

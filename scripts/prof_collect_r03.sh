@@ -40,17 +40,25 @@ pmc() {  # tag, bench args, kernel regex
     say "pmc $1 $t done"
   done
   python3 - "$RAW" "$1" "$3" "$OUT/pmc_$1.csv" <<'PY'
-import csv, glob, sys, re
+# per (kernel, grid, workgroup size, counter): mean counter value, launches, mean duration -- a few hundred rows
+import csv, glob, sys, re, collections
 raw, tag, pat, out = sys.argv[1], sys.argv[2], re.compile(sys.argv[3]), sys.argv[4]
-rows = []
+acc = collections.defaultdict(lambda: [0.0, 0, 0.0]); meta = {}
 for f in sorted(glob.glob(f"{raw}/pmc_{tag}_*/*/*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if pat.search(r['Kernel_Name']):
-            rows.append({k: r[k] for k in ('Dispatch_Id', 'Kernel_Name', 'Grid_Size', 'Workgroup_Size', 'VGPR_Count', 'Accum_VGPR_Count',
-                                           'SGPR_Count', 'LDS_Block_Size', 'Scratch_Size', 'Counter_Name', 'Counter_Value',
-                                           'Start_Timestamp', 'End_Timestamp')})
-w = csv.DictWriter(open(out, 'w'), fieldnames=rows[0].keys()); w.writeheader(); w.writerows(rows)
-print(len(rows), "counter rows ->", out)
+        if not pat.search(r['Kernel_Name']): continue
+        key = (r['Kernel_Name'], r['Grid_Size'], r['Workgroup_Size'], r['Counter_Name'])
+        a = acc[key]
+        a[0] += float(r['Counter_Value']); a[1] += 1; a[2] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+        meta[key[:3]] = (r['VGPR_Count'], r['Accum_VGPR_Count'], r['SGPR_Count'], r['LDS_Block_Size'], r['Scratch_Size'])
+with open(out, 'w') as fh:
+    w = csv.writer(fh)
+    w.writerow(['Kernel_Name', 'Grid_Size', 'Workgroup_Size', 'VGPR_Count', 'Accum_VGPR_Count', 'SGPR_Count', 'LDS_Block_Size',
+                'Scratch_Size', 'Counter_Name', 'Counter_Mean', 'Launches', 'Mean_us'])
+    for key in sorted(acc):
+        a = acc[key]
+        w.writerow(list(key[:3]) + list(meta[key[:3]]) + [key[3], a[0] / a[1], a[1], a[2] / a[1]])
+print(len(acc), "aggregated counter rows ->", out)
 PY
 }
 

@@ -44,7 +44,7 @@ static int ensure_device(sf_flow* f) {
   SF_HIP(hipMalloc(&f->d_s2, np * sizeof(int32_t)));
   SF_HIP(hipMemcpy(f->d_s1, f->L.src1.data(), np * sizeof(int32_t), hipMemcpyHostToDevice));
   SF_HIP(hipMemcpy(f->d_s2, f->L.src2.data(), np * sizeof(int32_t), hipMemcpyHostToDevice));
-  if (f->L.dev.m16_ok && f->L.n_packed16 > 0) {
+  if ((f->L.dev.m16_ok || f->L.nsfS.ok) && f->L.n_packed16 > 0) {
     const size_t n16 = (size_t)f->L.n_packed16;
     SF_HIP(hipMalloc(&f->d_packed16, n16 * sizeof(float)));
     SF_HIP(hipMalloc(&f->d_s16a, n16 * sizeof(int32_t)));
@@ -52,7 +52,7 @@ static int ensure_device(sf_flow* f) {
     SF_HIP(hipMemcpy(f->d_s16a, f->L.src16a.data(), n16 * sizeof(int32_t), hipMemcpyHostToDevice));
     SF_HIP(hipMemcpy(f->d_s16b, f->L.src16b.data(), n16 * sizeof(int32_t), hipMemcpyHostToDevice));
   }
-  if (f->L.dev.m16_ok && f->L.n_packed16B > 0) {
+  if ((f->L.dev.m16_ok || f->L.nsfS.ok) && f->L.n_packed16B > 0) {
     const size_t nB = (size_t)f->L.n_packed16B;
     SF_HIP(hipMalloc(&f->d_packed16B, nB * sizeof(unsigned short)));
     SF_HIP(hipMalloc(&f->d_s16B, nB * sizeof(int32_t)));
@@ -270,11 +270,20 @@ int sf_flow_inverse_from_noise(sf_flow* f, const float* z, const float* x, int64
   return SF_OK;
 }
 
+static void nsf_sampler_view(const sf_flow* f, SfDev& m);
 int sf_flow_inverse_from_noise_sampler(sf_flow* f, const float* z, const float* x, int64_t B, float* theta, void* stream) {
   if (!f) return fail(SF_ERR_INVALID, "null handle");
   if (B == 0) return SF_OK;
   if (!z || !x || !theta) return fail(SF_ERR_INVALID, "null argument");
   if (!f->params_set) return fail(SF_ERR_STATE, "sf_flow_set_params has not been called");
+  if (f->L.dev.kind == SF_NSF) {  // NSF: the sampling kernels themselves, on the sampler image when the flow has one
+    SfDev ms = f->dev();
+    nsf_sampler_view(f, ms);
+    SfSampleArgsHost a;
+    a.x = x; a.z_in = z; a.n_items = (long)B; a.out = theta;
+    SF_HIP(sf_launch_inverse(ms, a, (hipStream_t)stream));
+    return ms.hidden_bf16 == 2 ? SF_OK : 1;
+  }
   const SfDev m = f->dev();
   if (!sf_maf16b_available(m) || sf_sampler_fp32_get()) {  // the sampler of this flow is the fp32 path
     SfSampleArgsHost a;
@@ -347,12 +356,34 @@ int sf_flow_release_context(sf_flow* f) {
 }
 
 // device view for a sampling launch over context rows x: attaches the table when it was prepared for x
+// NSF: the sampling kernels run on the sampler image (fp32 blocks without W1 / W2 + their split-bf16 form, SfNsfSamp):
+// the descriptor handed to them has its image pointer, stride and block offsets replaced; the kernels themselves only see
+// hidden_bf16 == 2.  sf_set_sampler_fp32(1) / SF_SAMPLER_FP32=1 keeps the all-fp32 image.
+static void nsf_sampler_view(const sf_flow* f, SfDev& m) {
+  const SfNsfSamp& s = f->L.nsfS;
+  if (m.kind != SF_NSF || !s.ok || m.hidden_bf16 || !f->d_packed16 || !f->d_packed16B || f->packed16_stale || sf_sampler_fp32_get()) return;
+  m.packed = f->d_packed16;
+  m.t_stride = s.t_stride;
+  m.o_winu = s.o_winu; m.o_winc = s.o_winc; m.o_bin = s.o_bin; m.o_wout = s.o_wout; m.o_bout = s.o_bout; m.o_lu = s.o_lu;
+  for (int k = 0; k < SF_NBMAX; ++k) {
+    m.o_wg[k] = s.o_wg[k]; m.o_bg[k] = s.o_bg[k]; m.o_b1[k] = s.o_b1[k]; m.o_b2[k] = s.o_b2[k];
+    m.o_w1[k] = 0; m.o_w2[k] = 0;  // (not in this image)
+    m.oB_w1[k] = s.oB_w1[k]; m.oB_w2[k] = s.oB_w2[k];
+    m.blk_part[k] = 0;
+  }
+  m.n_parts = 1; m.part_off[0] = 0; m.part_off[1] = s.t_stride; m.part_max = s.t_stride; m.head_part = 0;
+  m.packedB = f->d_packed16B;
+  m.tB_stride = s.tB_stride;
+  m.hidden_bf16 = 2;
+  m.packed16 = nullptr; m.packed16B = nullptr;
+}
 static SfDev sampler_dev(const sf_flow* f, const float* x) {
   SfDev m = f->dev();
   if (f->ctab_x != nullptr && f->ctab_x == x) {
     sf_ctab_shape(m, m.ctab_R, m.ctab_NV);
     m.ctab = f->d_ctab;
   }
+  nsf_sampler_view(f, m);
   return m;
 }
 

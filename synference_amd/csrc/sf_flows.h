@@ -527,7 +527,8 @@ struct SfSplineBwd {
   }
 };
 
-template <int HT, int PT, int NS, bool LDSW = false, bool BF = false>
+// BF: 0 = fp32 hidden blocks; 1 = single bf16 operands (sf_flow_desc.hidden_bf16); 2 = split bf16 x3 (sampler image)
+template <int HT, int PT, int NS, bool LDSW = false, int BF = 0>
 struct NsfOps {
   // ResidualNet conditioner -> hidden tiles
   // returns the (possibly LDS) base pointer valid for the spline head
@@ -559,7 +560,11 @@ struct NsfOps {
           f32x16 t1[HT][NS];
           sf_init_bias<HT, NS>(t1, tp + m.o_b1[k], h);
           sf_init_bias<HT, NS>(t2, tp + m.o_b2[k], h);
-          if (BF) {
+          if (BF == 2) {
+            const unsigned short* tpB = sf_bf16_base<LDSW>(m, t, lds);
+            sf_mm_acc_bf16_split<HT, NS, HT, true>(t1, hid, tpB + m.oB_w1[k], m.nKS, m.nKS, lane);
+            sf_mm_acc_bf16_split<HT, NS, HT, true>(t2, t1, tpB + m.oB_w2[k], m.nKS, m.nKS, lane);
+          } else if (BF == 1) {
             const unsigned short* tpB = sf_bf16_base<LDSW>(m, t, lds);
             sf_mm_acc_bf16<HT, NS, HT, true>(t1, hid, tpB + m.oB_w1[k], m.nKS, m.nKS, lane);
             sf_mm_acc_bf16<HT, NS, HT, true>(t2, t1, tpB + m.oB_w2[k], m.nKS, m.nKS, lane);

@@ -144,11 +144,21 @@ static hipError_t launch_inverse(const SfDev& m, const SfSampleArgsHost& a, hipS
 
 #if SF_KIND == 0
 #define SF_BF_SWITCH(FN, ...) { using OB = MafOps<SF_HT, 1, true, true>; return FN<OB>(__VA_ARGS__); }
+#define SF_BFS_SWITCH(FN, ...) SF_BF_SWITCH(FN, __VA_ARGS__)
 #else
 #define SF_BF_SWITCH(FN, ...)                                                              \
   switch (m.PT) {                                                                          \
-    case 2: { using OB = NsfOps<SF_HT, 2, 1, true, true>; return FN<OB>(__VA_ARGS__); }    \
-    case 3: { using OB = NsfOps<SF_HT, 3, 1, true, true>; return FN<OB>(__VA_ARGS__); }    \
+    case 2: { using OB = NsfOps<SF_HT, 2, 1, true, 1>; return FN<OB>(__VA_ARGS__); }       \
+    case 3: { using OB = NsfOps<SF_HT, 3, 1, true, 1>; return FN<OB>(__VA_ARGS__); }       \
+    default: return hipErrorInvalidValue;                                                  \
+  }
+// sampling kernels: single bf16 (opt-in) or split bf16 x3 (the NSF sampler image)
+#define SF_BFS_SWITCH(FN, ...)                                                             \
+  switch (m.PT * 10 + m.hidden_bf16) {                                                     \
+    case 21: { using OB = NsfOps<SF_HT, 2, 1, true, 1>; return FN<OB>(__VA_ARGS__); }      \
+    case 31: { using OB = NsfOps<SF_HT, 3, 1, true, 1>; return FN<OB>(__VA_ARGS__); }      \
+    case 22: { using OB = NsfOps<SF_HT, 2, 1, true, 2>; return FN<OB>(__VA_ARGS__); }      \
+    case 32: { using OB = NsfOps<SF_HT, 3, 1, true, 2>; return FN<OB>(__VA_ARGS__); }      \
     default: return hipErrorInvalidValue;                                                  \
   }
 #endif
@@ -180,7 +190,7 @@ hipError_t SF_CAT(sf_launch_logprob_k, SF_KIND, _h, SF_HT)(const SfDev& m, int n
 
 hipError_t SF_CAT(sf_launch_inverse_k, SF_KIND, _h, SF_HT)(const SfDev& m, int ns, const SfSampleArgsHost& a,
                                                            hipStream_t st) {
-  if (m.hidden_bf16) SF_BF_SWITCH(launch_inverse_bf16, m, a, st)
+  if (m.hidden_bf16) SF_BFS_SWITCH(launch_inverse_bf16, m, a, st)
 #if SF_HT <= 2
   if (ns == 2 && !a.q) SF_PT_SWITCH(2, launch_inverse, m, a, st)
 #endif

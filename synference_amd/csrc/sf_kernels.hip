@@ -183,7 +183,7 @@ hipError_t sf_launch_inverse(const SfDev& m, const SfSampleArgsHost& a_in, hipSt
 // per-galaxy context table (sampling): which flows have one, and its builder
 void sf_ctab_shape(const SfDev& m, int& R, int& NV) {
   R = 0; NV = 0;
-  if (m.hidden_bf16) return;
+  if (m.hidden_bf16 == 1) return;
   if (m.kind == SF_NSF) { R = m.HT * 32; NV = 1 + m.NB; }
   else if (m.kind == SF_MAF && m.m16_ok && m.packed16 != nullptr) { R = m.nT16 * 16; NV = 1; }
 }

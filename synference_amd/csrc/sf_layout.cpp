@@ -91,6 +91,7 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
   SfDev& v = L.dev;
   std::memset(&v, 0, sizeof(v));
   std::memset(&L.trc, 0, sizeof(L.trc));
+  std::memset(&L.nsfS, 0, sizeof(L.nsfS));
   v.kind = d.kind; v.D = D; v.C = C; v.H = H; v.T = T; v.K = K; v.NB = NB;
   v.scale_fn = d.scale_fn;
   v.HT = ceil_div(H, 32);
@@ -636,6 +637,9 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
       }
     }
   } else {
+    Emitter ES{L.src16a, L.src16b, nullptr};  // NSF sampler image, fp32 part (sf_layout.h, SfNsfSamp)
+    SfNsfSamp& sS = L.nsfS;
+    sS.ok = d.hidden_bf16 ? 0 : 1;
     v.PT = K <= 11 ? 2 : 3;  // PT=1 (K<=5) is not instantiated: K<=11 shares the 2-tile layout
     v.KMAX = (v.PT * 16 + 1) / 3;
     const int dtr_max = (D + 1) / 2;
@@ -738,6 +742,72 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
         for (int i = 0; i < D; ++i) E.push(D > 1 ? (int32_t)(lDi + i) : -1, -1);
         for (int i = 0; i < D; ++i) E.push(D > 1 ? (int32_t)(lBi + i) : -1, -1);
       }
+      // ---- sampler image: the same blocks without W1 / W2, and those as split bf16
+      if (sS.ok) {
+        const int64_t tbS = ES.pad_to(64);
+        if (t == 1) sS.t_stride = (int)tbS;
+        int oS;
+        oS = (int)(ES.linear(HT, v.nGu, hrow_out, urow, lWin, in_dim, 1, nullptr) - tbS);
+        if (t == 0) sS.o_winu = oS;
+        oS = (int)(ES.linear(HT, v.nGc, hrow_out, crow, lWin, in_dim, 1, nullptr) - tbS);
+        if (t == 0) sS.o_winc = oS;
+        oS = (int)(ES.bias(HT, hrow_out, lbin, -1) - tbS);
+        if (t == 0) sS.o_bin = oS;
+        for (int k = 0; k < NB; ++k) {
+          oS = (int)(ES.linear(HT, v.nGc, hrow_out, crow_in, lWg[k], C, 1, nullptr) - tbS);
+          if (t == 0) sS.o_wg[k] = oS;
+          oS = (int)(ES.bias(HT, hrow_out, lbg[k], -1) - tbS);
+          if (t == 0) sS.o_bg[k] = oS;
+          oS = (int)(ES.bias(HT, hrow_out, lb1[k], -1) - tbS);
+          if (t == 0) sS.o_b1[k] = oS;
+          oS = (int)(ES.bias(HT, hrow_out, lb2[k], -1) - tbS);
+          if (t == 0) sS.o_b2[k] = oS;
+        }
+        oS = (int)(ES.linear(v.JP * v.PT, v.nGh, orow, hrow_in, lWout, H, 1, nullptr) - tbS);
+        if (t == 0) sS.o_wout = oS;
+        oS = (int)(ES.bias(v.JP * v.PT, orow, lbout, -1) - tbS);
+        if (t == 0) sS.o_bout = oS;
+        {
+          int64_t sl = ES.pad_to(4);
+          if (t == 0) sS.o_lu = (int)(sl - tbS);
+          std::vector<int32_t> Lm(D * D, -1), Um(D * D, -1);
+          if (D > 1) {
+            int n = 0;
+            for (int i = 0; i < D; ++i)
+              for (int j = 0; j < i; ++j) Lm[i * D + j] = (int32_t)(lLo + n++);
+            n = 0;
+            for (int i = 0; i < D; ++i)
+              for (int j = i + 1; j < D; ++j) Um[i * D + j] = (int32_t)(lUp + n++);
+          }
+          for (int i = 0; i < D * D; ++i) ES.push(Lm[i], -1);
+          for (int i = 0; i < D * D; ++i) ES.push(Um[i], -1);
+          for (int i = 0; i < D; ++i) ES.push(D > 1 ? (int32_t)(lDi + i) : -1, -1);
+          for (int i = 0; i < D; ++i) ES.push(D > 1 ? (int32_t)(lBi + i) : -1, -1);
+        }
+        // split-bf16 hidden blocks: [mt][ks][hi | lo][64 lanes][8]; element j of lane (c, h) = input row
+        // 16 ks + 8 (j >> 2) + 4 h + (j & 3) (the order sf_bfrag hands the activations to v_mfma_f32_32x32x16_bf16)
+        while (L.src16B.size() % 64) L.src16B.push_back(-1);
+        const int64_t tbB = (int64_t)L.src16B.size();
+        if (t == 1) sS.tB_stride = (int)tbB;
+        auto emit_split = [&](int64_t base) -> int {
+          const int64_t start = (int64_t)L.src16B.size() - (t >= 1 ? (int64_t)t * sS.tB_stride : 0);
+          for (int mt = 0; mt < HT; ++mt)
+            for (int ks = 0; ks < v.nKS; ++ks)
+              for (int part = 0; part < 2; ++part)
+                for (int l = 0; l < 64; ++l)
+                  for (int j = 0; j < 8; ++j) {
+                    const int o_ = hrow_full[mt * 32 + (l & 31)];
+                    const int rho = 16 * ks + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
+                    const int i_ = rho < 128 ? hrow_full[rho] : -1;
+                    L.src16B.push_back((o_ >= 0 && i_ >= 0) ? (int32_t)((base + (int64_t)o_ * H + i_) | ((int64_t)part << 30)) : -1);
+                  }
+          return (int)start;
+        };
+        for (int k = 0; k < NB; ++k) {
+          const int a1 = emit_split(lW1[k]), a2 = emit_split(lW2[k]);
+          if (t == 0) { sS.oB_w1[k] = a1; sS.oB_w2[k] = a2; }
+        }
+      }
       // ---- transposed operands for the data-gradient pass ("o" = forward input, "i" = forward output)
       {
         const int64_t tbT = ET.pad_to(64);
@@ -777,11 +847,19 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
     v.t_stride = (int)E.cur; v.tT_stride = (int)ET.cur; v.tB_stride = (int)L.srcB.size();
     v.t16_stride = (int)L.src16a.size();
   }
+  if (d.kind == SF_NSF && L.nsfS.ok) {
+    while (L.src16a.size() % 64) { L.src16a.push_back(-1); L.src16b.push_back(-1); }
+    while (L.src16B.size() % 64) L.src16B.push_back(-1);
+    if (T == 1) { L.nsfS.t_stride = (int)L.src16a.size(); L.nsfS.tB_stride = (int)L.src16B.size(); }
+    // one transform's fp32 part + split part must fit the LDS budget next to the sampler's control block
+    if ((size_t)L.nsfS.t_stride * 4 + (size_t)L.nsfS.tB_stride * 2 > (size_t)152 * 1024 || (L.nsfS.tB_stride & 7)) L.nsfS.ok = 0;
+    if (!L.nsfS.ok) { L.src16a.clear(); L.src16b.clear(); L.src16B.clear(); }
+  }
   L.n_packed16 = (int64_t)L.src16a.size();
-  while (L.src16B.size() % 2048) L.src16B.push_back(-1);
+  if (d.kind == SF_MAF) while (L.src16B.size() % 2048) L.src16B.push_back(-1);
   if (T == 1) v.t16B_stride = (int)(L.src16B.size() / 2);
   L.n_packed16B = (int64_t)L.src16B.size();
-  if (!v.m16_ok) { L.src16B.clear(); L.n_packed16B = 0; }
+  if (!v.m16_ok && !L.nsfS.ok) { L.src16B.clear(); L.n_packed16B = 0; }
   if (v.m16_ok && (size_t)v.t16_stride * sizeof(float) > 152 * 1024) v.m16_ok = 0;
   L.n_packedB = (int64_t)L.srcB.size();
   // ---- LDS staging plan (budget: 152 KiB of the 160 KiB LDS; the rest holds the persistent sampler's control block) ---------------------------------

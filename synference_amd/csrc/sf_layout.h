@@ -65,6 +65,7 @@ struct SfDev {
   // bf16 operand image of the hidden HxH layers (inference, opt-in): [mt][ks][lane][8] bf16, ks = 16-row steps
   const unsigned short* packedB;
   int hidden_bf16, nKS, tB_stride;            // nKS = ceil(nGh/2); strides / offsets in bf16 elements
+                                              // hidden_bf16: 1 = single bf16 operands (opt-in), 2 = split bf16 x3 (NSF sampler image)
   int oB_wk[SF_NBMAX], oB_w1[SF_NBMAX], oB_w2[SF_NBMAX];
   // 16-row-granular image of the incremental MAF inverse (v_mfma_f32_16x16x4_f32; sf_maf16.h) --------------
   //   tile = 16 samples x 16 rows in 4 VGPRs: lane l: sample l&15, rows 4*(l>>4)+r; degree groups packed whole
@@ -117,8 +118,22 @@ struct SfTrcDev {
   int c_jobs, n_jobs;  // constants image: [n_jobs] float-encoded (ot*4 + it) of the unmasked hidden weight blocks
 };
 
+// NSF sampler image (sampling kernels only): the fp32 operand image WITHOUT the hidden W1 / W2 blocks, followed in LDS
+// by those blocks as split bf16 -- hi = bf16(w), lo = bf16(w - hi), per block [mt][ks][hi | lo][64 lanes][8], the A operand of
+// v_mfma_f32_32x32x16_bf16 in the k order of sf_bfrag -- so that hi.hi + hi.lo + lo.hi reproduce the fp32 product to ~2^-17
+// at a fifth of the matrix-pipe time.  The tables live in SfLayout::src16a / src16b (fp32 part) and src16B (split part, logical
+// index | part << 30), like the 16-row MAF sampler image.  log_prob and training never use it.
+struct SfNsfSamp {
+  int ok;
+  int t_stride;   // floats per transform of the fp32 part
+  int o_winu, o_winc, o_bin, o_wg[SF_NBMAX], o_bg[SF_NBMAX], o_b1[SF_NBMAX], o_b2[SF_NBMAX], o_wout, o_bout, o_lu;
+  int tB_stride;  // bf16 elements per transform of the split part
+  int oB_w1[SF_NBMAX], oB_w2[SF_NBMAX];
+};
+
 struct SfLayout {
   SfDev dev;  // pointers left null
+  SfNsfSamp nsfS;                     // nsfS.ok == 0: no NSF sampler image
   SfTrcDev trc;                       // trc.ok == 0: no cooperative training image for this flow
   std::vector<int32_t> srcC1, srcC2;  // its gather table (sum of two sources, like src1/src2)
   std::vector<int32_t> gdstC;         // logical parameter -> index in a gradient partial (or -1)

@@ -53,7 +53,7 @@ def test_inverse_from_noise_matches_oracle(name):
     assert np.abs(lp - ref).max() < 5e-4, np.abs(lp - ref).max()
 
 
-@pytest.mark.parametrize("name", ["maf_cfg1", "maf_span6", "maf_span_h64"])
+@pytest.mark.parametrize("name", ["maf_cfg1", "maf_span6", "maf_span_h64", "nsf_cfg3", "nsf_odd", "nsf_k16"])
 def test_sampler_arithmetic_from_given_noise(name):
     """The persistent sampler evaluates the hidden H x H blocks as split-bf16 x3 products (fp32 accumulation).  Its pass
     functions, fed GIVEN noise (sf_flow_inverse_from_noise_sampler), must meet the fp64 oracle within 1e-4 of the
@@ -64,7 +64,7 @@ def test_sampler_arithmetic_from_given_noise(name):
     z = rng.normal(size=theta.shape).astype(np.float32)
     f = _flow(spec, flat)
     th, split = f.inverse_sampler(z, x)
-    assert split, "these shapes run the split-bf16 16-row sampler"
+    assert split, "these shapes run a split-bf16 sampler (MAF: 16-row kernel; NSF: sampler image, hidden_bf16 == 2)"
     th = th.cpu().double().numpy()
     rth, _ = oracle_inverse(ospec, flat, z, x, torch.float64)
     scale = np.asarray(ospec.theta_std)
