@@ -181,7 +181,7 @@ int sf_flow_release_context(sf_flow* f);
 
 /* Whole sampler.  ONE persistent launch works the catalogue's M*S output slots -- first attempts and the retries of
  * rejected slots are scheduled on the device (no host round trip per rejection round) -- up to 1024 attempts per slot
- * (256 on the 32-row kernels).  The few slots that are still empty then (their galaxy accepts less than about one draw
+ * (all kernels since round 3).  The few slots that are still empty then (their galaxy accepts less than about one draw
  * in a thousand) are continued chip-wide: a "find" launch evaluates a whole range of attempts of every open slot side by
  * side and records the lowest accepted one, a "resolve" launch re-evaluates exactly that attempt and writes the draw.
  * Every slot keeps the LOWEST accepted attempt of its Philox stream (slot, attempt): the draws do not depend on how the
@@ -220,7 +220,7 @@ int sf_flow_sample_slots(sf_flow* f, const float* x /*[M,C]*/, int64_t M, int64_
                          int32_t max_attempts, float* out /*[M,S,D]*/, int64_t* n_unfilled /*host*/, void* stream);
 
 /* Figures of the last sf_flow_sample / sf_flow_sample_slots call (host [4]): duration in ms of its first persistent
- * launch (HIP events on the call's stream; the only launch unless some slot needed more than 1024 / 256 attempts), number of
+ * launch (HIP events on the call's stream; the only launch unless some slot needed more than 1024 attempts), number of
  * launches, slots whose FIRST attempt was rejected, flow evaluations over all launches. */
 int sf_flow_sample_stats(const sf_flow* f, float* stats4);
 

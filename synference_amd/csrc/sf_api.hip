@@ -481,7 +481,11 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
   // the 16-row MAF kernel tries a slot 64 times per workgroup iteration, the 32-row kernels 32 times per tile: the
   // first (persistent) launch goes as deep as a short sequential chain allows, the windows beyond are chip-wide
   const bool fast16 = m.kind == SF_MAF && m.m16_ok && !m.hidden_bf16 && m.packed16 != nullptr;
-  uint32_t first_window = fast16 ? 1024u : 256u;
+  // (round 3: 1 024 for the 32-row kernels too -- with the split-bf16 NSF sampler cfg3 takes 80 ms per 2e7 draws at 1 024,
+  //  87 at 256, 101 at 4 096: deeper windows leave the persistent launch with a few slow slots, shallower ones leave more
+  //  survivors to the find / resolve launches)
+  uint32_t first_window = 1024u;
+  (void)fast16;
   {
     static int env_w = -1;  // developer knob: SF_FIRST_WINDOW=<attempts> (power of two)
     if (env_w < 0) { const char* e = std::getenv("SF_FIRST_WINDOW"); env_w = e ? std::atoi(e) : 0; }

@@ -36,8 +36,18 @@ struct SfTrcArgs {
     if (a.trace && blockIdx.x == 0 && (threadIdx.x & 63) == 0)                                              \
       a.trace[(threadIdx.x >> 6) * 256 + (slot)] = __builtin_readcyclecounter();                            \
   } while (0)
+// fine stamps inside one phase of one transform: `dep` (a VGPR value) must be complete before the stamp is taken
+#define SF_TCX(cond, slot, dep)                                                                             \
+  do {                                                                                                      \
+    if (cond) {                                                                                             \
+      float d_ = (dep);                                                                                     \
+      asm volatile("v_mov_b32 %0, %0\n\ts_waitcnt lgkmcnt(0)" : "+v"(d_) :: "memory");                     \
+      SF_TC(slot);                                                                                          \
+    }                                                                                                       \
+  } while (0)
 #else
 #define SF_TC(slot) do { } while (0)
+#define SF_TCX(cond, slot, dep) do { } while (0)
 #endif
 
 size_t sf_trainc_lds_bytes(const SfTrcDev& c, int TS, int NG);

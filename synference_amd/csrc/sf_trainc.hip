@@ -38,6 +38,17 @@ __device__ __forceinline__ f32x4 c_mma(const float4 w, const f32x4 in, f32x4 acc
   acc = SF_MFMA16(w.w, in[3], acc);
   return acc;
 }
+// two independent products, their MFMAs alternating (neither chain is dependent back to back)
+__device__ __forceinline__ void c_mma2(const float4 wa, const f32x4 ina, f32x4& acca, const float4 wb, const f32x4 inb, f32x4& accb) {
+  acca = SF_MFMA16(wa.x, ina[0], acca);
+  accb = SF_MFMA16(wb.x, inb[0], accb);
+  acca = SF_MFMA16(wa.y, ina[1], acca);
+  accb = SF_MFMA16(wb.y, inb[1], accb);
+  acca = SF_MFMA16(wa.z, ina[2], acca);
+  accb = SF_MFMA16(wb.z, inb[2], accb);
+  acca = SF_MFMA16(wa.w, ina[3], acca);
+  accb = SF_MFMA16(wb.w, inb[3], accb);
+}
 __device__ __forceinline__ f32x4 c_ld4(const float* p) {
   const float4 b = *reinterpret_cast<const float4*>(p);
   f32x4 r;
@@ -58,6 +69,16 @@ __device__ __forceinline__ f32x4 c_zero() {
   f32x4 z;
   z[0] = 0.f; z[1] = 0.f; z[2] = 0.f; z[3] = 0.f;
   return z;
+}
+
+// One block product split over two partial accumulators (k-steps 0, 2 -> acc0; 1, 3 -> acc1): two MFMAs on one accumulator
+// are always two issues apart, so the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32 (issue: 32) never stalls the
+// wave, without any extra control flow.  The caller adds the partials once per layer.
+__device__ __forceinline__ void c_mma_alt(const float4 w, const f32x4 in, f32x4& acc0, f32x4& acc1) {
+  acc0 = SF_MFMA16(w.x, in[0], acc0);
+  acc1 = SF_MFMA16(w.y, in[1], acc1);
+  acc0 = SF_MFMA16(w.z, in[2], acc0);
+  acc1 = SF_MFMA16(w.w, in[3], acc1);
 }
 // LDS tile addressing: a tile (16 rows x 16 samples of subtile q) is 256 floats
 //   B layout: lane l holds float4 at l*4 (rows 4*(l>>4)+r of sample l&15): the MFMA B operand of a data product
@@ -103,9 +124,9 @@ template <int NQ>
 __device__ __forceinline__ void c_dw_jobs(const CJob& A, const CJob& B, bool two, bool accumulate, int lane) {
   f32x4 accA = c_zero(), accB = c_zero();
   float bsA = 0.f, bsB = 0.f;
-  if (two) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
+  if (two) {  // (two blocks at once: their chains alternate, the 40-cycle dependent latency of the MFMA is hidden)
+#pragma unroll 2
+    for (int q = 0; q < NQ; ++q) {  // (two subtiles' operands in flight at a time: 32 registers, not 64)
       const float4 dA = *reinterpret_cast<const float4*>(A.Td + (A.ot * NQ + q) * 256 + lane * 4);
       const float4 iA = *reinterpret_cast<const float4*>(A.Ti + (A.it * NQ + q) * 256 + lane * 4);
       const float4 dB = *reinterpret_cast<const float4*>(B.Td + (B.ot * NQ + q) * 256 + lane * 4);
@@ -123,17 +144,19 @@ __device__ __forceinline__ void c_dw_jobs(const CJob& A, const CJob& B, bool two
     }
     c_dw_finish(A, accA, bsA, accumulate, lane);
     c_dw_finish(B, accB, bsB, accumulate, lane);
-  } else {
+  } else {  // one block: two partial accumulators over alternating k-steps, for the same reason
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const float4 dA = *reinterpret_cast<const float4*>(A.Td + (A.ot * NQ + q) * 256 + lane * 4);
       const float4 iA = *reinterpret_cast<const float4*>(A.Ti + (A.it * NQ + q) * 256 + lane * 4);
       accA = SF_MFMA16(dA.x, iA.x, accA);
-      accA = SF_MFMA16(dA.y, iA.y, accA);
+      accB = SF_MFMA16(dA.y, iA.y, accB);
       accA = SF_MFMA16(dA.z, iA.z, accA);
-      accA = SF_MFMA16(dA.w, iA.w, accA);
+      accB = SF_MFMA16(dA.w, iA.w, accB);
       bsA += (dA.x + dA.y) + (dA.z + dA.w);
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) accA[r] += accB[r];
     c_dw_finish(A, accA, bsA, accumulate, lane);
   }
 }
@@ -323,25 +346,36 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
         c_barrier();
         // F2: a1 = tanh(b1 + W1 h0)
         float4 wff[2];
+        SF_TCX(t == 1, 200, u0);
         if (has0) {
 #pragma unroll
           for (int i = 0; i < 5; ++i) w2f[i] = c_frag(tp + c.o_w2, NT, fslot_tile(i), fslot_it(i), lane);
           wff[0] = c_frag(tp + c.o_wf, NT, 0, tA, lane);
           wff[1] = c_frag(tp + c.o_wf, NT, 0, tB_, lane);
           f32x4 accA = c_ld4(cb + NT * 16 + (tA * 4 + g4) * 4), accB = c_ld4(cb + NT * 16 + (tB_ * 4 + g4) * 4);
+          SF_TCX(t == 1, 201, accA[0] + accB[0]);
+          SF_TCX(t == 1, 202, w1f[0].x + w1f[4].x);
+{
+            f32x4 accA1 = c_zero(), accB1 = c_zero();
 #pragma unroll
-          for (int i = 0; i < 5; ++i) {
-            if (i < nfT) {
-              const f32x4 tv = c_ld4(XBa + (fslot_it(i) * NQ + q) * 256 + lane * 4);
-              if (i < nfA) accA = c_mma(w1f[i], tv, accA);
-              else accB = c_mma(w1f[i], tv, accB);
+            for (int i = 0; i < 5; ++i) {
+              if (i < nfT) {
+                const f32x4 tv = c_ld4(XBa + (fslot_it(i) * NQ + q) * 256 + lane * 4);
+                if (i < nfA) c_mma_alt(w1f[i], tv, accA, accA1);
+                else c_mma_alt(w1f[i], tv, accB, accB1);
+              }
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { accA[r] += accA1[r]; accB[r] += accB1[r]; }
           }
+          SF_TCX(t == 1, 203, accA[0] + accB[0] + accA[3] + accB[3]);
 #pragma unroll
           for (int r = 0; r < 4; ++r) { accA[r] = sf_tanh(accA[r]); accB[r] = sf_tanh(accB[r]); }
+          SF_TCX(t == 1, 204, accA[0] + accB[0] + accA[3] + accB[3]);
           a1s[t][0] = accA; a1s[t][1] = accB;
           c_st4(XBb + (tA * NQ + q) * 256 + lane * 4, accA);
           if (has1) c_st4(XBb + (tB_ * NQ + q) * 256 + lane * 4, accB);
+          SF_TCX(t == 1, 205, accA[0]);
         }
         SF_TC(3 + 5 * t);
         c_barrier();
@@ -356,13 +390,18 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
             }
           }
           f32x4 accA = c_ld4(cb + 2 * NT * 16 + (tA * 4 + g4) * 4), accB = c_ld4(cb + 2 * NT * 16 + (tB_ * 4 + g4) * 4);
+{
+            f32x4 accA1 = c_zero(), accB1 = c_zero();
 #pragma unroll
-          for (int i = 0; i < 5; ++i) {
-            if (i < nfT) {
-              const f32x4 tv = c_ld4(XBb + (fslot_it(i) * NQ + q) * 256 + lane * 4);
-              if (i < nfA) accA = c_mma(w2f[i], tv, accA);
-              else accB = c_mma(w2f[i], tv, accB);
+            for (int i = 0; i < 5; ++i) {
+              if (i < nfT) {
+                const f32x4 tv = c_ld4(XBb + (fslot_it(i) * NQ + q) * 256 + lane * 4);
+                if (i < nfA) c_mma_alt(w2f[i], tv, accA, accA1);
+                else c_mma_alt(w2f[i], tv, accB, accB1);
+              }
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { accA[r] += accA1[r]; accB[r] += accB1[r]; }
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) { accA[r] = sf_tanh(accA[r]); accB[r] = sf_tanh(accB[r]); }
@@ -502,13 +541,18 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
           wiT[0] = c_frag(tp + c.o_winT, NT, 0, tA, lane);
           wiT[1] = c_frag(tp + c.o_winT, NT, 0, tB_, lane);
           f32x4 accA = c_zero(), accB = c_zero();
+{
+            f32x4 accA1 = c_zero(), accB1 = c_zero();
 #pragma unroll
-          for (int i = 0; i < 5; ++i) {
-            if (i < nbT) {
-              const f32x4 tv = c_ld4(XBa + (bslot_ot(i) * NQ + q) * 256 + lane * 4);
-              if (i < nbA) accA = c_mma(pw2T[i], tv, accA);
-              else accB = c_mma(pw2T[i], tv, accB);
+            for (int i = 0; i < 5; ++i) {
+              if (i < nbT) {
+                const f32x4 tv = c_ld4(XBa + (bslot_ot(i) * NQ + q) * 256 + lane * 4);
+                if (i < nbA) c_mma_alt(pw2T[i], tv, accA, accA1);
+                else c_mma_alt(pw2T[i], tv, accB, accB1);
+              }
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { accA[r] += accA1[r]; accB[r] += accB1[r]; }
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -542,13 +586,18 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
         auto b3_data = [&]() {
         if (has0) {
           f32x4 accA = c_zero(), accB = c_zero();
+{
+            f32x4 accA1 = c_zero(), accB1 = c_zero();
 #pragma unroll
-          for (int i = 0; i < 5; ++i) {
-            if (i < nbT) {
-              const f32x4 tv = c_ld4(XBb + (bslot_ot(i) * NQ + q) * 256 + lane * 4);
-              if (i < nbA) accA = c_mma(w1T[i], tv, accA);
-              else accB = c_mma(w1T[i], tv, accB);
+            for (int i = 0; i < 5; ++i) {
+              if (i < nbT) {
+                const f32x4 tv = c_ld4(XBb + (bslot_ot(i) * NQ + q) * 256 + lane * 4);
+                if (i < nbA) c_mma_alt(w1T[i], tv, accA, accA1);
+                else c_mma_alt(w1T[i], tv, accB, accB1);
+              }
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { accA[r] += accA1[r]; accB[r] += accB1[r]; }
           }
           c_put_T(TD0 + (tA * NQ + q) * 256, accA, s, g4);
           f32x4 dup = c_mma(wiT[0], accA, c_zero());
