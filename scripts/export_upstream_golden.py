@@ -44,6 +44,18 @@ def build(model, theta, x, hidden_features, num_transforms, num_bins):
     return est, kw
 
 
+def pip_freeze():
+    """exact versions of the packages the arithmetic lives in (they are un-pinned upstream)"""
+    import subprocess
+    import sys
+    try:
+        txt = subprocess.run([sys.executable, "-m", "pip", "freeze"], capture_output=True, text=True, timeout=120).stdout
+    except Exception:
+        return []
+    keep = ("sbi", "nflows", "pyknos", "torch", "numpy", "ltu-ili", "ili", "zuko", "lampe", "pyro")
+    return [ln for ln in txt.splitlines() if ln.split("==")[0].split(" @")[0].lower() in keep]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="tests/golden")
@@ -56,7 +68,11 @@ def main():
     except ImportError:
         import nflows as nf
         nfv = getattr(nf, "__version__", "nflows")
-    for model, D, C, H, T, K in (("maf", 5, 10, 50, 5, 10), ("nsf", 8, 20, 50, 5, 8)):
+    cases = (("maf", "maf", 5, 10, 50, 5, 10),          # BASELINE configs[1]
+             ("maf_span", "maf", 6, 10, 64, 3, 10),    # degree groups straddle the 16-row tiles of the sampler
+             ("nsf", "nsf", 8, 20, 50, 5, 8),           # BASELINE configs[2]
+             ("nsf_k10", "nsf", 5, 10, 30, 3, 10))      # sbi's default num_bins
+    for tag, model, D, C, H, T, K in cases:
         torch.manual_seed(a.seed)
         rng = np.random.default_rng(a.seed)
         theta = torch.as_tensor(rng.normal(size=(2000, D)) * rng.uniform(0.5, 2.0, size=D) + rng.normal(size=D), dtype=torch.float32)
@@ -73,13 +89,45 @@ def main():
             lp = flow.log_prob(te, context=xe)
             emb = flow._embedding_net(xe)
             th, lad = flow._transform.inverse(z, context=emb)
+        extra = {}
+        if model == "maf":
+            # which scale parametrisation this nflows build uses (softplus(a) + 1e-3 since 0.14, sigmoid(a + 2) + 1e-3
+            # before): with theta = 0 the first transform's log|det| is sum log(scale(final-layer bias))
+            t0 = flow._transform._transforms[-1]._transforms[0]
+            with torch.no_grad():
+                a_ = t0.autoregressive_net.final_layer.bias.detach().view(-1, 2)[:, 0].double()
+                _, ld0 = t0(torch.zeros(1, D), context=emb[:1])
+            sp = float(torch.log(torch.nn.functional.softplus(a_) + 1e-3).sum())
+            sg = float(torch.log(torch.sigmoid(a_ + 2.0) + 1e-3).sum())
+            # (the first output's degree is 1: it sees no hidden unit, so its scale is a function of the bias alone;
+            #  the other outputs depend on the context -- compare the bias-only output)
+            extra["scale_fn_probe"] = np.array([sp, sg, float(ld0)])
+        # [UPSTREAM] DirectPosterior.sample against a fixed prior box: acceptance rate per observation
+        try:
+            from sbi.inference.posteriors import DirectPosterior
+            from sbi.utils import BoxUniform
+            lo = theta.mean(0) - 1.0 * theta.std(0)
+            hi = theta.mean(0) + 1.0 * theta.std(0)
+            post = DirectPosterior(posterior_estimator=est, prior=BoxUniform(lo, hi))
+            acc = []
+            for i in range(8):
+                with torch.no_grad():
+                    smp = flow.sample(20000, context=xe[i:i + 1])[0]
+                acc.append(float(((smp >= lo) & (smp <= hi)).all(-1).float().mean()))
+            s8 = post.sample((64,), x=xe[0], show_progress_bars=False)
+            extra.update(box_lo=lo.numpy(), box_hi=hi.numpy(), box_acceptance=np.array(acc),
+                         direct_posterior_samples_x0=s8.numpy())
+        except Exception as e:  # the surface moved between sbi versions: the density / inverse vectors above are what matters
+            extra["direct_posterior_error"] = np.array(repr(e))
         out = {"sd/" + k: v.detach().cpu().numpy() for k, v in flow.state_dict().items()}
+        out.update(extra)
         out.update(theta=te.numpy(), x=xe.numpy(), log_prob=lp.numpy().astype(np.float64), z=z.numpy(),
                    theta_from_z=th.numpy().astype(np.float64), logabsdet_inv=lad.numpy().astype(np.float64),
-                   meta=np.array(json.dumps(dict(model=model, sbi=sbi.__version__, nflows=str(nfv), builder_kwargs=kw,
+                   meta=np.array(json.dumps(dict(model=model, case=tag, sbi=sbi.__version__, nflows=str(nfv), torch=torch.__version__,
+                                                 numpy=np.__version__, pip_freeze=pip_freeze(), builder_kwargs=kw,
                                                  wrapper=type(est).__name__))))
         os.makedirs(a.out, exist_ok=True)
-        path = os.path.join(a.out, f"upstream_{model}.npz")
+        path = os.path.join(a.out, f"upstream_{tag}.npz")
         np.savez_compressed(path, **out)
         print("wrote", path, "log_prob[:3] =", lp[:3].tolist())
 

@@ -506,3 +506,76 @@ def test_oracle_streams_are_keyed_by_the_row_position():
     whole, _ = OP.sample(ospec, torch.as_tensor(flat), x, 9, 5, dtype=torch.float64)
     part, _ = OP.sample(ospec, torch.as_tensor(flat), x[2:5], 9, 5, dtype=torch.float64, row_offset=2)
     assert np.array_equal(whole[2:5], part)
+
+
+# ------------------------------------------------------------------------------------------------
+# round 3: the importer against a HAND-WRITTEN nflows state dict (real key names, mask / degree / permutation buffers)
+# ------------------------------------------------------------------------------------------------
+def test_importer_reads_a_hand_written_nflows_state_dict():
+    """Every key below is spelled the way ``nflows.flows.Flow.state_dict()`` spells it for
+    ``sbi.neural_nets.flow.build_maf`` (D = 2, H = 4, C = 1, one transform, z-scored theta and x): buffers included
+    (``mask``, ``degrees``, ``_permutation``, ``_shape``, ``_log_z``).  Nothing here comes from ``param_layout`` or
+    ``state_dict_from_flat``; the expected log-density is computed by the ~20 lines of numpy below, written from the
+    nflows forward pass (MaskedLinear: y = (W * mask) x + b; no activation after the initial layer; tanh after each
+    block's linear; ``unconstrained_scale, shift = out.view(-1, D, 2)``; ``scale = softplus(u) + 1e-3``)."""
+    from oracle import flows as OF
+    from synference_amd.importer import spec_and_flat_from_state_dict
+    rs = np.random.RandomState(7)
+    H, D, C = 4, 2, 1
+    W0, b0 = rs.randn(H, D), rs.randn(H)
+    Wc, bc = rs.randn(H, C), rs.randn(H)
+    W1, b1, W2, b2 = rs.randn(H, H), rs.randn(H), rs.randn(H, H), rs.randn(H)
+    Wf, bf = rs.randn(2 * D, H), rs.randn(2 * D)
+    # nflows MADE buffers for features = 2, hidden = 4: input degrees [1, 2]; hidden degrees arange(4) % 1 + 1 = 1;
+    # output degrees tile([1, 2], 2) in nflows' order (out_features = 2 * D, "repeat-interleave": [1, 1, 2, 2])
+    m0 = np.array([[1., 0.]] * 4)                   # hidden_degree >= input_degree
+    mh = np.ones((4, 4))
+    mf = np.array([[0.] * 4, [0.] * 4, [1.] * 4, [1.] * 4])   # output_degree > hidden_degree
+    mean_t, std_t = np.array([0.5, -1.0]), np.array([2.0, 0.5])
+    mean_x, std_x = np.array([3.0]), np.array([4.0])
+    pre = "_transform._transforms.1._transforms.0.autoregressive_net."
+    sd = {
+        "_transform._transforms.0._shift": (-mean_t / std_t).astype(np.float32),
+        "_transform._transforms.0._scale": (1.0 / std_t).astype(np.float32),
+        pre + "initial_layer.weight": W0.astype(np.float32), pre + "initial_layer.bias": b0.astype(np.float32),
+        pre + "initial_layer.mask": m0.astype(np.float32), pre + "initial_layer.degrees": np.array([1, 1, 1, 1]),
+        pre + "context_layer.weight": Wc.astype(np.float32), pre + "context_layer.bias": bc.astype(np.float32),
+        pre + "blocks.0.linear.weight": W1.astype(np.float32), pre + "blocks.0.linear.bias": b1.astype(np.float32),
+        pre + "blocks.0.linear.mask": mh.astype(np.float32), pre + "blocks.0.linear.degrees": np.array([1, 1, 1, 1]),
+        pre + "blocks.1.linear.weight": W2.astype(np.float32), pre + "blocks.1.linear.bias": b2.astype(np.float32),
+        pre + "blocks.1.linear.mask": mh.astype(np.float32), pre + "blocks.1.linear.degrees": np.array([1, 1, 1, 1]),
+        pre + "final_layer.weight": Wf.astype(np.float32), pre + "final_layer.bias": bf.astype(np.float32),
+        pre + "final_layer.mask": mf.astype(np.float32), pre + "final_layer.degrees": np.array([1, 1, 2, 2]),
+        "_transform._transforms.1._transforms.1._permutation": np.array([1, 0]),
+        "_embedding_net.0._mean": mean_x.astype(np.float32), "_embedding_net.0._std": std_x.astype(np.float32),
+        "_distribution._shape": np.array([2]), "_distribution._log_z": np.array(0.5 * 2 * np.log(2 * np.pi)),
+    }
+    # a sbi >= 0.23 checkpoint carries the same keys behind "net."
+    for prefix in ("", "net."):
+        spec, flat = spec_and_flat_from_state_dict({prefix + k: v for k, v in sd.items()})
+        assert (spec.kind, spec.D, spec.C, spec.H, spec.T, spec.NB) == ("maf", 2, 1, 4, 1, 2)
+        assert list(spec.perms[0]) == [1, 0]
+        ospec = OF.FlowSpec(kind="maf", D=2, C=1, H=4, T=1, perms=np.asarray(spec.perms),
+                            theta_mean=np.asarray(spec.theta_mean, np.float64), theta_std=np.asarray(spec.theta_std, np.float64),
+                            x_mean=np.asarray(spec.x_mean, np.float64), x_std=np.asarray(spec.x_std, np.float64))
+        theta = rs.randn(9, 2) * std_t + mean_t
+        x = rs.randn(9, 1) * std_x + mean_x
+        got = OF.log_prob(ospec, torch.as_tensor(flat, dtype=torch.float64), torch.as_tensor(theta), torch.as_tensor(x)).numpy()
+        # ---- the nflows forward pass, by hand (float32 weights as stored)
+        f32 = lambda a: a.astype(np.float32).astype(np.float64)
+        u = (theta - mean_t) / std_t
+        e = (x - f32(mean_x)) / f32(std_x)
+        h = u @ (f32(W0) * m0).T + f32(b0) + e @ f32(Wc).T + f32(bc)
+        h = np.tanh(h @ (f32(W1) * mh).T + f32(b1))
+        h = np.tanh(h @ (f32(W2) * mh).T + f32(b2))
+        out = (h @ (f32(Wf) * mf).T + f32(bf)).reshape(-1, 2, 2)
+        scale = np.logaddexp(0.0, out[..., 0]) + 1e-3
+        v = scale * u + out[..., 1]
+        z = v[:, [1, 0]]
+        want = -0.5 * (z ** 2).sum(1) - np.log(2 * np.pi) + np.log(scale).sum(1) - np.log(std_t).sum()
+        assert np.abs(got - want).max() < 1e-6, np.abs(got - want).max()
+    # a checkpoint wired differently (other hidden degrees -> other masks) is refused, not silently re-masked
+    bad = dict(sd)
+    bad[pre + "initial_layer.mask"] = np.array([[1., 1.]] * 4, dtype=np.float32)
+    with pytest.raises(ValueError, match="mask"):
+        spec_and_flat_from_state_dict(bad)
