@@ -113,6 +113,35 @@ def accept_reject_sample(spec: flows.FlowSpec, flat: torch.Tensor, x_row: np.nda
     return np.concatenate(kept, 0)[:S], n_kept / n_total, warned
 
 
+def accept_reject_sample_batched(spec: flows.FlowSpec, flat: torch.Tensor, x: np.ndarray, S: int, lo, hi,
+                                 generator: torch.Generator, dtype=torch.float32, max_rounds: int = 200):
+    """The same rejection sampler as ``accept_reject_sample`` for a whole catalogue at once (what a batched CPU
+    implementation of the reference's loop would do; the CPU baseline of bench.py that scales over cores): every round
+    proposes one draw for every still-empty slot of every galaxy in ONE batched inverse pass (torch.randn noise), keeps
+    the draws inside the box, repeats.  Returns (samples[M, S, D] float32 -- NaN where ``max_rounds`` ran out --,
+    proposals drawn)."""
+    flat = flat.to(dtype)
+    lo_ = torch.as_tensor(np.asarray(lo, dtype=np.float32))
+    hi_ = torch.as_tensor(np.asarray(hi, dtype=np.float32))
+    xs = torch.as_tensor(np.asarray(x)).to(dtype)
+    M = xs.shape[0]
+    out = torch.full((M * S, spec.D), float("nan"), dtype=torch.float32)
+    pending = torch.arange(M * S)
+    drawn = 0
+    for _ in range(max_rounds):
+        if pending.numel() == 0:
+            break
+        z = torch.randn(pending.numel(), spec.D, generator=generator, dtype=dtype)
+        with torch.no_grad():
+            th, _ = flows.inverse_transform(spec, flat, z, xs[pending // S])
+        th32 = th.to(torch.float32)
+        ok = ((th32 >= lo_) & (th32 <= hi_)).all(-1)
+        out[pending[ok]] = th32[ok]
+        drawn += int(pending.numel())
+        pending = pending[~ok]
+    return out.reshape(M, S, spec.D).numpy(), drawn
+
+
 def sample(spec, flat, x, S, seed, lo=None, hi=None, max_attempts=None, dtype=torch.float32, row_offset=0):
     """``posterior.sample((S,), x=x[g])`` for every row g -> (samples[M,S,D], n_drawn[M])."""
     M = len(x)

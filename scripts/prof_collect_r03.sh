@@ -65,11 +65,11 @@ PY
 say "kernel trace, default bench"
 trace maf ""
 say "PMC passes, default bench"
-pmc maf "--steps 3 --warmup 1" "k_maf_samp16|k_maf_trainc|k_gather_c|k_train_prep|k_adam|k_logprob"
+pmc maf "--steps 3 --warmup 1 --skip-throughput-regime" "k_maf_samp16|k_maf_trainc|k_gather_c|k_train_prep|k_adam|k_logprob"
 say "kernel trace, nsf_cfg3"
 trace nsf "--workload nsf_cfg3 --steps 3 --warmup 1"
 say "PMC passes, nsf_cfg3"
-pmc nsf "--workload nsf_cfg3 --steps 2 --warmup 1" "k_sample_persist|k_logprob|k_nsf_train"
+pmc nsf "--workload nsf_cfg3 --steps 2 --warmup 1 --skip-throughput-regime" "k_sample_persist|k_logprob|k_nsf_train"
 say "un-profiled bench lines"
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 say "default bench done"

@@ -45,17 +45,20 @@ static int sf_cu_count() {
 template <class Ops, int NS, bool LDSW, int WPB>
 static hipError_t launch_persist_w(const SfDev& m, const SfSampleArgsHost& a, size_t image_bytes, hipStream_t st) {
   static SfAttrCache attr;
-  static int resident = 0;
+  static SfResidentCache rcache;
   constexpr int IPW = WPB * 32 * NS;
   const size_t sh = image_bytes + SF_Q_WORDS(IPW) * sizeof(unsigned int);
   hipError_t e = set_shmem(k_sample_persist<Ops, NS, LDSW, WPB>, sh, attr);
   if (e != hipSuccess) return e;
-  if (!resident) {
+  int resident = 0, cur_dev = 0;
+  (void)hipGetDevice(&cur_dev);
+  if (!rcache.get(cur_dev, sh, resident)) {
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_sample_persist<Ops, NS, LDSW, WPB>, 64 * WPB, sh) !=
             hipSuccess || occ < 1)
       occ = 1;
     resident = sf_cu_count() * occ;
+    rcache.put(cur_dev, sh, resident);
   }
   long grid = (a.n_items + IPW - 1) / IPW;
   if (grid > resident) grid = resident;

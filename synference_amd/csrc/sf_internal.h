@@ -79,6 +79,21 @@ struct SfAttrCache {
   }
   void set(int dev) { if (dev >= 0 && dev < 16) done[dev] = true; }
 };
+// resident workgroups of a persistent kernel, cached per (device, dynamic LDS bytes): the occupancy of one template instance
+// depends on the flow's LDS footprint and the grid on the device's CU count -- a process that samples flows of different
+// sizes, or on a second GPU, must not reuse the first answer
+struct SfResidentCache {
+  int dev[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+  size_t sh[8] = {0};
+  int val[8] = {0};
+  int n = 0;
+  bool get(int d, size_t s, int& v) const {
+    for (int i = 0; i < 8; ++i)
+      if (dev[i] == d && sh[i] == s) { v = val[i]; return true; }
+    return false;
+  }
+  void put(int d, size_t s, int v) { dev[n & 7] = d; sh[n & 7] = s; val[n & 7] = v; ++n; }
+};
 void sf_set_error(const std::string& msg);  // thread-local message behind sf_last_error()
 
 // ---- the handle (shared by sf_api.hip and sf_train.hip) -------------------------------------

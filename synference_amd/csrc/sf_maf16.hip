@@ -971,7 +971,7 @@ template <int NB, bool SPAN>
 static hipError_t sf_launch16(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
   if (a.q) {  // persistent sampler: no more workgroups than the chip holds (more would only queue behind the spinning ones)
     static SfAttrCache attr;
-    static int resident = 0;
+    static SfResidentCache rcache;
     const size_t sh = ((size_t)m.t16_a + (size_t)m.t16B_stride) * sizeof(float) + SF_Q_WORDS(64) * sizeof(unsigned int);
     int attr_dev;
     if (attr.need(attr_dev)) {
@@ -979,7 +979,12 @@ static hipError_t sf_launch16(const SfDev& m, const SfSampleArgsHost& a, hipStre
       if (e != hipSuccess) return e;
       attr.set(attr_dev);
     }
-    if (!resident) resident = sf_resident_blocks16((const void*)k_maf_samp16<NB, SPAN>, sh, SPAN ? 3 : 4);
+    int resident = 0, cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    if (!rcache.get(cur_dev, sh, resident)) {
+      resident = sf_resident_blocks16((const void*)k_maf_samp16<NB, SPAN>, sh, SPAN ? 3 : 4);
+      rcache.put(cur_dev, sh, resident);
+    }
     long grid = (a.n_items + 63) / 64;
     if (grid > resident) grid = resident;
     SfSamp16Args args;

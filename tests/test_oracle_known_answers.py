@@ -255,3 +255,22 @@ def test_pit_ranks_known_answer():
     r = F.pit_ranks(s, np.array([[4.5, 4.5]]))
     assert np.allclose(r, [[0.5, 4 / 9]])
     assert np.isnan(F.pit_ranks(np.full((1, 4, 1), np.nan), np.zeros((1, 1)))).all()
+
+
+def test_batched_accept_reject_fills_every_slot_inside_the_box():
+    """oracle/posterior.py::accept_reject_sample_batched (the multi-core CPU baseline of bench.py): same target
+    distribution as the per-galaxy loop -- every slot filled, inside the box, per-galaxy means close to the loop's."""
+    import torch
+    from cases import make_case
+    from oracle import posterior as OP
+    ospec, spec, flat, theta, x = make_case("maf_small", B=6, spread=0.2)
+    fl = torch.as_tensor(flat)
+    free, _ = OP.sample(ospec, fl, x, 300, 5, dtype=torch.float32)
+    lo = np.quantile(free.reshape(-1, spec.D), 0.05, axis=0).astype(np.float32)
+    hi = np.quantile(free.reshape(-1, spec.D), 0.95, axis=0).astype(np.float32)
+    s, drawn = OP.accept_reject_sample_batched(ospec, fl, x, 400, lo, hi, torch.Generator().manual_seed(3))
+    assert s.shape == (6, 400, spec.D) and np.isfinite(s).all() and drawn > 6 * 400
+    assert ((s >= lo) & (s <= hi)).all()
+    ref = np.stack([OP.accept_reject_sample(ospec, fl, x[g], 400, lo, hi, torch.Generator().manual_seed(10 + g))[0] for g in range(6)])
+    sd = ref.std(1) + 1e-9
+    assert (np.abs(s.mean(1) - ref.mean(1)) < 5 * sd / np.sqrt(400) * np.sqrt(2)).all()
