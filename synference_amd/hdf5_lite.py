@@ -20,6 +20,7 @@ Pure Python + numpy + zlib; a 1e6-row library decodes at zlib speed (the chunks 
 """
 from __future__ import annotations
 
+import os
 import struct
 import zlib
 from typing import Dict, List, Optional, Tuple
@@ -64,7 +65,10 @@ class Dataset:
         arr = self.read()
         return arr[key]
 
-    def read(self) -> np.ndarray:
+    def read(self, out: "np.ndarray | None" = None, workers: "int | None" = None) -> np.ndarray:
+        """The whole dataset.  ``out``: a C-contiguous array of the dataset's shape and dtype to fill instead of a fresh
+        one (e.g. the numpy view of a pinned torch tensor, so that the host-to-device copy that follows is one DMA);
+        ``workers``: threads that inflate the chunks of a chunked dataset (default: the usable cores, at most 16)."""
         f = self.file
         dt = self.dtype
         if dt is None or self.layout is None:
@@ -79,19 +83,58 @@ class Dataset:
             addr, size = self.layout[1], self.layout[2]
             raw = b"\x00" * (n * dt.size) if addr == UNDEF else f._read(addr, size)
         else:
-            return self._read_chunked()
-        return np.frombuffer(raw[: n * dt.size], dtype=dt.np_dtype).reshape(self.shape).copy()
+            return self._read_chunked(out, workers)
+        arr = np.frombuffer(raw[: n * dt.size], dtype=dt.np_dtype).reshape(self.shape)
+        if out is not None:
+            self._check_out(out)
+            out[...] = arr
+            return out
+        return arr.copy()
 
-    def _read_chunked(self) -> np.ndarray:
+    def _check_out(self, out):
+        if tuple(out.shape) != tuple(self.shape) or out.dtype != self.dtype.np_dtype.newbyteorder("=") and out.dtype != self.dtype.np_dtype:
+            raise Hdf5Error(f"{self.name}: out must have shape {self.shape} and dtype {self.dtype.np_dtype}")
+
+    def _read_chunked(self, out=None, workers=None) -> np.ndarray:
         f, dt = self.file, self.dtype
         btree, cdims = self.layout[1], self.layout[2]          # cdims: chunk shape (without the element-size entry)
         rank = len(self.shape)
-        out = np.zeros(self.shape, dtype=dt.np_dtype)
+        if out is None:
+            out = np.zeros(self.shape, dtype=dt.np_dtype)
+        else:
+            self._check_out(out)
+            out[...] = 0
         if btree == UNDEF:
             return out
         csize = int(np.prod(cdims)) * dt.size
-        for offs, addr, nbytes, mask in f._chunk_btree(btree, rank):
-            raw = f._read(addr, nbytes)
+        chunks = list(f._chunk_btree(btree, rank))
+        # Chunks are independent: inflate them on a thread pool (zlib and the numpy byte shuffles release the GIL; file
+        # reads go through os.pread, which needs no shared file position) and let every task write its own slice of `out`.
+        if workers is None:
+            try:
+                workers = len(os.sched_getaffinity(0))
+            except AttributeError:
+                workers = os.cpu_count() or 1
+            workers = max(1, min(16, workers))
+        if workers > 1 and len(chunks) >= 4 * workers:
+            from concurrent.futures import ThreadPoolExecutor
+            fd = f._fh.fileno()
+
+            def task(part):
+                for c in part:
+                    self._decode_chunk(os.pread(fd, c[2], f._base + c[1]), c, out, csize, cdims, rank)
+            step = max(1, len(chunks) // (8 * workers))
+            with ThreadPoolExecutor(workers) as ex:
+                list(ex.map(task, [chunks[i:i + step] for i in range(0, len(chunks), step)]))
+            return out
+        for c in chunks:
+            self._decode_chunk(f._read(c[1], c[2]), c, out, csize, cdims, rank)
+        return out
+
+    def _decode_chunk(self, raw, c, out, csize, cdims, rank):
+        dt = self.dtype
+        offs, addr, nbytes, mask = c
+        if True:
             for i in range(len(self.filters) - 1, -1, -1):     # undo the pipeline in reverse order
                 if mask & (1 << i):
                     continue
@@ -114,7 +157,6 @@ class Dataset:
                 sl_out.append(slice(offs[d], hi))
                 sl_in.append(slice(0, hi - offs[d]))
             out[tuple(sl_out)] = chunk[tuple(sl_in)]
-        return out
 
 
 class Group:

@@ -77,3 +77,32 @@ def test_fitter_from_library_file(tmp_path):
     assert f.parameter_names == ["a", "b", "c"] and f.library_path == p and not f.has_features
     out = SBI_Fitter.init_from_hdf5("m", p, return_output=True)
     assert set(out) >= {"parameters", "photometry", "filter_codes", "parameter_names", "photometry_units", "parameter_units"}
+
+
+def test_large_chunked_library_is_inflated_on_a_thread_pool(tmp_path):
+    """SURVEY 8f f1 at size: a chunked + deflated + shuffled library (2.5e5 galaxies x 20 filters here; the 1e6-row file of
+    BASELINE configs[3] goes through the same path in tests/test_gpu_configs.py) read with several workers equals the
+    single-thread read and the arrays that were written; the rate is printed."""
+    import time
+    from helpers.hdf5_fixture import write_library
+    from synference_amd.hdf5_lite import File
+    from synference_amd.library import load_library_from_hdf5
+    rng = np.random.default_rng(3)
+    N, C, D = 250_000, 20, 8
+    phot = (rng.lognormal(2.0, 1.0, size=(C, N))).astype(np.float64)
+    par = rng.normal(size=(D, N)).astype(np.float64)
+    path = str(tmp_path / "big.h5")
+    write_library(path, phot, par, [f"F{i}" for i in range(C)], [f"p{i}" for i in range(D)], chunks=(4, 8192), gzip=1, shuffle=True)
+    t0 = time.perf_counter()
+    lib = load_library_from_hdf5(path, workers=8)
+    dt = time.perf_counter() - t0
+    assert np.array_equal(lib["photometry"], phot) and np.array_equal(lib["parameters"], par)
+    with File(path) as f:
+        t0 = time.perf_counter()
+        one = f["Grid/Photometry"].read(workers=1)
+        dt1 = time.perf_counter() - t0
+        buf = np.empty((C, N), dtype=np.float64)
+        assert f["Grid/Photometry"].read(out=buf, workers=4) is buf
+    assert np.array_equal(one, phot) and np.array_equal(buf, phot)
+    print(f"hdf5_lite: {N} rows x ({C} + {D}) float64 in {dt:.2f} s with 8 workers = {N / dt / 1e6:.2f} M rows/s "
+          f"(photometry alone, 1 worker: {dt1:.2f} s)")

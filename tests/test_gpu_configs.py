@@ -116,17 +116,25 @@ def test_cfg4_full_size_catalogue_1e5_sources_x_1000_draws():
 
 
 def test_cfg3_data_parallel_training_on_the_hip_kernels(tmp_path):
-    """Two fresh child ranks (gloo, both on cuda:0) run train_flow with HipTrainOps on a 1e6-row NSF mock."""
+    """Two fresh child ranks (gloo, both on cuda:0) run train_flow with HipTrainOps on a 1e6-row NSF mock.  The ranks read
+    the catalogue from a library FILE in the reference's on-disk format (SURVEY 8f f1 at size: 1e6 x (20 + 8) float64,
+    chunked + deflate + shuffle, written here by the test-side writer) through synference_amd.hdf5_lite."""
     from synference_amd.engine import HipFlow
     from synference_amd.estimator import build_flow
     from synference_amd.synthetic import make_catalogue
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers.hdf5_fixture import write_library
+    x_all, theta_all, names_all = make_catalogue(1_000_000, 20, 8, seed=11)
+    h5 = str(tmp_path / "cfg3_library.h5")
+    write_library(h5, np.ascontiguousarray(x_all.T).astype(np.float64), np.ascontiguousarray(theta_all.T).astype(np.float64),
+                  [f"F{i}" for i in range(20)], list(names_all), chunks=(4, 8192), gzip=1, shuffle=True)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   SF_DP_OUT=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+                   SF_DP_OUT=str(tmp_path), SF_DP_H5=h5, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "helpers", "dp_child.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -149,7 +157,8 @@ def test_cfg3_data_parallel_training_on_the_hip_kernels(tmp_path):
     assert (r0["flat"] - r0["flat0"]).abs().max() > 1e-3               # it trained
     # the all-reduced sharded gradient == the single-process gradient of the global batch
     assert torch.equal(r0["grad"], r1["grad"])
-    x, theta, _ = make_catalogue(1_000_000, 20, 8, seed=11)
+    print([ln for o in outs for ln in o.splitlines() if ln.startswith("library file")][:1])
+    x, theta = x_all, theta_all
     dev = torch.device("cuda:0")
     est = build_flow("nsf", theta[:20000], x[:20000], hidden_features=50, num_transforms=5, num_bins=8, device=dev,
                      generator=torch.Generator().manual_seed(3)).to(dev)
