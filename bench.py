@@ -420,7 +420,7 @@ def main():
     # the same step with the all-fp32 sampler kernels (sf_set_sampler_fp32), quoted beside the default: the default MAF
     # sampler runs its hidden H x H blocks as split-bf16 x3 products with fp32 accumulation
     fp32_leg = None
-    if wl["kind"] == "maf" and not a.hidden_bf16 and desc.get("m16_ok"):
+    if not a.hidden_bf16 and (desc.get("m16_ok") if wl["kind"] == "maf" else desc.get("nsf_split_sampler")):
         from synference_amd import _lib as _sflib
         _sflib.load().sf_set_sampler_fp32(1)
         try:
@@ -433,7 +433,8 @@ def main():
                 unf32 += sample_step(k, False)
             barrier_sync(world)
             t32 = max_over_ranks(time.perf_counter() - t0, world, dev, gloo)
-            fp32_leg = {"kernel": "k_sample_persist<MafOps> (32-row tiles, v_mfma_f32_32x32x2_f32 everywhere)",
+            fp32_leg = {"kernel": ("k_sample_persist<MafOps>" if wl["kind"] == "maf" else "k_sample_persist<NsfOps<..., BF = 0>>") +
+                                  " (32-row tiles, v_mfma_f32_32x32x2_f32 everywhere)",
                         "ms_per_step": 1e3 * t32 / n32, "value": (world * n32 * M * S - unf32 * world) / t32,
                         "unit": "samples/s", "steps": n32}
         finally:
@@ -547,8 +548,10 @@ def main():
     train_tf = f_train * B / (train_kernel_ms * 1e-3) / 1e12
     ttraffic, ttraffic_src = pmc_traffic("train") if a.workload == "maf_cfg2" else (None, None)
     kname = (("k_maf_samp16<NB,SPAN>" if desc.get("m16_ok") and not a.hidden_bf16 else "k_sample_persist<MafOps>")
-             if wl["kind"] == "maf" else "k_sample_persist<NsfOps>")
-    split = wl["kind"] == "maf" and desc.get("m16_ok") and not a.hidden_bf16
+             if wl["kind"] == "maf" else
+             ("k_sample_persist<NsfOps<..., BF = 2>> (sampler image, split-bf16 hidden blocks)" if desc.get("nsf_split_sampler") and
+              not a.hidden_bf16 else "k_sample_persist<NsfOps>"))
+    split = (not a.hidden_bf16) and bool(desc.get("m16_ok") if wl["kind"] == "maf" else desc.get("nsf_split_sampler"))
     tpath = flow.train_path(B)
     tkname = ({1: "k_maf_trainc<TS,NI,NT,1> (cooperative 16-row tiles, 4 waves per 32 samples)",
                2: "k_maf_trainc<TS,NI,NT,2> (cooperative 16-row tiles, 8 waves per 64 samples)"}.get(tpath)

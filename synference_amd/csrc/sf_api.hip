@@ -178,6 +178,7 @@ int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen) {
   add("o_wout", v.o_wout); add("o_bout", v.o_bout); add("o_lu", v.o_lu);
   add("c_pscale", v.c_pscale); add("c_pshift", v.c_pshift); add("c_tdim", v.c_tdim);
   add("c_xmean", v.c_xmean); add("c_xstd", v.c_xstd); add("c_dslot", v.c_dslot);
+  add("nsf_split_sampler", f->L.nsfS.ok); add("trainc_ok", f->L.trc.ok);
   add("inc_ok", v.inc_ok); add("hidden_bf16", v.hidden_bf16); add("tB_stride", v.tB_stride); add("n_parts", v.n_parts); add("part_max", v.part_max);
   add("n_params", f->L.n_params); add("n_packed", f->L.n_packed);
   {
