@@ -181,6 +181,43 @@ __device__ __forceinline__ void c_barrier() {
   asm volatile("" ::: "memory");
 }
 
+// Block offsets of the cooperative image and of a gradient partial: functions of (NT, NI) alone (sf_layout.cpp emits the blocks
+// in this order; sf_trainc_eligible checks the descriptor against these formulas), so the kernel carries them as
+// immediates instead of ~25 descriptor words re-read from the kernarg segment in every phase.
+template <int NT, int NI>
+struct CLay {
+  static constexpr int o_win = 0;
+  static constexpr int o_b0 = o_win + NT * NI * 256;
+  static constexpr int o_w1 = o_b0 + NT * 16;
+  static constexpr int o_b1 = o_w1 + NT * NT * 256;
+  static constexpr int o_w2 = o_b1 + NT * 16;
+  static constexpr int o_b2 = o_w2 + NT * NT * 256;
+  static constexpr int o_wf = o_b2 + NT * 16;
+  static constexpr int o_bf = o_wf + NT * 256;
+  static constexpr int o_wfT = o_bf + 16;
+  static constexpr int o_w2T = o_wfT + NT * 256;
+  static constexpr int o_w1T = o_w2T + NT * NT * 256;
+  static constexpr int o_winT = o_w1T + NT * NT * 256;
+  static constexpr int t_end = o_winT + NI * NT * 256;
+  static constexpr int t_stride = (t_end + 255) / 256 * 256;
+  static constexpr int g_win = 0;
+  static constexpr int g_b0 = g_win + NT * NI * 256;
+  static constexpr int g_w1 = g_b0 + NT * 16;
+  static constexpr int g_b1 = g_w1 + NT * NT * 256;
+  static constexpr int g_w2 = g_b1 + NT * 16;
+  static constexpr int g_b2 = g_w2 + NT * NT * 256;
+  static constexpr int g_wf = g_b2 + NT * 16;
+  static constexpr int g_bf = g_wf + NT * 256;
+  static constexpr int g_end = g_bf + 16;
+  static constexpr int g_stride = (g_end + 63) / 64 * 64;
+  static bool matches(const SfTrcDev& c, int T) {
+    return c.o_win == o_win && c.o_b0 == o_b0 && c.o_w1 == o_w1 && c.o_b1 == o_b1 && c.o_w2 == o_w2 && c.o_b2 == o_b2 &&
+           c.o_wf == o_wf && c.o_bf == o_bf && c.o_wfT == o_wfT && c.o_w2T == o_w2T && c.o_w1T == o_w1T && c.o_winT == o_winT &&
+           (T == 1 || c.t_stride == t_stride) && c.g_win == g_win && c.g_b0 == g_b0 && c.g_w1 == g_w1 && c.g_b1 == g_b1 &&
+           c.g_w2 == g_w2 && c.g_b2 == g_b2 && c.g_wf == g_wf && c.g_bf == g_bf && c.g_stride == g_stride;
+  }
+};
+
 // floats of the constant block kept in LDS for the life of the workgroup
 __host__ __device__ inline int sf_trc_nbias(int NT) { return 3 * NT * 16 + 16; }
 __host__ __device__ inline int sf_trc_cb_floats(int NT, int NI, int TS) { return TS * sf_trc_nbias(NT) + 16 + NI * 16 * 3 + 8 * 3; }
@@ -194,6 +231,7 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
   extern __shared__ float lds[];
   constexpr int NQ = 2 * NG, NW = 4 * NG, NTH = 256 * NG;
   constexpr int NP = (NT + 1) / 2;  // wave rows (p) that own tiles
+  using L = CLay<NT, NI>;
   const SfTrcArgs& a = c_args();
   const SfTrcDev& c = a.c;
   // (the wave index is made visibly wave-uniform: tile indices, buffer bases and fragment bases then live in SGPRs and the
@@ -242,8 +280,8 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
     for (int i = threadIdx.x; i < a.T * NBIAS; i += NTH) {
       const int t = i / NBIAS, k = i - t * NBIAS;
       const int sec = k / (NT * 16), kk = k - sec * NT * 16;
-      const int off = sec == 0 ? c.o_b0 : (sec == 1 ? c.o_b1 : (sec == 2 ? c.o_b2 : c.o_bf));
-      CBb[i] = a.img[(size_t)t * c.t_stride + off + kk];
+      const int off = sec == 0 ? L::o_b0 : (sec == 1 ? L::o_b1 : (sec == 2 ? L::o_b2 : L::o_bf));
+      CBb[i] = a.img[(size_t)t * L::t_stride + off + kk];
     }
     if (threadIdx.x < 16) CBj[threadIdx.x] = threadIdx.x < c.n_jobs ? (int)cst[c.c_jobs + threadIdx.x] : 0;
     if (threadIdx.x < NI * 16) {
@@ -279,8 +317,8 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
       const float* tp0 = a.img + sf_opaque_zero();
 #pragma unroll
       for (int it = 0; it < NI; ++it) {
-        pwin[0][it] = c_frag(tp0 + c.o_win, NI, tA, it, lane);
-        pwin[1][it] = c_frag(tp0 + c.o_win, NI, tB_, it, lane);
+        pwin[0][it] = c_frag(tp0 + L::o_win, NI, tA, it, lane);
+        pwin[1][it] = c_frag(tp0 + L::o_win, NI, tB_, it, lane);
       }
     }
     // ------------------------------------------------------------------ per-sample inputs (one subtile per wave)
@@ -319,7 +357,7 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
       if (t < a.T) {
         const SfTrcArgs& a = c_args();
         const SfTrcDev& c = a.c;
-        const float* tp = a.img + (size_t)t * c.t_stride + sf_opaque_zero();  // (not loop-invariant: see sf_device.h)
+        const float* tp = a.img + (size_t)t * L::t_stride + sf_opaque_zero();  // (not loop-invariant: see sf_device.h)
         const float* cb = CBb + t * NBIAS;
         // F1: h0 = b0 + bc + Win . [u ; e(x)]
         SF_TC(1 + 5 * t);
@@ -327,7 +365,7 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
         if (has0) {
           // next phase's fragments: in flight across the barrier
 #pragma unroll
-          for (int i = 0; i < 5; ++i) w1f[i] = c_frag(tp + c.o_w1, NT, fslot_tile(i), fslot_it(i), lane);
+          for (int i = 0; i < 5; ++i) w1f[i] = c_frag(tp + L::o_w1, NT, fslot_tile(i), fslot_it(i), lane);
           f32x4 in0 = inx[0];
           in0[0] = s0on ? u0 : in0[0];
           in0[1] = s1on ? u1 : in0[1];
@@ -349,9 +387,9 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
         SF_TCX(t == 1, 200, u0);
         if (has0) {
 #pragma unroll
-          for (int i = 0; i < 5; ++i) w2f[i] = c_frag(tp + c.o_w2, NT, fslot_tile(i), fslot_it(i), lane);
-          wff[0] = c_frag(tp + c.o_wf, NT, 0, tA, lane);
-          wff[1] = c_frag(tp + c.o_wf, NT, 0, tB_, lane);
+          for (int i = 0; i < 5; ++i) w2f[i] = c_frag(tp + L::o_w2, NT, fslot_tile(i), fslot_it(i), lane);
+          wff[0] = c_frag(tp + L::o_wf, NT, 0, tA, lane);
+          wff[1] = c_frag(tp + L::o_wf, NT, 0, tB_, lane);
           f32x4 accA = c_ld4(cb + NT * 16 + (tA * 4 + g4) * 4), accB = c_ld4(cb + NT * 16 + (tB_ * 4 + g4) * 4);
           SF_TCX(t == 1, 201, accA[0] + accB[0]);
           SF_TCX(t == 1, 202, w1f[0].x + w1f[4].x);
@@ -382,11 +420,11 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
         // F3: a2 = tanh(b2 + W2 a1); head partial sums over my hidden rows
         if (has0) {
           {  // the next transform's first fragments (the last transform reloads its own: no branch around a load)
-            const float* tpn = tp + (t + 1 < a.T ? c.t_stride : 0);
+            const float* tpn = tp + (t + 1 < a.T ? L::t_stride : 0);
 #pragma unroll
             for (int it = 0; it < NI; ++it) {
-              pwin[0][it] = c_frag(tpn + c.o_win, NI, tA, it, lane);
-              pwin[1][it] = c_frag(tpn + c.o_win, NI, tB_, it, lane);
+              pwin[0][it] = c_frag(tpn + L::o_win, NI, tA, it, lane);
+              pwin[1][it] = c_frag(tpn + L::o_win, NI, tB_, it, lane);
             }
           }
           f32x4 accA = c_ld4(cb + 2 * NT * 16 + (tA * 4 + g4) * 4), accB = c_ld4(cb + 2 * NT * 16 + (tB_ * 4 + g4) * 4);
@@ -439,16 +477,16 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
     {
       const SfTrcArgs& a = c_args();
       const SfTrcDev& c = a.c;
-      const float* tpl = a.img + (size_t)(a.T - 1) * c.t_stride + sf_opaque_zero();
-      pwfT[0] = c_frag(tpl + c.o_wfT, 1, tA, 0, lane);
-      pwfT[1] = c_frag(tpl + c.o_wfT, 1, tB_, 0, lane);
+      const float* tpl = a.img + (size_t)(a.T - 1) * L::t_stride + sf_opaque_zero();
+      pwfT[0] = c_frag(tpl + L::o_wfT, 1, tA, 0, lane);
+      pwfT[1] = c_frag(tpl + L::o_wfT, 1, tB_, 0, lane);
 #pragma unroll
       for (int it = 0; it < NI; ++it) {
-        pwinB[0][it] = c_frag(tpl + c.o_win, NI, tA, it, lane);
-        pwinB[1][it] = c_frag(tpl + c.o_win, NI, tB_, it, lane);
+        pwinB[0][it] = c_frag(tpl + L::o_win, NI, tA, it, lane);
+        pwinB[1][it] = c_frag(tpl + L::o_win, NI, tB_, it, lane);
       }
 #pragma unroll
-      for (int i = 0; i < 5; ++i) pw2T[i] = c_frag(tpl + c.o_w2T, NT, bslot_tile(i), bslot_ot(i), lane);
+      for (int i = 0; i < 5; ++i) pw2T[i] = c_frag(tpl + L::o_w2T, NT, bslot_tile(i), bslot_ot(i), lane);
     }
     // ------------------------------------------------------------------ loss, dL/du_T
     float G0, G1;
@@ -482,9 +520,9 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
       if (t < a.T) {
         const SfTrcArgs& a = c_args();
         const SfTrcDev& c = a.c;
-        const float* tp = a.img + (size_t)t * c.t_stride + sf_opaque_zero();
+        const float* tp = a.img + (size_t)t * L::t_stride + sf_opaque_zero();
         const float* cb = CBb + t * NBIAS;
-        float* gp = gpart + (size_t)t * c.g_stride;
+        float* gp = gpart + (size_t)t * L::g_stride;
         // B1: head backward, delta of block 2, h0 recomputed
         SF_TC(40 + 12 * tt);
         float Gd0, Gd1;
@@ -537,9 +575,9 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
         auto b2_data = [&]() {
         if (has0) {
 #pragma unroll
-          for (int i = 0; i < 5; ++i) w1T[i] = c_frag(tp + c.o_w1T, NT, bslot_tile(i), bslot_ot(i), lane);
-          wiT[0] = c_frag(tp + c.o_winT, NT, 0, tA, lane);
-          wiT[1] = c_frag(tp + c.o_winT, NT, 0, tB_, lane);
+          for (int i = 0; i < 5; ++i) w1T[i] = c_frag(tp + L::o_w1T, NT, bslot_tile(i), bslot_ot(i), lane);
+          wiT[0] = c_frag(tp + L::o_winT, NT, 0, tA, lane);
+          wiT[1] = c_frag(tp + L::o_winT, NT, 0, tB_, lane);
           f32x4 accA = c_zero(), accB = c_zero();
 {
             f32x4 accA1 = c_zero(), accB1 = c_zero();
@@ -573,8 +611,8 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
         for (int n = wave; n < NT; n += 2 * NW) {  // dWf[head tile][hidden tile]; bias with the first block
           const bool two = n + NW < NT;
           const int n2 = two ? n + NW : n;
-          const CJob A = {TDF, TA2, gp + c.g_wf + n * 256, n == 0 ? gp + c.g_bf : nullptr, 0, n};
-          const CJob B = {TDF, TA2, gp + c.g_wf + n2 * 256, nullptr, 0, n2};
+          const CJob A = {TDF, TA2, gp + L::g_wf + n * 256, n == 0 ? gp + L::g_bf : nullptr, 0, n};
+          const CJob B = {TDF, TA2, gp + L::g_wf + n2 * 256, nullptr, 0, n2};
           c_dw_jobs<NQ>(A, B, two, accumulate, lane);
         }
         };
@@ -613,8 +651,8 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
           for (int n = wave; n < nj; n += 2 * NW) {
             const bool two = n + NW < nj;
             const int cA = CBj[n], cB = CBj[two ? n + NW : n];
-            const CJob A = {TD2, TA1, gp + c.g_w2 + ((cA >> 2) * NT + (cA & 3)) * 256, (cA & 3) == 0 ? gp + c.g_b2 : nullptr, cA >> 2, cA & 3};
-            const CJob B = {TD2, TA1, gp + c.g_w2 + ((cB >> 2) * NT + (cB & 3)) * 256, (cB & 3) == 0 ? gp + c.g_b2 : nullptr, cB >> 2, cB & 3};
+            const CJob A = {TD2, TA1, gp + L::g_w2 + ((cA >> 2) * NT + (cA & 3)) * 256, (cA & 3) == 0 ? gp + L::g_b2 : nullptr, cA >> 2, cA & 3};
+            const CJob B = {TD2, TA1, gp + L::g_w2 + ((cB >> 2) * NT + (cB & 3)) * 256, (cB & 3) == 0 ? gp + L::g_b2 : nullptr, cB >> 2, cB & 3};
             c_dw_jobs<NQ>(A, B, two, accumulate, lane);
           }
         };
@@ -625,16 +663,16 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
         // B4 (both waves of the subtile, replicated): dL/du of the transform below; weight gradients of block 1 and
         // the initial layer
         {  // first fragments of the transform below (the bottom transform reloads its own)
-          const float* tpn = tp - (t >= 1 ? c.t_stride : 0);
-          pwfT[0] = c_frag(tpn + c.o_wfT, 1, tA, 0, lane);
-          pwfT[1] = c_frag(tpn + c.o_wfT, 1, tB_, 0, lane);
+          const float* tpn = tp - (t >= 1 ? L::t_stride : 0);
+          pwfT[0] = c_frag(tpn + L::o_wfT, 1, tA, 0, lane);
+          pwfT[1] = c_frag(tpn + L::o_wfT, 1, tB_, 0, lane);
 #pragma unroll
           for (int it = 0; it < NI; ++it) {
-            pwinB[0][it] = c_frag(tpn + c.o_win, NI, tA, it, lane);
-            pwinB[1][it] = c_frag(tpn + c.o_win, NI, tB_, it, lane);
+            pwinB[0][it] = c_frag(tpn + L::o_win, NI, tA, it, lane);
+            pwinB[1][it] = c_frag(tpn + L::o_win, NI, tB_, it, lane);
           }
 #pragma unroll
-          for (int i = 0; i < 5; ++i) pw2T[i] = c_frag(tpn + c.o_w2T, NT, bslot_tile(i), bslot_ot(i), lane);
+          for (int i = 0; i < 5; ++i) pw2T[i] = c_frag(tpn + L::o_w2T, NT, bslot_tile(i), bslot_ot(i), lane);
         }
         {
           f32x4 du = c_zero();
@@ -664,11 +702,11 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
             if (n < n1) {
               const int code = CBj[n];
               const int ot = code >> 2, it = code & 3;
-              return CJob{TD1, TH0, gp + c.g_w1 + (ot * NT + it) * 256, it == 0 ? gp + c.g_b1 : nullptr, ot, it};
+              return CJob{TD1, TH0, gp + L::g_w1 + (ot * NT + it) * 256, it == 0 ? gp + L::g_b1 : nullptr, ot, it};
             }
             const int m = n - n1;
             const int ot = m / NI, it = m - ot * NI;
-            return CJob{TD0, TIN, gp + c.g_win + (ot * NI + it) * 256, it == 0 ? gp + c.g_b0 : nullptr, ot, it};
+            return CJob{TD0, TIN, gp + L::g_win + (ot * NI + it) * 256, it == 0 ? gp + L::g_b0 : nullptr, ot, it};
           };
           for (int n = wave; n < ntot; n += 2 * NW) {
             const bool two = n + NW < ntot;
@@ -736,6 +774,16 @@ bool sf_trainc_eligible(const SfLayout& L, bool want_dctx) {
   if (!env || !c.ok) return false;
   if (L.dev.T > SF_TRC_TS || c.NI > 2 || c.NT < 1 || c.NT > 4) return false;
   if (want_dctx && c.NI > 1) return false;
+  {
+    bool ok = false;
+    switch (c.NI * 10 + c.NT) {
+      case 11: ok = CLay<1, 1>::matches(c, L.dev.T); break; case 12: ok = CLay<2, 1>::matches(c, L.dev.T); break;
+      case 13: ok = CLay<3, 1>::matches(c, L.dev.T); break; case 14: ok = CLay<4, 1>::matches(c, L.dev.T); break;
+      case 21: ok = CLay<1, 2>::matches(c, L.dev.T); break; case 22: ok = CLay<2, 2>::matches(c, L.dev.T); break;
+      case 23: ok = CLay<3, 2>::matches(c, L.dev.T); break; case 24: ok = CLay<4, 2>::matches(c, L.dev.T); break;
+    }
+    if (!ok) return false;  // (the packer and the kernel disagree about the block order: never launch on that)
+  }
   // a wave holds the fragments of tiles p and NT-1-p in five slots per layer (aligned MADE placement: NT + 1 blocks)
   for (int p = 0; 2 * p < c.NT; ++p) {
     const int tA = p, tB = c.NT - 1 - p;
