@@ -756,15 +756,17 @@ size_t sf_trainc_lds_bytes(const SfTrcDev& c, int TS, int NG) {
           (size_t)sf_trc_cb_floats(c.NT, c.NI, TS)) * sizeof(float);
 }
 
-// groups of 4 waves (32 samples) per workgroup.  2 = one 8-wave workgroup per CU, weight-gradient products over 64
-// samples, half the gradient partials (batch 16 384: 72 us either way, 37 MB instead of 74 MB of partials); 1 = 4-wave
-// workgroups, taken while the batch leaves CUs idle anyway (<= 8 192 rows: one workgroup per CU, and a 32-sample
-// chain is shorter: batch 64 50 us instead of 63, batch 2 048 56 instead of 66).  SF_TRC_NG=1|2 overrides.
+// groups of 4 waves (32 samples) per workgroup.  1 = 4-wave workgroups, two per CU when the batch fills the chip: two
+// INDEPENDENT workgroups overlap better than the two groups of one 8-wave workgroup, which meet at every barrier (batch
+// 16 384: 67.6 us against 73.4; a lone workgroup takes 48 us, one per CU 56 us) -- taken while every chunk has its own
+// workgroup (<= 16 384 rows on 256 CUs).  2 = one 8-wave workgroup per CU: weight-gradient products over 64 samples, half
+// the gradient partials and half the read-modify-write traffic once workgroups loop over chunks (batch 131 072: 531 us
+// against 550).  SF_TRC_NG=1|2 overrides.
 int sf_trainc_groups(long B) {
   static int forced = -1;
   if (forced < 0) { const char* e = std::getenv("SF_TRC_NG"); forced = e ? std::atoi(e) : 0; }
   if (forced == 1 || forced == 2) return forced;
-  return B <= 8192 ? 1 : 2;
+  return B <= 16384 ? 1 : 2;
 }
 
 bool sf_trainc_eligible(const SfLayout& L, bool want_dctx) {
