@@ -756,17 +756,17 @@ size_t sf_trainc_lds_bytes(const SfTrcDev& c, int TS, int NG) {
           (size_t)sf_trc_cb_floats(c.NT, c.NI, TS)) * sizeof(float);
 }
 
-// groups of 4 waves (32 samples) per workgroup.  1 = 4-wave workgroups, two per CU when the batch fills the chip: two
-// INDEPENDENT workgroups overlap better than the two groups of one 8-wave workgroup, which meet at every barrier (batch
-// 16 384: 67.6 us against 73.4; a lone workgroup takes 48 us, one per CU 56 us) -- taken while every chunk has its own
-// workgroup (<= 16 384 rows on 256 CUs).  2 = one 8-wave workgroup per CU: weight-gradient products over 64 samples, half
-// the gradient partials and half the read-modify-write traffic once workgroups loop over chunks (batch 131 072: 531 us
-// against 550).  SF_TRC_NG=1|2 overrides.
+// groups of 4 waves (32 samples) per workgroup.  1 = 4-wave workgroups: a 32-sample chain is shorter (batch 64: 48 us
+// against 63, batch 2 048: 55 against 66) -- taken while the batch leaves CUs idle anyway (<= 8 192 rows: one workgroup per
+// CU).  2 = one 8-wave workgroup per CU: weight-gradient products over 64 samples and HALF the gradient partials.  At batch
+// 16 384 the flow kernel alone is faster with 4-wave workgroups, two per CU (67.6 us against 73.4: two independent
+// workgroups overlap better than two groups that meet at every barrier), but the 512 partials cost the gather kernel more
+// than that (step 107 us against 97): the step decides.  SF_TRC_NG=1|2 overrides.
 int sf_trainc_groups(long B) {
   static int forced = -1;
   if (forced < 0) { const char* e = std::getenv("SF_TRC_NG"); forced = e ? std::atoi(e) : 0; }
   if (forced == 1 || forced == 2) return forced;
-  return B <= 16384 ? 1 : 2;
+  return B <= 8192 ? 1 : 2;
 }
 
 bool sf_trainc_eligible(const SfLayout& L, bool want_dctx) {
