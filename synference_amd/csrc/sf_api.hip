@@ -190,7 +190,7 @@ int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen) {
   }
   add("o16_w0", v.o16_w0); add("o16_wc", v.o16_wc); add("o16_b0", v.o16_b0); add("o16_wk0", v.o16_wk[0]);
   add("o16_wk1", v.o16_wk[1]); add("o16_bk0", v.o16_bk[0]); add("o16_bk1", v.o16_bk[1]); add("o16_hv", v.o16_hv);
-  add("o16_hvb", v.o16_hvb);
+  add("o16_hvb", v.o16_hvb); add("o16_wh", v.o16_wh); add("o16_bh", v.o16_bh); add("t16_a_tab", v.t16_a_tab);
   add("t16_a", v.t16_a); add("t16B_stride", v.t16B_stride); add("nP16", v.nP16); add("o16B_wk0", v.o16B_wk[0]); add("o16B_wk1", v.o16B_wk[1]);
   add("m16_ok", v.m16_ok); add("m16_span", v.m16_span); add("nT16", v.nT16); add("nC16", v.nC16); add("t16_stride", v.t16_stride);
   s += "\"g16_tile\": [";
@@ -520,9 +520,26 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
 #endif
     if (progress_rule) SF_HIP(hipMemsetAsync(f->d_galacc, 0, (size_t)M * sizeof(int32_t), st));
     a.slots = cur; a.slot_base = 0; a.n_items = (long)pending; a.n_total = (uint32_t)pending;
+    {
+      static int env_il = -1;  // developer knob: SF_INTERLEAVE=0 keeps the dense list in slot order (A-B runs)
+      if (env_il < 0) { const char* e = std::getenv("SF_INTERLEAVE"); env_il = e ? std::atoi(e) : 1; }
+      a.dense_M = (!cur && env_il && pending == M * S && M > 1) ? (uint32_t)M : 0u;
+      static int env_sp = -1;  // developer knob: SF_SPEC_AFTER=<attempts> (0 = width grows with the attempt number only)
+      if (env_sp < 0) { const char* e = std::getenv("SF_SPEC_AFTER"); env_sp = e ? std::atoi(e) : 0; }
+      a.spec_full_after = (uint32_t)env_sp;
+    }
     a.attempt = 0; a.attempt_limit = limit; a.attempts_per_slot = 1;
     a.rejected = f->d_rej[buf];
     a.gal_acc = progress_rule ? f->d_galacc : nullptr;
+#ifdef SF_Q_STATS
+    static uint32_t* d_qtrace = nullptr;
+    const size_t qtrace_bytes = (size_t)2048 * 256 * 4 * sizeof(uint32_t);
+    if (std::getenv("SF_Q_TRACE")) {
+      if (!d_qtrace) SF_HIP(hipMalloc(&d_qtrace, qtrace_bytes));
+      SF_HIP(hipMemsetAsync(d_qtrace, 0, qtrace_bytes, st));
+      a.qtrace = d_qtrace;
+    }
+#endif
     SF_HIP(hipEventRecord(f->ev_dense[0], st));
     hipError_t e = sf_launch_inverse(m, a, st);
     if (e != hipSuccess) { f->ctab_x = nullptr; return hip_fail(e, "persistent sampler launch"); }
@@ -547,6 +564,16 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
     f->ring_dirty = false;  // clean end: every ring entry was consumed
     evals += (double)f->h_queue->evals;
     dropped += (int64_t)f->h_queue->dropped;
+#ifdef SF_Q_STATS
+    if (a.qtrace) {  // the last launch's trace stays in the file
+      std::vector<uint32_t> h(qtrace_bytes / sizeof(uint32_t));
+      SF_HIP(hipMemcpy(h.data(), a.qtrace, qtrace_bytes, hipMemcpyDeviceToHost));
+      if (h[1] != 0u) {  // (kernels without the trace code leave the buffer empty: keep the previous file)
+        if (FILE* fp = std::fopen(std::getenv("SF_Q_TRACE"), "wb")) { std::fwrite(h.data(), 1, qtrace_bytes, fp); std::fclose(fp); }
+      }
+      a.qtrace = nullptr;
+    }
+#endif
     if (std::getenv("SF_Q_STATS")) {
       const unsigned long long* q = f->h_queue->stats;
       std::fprintf(stderr, "[sf_queue] stage %d: entry-barrier %.3e cyc, serial %.3e cyc, exit-barrier %.3e cyc, idle %.3e cyc in %llu "
@@ -555,6 +582,8 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
                    (unsigned long long)f->h_queue->evals, f->h_queue->resolved, (unsigned)a.n_total);
       std::fprintf(stderr, "[sf_queue]   max iterations of a workgroup %llu; last flow evaluation ended %.1f us, last exit %.1f us after the first start\n",
                    q[11], ((double)q[12] - (double)q[10]) * 0.01, ((double)q[13] - (double)q[10]) * 0.01);
+      std::fprintf(stderr, "[sf_queue]   wave 0 of every workgroup, summed (us): fetch %.0f, prologue %.0f, staging %.0f, passes %.0f, epilogue %.0f\n",
+                   (double)q[14] * 0.01, (double)q[15] * 0.01, (double)q[16] * 0.01, (double)q[17] * 0.01, (double)q[18] * 0.01);
     }
     rej0 = (float)f->h_queue->rej0;
     pending = (int64_t)f->h_queue->n_surv;

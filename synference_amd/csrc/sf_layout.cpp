@@ -429,8 +429,6 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
         // part A (everything but the hidden H x H blocks; staged by both sampler kernels)
         if (t == 0) v.o16_w0 = here();
         linear16(NT, 1, h16row, u16, lW0, D, [&](int j, int i) { return deg_h(j) >= i + 1; });
-        if (t == 0) v.o16_wc = here();
-        linear16(NT, v.nC16, h16row, c16, lWc, C, nullptr);
         if (t == 0) v.o16_b0 = here();
         bias16(NT, h16row, lb0, lbc);
         for (int k = 0; k < NB && k < 2; ++k) {
@@ -453,6 +451,25 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
         if (t == 0) v.o16_hvb = here();
         for (int q = 0; q < D; ++q)
           for (int ab = 0; ab < 2; ++ab) push16((int32_t)(lbf + 2 * sinv[q] + ab), -1);
+        // the same head rows as ONE 16-row output tile of the matrix pipe (D <= 8): row 2q + ab = (a | m) of physical
+        // slot q, one A fragment per hidden tile, and the head biases as that tile's initial accumulator
+        if (D <= 8) {
+          while (L.src16a.size() % 4) push16(-1, -1);
+          if (t == 0) v.o16_wh = here();
+          std::vector<int> hrow16(16, -1);
+          for (int q = 0; q < D; ++q)
+            for (int ab = 0; ab < 2; ++ab) hrow16[2 * q + ab] = 2 * sinv[q] + ab;
+          linear16(1, NT, hrow16, h16row, lWf, H, [&](int oo, int unit) { return (oo / 2 + 1) > deg_h(unit); });
+          if (t == 0) v.o16_bh = here();
+          bias16(1, hrow16, lbf, -1);
+        } else if (t == 0) {
+          v.o16_wh = v.o16_bh = -1;
+        }
+        // what the sampler stages when the per-galaxy context table exists (it then never reads Wc) ends here
+        while (L.src16a.size() % 1024) push16(-1, -1);
+        if (t == 0) v.t16_a_tab = here();
+        if (t == 0) v.o16_wc = here();
+        linear16(NT, v.nC16, h16row, c16, lWc, C, nullptr);
         while (L.src16a.size() % 1024) push16(-1, -1);
         if (t == 0) v.t16_a = here();
         // part B: the hidden blocks in fp32 (k_maf_inv16: parity hook, acceptance counts, explicit rounds)

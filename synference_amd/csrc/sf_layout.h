@@ -73,6 +73,8 @@ struct SfDev {
   const float* packed16;
   int m16_ok, nT16, nC16, t16_stride;
   int t16_a;     // floats of part A of the 16-row image (everything but the fp32 hidden blocks): what k_maf_samp16 stages
+  int t16_a_tab; // ... and of its prefix without the context block Wc: what it stages when the context table exists
+  int o16_wh, o16_bh;  // head rows as one MFMA output tile (row 2q + ab of slot q; D <= 8, else -1) and their biases
   // split-bf16 hidden blocks of the 16-row sampler: 32-bit words (2 bf16 each), [ot][pair][hi|lo][64 lanes][4 words]
   const uint32_t* packed16B;
   int t16B_stride, nP16, o16B_wk[2];  // words per transform, in-tile pairs, block offsets in words

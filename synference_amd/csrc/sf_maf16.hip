@@ -410,11 +410,20 @@ struct SfPass16B {
   // split inputs of hidden block k ([0] = initial layer, [1] = output of block 0), held per PAIR of tiles exactly as
   // the MFMA wants its B operand: components 0,1 = tile 2p (rows 0,1 | rows 2,3), components 2,3 = tile 2p+1
   u32x4 ph[2][2], pl[2][2];
-  f32x4 head[4];       // output of the last block (fp32: the head rows are per-lane dot products); [tile]
+  f32x4 head[4];       // output of the last block (fp32: the head rows are per-lane dot products); [tile]   (HM = false)
+  f32x4 hdone;         // HM: head biases + the head rows' products with every FINISHED hidden tile, as one MFMA output
+                       // tile: lane (s, g4), register r = row 4*g4 + r = (a | m) of physical slot (4*g4 + r) >> 1
   f32x4 ut;            // finished dimensions of this transform, tile layout: slot 4*g4 + r
   const float* c0p;    // this draw's context-table row for the transform (b0 + bc + Wc e(x), tile order), or nullptr
   const float* xr;     // the draw's context row (no-table path: c0 is evaluated where it is needed)
+  f32x4 c0n;           // table path, aligned placement: c0 of the NEXT pass's tile, requested one pass ahead so that the
+                       // L2 round trip is over before the pass that starts its dependent chain with it
+  bool tab;            // wave-uniform: the table exists (c0p is per lane, the decision is not)
 };
+// request c0 of tile `ot` of the current transform (table path only)
+__device__ __forceinline__ void sf_c0_prefetch(SfPass16B& S, int ot, int g4) {
+  S.c0n = *reinterpret_cast<const f32x4*>(S.c0p + ot * 16 + 4 * g4);
+}
 // c0 of tile ot = b0 + bc + Wc e(x): from the per-galaxy table, else evaluated on the spot (rare: tables above the
 // size cap); either way it is not kept in registers across the passes
 __device__ __forceinline__ f32x4 sf_c0_16(const SfDev& m, const float* tp, const SfPass16B& S, int ot, int lane, int g4) {
@@ -444,20 +453,72 @@ __device__ __forceinline__ void sf_put16b(SfPass16B& S, int k, const f32x4& v) {
 }
 
 // One autoregressive pass with the degree group in (static) tile OT (see sf_pass16); hidden blocks on split bf16.
-template <int OT, int NB, bool CP>
+// HM (aligned placement, D <= 8): the head rows of ALL slots are one 16-row MFMA output tile (sf_layout.cpp, o16_wh); a
+// pass adds its tile's product to the running tile S.hdone and reads its own (a, m) out of the result -- 4 MFMAs
+// instead of 4 (OT + 1) packed FMAs, 2 (OT + 1) LDS reads and a two-step cross-row-group sum, and 4 registers of state
+// instead of 16.
+template <int OT, int NB, bool CP, bool HM = false>
 __device__ __forceinline__ void sf_pass16b(const SfDev& m, const float* tp, const unsigned int* tpB, SfPass16B& S, int NT, int sl,
-                                           float u_sl, int lane, int g4) {
+                                           float u_sl, int lane, int g4, int next_ot = -1) {
   constexpr int PR = OT >> 1;  // the pair that holds tile OT; pairs below it are complete
   const int NP = m.nP16;
+  f32x4 c0;
+  if (CP && HM && S.tab) {  // (aligned placement: one tile per pass, so the caller knows the next one; HM: the registers for it)
+    c0 = S.c0n;
+    if (next_ot >= 0) sf_c0_prefetch(S, next_ot, g4);
+  } else {
+    c0 = sf_c0_16(m, tp, S, OT, lane, g4);
+  }
   const float* hv = tp + m.o16_hv + sl * 128 + g4 * 32;
   const float4 w0 = sf_w16(tp + m.o16_w0, 1, OT, 0, lane);
   // head rows of the tiles finished in earlier passes: partial sums first (nothing here depends on this pass)
   f32x2 pam = {0.f, 0.f};
+  if (!HM) {
 #pragma unroll
-  for (int tl = 0; tl < OT; ++tl)
-    pam = sf_head_acc(pam, *reinterpret_cast<const float4*>(hv + tl * 8), *reinterpret_cast<const float4*>(hv + tl * 8 + 4), S.head[tl]);
+    for (int tl = 0; tl < OT; ++tl)
+      pam = sf_head_acc(pam, *reinterpret_cast<const float4*>(hv + tl * 8), *reinterpret_cast<const float4*>(hv + tl * 8 + 4), S.head[tl]);
+  }
+  f32x4 last;
+  float4 wh;
+  if (HM) {
+    // operand fragments are requested one stage ahead of the MFMAs that read them (block 0 under the initial layer's
+    // chain, block k + 1 / the head rows under block k's tanh and split), so that an LDS round trip per fragment does
+    // not sit in the dependent chain; the scheduling barriers pin that order
+    u32x4 fh[PR + 1], fl[PR + 1];
+    f32x4 b = sf_ld4(tp + m.o16_bk[0] + (OT * 4 + g4) * 4);
+#pragma unroll
+    for (int pr = 0; pr <= PR; ++pr) {
+      fh[pr] = sf_w16b<CP>(tpB + m.o16B_wk[0], NP, OT, pr, 0, lane);
+      fl[pr] = sf_w16b<CP>(tpB + m.o16B_wk[0], NP, OT, pr, 1, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    sf_put16b<OT>(S, 0, sf_mma16(w0, S.ut, c0));
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+#pragma unroll
+      for (int pr = 0; pr <= PR; ++pr) b = sf_mma16x3(fh[pr], fl[pr], S.ph[k][pr], S.pl[k][pr], b);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 bn;
+      if (k + 1 < NB) {
+        bn = sf_ld4(tp + m.o16_bk[k + 1 < NB ? k + 1 : k] + (OT * 4 + g4) * 4);
+#pragma unroll
+        for (int pr = 0; pr <= PR; ++pr) {
+          fh[pr] = sf_w16b<CP>(tpB + m.o16B_wk[k + 1 < NB ? k + 1 : k], NP, OT, pr, 0, lane);
+          fl[pr] = sf_w16b<CP>(tpB + m.o16B_wk[k + 1 < NB ? k + 1 : k], NP, OT, pr, 1, lane);
+        }
+      } else {
+        wh = sf_w16(tp + m.o16_wh, NT, 0, OT, lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 th;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) th[r] = sf_tanh(b[r]);
+      if (k + 1 < NB) { sf_put16b<OT>(S, k + 1, th); b = bn; }
+      else last = th;
+    }
+  } else {
   // initial layer of tile OT (the start of the dependent chain)
-  sf_put16b<OT>(S, 0, sf_mma16(w0, S.ut, sf_c0_16(m, tp, S, OT, lane, g4)));
+  sf_put16b<OT>(S, 0, sf_mma16(w0, S.ut, c0));
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
     __builtin_amdgcn_sched_barrier(0);  // keep one block's fragments in flight at a time (registers)
@@ -474,9 +535,22 @@ __device__ __forceinline__ void sf_pass16b(const SfDev& m, const float* tp, cons
     if (k + 1 < NB) sf_put16b<OT>(S, k + 1, th);
     else S.head[OT] = th;
   }
-  pam = sf_head_acc(pam, *reinterpret_cast<const float4*>(hv + OT * 8), *reinterpret_cast<const float4*>(hv + OT * 8 + 4), S.head[OT]);
-  const float av = tp[m.o16_hvb + 2 * sl] + sf_sum4groups(pam[0]);
-  const float mv = tp[m.o16_hvb + 2 * sl + 1] + sf_sum4groups(pam[1]);
+  }
+  float av, mv;
+  if (HM) {
+    const f32x4 fresh = sf_mma16(wh, last, S.hdone);
+    // the tile is final once the next pass works on another one (several small degree groups may share a tile: each of
+    // their passes recomputes it, the running tile takes it once)
+    if (next_ot != OT) S.hdone = fresh;
+    const bool odd = (sl & 1) != 0;  // rows 2 sl, 2 sl + 1 sit in row group sl >> 1, registers 0,1 or 2,3
+    const int src = (lane & 15) + 16 * (sl >> 1);
+    av = __shfl(odd ? fresh[2] : fresh[0], src, 64);
+    mv = __shfl(odd ? fresh[3] : fresh[1], src, 64);
+  } else {
+    pam = sf_head_acc(pam, *reinterpret_cast<const float4*>(hv + OT * 8), *reinterpret_cast<const float4*>(hv + OT * 8 + 4), S.head[OT]);
+    av = tp[m.o16_hvb + 2 * sl] + sf_sum4groups(pam[0]);
+    mv = tp[m.o16_hvb + 2 * sl + 1] + sf_sum4groups(pam[1]);
+  }
   const float sc = (m.scale_fn == 0 ? sf_softplus(av) : sf_sigmoid(av + 2.0f)) + m.eps;
   const float wv = sf_div(u_sl - mv, sc);
 #pragma unroll
@@ -545,15 +619,37 @@ struct SfSamp16Args {
   SfSampleArgsHost a;
 };
 
-template <int NB, bool SPAN>
+// TPW = draw tiles per wave and iteration (1 or 2): with 2 a workgroup takes 128 items per iteration and every wave walks
+// TWO tiles of 16 draws through each staged transform, one after the other -- the queue fetch, the image copy and their
+// barriers are paid once per 128 draws instead of once per 64 (together ~20 % of a workgroup's time at TPW = 1); between
+// transforms a tile is just its 4 registers of u and its galaxy index.
+template <int NB, bool SPAN, bool HM, int TPW>
 __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args args_in) {
+  constexpr int IPW = 64 * TPW;
   const int wave = threadIdx.x >> 6;
-  unsigned int* ctrl = reinterpret_cast<unsigned int*>(sf_lds16 + args_in.m.t16_a + args_in.m.t16B_stride);
+  // with the per-galaxy context table the context block Wc is never read: only the prefix of part A before it is staged
+  unsigned int* ctrl = reinterpret_cast<unsigned int*>(
+      sf_lds16 + (args_in.m.ctab ? args_in.m.t16_a_tab : args_in.m.t16_a) + args_in.m.t16B_stride);
   unsigned int pf;
-  sf_q_begin<64>(args_in.a, ctrl, pf);
+  sf_q_begin<IPW>(args_in.a, ctrl, pf);
+  // per-slot constants of the epilogue, once per workgroup: {shift, 1 / scale, lo, hi, theta column} of physical slot p.
+  // (Read from global memory where they are used they cost every iteration two dependent L2 round trips.)
+  float* ecb = reinterpret_cast<float*>(ctrl + SF_Q_WORDS(IPW));
+  if (threadIdx.x < 16) {
+    const int p = threadIdx.x;
+    const bool on = p < args_in.m.D;
+    const int td = on ? (int)args_in.m.cst[args_in.m.c_tdim + p] : 0;
+    ecb[p * 5 + 0] = on ? args_in.m.cst[args_in.m.c_pshift + p] : 0.f;
+    ecb[p * 5 + 1] = on ? __builtin_amdgcn_rcpf(args_in.m.cst[args_in.m.c_pscale + p]) : 0.f;
+    ecb[p * 5 + 2] = (on && args_in.a.lo) ? args_in.a.lo[td] : -3.4e38f;
+    ecb[p * 5 + 3] = (on && args_in.a.lo) ? args_in.a.hi[td] : 3.4e38f;
+    reinterpret_cast<int*>(ecb)[p * 5 + 4] = td;
+  }
+  // (the first sf_q_fetch begins with a barrier: the block is visible to every wave before its first epilogue)
 #ifdef SF_Q_STATS
   const unsigned long long qs_k0 = __builtin_amdgcn_s_memtime();
   unsigned long long qs_iters = 0, qs_last_work = 0;
+  unsigned long long qs_ph[5] = {0, 0, 0, 0, 0};
   if (threadIdx.x == 0) atomicMin(&args_in.a.q->stats[10], __builtin_amdgcn_s_memrealtime());  // first start (100 MHz)
 #endif
   for (;;) {
@@ -567,9 +663,13 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
     const SfSampleArgsHost& a = ap->a;
     const int lane = (threadIdx.x & 63) + sf_opaque_zero();  // lane-derived addresses are recomputed per iteration
     const int s = lane & 15, g4 = lane >> 4;
-    if (!sf_q_fetch<64, 64>(a, ctrl, pf)) {
+#ifdef SF_Q_STATS
+    const unsigned long long qs_t_top = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (!sf_q_fetch<IPW, 64>(a, ctrl, pf)) {
 #ifdef SF_Q_STATS
       if (threadIdx.x == 0) {
+        for (int i = 0; i < 5; ++i) atomicAdd(&a.q->stats[14 + i], qs_ph[i]);  // fetch | prologue | staging | passes | epilogue (10 ns)
         atomicAdd(&a.q->stats[9], __builtin_amdgcn_s_memtime() - qs_k0);  // workgroup lifetime
         atomicMax(&a.q->stats[11], qs_iters);                              // most iterations of one workgroup
         atomicMax(&a.q->stats[12], qs_last_work);                          // end of the last flow evaluation (100 MHz)
@@ -579,30 +679,41 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
       break;
     }
 #ifdef SF_Q_STATS
+    if (a.qtrace && threadIdx.x == 0 && qs_iters < 256) {
+      uint32_t* tr = a.qtrace + ((size_t)blockIdx.x * 256 + qs_iters) * 4;
+      tr[0] = (uint32_t)__builtin_amdgcn_s_memrealtime(); tr[1] = ctrl[0]; tr[2] = ctrl[1] | (ctrl[9] << 8);
+    }
     ++qs_iters;
+    const unsigned long long qs_t_fetch = __builtin_amdgcn_s_memrealtime();
+    qs_ph[0] += qs_t_fetch - qs_t_top;
+    unsigned long long qs_t_mark = qs_t_fetch;
 #endif
-    const int wi = wave * 16 + s;
     const int NT = m.nT16;
-    // a wave whose 16 lanes hold no item (tail iterations with few entries) only takes part in the staging: its issue
-    // slots go to the other workgroups of the CU
-    const bool wave_has_work = (unsigned)(wave * 16) < (ctrl[0] << ctrl[1]);
-    f32x4 u;
-    const float* xr;
-    const float* ctg;
-    {
+    const unsigned int n_items = ctrl[0] << ctrl[1];  // items of this iteration (entries x attempts per entry)
+    // the wave's tiles: tile j covers items (j * 4 + wave) * 16 .. + 15.  Between transforms a tile is its u registers
+    // and its galaxy; `cur` is the tile being worked on, `oth` the other one (TPW = 2), swapped after every tile.
+    f32x4 u_cur, u_oth;
+    long gal_cur = 0, gal_oth = 0;
+#pragma unroll
+    for (int j = TPW - 1; j >= 0; --j) {  // (j = 0 last: it is the first `cur`)
+      const int wi = (j * 4 + wave) * 16 + s;
       const unsigned int n_ent = ctrl[0];
       const int lgA = (int)ctrl[1];
       const unsigned int e = (unsigned)wi >> lgA;
       const unsigned int ee = e < n_ent ? e : 0u;
       const uint32_t slot = ctrl[SF_Q_HDR + ee];
-      const uint32_t att = ctrl[SF_Q_HDR + 64 + ee] + ((unsigned)wi & ((1u << lgA) - 1u));
-      const long gal = (long)(slot / (uint32_t)a.S);
+      const uint32_t att = ctrl[SF_Q_HDR + IPW + ee] + ((unsigned)wi & ((1u << lgA) - 1u));
       float z4[4];
       sf_normal4(a.k0, a.k1, (uint64_t)slot + a.rng_slot_offset, att, (uint32_t)g4, z4);  // Philox block g4 = dimensions 4*g4 .. 4*g4+3
+      if (TPW == 2 && j == 1) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) u[r] = (4 * g4 + r < m.D) ? z4[r] : 0.f;
-      xr = a.x + gal * m.C;
-      ctg = m.ctab ? m.ctab + (size_t)gal * m.T * m.ctab_R : nullptr;  // wave-uniform choice
+        for (int r = 0; r < 4; ++r) u_oth[r] = (4 * g4 + r < m.D) ? z4[r] : 0.f;
+        gal_oth = (long)(slot / (uint32_t)a.S);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u_cur[r] = (4 * g4 + r < m.D) ? z4[r] : 0.f;
+        gal_cur = (long)(slot / (uint32_t)a.S);
+      }
     }
     uint32_t tile_bits = 0, lo_bits = 0;  // g16_tile / g16_lo packed 2 bits per degree
 #pragma unroll
@@ -610,26 +721,24 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
       tile_bits |= (uint32_t)(m.g16_tile[q] & 3) << (2 * q);
       lo_bits |= (uint32_t)(m.g16_lo[q] & 3) << (2 * q);
     }
-    // cleared per tile of draws: a non-finite value left behind by one draw must not reach the next one through a
-    // structural zero (see k_maf_inv16 for why once per tile is enough)
     SfPass16B S;
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-      for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { S.ph[k][pr][c] = 0u; S.pl[k][pr][c] = 0u; }
-#pragma unroll
-    for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) S.head[ot][r] = 0.f;
+    S.tab = m.ctab != nullptr;
     for (int t = m.T - 1; t >= 0; --t) {
+      // requested before the staging barriers so that their round trips overlap with the image copy: the degree ->
+      // slot table of the transform and (table path) c0 of the first tile's first MFMA pass
+      const int dsl = (int)m.cst[m.c_dslot + t * SF_DMAX + s];
+      S.c0p = S.tab ? m.ctab + ((size_t)gal_cur * m.T + t) * m.ctab_R : nullptr;
+      if (HM && S.tab) sf_c0_prefetch(S, (int)((tile_bits >> 2) & 3u), g4);
+#ifdef SF_Q_STATS
+      { const unsigned long long n = __builtin_amdgcn_s_memrealtime(); qs_ph[t == m.T - 1 ? 1 : 3] += n - qs_t_mark; qs_t_mark = n; }
+#endif
       __syncthreads();
       {
-        // part A of the fp32 image (input / context layers, biases, head rows) and the split-bf16 hidden blocks, one
-        // behind the other in LDS: direct global -> LDS copies, 4 KiB groups (ONE address, four immediate offsets)
+        // part A of the fp32 image (input layer, biases, head rows; + the context block without a table) and the
+        // split-bf16 hidden blocks, one behind the other in LDS: direct global -> LDS copies, 4 KiB groups (ONE
+        // address, four immediate offsets)
         const int lane_ = threadIdx.x & 63;
-        const int ga = m.t16_a >> 10, gb = m.t16B_stride >> 10;
+        const int ga = (S.tab ? m.t16_a_tab : m.t16_a) >> 10, gb = m.t16B_stride >> 10;
         const float4* __restrict__ sa = reinterpret_cast<const float4*>(m.packed16 + (size_t)t * m.t16_stride);
         const float4* __restrict__ sb = reinterpret_cast<const float4*>(m.packed16B + (size_t)t * m.t16B_stride);
         float4* __restrict__ d4 = reinterpret_cast<float4*>(sf_lds16);
@@ -644,130 +753,176 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the copies have landed
       }
       __syncthreads();
+#ifdef SF_Q_STATS
+      { const unsigned long long n = __builtin_amdgcn_s_memrealtime(); qs_ph[2] += n - qs_t_mark; qs_t_mark = n; }
+#endif
       const float* tp = sf_lds16;
-      const unsigned int* tpB = reinterpret_cast<const unsigned int*>(sf_lds16 + m.t16_a);
-      S.c0p = ctg ? ctg + (size_t)t * m.ctab_R : nullptr;
-      S.xr = xr;
+      const unsigned int* tpB = reinterpret_cast<const unsigned int*>(sf_lds16 + (S.tab ? m.t16_a_tab : m.t16_a));
+#pragma unroll 1
+      for (int j = 0; j < TPW; ++j) {
+        // a wave whose tile holds no item (tail iterations with few entries) skips the flow: its issue slots go to the
+        // other workgroups of the CU
+        const bool tile_has_work = (unsigned)((j * 4 + wave) * 16) < n_items;
+        if (tile_has_work) {
+          if (j > 0) {  // (tile 0's requests went out before the staging barriers)
+            S.c0p = S.tab ? m.ctab + ((size_t)gal_cur * m.T + t) * m.ctab_R : nullptr;
+            if (HM && S.tab) sf_c0_prefetch(S, (int)((tile_bits >> 2) & 3u), g4);
+          }
+          S.xr = a.x + gal_cur * m.C;
+          // cleared per tile and transform: a non-finite value left behind by one draw must not reach another one
+          // through a structural zero (a pass only reads tiles that an earlier pass of the SAME tile and transform wrote,
+          // or zeros)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) S.ut[r] = 0.f;
-      if (!wave_has_work) continue;
-      const int dsl = (int)m.cst[m.c_dslot + t * SF_DMAX + s];
-      {
-        const int sl = __builtin_amdgcn_readlane(dsl, 0);
-        const float av = tp[m.o16_hvb + 2 * sl], mv = tp[m.o16_hvb + 2 * sl + 1];
-        const float sc = (m.scale_fn == 0 ? sf_softplus(av) : sf_sigmoid(av + 2.0f)) + m.eps;
-        const float wv = sf_div(sf_slot16(u, sl, lane) - mv, sc);
+          for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) S.ut[r] = (g4 == (sl >> 2) && r == (sl & 3)) ? wv : S.ut[r];
-      }
-      for (int p = 2; p <= m.D; ++p) {
-        const int sl = __builtin_amdgcn_readlane(dsl, p - 1);
-        const float u_sl = sf_slot16(u, sl, lane);
-        const uint32_t hi_t = (tile_bits >> (2 * (p - 1))) & 3u;
-        const uint32_t lo_t = SPAN ? (lo_bits >> (2 * (p - 1))) & 3u : hi_t;
-        switch (lo_t * 4 + hi_t) {
-          case 0: sf_pass16b<0, NB, !SPAN>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
-          case 5: sf_pass16b<1, NB, !SPAN>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
-          case 10: sf_pass16b<2, NB, !SPAN>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
-          case 15: sf_pass16b<3, NB, !SPAN>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
-          case 1: if (SPAN) sf_pass16b_span<0, 1, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
-          case 2: if (SPAN) sf_pass16b_span<0, 2, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
-          case 3: if (SPAN) sf_pass16b_span<0, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
-          case 6: if (SPAN) sf_pass16b_span<1, 2, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
-          case 7: if (SPAN) sf_pass16b_span<1, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
-          default: if (SPAN) sf_pass16b_span<2, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+            for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) { S.ph[k][pr][c] = 0u; S.pl[k][pr][c] = 0u; }
+          if (!HM) {
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) S.head[ot][r] = 0.f;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) S.ut[r] = 0.f;
+          if (HM) S.hdone = sf_ld4(tp + m.o16_bh + g4 * 4);
+          {
+            const int sl = __builtin_amdgcn_readlane(dsl, 0);
+            const float av = tp[m.o16_hvb + 2 * sl], mv = tp[m.o16_hvb + 2 * sl + 1];
+            const float sc = (m.scale_fn == 0 ? sf_softplus(av) : sf_sigmoid(av + 2.0f)) + m.eps;
+            const float wv = sf_div(sf_slot16(u_cur, sl, lane) - mv, sc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S.ut[r] = (g4 == (sl >> 2) && r == (sl & 3)) ? wv : S.ut[r];
+          }
+          for (int p = 2; p <= m.D; ++p) {
+            const int sl = __builtin_amdgcn_readlane(dsl, p - 1);
+            const float u_sl = sf_slot16(u_cur, sl, lane);
+            const uint32_t hi_t = (tile_bits >> (2 * (p - 1))) & 3u;
+            const uint32_t lo_t = SPAN ? (lo_bits >> (2 * (p - 1))) & 3u : hi_t;
+            const int nx = p < m.D ? (int)((tile_bits >> (2 * p)) & 3u) : -1;  // tile of the next pass (aligned placement)
+            switch (lo_t * 4 + hi_t) {
+              case 0: sf_pass16b<0, NB, !SPAN, HM>(m, tp, tpB, S, NT, sl, u_sl, lane, g4, nx); break;
+              case 5: sf_pass16b<1, NB, !SPAN, HM>(m, tp, tpB, S, NT, sl, u_sl, lane, g4, nx); break;
+              case 10: sf_pass16b<2, NB, !SPAN, HM>(m, tp, tpB, S, NT, sl, u_sl, lane, g4, nx); break;
+              case 15: sf_pass16b<3, NB, !SPAN, HM>(m, tp, tpB, S, NT, sl, u_sl, lane, g4, nx); break;
+              case 1: if (SPAN) sf_pass16b_span<0, 1, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+              case 2: if (SPAN) sf_pass16b_span<0, 2, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+              case 3: if (SPAN) sf_pass16b_span<0, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+              case 6: if (SPAN) sf_pass16b_span<1, 2, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+              case 7: if (SPAN) sf_pass16b_span<1, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+              default: if (SPAN) sf_pass16b_span<2, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+            }
+          }
+          u_cur = S.ut;
+        }
+        if (TPW == 2) {  // the other tile's turn (after TPW turns every tile is `cur` under its own name again)
+          const f32x4 tu = u_cur; u_cur = u_oth; u_oth = tu;
+          const long tg = gal_cur; gal_cur = gal_oth; gal_oth = tg;
         }
       }
-      u = S.ut;
     }
-    // ---------------------------------------------------------------- un-standardise, box test, outputs
-    float th[4];
-    bool ok = true;
+#ifdef SF_Q_STATS
+    { const unsigned long long n = __builtin_amdgcn_s_memrealtime(); qs_ph[3] += n - qs_t_mark; qs_t_mark = n; }
+#endif
+    // ---------------------------------------------------------------- un-standardise, box test, outputs (per tile)
+#pragma unroll 1
+    for (int j = 0; j < TPW; ++j) {
+      const int wi = (j * 4 + wave) * 16 + s;
+      float th[4];
+      int tdc[4];
+      bool ok = true;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int p = 4 * g4 + r;
-      th[r] = 0.f;
-      if (p < m.D) {
-        const int td = (int)m.cst[m.c_tdim + p];
-        th[r] = sf_div(u[r] - m.cst[m.c_pshift + p], m.cst[m.c_pscale + p]);
-        ok = ok && (fabsf(th[r]) <= 3.0e38f);  // finite (NaN compares false)
-        if (a.lo) ok = ok && (th[r] >= a.lo[td]) && (th[r] <= a.hi[td]);
+      for (int r = 0; r < 4; ++r) {
+        const int p = 4 * g4 + r;
+        const float* e = ecb + p * 5;
+        th[r] = (u_cur[r] - e[0]) * e[1];
+        tdc[r] = reinterpret_cast<const int*>(e)[4];
+        // finite (NaN compares false) and inside the box; slots >= D: u = 0, shift = 0, 1 / scale = 0 -> 0, always inside
+        ok = ok && (fabsf(th[r]) <= 3.0e38f) && (th[r] >= e[2]) && (th[r] <= e[3]);
       }
-    }
-    // the work words are still in LDS: nothing about the item had to stay in registers through the flow
-    const unsigned int n_ent = ctrl[0];
-    const int lgA = (int)ctrl[1];
-    const unsigned int e = (unsigned)wi >> lgA;
-    const bool entry_ok = e < n_ent;
-    const unsigned int ee = entry_ok ? e : 0u;
-    const uint32_t slot = ctrl[SF_Q_HDR + ee];
-    const uint32_t att_base = ctrl[SF_Q_HDR + 64 + ee];
-    const uint32_t att = att_base + ((unsigned)wi & ((1u << lgA) - 1u));
-    const bool valid = entry_ok && att < a.attempt_limit;
-    const unsigned long long okb = __ballot(ok);
-    const uint32_t acc16 = (uint32_t)(okb & (okb >> 16) & (okb >> 32) & (okb >> 48) & 0xffffull) &
-                           (uint32_t)(__ballot(valid) & 0xffffull);
-    // A consecutive items hold attempts att_base .. att_base+A-1 of one slot: the lowest accepted one wins.
-    // A <= 16: the group sits inside this wave's tile.  A = 32 / 64 (the last few slots of a catalogue, each tried by
-    // half of / the whole workgroup at once): the waves of the group combine through four LDS words.
-    const int A = 1 << lgA;
-    int first, me;
-    if (lgA <= 4) {
-      const int grp0 = (s / A) * A;
-      const uint32_t gmask = (acc16 >> grp0) & ((1u << A) - 1u);
-      first = gmask ? (int)__builtin_ctz(gmask) : -1;
-      me = s - grp0;
-    } else {
-      if ((threadIdx.x & 63) == 0) ctrl[20 + wave] = acc16 ? (unsigned)__builtin_ctz(acc16) : 16u;
-      __syncthreads();  // (lgA is the same for the whole workgroup)
-      const int gw0 = (int)((e << lgA) >> 4), gwn = A >> 4;  // first wave of the group, waves per group
-      first = -1;
+      // the work words are still in LDS: nothing about the item had to stay in registers through the flow
+      const unsigned int n_ent = ctrl[0];
+      const int lgA = (int)ctrl[1];
+      const unsigned int e = (unsigned)wi >> lgA;
+      const bool entry_ok = e < n_ent;
+      const unsigned int ee = entry_ok ? e : 0u;
+      const uint32_t slot = ctrl[SF_Q_HDR + ee];
+      const uint32_t att_base = ctrl[SF_Q_HDR + IPW + ee];
+      const uint32_t att = att_base + ((unsigned)wi & ((1u << lgA) - 1u));
+      const bool valid = entry_ok && att < a.attempt_limit;
+      const unsigned long long okb = __ballot(ok);
+      const uint32_t acc16 = (uint32_t)(okb & (okb >> 16) & (okb >> 32) & (okb >> 48) & 0xffffull) &
+                             (uint32_t)(__ballot(valid) & 0xffffull);
+      // A consecutive items hold attempts att_base .. att_base+A-1 of one slot: the lowest accepted one wins.
+      // A <= 16: the group sits inside this wave's tile.  A = 32 / 64 (the last few slots of a catalogue, each tried by
+      // half of / the whole workgroup at once): the group is tiles j*4 + gw0 .. of the SAME j, one per wave; the waves
+      // combine through four LDS words.
+      const int A = 1 << lgA;
+      int first, me;
+      if (lgA <= 4) {
+        const int grp0 = (s / A) * A;
+        const uint32_t gmask = (acc16 >> grp0) & ((1u << A) - 1u);
+        first = gmask ? (int)__builtin_ctz(gmask) : -1;
+        me = s - grp0;
+      } else {
+        if ((threadIdx.x & 63) == 0) ctrl[20 + wave] = acc16 ? (unsigned)__builtin_ctz(acc16) : 16u;
+        __syncthreads();  // (lgA is the same for the whole workgroup)
+        const int gw0 = (int)(((e << lgA) >> 4) & 3u), gwn = A >> 4;  // first wave of the group, waves per group
+        first = -1;
 #pragma unroll
-      for (int w = 3; w >= 0; --w) {
-        const unsigned int cw = ctrl[20 + w];
-        if (w >= gw0 && w < gw0 + gwn && cw < 16u) first = (w - gw0) * 16 + (int)cw;
+        for (int w = 3; w >= 0; --w) {
+          const unsigned int cw = ctrl[20 + w];
+          if (w >= gw0 && w < gw0 + gwn && cw < 16u) first = (w - gw0) * 16 + (int)cw;
+        }
+        me = wi - (int)(e << lgA);
+        if (TPW == 2) __syncthreads();  // the four words are rewritten for the other tile
       }
-      me = wi - (int)(e << lgA);
-    }
-    if (valid && me == first) {
+      if (valid && me == first) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (4 * g4 + r < m.D) a.out[(size_t)slot * m.D + (int)m.cst[m.c_tdim + 4 * g4 + r]] = th[r];
-    }
-    // accepted -> resolved; rejected -> staged for the retry ring, or for the survivor list once the launch's attempt
-    // limit is reached; wave 0 publishes everything the workgroup staged at the top of the next sf_q_fetch
-    const bool leader = entry_ok && g4 == 0 && me == 0;
-    const uint32_t room = a.attempt_limit > att_base ? a.attempt_limit - att_base : 0u;
-    const uint32_t tried = room < (uint32_t)A ? room : (uint32_t)A;  // attempts of this entry evaluated here
-    const bool hit = leader && first >= 0;
-    const bool retry = leader && first < 0 && att_base + (uint32_t)A < a.attempt_limit;
-    const bool surv = leader && first < 0 && !retry;
-    if (leader && (a.n_drawn || a.gal_acc)) {
-      const long gal = (long)(slot / (uint32_t)a.S);
-      // (the caller pre-counts ONE attempt per slot; a first attempt that ran with speculation may have used more)
-      const int used = (first >= 0 ? first + 1 : (int)tried) - (att_base == 0u ? 1 : 0);
-      if (a.n_drawn && used > 0) atomicAdd(&a.n_drawn[gal], used);
-      if (hit && a.gal_acc && att_base >= 64u) atomicAdd(&a.gal_acc[gal], 1);  // progress past the 64th attempt
-    }
-    if (retry) {
-      const unsigned int pos = atomicAdd(&ctrl[2], 1u);
-      ctrl[SF_Q_HDR + 2 * 64 + pos] = slot;
-      ctrl[SF_Q_HDR + 3 * 64 + pos] = att_base + (uint32_t)A;
-    }
-    if (surv) {
-      const unsigned int pos = atomicAdd(&ctrl[3], 1u);
-      ctrl[SF_Q_HDR + 4 * 64 + pos] = slot;
-    }
-    const unsigned int n_res = (unsigned)__popcll(__ballot(hit || surv));
-    const unsigned int n_ev = (unsigned)__popcll(__ballot(valid && g4 == 0));
-    const unsigned int n_r0 = (unsigned)__popcll(__ballot(leader && first < 0 && att_base == 0u));
-    if ((threadIdx.x & 63) == 0) {
-      if (n_res) atomicAdd(&ctrl[4], n_res);
-      if (n_ev) atomicAdd(&ctrl[5], n_ev);
-      if (n_r0) atomicAdd(&ctrl[6], n_r0);
+        for (int r = 0; r < 4; ++r)
+          if (4 * g4 + r < m.D) a.out[(size_t)slot * m.D + tdc[r]] = th[r];
+      }
+      // accepted -> resolved; rejected -> staged for the retry ring, or for the survivor list once the launch's attempt
+      // limit is reached; wave 0 publishes everything the workgroup staged at the top of the next sf_q_fetch
+      const bool leader = entry_ok && g4 == 0 && me == 0;
+      const uint32_t room = a.attempt_limit > att_base ? a.attempt_limit - att_base : 0u;
+      const uint32_t tried = room < (uint32_t)A ? room : (uint32_t)A;  // attempts of this entry evaluated here
+      const bool hit = leader && first >= 0;
+      const bool retry = leader && first < 0 && att_base + (uint32_t)A < a.attempt_limit;
+      const bool surv = leader && first < 0 && !retry;
+      if (leader && (a.n_drawn || a.gal_acc)) {
+        const long gal = (long)(slot / (uint32_t)a.S);
+        // (the caller pre-counts ONE attempt per slot; a first attempt that ran with speculation may have used more)
+        const int used = (first >= 0 ? first + 1 : (int)tried) - (att_base == 0u ? 1 : 0);
+        if (a.n_drawn && used > 0) atomicAdd(&a.n_drawn[gal], used);
+        if (hit && a.gal_acc && att_base >= 64u) atomicAdd(&a.gal_acc[gal], 1);  // progress past the 64th attempt
+      }
+      if (retry) {
+        const unsigned int pos = atomicAdd(&ctrl[2], 1u);
+        ctrl[SF_Q_HDR + 2 * IPW + pos] = slot;
+        ctrl[SF_Q_HDR + 3 * IPW + pos] = att_base + (uint32_t)A;
+      }
+      if (surv) {
+        const unsigned int pos = atomicAdd(&ctrl[3], 1u);
+        ctrl[SF_Q_HDR + 4 * IPW + pos] = slot;
+      }
+      const unsigned int n_res = (unsigned)__popcll(__ballot(hit || surv));
+      const unsigned int n_ev = (unsigned)__popcll(__ballot(valid && g4 == 0));
+      const unsigned int n_r0 = (unsigned)__popcll(__ballot(leader && first < 0 && att_base == 0u));
+      if ((threadIdx.x & 63) == 0) {
+        if (n_res) atomicAdd(&ctrl[4], n_res);
+        if (n_ev) atomicAdd(&ctrl[5], n_ev);
+        if (n_r0) atomicAdd(&ctrl[6], n_r0);
+      }
+      if (TPW == 2) {
+        const f32x4 tu = u_cur; u_cur = u_oth; u_oth = tu;
+      }
     }
 #ifdef SF_Q_STATS
     qs_last_work = __builtin_amdgcn_s_memrealtime();
+    qs_ph[4] += qs_last_work - qs_t_mark;
+    if (a.qtrace && threadIdx.x == 0 && qs_iters <= 256) a.qtrace[((size_t)blockIdx.x * 256 + qs_iters - 1) * 4 + 3] = (uint32_t)qs_last_work;
 #endif
   }
 }
@@ -776,7 +931,7 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
 // functions k_maf_samp16 runs (sf_pass16b / sf_pass16b_span: hidden H x H blocks as split-bf16 x3, everything else
 // fp32), so that the sampler's precision can be asserted against the fp64 oracle draw for draw, with no Philox and no
 // rejection in between (sf_flow_inverse_from_noise_sampler; tests/test_gpu_parity.py).  One wave = 16 rows of z.
-template <int NB, bool SPAN>
+template <int NB, bool SPAN, bool HM>
 __global__ __launch_bounds__(256, 3) void k_maf_inv16b(SfDev m, const float* __restrict__ z, const float* __restrict__ x,
                                                        long n, float* __restrict__ out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -827,7 +982,9 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16b(SfDev m, const float* __r
     const float* tp = sf_lds16;
     const unsigned int* tpB = reinterpret_cast<const unsigned int*>(sf_lds16 + m.t16_a);
     S.c0p = nullptr;
+    S.tab = false;
     S.xr = x + it * m.C;
+    if (HM) S.hdone = sf_ld4(tp + m.o16_bh + g4 * 4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) S.ut[r] = 0.f;
     const int dsl = (int)m.cst[m.c_dslot + t * SF_DMAX + s];
@@ -844,11 +1001,12 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16b(SfDev m, const float* __r
       const float u_sl = sf_slot16(u, sl, lane);
       const uint32_t hi_t = (tile_bits >> (2 * (p - 1))) & 3u;
       const uint32_t lo_t = SPAN ? (lo_bits >> (2 * (p - 1))) & 3u : hi_t;
+      const int nx = p < m.D ? (int)((tile_bits >> (2 * p)) & 3u) : -1;
       switch (lo_t * 4 + hi_t) {
-        case 0: sf_pass16b<0, NB, !SPAN>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
-        case 5: sf_pass16b<1, NB, !SPAN>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
-        case 10: sf_pass16b<2, NB, !SPAN>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
-        case 15: sf_pass16b<3, NB, !SPAN>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+        case 0: sf_pass16b<0, NB, !SPAN, HM>(m, tp, tpB, S, NT, sl, u_sl, lane, g4, nx); break;
+        case 5: sf_pass16b<1, NB, !SPAN, HM>(m, tp, tpB, S, NT, sl, u_sl, lane, g4, nx); break;
+        case 10: sf_pass16b<2, NB, !SPAN, HM>(m, tp, tpB, S, NT, sl, u_sl, lane, g4, nx); break;
+        case 15: sf_pass16b<3, NB, !SPAN, HM>(m, tp, tpB, S, NT, sl, u_sl, lane, g4, nx); break;
         case 1: if (SPAN) sf_pass16b_span<0, 1, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
         case 2: if (SPAN) sf_pass16b_span<0, 2, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
         case 3: if (SPAN) sf_pass16b_span<0, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
@@ -868,26 +1026,34 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16b(SfDev m, const float* __r
   }
 }
 
-template <int NB, bool SPAN>
+template <int NB, bool SPAN, bool HM>
 static hipError_t sf_launch16b_hook(const SfDev& m, const float* z, const float* x, long n, float* out, hipStream_t st) {
   static SfAttrCache attr;
   const size_t sh = ((size_t)m.t16_a + (size_t)m.t16B_stride) * sizeof(float);
   int attr_dev;
   if (attr.need(attr_dev)) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_maf_inv16b<NB, SPAN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)k_maf_inv16b<NB, SPAN, HM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr.set(attr_dev);
   }
-  hipLaunchKernelGGL((k_maf_inv16b<NB, SPAN>), dim3((unsigned)((n + 63) / 64)), dim3(256), sh, st, m, z, x, n, out);
+  hipLaunchKernelGGL((k_maf_inv16b<NB, SPAN, HM>), dim3((unsigned)((n + 63) / 64)), dim3(256), sh, st, m, z, x, n, out);
   return hipGetLastError();
+}
+// head rows on the matrix pipe (aligned placement with the head tile in the image: D <= 8); SF_HEAD_MFMA=0 keeps the
+// per-lane dot products (A-B runs)
+static bool sf_maf16_head_mfma(const SfDev& m) {
+  static int env = -1;
+  if (env < 0) { const char* e = std::getenv("SF_HEAD_MFMA"); env = e ? std::atoi(e) : 1; }
+  return env != 0 && !m.m16_span && m.o16_wh >= 0;
 }
 // false when the flow has no split-bf16 sampler (then the sampler IS the fp32 path and sf_flow_inverse_from_noise covers it)
 bool sf_maf16b_available(const SfDev& m) {
   return m.kind == SF_MAF && m.m16_ok && !m.hidden_bf16 && m.packed16 != nullptr && m.packed16B != nullptr;
 }
 hipError_t sf_launch_maf_inv16b_hook(const SfDev& m, const float* z, const float* x, long n, float* out, hipStream_t st) {
-  if (m.m16_span) return m.NB == 1 ? sf_launch16b_hook<1, true>(m, z, x, n, out, st) : sf_launch16b_hook<2, true>(m, z, x, n, out, st);
-  return m.NB == 1 ? sf_launch16b_hook<1, false>(m, z, x, n, out, st) : sf_launch16b_hook<2, false>(m, z, x, n, out, st);
+  if (m.m16_span) return m.NB == 1 ? sf_launch16b_hook<1, true, false>(m, z, x, n, out, st) : sf_launch16b_hook<2, true, false>(m, z, x, n, out, st);
+  if (sf_maf16_head_mfma(m)) return m.NB == 1 ? sf_launch16b_hook<1, false, true>(m, z, x, n, out, st) : sf_launch16b_hook<2, false, true>(m, z, x, n, out, st);
+  return m.NB == 1 ? sf_launch16b_hook<1, false, false>(m, z, x, n, out, st) : sf_launch16b_hook<2, false, false>(m, z, x, n, out, st);
 }
 
 // Per-galaxy context table of the 16-row path: tab[gal][t][row] = b0 + bc + Wc e(x_gal), rows in tile order.
@@ -967,32 +1133,35 @@ static int sf_resident_blocks16(const void* fn, size_t sh, int cap) {
   return cus * per;
 }
 
+// persistent sampler: no more workgroups than the chip holds (more would only queue behind the spinning ones)
+template <int NB, bool SPAN, bool HM, int TPW>
+static hipError_t sf_launch16q(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
+  static SfAttrCache attr;
+  static SfResidentCache rcache;
+  const size_t sh = ((size_t)(m.ctab ? m.t16_a_tab : m.t16_a) + (size_t)m.t16B_stride) * sizeof(float) +
+                    (SF_Q_WORDS(64 * TPW) + 80) * sizeof(unsigned int);
+  int attr_dev;
+  if (attr.need(attr_dev)) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_maf_samp16<NB, SPAN, HM, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr.set(attr_dev);
+  }
+  int resident = 0, cur_dev = 0;
+  (void)hipGetDevice(&cur_dev);
+  if (!rcache.get(cur_dev, sh, resident)) {
+    resident = sf_resident_blocks16((const void*)k_maf_samp16<NB, SPAN, HM, TPW>, sh, SPAN ? 3 : 4);
+    rcache.put(cur_dev, sh, resident);
+  }
+  long grid = (a.n_items + 64 * TPW - 1) / (64 * TPW);
+  if (grid > resident) grid = resident;
+  SfSamp16Args args;
+  args.m = m;
+  args.a = a;
+  hipLaunchKernelGGL((k_maf_samp16<NB, SPAN, HM, TPW>), dim3((unsigned)grid), dim3(256), sh, st, args);
+  return hipGetLastError();
+}
 template <int NB, bool SPAN>
 static hipError_t sf_launch16(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
-  if (a.q) {  // persistent sampler: no more workgroups than the chip holds (more would only queue behind the spinning ones)
-    static SfAttrCache attr;
-    static SfResidentCache rcache;
-    const size_t sh = ((size_t)m.t16_a + (size_t)m.t16B_stride) * sizeof(float) + SF_Q_WORDS(64) * sizeof(unsigned int);
-    int attr_dev;
-    if (attr.need(attr_dev)) {
-      hipError_t e = hipFuncSetAttribute((const void*)k_maf_samp16<NB, SPAN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return e;
-      attr.set(attr_dev);
-    }
-    int resident = 0, cur_dev = 0;
-    (void)hipGetDevice(&cur_dev);
-    if (!rcache.get(cur_dev, sh, resident)) {
-      resident = sf_resident_blocks16((const void*)k_maf_samp16<NB, SPAN>, sh, SPAN ? 3 : 4);
-      rcache.put(cur_dev, sh, resident);
-    }
-    long grid = (a.n_items + 63) / 64;
-    if (grid > resident) grid = resident;
-    SfSamp16Args args;
-    args.m = m;
-    args.a = a;
-    hipLaunchKernelGGL((k_maf_samp16<NB, SPAN>), dim3((unsigned)grid), dim3(256), sh, st, args);
-    return hipGetLastError();
-  }
   static SfAttrCache attr;
   const size_t sh = (size_t)m.t16_stride * sizeof(float);
   int attr_dev;
@@ -1005,7 +1174,22 @@ static hipError_t sf_launch16(const SfDev& m, const SfSampleArgsHost& a, hipStre
   hipLaunchKernelGGL((k_maf_inv16<NB, SPAN>), dim3((unsigned)((a.n_items + per_block - 1) / per_block)), dim3(256), sh, st, m, a);
   return hipGetLastError();
 }
+// SF_TPW=1: one draw tile per wave and iteration (64 items per workgroup iteration) instead of two (A-B runs)
+static int sf_maf16_tpw() {
+  static int env = -1;
+  if (env < 0) { const char* e = std::getenv("SF_TPW"); env = (e && std::atoi(e) == 1) ? 1 : 2; }
+  return env;
+}
+template <int NB, bool SPAN, bool HM>
+static hipError_t sf_launch16q_t(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
+  return sf_maf16_tpw() == 1 ? sf_launch16q<NB, SPAN, HM, 1>(m, a, st) : sf_launch16q<NB, SPAN, HM, 2>(m, a, st);
+}
 hipError_t sf_launch_maf_inv16(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
+  if (a.q) {
+    if (m.m16_span) return m.NB == 1 ? sf_launch16q_t<1, true, false>(m, a, st) : sf_launch16q_t<2, true, false>(m, a, st);
+    if (sf_maf16_head_mfma(m)) return m.NB == 1 ? sf_launch16q_t<1, false, true>(m, a, st) : sf_launch16q_t<2, false, true>(m, a, st);
+    return m.NB == 1 ? sf_launch16q_t<1, false, false>(m, a, st) : sf_launch16q_t<2, false, false>(m, a, st);
+  }
   if (m.m16_span) return m.NB == 1 ? sf_launch16<1, true>(m, a, st) : sf_launch16<2, true>(m, a, st);
   return m.NB == 1 ? sf_launch16<1, false>(m, a, st) : sf_launch16<2, false>(m, a, st);
 }

@@ -29,7 +29,7 @@ struct SfQueue {  // device memory owned by the handle; zeroed before each persi
   unsigned int error;      unsigned int _p5[31];
   unsigned int rej0;       unsigned int _p6[31];  // slots whose FIRST attempt was rejected (acceptance statistic)
   unsigned long long evals; unsigned int _p7[30]; // flow evaluations (items with a valid attempt)
-  unsigned long long stats[16];  // SF_Q_STATS builds: cycles / counts per phase, summed over workgroups (diagnostics)
+  unsigned long long stats[24];  // SF_Q_STATS builds: cycles / counts per phase, summed over workgroups (diagnostics)
 };
 
 #define SF_Q_SPIN_TICKS 1500000000ull  // 15 s of s_memrealtime (100 MHz)
@@ -128,7 +128,15 @@ __device__ __forceinline__ bool sf_q_fetch(const Args& a, unsigned int* ctrl, un
       const unsigned int want = (unsigned)IPW - n;
       const unsigned int nd = dend - dcur < want ? dend - dcur : want;
       for (unsigned int i = lane; i < nd; i += 64) {
-        unsigned int sl = a.slots ? a.slots[dcur + i] : (unsigned int)a.slot_base + dcur + i;
+        unsigned int sl;
+        if (a.slots) {
+          sl = a.slots[dcur + i];
+        } else if (a.dense_M) {  // galaxy-interleaved order of a whole catalogue (sf_internal.h)
+          const unsigned int idx = dcur + i, row = idx / a.dense_M;
+          sl = (idx - row * a.dense_M) * (unsigned int)a.S + row;
+        } else {
+          sl = (unsigned int)a.slot_base + dcur + i;
+        }
         if (sl >= a.out_slots) { atomicExch(&q->error, 4u); sl = 0u; }  // a listed slot outside out[M*S]
         w_slot[n + i] = sl;
         w_att[n + i] = a.attempt;
@@ -234,7 +242,8 @@ __device__ __forceinline__ bool sf_q_fetch(const Args& a, unsigned int* ctrl, un
           const unsigned int ot = (unsigned int)__shfl_xor((int)mn, o, 64);
           mn = ot < mn ? ot : mn;
         }
-        const unsigned int amax_now = mn < 4u ? 2u : (mn < (unsigned)AMAX ? mn : (unsigned)AMAX);
+        unsigned int amax_now = mn < 4u ? 2u : (mn < (unsigned)AMAX ? mn : (unsigned)AMAX);
+        if (a.spec_full_after && mn >= a.spec_full_after) amax_now = (unsigned)AMAX;
         while ((2u << lg) * n <= (unsigned)IPW && (2u << lg) <= amax_now) ++lg;
       }
       if (lane == 0) ctrl[10] = nt;

@@ -246,8 +246,10 @@ def mma16(packed, woff, IT, ot, it, tile_in, acc4):
         mfma16(packed[base + r], tile_in[r], acc4)
 
 
-def maf_inverse16(d, packed, z16, x16):
-    """z16 [16,D] base noise, x16 [16,C] context rows -> theta [16,D] through the 16-row image (table-free path)."""
+def maf_inverse16(d, packed, z16, x16, head_mfma=False):
+    """z16 [16,D] base noise, x16 [16,C] context rows -> theta [16,D] through the 16-row image (table-free path).
+    head_mfma: the (a, m) head rows as ONE MFMA output tile accumulated over the finished hidden tiles (o16_wh / o16_bh,
+    the HM variant of sf_pass16b) instead of the per-lane dot products over o16_hv."""
     cst = np.asarray(d["cst"])
     D, T, NB, NT, C = d["D"], d["T"], d["NB"], d["nT16"], d["C"]
     # draw in tile layout: lane (s, g4), reg r = physical slot 4*g4 + r
@@ -279,9 +281,14 @@ def maf_inverse16(d, packed, z16, x16):
                 mma16(packed, tp + d["o16_wc"], d["nC16"], ot, ic, ctx_tile(ic), c0[ot])
         act = np.zeros((3, NT, 4, 64))
         ut = np.zeros((4, 64))
+        hdone = np.zeros((4, 64))
+        if head_mfma:
+            for r in range(4):
+                hdone[r] = packed[tp + d["o16_bh"] + G4 * 4 + r]
         for p in range(1, D + 1):
             sl = int(cst[d["c_dslot"] + t * 16 + (p - 1)])
             pa = np.zeros(64); pm = np.zeros(64)
+            fresh = None
             if p >= 2:
                 lo, hi = d["g16_lo"][p - 1], d["g16_tile"][p - 1]     # tiles holding the group of degree p-1
                 for ot in range(lo, hi + 1):
@@ -298,6 +305,13 @@ def maf_inverse16(d, packed, z16, x16):
                         new[ot] = np.tanh(b)
                     for ot, v in new.items():
                         act[k + 1, ot] = v
+                if head_mfma:
+                    assert lo == hi, "the MFMA head exists for the aligned placement only"
+                    fresh = hdone.copy()
+                    mma16(packed, tp + d["o16_wh"], NT, 0, hi, act[NB, hi], fresh)
+                    nxt = d["g16_tile"][p] if p < D else -1
+                    if nxt != hi:
+                        hdone = fresh
                 hv = tp + d["o16_hv"] + sl * 128 + G4 * 32          # [slot][g4][tile][r][a|m]
                 for tl in range(hi + 1):
                     for r in range(4):
@@ -306,8 +320,13 @@ def maf_inverse16(d, packed, z16, x16):
             def sum4(v):
                 v = v + v[LANES ^ 16]
                 return v + v[LANES ^ 32]
-            av = packed[tp + d["o16_hvb"] + 2 * sl] + sum4(pa)
-            mv = packed[tp + d["o16_hvb"] + 2 * sl + 1] + sum4(pm)
+            if fresh is not None:   # rows 2 sl, 2 sl + 1 of the head tile: row group sl >> 1, registers 0,1 or 2,3
+                src = (LANES & 15) + 16 * (sl >> 1)
+                av = fresh[(sl & 1) * 2][src]
+                mv = fresh[(sl & 1) * 2 + 1][src]
+            else:
+                av = packed[tp + d["o16_hvb"] + 2 * sl] + sum4(pa)
+                mv = packed[tp + d["o16_hvb"] + 2 * sl + 1] + sum4(pm)
             wv = (slot_val(u, sl) - mv) / scale(av)
             for r in range(4):
                 ut[r] = np.where((G4 == (sl >> 2)) & (r == (sl & 3)), wv, ut[r])
