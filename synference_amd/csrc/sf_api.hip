@@ -521,9 +521,9 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
     if (progress_rule) SF_HIP(hipMemsetAsync(f->d_galacc, 0, (size_t)M * sizeof(int32_t), st));
     a.slots = cur; a.slot_base = 0; a.n_items = (long)pending; a.n_total = (uint32_t)pending;
     {
-      static int env_il = -1;  // developer knob: SF_INTERLEAVE=0 keeps the dense list in slot order (A-B runs)
-      if (env_il < 0) { const char* e = std::getenv("SF_INTERLEAVE"); env_il = e ? std::atoi(e) : 1; }
-      a.dense_M = (!cur && env_il && pending == M * S && M > 1) ? (uint32_t)M : 0u;
+      static int env_il = -1;  // developer knob: SF_INTERLEAVE=<galaxies per block>, 0 = plain slot order (A-B runs)
+      if (env_il < 0) { const char* e = std::getenv("SF_INTERLEAVE"); env_il = e ? std::atoi(e) : 128; }
+      a.dense_G = (!cur && env_il > 0 && pending == M * S && M > 1 && (int64_t)env_il * S < (int64_t)1 << 31) ? (uint32_t)env_il : 0u;
       static int env_sp = -1;  // developer knob: SF_SPEC_AFTER=<attempts> (0 = width grows with the attempt number only)
       if (env_sp < 0) { const char* e = std::getenv("SF_SPEC_AFTER"); env_sp = e ? std::atoi(e) : 0; }
       a.spec_full_after = (uint32_t)env_sp;

@@ -39,12 +39,14 @@ struct SfSampleArgsHost {
   uint32_t attempt_limit = 0xffffffffu;  // attempts [attempt, attempt_limit) are tried by this launch; then -> rejected[]
   uint32_t n_total = 0;                // slots of the dense list (== n_items)
   uint32_t out_slots = 0;              // M * S: every slot id must be below this
-  // != 0 (whole-catalogue launches: slots == nullptr, slot_base == 0, n_total == dense_M * S): item i of the dense list is
-  // slot (i % dense_M) * S + i / dense_M -- consecutive items walk ACROSS the galaxies.  In slot order the ~8 workgroups
-  // that draw the ranges of a low-acceptance galaxy grind through its retries alone while the rest of the chip runs dry
-  // (their own retries come first and the dense phase does not share work); interleaved, every workgroup carries the
-  // same mix.  The draws do not depend on the order (streams are keyed by slot and attempt).
-  uint32_t dense_M = 0;
+  // != 0 (whole-catalogue launches: slots == nullptr, slot_base == 0, n_total == M * S): the dense list walks ACROSS the
+  // galaxies inside blocks of dense_G consecutive galaxies -- item i lies in block b = i / (dense_G * S); with Gb =
+  // min(dense_G, M - b * dense_G) galaxies in that block and j = i - b * dense_G * S it is slot
+  // (b * dense_G + j % Gb) * S + j / Gb.  In plain slot order the ~8 workgroups that draw the ranges of a low-acceptance
+  // galaxy grind through its retries alone while the rest of the chip runs dry (their own retries come first and the dense
+  // phase does not share work); interleaved, every workgroup carries the same mix, and a block keeps the context rows
+  // in flight few enough to stay cached.  The draws do not depend on the order (streams are keyed by slot and attempt).
+  uint32_t dense_G = 0;
   // tail mode: entries that have failed at least this many attempts are tried at the full speculation width at once
   // (0 = the width only grows with the attempt number)
   uint32_t spec_full_after = 0;

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "sf_device.h"
 #include "sf_internal.h"
@@ -623,8 +624,12 @@ struct SfSamp16Args {
 // TWO tiles of 16 draws through each staged transform, one after the other -- the queue fetch, the image copy and their
 // barriers are paid once per 128 draws instead of once per 64 (together ~20 % of a workgroup's time at TPW = 1); between
 // transforms a tile is just its 4 registers of u and its galaxy index.
-template <int NB, bool SPAN, bool HM, int TPW>
+// DD > 0 (HM, aligned placement with ONE degree group per tile, D == DD <= 5): the passes of a transform are unrolled
+// with the tile of each known at compile time (pass p works on tile p - 2) -- no dispatch, and the per-tile state is
+// updated in place instead of being copied into the registers every arm of the switch has to agree on.
+template <int NB, bool SPAN, bool HM, int TPW, int DD = 0>
 __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args args_in) {
+  static_assert(DD == 0 || (HM && !SPAN && DD >= 2 && DD <= 5), "unrolled passes: head tile, aligned placement, D <= 5");
   constexpr int IPW = 64 * TPW;
   const int wave = threadIdx.x >> 6;
   // with the per-galaxy context table the context block Wc is never read: only the prefix of part A before it is staged
@@ -795,6 +800,17 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
 #pragma unroll
             for (int r = 0; r < 4; ++r) S.ut[r] = (g4 == (sl >> 2) && r == (sl & 3)) ? wv : S.ut[r];
           }
+          if constexpr (DD > 0) {
+            auto seq_pass = [&](auto otc) {
+              constexpr int OT = decltype(otc)::value;
+              const int sl = __builtin_amdgcn_readlane(dsl, OT + 1);
+              sf_pass16b<OT, NB, true, true>(m, tp, tpB, S, NT, sl, sf_slot16(u_cur, sl, lane), lane, g4, OT + 2 < DD ? OT + 1 : -1);
+            };
+            seq_pass(std::integral_constant<int, 0>{});
+            if constexpr (DD >= 3) seq_pass(std::integral_constant<int, 1>{});
+            if constexpr (DD >= 4) seq_pass(std::integral_constant<int, 2>{});
+            if constexpr (DD >= 5) seq_pass(std::integral_constant<int, 3>{});
+          } else
           for (int p = 2; p <= m.D; ++p) {
             const int sl = __builtin_amdgcn_readlane(dsl, p - 1);
             const float u_sl = sf_slot16(u_cur, sl, lane);
@@ -1134,7 +1150,7 @@ static int sf_resident_blocks16(const void* fn, size_t sh, int cap) {
 }
 
 // persistent sampler: no more workgroups than the chip holds (more would only queue behind the spinning ones)
-template <int NB, bool SPAN, bool HM, int TPW>
+template <int NB, bool SPAN, bool HM, int TPW, int DD = 0>
 static hipError_t sf_launch16q(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
   static SfAttrCache attr;
   static SfResidentCache rcache;
@@ -1142,14 +1158,14 @@ static hipError_t sf_launch16q(const SfDev& m, const SfSampleArgsHost& a, hipStr
                     (SF_Q_WORDS(64 * TPW) + 80) * sizeof(unsigned int);
   int attr_dev;
   if (attr.need(attr_dev)) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_maf_samp16<NB, SPAN, HM, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)k_maf_samp16<NB, SPAN, HM, TPW, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr.set(attr_dev);
   }
   int resident = 0, cur_dev = 0;
   (void)hipGetDevice(&cur_dev);
   if (!rcache.get(cur_dev, sh, resident)) {
-    resident = sf_resident_blocks16((const void*)k_maf_samp16<NB, SPAN, HM, TPW>, sh, SPAN ? 3 : 4);
+    resident = sf_resident_blocks16((const void*)k_maf_samp16<NB, SPAN, HM, TPW, DD>, sh, SPAN ? 3 : 4);
     rcache.put(cur_dev, sh, resident);
   }
   long grid = (a.n_items + 64 * TPW - 1) / (64 * TPW);
@@ -1157,7 +1173,7 @@ static hipError_t sf_launch16q(const SfDev& m, const SfSampleArgsHost& a, hipStr
   SfSamp16Args args;
   args.m = m;
   args.a = a;
-  hipLaunchKernelGGL((k_maf_samp16<NB, SPAN, HM, TPW>), dim3((unsigned)grid), dim3(256), sh, st, args);
+  hipLaunchKernelGGL((k_maf_samp16<NB, SPAN, HM, TPW, DD>), dim3((unsigned)grid), dim3(256), sh, st, args);
   return hipGetLastError();
 }
 template <int NB, bool SPAN>
@@ -1180,9 +1196,27 @@ static int sf_maf16_tpw() {
   if (env < 0) { const char* e = std::getenv("SF_TPW"); env = (e && std::atoi(e) == 1) ? 1 : 2; }
   return env;
 }
+// the unrolled-pass kernels apply when degree p - 1 sits alone in tile p - 2 (SF_SEQ=0: the dispatching kernel, A-B runs)
+static int sf_maf16_seq_d(const SfDev& m) {
+  static int env = -1;
+  if (env < 0) { const char* e = std::getenv("SF_SEQ"); env = e ? std::atoi(e) : 1; }
+  if (!env || m.m16_span || m.D < 3 || m.D > 5 || m.nT16 != m.D - 1) return 0;
+  for (int p = 2; p <= m.D; ++p)
+    if (m.g16_tile[p - 1] != p - 2) return 0;
+  return m.D;
+}
 template <int NB, bool SPAN, bool HM>
 static hipError_t sf_launch16q_t(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
-  return sf_maf16_tpw() == 1 ? sf_launch16q<NB, SPAN, HM, 1>(m, a, st) : sf_launch16q<NB, SPAN, HM, 2>(m, a, st);
+  if (sf_maf16_tpw() == 1) return sf_launch16q<NB, SPAN, HM, 1>(m, a, st);
+  if constexpr (HM && !SPAN) {
+    switch (sf_maf16_seq_d(m)) {
+      case 3: return sf_launch16q<NB, SPAN, HM, 2, 3>(m, a, st);
+      case 4: return sf_launch16q<NB, SPAN, HM, 2, 4>(m, a, st);
+      case 5: return sf_launch16q<NB, SPAN, HM, 2, 5>(m, a, st);
+      default: break;
+    }
+  }
+  return sf_launch16q<NB, SPAN, HM, 2>(m, a, st);
 }
 hipError_t sf_launch_maf_inv16(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
   if (a.q) {

@@ -131,9 +131,12 @@ __device__ __forceinline__ bool sf_q_fetch(const Args& a, unsigned int* ctrl, un
         unsigned int sl;
         if (a.slots) {
           sl = a.slots[dcur + i];
-        } else if (a.dense_M) {  // galaxy-interleaved order of a whole catalogue (sf_internal.h)
-          const unsigned int idx = dcur + i, row = idx / a.dense_M;
-          sl = (idx - row * a.dense_M) * (unsigned int)a.S + row;
+        } else if (a.dense_G) {  // block-interleaved order of a whole catalogue (sf_internal.h)
+          const unsigned int idx = dcur + i, S_ = (unsigned int)a.S, M_ = a.n_total / S_;
+          const unsigned int per_block = a.dense_G * S_, b = idx / per_block, j = idx - b * per_block;
+          const unsigned int left = M_ - b * a.dense_G, Gb = left < a.dense_G ? left : a.dense_G;
+          const unsigned int smp = j / Gb;
+          sl = (b * a.dense_G + (j - smp * Gb)) * S_ + smp;
         } else {
           sl = (unsigned int)a.slot_base + dcur + i;
         }
