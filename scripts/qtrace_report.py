@@ -1,8 +1,10 @@
 """Reads the iteration trace of the SF_Q_STATS build (SF_Q_TRACE=file): utilisation of the persistent sampler over time."""
 import sys
 import numpy as np
-tr = np.fromfile(sys.argv[1], dtype=np.uint32).reshape(2048, 256, 4)
 ipw = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+grid = int(sys.argv[3]) if len(sys.argv) > 3 else 1024          # workgroups of the launch: [grid][2048 * 256 / grid][4]
+step = float(sys.argv[4]) if len(sys.argv) > 4 else 100.0        # report window, us
+tr = np.fromfile(sys.argv[1], dtype=np.uint32).reshape(grid, (2048 * 256) // grid, 4)
 used = tr[:, :, 1] > 0
 wg = used.any(axis=1)
 t0 = tr[:, :, 0][used].min()
@@ -15,7 +17,7 @@ items = ent << lg
 print(f"workgroups {wg.sum()}, iterations {used.sum()}, last end {end[used].max():.0f} us, items {items[used].sum()}")
 dense_end = start[used & (tail == 0)].max()
 print(f"last dense iteration starts at {dense_end:.0f} us; first tail iteration at {start[used & (tail == 1)].min():.0f} us")
-edges = np.arange(0, end[used].max() + 100, 100.0)
+edges = np.arange(0, end[used].max() + step, step)
 print(" window_us  active_wgs  mean_items/iter  iter_us  lgA_hist")
 for a, b in zip(edges[:-1], edges[1:]):
     sel = used & (start >= a) & (start < b)

@@ -482,11 +482,11 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
   // the 16-row MAF kernel tries a slot 64 times per workgroup iteration, the 32-row kernels 32 times per tile: the
   // first (persistent) launch goes as deep as a short sequential chain allows, the windows beyond are chip-wide
   const bool fast16 = m.kind == SF_MAF && m.m16_ok && !m.hidden_bf16 && m.packed16 != nullptr;
-  // (round 3: 1 024 for the 32-row kernels too -- with the split-bf16 NSF sampler cfg3 takes 80 ms per 2e7 draws at 1 024,
-  //  87 at 256, 101 at 4 096: deeper windows leave the persistent launch with a few slow slots, shallower ones leave more
-  //  survivors to the find / resolve launches)
-  uint32_t first_window = 1024u;
-  (void)fast16;
+  // (32-row kernels, NSF cfg3 per 2e7 draws with the interleaved dense order and find launches that double the attempts
+  //  instead of covering a whole window: 78 ms at 256, 81 at 1 024 -- an iteration of that kernel costs 180 us, so a
+  //  slot that needs hundreds of attempts is cheaper side by side in a find launch than 32 at a time in the tail; the
+  //  16-row MAF kernel, 35 us per sparse iteration and 64 attempts wide, is best left at 1 024)
+  uint32_t first_window = fast16 ? 1024u : 256u;
   {
     static int env_w = -1;  // developer knob: SF_FIRST_WINDOW=<attempts> (power of two)
     if (env_w < 0) { const char* e = std::getenv("SF_FIRST_WINDOW"); env_w = e ? std::atoi(e) : 0; }
@@ -527,6 +527,9 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
       static int env_sp = -1;  // developer knob: SF_SPEC_AFTER=<attempts> (0 = width grows with the attempt number only)
       if (env_sp < 0) { const char* e = std::getenv("SF_SPEC_AFTER"); env_sp = e ? std::atoi(e) : 0; }
       a.spec_full_after = (uint32_t)env_sp;
+      static int env_tc = -1;  // developer knob: SF_TAIL_CAP=<items> (0 = the whole iteration)
+      if (env_tc < 0) { const char* e = std::getenv("SF_TAIL_CAP"); env_tc = e ? std::atoi(e) : 0; }
+      a.tail_cap = (uint32_t)env_tc;
     }
     a.attempt = 0; a.attempt_limit = limit; a.attempts_per_slot = 1;
     a.rejected = f->d_rej[buf];
@@ -609,8 +612,11 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
     uint32_t window_end = attempt < 1024u ? 1024u : ((attempt > ceiling / 16u) ? ceiling : attempt * 16u);
     if (window_end > ceiling) window_end = ceiling;
     while (pending > 0 && attempt < ceiling && !out_of_time()) {
+      // as many new attempts per survivor as it has already failed (a slot that has failed n attempts needs ~n more on
+      // average: doubling wastes at most half of a launch, a launch over the whole window up to 15/16 of it), within a
+      // budget of 4M items per launch
       uint32_t A = 32;
-      while ((uint64_t)(2u * A) * (uint64_t)pending <= (1ull << 22) && 2u * A <= 65536u) A *= 2;
+      while ((uint64_t)(2u * A) * (uint64_t)pending <= (1ull << 22) && 2u * A <= 65536u && 2u * A <= (attempt < 64u ? 64u : attempt)) A *= 2;
       while (A > 1 && (uint64_t)attempt + A > (uint64_t)window_end) A /= 2;  // windows (and the caller's ceiling) are exact
       SF_HIP(hipMemsetAsync(f->d_best, 0xff, (size_t)pending * sizeof(uint32_t), st));
       p.slots = cur; p.slot_base = 0; p.n_items = (long)pending * A; p.attempts_per_slot = (int)A; p.attempt = attempt;

@@ -268,7 +268,8 @@ struct MafOps {
   static __device__ __forceinline__ void inverse(const SfDev& m, float (&u)[NS][SF_DMAX],
                                                  const float* const (&xr)[NS], float (&logdet)[NS],
                                                  int lane, float* lds = nullptr,
-                                                 const float* const (*cg)[NS] = nullptr) {  // (no table on this path)
+                                                 const float* const (*cg)[NS] = nullptr,  // (no table on this path)
+                                                 bool active = true) {                    // (MAF: every wave runs)
     if (m.inc_ok && m.NB <= 2) inverse_incremental(m, u, xr, logdet, lane, lds);
     else inverse_full(m, u, xr, logdet, lane, lds);
   }
@@ -536,10 +537,13 @@ struct NsfOps {
                                                         const float (&u)[NS][SF_DMAX],
                                                         const float* const (&xr)[NS], f32x16 (&hid)[HT][NS],
                                                         int lane, const f32x16 (*pre)[1][NS] = nullptr,
-                                                        const float* const (*cg)[NS] = nullptr) {
+                                                        const float* const (*cg)[NS] = nullptr, bool active = true) {
+    // active (wave-uniform): false for a wave of the persistent sampler whose tile holds no item -- it only takes part
+    // in the staging barriers, its issue slots go to the waves that have work
     const int h = lane >> 5;
     int part = 0;
     const float* tp = tp0;  // part 0 was staged by the caller
+    if (active) {
     if (cg) sf_ctab_load<HT, NS>(hid, *cg, (t * m.ctab_NV) * m.ctab_R, h);  // bin + Win_c e(x) from the galaxy table
     else sf_init_bias<HT, NS>(hid, tp + m.o_bin, h);
     {
@@ -548,6 +552,7 @@ struct NsfOps {
       sf_mm_acc<HT, NS, 1, false>(hid, ut, tp + m.o_winu, m.nGu, 0, m.nGu, lane);
     }
     if (!cg) sf_ctx_mm<HT, NS>(hid, xr, m, tp + m.o_winc, lane, pre);
+    }
 #pragma unroll
     for (int k = 0; k < SF_NBMAX; ++k) {
       if (k < m.NB) {
@@ -555,6 +560,7 @@ struct NsfOps {
           part = m.blk_part[k];
           tp = sf_stage_part<LDSW>(m, t, part, lds);
         }
+        if (!active) continue;
         f32x16 t2[HT][NS];
         {
           f32x16 t1[HT][NS];
@@ -640,10 +646,10 @@ struct NsfOps {
                                                   float (&u)[NS][SF_DMAX], const float* const (&xr)[NS],
                                                   float (&logdet)[NS], bool inverse, int lane,
                                                   const f32x16 (*pre)[1][NS] = nullptr,
-                                                  const float* const (*cg)[NS] = nullptr) {
+                                                  const float* const (*cg)[NS] = nullptr, bool active = true) {
     f32x16 hid[HT][NS];
-    const float* tp = resnet(m, t, lds, tp0, u, xr, hid, lane, pre, cg);
-    spline_apply(m, tp, t, hid, u, logdet, inverse, lane);
+    const float* tp = resnet(m, t, lds, tp0, u, xr, hid, lane, pre, cg, active);
+    if (active) spline_apply(m, tp, t, hid, u, logdet, inverse, lane);
   }
 
   // LULinear:  y = L (U u) + b ;  diag(U) = softplus(udiag) + eps
@@ -761,7 +767,7 @@ struct NsfOps {
   static __device__ __forceinline__ void inverse(const SfDev& m0, float (&u)[NS][SF_DMAX],
                                                  const float* const (&xr)[NS], float (&logdet)[NS],
                                                  int lane, float* lds = nullptr,
-                                                 const float* const (*cg)[NS] = nullptr) {
+                                                 const float* const (*cg)[NS] = nullptr, bool active = true) {
     // first standardised context tile, built once for all transforms (one sample tile per wave only: registers)
     f32x16 ct0[1][NS];
     if (NS == 1) sf_build_ctx_tile<NS>(ct0, xr, m0, 0, lane >> 5);
@@ -769,11 +775,11 @@ struct NsfOps {
     for (int t = m0.T - 1; t >= 0; --t) {
       const SfDev m = sf_iter_view(m0);
       const float* tp0 = sf_stage_part<LDSW>(m, t, 0, lds);
-      if (m.D > 1) {
+      if (active && m.D > 1) {
         if (LDSW && m.n_parts == 1) lu_inverse(m, tp0 + m.o_lu, u, logdet);
         else lu_inverse(m, m.packed + (size_t)t * m.t_stride + m.o_lu, u, logdet);
       }
-      coupling(m, t, lds, tp0, u, xr, logdet, true, lane, pre, cg);
+      coupling(m, t, lds, tp0, u, xr, logdet, true, lane, pre, cg, active);
     }
   }
 };

@@ -191,6 +191,9 @@ __global__ __launch_bounds__(64 * WPB) void k_sample_persist(SfSampArgs args_in,
   unsigned int* ctrl = reinterpret_cast<unsigned int*>(sf_lds_image + ctrl_off);
   unsigned int pf;
   sf_q_begin<IPW>(args_in.a, ctrl, pf);
+#ifdef SF_Q_STATS
+  unsigned int qs_iters = 0;
+#endif
   for (;;) {
     const SfSampArgs* ap;
     {
@@ -203,6 +206,13 @@ __global__ __launch_bounds__(64 * WPB) void k_sample_persist(SfSampArgs args_in,
     const int lane = (threadIdx.x & 63) + sf_opaque_zero();
     const int c = lane & 31, h = lane >> 5;
     if (!sf_q_fetch<IPW, 32>(a, ctrl, pf)) break;
+#ifdef SF_Q_STATS
+    if (a.qtrace && threadIdx.x == 0 && qs_iters < (2048u * 256u) / gridDim.x) {
+      uint32_t* tr = a.qtrace + ((size_t)blockIdx.x * ((2048u * 256u) / gridDim.x) + qs_iters) * 4;
+      tr[0] = (uint32_t)__builtin_amdgcn_s_memrealtime(); tr[1] = ctrl[0]; tr[2] = ctrl[1] | (ctrl[9] << 8);
+    }
+    ++qs_iters;
+#endif
     float u[NS][SF_DMAX];
     const float* xr[NS];
     float logdet[NS];
@@ -234,7 +244,9 @@ __global__ __launch_bounds__(64 * WPB) void k_sample_persist(SfSampArgs args_in,
         cg[ns] = use_tab ? m.ctab + (size_t)gal * m.T * m.ctab_NV * m.ctab_R : nullptr;
       }
     }
-    Ops::inverse(m, u, xr, logdet, lane, sf_lds_image, use_tab ? &cg : nullptr);
+    // a wave whose tiles hold no item (sparse iterations of the tail) only takes part in the staging barriers
+    const bool wave_active = __builtin_amdgcn_readfirstlane((unsigned)(wave * NS * 32) < (ctrl[0] << ctrl[1]) ? 1 : 0) != 0;
+    Ops::inverse(m, u, xr, logdet, lane, sf_lds_image, use_tab ? &cg : nullptr, wave_active);
     const unsigned int n_ent = ctrl[0];
     const int lgA = (int)ctrl[1];
     const int A = 1 << lgA;
@@ -300,6 +312,10 @@ __global__ __launch_bounds__(64 * WPB) void k_sample_persist(SfSampArgs args_in,
         if (n_r0) atomicAdd(&ctrl[6], n_r0);
       }
     }
+#ifdef SF_Q_STATS
+    if (a.qtrace && threadIdx.x == 0 && qs_iters <= (2048u * 256u) / gridDim.x)
+      a.qtrace[((size_t)blockIdx.x * ((2048u * 256u) / gridDim.x) + qs_iters - 1) * 4 + 3] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
   }
 }
 

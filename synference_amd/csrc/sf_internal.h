@@ -50,6 +50,9 @@ struct SfSampleArgsHost {
   // tail mode: entries that have failed at least this many attempts are tried at the full speculation width at once
   // (0 = the width only grows with the attempt number)
   uint32_t spec_full_after = 0;
+  // tail mode: speculation fills at most this many items of a workgroup iteration (0 = all of them).  A wave walks its
+  // tiles one after the other, so items beyond one tile per wave double the latency of the iteration.
+  uint32_t tail_cap = 0;
   int32_t* gal_acc = nullptr;          // optional [M]: += 1 per accepted slot of the galaxy (progress test between stages)
 #ifdef SF_Q_STATS
   // developer build: [workgroup][256][4] = {start of the iteration (10 ns since the first workgroup's start is taken on

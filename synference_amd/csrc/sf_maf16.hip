@@ -684,8 +684,8 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
       break;
     }
 #ifdef SF_Q_STATS
-    if (a.qtrace && threadIdx.x == 0 && qs_iters < 256) {
-      uint32_t* tr = a.qtrace + ((size_t)blockIdx.x * 256 + qs_iters) * 4;
+    if (a.qtrace && threadIdx.x == 0 && qs_iters < (2048u * 256u) / gridDim.x) {
+      uint32_t* tr = a.qtrace + ((size_t)blockIdx.x * ((2048u * 256u) / gridDim.x) + qs_iters) * 4;
       tr[0] = (uint32_t)__builtin_amdgcn_s_memrealtime(); tr[1] = ctrl[0]; tr[2] = ctrl[1] | (ctrl[9] << 8);
     }
     ++qs_iters;
@@ -938,7 +938,8 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
 #ifdef SF_Q_STATS
     qs_last_work = __builtin_amdgcn_s_memrealtime();
     qs_ph[4] += qs_last_work - qs_t_mark;
-    if (a.qtrace && threadIdx.x == 0 && qs_iters <= 256) a.qtrace[((size_t)blockIdx.x * 256 + qs_iters - 1) * 4 + 3] = (uint32_t)qs_last_work;
+    if (a.qtrace && threadIdx.x == 0 && qs_iters <= (2048u * 256u) / gridDim.x)
+      a.qtrace[((size_t)blockIdx.x * ((2048u * 256u) / gridDim.x) + qs_iters - 1) * 4 + 3] = (uint32_t)qs_last_work;
 #endif
   }
 }

@@ -247,7 +247,8 @@ __device__ __forceinline__ bool sf_q_fetch(const Args& a, unsigned int* ctrl, un
         }
         unsigned int amax_now = mn < 4u ? 2u : (mn < (unsigned)AMAX ? mn : (unsigned)AMAX);
         if (a.spec_full_after && mn >= a.spec_full_after) amax_now = (unsigned)AMAX;
-        while ((2u << lg) * n <= (unsigned)IPW && (2u << lg) <= amax_now) ++lg;
+        const unsigned int cap = (a.tail_cap && a.tail_cap < (unsigned)IPW) ? a.tail_cap : (unsigned)IPW;
+        while ((2u << lg) * n <= cap && (2u << lg) <= amax_now) ++lg;
       }
       if (lane == 0) ctrl[10] = nt;
     }
