@@ -152,6 +152,12 @@ __device__ __forceinline__ float sf_slot16(const f32x4& t, int sl, int lane) {
   return __shfl(v, (lane & 15) + 16 * (sl >> 2), 64);
 }
 
+// the same value where it is needed only in the row group that owns the slot (lanes of group sl >> 2): no cross-lane move
+__device__ __forceinline__ float sf_slot16_own(const f32x4& t, int sl) {
+  const int r = sl & 3;
+  return r == 0 ? t[0] : (r == 1 ? t[1] : (r == 2 ? t[2] : t[3]));
+}
+
 template <int NB, bool SPAN>
 __global__ __launch_bounds__(256, 3) void k_maf_inv16(SfDev m, SfSampleArgsHost a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -380,13 +386,13 @@ __device__ __forceinline__ SfSplit2 sf_split16(const f32x4& v) {
   SfSplit2 t;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    const sf_bf16x2 h = {(__bf16)v[2 * q], (__bf16)v[2 * q + 1]};
-    const unsigned int hw = __builtin_bit_cast(unsigned int, h);
-    const float r0 = v[2 * q] - __builtin_bit_cast(float, hw << 16);
-    const float r1 = v[2 * q + 1] - __builtin_bit_cast(float, hw & 0xffff0000u);
-    const sf_bf16x2 l = {(__bf16)r0, (__bf16)r1};
+    // ONE packed conversion per pair (element-wise casts make the compiler convert the pair once packed and its first
+    // element once more on its own); round-to-nearest-even, the same values
+    const f32x2 pv = {v[2 * q], v[2 * q + 1]};
+    const unsigned int hw = __builtin_bit_cast(unsigned int, __builtin_convertvector(pv, sf_bf16x2));
+    const f32x2 rv = {v[2 * q] - __builtin_bit_cast(float, hw << 16), v[2 * q + 1] - __builtin_bit_cast(float, hw & 0xffff0000u)};
     t.hi[q] = hw;
-    t.lo[q] = __builtin_bit_cast(unsigned int, l);
+    t.lo[q] = __builtin_bit_cast(unsigned int, __builtin_convertvector(rv, sf_bf16x2));
   }
   return t;
 }
@@ -777,12 +783,23 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
           // cleared per tile and transform: a non-finite value left behind by one draw must not reach another one
           // through a structural zero (a pass only reads tiles that an earlier pass of the SAME tile and transform wrote,
           // or zeros)
+          if constexpr (DD > 0) {
+            // passes run in tile order 0, 1, 2, 3: the only operands read before this tile and transform wrote them are
+            // the odd tiles (the second half of a pair, read with all-zero weights by the pass of the even tile)
 #pragma unroll
-          for (int k = 0; k < 2; ++k)
+            for (int k = 0; k < 2; ++k)
 #pragma unroll
-            for (int pr = 0; pr < 2; ++pr)
+              for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
-              for (int c = 0; c < 4; ++c) { S.ph[k][pr][c] = 0u; S.pl[k][pr][c] = 0u; }
+                for (int c = 2; c < 4; ++c) { S.ph[k][pr][c] = 0u; S.pl[k][pr][c] = 0u; }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+              for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { S.ph[k][pr][c] = 0u; S.pl[k][pr][c] = 0u; }
+          }
           if (!HM) {
 #pragma unroll
             for (int ot = 0; ot < 4; ++ot)
@@ -796,7 +813,7 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
             const int sl = __builtin_amdgcn_readlane(dsl, 0);
             const float av = tp[m.o16_hvb + 2 * sl], mv = tp[m.o16_hvb + 2 * sl + 1];
             const float sc = (m.scale_fn == 0 ? sf_softplus(av) : sf_sigmoid(av + 2.0f)) + m.eps;
-            const float wv = sf_div(sf_slot16(u_cur, sl, lane) - mv, sc);
+            const float wv = sf_div(sf_slot16_own(u_cur, sl) - mv, sc);
 #pragma unroll
             for (int r = 0; r < 4; ++r) S.ut[r] = (g4 == (sl >> 2) && r == (sl & 3)) ? wv : S.ut[r];
           }
@@ -804,7 +821,7 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
             auto seq_pass = [&](auto otc) {
               constexpr int OT = decltype(otc)::value;
               const int sl = __builtin_amdgcn_readlane(dsl, OT + 1);
-              sf_pass16b<OT, NB, true, true>(m, tp, tpB, S, NT, sl, sf_slot16(u_cur, sl, lane), lane, g4, OT + 2 < DD ? OT + 1 : -1);
+              sf_pass16b<OT, NB, true, true>(m, tp, tpB, S, NT, sl, sf_slot16_own(u_cur, sl), lane, g4, OT + 2 < DD ? OT + 1 : -1);
             };
             seq_pass(std::integral_constant<int, 0>{});
             if constexpr (DD >= 3) seq_pass(std::integral_constant<int, 1>{});
@@ -813,7 +830,7 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
           } else
           for (int p = 2; p <= m.D; ++p) {
             const int sl = __builtin_amdgcn_readlane(dsl, p - 1);
-            const float u_sl = sf_slot16(u_cur, sl, lane);
+            const float u_sl = sf_slot16_own(u_cur, sl);  // (only the owning row group keeps what is computed from it)
             const uint32_t hi_t = (tile_bits >> (2 * (p - 1))) & 3u;
             const uint32_t lo_t = SPAN ? (lo_bits >> (2 * (p - 1))) & 3u : hi_t;
             const int nx = p < m.D ? (int)((tile_bits >> (2 * p)) & 3u) : -1;  // tile of the next pass (aligned placement)
