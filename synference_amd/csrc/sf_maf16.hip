@@ -48,6 +48,19 @@ __device__ __forceinline__ f32x4 sf_ld4(const float* p) {
   r[0] = b.x; r[1] = b.y; r[2] = b.z; r[3] = b.w;
   return r;
 }
+// tanh of a tile's four values with the plain arithmetic on packed-f32 instructions (v_pk_mul / v_pk_add / v_pk_fma: two
+// values per instruction at the full rate) -- the kernel is bound by vector ISSUE, and the four exp2 / four rcp cannot be
+// packed.  Same operations per value as sf_tanh, so the same results.
+__device__ __forceinline__ f32x4 sf_tanh4(const f32x4& b) {
+  const f32x2 c = {2.8853900817779268f, 2.8853900817779268f}, one = {1.0f, 1.0f}, m2 = {-2.0f, -2.0f};
+  const f32x2 t01 = f32x2{b[0], b[1]} * c, t23 = f32x2{b[2], b[3]} * c;
+  const f32x2 e01 = f32x2{__builtin_amdgcn_exp2f(t01[0]), __builtin_amdgcn_exp2f(t01[1])} + one;
+  const f32x2 e23 = f32x2{__builtin_amdgcn_exp2f(t23[0]), __builtin_amdgcn_exp2f(t23[1])} + one;
+  const f32x2 r01 = {__builtin_amdgcn_rcpf(e01[0]), __builtin_amdgcn_rcpf(e01[1])};
+  const f32x2 r23 = {__builtin_amdgcn_rcpf(e23[0]), __builtin_amdgcn_rcpf(e23[1])};
+  const f32x2 o01 = __builtin_elementwise_fma(r01, m2, one), o23 = __builtin_elementwise_fma(r23, m2, one);
+  return f32x4{o01[0], o01[1], o23[0], o23[1]};
+}
 // weight fragment of (out tile ot, in tile it) of a block with IT input tiles
 __device__ __forceinline__ float4 sf_w16(const float* wp, int IT, int ot, int it, int lane) {
   return reinterpret_cast<const float4*>(wp)[(ot * IT + it) * 64 + lane];
@@ -517,9 +530,7 @@ __device__ __forceinline__ void sf_pass16b(const SfDev& m, const float* tp, cons
         wh = sf_w16(tp + m.o16_wh, NT, 0, OT, lane);
       }
       __builtin_amdgcn_sched_barrier(0);
-      f32x4 th;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) th[r] = sf_tanh(b[r]);
+      const f32x4 th = sf_tanh4(b);
       if (k + 1 < NB) { sf_put16b<OT>(S, k + 1, th); b = bn; }
       else last = th;
     }
