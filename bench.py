@@ -547,7 +547,7 @@ def main():
     f_train = 3.0 * wl["f_lp"]   # a training step costs 3x the log_prob figure per row
     train_tf = f_train * B / (train_kernel_ms * 1e-3) / 1e12
     ttraffic, ttraffic_src = pmc_traffic("train") if a.workload == "maf_cfg2" else (None, None)
-    kname = (("k_maf_samp16<NB,SPAN>" if desc.get("m16_ok") and not a.hidden_bf16 else "k_sample_persist<MafOps>")
+    kname = (("k_maf_samp16<NB,SPAN,HM,TPW,DD>" if desc.get("m16_ok") and not a.hidden_bf16 else "k_sample_persist<MafOps>")
              if wl["kind"] == "maf" else
              ("k_sample_persist<NsfOps<..., BF = 2>> (sampler image, split-bf16 hidden blocks)" if desc.get("nsf_split_sampler") and
               not a.hidden_bf16 else "k_sample_persist<NsfOps>"))
@@ -586,7 +586,7 @@ def main():
                              "reference's D-pass inverse spends 175150) x ACCEPTED draws; rejected evaluations, tile "
                              "padding and the per-galaxy context kernel are overhead.  issue_busy = SQ counters "
                              "of the committed PMC summary (the hidden blocks run as three bf16 MFMAs, so MFMA FLOPs are no "
-                             "longer comparable with the fp32 peak; what binds is VALU issue + latency); contract_* = SURVEY "
+                             "longer comparable with the fp32 peak; what binds is vector ISSUE: VALU + the MFMAs' issue slots, DESIGN.md section 3); contract_* = SURVEY "
                              "8d's figure for the reference algorithm x accepted draws (an algorithmic ratio, can exceed 1).",
                      "issue_busy": busy, "fp32_sampler": fp32_leg,
                      "contract_tflops": contract, "contract_ratio": contract / PEAK_FP32_TFLOPS},

@@ -42,6 +42,11 @@ def section(rows, pat, grid=None, alg_bytes=None, note=None):
         out["mfma_busy_frac"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles
         out["valu_busy_frac"] = 4 * m["SQ_ACTIVE_INST_VALU"] / simd_cycles
         out["wait_frac_of_wave_cycles"] = m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"]
+    if all(k in m for k in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_VALU_TRANS_F32")):
+        # what the vector issue port of a SIMD spends: 4 cycles per plain VALU instruction, 8 per transcendental, 8 per MFMA
+        # (MI355X_MICROARCH.md, per-instruction constants) -- an estimate from instruction counts, not a counter
+        port = 4 * (m["SQ_INSTS_VALU"] - m["SQ_INSTS_VALU_TRANS_F32"]) + 8 * m["SQ_INSTS_VALU_TRANS_F32"] + 8 * m["SQ_INSTS_MFMA"]
+        out["vector_issue_port_frac_est"] = port / simd_cycles
     if "SQ_WAIT_INST_ANY" in m and "SQ_WAVE_CYCLES" in m:
         out["issue_stall_frac_of_wave_cycles"] = m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]
         out["issuing_frac_of_wave_cycles"] = m["SQ_ACTIVE_INST_ANY"] / m["SQ_WAVE_CYCLES"]
