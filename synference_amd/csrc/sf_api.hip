@@ -424,8 +424,10 @@ int sf_flow_sample_round(sf_flow* f, const float* x, int64_t S, const uint32_t* 
 static int ensure_queue(sf_flow* f, int64_t n_slots, int64_t M) {
   if (!f->d_queue) SF_HIP(hipMalloc(&f->d_queue, sizeof(SfQueue)));
   if (!f->h_queue) SF_HIP(hipHostMalloc((void**)&f->h_queue, sizeof(SfQueue), hipHostMallocDefault));
+  // ring positions are tickets of idle workgroups: at most (resident workgroups x items per iteration) are in flight at a
+  // time (<= 2048 x 256), whatever the size of the catalogue -- 2^20 entries (8 MiB) never alias
   uint64_t cap = 1u << 16;
-  while (cap < (uint64_t)n_slots) cap <<= 1;
+  while (cap < (uint64_t)n_slots && cap < (1ull << 20)) cap <<= 1;
   if (f->ring_cap < cap) {
     (void)hipFree(f->d_ring);
     f->d_ring = nullptr; f->ring_cap = 0;

@@ -103,10 +103,13 @@ class FlowPosterior:
         est = self.posterior_estimator
         X = self._embed(X)
         est._sync_params()
-        est.flow.set_sample_time_limit(timeout_seconds)
         lo, hi = self._box()
         seed = self._next_seed(seed)
         N, S = X.shape[0], int(num_samples)
+        # the ceiling is the CALL's: a chunk gets what is left of it (never less than a second, so that a late chunk still
+        # runs its first launch and reports NaN rows instead of raising)
+        import time as _time
+        t_call = _time.monotonic()
         out = torch.empty((N, S, self.spec.D), dtype=torch.float32, device=self.device)
         counts = torch.empty(N, dtype=torch.int32, device=self.device)
         rows_per = max(1, _MAX_SLOTS_PER_CALL // max(S, 1))
@@ -120,6 +123,8 @@ class FlowPosterior:
                 r1 = min(N, r0 + rows_per)
                 # slot ids restart per chunk; the random streams are keyed by the row's position in the whole catalogue
                 est.flow.set_sample_row_offset(int(row_offset) + r0)
+                est.flow.set_sample_time_limit(None if timeout_seconds is None
+                                               else max(1.0, float(timeout_seconds) - (_time.monotonic() - t_call)))
                 o, c = est.flow.sample(X[r0:r1], S, lo, hi, seed=seed, max_attempts=self.max_sampling_attempts,
                                        out=out[r0:r1], return_counts=True)
                 counts[r0:r1] = c

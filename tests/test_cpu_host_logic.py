@@ -579,3 +579,29 @@ def test_importer_reads_a_hand_written_nflows_state_dict():
     bad[pre + "initial_layer.mask"] = np.array([[1., 1.]] * 4, dtype=np.float32)
     with pytest.raises(ValueError, match="mask"):
         spec_and_flat_from_state_dict(bad)
+
+
+def dense_order_slot(idx, M, S, G):
+    """The block-interleaved dense order of a whole-catalogue sampling call, restated from sf_queue.h (sf_q_fetch, the
+    `a.dense_G` branch; described at SfSampleArgsHost::dense_G in sf_internal.h): item idx -> slot."""
+    per_block = G * S
+    b, j = divmod(idx, per_block)
+    Gb = min(G, M - b * G)
+    smp, g = divmod(j, Gb)
+    return (b * G + g) * S + smp
+
+
+@pytest.mark.parametrize("M,S,G", [(1, 7, 128), (5, 3, 128), (128, 4, 128), (129, 4, 128), (300, 5, 128), (2000, 3, 128),
+                                   (37, 11, 8), (64, 2, 32)])
+def test_block_interleaved_dense_order_is_a_permutation_that_spreads_a_galaxy(M, S, G):
+    """Every slot exactly once (nothing sampled twice, nothing left empty), also with a ragged last block; and inside a
+    full block a range of G consecutive items holds G different galaxies -- the point of the order."""
+    slots = np.array([dense_order_slot(i, M, S, G) for i in range(M * S)])
+    assert np.array_equal(np.sort(slots), np.arange(M * S))
+    if M >= G:
+        first = slots[:G] // S
+        assert len(set(first.tolist())) == G
+    # the slots of one galaxy are S items, one per run of Gb, never adjacent (unless the block is a single galaxy)
+    gal = slots // S
+    if M > 1:
+        assert (np.diff(np.flatnonzero(gal == 0)) >= min(G, M)).all()
