@@ -587,8 +587,10 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
                    (unsigned long long)f->h_queue->evals, f->h_queue->resolved, (unsigned)a.n_total);
       std::fprintf(stderr, "[sf_queue]   max iterations of a workgroup %llu; last flow evaluation ended %.1f us, last exit %.1f us after the first start\n",
                    q[11], ((double)q[12] - (double)q[10]) * 0.01, ((double)q[13] - (double)q[10]) * 0.01);
-      std::fprintf(stderr, "[sf_queue]   wave 0 of every workgroup, summed (us): fetch %.0f, prologue %.0f, staging %.0f, passes %.0f, epilogue %.0f\n",
+      std::fprintf(stderr, "[sf_queue]   wave 0 of every workgroup, summed, dense mode (us): fetch %.0f, prologue %.0f, staging %.0f, passes %.0f, epilogue %.0f\n",
                    (double)q[14] * 0.01, (double)q[15] * 0.01, (double)q[16] * 0.01, (double)q[17] * 0.01, (double)q[18] * 0.01);
+      std::fprintf(stderr, "[sf_queue]   the same in tail mode (us): fetch %.0f, prologue %.0f, staging %.0f, passes %.0f, epilogue %.0f\n",
+                   (double)q[19] * 0.01, (double)q[20] * 0.01, (double)q[21] * 0.01, (double)q[22] * 0.01, (double)q[23] * 0.01);
     }
     rej0 = (float)f->h_queue->rej0;
     pending = (int64_t)f->h_queue->n_surv;

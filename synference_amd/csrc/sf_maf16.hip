@@ -671,7 +671,7 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
 #ifdef SF_Q_STATS
   const unsigned long long qs_k0 = __builtin_amdgcn_s_memtime();
   unsigned long long qs_iters = 0, qs_last_work = 0;
-  unsigned long long qs_ph[5] = {0, 0, 0, 0, 0};
+  unsigned long long qs_ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [5..9]: the same phases in tail mode
   if (threadIdx.x == 0) atomicMin(&args_in.a.q->stats[10], __builtin_amdgcn_s_memrealtime());  // first start (100 MHz)
 #endif
   for (;;) {
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
     if (!sf_q_fetch<IPW, 64>(a, ctrl, pf)) {
 #ifdef SF_Q_STATS
       if (threadIdx.x == 0) {
-        for (int i = 0; i < 5; ++i) atomicAdd(&a.q->stats[14 + i], qs_ph[i]);  // fetch | prologue | staging | passes | epilogue (10 ns)
+        for (int i = 0; i < 10; ++i) atomicAdd(&a.q->stats[14 + i], qs_ph[i]);  // fetch | prologue | staging | passes | epilogue (10 ns), dense then tail
         atomicAdd(&a.q->stats[9], __builtin_amdgcn_s_memtime() - qs_k0);  // workgroup lifetime
         atomicMax(&a.q->stats[11], qs_iters);                              // most iterations of one workgroup
         atomicMax(&a.q->stats[12], qs_last_work);                          // end of the last flow evaluation (100 MHz)
@@ -707,7 +707,8 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
     }
     ++qs_iters;
     const unsigned long long qs_t_fetch = __builtin_amdgcn_s_memrealtime();
-    qs_ph[0] += qs_t_fetch - qs_t_top;
+    const int qs_o = ctrl[9] ? 5 : 0;
+    qs_ph[qs_o + 0] += qs_t_fetch - qs_t_top;
     unsigned long long qs_t_mark = qs_t_fetch;
 #endif
     const int NT = m.nT16;
@@ -752,7 +753,7 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
       S.c0p = S.tab ? m.ctab + ((size_t)gal_cur * m.T + t) * m.ctab_R : nullptr;
       if (HM && S.tab) sf_c0_prefetch(S, (int)((tile_bits >> 2) & 3u), g4);
 #ifdef SF_Q_STATS
-      { const unsigned long long n = __builtin_amdgcn_s_memrealtime(); qs_ph[t == m.T - 1 ? 1 : 3] += n - qs_t_mark; qs_t_mark = n; }
+      { const unsigned long long n = __builtin_amdgcn_s_memrealtime(); qs_ph[qs_o + (t == m.T - 1 ? 1 : 3)] += n - qs_t_mark; qs_t_mark = n; }
 #endif
       __syncthreads();
       {
@@ -776,7 +777,7 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
       }
       __syncthreads();
 #ifdef SF_Q_STATS
-      { const unsigned long long n = __builtin_amdgcn_s_memrealtime(); qs_ph[2] += n - qs_t_mark; qs_t_mark = n; }
+      { const unsigned long long n = __builtin_amdgcn_s_memrealtime(); qs_ph[qs_o + 2] += n - qs_t_mark; qs_t_mark = n; }
 #endif
       const float* tp = sf_lds16;
       const unsigned int* tpB = reinterpret_cast<const unsigned int*>(sf_lds16 + (S.tab ? m.t16_a_tab : m.t16_a));
@@ -867,7 +868,7 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
       }
     }
 #ifdef SF_Q_STATS
-    { const unsigned long long n = __builtin_amdgcn_s_memrealtime(); qs_ph[3] += n - qs_t_mark; qs_t_mark = n; }
+    { const unsigned long long n = __builtin_amdgcn_s_memrealtime(); qs_ph[qs_o + 3] += n - qs_t_mark; qs_t_mark = n; }
 #endif
     // ---------------------------------------------------------------- un-standardise, box test, outputs (per tile)
 #pragma unroll 1
@@ -965,7 +966,7 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
     }
 #ifdef SF_Q_STATS
     qs_last_work = __builtin_amdgcn_s_memrealtime();
-    qs_ph[4] += qs_last_work - qs_t_mark;
+    qs_ph[qs_o + 4] += qs_last_work - qs_t_mark;
     if (a.qtrace && threadIdx.x == 0 && qs_iters <= (2048u * 256u) / gridDim.x)
       a.qtrace[((size_t)blockIdx.x * ((2048u * 256u) / gridDim.x) + qs_iters - 1) * 4 + 3] = (uint32_t)qs_last_work;
 #endif
