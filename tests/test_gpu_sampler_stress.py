@@ -77,3 +77,24 @@ def test_many_handles_and_back_to_back_catalogues_share_the_device_cleanly():
                 outs[tag] = got
             else:
                 assert np.array_equal(outs[tag], got)            # same seed, same slots -> same draws, whatever ran in between
+
+
+@pytest.mark.parametrize("name,M,S", [("maf_cfg1", 300, 400), ("nsf_nb1", 150, 200)])
+def test_draws_do_not_depend_on_the_dense_order(name, M, S):
+    """The whole-catalogue call walks its dense list across the galaxies in blocks (sf_internal.h, dense_G); streams are
+    keyed by slot and attempt and a slot keeps its LOWEST accepted attempt, so the output must be bit-identical in plain
+    slot order, with the default block and with a ragged small block -- three fresh processes (the order is an
+    environment switch read once per process)."""
+    import os
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(__file__), "helpers", "order_child.py")
+    digests = []
+    for il in ("0", "128", "7"):
+        env = dict(os.environ, SF_INTERLEAVE=il)
+        r = subprocess.run([sys.executable, child, name, str(M), str(S)], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1]
+        digests.append(line)
+    assert digests[0] == digests[1] == digests[2], digests
+    assert digests[0].split()[2] == "0"   # every slot filled
