@@ -510,8 +510,14 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
   // single-slot galaxy of acceptance 1e-3 was written off after one 1 024-attempt window).
   const uint64_t S_rule = slots ? 1ull : (uint64_t)S;
   auto rule_due = [&](uint32_t att_now) { return progress_rule && (uint64_t)(att_now - acc_from) * S_rule >= 100000ull; };
-  // ---- launch 1: the persistent kernel -- first attempts and retries of every slot, attempts [0, limit)
-  {
+  // ---- the persistent kernel -- first attempts and retries of every slot, attempts [0, limit); then, while MANY slots are
+  // still open (a catalogue of 1e5 galaxies leaves tens of thousands past 1 024 attempts: its few-per-mille galaxies of
+  // acceptance ~1e-4 need ~1e4 attempts for each of their S slots), further persistent launches over the survivor list
+  // with the windows [1 024, 16 384), [16 384, 262 144) ...: the queue keeps every lane busy with speculation 64 wide
+  // at the sampler kernel's cost per evaluation.  (Chip-wide find / resolve launches, below, are for the FEW slots that
+  // remain: they spread one slot's attempts over the whole chip, on the plain fp32 kernels.)
+  const int64_t persist_min = 8192;
+  for (;;) {
     // The retry ring stays all-zero only while every launch ends cleanly (consumers clear what they take).  A launch that
     // ended on a queue error, or never completed, may have left donated entries behind: clear the ring before it is reused.
     if (f->ring_dirty) SF_HIP(hipMemsetAsync(f->d_ring, 0, f->ring_cap * sizeof(unsigned long long), st));
@@ -520,7 +526,7 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
 #ifdef SF_Q_STATS
     SF_HIP(hipMemsetAsync(&f->d_queue->stats[10], 0xff, sizeof(unsigned long long), st));  // atomicMin target
 #endif
-    if (progress_rule) SF_HIP(hipMemsetAsync(f->d_galacc, 0, (size_t)M * sizeof(int32_t), st));
+    if (progress_rule && stage == 0) SF_HIP(hipMemsetAsync(f->d_galacc, 0, (size_t)M * sizeof(int32_t), st));  // (later: carried over)
     a.slots = cur; a.slot_base = 0; a.n_items = (long)pending; a.n_total = (uint32_t)pending;
     {
       static int env_il = -1;  // developer knob: SF_INTERLEAVE=<galaxies per block>, 0 = plain slot order (A-B runs)
@@ -533,7 +539,7 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
       if (env_tc < 0) { const char* e = std::getenv("SF_TAIL_CAP"); env_tc = e ? std::atoi(e) : 0; }
       a.tail_cap = (uint32_t)env_tc;
     }
-    a.attempt = 0; a.attempt_limit = limit; a.attempts_per_slot = 1;
+    a.attempt = attempt; a.attempt_limit = limit; a.attempts_per_slot = 1;
     a.rejected = f->d_rej[buf];
     a.gal_acc = progress_rule ? f->d_galacc : nullptr;
 #ifdef SF_Q_STATS
@@ -545,10 +551,10 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
       a.qtrace = d_qtrace;
     }
 #endif
-    SF_HIP(hipEventRecord(f->ev_dense[0], st));
+    if (stage == 0) SF_HIP(hipEventRecord(f->ev_dense[0], st));  // (the reported launch time is the first window's)
     hipError_t e = sf_launch_inverse(m, a, st);
     if (e != hipSuccess) { f->ctab_x = nullptr; return hip_fail(e, "persistent sampler launch"); }
-    SF_HIP(hipEventRecord(f->ev_dense[1], st));
+    if (stage == 0) SF_HIP(hipEventRecord(f->ev_dense[1], st));
     if (limit >= 1024u && rule_due(limit)) {  // drop the open slots of galaxies that made no progress (NaN rows), in place
       SF_HIP(sf_launch_filter_survivors(f->d_rej[buf], &f->d_queue->n_surv, (long)S, f->d_galacc, out, f->L.dev.D, st));
       SF_HIP(hipMemsetAsync(f->d_galacc, 0, (size_t)M * sizeof(int32_t), st));
@@ -592,12 +598,14 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
       std::fprintf(stderr, "[sf_queue]   the same in tail mode (us): fetch %.0f, prologue %.0f, staging %.0f, passes %.0f, epilogue %.0f\n",
                    (double)q[19] * 0.01, (double)q[20] * 0.01, (double)q[21] * 0.01, (double)q[22] * 0.01, (double)q[23] * 0.01);
     }
-    rej0 = (float)f->h_queue->rej0;
+    if (stage == 0) rej0 = (float)f->h_queue->rej0;
     pending = (int64_t)f->h_queue->n_surv;
     cur = f->d_rej[buf];
     buf ^= 1;
-    stage = 1;
+    ++stage;
     attempt = limit;
+    if (pending < persist_min || attempt >= ceiling || out_of_time()) break;
+    limit = (attempt > ceiling / 16u) ? ceiling : attempt * 16u;
   }
   // ---- deep tail: the few slots that used up `limit` attempts (their galaxies accept less than ~1 draw in a
   // thousand).  One slot's attempts are now spread over the whole chip instead of over one workgroup: a FIND launch

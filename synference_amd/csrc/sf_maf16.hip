@@ -973,6 +973,165 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
   }
 }
 
+// Find / resolve launches of the deep tail (sf_api.hip: the slots that used up the persistent windows) on the sampler's OWN
+// arithmetic and cost per evaluation: the unrolled split-bf16 pass sequence of k_maf_samp16<.., DD> without the queue.
+//   find    (a.best):     item i = attempt a.attempt + (i & (A - 1)) of listed slot i >> log2 A; an accepted attempt only lowers
+//                         best[slot index] (atomic min)
+//   resolve (a.att_list): item i = attempt att_list[i] of listed slot i (0xffffffff: none): writes the draw, or lists the slot
+//                         as still open
+// A catalogue of 1e5 galaxies spends two thirds of its evaluations here (a few galaxies of acceptance ~1e-4 x 1 000 slots x
+// ~1e4 attempts); on the fp32 kernel k_maf_inv16 those ran at 0.6 of the sampler's rate.  Table path, aligned placement with
+// one degree group per tile (the shapes of the unrolled sampler); two tiles of 16 items per wave and staged transform.
+template <int NB, int DD>
+__global__ __launch_bounds__(256, 4) void k_maf_find16s(SfDev m, SfSampleArgsHost a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = lane & 15, g4 = lane >> 4;
+  float* ecb = sf_lds16 + m.t16_a_tab + m.t16B_stride;
+  if (threadIdx.x < 16) {  // per-slot constants of the epilogue (see k_maf_samp16)
+    const int p = threadIdx.x;
+    const bool on = p < m.D;
+    const int td = on ? (int)m.cst[m.c_tdim + p] : 0;
+    ecb[p * 5 + 0] = on ? m.cst[m.c_pshift + p] : 0.f;
+    ecb[p * 5 + 1] = on ? __builtin_amdgcn_rcpf(m.cst[m.c_pscale + p]) : 0.f;
+    ecb[p * 5 + 2] = (on && a.lo) ? a.lo[td] : -3.4e38f;
+    ecb[p * 5 + 3] = (on && a.lo) ? a.hi[td] : 3.4e38f;
+    reinterpret_cast<int*>(ecb)[p * 5 + 4] = td;
+  }
+  const int NT = m.nT16;
+  f32x4 u_cur, u_oth;
+  long gal_cur = 0, gal_oth = 0;
+#pragma unroll
+  for (int j = 1; j >= 0; --j) {
+    const long item = ((long)blockIdx.x * 8 + j * 4 + wave) * 16 + s;
+    const long it = item < a.n_items ? item : a.n_items - 1;
+    const long ps = it >> a.log2_attempts;
+    const uint32_t slot = a.slots ? a.slots[ps] : (uint32_t)(a.slot_base + ps);
+    const uint32_t att = a.att_list ? a.att_list[ps] : a.attempt + (uint32_t)(it & ((1L << a.log2_attempts) - 1));
+    float z4[4];
+    sf_normal4(a.k0, a.k1, (uint64_t)slot + a.rng_slot_offset, att, (uint32_t)g4, z4);
+    f32x4 u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) u[r] = (4 * g4 + r < m.D) ? z4[r] : 0.f;
+    if (j == 1) { u_oth = u; gal_oth = (long)(slot / (uint32_t)a.S); }
+    else { u_cur = u; gal_cur = (long)(slot / (uint32_t)a.S); }
+  }
+  SfPass16B S;
+  S.tab = true;
+  S.xr = nullptr;
+  for (int t = m.T - 1; t >= 0; --t) {
+    const int dsl = (int)m.cst[m.c_dslot + t * SF_DMAX + s];
+    S.c0p = m.ctab + ((size_t)gal_cur * m.T + t) * m.ctab_R;
+    sf_c0_prefetch(S, 0, g4);
+    __syncthreads();
+    {
+      const int ga = m.t16_a_tab >> 10, gb = m.t16B_stride >> 10;
+      const float4* __restrict__ sa = reinterpret_cast<const float4*>(m.packed16 + (size_t)t * m.t16_stride);
+      const float4* __restrict__ sb = reinterpret_cast<const float4*>(m.packed16B + (size_t)t * m.t16B_stride);
+      float4* __restrict__ d4 = reinterpret_cast<float4*>(sf_lds16);
+      for (int gi = __builtin_amdgcn_readfirstlane(wave); gi < ga + gb; gi += 4) {
+        const float4* g = (gi < ga ? sa + gi * 256 : sb + (gi - ga) * 256) + (threadIdx.x & 63);
+        float4* l = d4 + gi * 256;
+        __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 1024, 0);
+        __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 3072, 0);
+      }
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+    }
+    __syncthreads();
+    const float* tp = sf_lds16;
+    const unsigned int* tpB = reinterpret_cast<const unsigned int*>(sf_lds16 + m.t16_a_tab);
+#pragma unroll 1
+    for (int j = 0; j < 2; ++j) {
+      if (((long)blockIdx.x * 8 + j * 4 + wave) * 16 < a.n_items) {  // (wave-uniform: the tile holds an item)
+        if (j > 0) {
+          S.c0p = m.ctab + ((size_t)gal_cur * m.T + t) * m.ctab_R;
+          sf_c0_prefetch(S, 0, g4);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+            for (int c = 2; c < 4; ++c) { S.ph[k][pr][c] = 0u; S.pl[k][pr][c] = 0u; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S.ut[r] = 0.f;
+        S.hdone = sf_ld4(tp + m.o16_bh + g4 * 4);
+        {
+          const int sl = __builtin_amdgcn_readlane(dsl, 0);
+          const float av = tp[m.o16_hvb + 2 * sl], mv = tp[m.o16_hvb + 2 * sl + 1];
+          const float sc = (m.scale_fn == 0 ? sf_softplus(av) : sf_sigmoid(av + 2.0f)) + m.eps;
+          const float wv = sf_div(sf_slot16_own(u_cur, sl) - mv, sc);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) S.ut[r] = (g4 == (sl >> 2) && r == (sl & 3)) ? wv : S.ut[r];
+        }
+        auto seq_pass = [&](auto otc) {
+          constexpr int OT = decltype(otc)::value;
+          const int sl = __builtin_amdgcn_readlane(dsl, OT + 1);
+          sf_pass16b<OT, NB, true, true>(m, tp, tpB, S, NT, sl, sf_slot16_own(u_cur, sl), lane, g4, OT + 2 < DD ? OT + 1 : -1);
+        };
+        seq_pass(std::integral_constant<int, 0>{});
+        if constexpr (DD >= 3) seq_pass(std::integral_constant<int, 1>{});
+        if constexpr (DD >= 4) seq_pass(std::integral_constant<int, 2>{});
+        if constexpr (DD >= 5) seq_pass(std::integral_constant<int, 3>{});
+        u_cur = S.ut;
+      }
+      { const f32x4 tu = u_cur; u_cur = u_oth; u_oth = tu; }
+      { const long tg = gal_cur; gal_cur = gal_oth; gal_oth = tg; }
+    }
+  }
+#pragma unroll 1
+  for (int j = 0; j < 2; ++j) {
+    const long item = ((long)blockIdx.x * 8 + j * 4 + wave) * 16 + s;
+    const bool valid = item < a.n_items;
+    const long it = valid ? item : a.n_items - 1;
+    const long ps = it >> a.log2_attempts;
+    const uint32_t att = a.att_list ? a.att_list[ps] : a.attempt + (uint32_t)(it & ((1L << a.log2_attempts) - 1));
+    float th[4];
+    int tdc[4];
+    bool ok = true;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* e = ecb + (4 * g4 + r) * 5;
+      th[r] = (u_cur[r] - e[0]) * e[1];
+      tdc[r] = reinterpret_cast<const int*>(e)[4];
+      ok = ok && (fabsf(th[r]) <= 3.0e38f) && (th[r] >= e[2]) && (th[r] <= e[3]);
+    }
+    if (a.att_list && att == 0xffffffffu) ok = false;  // no attempt to resolve: straight to the open list
+    const unsigned long long okb = __ballot(ok);
+    const uint32_t acc16 = (uint32_t)(okb & (okb >> 16) & (okb >> 32) & (okb >> 48) & 0xffffull) & (uint32_t)(__ballot(valid) & 0xffffull);
+    const bool accepted = (acc16 >> s) & 1u;
+    if (a.best) {
+      if (accepted && g4 == 0) atomicMin(&a.best[ps], att);
+    } else if (valid) {  // resolve: one item per listed slot
+      const uint32_t slot = a.slots ? a.slots[ps] : (uint32_t)(a.slot_base + ps);
+      if (accepted) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * g4 + r < m.D) a.out[(size_t)slot * m.D + tdc[r]] = th[r];
+      } else if (g4 == 0) {
+        const uint32_t pos = atomicAdd(a.n_rejected, 1u);
+        a.rejected[pos] = slot;
+      }
+    }
+    { const f32x4 tu = u_cur; u_cur = u_oth; u_oth = tu; }
+  }
+}
+
+template <int NB, int DD>
+static hipError_t sf_launch_find16s(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
+  static SfAttrCache attr;
+  const size_t sh = ((size_t)m.t16_a_tab + (size_t)m.t16B_stride) * sizeof(float) + 80 * sizeof(float);
+  int attr_dev;
+  if (attr.need(attr_dev)) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_maf_find16s<NB, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr.set(attr_dev);
+  }
+  hipLaunchKernelGGL((k_maf_find16s<NB, DD>), dim3((unsigned)((a.n_items + 127) / 128)), dim3(256), sh, st, m, a);
+  return hipGetLastError();
+}
+
 // Parity hook of the persistent sampler's ARITHMETIC: theta = inverse(z | x) from GIVEN noise through exactly the pass
 // functions k_maf_samp16 runs (sf_pass16b / sf_pass16b_span: hidden H x H blocks as split-bf16 x3, everything else
 // fp32), so that the sampler's precision can be asserted against the fp64 oracle draw for draw, with no Philox and no
@@ -1253,6 +1412,22 @@ hipError_t sf_launch_maf_inv16(const SfDev& m, const SfSampleArgsHost& a, hipStr
     if (m.m16_span) return m.NB == 1 ? sf_launch16q_t<1, true, false>(m, a, st) : sf_launch16q_t<2, true, false>(m, a, st);
     if (sf_maf16_head_mfma(m)) return m.NB == 1 ? sf_launch16q_t<1, false, true>(m, a, st) : sf_launch16q_t<2, false, true>(m, a, st);
     return m.NB == 1 ? sf_launch16q_t<1, false, false>(m, a, st) : sf_launch16q_t<2, false, false>(m, a, st);
+  }
+  // find / resolve launches of the deep tail: the unrolled split-bf16 kernel where the sampler itself runs one
+  // (SF_FIND16S=0: the fp32 kernel, A-B runs)
+  if ((a.best || a.att_list) && !a.z_in && !a.count && m.ctab && m.packed16B && !sf_sampler_fp32_get() && sf_maf16_head_mfma(m)) {
+    static int env = -1;
+    if (env < 0) { const char* e = std::getenv("SF_FIND16S"); env = e ? std::atoi(e) : 1; }
+    const int dd = env ? sf_maf16_seq_d(m) : 0;
+    if (m.NB == 1) {
+      if (dd == 3) return sf_launch_find16s<1, 3>(m, a, st);
+      if (dd == 4) return sf_launch_find16s<1, 4>(m, a, st);
+      if (dd == 5) return sf_launch_find16s<1, 5>(m, a, st);
+    } else {
+      if (dd == 3) return sf_launch_find16s<2, 3>(m, a, st);
+      if (dd == 4) return sf_launch_find16s<2, 4>(m, a, st);
+      if (dd == 5) return sf_launch_find16s<2, 5>(m, a, st);
+    }
   }
   if (m.m16_span) return m.NB == 1 ? sf_launch16<1, true>(m, a, st) : sf_launch16<2, true>(m, a, st);
   return m.NB == 1 ? sf_launch16<1, false>(m, a, st) : sf_launch16<2, false>(m, a, st);
