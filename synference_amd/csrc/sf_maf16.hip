@@ -979,6 +979,7 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
 //                         best[slot index] (atomic min)
 //   resolve (a.att_list): item i = attempt att_list[i] of listed slot i (0xffffffff: none): writes the draw, or lists the slot
 //                         as still open
+//   count   (a.count):    item i = first attempt of slot i: += 1 per accepted draw of its galaxy (sf_flow_acceptance)
 // A catalogue of 1e5 galaxies spends two thirds of its evaluations here (a few galaxies of acceptance ~1e-4 x 1 000 slots x
 // ~1e4 attempts); on the fp32 kernel k_maf_inv16 those ran at 0.6 of the sampler's rate.  Table path, aligned placement with
 // one degree group per tile (the shapes of the unrolled sampler); two tiles of 16 items per wave and staged transform.
@@ -1103,6 +1104,14 @@ __global__ __launch_bounds__(256, 4) void k_maf_find16s(SfDev m, SfSampleArgsHos
     const bool accepted = (acc16 >> s) & 1u;
     if (a.best) {
       if (accepted && g4 == 0) atomicMin(&a.best[ps], att);
+    } else if (a.count) {  // acceptance counts (leakage correction): item = draw item % S of galaxy item / S
+      const long gal = (long)((uint32_t)(a.slots ? a.slots[ps] : (uint32_t)(a.slot_base + ps)) / (uint32_t)a.S);
+      const long g_first = __shfl(gal, 0, 64), g_last = __shfl(gal, 15, 64);
+      if (g_first == g_last) {
+        if (lane == 0 && acc16) atomicAdd(&a.count[g_first], (int)__popc(acc16));
+      } else if (accepted && g4 == 0) {
+        atomicAdd(&a.count[gal], 1);
+      }
     } else if (valid) {  // resolve: one item per listed slot
       const uint32_t slot = a.slots ? a.slots[ps] : (uint32_t)(a.slot_base + ps);
       if (accepted) {
@@ -1415,7 +1424,7 @@ hipError_t sf_launch_maf_inv16(const SfDev& m, const SfSampleArgsHost& a, hipStr
   }
   // find / resolve launches of the deep tail: the unrolled split-bf16 kernel where the sampler itself runs one
   // (SF_FIND16S=0: the fp32 kernel, A-B runs)
-  if ((a.best || a.att_list) && !a.z_in && !a.count && m.ctab && m.packed16B && !sf_sampler_fp32_get() && sf_maf16_head_mfma(m)) {
+  if ((a.best || a.att_list || a.count) && !a.z_in && m.ctab && m.packed16B && !sf_sampler_fp32_get() && sf_maf16_head_mfma(m)) {
     static int env = -1;
     if (env < 0) { const char* e = std::getenv("SF_FIND16S"); env = e ? std::atoi(e) : 1; }
     const int dd = env ? sf_maf16_seq_d(m) : 0;
