@@ -105,6 +105,8 @@ def parse():
     ap.add_argument("--hidden-bf16", action="store_true",
                     help="opt-in bf16 MFMA operands for the hidden HxH layers of the sampler (BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-large-catalogue", action="store_true",
+                    help="leave out the configs[4]-sized sampling leg (1e5 galaxies x 1000 draws, N = 1 only)")
     ap.add_argument("--skip-throughput-regime", action="store_true",
                     help="leave out the 8 x batch training launches (profiling runs: they share the bench batch's grid size)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the sampling leg of the CPU baseline")
@@ -611,6 +613,32 @@ def main():
         "log_prob": {"value": lp_rows, "unit": "rows/s", "rows_per_call": int(Xl.shape[0]),
                      "achieved_tflops": lp_rows * wl["f_lp"] / 1e12},
     }
+    # ---------------- BASELINE configs[4] on one GPU: 1e5 galaxies x 1000 draws through the same call (its own catalogue; the
+    # few galaxies of acceptance ~1e-4 that a catalogue of this size holds put two thirds of the evaluations into the
+    # find / resolve launches of the deep tail -- DESIGN.md section 3)
+    if (world == 1 and a.workload == "maf_cfg2" and not a.skip_large_catalogue and not a.galaxies and not a.hidden_bf16
+            and torch.cuda.get_device_properties(dev).total_memory > 16 << 30):
+        nbig = 100000
+        xb, _, _ = make_catalogue(nbig, C, D, seed=97531)
+        Xb = torch.as_tensor(xb).to(dev)
+        outb = torch.empty((nbig, S, D), dtype=torch.float32, device=dev)
+        flow.sample(Xb, S, lo, hi, seed=5, out=outb)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        nrep, unfb, evb, kb = 2, 0, 0.0, []
+        for k in range(nrep):
+            flow.sample(Xb, S, lo, hi, seed=2000 + k, out=outb)
+            unfb += flow.last_unfilled
+            evb += flow.last_sample_stats["evaluations"]
+            kb.append(flow.last_sample_stats["dense_ms"])
+        torch.cuda.synchronize(dev)
+        tb = (time.perf_counter() - t0) / nrep
+        rec["large_catalogue"] = {"workload": "BASELINE configs[4] shape on one GPU: 100000 galaxies x %d draws, same flow" % S,
+                                  "value": (nbig * S - unfb / nrep) / tb, "unit": "samples/s", "ms_per_step": 1e3 * tb,
+                                  "persistent_launch_ms": float(np.mean(kb)), "flow_evaluations_per_step": evb / nrep,
+                                  "unfilled_slots": unfb, "steps": nrep}
+        del outb, Xb
+        note(f"large catalogue: {1e3 * tb:.1f} ms per 1e8 draws")
     note("GPU legs done; CPU baseline (about 30 s)" if world == 1 and not a.no_cpu_baseline else "GPU legs done")
     if world == 1 and not a.no_cpu_baseline:
         rec["cpu_baseline"] = cpu_baseline(est.spec, flat.cpu().numpy(), x_test, th_test, prior.low.numpy(),
