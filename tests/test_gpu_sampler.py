@@ -158,3 +158,24 @@ def test_deep_tail_slots_beyond_the_first_window_match_the_oracle(name, q):
     err = np.abs((got - ref) / (hi - lo).astype(np.float64)).max(-1)
     assert (err > 5e-4).mean() < 0.1, ((err > 5e-4).mean(), err.max())
     assert np.abs(nd - rnd).sum() <= 0.1 * rnd.sum()
+
+
+def test_deep_tail_find_and_resolve_launches_equal_the_oracle_draw_for_draw():
+    """A box so tight (acceptance ~ 2e-3) that most slots use up the persistent launch's 1 024 attempts: they are filled
+    by the find / resolve launches of the deep tail (k_maf_find16s on this shape: the sampler's own split-bf16
+    arithmetic) and must still be the oracle's draws -- the LOWEST accepted attempt of every slot."""
+    ospec, spec, flat, theta, x = make_case("maf_cfg1", B=2, spread=0.2)
+    lo, hi = _quantile_box(ospec, flat, x, 0.36, 0.64, n=2000)
+    S, seed = 24, 5
+    f = _flow(spec, flat)
+    got, nd = f.sample(x, S, lo, hi, seed=seed, return_counts=True)
+    got, nd = got.cpu().double().numpy(), nd.cpu().numpy()
+    assert f.last_unfilled == 0 and np.isfinite(got).all()
+    assert f.last_sample_stats["rounds"] >= 3               # persistent launch + at least one find / resolve pair
+    ref, rnd = OP.sample(ospec, torch.as_tensor(flat), x, S, seed, lo, hi, dtype=torch.float32)
+    acc = S * len(x) / rnd.sum()
+    assert acc < 5e-3, acc
+    assert (rnd > 1024 * S * 0.5).any()                     # a galaxy whose slots mostly went past the first window
+    err = np.abs((got - ref) / (hi - lo).astype(np.float64)).max(-1)
+    assert (err > 5e-4).mean() <= 0.05, ((err > 5e-4).mean(), err.max())   # boundary accept/reject flips only
+    assert np.abs(nd - rnd).sum() <= 0.08 * rnd.sum()
