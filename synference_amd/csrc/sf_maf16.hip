@@ -739,10 +739,12 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
       }
     }
     uint32_t tile_bits = 0, lo_bits = 0;  // g16_tile / g16_lo packed 2 bits per degree
+    if constexpr (DD == 0) {                // (the unrolled kernels know the tile of every pass: p - 2)
 #pragma unroll
-    for (int q = 0; q < SF_DMAX; ++q) {
-      tile_bits |= (uint32_t)(m.g16_tile[q] & 3) << (2 * q);
-      lo_bits |= (uint32_t)(m.g16_lo[q] & 3) << (2 * q);
+      for (int q = 0; q < SF_DMAX; ++q) {
+        tile_bits |= (uint32_t)(m.g16_tile[q] & 3) << (2 * q);
+        lo_bits |= (uint32_t)(m.g16_lo[q] & 3) << (2 * q);
+      }
     }
     SfPass16B S;
     S.tab = m.ctab != nullptr;
