@@ -23,6 +23,8 @@ CASES = {
     "maf_span6": ("maf", 6, 10, 50, 3, 10),    # 5 groups of 10 in 4 tiles
     "maf_span_h64": ("maf", 8, 12, 64, 2, 10), # the example CLI width: 7 groups of 9-10
     "maf_d2_span": ("maf", 2, 4, 40, 2, 10),   # one group of 40 units over 3 tiles
+    "maf_d4": ("maf", 4, 6, 40, 3, 10),        # 3 groups of 13-14, one per tile: the unrolled sampler kernel with DD = 4
+    "maf_d3": ("maf", 3, 5, 26, 3, 10),        # 2 groups of 13, one per tile: DD = 3
 }
 
 

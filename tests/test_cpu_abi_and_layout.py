@@ -66,7 +66,7 @@ def test_packer_plus_wave_model_reproduce_oracle(name):
     assert np.abs(got - ref).max() < 5e-6
 
 
-@pytest.mark.parametrize("name", ["maf_cfg1", "maf_small", "maf_sig2", "maf_span6", "maf_span_h64", "maf_d2_span"])
+@pytest.mark.parametrize("name", ["maf_cfg1", "maf_small", "maf_sig2", "maf_span6", "maf_span_h64", "maf_d2_span", "maf_d4", "maf_d3"])
 def test_16_row_image_plus_wave_model_reproduce_the_oracle_inverse(name):
     """sf_layout.cpp's image for the 16-row sampler (degree groups packed into 16-row tiles, per-tile weight
     fragments of v_mfma_f32_16x16x4_f32, head rows for the per-lane dot product) drives a numpy model of

@@ -53,7 +53,7 @@ def test_inverse_from_noise_matches_oracle(name):
     assert np.abs(lp - ref).max() < 5e-4, np.abs(lp - ref).max()
 
 
-@pytest.mark.parametrize("name", ["maf_cfg1", "maf_span6", "maf_span_h64", "nsf_cfg3", "nsf_odd", "nsf_k16"])
+@pytest.mark.parametrize("name", ["maf_cfg1", "maf_span6", "maf_span_h64", "maf_d4", "maf_d3", "nsf_cfg3", "nsf_odd", "nsf_k16"])
 def test_sampler_arithmetic_from_given_noise(name):
     """The persistent sampler evaluates the hidden H x H blocks as split-bf16 x3 products (fp32 accumulation).  Its pass
     functions, fed GIVEN noise (sf_flow_inverse_from_noise_sampler), must meet the fp64 oracle within 1e-4 of the
@@ -87,7 +87,7 @@ def test_tiny_and_empty_batches():
     assert f.log_prob(theta[:0], x[:0]).numel() == 0
 
 
-@pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "nsf_odd", "maf_span6", "maf_d2_span"])
+@pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "nsf_odd", "maf_span6", "maf_d2_span", "maf_d4", "maf_d3", "maf_sig2"])
 def test_sampler_matches_oracle_draw_for_draw(name):
     ospec, spec, flat, theta, x = make_case(name, B=6, spread=0.2)
     S, seed = 257, 2025
