@@ -641,6 +641,29 @@ struct SfSamp16Args {
 // TWO tiles of 16 draws through each staged transform, one after the other -- the queue fetch, the image copy and their
 // barriers are paid once per 128 draws instead of once per 64 (together ~20 % of a workgroup's time at TPW = 1); between
 // transforms a tile is just its 4 registers of u and its galaxy index.
+// Offsets of the 16-row sampler image for the shapes of the unrolled kernels (D = DD, DD - 1 hidden tiles of one degree
+// group each, NB blocks), as sf_layout.cpp emits them: compile-time constants in those kernels (LDS reads with immediate
+// offsets, no descriptor loads inside a pass); the host checks them against the packer's before it picks such a kernel.
+template <int NB, int DD>
+struct SfFix16 {
+  static constexpr int NT = DD - 1;
+  static constexpr int o_w0 = 0, o_b0 = NT * 256, o_bk0 = o_b0 + NT * 16, o_bk1 = o_bk0 + NT * 16;
+  static constexpr int o_hv = o_b0 + NT * 16 * (1 + NB), o_hvb = o_hv + DD * 128;
+  static constexpr int o_wh = (o_hvb + 2 * DD + 3) / 4 * 4, o_bh = o_wh + NT * 256;
+  static constexpr int a_tab = (o_bh + 16 + 1023) / 1024 * 1024;
+  static constexpr int entries = NT == 4 ? 6 : (NT == 3 ? 4 : 2);   // (ot, pair) fragments a block keeps: sum of ot / 2 + 1
+  static constexpr int oB_wk1 = entries * 512, B_stride = (NB * entries * 512 + 1023) / 1024 * 1024;
+  static bool matches(const SfDev& m) {
+    return m.nT16 == NT && m.o16_w0 == o_w0 && m.o16_b0 == o_b0 && m.o16_bk[0] == o_bk0 && (NB < 2 || m.o16_bk[1] == o_bk1) &&
+           m.o16_hv == o_hv && m.o16_hvb == o_hvb && m.o16_wh == o_wh && m.o16_bh == o_bh && m.t16_a_tab == a_tab &&
+           m.o16B_wk[0] == 0 && (NB < 2 || m.o16B_wk[1] == oB_wk1) && m.t16B_stride == B_stride;
+  }
+  static __device__ __forceinline__ void apply(SfDev& m) {
+    m.nT16 = NT; m.o16_w0 = o_w0; m.o16_b0 = o_b0; m.o16_bk[0] = o_bk0; m.o16_bk[1] = o_bk1; m.o16_hv = o_hv; m.o16_hvb = o_hvb;
+    m.o16_wh = o_wh; m.o16_bh = o_bh; m.t16_a_tab = a_tab; m.o16B_wk[0] = 0; m.o16B_wk[1] = oB_wk1; m.t16B_stride = B_stride;
+  }
+};
+
 // DD > 0 (HM, aligned placement with ONE degree group per tile, D == DD <= 5): the passes of a transform are unrolled
 // with the tile of each known at compile time (pass p works on tile p - 2) -- no dispatch, and the per-tile state is
 // updated in place instead of being copied into the registers every arm of the switch has to agree on.
@@ -681,7 +704,10 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
       asm volatile("" : "+s"(kp));
       ap = (const SfSamp16Args*)kp;
     }
-    const SfDev& m = ap->m;
+    const SfDev& m_arg = ap->m;
+    SfDev m_fix;  // (DD > 0: the descriptor with the image offsets replaced by their compile-time values)
+    if constexpr (DD > 0) { m_fix = m_arg; SfFix16<NB, DD>::apply(m_fix); }
+    const SfDev& m = DD > 0 ? m_fix : m_arg;
     const SfSampleArgsHost& a = ap->a;
     const int lane = (threadIdx.x & 63) + sf_opaque_zero();  // lane-derived addresses are recomputed per iteration
     const int s = lane & 15, g4 = lane >> 4;
@@ -987,6 +1013,7 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
 // one degree group per tile (the shapes of the unrolled sampler); two tiles of 16 items per wave and staged transform.
 template <int NB, int DD>
 __global__ __launch_bounds__(256, 4) void k_maf_find16s(SfDev m, SfSampleArgsHost a) {
+  SfFix16<NB, DD>::apply(m);  // (the launcher only picks this kernel when the packer's offsets are these)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int s = lane & 15, g4 = lane >> 4;
   float* ecb = sf_lds16 + m.t16_a_tab + m.t16B_stride;
@@ -1403,7 +1430,10 @@ static int sf_maf16_seq_d(const SfDev& m) {
   if (!env || m.m16_span || m.D < 3 || m.D > 5 || m.nT16 != m.D - 1) return 0;
   for (int p = 2; p <= m.D; ++p)
     if (m.g16_tile[p - 1] != p - 2) return 0;
-  return m.D;
+  bool fits = false;  // the image offsets the unrolled kernels hard-wire
+  if (m.NB == 1) fits = m.D == 3 ? SfFix16<1, 3>::matches(m) : (m.D == 4 ? SfFix16<1, 4>::matches(m) : SfFix16<1, 5>::matches(m));
+  else if (m.NB == 2) fits = m.D == 3 ? SfFix16<2, 3>::matches(m) : (m.D == 4 ? SfFix16<2, 4>::matches(m) : SfFix16<2, 5>::matches(m));
+  return fits ? m.D : 0;
 }
 template <int NB, bool SPAN, bool HM>
 static hipError_t sf_launch16q_t(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
