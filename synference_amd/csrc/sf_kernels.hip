@@ -17,6 +17,7 @@ __global__ void k_pack(const float* __restrict__ flat, const int32_t* __restrict
   float v = 0.f;
   if (a >= 0) v = flat[a];
   if (b >= 0) v += flat[b];
+  else if (b == SF_PACK_TANH_SCALE) v *= SF_TANH_PRESCALE;
   packed[i] = v;
 }
 
@@ -38,7 +39,7 @@ __global__ void k_pack_bf16_split(const float* __restrict__ flat, const int32_t*
   const int a = src[i];
   unsigned short r = 0;
   if (a >= 0) {
-    const float w = flat[a & 0x3fffffff];
+    const float w = flat[a & SF_PACK_SPLIT_INDEX] * ((a & SF_PACK_SPLIT_SCALED) ? SF_TANH_PRESCALE : 1.0f);
     const __bf16 hi = (__bf16)w;
     r = __builtin_bit_cast(unsigned short, (a >> 30) & 1 ? (__bf16)(w - (float)hi) : hi);
   }

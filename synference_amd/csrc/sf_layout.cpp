@@ -404,14 +404,18 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
         if (t == 1) v.t16_stride = (int)tb16;
         auto here = [&]() { return (int)((int64_t)L.src16a.size() - tb16); };
         // weight block [ot][it][64 lanes][4]: lane l: out row ot*16+(l&15), in rows it*16 + 4*(l>>4) + r
+        // second index SF_PACK_TANH_SCALE (-2): the packed value is multiplied by 2 log2(e) -- the hidden blocks' weights and
+        // biases of the 16-row images carry the factor of tanh(x) = 1 - 2 / (1 + 2^(2 log2(e) x)), so that the kernels'
+        // tanh starts at the exp2 (the kernel is bound by vector issue: one multiply per activation less)
         auto linear16 = [&](int OT, int IT, const std::vector<int>& orow, const std::vector<int>& irow, int64_t base,
-                            int in_dim, const std::function<bool(int, int)>& mask) {
+                            int in_dim, const std::function<bool(int, int)>& mask, int32_t second = -1) {
           for (int ot = 0; ot < OT; ++ot)
             for (int it = 0; it < IT; ++it)
               for (int l = 0; l < 64; ++l)
                 for (int r = 0; r < 4; ++r) {
                   const int oo = orow[ot * 16 + (l & 15)], ii = irow[it * 16 + 4 * (l >> 4) + r];
-                  push16((oo >= 0 && ii >= 0 && (!mask || mask(oo, ii))) ? (int32_t)(base + (int64_t)oo * in_dim + ii) : -1, -1);
+                  const bool on = oo >= 0 && ii >= 0 && (!mask || mask(oo, ii));
+                  push16(on ? (int32_t)(base + (int64_t)oo * in_dim + ii) : -1, on ? second : -1);
                 }
         };
         auto bias16 = [&](int OT, const std::vector<int>& orow, int64_t b1, int64_t b2) {
@@ -419,7 +423,8 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
             for (int g4 = 0; g4 < 4; ++g4)
               for (int r = 0; r < 4; ++r) {
                 const int oo = orow[ot * 16 + 4 * g4 + r];
-                push16(oo >= 0 ? (int32_t)(b1 + oo) : -1, (oo >= 0 && b2 >= 0) ? (int32_t)(b2 + oo) : -1);
+                push16(oo >= 0 ? (int32_t)(b1 + oo) : -1,
+                       oo < 0 ? -1 : (b2 >= 0 ? (int32_t)(b2 + oo) : (b2 == SF_PACK_TANH_SCALE ? SF_PACK_TANH_SCALE : -1)));
               }
         };
         std::vector<int> u16(16, -1);
@@ -433,7 +438,7 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
         bias16(NT, h16row, lb0, lbc);
         for (int k = 0; k < NB && k < 2; ++k) {
           if (t == 0) v.o16_bk[k] = here();
-          bias16(NT, h16row, lbk[k], -1);
+          bias16(NT, h16row, lbk[k], SF_PACK_TANH_SCALE);
         }
         // head rows for the per-lane dot product: [slot][g4][tile (4)][r][a|m]  (a and m interleaved: one packed
         // v_pk_fma_f32 updates both partial sums)
@@ -475,7 +480,7 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
         // part B: the hidden blocks in fp32 (k_maf_inv16: parity hook, acceptance counts, explicit rounds)
         for (int k = 0; k < NB && k < 2; ++k) {
           if (t == 0) v.o16_wk[k] = here();
-          linear16(NT, NT, h16row, h16row, lWk[k], H, [&](int j, int i) { return deg_h(j) >= deg_h(i); });
+          linear16(NT, NT, h16row, h16row, lWk[k], H, [&](int j, int i) { return deg_h(j) >= deg_h(i); }, SF_PACK_TANH_SCALE);
         }
         // ---- split-bf16 image of the hidden blocks (k_maf_samp16): per block [ot][pair][hi|lo][64 lanes][8 bf16];
         // element j of lane l is W[out row ot*16 + (l&15)][in row 16*(2*pair + (j>>2)) + 4*(l>>4) + (j&3)] -- the k order
@@ -503,7 +508,7 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
                       const int oo = h16row[ot * 16 + (l & 15)];
                       const int ii = it < NT ? h16row[it * 16 + 4 * (l >> 4) + (j & 3)] : -1;
                       const bool on = oo >= 0 && ii >= 0 && deg_h(oo) >= deg_h(ii);
-                      L.src16B.push_back(on ? (int32_t)((lWk[k] + (int64_t)oo * H + ii) | ((int64_t)part << 30)) : -1);
+                      L.src16B.push_back(on ? (int32_t)((lWk[k] + (int64_t)oo * H + ii) | ((int64_t)part << 30) | SF_PACK_SPLIT_SCALED) : -1);
                     }
               }
           }

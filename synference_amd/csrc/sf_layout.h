@@ -95,6 +95,14 @@ struct SfDev {
   float tail_bound, min_w, min_h, min_d, eps, lu_eps, inv_sqrt_h, deriv_const;
 };
 
+// pack-table flags of the 16-row MAF images (sf_layout.cpp; applied by k_pack / k_pack_bf16_split / k_train_prep):
+//   second index of an fp32 entry == SF_PACK_TANH_SCALE: value x 2 log2(e)
+//   bit 29 of a split-bf16 entry (SF_PACK_SPLIT_SCALED): the weight is multiplied by 2 log2(e) before it is split
+#define SF_PACK_TANH_SCALE (-2)
+#define SF_PACK_SPLIT_SCALED (1 << 29)
+#define SF_PACK_SPLIT_INDEX 0x1fffffff
+#define SF_TANH_PRESCALE 2.8853900817779268f
+
 // ---- cooperative 16-row training image (sf_trainc.hip; MAF, num_blocks = 2, D <= 8, <= 4 hidden tiles of 16 rows) ----
 // One workgroup = 8 waves = 64 samples; wave (grp, j) owns hidden tile j (grp 0) / NT-1-j (grp 1) of its group's 32
 // samples, the waves exchange activation tiles through LDS at every layer.  Tile = 16 rows x 16 samples in 4 VGPRs

@@ -48,14 +48,18 @@ __device__ __forceinline__ f32x4 sf_ld4(const float* p) {
   r[0] = b.x; r[1] = b.y; r[2] = b.z; r[3] = b.w;
   return r;
 }
-// tanh of a tile's four values with the plain arithmetic on packed-f32 instructions (v_pk_mul / v_pk_add / v_pk_fma: two
+// tanh of a tile's four values with the plain arithmetic on packed-f32 instructions (v_pk_add / v_pk_fma: two
 // values per instruction at the full rate) -- the kernel is bound by vector ISSUE, and the four exp2 / four rcp cannot be
-// packed.  Same operations per value as sf_tanh, so the same results.
+// packed.
+// The argument is PRE-SCALED: the packer multiplies the hidden blocks' weights and biases of the 16-row images by
+// 2 log2(e) (SF_PACK_TANH_SCALE, sf_layout.h), so tanh(x) = 1 - 2 / (1 + 2^b) with b = 2 log2(e) x starts at the exp2.
+__device__ __forceinline__ float sf_tanh_pre(float b) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(b));
+}
 __device__ __forceinline__ f32x4 sf_tanh4(const f32x4& b) {
-  const f32x2 c = {2.8853900817779268f, 2.8853900817779268f}, one = {1.0f, 1.0f}, m2 = {-2.0f, -2.0f};
-  const f32x2 t01 = f32x2{b[0], b[1]} * c, t23 = f32x2{b[2], b[3]} * c;
-  const f32x2 e01 = f32x2{__builtin_amdgcn_exp2f(t01[0]), __builtin_amdgcn_exp2f(t01[1])} + one;
-  const f32x2 e23 = f32x2{__builtin_amdgcn_exp2f(t23[0]), __builtin_amdgcn_exp2f(t23[1])} + one;
+  const f32x2 one = {1.0f, 1.0f}, m2 = {-2.0f, -2.0f};
+  const f32x2 e01 = f32x2{__builtin_amdgcn_exp2f(b[0]), __builtin_amdgcn_exp2f(b[1])} + one;
+  const f32x2 e23 = f32x2{__builtin_amdgcn_exp2f(b[2]), __builtin_amdgcn_exp2f(b[3])} + one;
   const f32x2 r01 = {__builtin_amdgcn_rcpf(e01[0]), __builtin_amdgcn_rcpf(e01[1])};
   const f32x2 r23 = {__builtin_amdgcn_rcpf(e23[0]), __builtin_amdgcn_rcpf(e23[1])};
   const f32x2 o01 = __builtin_elementwise_fma(r01, m2, one), o23 = __builtin_elementwise_fma(r23, m2, one);
@@ -111,7 +115,7 @@ __device__ __forceinline__ void sf_pass16(const SfDev& m, const float* tp, SfPas
   for (int k = 0; k < NB; ++k) {
     const f32x4 b = sf_mma16(wk[k][OT], S.act[k][OT], bk[k]);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) S.act[k + 1][OT][r] = sf_tanh(b[r]);
+    for (int r = 0; r < 4; ++r) S.act[k + 1][OT][r] = sf_tanh_pre(b[r]);
   }
   pam = sf_head_acc(pam, h01[OT], h23[OT], S.act[NB][OT]);
   const float av = ba + sf_sum4groups(pam[0]);
@@ -141,7 +145,7 @@ __device__ __forceinline__ void sf_pass16_span(const SfDev& m, const float* tp, 
 #pragma unroll
       for (int it = 0; it <= HI; ++it) b = sf_mma16(sf_w16(tp + m.o16_wk[k], NT, ot, it, lane), S.act[k][it], b);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) S.act[k + 1][ot][r] = sf_tanh(b[r]);
+      for (int r = 0; r < 4; ++r) S.act[k + 1][ot][r] = sf_tanh_pre(b[r]);
     }
   }
   f32x2 pam = {0.f, 0.f};
@@ -549,7 +553,7 @@ __device__ __forceinline__ void sf_pass16b(const SfDev& m, const float* tp, cons
                      S.ph[k][pr], S.pl[k][pr], b);
     f32x4 th;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) th[r] = sf_tanh(b[r]);
+    for (int r = 0; r < 4; ++r) th[r] = sf_tanh_pre(b[r]);
     if (k + 1 < NB) sf_put16b<OT>(S, k + 1, th);
     else S.head[OT] = th;
   }
@@ -602,7 +606,7 @@ __device__ __forceinline__ void sf_pass16b_span(const SfDev& m, const float* tp,
         b = sf_mma16x3(sf_w16b<false>(tpB + m.o16B_wk[k], NP, ot, pr, 0, lane), sf_w16b<false>(tpB + m.o16B_wk[k], NP, ot, pr, 1, lane),
                        S.ph[k][pr], S.pl[k][pr], b);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) nb[ot - LO][r] = sf_tanh(b[r]);
+      for (int r = 0; r < 4; ++r) nb[ot - LO][r] = sf_tanh_pre(b[r]);
     }
 #pragma unroll
     for (int ot = LO; ot <= HI; ++ot) {

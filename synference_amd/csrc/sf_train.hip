@@ -190,6 +190,7 @@ __global__ void k_train_prep(const float* __restrict__ flat, const int32_t* __re
     float v = 0.f;
     if (a >= 0) v = flat[a];
     if (b >= 0) v += flat[b];
+    else if (b == SF_PACK_TANH_SCALE) v *= SF_TANH_PRESCALE;
     packed16[i] = v;
     return;
   }
@@ -198,7 +199,7 @@ __global__ void k_train_prep(const float* __restrict__ flat, const int32_t* __re
     const int a = sB[i];
     unsigned short r = 0;
     if (a >= 0) {
-      const float w = flat[a & 0x3fffffff];
+      const float w = flat[a & SF_PACK_SPLIT_INDEX] * ((a & SF_PACK_SPLIT_SCALED) ? SF_TANH_PRESCALE : 1.0f);
       const __bf16 hi = (__bf16)w;
       r = __builtin_bit_cast(unsigned short, (a >> 30) & 1 ? (__bf16)(w - (float)hi) : hi);
     }

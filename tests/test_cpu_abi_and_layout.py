@@ -157,9 +157,10 @@ def test_split_bf16_table_of_the_16_row_sampler_reconstructs_the_masked_hidden_w
         pytest.skip("no 16-row image for this shape")
     tab = hf.pack_table16b()
     assert len(tab) == 2 * d["t16B_stride"] * d["T"] and d["t16B_stride"] % 1024 == 0 and d["t16_a"] % 1024 == 0
-    idx, part = tab & 0x3FFFFFFF, (tab >> 30) & 1
+    idx, part = tab & 0x1FFFFFFF, (tab >> 30) & 1
     on = tab >= 0
-    w = np.where(on, np.asarray(flat, np.float32)[np.where(on, idx, 0)], np.float32(0))
+    assert (((tab >> 29) & 1) == 1)[on].all()      # MAF hidden blocks: every entry carries the tanh pre-scale flag
+    w = np.where(on, np.asarray(flat, np.float32)[np.where(on, idx, 0)] * np.float32(ws.TANH_PRESCALE), np.float32(0))
 
     def bf16(v):  # round to nearest even
         u = np.asarray(v, np.float32).view(np.uint32).astype(np.uint64)
@@ -184,8 +185,8 @@ def test_split_bf16_table_of_the_16_row_sampler_reconstructs_the_masked_hidden_w
             rec = blk[:, 0].astype(np.float64) + blk[:, 1].astype(np.float64)
             shape, off = lay[f"t{t}.W{k + 1}"]
             W = np.asarray(flat, np.float64)[off: off + spec.H * spec.H].reshape(spec.H, spec.H)
-            ref = np.where(ob[:, 0], np.asarray(flat, np.float64)[np.where(ob[:, 0], ib[:, 0], 0)], 0.0)
-            assert np.abs(rec - ref).max() <= 2.0 ** -16 * max(np.abs(W).max(), 1e-30)
+            ref = np.where(ob[:, 0], np.asarray(flat, np.float32)[np.where(ob[:, 0], ib[:, 0], 0)] * np.float32(ws.TANH_PRESCALE), 0.0)
+            assert np.abs(rec - ref).max() <= 2.0 ** -16 * ws.TANH_PRESCALE * max(np.abs(W).max(), 1e-30)
             # the block holds exactly the unmasked entries of W_k, each once (so dropping the unreadable pairs lost nothing)
             used = np.unique(ib[:, 0][ob[:, 0]]) - off
             assert len(used) == int(Mh.sum()) and np.array_equal(np.sort(used), np.flatnonzero(Mh.reshape(-1)))

@@ -218,9 +218,16 @@ def nsf_logprob(d, packed, theta32, x32):
     return lp[:32]
 
 
+TANH_PRESCALE = float(np.float32(2.8853900817779268))   # SF_TANH_PRESCALE (sf_layout.h)
+
+
 def pack(flat, s1, s2):
+    """The pack kernels' rule (k_pack): flat[s1] + flat[s2], -1 = nothing; second index -2 (SF_PACK_TANH_SCALE: hidden
+    blocks of the 16-row MAF images) = the value times 2 log2(e)."""
     f = np.concatenate([np.asarray(flat, dtype=np.float64), [0.0]])
-    return f[s1] + f[s2]  # index -1 hits the appended zero
+    s2 = np.asarray(s2)
+    v = f[s1] + f[np.where(s2 == -2, -1, s2)]  # index -1 hits the appended zero
+    return np.where(s2 == -2, v * TANH_PRESCALE, v)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -302,7 +309,7 @@ def maf_inverse16(d, packed, z16, x16, head_mfma=False):
                             b[r] = packed[tp + d[f"o16_bk{k}"] + (ot * 4 + G4) * 4 + r]
                         for it in range(hi + 1):
                             mma16(packed, tp + d[f"o16_wk{k}"], NT, ot, it, act[k, it], b)
-                        new[ot] = np.tanh(b)
+                        new[ot] = np.tanh(b / TANH_PRESCALE)   # (weights and biases of the hidden blocks are packed pre-scaled)
                     for ot, v in new.items():
                         act[k + 1, ot] = v
                 if head_mfma:
