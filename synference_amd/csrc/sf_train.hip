@@ -61,23 +61,30 @@ __global__ __launch_bounds__(1024) void k_adam_fused(float* __restrict__ p, cons
                                                     float* __restrict__ v, float* __restrict__ sq_out, long n,
                                                     sf_adam_desc d, float bc1, float bc2, float max_norm,
                                                     float* __restrict__ norm_out) {
+  // Everything this thread will need is requested before anything is waited for: its own elements of p / m / v / g (one
+  // float4 each for n <= 4096 x blocks: the common case) AND its eight float4 of the gradient for the norm -- the kernel
+  // is a chain of L2 round trips (32 k parameters: 12 us when the norm took two trips and the update a third).
+  const long n4 = n >> 2;
+  const float4* __restrict__ g4 = reinterpret_cast<const float4*>(g);
+  const long own = (long)blockIdx.x * blockDim.x + threadIdx.x;  // first float4 this thread updates (n % 4 == 0 path)
+  const bool vec = (n & 3) == 0 && (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+  const bool has_own = vec && own < n4;
+  float4 po, mo, vo, go;
+  if (has_own) {
+    po = reinterpret_cast<const float4*>(p)[own]; mo = reinterpret_cast<const float4*>(m)[own];
+    vo = reinterpret_cast<const float4*>(v)[own]; go = g4[own];
+  }
   float s = 0.f;
   {
-    // 1024 threads x float4, 4 loads in flight: the whole vector in <= 8 trips
-    const float4* __restrict__ g4 = reinterpret_cast<const float4*>(g);
-    const long n4 = n >> 2;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    for (long i = threadIdx.x; i < n4; i += 4 * 1024) {
-      const float4 a = g4[i];
-      const float4 b = i + 1024 < n4 ? g4[i + 1024] : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 c = i + 2048 < n4 ? g4[i + 2048] : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 e = i + 3072 < n4 ? g4[i + 3072] : make_float4(0.f, 0.f, 0.f, 0.f);
-      s0 += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
-      s1 += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
-      s2 += c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
-      s3 += e.x * e.x + e.y * e.y + e.z * e.z + e.w * e.w;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long i = threadIdx.x; i < n4; i += 8 * 1024) {
+      float4 q[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) q[k] = i + k * 1024 < n4 ? g4[i + k * 1024] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += q[k].x * q[k].x + q[k].y * q[k].y + q[k].z * q[k].z + q[k].w * q[k].w;
     }
-    s = (s0 + s1) + (s2 + s3);
+    s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     for (long i = (n4 << 2) + threadIdx.x; i < n; i += 1024) s += g[i] * g[i];
   }
 #pragma unroll
@@ -97,17 +104,34 @@ __global__ __launch_bounds__(1024) void k_adam_fused(float* __restrict__ p, cons
   }
   const float step_size = d.lr / bc1;
   const float inv_sqrt_bc2 = rsqrtf(bc2);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float pi = p[i];
-    float gi = g[i] * coef;
+  auto upd = [&](float& pi, float& mi, float& vi, float gi_raw) {
+    float gi = gi_raw * coef;
     if (d.decoupled) pi *= (1.f - d.lr * d.weight_decay);
     else if (d.weight_decay != 0.f) gi += d.weight_decay * pi;
-    const float mi = d.beta1 * m[i] + (1.f - d.beta1) * gi;
-    const float vi = d.beta2 * v[i] + (1.f - d.beta2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
+    mi = d.beta1 * mi + (1.f - d.beta1) * gi;
+    vi = d.beta2 * vi + (1.f - d.beta2) * gi * gi;
     const float denom = sqrtf(vi) * inv_sqrt_bc2 + d.eps;
-    p[i] = pi - step_size * (mi / denom);
+    pi = pi - step_size * (mi / denom);
+  };
+  if (vec) {
+    if (has_own) {
+      upd(po.x, mo.x, vo.x, go.x); upd(po.y, mo.y, vo.y, go.y); upd(po.z, mo.z, vo.z, go.z); upd(po.w, mo.w, vo.w, go.w);
+      reinterpret_cast<float4*>(p)[own] = po; reinterpret_cast<float4*>(m)[own] = mo; reinterpret_cast<float4*>(v)[own] = vo;
+    }
+    // (more float4 than threads: the rest in a strided loop)
+    for (long i = own + (long)gridDim.x * blockDim.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+      float4 pp = reinterpret_cast<const float4*>(p)[i], mm = reinterpret_cast<const float4*>(m)[i];
+      float4 vv = reinterpret_cast<const float4*>(v)[i];
+      const float4 gg = g4[i];
+      upd(pp.x, mm.x, vv.x, gg.x); upd(pp.y, mm.y, vv.y, gg.y); upd(pp.z, mm.z, vv.z, gg.z); upd(pp.w, mm.w, vv.w, gg.w);
+      reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+    }
+  } else {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+      float pi = p[i], mi = m[i], vi = v[i];
+      upd(pi, mi, vi, g[i]);
+      p[i] = pi; m[i] = mi; v[i] = vi;
+    }
   }
 }
 
