@@ -141,6 +141,9 @@ struct sf_flow {
   // cooperative 16-row training path (sf_trainc.hip): operand image, its gather table, gradient partials
   float* d_imgC = nullptr;
   int32_t *d_sC1 = nullptr, *d_sC2 = nullptr, *d_gdstC = nullptr;
+  int32_t* d_gsrcC = nullptr;  // inverse of gdstC: [n_gradC][2] parameters fed by a position of the gradient partial (-1: none); nullptr: not invertible
+  int32_t* d_gzeroC = nullptr; // parameters without a position (their gradient is 0)
+  long n_gzeroC = 0;
   float* d_gpartC = nullptr;
   size_t gpartC_cap = 0;        // floats
   bool trainc_ready = false;

@@ -263,7 +263,8 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
     if (!f->trainc_ready) {
       auto undo = [&]() {
         (void)hipFree(f->d_imgC); (void)hipFree(f->d_sC1); (void)hipFree(f->d_sC2); (void)hipFree(f->d_gdstC);
-        f->d_imgC = nullptr; f->d_sC1 = f->d_sC2 = f->d_gdstC = nullptr;
+        (void)hipFree(f->d_gsrcC); (void)hipFree(f->d_gzeroC);
+        f->d_imgC = nullptr; f->d_sC1 = f->d_sC2 = f->d_gdstC = f->d_gsrcC = f->d_gzeroC = nullptr; f->n_gzeroC = 0;
       };
 #define SF_TRY_C(call)                                                       \
   do {                                                                       \
@@ -281,6 +282,29 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
       SF_TRY_C(hipMemcpy(f->d_sC2, L.srcC2.data(), (size_t)L.n_imgC * sizeof(int32_t), hipMemcpyHostToDevice));
       SF_TRY_C(hipMalloc(&f->d_gdstC, (size_t)L.n_params * sizeof(int32_t)));
       SF_TRY_C(hipMemcpy(f->d_gdstC, L.gdstC.data(), (size_t)L.n_params * sizeof(int32_t), hipMemcpyHostToDevice));
+      {
+        // position -> parameter(s), for the gather that walks the partials in THEIR order (coalesced reads): a position
+        // feeds at most two parameters (b0 and bc share one); if the packer ever maps more, the parameter-order gather stays
+        std::vector<int32_t> inv((size_t)L.n_gradC * 2, -1), zero;
+        bool ok = true;
+        for (long i = 0; i < (long)L.n_params && ok; ++i) {
+          const int32_t g = L.gdstC[(size_t)i];
+          if (g < 0) { zero.push_back((int32_t)i); continue; }
+          if (g >= (int32_t)L.n_gradC) { ok = false; break; }
+          if (inv[(size_t)g * 2] < 0) inv[(size_t)g * 2] = (int32_t)i;
+          else if (inv[(size_t)g * 2 + 1] < 0) inv[(size_t)g * 2 + 1] = (int32_t)i;
+          else ok = false;
+        }
+        if (ok) {
+          SF_TRY_C(hipMalloc(&f->d_gsrcC, inv.size() * sizeof(int32_t)));
+          SF_TRY_C(hipMemcpy(f->d_gsrcC, inv.data(), inv.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+          f->n_gzeroC = (long)zero.size();
+          if (!zero.empty()) {
+            SF_TRY_C(hipMalloc(&f->d_gzeroC, zero.size() * sizeof(int32_t)));
+            SF_TRY_C(hipMemcpy(f->d_gzeroC, zero.data(), zero.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+          }
+        }
+      }
 #undef SF_TRY_C
       f->trainc_ready = true;
     }
@@ -324,7 +348,8 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
       SF_TRY(hipEventRecord(f->ev_train[1], st));
       f->ev_train_valid = true;
     }
-    SF_TRY(sf_launch_gather_c(f->d_gpartC, (long)L.n_gradC, grid, f->d_gdstC, grad, (long)L.n_params, st));
+    if (f->d_gsrcC) SF_TRY(sf_launch_gather_c2(f->d_gpartC, (long)L.n_gradC, grid, f->d_gsrcC, f->d_gzeroC, f->n_gzeroC, grad, st));
+    else SF_TRY(sf_launch_gather_c(f->d_gpartC, (long)L.n_gradC, grid, f->d_gdstC, grad, (long)L.n_params, st));
     return SF_OK;
   }
   // ---- lazily built training state

@@ -56,3 +56,5 @@ bool sf_trainc_eligible(const SfLayout& L, bool want_dctx);
 int sf_trainc_grid(long B);
 hipError_t sf_launch_maf_trainc(const SfTrcArgs& a, int grid, hipStream_t st);
 hipError_t sf_launch_gather_c(const float* gpart, long stride, int nwg, const int32_t* gdst, float* grad, long n, hipStream_t st);
+hipError_t sf_launch_gather_c2(const float* gpart, long stride, int nwg, const int32_t* gsrc, const int32_t* gzero, long n_zero,
+                               float* grad, hipStream_t st);
