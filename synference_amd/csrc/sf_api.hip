@@ -532,6 +532,13 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
       static int env_il = -1;  // developer knob: SF_INTERLEAVE=<galaxies per block>, 0 = plain slot order (A-B runs)
       if (env_il < 0) { const char* e = std::getenv("SF_INTERLEAVE"); env_il = e ? std::atoi(e) : 128; }
       a.dense_G = (!cur && env_il > 0 && pending == M * S && M > 1 && (int64_t)env_il * S < (int64_t)1 << 31) ? (uint32_t)env_il : 0u;
+      a.list_mul = 0; a.list_log2 = 0;
+      if (cur && stage == 0 && env_il > 0 && pending >= 4096 && pending < (1ll << 31)) {  // the caller's list (sorted by slot): strided walk
+        uint32_t k = 12;
+        while ((1ull << k) < (uint64_t)pending) ++k;
+        a.list_log2 = k;
+        a.list_mul = (uint32_t)(((1ull << k) / 128u) | 1u);   // odd: a bijection of [0, 2^k)
+      }
       static int env_sp = -1;  // developer knob: SF_SPEC_AFTER=<attempts> (0 = width grows with the attempt number only)
       if (env_sp < 0) { const char* e = std::getenv("SF_SPEC_AFTER"); env_sp = e ? std::atoi(e) : 0; }
       a.spec_full_after = (uint32_t)env_sp;

@@ -47,6 +47,10 @@ struct SfSampleArgsHost {
   // phase does not share work); interleaved, every workgroup carries the same mix, and a block keeps the context rows
   // in flight few enough to stay cached.  The draws do not depend on the order (streams are keyed by slot and attempt).
   uint32_t dense_G = 0;
+  // != 0 (an explicit slot list, e.g. an ensemble member's share, sorted by slot): item i of the dense list is list entry
+  // walk(i), walk = i -> i * list_mul mod 2^list_log2, repeated until the result is < n_total (cycle walking: a
+  // permutation of [0, n_total)) -- consecutive items lie ~n_total / 128 entries apart, for the same reason as dense_G
+  uint32_t list_mul = 0, list_log2 = 0;
   // tail mode: entries that have failed at least this many attempts are tried at the full speculation width at once
   // (0 = the width only grows with the attempt number)
   uint32_t spec_full_after = 0;

@@ -130,7 +130,12 @@ __device__ __forceinline__ bool sf_q_fetch(const Args& a, unsigned int* ctrl, un
       for (unsigned int i = lane; i < nd; i += 64) {
         unsigned int sl;
         if (a.slots) {
-          sl = a.slots[dcur + i];
+          unsigned int pos = dcur + i;
+          if (a.list_mul) {  // strided walk through a sorted list (sf_internal.h)
+            const unsigned int msk = (1u << a.list_log2) - 1u;
+            do { pos = (pos * a.list_mul) & msk; } while (pos >= a.n_total);
+          }
+          sl = a.slots[pos];
         } else if (a.dense_G) {  // block-interleaved order of a whole catalogue (sf_internal.h)
           const unsigned int idx = dcur + i, S_ = (unsigned int)a.S, M_ = a.n_total / S_;
           const unsigned int per_block = a.dense_G * S_, b = idx / per_block, j = idx - b * per_block;

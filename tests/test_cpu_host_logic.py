@@ -605,3 +605,25 @@ def test_block_interleaved_dense_order_is_a_permutation_that_spreads_a_galaxy(M,
     gal = slots // S
     if M > 1:
         assert (np.diff(np.flatnonzero(gal == 0)) >= min(G, M)).all()
+
+
+@pytest.mark.parametrize("n", [4096, 4097, 5000, 8191, 8192, 100003])
+def test_strided_walk_through_a_slot_list_is_a_permutation(n):
+    """sf_queue.h (a.list_mul): item i of the dense list of an explicit slot list is entry walk(i) = i * mul mod 2^k,
+    repeated until < n (cycle walking).  Every entry exactly once; neighbours far apart."""
+    k = 12
+    while (1 << k) < n:
+        k += 1
+    mul = ((1 << k) // 128) | 1
+    msk = (1 << k) - 1
+    pos = np.arange(n, dtype=np.uint64)
+    out = np.empty(n, dtype=np.int64)
+    todo = np.ones(n, bool)
+    cur = pos.copy()
+    while todo.any():
+        cur[todo] = (cur[todo] * mul) & msk
+        done = todo & (cur < n)
+        out[done] = cur[done]
+        todo &= ~done
+    assert np.array_equal(np.sort(out), np.arange(n))
+    assert np.median(np.abs(np.diff(out))) >= n // 256
