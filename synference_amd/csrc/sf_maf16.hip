@@ -777,7 +777,7 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
       }
     }
     SfPass16B S;
-    S.tab = m.ctab != nullptr;
+    S.tab = DD > 0 ? true : m.ctab != nullptr;  // (the unrolled kernels are only launched with the context table)
     for (int t = m.T - 1; t >= 0; --t) {
       // requested before the staging barriers so that their round trips overlap with the image copy: the degree ->
       // slot table of the transform and (table path) c0 of the first tile's first MFMA pass
@@ -1431,7 +1431,7 @@ static int sf_maf16_tpw() {
 static int sf_maf16_seq_d(const SfDev& m) {
   static int env = -1;
   if (env < 0) { const char* e = std::getenv("SF_SEQ"); env = e ? std::atoi(e) : 1; }
-  if (!env || m.m16_span || m.D < 3 || m.D > 5 || m.nT16 != m.D - 1) return 0;
+  if (!env || !m.ctab || m.m16_span || m.D < 3 || m.D > 5 || m.nT16 != m.D - 1) return 0;
   for (int p = 2; p <= m.D; ++p)
     if (m.g16_tile[p - 1] != p - 2) return 0;
   bool fits = false;  // the image offsets the unrolled kernels hard-wire
