@@ -90,11 +90,17 @@ def test_draws_do_not_depend_on_the_dense_order(name, M, S):
     import sys
     child = os.path.join(os.path.dirname(__file__), "helpers", "order_child.py")
     digests = []
-    for il in ("0", "128", "7"):
-        env = dict(os.environ, SF_INTERLEAVE=il)
+    # ... and without the per-galaxy context table (size cap 0: the kernels evaluate the context products per draw, on the
+    # dispatching kernels instead of the unrolled ones): the table holds the same MFMA sums
+    for extra in ({"SF_INTERLEAVE": "0"}, {"SF_INTERLEAVE": "128"}, {"SF_INTERLEAVE": "7"}, {"SF_CTAB_MAX_MB": "0"}):
+        env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, child, name, str(M), str(S)], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1]
         digests.append(line)
     assert digests[0] == digests[1] == digests[2], digests
+    if name.startswith("maf"):
+        assert digests[3] == digests[0], digests       # the MAF table holds exactly the sums the kernel would form
+    else:                                              # NSF: the table's products are summed in another order (fp32 rounding)
+        assert abs(float(digests[3].split()[3]) - float(digests[0].split()[3])) <= 1e-6 * abs(float(digests[0].split()[3]))
     assert digests[0].split()[2] == "0"   # every slot filled
