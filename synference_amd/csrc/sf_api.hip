@@ -532,6 +532,13 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
       static int env_il = -1;  // developer knob: SF_INTERLEAVE=<galaxies per block>, 0 = plain slot order (A-B runs)
       if (env_il < 0) { const char* e = std::getenv("SF_INTERLEAVE"); env_il = e ? std::atoi(e) : 128; }
       a.dense_G = (!cur && env_il > 0 && pending == M * S && M > 1 && (int64_t)env_il * S < (int64_t)1 << 31) ? (uint32_t)env_il : 0u;
+      {
+        static int env_run = -1;  // developer knob: SF_DENSE_RUN=<draws> (0 = the kernel's tile: 16 / 32)
+        if (env_run < 0) { const char* e = std::getenv("SF_DENSE_RUN"); env_run = e ? std::atoi(e) : 0; }
+        uint32_t run = env_run > 0 ? (uint32_t)env_run : (fast16 ? 16u : 32u);
+        if (S % (int64_t)run != 0) run = 1;
+        a.dense_run = run;
+      }
       a.list_mul = 0; a.list_log2 = 0;
       if (cur && stage == 0 && env_il > 0 && pending >= 4096 && pending < (1ll << 31)) {  // the caller's list (sorted by slot): strided walk
         uint32_t k = 12;

@@ -47,6 +47,11 @@ struct SfSampleArgsHost {
   // phase does not share work); interleaved, every workgroup carries the same mix, and a block keeps the context rows
   // in flight few enough to stay cached.  The draws do not depend on the order (streams are keyed by slot and attempt).
   uint32_t dense_G = 0;
+  // ... in RUNS of dense_run consecutive draws of one galaxy (dense_run divides S; 1 = draw by draw): with a run = one tile
+  // of draws (16 / 32) the lanes of a tile share their galaxy's context-table rows and write one contiguous piece of the
+  // output, and a galaxy's S slots still spread over S / dense_run ranges.  Within a block of Gb galaxies item j is draw
+  // (j / run / Gb) * run + j % run of galaxy (j / run) % Gb.
+  uint32_t dense_run = 1;
   // != 0 (an explicit slot list, e.g. an ensemble member's share, sorted by slot): item i of the dense list is list entry
   // walk(i), walk = i -> i * list_mul mod 2^list_log2, repeated until the result is < n_total (cycle walking: a
   // permutation of [0, n_total)) -- consecutive items lie ~n_total / 128 entries apart, for the same reason as dense_G

@@ -140,8 +140,10 @@ __device__ __forceinline__ bool sf_q_fetch(const Args& a, unsigned int* ctrl, un
           const unsigned int idx = dcur + i, S_ = (unsigned int)a.S, M_ = a.n_total / S_;
           const unsigned int per_block = a.dense_G * S_, b = idx / per_block, j = idx - b * per_block;
           const unsigned int left = M_ - b * a.dense_G, Gb = left < a.dense_G ? left : a.dense_G;
-          const unsigned int smp = j / Gb;
-          sl = (b * a.dense_G + (j - smp * Gb)) * S_ + smp;
+          const unsigned int run = a.dense_run ? a.dense_run : 1u;
+          const unsigned int q = j / run, ln = j - q * run;    // run number inside the block, position inside the run
+          const unsigned int rr = q / Gb, g = q - rr * Gb;      // which run of the galaxy, which galaxy of the block
+          sl = (b * a.dense_G + g) * S_ + rr * run + ln;
         } else {
           sl = (unsigned int)a.slot_base + dcur + i;
         }

@@ -581,18 +581,19 @@ def test_importer_reads_a_hand_written_nflows_state_dict():
         spec_and_flat_from_state_dict(bad)
 
 
-def dense_order_slot(idx, M, S, G):
+def dense_order_slot(idx, M, S, G, run=1):
     """The block-interleaved dense order of a whole-catalogue sampling call, restated from sf_queue.h (sf_q_fetch, the
-    `a.dense_G` branch; described at SfSampleArgsHost::dense_G in sf_internal.h): item idx -> slot."""
+    `a.dense_G` branch; described at SfSampleArgsHost::dense_G / dense_run in sf_internal.h): item idx -> slot."""
     per_block = G * S
     b, j = divmod(idx, per_block)
     Gb = min(G, M - b * G)
-    smp, g = divmod(j, Gb)
-    return (b * G + g) * S + smp
+    q, ln = divmod(j, run)
+    rr, g = divmod(q, Gb)
+    return (b * G + g) * S + rr * run + ln
 
 
 @pytest.mark.parametrize("M,S,G", [(1, 7, 128), (5, 3, 128), (128, 4, 128), (129, 4, 128), (300, 5, 128), (2000, 3, 128),
-                                   (37, 11, 8), (64, 2, 32)])
+                                   (37, 11, 8), (64, 2, 32), (70, 32, 16), (9, 48, 4)])
 def test_block_interleaved_dense_order_is_a_permutation_that_spreads_a_galaxy(M, S, G):
     """Every slot exactly once (nothing sampled twice, nothing left empty), also with a ragged last block; and inside a
     full block a range of G consecutive items holds G different galaxies -- the point of the order."""
@@ -605,6 +606,13 @@ def test_block_interleaved_dense_order_is_a_permutation_that_spreads_a_galaxy(M,
     gal = slots // S
     if M > 1:
         assert (np.diff(np.flatnonzero(gal == 0)) >= min(G, M)).all()
+    # in runs of `run` draws (a tile of the kernel): still a permutation; a tile-aligned group of `run` items is `run`
+    # consecutive slots of one galaxy
+    for run in (r for r in (2, 4, 16) if S % r == 0):
+        sl = np.array([dense_order_slot(i, M, S, G, run) for i in range(M * S)])
+        assert np.array_equal(np.sort(sl), np.arange(M * S))
+        grp = sl.reshape(-1, run)
+        assert (np.diff(grp, axis=1) == 1).all() and (grp[:, 0] // S == grp[:, -1] // S).all()
 
 
 @pytest.mark.parametrize("n", [4096, 4097, 5000, 8191, 8192, 100003])
