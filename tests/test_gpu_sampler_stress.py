@@ -104,3 +104,37 @@ def test_draws_do_not_depend_on_the_dense_order(name, M, S):
     else:                                              # NSF: the table's products are summed in another order (fp32 rounding)
         assert abs(float(digests[3].split()[3]) - float(digests[0].split()[3])) <= 1e-6 * abs(float(digests[0].split()[3]))
     assert digests[0].split()[2] == "0"   # every slot filled
+
+
+@pytest.mark.parametrize("D,H,T,NB", [(5, 64, 2, 1), (5, 40, 3, 2), (5, 52, 1, 2), (4, 48, 2, 1), (4, 30, 4, 2), (3, 32, 2, 1),
+                                      (3, 20, 5, 2), (5, 50, 5, 1)])
+def test_unrolled_sampler_shapes_match_the_oracle(D, H, T, NB):
+    """One degree group per 16-row tile (H <= 16 (D - 1)), D = 3 ... 5, one or two blocks: the shapes of the unrolled
+    sampler kernels (k_maf_samp16<NB, .., DD>, compile-time image offsets) and of the deep tail's k_maf_find16s."""
+    from oracle import flows as OF
+    from synference_amd.spec import FlowSpec
+    rng = np.random.default_rng(1000 * D + H + T)
+    C = int(rng.integers(3, 20))
+    perms = OF.random_perms(D, T, 7 + H)
+    st = dict(theta_mean=rng.normal(size=D).astype(np.float32), theta_std=rng.uniform(0.5, 2, size=D).astype(np.float32),
+              x_mean=rng.normal(size=C).astype(np.float32), x_std=rng.uniform(0.5, 2, size=C).astype(np.float32))
+    ospec = OF.FlowSpec(kind="maf", D=D, C=C, H=H, T=T, K=10, NB=NB, perms=perms, **{k: v.astype(np.float64) for k, v in st.items()})
+    spec = FlowSpec(kind="maf", D=D, C=C, H=H, T=T, K=10, NB=NB, perms=perms, **st)
+    flat = OF.init_params(ospec, 11 + H)
+    flat = (flat + 0.3 * rng.normal(size=flat.shape) * np.abs(flat).mean()).astype(np.float32)
+    M, S = 7, 160
+    x = (rng.normal(size=(M, C)) * st["x_std"] + st["x_mean"]).astype(np.float32)
+    f = HipFlow(spec, "cuda:0")
+    d = f.describe()
+    assert d["m16_ok"] and not d["m16_span"] and d["nT16"] == D - 1, d     # really one of the unrolled shapes
+    f.set_params(torch.as_tensor(flat))
+    free, _ = OP.sample(ospec, torch.as_tensor(flat), x, 300, 99, dtype=torch.float32)
+    lo = np.quantile(free.reshape(-1, D), 0.1, axis=0).astype(np.float32)
+    hi = np.quantile(free.reshape(-1, D), 0.9, axis=0).astype(np.float32)
+    got, nd = f.sample(x, S, lo, hi, seed=3, return_counts=True)
+    got, nd = got.cpu().double().numpy(), nd.cpu().numpy()
+    ref, rnd = OP.sample(ospec, torch.as_tensor(flat), x, S, 3, lo, hi, dtype=torch.float32)
+    assert f.last_unfilled == 0 and np.isfinite(got).all() and ((got >= lo) & (got <= hi)).all()
+    err = np.abs((got - ref) / (hi - lo).astype(np.float64)).max(-1)
+    assert (err > 5e-4).mean() < 0.01, ((err > 5e-4).mean(), err.max())
+    assert np.abs(nd - rnd).sum() <= max(3, 0.02 * rnd.sum())
