@@ -516,7 +516,12 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
   // with the windows [1 024, 16 384), [16 384, 262 144) ...: the queue keeps every lane busy with speculation 64 wide
   // at the sampler kernel's cost per evaluation.  (Chip-wide find / resolve launches, below, are for the FEW slots that
   // remain: they spread one slot's attempts over the whole chip, on the plain fp32 kernels.)
-  const int64_t persist_min = 8192;
+  int64_t persist_min = 8192;
+  {
+    static long env_pm = -1;  // developer knob: SF_PERSIST_MIN=<slots> (1 = every window on the persistent kernel: tests)
+    if (env_pm < 0) { const char* e = std::getenv("SF_PERSIST_MIN"); env_pm = e ? std::atol(e) : 0; }
+    if (env_pm > 0) persist_min = env_pm;
+  }
   for (;;) {
     // The retry ring stays all-zero only while every launch ends cleanly (consumers clear what they take).  A launch that
     // ended on a queue error, or never completed, may have left donated entries behind: clear the ring before it is reused.

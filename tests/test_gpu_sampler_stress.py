@@ -138,3 +138,21 @@ def test_unrolled_sampler_shapes_match_the_oracle(D, H, T, NB):
     err = np.abs((got - ref) / (hi - lo).astype(np.float64)).max(-1)
     assert (err > 5e-4).mean() < 0.01, ((err > 5e-4).mean(), err.max())
     assert np.abs(nd - rnd).sum() <= max(3, 0.02 * rnd.sum())
+
+
+def test_later_persistent_windows_equal_the_find_and_resolve_launches():
+    """Slots that use up the first 1 024 attempts go to find / resolve launches, or -- while many are open (>= 8 192; here
+    forced with SF_PERSIST_MIN=1) -- to further persistent launches over the windows [1 024, 16 384) ...: the same draws
+    and attempt counts, bit for bit (the find / resolve route is checked against the oracle in test_gpu_sampler.py)."""
+    import os
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(__file__), "helpers", "order_child.py")
+    lines = []
+    for extra in ({}, {"SF_PERSIST_MIN": "1"}):
+        r = subprocess.run([sys.executable, child, "maf_cfg1", "2", "24", "0.36"], env=dict(os.environ, **extra),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1].split())
+    assert lines[0][1] == lines[1][1] and lines[0][2] == lines[1][2] == "0", lines
+    assert int(lines[0][4]) >= 3 and int(lines[1][4]) == 2, lines     # find / resolve pairs vs a second persistent launch
