@@ -122,7 +122,8 @@ int sf_flow_trainc_table(const sf_flow* f, int32_t* src1, int32_t* src2, int64_t
                          int32_t* desc /*[64]*/, float* cst, int64_t n_cst);
 int64_t sf_flow_cst_size(const sf_flow* f);
 /* which kernel sf_flow_loss_grad* runs for a batch of B rows: 0 = one producer wave per 32-sample tile (k_maf_train /
- * k_nsf_train), 1 / 2 = the cooperative 16-row kernel with 4-wave / 8-wave workgroups (k_maf_trainc) */
+ * k_nsf_train), 1 / 2 = the cooperative 16-row MAF kernel with 4-wave / 8-wave workgroups (k_maf_trainc), 3 = the
+ * cooperative 16-row NSF kernel (k_nsf_trainc) */
 int sf_flow_train_path(const sf_flow* f, int64_t B, int want_dctx);
 /* byte-for-byte description of the packed image for diagnostics (JSON, NUL-terminated) */
 int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen);

@@ -11,6 +11,7 @@
 
 #include "sf_internal.h"
 #include "sf_train.h"
+#include "sf_nsfc.h"
 #include "sf_trainc.h"
 
 namespace {
@@ -104,7 +105,7 @@ void sf_flow_destroy(sf_flow* f) {
     (void)hipFree(f->d_ctab); (void)hipFree(f->d_packed16B); (void)hipFree(f->d_s16B); (void)hipFree(f->d_packed16); (void)hipFree(f->d_s16a); (void)hipFree(f->d_s16b);
     (void)hipFree(f->d_s1); (void)hipFree(f->d_s2); (void)hipFree(f->d_t1); (void)hipFree(f->d_t2);
     (void)hipFree(f->d_flat); (void)hipFree(f->d_gpacked); (void)hipFree(f->d_gdst);
-    (void)hipFree(f->d_imgC); (void)hipFree(f->d_sC1); (void)hipFree(f->d_sC2); (void)hipFree(f->d_gdstC); (void)hipFree(f->d_gsrcC); (void)hipFree(f->d_gzeroC); (void)hipFree(f->d_gpartC);
+    (void)hipFree(f->d_imgC); (void)hipFree(f->d_sC1); (void)hipFree(f->d_sC2); (void)hipFree(f->d_gdstC); (void)hipFree(f->d_gsrcC); (void)hipFree(f->d_gzeroC); (void)hipFree(f->d_gpartC); (void)hipFree(f->d_ustash);
     (void)hipFree(f->d_queue); (void)hipFree(f->d_ring); (void)hipFree(f->d_galacc); (void)hipFree(f->d_best); (void)hipHostFree(f->h_queue);
     (void)hipFree(f->d_act); (void)hipFree(f->d_rej[0]); (void)hipFree(f->d_rej[1]); (void)hipFree(f->d_cnt);
   }
@@ -141,20 +142,21 @@ int sf_flow_pack_table16b(const sf_flow* f, int32_t* src, int64_t n) {
   return SF_OK;
 }
 
-int64_t sf_flow_trainc_size(const sf_flow* f) { return (f && f->L.trc.ok) ? f->L.n_imgC : 0; }
-int64_t sf_flow_trainc_grad_size(const sf_flow* f) { return (f && f->L.trc.ok) ? f->L.n_gradC : 0; }
+int64_t sf_flow_trainc_size(const sf_flow* f) { return (f && (f->L.trc.ok || f->L.nsc.ok)) ? f->L.n_imgC : 0; }
+int64_t sf_flow_trainc_grad_size(const sf_flow* f) { return (f && (f->L.trc.ok || f->L.nsc.ok)) ? f->L.n_gradC : 0; }
 int64_t sf_flow_cst_size(const sf_flow* f) { return f ? (int64_t)f->L.cst.size() : 0; }
 int sf_flow_trainc_table(const sf_flow* f, int32_t* src1, int32_t* src2, int64_t n, int32_t* gdst, int64_t n_params,
                          int32_t* desc, float* cst, int64_t n_cst) {
   if (!f || !src1 || !src2 || !gdst || !desc || !cst) return fail(SF_ERR_INVALID, "null argument");
-  if (!f->L.trc.ok || n != f->L.n_imgC || n_params != f->L.n_params || n_cst != (int64_t)f->L.cst.size())
+  if ((!f->L.trc.ok && !f->L.nsc.ok) || n != f->L.n_imgC || n_params != f->L.n_params || n_cst != (int64_t)f->L.cst.size())
     return fail(SF_ERR_INVALID, "no cooperative training image or size mismatch");
-  static_assert(sizeof(SfTrcDev) <= 64 * sizeof(int32_t), "descriptor words");
+  static_assert(sizeof(SfTrcDev) <= 64 * sizeof(int32_t) && sizeof(SfNscDev) <= 64 * sizeof(int32_t), "descriptor words");
   std::memcpy(src1, f->L.srcC1.data(), (size_t)n * sizeof(int32_t));
   std::memcpy(src2, f->L.srcC2.data(), (size_t)n * sizeof(int32_t));
   std::memcpy(gdst, f->L.gdstC.data(), (size_t)n_params * sizeof(int32_t));
   std::memset(desc, 0, 64 * sizeof(int32_t));
-  std::memcpy(desc, &f->L.trc, sizeof(SfTrcDev));
+  if (f->L.trc.ok) std::memcpy(desc, &f->L.trc, sizeof(SfTrcDev));   // MAF: SfTrcDev, NSF: SfNscDev (sf_layout.h)
+  else std::memcpy(desc, &f->L.nsc, sizeof(SfNscDev));
   std::memcpy(cst, f->L.cst.data(), (size_t)n_cst * sizeof(float));
   return SF_OK;
 }
@@ -178,7 +180,7 @@ int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen) {
   add("o_wout", v.o_wout); add("o_bout", v.o_bout); add("o_lu", v.o_lu);
   add("c_pscale", v.c_pscale); add("c_pshift", v.c_pshift); add("c_tdim", v.c_tdim);
   add("c_xmean", v.c_xmean); add("c_xstd", v.c_xstd); add("c_dslot", v.c_dslot);
-  add("nsf_split_sampler", f->L.nsfS.ok); add("trainc_ok", f->L.trc.ok);
+  add("nsf_split_sampler", f->L.nsfS.ok); add("trainc_ok", f->L.trc.ok); add("nsfc_ok", f->L.nsc.ok);
   add("inc_ok", v.inc_ok); add("hidden_bf16", v.hidden_bf16); add("tB_stride", v.tB_stride); add("n_parts", v.n_parts); add("part_max", v.part_max);
   add("n_params", f->L.n_params); add("n_packed", f->L.n_packed);
   {
@@ -304,6 +306,7 @@ int sf_set_sampler_fp32(int on) {
 int sf_flow_train_path(const sf_flow* f, int64_t B, int want_dctx) {
   if (!f) return fail(SF_ERR_INVALID, "null handle");
   if (B > 0 && sf_trainc_eligible(f->L, want_dctx != 0)) return sf_trainc_groups((long)B);
+  if (B > 0 && sf_nsfc_eligible(f->L, want_dctx != 0)) return 3;
   return 0;
 }
 

@@ -156,6 +156,8 @@ struct sf_flow {
   float* d_gpartC = nullptr;
   size_t gpartC_cap = 0;        // floats
   bool trainc_ready = false;
+  float* d_ustash = nullptr;    // cooperative NSF training (sf_nsfc.hip): u / u' of every transform, [rows][T][16]
+  size_t ustash_cap = 0;        // floats
   float* d_act = nullptr;       // activation stash (training)
   size_t act_cap = 0;           // floats
   uint32_t* d_rej[2] = {nullptr, nullptr};

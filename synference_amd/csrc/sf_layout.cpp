@@ -91,6 +91,7 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
   SfDev& v = L.dev;
   std::memset(&v, 0, sizeof(v));
   std::memset(&L.trc, 0, sizeof(L.trc));
+  std::memset(&L.nsc, 0, sizeof(L.nsc));
   std::memset(&L.nsfS, 0, sizeof(L.nsfS));
   v.kind = d.kind; v.D = D; v.C = C; v.H = H; v.T = T; v.K = K; v.NB = NB;
   v.scale_fn = d.scale_fn;
@@ -859,6 +860,146 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
           if (t == 0) v.oT_wg[k] = o;
         }
       }
+      // ---- cooperative 16-row training image (sf_layout.h, SfNscDev; sf_nsfc.hip) -----------------------------
+      if (NB == 2 && D >= 2 && D <= 8 && H <= 64 && 3 * K - 1 <= 32 && 8 + C <= 48) {
+        SfNscDev& c = L.nsc;
+        const int NT = ceil_div(H, 16), NI = ceil_div(8 + C, 16);
+        const int OTQ = 3 * K - 1 <= 24 ? 6 : 8, KM = OTQ == 6 ? 8 : 11;
+        if (t == 0) {
+          c.ok = 1;
+          c.NT = NT; c.NI = NI; c.OTQ = OTQ; c.KM = KM;
+          c.kc_h = ceil_div(H - 16 * (NT - 1), 4);
+          c.kc_in[0] = 4; c.kc_in[1] = c.kc_in[2] = 0;
+          for (int it = 1; it < NI; ++it) c.kc_in[it] = ceil_div(std::min(16, C - 8 - 16 * (it - 1)), 4);
+        }
+        auto pushC = [&](int32_t a) { L.srcC1.push_back(a); L.srcC2.push_back(-1); };
+        while (L.srcC1.size() % 256) pushC(-1);
+        const int64_t tbC = (int64_t)L.srcC1.size();
+        if (t == 1) c.t_stride = (int)tbC;
+        auto hereC = [&]() { return (int)((int64_t)L.srcC1.size() - tbC); };
+        int64_t gcur = 0;
+        const int64_t gbase_t = (int64_t)t * c.g_stride;   // (g_stride is known from t = 0 on; 0 * anything for t = 0)
+        if (t == 0) L.gdstC.assign((size_t)0, -1);
+        if (L.gdstC.size() < (size_t)P) L.gdstC.resize((size_t)P, -1);
+        // row maps (sf_layout.h)
+        auto hid_unit = [&](int tile, int rho) -> int { const int u = tile * 16 + (rho >> 2) + 4 * (rho & 3); return u < H ? u : -1; };
+        std::vector<int> id_col(8, -1);   // theta dimension -> column of W_in (identity dimensions only)
+        for (int j = 0; j < d_id; ++j) id_col[idn[j]] = j;
+        auto in_col = [&](int it, int rho, bool gate) -> int {   // column of W_in (gate: of W_g) behind an input-tile row
+          const int g = rho >> 2, m = rho & 3;
+          if (it == 0 && m < 2) { const int dd = 2 * g + m; return (!gate && dd < D) ? id_col[dd] : -1; }
+          const int f = it == 0 ? (m - 2) * 4 + g : 8 + (it - 1) * 16 + 4 * m + g;
+          if (f >= C) return -1;
+          return gate ? f : d_id + f;
+        };
+        auto q_row = [&](int tile, int rho) -> int {   // row of W_out behind a spline-head tile row
+          const int g = rho >> 2, sl = 4 * tile + (rho & 3);
+          if (g >= d_tr) return -1;
+          const int fam = sl / KM, kk = sl % KM;
+          if (fam > 2 || kk >= (fam < 2 ? K : K - 1)) return -1;
+          return g * NP + fam * K + kk;
+        };
+        using WFn = std::function<int64_t(int, int, int, int)>;   // (ot, ro, it, ri) -> logical index or -1
+        auto fwd_block = [&](int OT, int IT, const WFn& fn, int64_t g_off) {
+          for (int ot = 0; ot < OT; ++ot)
+            for (int it = 0; it < IT; ++it)
+              for (int l = 0; l < 64; ++l)
+                for (int r = 0; r < 4; ++r) {
+                  const int ro = l & 15, ri = 4 * (l >> 4) + r;
+                  const int64_t idx = fn(ot, ro, it, ri);
+                  pushC((int32_t)idx);
+                  if (idx >= 0) L.gdstC[(size_t)idx] = (int32_t)(gbase_t + g_off + ((int64_t)ot * IT + it) * 256 + (ro & 3) * 64 + (ro >> 2) * 16 + ri);
+                }
+        };
+        auto tr_block = [&](int ITr, int OTk, const WFn& fn) {   // rows = forward input tiles, K = forward output tiles
+          for (int it = 0; it < ITr; ++it)
+            for (int ot = 0; ot < OTk; ++ot)
+              for (int l = 0; l < 64; ++l)
+                for (int r = 0; r < 4; ++r) pushC((int32_t)fn(ot, 4 * (l >> 4) + r, it, l & 15));
+        };
+        auto bias_block = [&](int OT, const std::function<int64_t(int, int)>& f1, int64_t g_off) {
+          for (int ot = 0; ot < OT; ++ot)
+            for (int ro = 0; ro < 16; ++ro) {
+              const int64_t a1 = f1(ot, ro);
+              pushC((int32_t)a1);
+              if (a1 >= 0) L.gdstC[(size_t)a1] = (int32_t)(gbase_t + g_off + ot * 16 + ro);
+            }
+        };
+        auto w_in = [&](int ot, int ro, int it, int ri) -> int64_t {
+          const int oo = hid_unit(ot, ro), cc = in_col(it, ri, false);
+          return (oo >= 0 && cc >= 0) ? lWin + (int64_t)oo * in_dim + cc : -1;
+        };
+        auto w_gate = [&](int64_t base) {
+          return [&, base](int ot, int ro, int it, int ri) -> int64_t {
+            const int oo = hid_unit(ot, ro), cc = in_col(it, ri, true);
+            return (oo >= 0 && cc >= 0) ? base + (int64_t)oo * C + cc : -1;
+          };
+        };
+        auto w_hid = [&](int64_t base) {
+          return [&, base](int ot, int ro, int it, int ri) -> int64_t {
+            const int oo = hid_unit(ot, ro), ii = hid_unit(it, ri);
+            return (oo >= 0 && ii >= 0) ? base + (int64_t)oo * H + ii : -1;
+          };
+        };
+        auto w_out = [&](int ot, int ro, int it, int ri) -> int64_t {
+          const int oo = q_row(ot, ro), ii = hid_unit(it, ri);
+          return (oo >= 0 && ii >= 0) ? lWout + (int64_t)oo * H + ii : -1;
+        };
+        auto hid_bias = [&](int64_t base) {
+          return [&, base](int ot, int ro) -> int64_t { const int oo = hid_unit(ot, ro); return oo >= 0 ? base + oo : -1; };
+        };
+        int oC; int64_t g;
+#define SF_NSC_FWD(field_o, field_g, OT_, IT_, fn)                                   \
+  oC = hereC(); g = gcur; gcur += (int64_t)(OT_) * (IT_) * 256; fwd_block(OT_, IT_, fn, g); \
+  if (t == 0) { c.field_o = oC; c.field_g = (int)g; }
+#define SF_NSC_BIAS(field_o, field_g, OT_, fn)                                       \
+  oC = hereC(); g = gcur; gcur += (int64_t)(OT_) * 16; bias_block(OT_, fn, g);       \
+  if (t == 0) { c.field_o = oC; c.field_g = (int)g; }
+        SF_NSC_FWD(o_win, g_win, NT, NI, w_in)
+        SF_NSC_BIAS(o_bin, g_bin, NT, hid_bias(lbin))
+        for (int k = 0; k < 2; ++k) {
+          SF_NSC_FWD(o_wg[k], g_wg[k], NT, NI, w_gate(lWg[k]))
+          SF_NSC_BIAS(o_bg[k], g_bg[k], NT, hid_bias(lbg[k]))
+          SF_NSC_FWD(o_w1[k], g_w1[k], NT, NT, w_hid(lW1[k]))
+          SF_NSC_BIAS(o_b1[k], g_b1[k], NT, hid_bias(lb1[k]))
+          SF_NSC_FWD(o_w2[k], g_w2[k], NT, NT, w_hid(lW2[k]))
+          SF_NSC_BIAS(o_b2[k], g_b2[k], NT, hid_bias(lb2[k]))
+        }
+        SF_NSC_FWD(o_wout, g_wout, OTQ, NT, w_out)
+        SF_NSC_BIAS(o_bout, g_bout, OTQ, [&](int ot, int ro) -> int64_t { const int oo = q_row(ot, ro); return oo >= 0 ? lbout + oo : -1; })
+#undef SF_NSC_FWD
+#undef SF_NSC_BIAS
+        // LU block: L[8][8], U[8][8], udiag[8], bias[8]; gradient: two 16 x 16 blocks + 16 row sums
+        {
+          oC = hereC(); g = gcur; gcur += 2 * 256 + 16;
+          if (t == 0) { c.o_lu = oC; c.g_lu = (int)g; }
+          auto gpos = [&](int blk, int ro, int ri) { return (int32_t)(gbase_t + g + blk * 256 + (ro & 3) * 64 + (ro >> 2) * 16 + ri); };
+          std::vector<int32_t> Lm(64, -1), Um(64, -1);
+          int n = 0;
+          for (int i = 0; i < D; ++i)
+            for (int j = 0; j < i; ++j) { Lm[i * 8 + j] = (int32_t)(lLo + n); L.gdstC[(size_t)(lLo + n)] = gpos(0, i, j); ++n; }
+          n = 0;
+          for (int i = 0; i < D; ++i)
+            for (int j = i + 1; j < D; ++j) { Um[i * 8 + j] = (int32_t)(lUp + n); L.gdstC[(size_t)(lUp + n)] = gpos(1, i, j); ++n; }
+          for (int i = 0; i < 64; ++i) pushC(Lm[i]);
+          for (int i = 0; i < 64; ++i) pushC(Um[i]);
+          for (int i = 0; i < 8; ++i) { pushC(i < D ? (int32_t)(lDi + i) : -1); if (i < D) L.gdstC[(size_t)(lDi + i)] = (int32_t)(gbase_t + g + 512 + 8 + i); }
+          for (int i = 0; i < 8; ++i) { pushC(i < D ? (int32_t)(lBi + i) : -1); if (i < D) L.gdstC[(size_t)(lBi + i)] = (int32_t)(gbase_t + g + 512 + i); }
+          while ((L.srcC1.size() - (size_t)tbC) % 16) pushC(-1);
+        }
+        // transposed blocks (data gradients)
+        oC = hereC(); tr_block(NT, OTQ, w_out);
+        if (t == 0) c.o_woutT = oC;
+        for (int k = 0; k < 2; ++k) {
+          oC = hereC(); tr_block(NT, NT, w_hid(lW2[k]));
+          if (t == 0) c.o_w2T[k] = oC;
+          oC = hereC(); tr_block(NT, NT, w_hid(lW1[k]));
+          if (t == 0) c.o_w1T[k] = oC;
+        }
+        oC = hereC(); tr_block(1, NT, w_in);   // only input tile 0 holds theta dimensions (no context gradient on this path)
+        if (t == 0) c.o_winT = oC;
+        if (t == 0) c.g_stride = (int)((gcur + 63) / 64 * 64);
+      }
     }
   }
   E.pad_to(64);
@@ -928,11 +1069,11 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
         return fail("hidden_bf16: one transform's fp32 + bf16 operand images must fit the 152 KiB LDS budget");
     }
   }
-  if (L.trc.ok) {
+  if (L.trc.ok || L.nsc.ok) {
     while (L.srcC1.size() % 256) { L.srcC1.push_back(-1); L.srcC2.push_back(-1); }
-    if (T == 1) L.trc.t_stride = (int)L.srcC1.size();
+    if (T == 1) { L.trc.t_stride = (int)L.srcC1.size(); L.nsc.t_stride = (int)L.srcC1.size(); }
     L.n_imgC = (int64_t)L.srcC1.size();
-    L.n_gradC = (int64_t)T * L.trc.g_stride;
+    L.n_gradC = (int64_t)T * (L.trc.ok ? L.trc.g_stride : L.nsc.g_stride);
     L.gdstC.resize((size_t)P, -1);
   }
   L.n_packed = E.cur;

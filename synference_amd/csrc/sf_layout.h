@@ -128,6 +128,31 @@ struct SfTrcDev {
   int c_jobs, n_jobs;  // constants image: [n_jobs] float-encoded (ot*4 + it) of the unmasked hidden weight blocks
 };
 
+// ---- cooperative 16-row NSF training image (sf_nsfc.hip; NSF, num_blocks = 2, 2 <= D <= 8, <= 4 hidden tiles) ----
+// One workgroup = 4 waves = 32 samples (two 16-sample subtiles); wave j owns hidden tile j of both subtiles.  Tiles as above
+// (lane l: sample l & 15, rows 4*(l >> 4) + r).  Rows are placed so that the k-components an MFMA step consumes (rows m,
+// 4 + m, 8 + m, 12 + m of a tile for component m) fill up one after the other: a tile with n used rows costs
+// ceil(n / 4) of the four v_mfma_f32_16x16x4_f32 steps.
+//   hidden tile ot, row rho:            unit ot*16 + (rho >> 2) + 4*(rho & 3)                      (kc_h: components of the last tile)
+//   input tile 0, row 4*g + m:          m < 2: theta dimension 2*g + m (zero weight where that dimension is transformed);
+//                                       m >= 2: context feature (m - 2)*4 + g
+//   input tile it >= 1, row 4*g + m:    context feature 8 + (it - 1)*16 + 4*m + g                  (kc_in[it] components)
+//   spline-head tile j, row 4*g + r:    parameter slot 4*j + r of transformed dimension g (the lane that evaluates the spline
+//                                       of (sample, dimension g) receives its own parameters); slots [0, KM) widths,
+//                                       [KM, 2 KM) heights, [2 KM, 3 KM - 1) interior derivatives, KM = 8 (OTQ = 6) / 11 (OTQ = 8)
+//   forward / transposed / gradient blocks exactly as SfTrcDev's
+//   LU block: L[8][8] (strictly lower), U[8][8] (strictly upper), udiag[8], bias[8]; its gradient: block 0 = G . tt^T (dL below
+//             the diagonal), block 1 = dt . u'^T (dU above it), then 16 row sums: [0, 8) dbias, [8, 16) d udiag
+struct SfNscDev {
+  int ok;
+  int NT, NI, OTQ, KM;
+  int kc_h, kc_in[3];
+  int t_stride, g_stride;
+  int o_win, o_bin, o_wg[2], o_bg[2], o_w1[2], o_b1[2], o_w2[2], o_b2[2], o_wout, o_bout, o_lu;   // forward blocks
+  int o_woutT, o_w2T[2], o_w1T[2], o_winT;                                                        // transposed blocks
+  int g_win, g_bin, g_wg[2], g_bg[2], g_w1[2], g_b1[2], g_w2[2], g_b2[2], g_wout, g_bout, g_lu;   // gradient partial
+};
+
 // NSF sampler image (sampling kernels only): the fp32 operand image WITHOUT the hidden W1 / W2 blocks, followed in LDS
 // by those blocks as split bf16 -- hi = bf16(w), lo = bf16(w - hi), per block [mt][ks][hi | lo][64 lanes][8], the A operand of
 // v_mfma_f32_32x32x16_bf16 in the k order of sf_bfrag -- so that hi.hi + hi.lo + lo.hi reproduce the fp32 product to ~2^-17
@@ -144,7 +169,8 @@ struct SfNsfSamp {
 struct SfLayout {
   SfDev dev;  // pointers left null
   SfNsfSamp nsfS;                     // nsfS.ok == 0: no NSF sampler image
-  SfTrcDev trc;                       // trc.ok == 0: no cooperative training image for this flow
+  SfTrcDev trc;                       // trc.ok == 0: no cooperative training image for this flow (MAF)
+  SfNscDev nsc;                       // nsc.ok == 0: ... (NSF); srcC1 / srcC2 / gdstC / n_imgC / n_gradC are shared with trc
   std::vector<int32_t> srcC1, srcC2;  // its gather table (sum of two sources, like src1/src2)
   std::vector<int32_t> gdstC;         // logical parameter -> index in a gradient partial (or -1)
   int64_t n_imgC = 0, n_gradC = 0;

@@ -9,6 +9,7 @@
 
 #include "sf_internal.h"
 #include "sf_train_args.h"
+#include "sf_nsfc.h"
 #include "sf_trainc.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -258,8 +259,11 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
                        float grad_scale, const float* weights, float* loss, double* loss_sum, float* grad, float* dctx,
                        hipStream_t st, std::string& err) {
   const SfLayout& L = f->L;
-  // ---- cooperative 16-row kernel (sf_trainc.hip): MAF, two blocks, D <= 8, T <= SF_TRC_TS, <= 4 hidden tiles
-  if (B > 0 && sf_trainc_eligible(L, dctx != nullptr)) {
+  // ---- cooperative 16-row kernels: MAF (sf_trainc.hip: two blocks, D <= 8, T <= SF_TRC_TS, <= 4 hidden tiles) and
+  //      NSF (sf_nsfc.hip: two blocks, D <= 8, H <= 64, K <= 11); they share the image / gather machinery
+  const bool coop_maf = B > 0 && sf_trainc_eligible(L, dctx != nullptr);
+  const bool coop_nsf = B > 0 && !coop_maf && sf_nsfc_eligible(L, dctx != nullptr);
+  if (coop_maf || coop_nsf) {
     if (!f->trainc_ready) {
       auto undo = [&]() {
         (void)hipFree(f->d_imgC); (void)hipFree(f->d_sC1); (void)hipFree(f->d_sC2); (void)hipFree(f->d_gdstC);
@@ -308,8 +312,11 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
 #undef SF_TRY_C
       f->trainc_ready = true;
     }
-    const int grid = sf_trainc_grid(B);
-    const size_t need = (size_t)grid * (size_t)L.n_gradC;
+    const int grid = coop_maf ? sf_trainc_grid(B) : sf_nsfc_grid(B);
+    // NSF at large batch: the workgroups add into one zeroed replica per XCD (f32 atomics) instead of one partial each
+    const bool nsf_atomic = coop_nsf && sf_nsfc_atomic(B, grid, (long)L.n_gradC);
+    const int n_part = nsf_atomic ? SF_NSC_REPLICAS : grid;
+    const size_t need = (size_t)n_part * (size_t)L.n_gradC;
     if (need > f->gpartC_cap) {
       if (f->d_gpartC) SF_TRY(hipFree(f->d_gpartC));
       f->d_gpartC = nullptr; f->gpartC_cap = 0;
@@ -330,6 +337,44 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
     }
     f->packed16_stale = false;
     if (L.n_packedB > 0) SF_TRY(sf_launch_pack_bf16(flat, f->d_bsrc, f->d_packedB, (long)L.n_packedB, st));
+    if (coop_nsf) {
+      const long n_chunks = (B + 31) / 32;
+      const size_t ust_need = (size_t)n_chunks * 32 * (size_t)L.dev.T * 16;
+      if (ust_need > f->ustash_cap) {
+        if (f->d_ustash) SF_TRY(hipFree(f->d_ustash));
+        f->d_ustash = nullptr; f->ustash_cap = 0;
+        SF_TRY(hipMalloc(&f->d_ustash, ust_need * sizeof(float)));
+        f->ustash_cap = ust_need;
+      }
+      if (nsf_atomic) SF_TRY(hipMemsetAsync(f->d_gpartC, 0, need * sizeof(float), st));
+      const SfDev& v = L.dev;
+      SfNscArgs a;
+      a.c = L.nsc;
+      a.img = f->d_imgC; a.cst = f->d_cst;
+      a.D = v.D; a.C = v.C; a.T = v.T; a.K = v.K;
+      a.tail_bound = v.tail_bound; a.min_w = v.min_w; a.min_h = v.min_h; a.min_d = v.min_d; a.lu_eps = v.lu_eps;
+      a.inv_sqrt_h = v.inv_sqrt_h; a.deriv_const = v.deriv_const; a.logdet0 = v.logdet0;
+      a.c_pscale = v.c_pscale; a.c_pshift = v.c_pshift; a.c_xmean = v.c_xmean; a.c_xstd = v.c_xstd;
+      a.theta = theta; a.x = x; a.idx = idx; a.wts = weights; a.B = B; a.n_chunks = n_chunks; a.w = grad_scale;
+      a.loss = loss; a.loss_sum = loss_sum;
+      a.gpart = f->d_gpartC; a.gpart_stride = (long)L.n_gradC; a.atomic = nsf_atomic ? 1 : 0;
+      a.ustash = f->d_ustash;
+#ifdef SF_NSC_TRACE
+      a.trace = nullptr;
+#endif
+      if (f->profiling) {
+        if (!f->ev_train[0]) { SF_TRY(hipEventCreate(&f->ev_train[0])); SF_TRY(hipEventCreate(&f->ev_train[1])); }
+        SF_TRY(hipEventRecord(f->ev_train[0], st));
+      }
+      SF_TRY(sf_launch_nsf_trainc(a, grid, st));
+      if (f->profiling) {
+        SF_TRY(hipEventRecord(f->ev_train[1], st));
+        f->ev_train_valid = true;
+      }
+      if (f->d_gsrcC) SF_TRY(sf_launch_gather_c2(f->d_gpartC, (long)L.n_gradC, n_part, f->d_gsrcC, f->d_gzeroC, f->n_gzeroC, grad, st));
+      else SF_TRY(sf_launch_gather_c(f->d_gpartC, (long)L.n_gradC, n_part, f->d_gdstC, grad, (long)L.n_params, st));
+      return SF_OK;
+    }
     SfTrcArgs a;
     a.c = L.trc;
     a.img = f->d_imgC; a.cst = f->d_cst;

@@ -106,9 +106,13 @@ class HipFlow:
                   "g_win g_b0 g_w1 g_b1 g_w2 g_b2 g_wf g_bf kend0 kend1 kend2 kend3 kbeg0 kbeg1 kbeg2 kbeg3 c_insrc c_jobs "
                   "n_jobs").split()
 
+    NSC_FIELDS = ("ok NT NI OTQ KM kc_h kc_in0 kc_in1 kc_in2 t_stride g_stride o_win o_bin o_wg0 o_wg1 o_bg0 o_bg1 o_w10 o_w11 "
+                  "o_b10 o_b11 o_w20 o_w21 o_b20 o_b21 o_wout o_bout o_lu o_woutT o_w2T0 o_w2T1 o_w1T0 o_w1T1 o_winT "
+                  "g_win g_bin g_wg0 g_wg1 g_bg0 g_bg1 g_w10 g_w11 g_b10 g_b11 g_w20 g_w21 g_b20 g_b21 g_wout g_bout g_lu").split()
+
     def trainc_table(self):
-        """Cooperative 16-row training image (csrc/sf_layout.h, SfTrcDev): None when the flow has none, else
-        (src1, src2, gdst, descriptor dict, constants image)."""
+        """Cooperative 16-row training image (csrc/sf_layout.h: SfTrcDev for a MAF, SfNscDev for an NSF): None when the
+        flow has none, else (src1, src2, gdst, descriptor dict, constants image)."""
         n = int(self.lib.sf_flow_trainc_size(self.handle))
         if not n:
             return None
@@ -120,7 +124,7 @@ class HipFlow:
         cst = np.empty(ncst, np.float32)
         _lib.check(self.lib.sf_flow_trainc_table(self.handle, s1.ctypes.data, s2.ctypes.data, n, gd.ctypes.data, self.n_params,
                                                  desc.ctypes.data, cst.ctypes.data, ncst))
-        d = {k: int(v) for k, v in zip(self.TRC_FIELDS, desc)}
+        d = {k: int(v) for k, v in zip(self.TRC_FIELDS if self.spec.kind == "maf" else self.NSC_FIELDS, desc)}
         d["n_grad"] = int(self.lib.sf_flow_trainc_grad_size(self.handle))
         return s1, s2, gd, d, cst
 

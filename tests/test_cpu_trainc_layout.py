@@ -137,6 +137,6 @@ def test_trainc_image_reproduces_log_prob_and_gradient_map(name):
 
 def test_shapes_without_a_cooperative_image():
     from synference_amd.engine import HipFlow
-    for name in ("maf_wide", "maf_nb3", "maf_d1", "nsf_cfg3"):
+    for name in ("maf_wide", "maf_nb3", "maf_d1", "nsf_nb1", "nsf_k16"):
         _, spec, *_ = make_case(name, B=4)
         assert HipFlow(spec).trainc_table() is None
