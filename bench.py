@@ -556,7 +556,8 @@ def main():
     split = (not a.hidden_bf16) and bool(desc.get("m16_ok") if wl["kind"] == "maf" else desc.get("nsf_split_sampler"))
     tpath = flow.train_path(B)
     tkname = ({1: "k_maf_trainc<TS,NI,NT,1> (cooperative 16-row tiles, 4 waves per 32 samples)",
-               2: "k_maf_trainc<TS,NI,NT,2> (cooperative 16-row tiles, 8 waves per 64 samples)"}.get(tpath)
+               2: "k_maf_trainc<TS,NI,NT,2> (cooperative 16-row tiles, 8 waves per 64 samples)",
+               3: "k_nsf_trainc<NT,OTQ> (cooperative 16-row tiles, 4 waves per 32 samples, conditioner recomputed in the backward sweep)"}.get(tpath)
               or ("k_maf_train<HT>" if wl["kind"] == "maf" else "k_nsf_train<HT,PT>"))
     observed_world = dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1
     observed_backend = dist.get_backend() if (world > 1 and dist.is_initialized()) else "none (single process, no process group)"
