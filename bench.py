@@ -105,6 +105,7 @@ def parse():
     ap.add_argument("--hidden-bf16", action="store_true",
                     help="opt-in bf16 MFMA operands for the hidden HxH layers of the sampler (BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-api", action="store_true", help="skip the API-level leg (SBI_Fitter.sample_posterior -> host float64)")
     ap.add_argument("--skip-large-catalogue", action="store_true",
                     help="leave out the configs[4]-sized sampling leg (1e5 galaxies x 1000 draws, N = 1 only)")
     ap.add_argument("--skip-throughput-regime", action="store_true",
@@ -442,6 +443,56 @@ def main():
         finally:
             _sflib.load().sf_set_sampler_fp32(0)
         note(f"fp32 sampler leg: {fp32_leg['ms_per_step']:.3f} ms/step")
+    # ---------------- API level: the reference's own call, SBI_Fitter.sample_posterior(X, num_samples) -> HOST float64 (N, S, D)
+    # (sbi_runner.py:6436-6442; `log_times` statistic of 6461-6469; examples/paper/model_testing.ipynb:1543-1553), and
+    # fit_catalogue's quantile-only path (device quantiles, only (N, D, Q) leaves the GPU).  Rank-local (shard=False): every
+    # rank fits its own block, like the engine-level leg above.
+    api = None
+    if not a.skip_api:
+        from synference_amd.fitter import SBI_Fitter
+        from synference_amd.hostio import usable_cores
+        from synference_amd.posterior import EnsemblePosterior, FlowPosterior
+        fitter = SBI_Fitter("bench", names, [f"F{i}" for i in range(C)], feature_array=x_lib, parameter_array=th_lib)
+        fitter.posteriors = EnsemblePosterior([FlowPosterior(est, prior)], weights=[1.0])
+        fitter._prior = prior
+        n_api = max(2, min(a.steps, 10))
+        for k in range(2):
+            fitter.sample_posterior(x_test, num_samples=S, seed=500 + k, shard=False)
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        nan_rows = 0
+        for k in range(n_api):
+            arr = fitter.sample_posterior(x_test, num_samples=S, seed=1000 + k, shard=False)
+        barrier_sync(world)
+        t_api = max_over_ranks(time.perf_counter() - t0, world, dev, gloo)
+        assert arr.shape == (M, S, D) and arr.dtype == np.float64
+        nan_rows = int(np.isnan(arr[:, :, 0]).sum())
+        # the draws the API hands over are the engine's (same seed -> same bits, widened)
+        flow.sample(X, S, lo, hi, seed=1000 + n_api - 1, out=out)
+        same = bool(np.array_equal(arr, out.double().cpu().numpy(), equal_nan=True))
+        fitter.sample_posterior(x_test, num_samples=S, seed=77, shard=False, log_times=True)
+        tpo = np.asarray(fitter.last_times_per_object)
+        import pandas as pd
+        df_obs = pd.DataFrame(x_test, columns=list(fitter.feature_names))
+        fitter.fit_catalogue(df_obs, num_samples=S, seed=5, append_to_input=False)
+        t0 = time.perf_counter()
+        n_q = max(2, min(a.steps, 5))
+        for k in range(n_q):
+            tab = fitter.fit_catalogue(df_obs, num_samples=S, seed=6 + k, append_to_input=False)
+        t_q = (time.perf_counter() - t0) / n_q
+        api = {"call": "SBI_Fitter.sample_posterior(X, num_samples=%d) -> host float64 (%d, %d, %d)" % (S, M, S, D),
+               "value": world * n_api * M * S / t_api, "unit": "samples/s", "ms_per_call": 1e3 * t_api / n_api, "calls": n_api,
+               "fraction_of_engine_value": (world * n_api * M * S / t_api) / value,
+               "bit_identical_to_engine_draws": same, "nan_draws": nan_rows,
+               "log_times": {"median_s_per_object": float(np.median(tpo)), "p16": float(np.percentile(tpo, 16)),
+                             "p84": float(np.percentile(tpo, 84)),
+                             "note": "the statistic of sbi_runner.py:6461-6469 (the catalogue call is timed in 16 chunks)"},
+               "fit_catalogue_quantiles": {"ms_per_call": 1e3 * t_q, "samples_per_s": M * S / t_q, "columns": int(tab.shape[1]),
+                                           "note": "16 / 50 / 84 % per parameter reduced on the device; the draws never leave the GPU"},
+               "host": {"usable_cores": usable_cores(), "pipeline": "D2H of fp32 chunks on a copy stream into a pinned ring, "
+                        "widened to float64 by a thread pool (synference_amd/hostio.py)"}}
+        note(f"API leg: {api['ms_per_call']:.2f} ms per sample_posterior call = {api['fraction_of_engine_value']:.2f} of the engine-level "
+             f"value; fit_catalogue quantiles {1e3 * t_q:.2f} ms")
     # ---------------- train leg: fwd+bwd (+ all-reduce) + clip + Adam at the per-GPU batch
     tsteps = a.train_steps or a.steps
     B = a.train_batch
@@ -601,6 +652,7 @@ def main():
                            "note": "3 x the log_prob figure per row (SURVEY 8d: forward + 2 x backward) / the flow kernel's "
                                    "duration (HIP events on its stream, sf_flow_train_stats); prep / gather / Adam launches "
                                    "are in train.ms_per_step, not here"},
+        "api": api,
         "train": {"metric": "flow-train theta.x pairs/sec (fwd+bwd+allreduce+clip+Adam)", "value": pairs,
                   "unit": "pairs/s", "per_gpu_batch": B, "steps": tsteps, "ms_per_step": 1e3 * t_train / tsteps,
                   "achieved_tflops": pairs * f_train / 1e12,

@@ -6,8 +6,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from synference_amd.spec import FlowSpec, init_params, random_perms
 from synference_amd.engine import HipFlow
 g = torch.Generator().manual_seed(0)
-D, C = 5, 10
-spec = FlowSpec(kind="maf", D=D, C=C, H=50, T=5, K=10, perms=random_perms(D, 5, g))
+KIND = os.environ.get("SF_PROBE_KIND", "maf")   # maf: BASELINE cfg1 shape; nsf: cfg3 shape
+D, C = (5, 10) if KIND == "maf" else (8, 20)
+spec = (FlowSpec(kind="maf", D=D, C=C, H=50, T=5, K=10, perms=random_perms(D, 5, g)) if KIND == "maf" else
+        FlowSpec(kind="nsf", D=D, C=C, H=int(os.environ.get("SF_PROBE_H", "50")), T=int(os.environ.get("SF_PROBE_T", "5")),
+                 K=int(os.environ.get("SF_PROBE_K", "8"))))
+F_LP = 40030 if KIND == "maf" else 178640
 f = HipFlow(spec); flat = init_params(spec, g).cuda(); grad = torch.empty_like(flat)
 f.set_profiling(True)
 for B in [int(b) for b in os.environ.get("SF_PROBE_BS", "64,2048,16384,131072").split(",")]:
@@ -22,5 +26,5 @@ for B in [int(b) for b in os.environ.get("SF_PROBE_BS", "64,2048,16384,131072").
         ks.append(f.train_kernel_ms())
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     k = float(np.median(ks))
-    print(f"SF_TRAINC={os.environ.get('SF_TRAINC','1')} B={B}: kernel {k*1e3:.1f} us (min {min(ks)*1e3:.1f}), wall {dt*1e3:.3f} ms, "
-          f"{3*40030*B/(k*1e-3)/1e12:.2f} TFLOP/s = {3*40030*B/(k*1e-3)/157.3e12:.3f} of fp32 peak", flush=True)
+    print(f"{KIND} SF_TRAINC={os.environ.get('SF_TRAINC','1')} path={f.train_path(B)} B={B}: kernel {k*1e3:.1f} us (min {min(ks)*1e3:.1f}), wall {dt*1e3:.3f} ms, "
+          f"{3*F_LP*B/(k*1e-3)/1e12:.2f} TFLOP/s = {3*F_LP*B/(k*1e-3)/157.3e12:.3f} of fp32 peak", flush=True)

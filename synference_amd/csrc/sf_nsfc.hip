@@ -212,8 +212,9 @@ struct NSpl {
         r_k1 = (j == idx + 1) ? rj : r_k1;
       }
     const float d_k = c.min_d + sf_softplus(r_k), d_k1 = c.min_d + sf_softplus(r_k1);
-    const float s = h_k / w_k;
-    const float xi = (vc - x_k) / w_k;
+    const float inv_w = __builtin_amdgcn_rcpf(w_k);
+    const float s = h_k * inv_w;
+    const float xi = (vc - x_k) * inv_w;
     const float om = xi * (1.f - xi);
     const float A = d_k + d_k1 - 2.f * s;
     const float N = s * xi * xi + d_k * om;
@@ -221,7 +222,7 @@ struct NSpl {
     const float Mq = d_k1 * xi * xi + 2.f * s * om + d_k * (1.f - xi) * (1.f - xi);
     const float dnum = s * s * Mq;
     const float go = inside ? Go : 0.f, gl = inside ? Gl : 0.f;
-    const float inv_den = 1.f / den, inv_dnum = 1.f / dnum;
+    const float inv_den = __builtin_amdgcn_rcpf(den), inv_dnum = __builtin_amdgcn_rcpf(dnum);
     const float cN = go * h_k * inv_den;
     const float cD = -go * h_k * N * inv_den * inv_den - 2.f * gl * inv_den;
     const float cQ = gl * inv_dnum;
@@ -230,7 +231,6 @@ struct NSpl {
     const float L_dk1 = cD * om + cQ * (s * s * xi * xi);
     const float L_xi = cN * (2.f * s * xi + d_k * (1.f - 2.f * xi)) + cD * (A * (1.f - 2.f * xi)) +
                        cQ * (s * s * (2.f * d_k1 * xi + 2.f * s * (1.f - 2.f * xi) - 2.f * d_k * (1.f - xi)));
-    const float inv_w = 1.f / w_k;
     const float L_y = go;
     const float L_h = go * N * inv_den + L_s * inv_w;
     const float L_w = -(L_s * s + L_xi * xi) * inv_w;
@@ -351,7 +351,12 @@ __global__ __launch_bounds__(256, 2) void k_nsf_trainc(SfNscArgs a_in) {
   using Spl = NSpl<KM, NQV>;
   const SfNscArgs& a = n_args();
   const SfNscDev& c = a.c;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // wave = the wave's ROLE (tile ownership, spline wave of subtile `wave` for roles 0 and 1).  The second half of the grid
+  // rotates the roles by two: the two workgroups that share a CU (w and w + grid / 2: the dispatcher fills every CU once
+  // before it starts a second round) then keep their spline waves -- the waves with the extra VALU phases -- on different
+  // SIMD pairs
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) ^ ((2 * blockIdx.x >= gridDim.x && gridDim.x > 1) ? 2 : 0));
   const int s = lane & 15, g4 = lane >> 4;
   const int NI = c.NI, D = a.D, T = a.T;
   const bool has = wave < NT;   // owns hidden tile `wave` of both subtiles
@@ -371,6 +376,10 @@ __global__ __launch_bounds__(256, 2) void k_nsf_trainc(SfNscArgs a_in) {
   float* TI2 = TI + NT * NQ * TT;
   float* TL = TI2 + NT * NQ * TT;        // transposed LU inputs [2][NQ]
   float* LUC = TL + 2 * NQ * TT;         // LU block of the current transform (144 floats)
+  // per-sample state of the spline waves between their phases, [subtile][16 samples][24]: u (forward) / dL/du (backward) [0, 8),
+  // u entering the transform [8, 16), the spline's outputs u' [16, 24).  (Held in registers, replicated over the four row
+  // groups of a sample, they were 24-32 live VGPRs through every matrix phase of every wave.)
+  float* SST = LUC + 160;
   const NSplC sc = {a.K, a.tail_bound, a.min_w, a.min_h, a.min_d, a.inv_sqrt_h, a.deriv_const};
   int xcc = 0;
   if (a.atomic) asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -384,20 +393,31 @@ __global__ __launch_bounds__(256, 2) void k_nsf_trainc(SfNscArgs a_in) {
     const long row = chunk * 32 + (spl ? wave : 0) * 16 + s;
     const bool valid = spl && row < a.B;
     float wgt = 0.f;
-    float u[8], ui[8], up[8], G[8];
-    f32x4 ein0 = n_zero();
     float ld = 0.f, ldlu = 0.f;
-#pragma unroll
-    for (int p = 0; p < 8; ++p) { u[p] = 0.f; ui[p] = 0.f; up[p] = 0.f; G[p] = 0.f; }
+    float* sst = SST + ((spl ? wave : 0) * 16 + s) * 24;   // my sample's state
+    auto st8 = [&](int off, const float (&v)[8]) {   // (one lane of the four that hold identical copies writes)
+      if (g4 == 0) {
+        *reinterpret_cast<float4*>(sst + off) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(sst + off + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+    };
+    auto ld8 = [&](int off, float (&v)[8]) {
+      const float4 a0 = *reinterpret_cast<const float4*>(sst + off), a1 = *reinterpret_cast<const float4*>(sst + off + 4);
+      v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+    };
     if (spl) {
       const long ii = row < a.B ? row : a.B - 1;
       const long src = a.idx ? (long)a.idx[ii] : ii;
       wgt = valid ? (a.wts ? a.w * a.wts[row] : a.w) : 0.f;
       const float* xr = a.x + src * a.C;
       const float* th = a.theta + src * D;
+      float u[8];
 #pragma unroll
-      for (int p = 0; p < 8; ++p)
+      for (int p = 0; p < 8; ++p) {
+        u[p] = 0.f;
         if (p < D) u[p] = th[p] * a.cst[a.c_pscale + p] + a.cst[a.c_pshift + p];
+      }
+      st8(0, u);
       for (int it = 0; it < NI; ++it) {
         f32x4 e = n_zero();
 #pragma unroll
@@ -409,7 +429,6 @@ __global__ __launch_bounds__(256, 2) void k_nsf_trainc(SfNscArgs a_in) {
           e[m] = on ? v : 0.f;
         }
         if (it == 0) {
-          ein0 = e;
           e[0] = n_sel4(g4, u[0], u[2], u[4], u[6]);
           e[1] = n_sel4(g4, u[1], u[3], u[5], u[7]);
         }
@@ -419,65 +438,92 @@ __global__ __launch_bounds__(256, 2) void k_nsf_trainc(SfNscArgs a_in) {
     }
     n_barrier();
 
-    // F1 .. F6 of transform t: conditioner forward; leaves the head outputs in XQ.  bw: recomputation at the start of the
-    // transform's backward sweep (also writes h2 transposed for the head's weight gradient)
+    // The fragments of the HIDDEN layers (NT per phase) and their bias are requested ONE PHASE AHEAD, into the register set the
+    // running phase does not use (wA / bA and wB / bB alternate): their L2 round trip hides behind the running phase's
+    // products and the barrier.  Input-layer / gate fragments are requested at the top of their own phase (they are used after
+    // the hidden product).  (Everything one phase ahead: 80 live registers, 200 spilled.)
     f32x4 h0[2], t1[2], t2[2], sg[2], t1b[2], t2b[2], sgb[2];
+    auto bias4 = [&](const float* tp, int off, int tile) { return n_ld4(tp + off + tile * 16 + 4 * g4); };
+    auto ld_hid = [&](const float* tp, int o_w, int o_b, float4 (&W)[4], f32x4& b) {   // (unconditional: a wave without a tile
+#pragma unroll                                                                          //  loads tile 0's and drops them)
+      for (int it = 0; it < NT; ++it) W[it] = n_frag(tp + o_w, NT, j, it, lane);
+      b = bias4(tp, o_b, j);
+    };
+    // acc[q] = b + W[j][:] . X[:][q] over the NT hidden input tiles
+    auto go_hid = [&](const float4 (&W)[4], const f32x4 b, const float* X, f32x4& acc0, f32x4& acc1) {
+      acc0 = b;
+      acc1 = b;
+#pragma unroll
+      for (int it = 0; it < NT; ++it) {
+        const f32x4 i0 = n_ld4(X + (it * NQ + 0) * PBT + pbo), i1 = n_ld4(X + (it * NQ + 1) * PBT + pbo);
+        n_mma2(W[it], i0, i1, acc0, acc1, it == NT - 1 ? kc_h : 4);
+      }
+    };
+    // the same over the input tiles; k0: first component in use (2 for the gates: context rows only)
+    auto ld_in = [&](const float* tp, int o_w, int o_b, float4 (&W)[3], f32x4& b) {
+#pragma unroll
+      for (int it = 0; it < 3; ++it)
+        if (it < NI) W[it] = n_frag(tp + o_w, NI, j, it, lane);
+      b = bias4(tp, o_b, j);
+    };
+    auto go_in = [&](const float4 (&W)[3], const f32x4 b, int k0, f32x4& acc0, f32x4& acc1) {
+      acc0 = b;
+      acc1 = b;
+#pragma unroll
+      for (int it = 0; it < 3; ++it)
+        if (it < NI) {
+          const f32x4 i0 = n_ld4(XIN + (it * NQ + 0) * PBT + pbo), i1 = n_ld4(XIN + (it * NQ + 1) * PBT + pbo);
+          n_mma2(W[it], i0, i1, acc0, acc1, kc_in(it), it == 0 ? k0 : 0);
+        }
+    };
+    auto put2 = [&](float* X, const f32x4 v0, const f32x4 v1) {
+      n_st4(X + (j * NQ + 0) * PBT + pbo, v0);
+      n_st4(X + (j * NQ + 1) * PBT + pbo, v1);
+    };
+    auto putT2 = [&](float* Tb, const f32x4 v0, const f32x4 v1) {
+      n_put_T(Tb + (j * NQ + 0) * TT, v0, s, g4);
+      n_put_T(Tb + (j * NQ + 1) * TT, v1, s, g4);
+    };
+    auto img_of = [&](int t) { const SfNscArgs& a = n_args(); return a.img + (size_t)t * a.c.t_stride + sf_opaque_zero(); };
+
+    // F1 .. F6 of transform t: conditioner forward; leaves the head outputs in XQ.  bw: recomputation at the start of the
+    // transform's backward sweep (also writes h2 transposed for the head's weight gradient).
     auto fwd_mat = [&](int t, bool bw) {
       const SfNscArgs& a = n_args();
       const SfNscDev& c = a.c;
-      const float* tp = a.img + (size_t)t * c.t_stride + sf_opaque_zero();
+      const float* tp = img_of(t);
+      float4 wA[4], wB[4];
+      f32x4 bA, bB;
       // LU block of this transform -> LDS (read by the spline waves many barriers later)
       if (threadIdx.x < 144) LUC[threadIdx.x] = tp[c.o_lu + threadIdx.x];
-      auto bias4 = [&](int off, int tile) { return n_ld4(tp + off + tile * 16 + 4 * g4); };
-      // acc[q] = b[j] + W[j][:] . X[:][q] over NT hidden input tiles
-      auto hid_mm = [&](int o_w, int o_b, const float* X, f32x4& acc0, f32x4& acc1) {
-        float4 wf[NT];
-#pragma unroll
-        for (int it = 0; it < NT; ++it) wf[it] = n_frag(tp + o_w, NT, j, it, lane);
-        acc0 = bias4(o_b, j);
-        acc1 = acc0;
-#pragma unroll
-        for (int it = 0; it < NT; ++it) {
-          const f32x4 i0 = n_ld4(X + (it * NQ + 0) * PBT + pbo), i1 = n_ld4(X + (it * NQ + 1) * PBT + pbo);
-          n_mma2(wf[it], i0, i1, acc0, acc1, it == NT - 1 ? kc_h : 4);
-        }
-      };
-      // the same over the input tiles; k0: first component in use (2 for the gates: context rows only)
-      auto in_mm = [&](int o_w, int o_b, int k0, f32x4& acc0, f32x4& acc1) {
-        float4 wf[3];
-#pragma unroll
-        for (int it = 0; it < 3; ++it)
-          if (it < NI) wf[it] = n_frag(tp + o_w, NI, j, it, lane);
-        acc0 = bias4(o_b, j);
-        acc1 = acc0;
-#pragma unroll
-        for (int it = 0; it < 3; ++it)
-          if (it < NI) {
-            const f32x4 i0 = n_ld4(XIN + (it * NQ + 0) * PBT + pbo), i1 = n_ld4(XIN + (it * NQ + 1) * PBT + pbo);
-            n_mma2(wf[it], i0, i1, acc0, acc1, kc_in(it), it == 0 ? k0 : 0);
-          }
-      };
-      auto put2 = [&](float* X, const f32x4 v0, const f32x4 v1) {
-        n_st4(X + (j * NQ + 0) * PBT + pbo, v0);
-        n_st4(X + (j * NQ + 1) * PBT + pbo, v1);
-      };
       // F1: h0 = bin + Win . [u ; e(x)]
-      if (has) {
-        in_mm(c.o_win, c.o_bin, 0, h0[0], h0[1]);
-        put2(XA, n_relu(h0[0]), n_relu(h0[1]));
+      {
+        float4 wi[3];
+        f32x4 bi;
+        ld_in(tp, c.o_win, c.o_bin, wi, bi);
+        ld_hid(tp, c.o_w1[0], c.o_b1[0], wB, bB);
+        if (has) {
+          go_in(wi, bi, 0, h0[0], h0[1]);
+          put2(XA, n_relu(h0[0]), n_relu(h0[1]));
+        }
       }
       n_barrier();
       // F2: t1 = b1 + W1 relu(h0)
+      ld_hid(tp, c.o_w2[0], c.o_b2[0], wA, bA);
       if (has) {
-        hid_mm(c.o_w1[0], c.o_b1[0], XA, t1[0], t1[1]);
+        go_hid(wB, bB, XA, t1[0], t1[1]);
         put2(XB, n_relu(t1[0]), n_relu(t1[1]));
       }
       n_barrier();
       // F3: t2 = b2 + W2 relu(t1); gate = sigmoid(bg + Wg e); h1 = h0 + t2 * gate
+      ld_hid(tp, c.o_w1[1], c.o_b1[1], wB, bB);
       if (has) {
-        hid_mm(c.o_w2[0], c.o_b2[0], XB, t2[0], t2[1]);
+        float4 wi[3];
+        f32x4 bi;
+        ld_in(tp, c.o_wg[0], c.o_bg[0], wi, bi);
+        go_hid(wA, bA, XB, t2[0], t2[1]);
         f32x4 ga0, ga1;
-        in_mm(c.o_wg[0], c.o_bg[0], 2, ga0, ga1);
+        go_in(wi, bi, 2, ga0, ga1);
         f32x4 h1a, h1b;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -489,16 +535,24 @@ __global__ __launch_bounds__(256, 2) void k_nsf_trainc(SfNscArgs a_in) {
       }
       n_barrier();
       // F4: t1' = b1' + W1' relu(h1)
+      ld_hid(tp, c.o_w2[1], c.o_b2[1], wA, bA);
       if (has) {
-        hid_mm(c.o_w1[1], c.o_b1[1], XA, t1b[0], t1b[1]);
+        go_hid(wB, bB, XA, t1b[0], t1b[1]);
         put2(XB, n_relu(t1b[0]), n_relu(t1b[1]));
       }
       n_barrier();
-      // F5: t2' = b2' + W2' relu(t1'); gate'; h2 = h1 + t2' * gate'  (no activation in front of the head)
+      // F5: t2' = b2' + W2' relu(t1'); gate'; h2 = h1 + t2' * gate'  (no activation in front of the head).  Ahead: the head
+      // fragments of tile `wave` (both subtiles)
+#pragma unroll
+      for (int it = 0; it < NT; ++it) wB[it] = n_frag(tp + c.o_wout, NT, wave, it, lane);
+      bB = bias4(tp, c.o_bout, wave);
       if (has) {
-        hid_mm(c.o_w2[1], c.o_b2[1], XB, t2b[0], t2b[1]);
+        float4 wi[3];
+        f32x4 bi;
+        ld_in(tp, c.o_wg[1], c.o_bg[1], wi, bi);
+        go_hid(wA, bA, XB, t2b[0], t2b[1]);
         f32x4 ga0, ga1;
-        in_mm(c.o_wg[1], c.o_bg[1], 2, ga0, ga1);
+        go_in(wi, bi, 2, ga0, ga1);
         f32x4 h2a, h2b;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -507,39 +561,52 @@ __global__ __launch_bounds__(256, 2) void k_nsf_trainc(SfNscArgs a_in) {
           h2b[r] = h0[1][r] + t2[1][r] * sg[1][r] + t2b[1][r] * sgb[1][r];
         }
         put2(XA, h2a, h2b);
-        if (bw) {
-          n_put_T(TI2 + (j * NQ + 0) * TT, h2a, s, g4);
-          n_put_T(TI2 + (j * NQ + 1) * TT, h2b, s, g4);
-        }
+        if (bw) putT2(TI2, h2a, h2b);
       }
       n_barrier();
-      // F6: q = bout + Wout h2 (tiles wave, wave + 4 for both subtiles; the remaining tiles one (tile, subtile) unit per wave)
+      // F6: q = bout + Wout h2: tiles wave, wave + 4 for both subtiles; the remaining tiles one (tile, subtile) unit per wave
+      {
+        // second portion of the head's fragments: tile wave + 4 (OTQ = 8) or this wave's extra unit (OTQ = 6)
+        constexpr bool OWN2 = NOWN > 1;
+        const int tile2 = OWN2 ? wave + 4 : 4 * NOWN + (wave >> 1);
+        const bool do2 = OWN2 || (NEXT > 0 && wave < NEXT);
+        float4 w2[NT];
+        f32x4 b2 = n_zero();
+        if (do2) {
 #pragma unroll
-      for (int k = 0; k < NOWN; ++k) {
-        const int tile = wave + 4 * k;
-        float4 wf[NT];
-#pragma unroll
-        for (int it = 0; it < NT; ++it) wf[it] = n_frag(tp + c.o_wout, NT, tile, it, lane);
-        f32x4 acc0 = bias4(c.o_bout, tile), acc1 = acc0;
+          for (int it = 0; it < NT; ++it) w2[it] = n_frag(tp + c.o_wout, NT, tile2, it, lane);
+          b2 = bias4(tp, c.o_bout, tile2);
+        }
+        f32x4 acc0 = bB, acc1 = bB;
 #pragma unroll
         for (int it = 0; it < NT; ++it) {
           const f32x4 i0 = n_ld4(XA + (it * NQ + 0) * PBT + pbo), i1 = n_ld4(XA + (it * NQ + 1) * PBT + pbo);
-          n_mma2(wf[it], i0, i1, acc0, acc1, it == NT - 1 ? kc_h : 4);
+          n_mma2(wB[it], i0, i1, acc0, acc1, it == NT - 1 ? kc_h : 4);
         }
-        n_st4(XQ + (tile * NQ + 0) * PBT + pbo, acc0);
-        n_st4(XQ + (tile * NQ + 1) * PBT + pbo, acc1);
-      }
-      if (NEXT > 0 && wave < NEXT) {
-        const int tile = 4 * NOWN + (wave >> 1), sub = wave & 1;
-        float4 wf[NT];
+        n_st4(XQ + (wave * NQ + 0) * PBT + pbo, acc0);
+        n_st4(XQ + (wave * NQ + 1) * PBT + pbo, acc1);
+        if (do2) {
+          if (OWN2) {
+            acc0 = b2;
+            acc1 = b2;
 #pragma unroll
-        for (int it = 0; it < NT; ++it) wf[it] = n_frag(tp + c.o_wout, NT, tile, it, lane);
-        f32x4 acc0 = bias4(c.o_bout, tile), acc1 = n_zero();
+            for (int it = 0; it < NT; ++it) {
+              const f32x4 i0 = n_ld4(XA + (it * NQ + 0) * PBT + pbo), i1 = n_ld4(XA + (it * NQ + 1) * PBT + pbo);
+              n_mma2(w2[it], i0, i1, acc0, acc1, it == NT - 1 ? kc_h : 4);
+            }
+            n_st4(XQ + (tile2 * NQ + 0) * PBT + pbo, acc0);
+            n_st4(XQ + (tile2 * NQ + 1) * PBT + pbo, acc1);
+          } else {
+            const int sub = wave & 1;
+            acc0 = b2;
+            acc1 = n_zero();
 #pragma unroll
-        for (int it = 0; it < NT; ++it) n_mma1(wf[it], n_ld4(XA + (it * NQ + sub) * PBT + pbo), acc0, acc1, it == NT - 1 ? kc_h : 4);
+            for (int it = 0; it < NT; ++it) n_mma1(w2[it], n_ld4(XA + (it * NQ + sub) * PBT + pbo), acc0, acc1, it == NT - 1 ? kc_h : 4);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc0[r] += acc1[r];
-        n_st4(XQ + (tile * NQ + sub) * PBT + pbo, acc0);
+            for (int r = 0; r < 4; ++r) acc0[r] += acc1[r];
+            n_st4(XQ + (tile2 * NQ + sub) * PBT + pbo, acc0);
+          }
+        }
       }
       n_barrier();
     };
@@ -548,116 +615,132 @@ __global__ __launch_bounds__(256, 2) void k_nsf_trainc(SfNscArgs a_in) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) dg[i] = i < D ? sf_softplus(LUC[128 + i]) + a.lu_eps : 1.f;
     };
-    auto write_in0 = [&](const float (&uu)[8]) {   // input tile 0 of my subtile: theta rows from uu, context rows as loaded
-      f32x4 e = ein0;
+    auto write_in0 = [&](const float (&uu)[8]) {   // input tile 0 of my subtile: theta rows from uu, context rows as they are
+      f32x4 e = n_ld4(XIN + (0 * NQ + wave) * PBT + pbo);
       e[0] = n_sel4(g4, uu[0], uu[2], uu[4], uu[6]);
       e[1] = n_sel4(g4, uu[1], uu[3], uu[5], uu[7]);
       n_st4(XIN + (0 * NQ + wave) * PBT + pbo, e);
       n_put_T(TIN + (0 * NQ + wave) * TT, e, s, g4);
     };
     float* ust = a.ustash + ((size_t)(chunk * 32 + (spl ? wave : 0) * 16 + s) * T) * 16;
+    // F7 (spline waves): spline on my (sample, transformed dimension g4), then LULinear on replicated registers.
+    // keep: the transform's backward sweep follows at once (the top transform): nothing is stashed, the input tile stays
+    auto fwd_spline = [&](int t, bool keep, float (&u)[8], float (&ui)[8], float (&up)[8]) {
+      const int start = t & 1, d_tr = (D - start + 1) >> 1;
+      const bool have = g4 < d_tr;
+      float q[NQV];
+#pragma unroll
+      for (int jt = 0; jt < OTQ; ++jt) {
+        const f32x4 v = n_ld4(XQ + (jt * NQ + wave) * PBT + pbo);
+        q[4 * jt] = v[0]; q[4 * jt + 1] = v[1]; q[4 * jt + 2] = v[2]; q[4 * jt + 3] = v[3];
+      }
+      ld8(0, u);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) ui[p] = u[p];
+      const float vin = start ? n_sel4(g4, u[1], u[3], u[5], u[7]) : n_sel4(g4, u[0], u[2], u[4], u[6]);
+      float vout, lad;
+      Spl::fwd(sc, q, vin, vout, lad);
+      ld += have ? lad : 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float vg = __shfl(vout, s + 16 * g, 64);
+        const bool on = g < d_tr;
+        u[2 * g] = (on && start == 0) ? vg : u[2 * g];
+        u[2 * g + 1] = (on && start == 1) ? vg : u[2 * g + 1];
+      }
+#pragma unroll
+      for (int p = 0; p < 8; ++p) up[p] = u[p];
+      if (!keep && g4 == 0) {
+        float4* dst = reinterpret_cast<float4*>(ust + t * 16);
+        dst[0] = make_float4(ui[0], ui[1], ui[2], ui[3]); dst[1] = make_float4(ui[4], ui[5], ui[6], ui[7]);
+        dst[2] = make_float4(up[0], up[1], up[2], up[3]); dst[3] = make_float4(up[4], up[5], up[6], up[7]);
+      }
+      // y = L (U u') + b
+      float dg[8], tt[8];
+      lu_diag(dg);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        tt[i] = dg[i] * up[i];
+        if (i < D) ldlu += sf_log(dg[i]);
+#pragma unroll
+        for (int jj = i + 1; jj < 8; ++jj) tt[i] += LUC[64 + i * 8 + jj] * up[jj];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float y = tt[i] + LUC[136 + i];
+#pragma unroll
+        for (int jj = 0; jj < i; ++jj) y += LUC[i * 8 + jj] * tt[jj];
+        u[i] = i < D ? y : 0.f;
+      }
+      if (!keep) {
+        write_in0(u);
+        st8(0, u);
+      }
+    };
 
-    // ------------------------------------------------------------------ forward sweep
-    for (int t = 0; t < T; ++t) {
+    // ------------------------------------------------------------------ forward sweep (all transforms but the top one)
+    for (int t = 0; t < T - 1; ++t) {
       SF_NC(1 + t);
       fwd_mat(t, false);
-      if (spl) {  // F7: spline on my (sample, transformed dimension g4), then LULinear on replicated registers
-        const int start = t & 1, d_tr = (D - start + 1) >> 1;
-        const bool have = g4 < d_tr;
-        float q[NQV];
-#pragma unroll
-        for (int jt = 0; jt < OTQ; ++jt) {
-          const f32x4 v = n_ld4(XQ + (jt * NQ + wave) * PBT + pbo);
-          q[4 * jt] = v[0]; q[4 * jt + 1] = v[1]; q[4 * jt + 2] = v[2]; q[4 * jt + 3] = v[3];
-        }
-#pragma unroll
-        for (int p = 0; p < 8; ++p) ui[p] = u[p];
-        const float vin = start ? n_sel4(g4, u[1], u[3], u[5], u[7]) : n_sel4(g4, u[0], u[2], u[4], u[6]);
-        float vout, lad;
-        Spl::fwd(sc, q, vin, vout, lad);
-        ld += have ? lad : 0.f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float vg = __shfl(vout, s + 16 * g, 64);
-          const bool on = g < d_tr;
-          u[2 * g] = (on && start == 0) ? vg : u[2 * g];
-          u[2 * g + 1] = (on && start == 1) ? vg : u[2 * g + 1];
-        }
-#pragma unroll
-        for (int p = 0; p < 8; ++p) up[p] = u[p];
-        if (g4 == 0) {
-          float4* dst = reinterpret_cast<float4*>(ust + t * 16);
-          dst[0] = make_float4(ui[0], ui[1], ui[2], ui[3]); dst[1] = make_float4(ui[4], ui[5], ui[6], ui[7]);
-          dst[2] = make_float4(up[0], up[1], up[2], up[3]); dst[3] = make_float4(up[4], up[5], up[6], up[7]);
-        }
-        // y = L (U u') + b
-        float dg[8], tt[8];
-        lu_diag(dg);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          tt[i] = dg[i] * up[i];
-          if (i < D) ldlu += sf_log(dg[i]);
-#pragma unroll
-          for (int jj = i + 1; jj < 8; ++jj) tt[i] += LUC[64 + i * 8 + jj] * up[jj];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          float y = tt[i] + LUC[136 + i];
-#pragma unroll
-          for (int jj = 0; jj < i; ++jj) y += LUC[i * 8 + jj] * tt[jj];
-          u[i] = i < D ? y : 0.f;
-        }
-        write_in0(u);
+      if (spl) {
+        float u[8], ui[8], up[8];
+        fwd_spline(t, false, u, ui, up);
       }
       n_barrier();
     }
-    // ------------------------------------------------------------------ loss, dL/du_T
-    if (spl) {
-      float ss = 0.f;
-#pragma unroll
-      for (int p = 0; p < 8; ++p) ss += u[p] * u[p];
-      float lds_ = ld;
-      lds_ += __shfl_xor(lds_, 16, 64);
-      lds_ += __shfl_xor(lds_, 32, 64);
-      const float nll = 0.5f * ss + 0.5f * (float)D * 1.8378770664093453f - (a.logdet0 + ldlu + lds_);
-      if (a.loss && valid && g4 == 0) a.loss[row] = nll;
-      if (a.loss_sum) {
-        float tsum = (valid && g4 == 0) ? nll : 0.f;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) tsum += __shfl_xor(tsum, o, 64);
-        // values on a 2^-20 grid add exactly in double: the sum does not depend on the order of the atomics
-        if (lane == 0) atomicAdd(a.loss_sum, (double)rintf(tsum * 1048576.0f) * (1.0 / 1048576.0));
-      }
-#pragma unroll
-      for (int p = 0; p < 8; ++p) G[p] = wgt * u[p];
-    }
 
-    // ------------------------------------------------------------------ backward sweep
-    float nui[8], nup[8];  // u / u' of the transform below, requested one transform ahead
-#pragma unroll
-    for (int p = 0; p < 8; ++p) { nui[p] = 0.f; nup[p] = 0.f; }
+    // ------------------------------------------------------------------ backward sweep (the top transform: first evaluation)
     for (int t = T - 1; t >= 0; --t) {
       const SfNscArgs& a = n_args();
       const SfNscDev& c = a.c;
-      const float* tp = a.img + (size_t)t * c.t_stride + sf_opaque_zero();
+      const float* tp = img_of(t);
       float* gp = gpart + (size_t)t * c.g_stride;
+      const bool top = t == T - 1;
       SF_NC(40 + 10 * (T - 1 - t));
-      if (spl) {
-        write_in0(ui);
-        if (t > 0) {
-          const float4* srcp = reinterpret_cast<const float4*>(ust + (t - 1) * 16);
-          const float4 a0 = srcp[0], a1 = srcp[1], a2 = srcp[2], a3 = srcp[3];
-          nui[0] = a0.x; nui[1] = a0.y; nui[2] = a0.z; nui[3] = a0.w; nui[4] = a1.x; nui[5] = a1.y; nui[6] = a1.z; nui[7] = a1.w;
-          nup[0] = a2.x; nup[1] = a2.y; nup[2] = a2.z; nup[3] = a2.w; nup[4] = a3.x; nup[5] = a3.y; nup[6] = a3.z; nup[7] = a3.w;
+      if (!top) {
+        if (spl) {
+          float ui[8];
+          ld8(8, ui);
+          write_in0(ui);
         }
+        n_barrier();
       }
-      n_barrier();
       fwd_mat(t, true);
       SF_NC(41 + 10 * (T - 1 - t));
+      if (spl && top) {
+        // ---------------------------------------------------------------- loss, dL/du_T
+        float u[8], ui[8], up[8], G[8];
+        fwd_spline(t, true, u, ui, up);
+        float ss = 0.f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) ss += u[p] * u[p];
+        float lds_ = ld;
+        lds_ += __shfl_xor(lds_, 16, 64);
+        lds_ += __shfl_xor(lds_, 32, 64);
+        const float nll = 0.5f * ss + 0.5f * (float)D * 1.8378770664093453f - (a.logdet0 + ldlu + lds_);
+        if (a.loss && valid && g4 == 0) a.loss[row] = nll;
+        if (a.loss_sum) {
+          float tsum = (valid && g4 == 0) ? nll : 0.f;
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) tsum += __shfl_xor(tsum, o, 64);
+          // values on a 2^-20 grid add exactly in double: the sum does not depend on the order of the atomics
+          if (lane == 0) atomicAdd(a.loss_sum, (double)rintf(tsum * 1048576.0f) * (1.0 / 1048576.0));
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p) G[p] = wgt * u[p];
+        st8(0, G);
+        st8(8, ui);
+        st8(16, up);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the four lanes of a sample read what lane g4 == 0 wrote)
+      }
       // B0 (spline waves): LULinear backward, spline backward; deltas of the head into XQ
       if (spl) {
         const int start = t & 1, d_tr = (D - start + 1) >> 1;
         const bool have = g4 < d_tr;
+        float G[8], ui[8], up[8];
+        ld8(0, G);
+        ld8(8, ui);
+        ld8(16, up);
         float dg[8], tt[8], dt[8], Gn[8], z[8];
         lu_diag(dg);
 #pragma unroll
@@ -696,6 +779,8 @@ __global__ __launch_bounds__(256, 2) void k_nsf_trainc(SfNscArgs a_in) {
         }
 #pragma unroll
         for (int p = 0; p < 8; ++p) G[p] = p < D ? Gn[p] : 0.f;
+        // (the spline's 2 x (3K - 1) parameter registers are not wanted while the LU arrays above are alive)
+        __builtin_amdgcn_sched_barrier(0);
         float q[NQV], dq[NQV];
 #pragma unroll
         for (int jt = 0; jt < OTQ; ++jt) {
@@ -720,6 +805,7 @@ __global__ __launch_bounds__(256, 2) void k_nsf_trainc(SfNscArgs a_in) {
           G[2 * g] = (on && start == 0) ? vg : G[2 * g];
           G[2 * g + 1] = (on && start == 1) ? vg : G[2 * g + 1];
         }
+        st8(0, G);
       }
       n_barrier();
       SF_NC(42 + 10 * (T - 1 - t));
@@ -731,53 +817,32 @@ __global__ __launch_bounds__(256, 2) void k_nsf_trainc(SfNscArgs a_in) {
           n_dw_jobs(A, B, two, mode, lane);
         }
       };
-      // data product of the backward sweep: acc[q] = W^T[j][:] . X[:][q] over nk tiles (the last with kcl components)
-      auto bwd_mm = [&](int o_wT, const float* X, f32x4& acc0, f32x4& acc1) {
-        float4 wf[NT];
+      // Phases B1 .. B6: the phase's transposed fragments are requested first, then the weight-gradient blocks of the layer
+      // above run (LDS operands only: they cover the fragments' L2 round trip, and their stores / atomics are issued AFTER
+      // the loads, so that waiting for the fragments never waits for a store acknowledgement), then the data product.
+      auto ld_hidT = [&](int o_wT, float4 (&W)[NT]) {
+        if (has) {
 #pragma unroll
-        for (int ot = 0; ot < NT; ++ot) wf[ot] = n_frag(tp + o_wT, NT, j, ot, lane);
+          for (int ot = 0; ot < NT; ++ot) W[ot] = n_frag(tp + o_wT, NT, j, ot, lane);
+        }
+      };
+      auto go_hidT = [&](const float4 (&W)[NT], const float* X, f32x4& acc0, f32x4& acc1) {
         acc0 = n_zero();
         acc1 = n_zero();
 #pragma unroll
         for (int ot = 0; ot < NT; ++ot) {
           const f32x4 i0 = n_ld4(X + (ot * NQ + 0) * PBT + pbo), i1 = n_ld4(X + (ot * NQ + 1) * PBT + pbo);
-          n_mma2(wf[ot], i0, i1, acc0, acc1, ot == NT - 1 ? kc_h : 4);
+          n_mma2(W[ot], i0, i1, acc0, acc1, ot == NT - 1 ? kc_h : 4);
         }
-      };
-      auto put2 = [&](float* X, const f32x4 v0, const f32x4 v1) {
-        n_st4(X + (j * NQ + 0) * PBT + pbo, v0);
-        n_st4(X + (j * NQ + 1) * PBT + pbo, v1);
-      };
-      auto putT2 = [&](float* Tb, const f32x4 v0, const f32x4 v1) {
-        n_put_T(Tb + (j * NQ + 0) * TT, v0, s, g4);
-        n_put_T(Tb + (j * NQ + 1) * TT, v1, s, g4);
       };
       f32x4 dh[2];
       // B1: dh2 = Wout^T dq; deltas of block 1's second layer and gate; weight gradients of the head and of LULinear
-      if (has) {
-        float4 wf[OTQ];
-#pragma unroll
-        for (int ot = 0; ot < OTQ; ++ot) wf[ot] = n_frag(tp + c.o_woutT, OTQ, j, ot, lane);
-        dh[0] = n_zero();
-        dh[1] = n_zero();
-#pragma unroll
-        for (int ot = 0; ot < OTQ; ++ot) {
-          const f32x4 i0 = n_ld4(XQ + (ot * NQ + 0) * PBT + pbo), i1 = n_ld4(XQ + (ot * NQ + 1) * PBT + pbo);
-          n_mma2(wf[ot], i0, i1, dh[0], dh[1], 4);
-        }
-        f32x4 d2[2], dgt[2];
-#pragma unroll
-        for (int qq = 0; qq < 2; ++qq)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            d2[qq][r] = dh[qq][r] * sgb[qq][r];
-            dgt[qq][r] = dh[qq][r] * t2b[qq][r] * sgb[qq][r] * (1.f - sgb[qq][r]);
-          }
-        put2(XB, d2[0], d2[1]);
-        put2(XG, dgt[0], dgt[1]);
-        putT2(TI, n_relu(t1b[0]), n_relu(t1b[1]));
-      }
       {
+        float4 wf[OTQ];
+        if (has) {
+#pragma unroll
+          for (int ot = 0; ot < OTQ; ++ot) wf[ot] = n_frag(tp + c.o_woutT, OTQ, j, ot, lane);
+        }
         const int nw = OTQ * NT;
         run_jobs(nw + 2, [&](int n) -> NJob {
           if (n < nw) {
@@ -787,6 +852,26 @@ __global__ __launch_bounds__(256, 2) void k_nsf_trainc(SfNscArgs a_in) {
           const int b = n - nw;
           return NJob{XL, TL, gp + c.g_lu + b * 256, b == 0 ? gp + c.g_lu + 512 : nullptr, b, b};
         });
+        if (has) {
+          dh[0] = n_zero();
+          dh[1] = n_zero();
+#pragma unroll
+          for (int ot = 0; ot < OTQ; ++ot) {
+            const f32x4 i0 = n_ld4(XQ + (ot * NQ + 0) * PBT + pbo), i1 = n_ld4(XQ + (ot * NQ + 1) * PBT + pbo);
+            n_mma2(wf[ot], i0, i1, dh[0], dh[1], 4);
+          }
+          f32x4 d2[2], dgt[2];
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              d2[qq][r] = dh[qq][r] * sgb[qq][r];
+              dgt[qq][r] = dh[qq][r] * t2b[qq][r] * sgb[qq][r] * (1.f - sgb[qq][r]);
+            }
+          put2(XB, d2[0], d2[1]);
+          put2(XG, dgt[0], dgt[1]);
+          putT2(TI, n_relu(t1b[0]), n_relu(t1b[1]));
+        }
       }
       n_barrier();
       SF_NC(43 + 10 * (T - 1 - t));
@@ -799,24 +884,9 @@ __global__ __launch_bounds__(256, 2) void k_nsf_trainc(SfNscArgs a_in) {
         const int g_wg = k ? c.g_wg[1] : c.g_wg[0], g_bg = k ? c.g_bg[1] : c.g_bg[0];
         const int g_w1 = k ? c.g_w1[1] : c.g_w1[0], g_b1 = k ? c.g_b1[1] : c.g_b1[0];
         // B2 / B4: delta of the block's first layer; weight gradients of its second layer and of its gate
-        if (has) {
-          f32x4 a0, a1;
-          bwd_mm(o_w2T, XB, a0, a1);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            a0[r] = (k ? t1b[0][r] : t1[0][r]) > 0.f ? a0[r] : 0.f;
-            a1[r] = (k ? t1b[1][r] : t1[1][r]) > 0.f ? a1[r] : 0.f;
-          }
-          put2(XA, a0, a1);
-          // the block's input, transposed, for the first layer's weight gradient: relu(h1) (block 1) / relu(h0) (block 0)
-          f32x4 hin[2];
-#pragma unroll
-          for (int qq = 0; qq < 2; ++qq)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hin[qq][r] = fmaxf(k ? h0[qq][r] + t2[qq][r] * sg[qq][r] : h0[qq][r], 0.f);
-          putT2(TI2, hin[0], hin[1]);
-        }
         {
+          float4 wf[NT];
+          ld_hidT(o_w2T, wf);
           const int n2 = NT * NT;
           run_jobs(n2 + NT * NI, [&](int n) -> NJob {
             if (n < n2) {
@@ -827,59 +897,95 @@ __global__ __launch_bounds__(256, 2) void k_nsf_trainc(SfNscArgs a_in) {
             const int ot = m / NI, it = m - ot * NI;
             return NJob{XG, TIN, gp + g_wg + m * 256, it == 0 ? gp + g_bg : nullptr, ot, it};
           });
+          if (has) {
+            f32x4 a0, a1;
+            go_hidT(wf, XB, a0, a1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              a0[r] = (k ? t1b[0][r] : t1[0][r]) > 0.f ? a0[r] : 0.f;
+              a1[r] = (k ? t1b[1][r] : t1[1][r]) > 0.f ? a1[r] : 0.f;
+            }
+            put2(XA, a0, a1);
+            // the block's input, transposed, for the first layer's weight gradient: relu(h1) (block 1) / relu(h0) (block 0)
+            f32x4 hin[2];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) hin[qq][r] = fmaxf(k ? h0[qq][r] + t2[qq][r] * sg[qq][r] : h0[qq][r], 0.f);
+            putT2(TI2, hin[0], hin[1]);
+          }
         }
         n_barrier();
         // B3 / B5: gradient at the block's input; (block 1) deltas of block 0's second layer and gate; weight gradients
         // of the block's first layer
-        if (has) {
-          f32x4 a0, a1;
-          bwd_mm(o_w1T, XA, a0, a1);
-#pragma unroll
-          for (int qq = 0; qq < 2; ++qq)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float hin = k ? h0[qq][r] + t2[qq][r] * sg[qq][r] : h0[qq][r];
-              const float av = qq ? a1[r] : a0[r];
-              dh[qq][r] += hin > 0.f ? av : 0.f;
-            }
-          if (k == 1) {
-            f32x4 d2[2], dgt[2];
+        {
+          float4 wf[NT];
+          ld_hidT(o_w1T, wf);
+          run_jobs(NT * NT, [&](int n) -> NJob {
+            const int ot = n / NT, it = n - ot * NT;
+            return NJob{XA, TI2, gp + g_w1 + n * 256, it == 0 ? gp + g_b1 : nullptr, ot, it};
+          });
+          if (has) {
+            f32x4 a0, a1;
+            go_hidT(wf, XA, a0, a1);
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                d2[qq][r] = dh[qq][r] * sg[qq][r];
-                dgt[qq][r] = dh[qq][r] * t2[qq][r] * sg[qq][r] * (1.f - sg[qq][r]);
+                const float hin = k ? h0[qq][r] + t2[qq][r] * sg[qq][r] : h0[qq][r];
+                const float av = qq ? a1[r] : a0[r];
+                dh[qq][r] += hin > 0.f ? av : 0.f;
               }
-            put2(XB, d2[0], d2[1]);
-            put2(XG, dgt[0], dgt[1]);
-            putT2(TI, n_relu(t1[0]), n_relu(t1[1]));
-          } else {
-            put2(XB, dh[0], dh[1]);  // delta of the initial layer
+            if (k == 1) {
+              f32x4 d2[2], dgt[2];
+#pragma unroll
+              for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  d2[qq][r] = dh[qq][r] * sg[qq][r];
+                  dgt[qq][r] = dh[qq][r] * t2[qq][r] * sg[qq][r] * (1.f - sg[qq][r]);
+                }
+              put2(XB, d2[0], d2[1]);
+              put2(XG, dgt[0], dgt[1]);
+              putT2(TI, n_relu(t1[0]), n_relu(t1[1]));
+            } else {
+              put2(XB, dh[0], dh[1]);  // delta of the initial layer
+            }
           }
         }
-        run_jobs(NT * NT, [&](int n) -> NJob {
-          const int ot = n / NT, it = n - ot * NT;
-          return NJob{XA, TI2, gp + g_w1 + n * 256, it == 0 ? gp + g_b1 : nullptr, ot, it};
-        });
         n_barrier();
       }
       SF_NC(44 + 10 * (T - 1 - t));
-      // B6: partial sums of Win^T delta over my hidden tile (operand straight from registers); weight gradients of Win
-      if (has) {
-        const float4 w = n_frag(tp + c.o_winT, NT, 0, j, lane);
-        f32x4 p0 = n_zero(), p1 = n_zero();
-        n_mma2(w, dh[0], dh[1], p0, p1, j == NT - 1 ? kc_h : 4);
-        put2(XA, p0, p1);
+      // B6: partial sums of Win^T delta over my hidden tile (operand straight from registers); weight gradients of Win;
+      // spline waves: u / u' of the transform below (used in B7 and in its backward sweep)
+      {
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has) w = n_frag(tp + c.o_winT, NT, 0, j, lane);
+        float4 s0 = w, s1 = w, s2 = w, s3 = w;
+        run_jobs(NT * NI, [&](int n) -> NJob {
+          const int ot = n / NI, it = n - ot * NI;
+          return NJob{XB, TIN, gp + c.g_win + n * 256, it == 0 ? gp + c.g_bin : nullptr, ot, it};
+        });
+        if (spl && t > 0) {
+          const float4* srcp = reinterpret_cast<const float4*>(ust + (t - 1) * 16);
+          s0 = srcp[0]; s1 = srcp[1]; s2 = srcp[2]; s3 = srcp[3];
+        }
+        if (has) {
+          f32x4 p0 = n_zero(), p1 = n_zero();
+          n_mma2(w, dh[0], dh[1], p0, p1, j == NT - 1 ? kc_h : 4);
+          put2(XA, p0, p1);
+        }
+        if (spl && t > 0 && g4 == 0) {   // u / u' of the transform below -> my sample's state
+          *reinterpret_cast<float4*>(sst + 8) = s0; *reinterpret_cast<float4*>(sst + 12) = s1;
+          *reinterpret_cast<float4*>(sst + 16) = s2; *reinterpret_cast<float4*>(sst + 20) = s3;
+        }
       }
-      run_jobs(NT * NI, [&](int n) -> NJob {
-        const int ot = n / NI, it = n - ot * NI;
-        return NJob{XB, TIN, gp + c.g_win + n * 256, it == 0 ? gp + c.g_bin : nullptr, ot, it};
-      });
       n_barrier();
       SF_NC(45 + 10 * (T - 1 - t));
       // B7 (spline waves): dL/du of the transform below = what came through the spline / the identity + Win^T delta
       if (spl) {
+        float G[8];
+        ld8(0, G);
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
@@ -889,11 +995,8 @@ __global__ __launch_bounds__(256, 2) void k_nsf_trainc(SfNscArgs a_in) {
             G[2 * g + 1] += v.y;
           }
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-          G[p] = p < D ? G[p] : 0.f;
-          ui[p] = nui[p];
-          up[p] = nup[p];
-        }
+        for (int p = 0; p < 8; ++p) G[p] = p < D ? G[p] : 0.f;
+        st8(0, G);
       }
     }
     n_barrier();  // the last reads of XA / XIN are done before the next chunk's inputs are written
@@ -905,7 +1008,7 @@ __global__ __launch_bounds__(256, 2) void k_nsf_trainc(SfNscArgs a_in) {
 size_t sf_nsfc_lds_bytes(const SfNscDev& c) {
   const size_t pb = (size_t)(c.NI + 3 * c.NT + c.OTQ + 2) * 2 * PBT;
   const size_t tt = (size_t)(c.NI + 2 * c.NT + 2) * 2 * TT;
-  return (pb + tt + 160) * sizeof(float);
+  return (pb + tt + 160 + 2 * 16 * 24) * sizeof(float);
 }
 
 bool sf_nsfc_eligible(const SfLayout& L, bool want_dctx) {

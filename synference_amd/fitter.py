@@ -482,9 +482,13 @@ class SBI_Fitter:
             X = X[None, :]
         # Under an initialised process group (one process per GPU) the catalogue is sharded: rank r samples rows
         # [r N / W, (r+1) N / W) -- rows are independent (ref: sbi_runner.py:6438-6442), weights are replicated, there is no
-        # data-path collective -- and the blocks are gathered so that every rank returns the whole array.  The random
-        # streams are keyed by the row's position in the catalogue: the result is the single-process one, bit for bit.
-        from .posterior import all_gather_rows, broadcast_seed, dist_world, shard_bounds
+        # data-path collective -- and the blocks are gathered afterwards.  ``gather`` (keyword): "rank0" (default) -- rank 0
+        # returns the whole (N, S, D) array, every other rank its own block (rows ``self.last_shard_rows``): ONE copy of the
+        # array exists (configs[4]: 3.2 GB; all ranks holding it would move 8 x that over xGMI); "all" -- every rank returns
+        # the whole array; "none" -- every rank keeps its block.  The random streams are keyed by the row's position in the
+        # catalogue: the gathered result is the single-process one, bit for bit.
+        from .hostio import to_host_f64
+        from .posterior import all_gather_rows, broadcast_seed, dist_world, gather_rows, shard_bounds
         rank, world = dist_world()
         if world > 1 and len(X) >= world and kwargs.get("shard", True):
             if seed is None:
@@ -499,8 +503,12 @@ class SBI_Fitter:
                 per = (time.time() - t0) / max(1, b[rank + 1] - b[rank])
                 self.last_times_per_object = np.full(b[rank + 1] - b[rank], per)
                 self.last_time_per_object = float(per)
-            full = all_gather_rows(local, b)
-            return full.double().cpu().numpy()
+            self.last_shard_rows = (int(b[rank]), int(b[rank + 1]))
+            how = kwargs.get("gather", "rank0")
+            if how not in ("rank0", "all", "none"):
+                raise ValueError("gather must be 'rank0', 'all' or 'none'")
+            full = all_gather_rows(local, b) if how == "all" else (gather_rows(local, b, dst=0) if how == "rank0" else None)
+            return to_host_f64(full if full is not None else local)
         # log_times: the reference times every object (sbi_runner.py:6438-6469: median and 16th-84th percentile of the
         # per-object wall time); the catalogue call is timed in chunks instead and each chunk's time is shared equally
         # by its objects, so the three statistics keep their meaning without a per-galaxy host loop
@@ -508,7 +516,8 @@ class SBI_Fitter:
         if seed is None and n_chunks > 1:
             seed = posteriors._next_seed(None)
         bounds = np.linspace(0, len(X), n_chunks + 1).astype(int)
-        samples = np.full((len(X), num_samples, len(self.fitted_parameter_names)), np.nan)
+        # (uninitialised: every chunk either fills its rows or, on failure, sets them to NaN below)
+        samples = np.empty((len(X), num_samples, len(self.fitted_parameter_names)), dtype=np.float64)
         times = []
         for ci in range(n_chunks):
             a, b = int(bounds[ci]), int(bounds[ci + 1])
@@ -520,14 +529,13 @@ class SBI_Fitter:
                 tmo = float(timeout_seconds_per_test) * (b - a) if timeout_seconds_per_test else None
                 # (same seed, rows keyed by their position: the draws do not depend on the timing chunks)
                 s = posteriors.sample_catalogue(torch.as_tensor(X[a:b]), num_samples, seed, timeout_seconds=tmo, row_offset=a)
-                # D2H in float32 through a pinned buffer (half the PCIe bytes of a device-side .double()),
-                # widened to the reference's float64 container on the host
-                host = torch.empty(s.shape, dtype=torch.float32, pin_memory=True)
-                host.copy_(s, non_blocking=True)
-                torch.cuda.current_stream(s.device).synchronize()
-                samples[a:b] = host.double().numpy()
+                # D2H in float32 (half the PCIe bytes of a device-side .double()) through a ring of pinned staging buffers
+                # on a copy stream, widened into the reference's float64 container by a thread pool while the next piece
+                # is on the bus (hostio.py)
+                to_host_f64(s, out=samples[a:b])
             except Exception as e:  # sbi_runner.py:6458-6460: failed objects are NaN rows
                 logger.error(f"Error occurred while sampling objects {a}..{b}: {e}")
+                samples[a:b] = np.nan
             times.extend([(time.time() - t0) / (b - a)] * (b - a))
         if log_times and times:
             self.last_times_per_object = np.asarray(times)

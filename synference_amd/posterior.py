@@ -399,6 +399,32 @@ def all_gather_rows(local: torch.Tensor, bounds):
     return out.to(local.device)
 
 
+def gather_rows(local: torch.Tensor, bounds, dst: int = 0):
+    """Rank ``dst`` receives the whole array (rows [bounds[r], bounds[r+1]) from rank r) and returns it; every other rank
+    returns None.  For the big outputs -- (N, S, D) draws: 3.2 GB for BASELINE configs[4] -- of which one copy on one rank is
+    what the caller wants (per-rank slices, gathered once), where all_gather_rows would move world x the array
+    over xGMI to hold world identical copies."""
+    import torch.distributed as dist
+    rank, world = dist_world()
+    if world == 1:
+        return local
+    sizes = [bounds[r + 1] - bounds[r] for r in range(world)]
+    mx = max(sizes)
+    nccl = dist.get_backend() == "nccl"
+    src = local if nccl else local.cpu()
+    if sizes[rank] == mx:
+        pad = src.contiguous()
+    else:
+        pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=src.device)
+        pad[: sizes[rank]] = src
+    parts = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, parts, dst=dst)
+    if rank != dst:
+        return None
+    out = torch.cat([parts[r][: sizes[r]] for r in range(world)], 0)
+    return out.to(local.device)
+
+
 def broadcast_seed(seed):
     """The same seed on every rank (rank 0's: a call with seed=None draws one from the posterior's own counter)."""
     import torch.distributed as dist

@@ -44,11 +44,13 @@ def build(kind):
 
 def run(f, x, theta):
     X, Y = x[2000:2101], theta[2000:2101]            # 101 rows: the blocks of two ranks differ in length
-    s = f.sample_posterior(X, num_samples=64, seed=17)
+    s = f.sample_posterior(X, num_samples=64, seed=17)     # under a process group: rank 0 the whole array, others their block
+    s_all = f.sample_posterior(X, num_samples=64, seed=17, gather="all") if dist.is_initialized() else s
     lp = f.log_prob(X, Y, num_rejection_samples=512)
     import pandas as pd
     tab = f.fit_catalogue(pd.DataFrame(X, columns=list(f.feature_names)), num_samples=128, seed=9, append_to_input=False)
-    return {"samples": s, "lp": lp, "table": tab.to_numpy(float)}
+    return {"samples": s, "samples_all": s_all, "lp": lp, "table": tab.to_numpy(float),
+            "rows": getattr(f, "last_shard_rows", (0, len(X)))}
 
 
 def main():

@@ -469,13 +469,17 @@ def test_create_features_from_observations_follows_the_reference_rules():
 def _shard_worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from synference_amd.posterior import all_gather_rows, broadcast_seed, dist_world, shard_bounds
+    from synference_amd.posterior import all_gather_rows, broadcast_seed, dist_world, gather_rows, shard_bounds
     assert dist_world() == (rank, world)
     full = torch.arange(7 * 3 * 2, dtype=torch.float32).reshape(7, 3, 2)      # 7 rows over 2 ranks: blocks of 3 and 4
     b = shard_bounds(7, world)
     got = all_gather_rows(full[b[rank]:b[rank + 1]].clone(), b)
     seed = broadcast_seed(1234 if rank == 0 else 999)
     vec = all_gather_rows(torch.arange(b[rank], b[rank + 1], dtype=torch.float32), b)  # 1-D payload (log_prob)
+    one = gather_rows(full[b[rank]:b[rank + 1]].clone(), b, dst=0)            # rank 0 only holds the whole array
+    assert (one is None) == (rank != 0)
+    if rank == 0:
+        assert torch.equal(one, full)
     ret[rank] = (got.clone(), seed, b, vec.clone())
     dist.destroy_process_group()
 

@@ -204,7 +204,14 @@ def test_rank_sharded_catalogue_evaluation_equals_the_single_process_call(tmp_pa
         assert np.isfinite(ref["samples"]).all() and np.isfinite(ref["lp"]).any()   # (-inf: theta outside the box)
         for k in ("samples", "lp", "table"):
             assert np.array_equal(r0[kind][k], ref[k], equal_nan=True), (kind, k, "rank 0 vs single process")
+        # rank 1 keeps its own block of the draws by default (one copy of the big array, on rank 0) ...
+        a1, b1 = r1[kind]["rows"]
+        assert (a1, b1) == (50, 101) and np.array_equal(r1[kind]["samples"], ref["samples"][a1:b1], equal_nan=True)
+        # ... and the small outputs, and gather="all", are the whole thing on every rank
+        for k in ("lp", "table"):
             assert np.array_equal(r1[kind][k], ref[k], equal_nan=True), (kind, k, "rank 1 vs single process")
+        for r in (r0, r1):
+            assert np.array_equal(r[kind]["samples_all"], ref["samples"], equal_nan=True)
     # and the draws of a block do not depend on how the catalogue is cut: rows 40..60 alone, keyed by their position
     f, x, theta = shard_child.build("maf")
     whole = f.posteriors.sample_catalogue(torch.as_tensor(x[2000:2101]), 64, 17)
