@@ -95,6 +95,13 @@ class FlowSpec:
     def has_lu(self) -> bool:
         return self.kind == "nsf" and self.D > 1
 
+    @property
+    def nsf_1d(self) -> bool:
+        """[UPSTREAM] sbi build_nsf, `if x_numel == 1`: the coupling mask is [1] in EVERY transform (the single dimension is
+        always transformed, nothing is left to condition on) and the spline parameters come from the context alone through
+        ContextSplineMap; reached through the same load_nde_sbi call (ref: sbi_runner.py:5121-5146) for a one-parameter fit."""
+        return self.kind == "nsf" and self.D == 1
+
 
 def standardize_stats(theta: np.ndarray, x: np.ndarray) -> Dict[str, np.ndarray]:
     """z-score buffers as sbi builds them: unbiased std, clamped.
@@ -127,6 +134,7 @@ def param_layout(spec: FlowSpec) -> List[Tuple[str, Tuple[int, ...], int]]:
       NSF: Win[H,d_id+C] bin[H] {Wg[H,C] bg[H] W1[H,H] b1[H] W2[H,H] b2[H]}xNB
            Wout[d_tr*(3K-1),H] bout[...]  then (D>1) LU: lower[D(D-1)/2]
            upper[D(D-1)/2] udiag[D] lubias[D]
+      NSF with D = 1: csm.W0[H,C] b0[H] W1[H,H] b1[H] W2[3K-1,H] b2[3K-1]
     cfg1 MAF: 6460 per transform; cfg3 NSF: 18314 per transform.
     """
     out: List[Tuple[str, Tuple[int, ...], int]] = []
@@ -146,6 +154,12 @@ def param_layout(spec: FlowSpec) -> List[Tuple[str, Tuple[int, ...], int]]:
             for k in range(spec.NB):
                 add(p + f"W{k + 1}", (H, H)); add(p + f"b{k + 1}", (H,))
             add(p + "Wf", (2 * D, H)); add(p + "bf", (2 * D,))
+        elif spec.nsf_1d:
+            # sbi build_nsf with a scalar theta: ContextSplineMap(hidden_layers=1) -- Linear(C, H), ReLU, Linear(H, H), ReLU,
+            # Linear(H, 3K - 1) on the embedded context alone; no LULinear
+            add(p + "csm.W0", (H, C)); add(p + "csm.b0", (H,))
+            add(p + "csm.W1", (H, H)); add(p + "csm.b1", (H,))
+            add(p + "csm.W2", (3 * spec.K - 1, H)); add(p + "csm.b2", (3 * spec.K - 1,))
         else:
             idn, tr = spec.nsf_split(t)
             nout = len(tr) * (3 * spec.K - 1)
@@ -278,6 +292,14 @@ def _resnet(spec: FlowSpec, P: Dict[str, torch.Tensor], t: int, u_id: torch.Tens
     return F.linear(h, P[p + "Wout"], P[p + "bout"])
 
 
+def _context_spline_map(spec: FlowSpec, P: Dict[str, torch.Tensor], t: int, e: torch.Tensor) -> torch.Tensor:
+    """[UPSTREAM] sbi ContextSplineMap.__call__: ``spline_predictor(context)``, the inputs are ignored."""
+    p = f"t{t}.csm."
+    h = F.relu(F.linear(e, P[p + "W0"], P[p + "b0"]))
+    h = F.relu(F.linear(h, P[p + "W1"], P[p + "b1"]))
+    return F.linear(h, P[p + "W2"], P[p + "b2"])
+
+
 def _knots(spec: FlowSpec, logits: torch.Tensor, min_size: float) -> Tuple[torch.Tensor, torch.Tensor]:
     """softmax -> min size -> cumsum -> [-B, B] knots; returns (knots[...,K+1], sizes[...,K])."""
     K, B = spec.K, spec.tail_bound
@@ -379,6 +401,11 @@ def forward_transform(spec: FlowSpec, flat: torch.Tensor, theta: torch.Tensor, x
             u = u[:, torch.as_tensor(spec.perms[t])]
     else:
         for t in range(spec.T):
+            if spec.nsf_1d:
+                q = _context_spline_map(spec, P, t, e).view(-1, 1, 3 * spec.K - 1)
+                u, lad = rq_spline(spec, u, q, inverse=False)
+                logdet = logdet + lad.sum(-1)
+                continue
             idn, tr = spec.nsf_split(t)
             q = _resnet(spec, P, t, u[:, idn], e).view(-1, len(tr), 3 * spec.K - 1)
             v, lad = rq_spline(spec, u[:, tr], q, inverse=False)
@@ -426,6 +453,11 @@ def inverse_transform(spec: FlowSpec, flat: torch.Tensor, z: torch.Tensor, x: to
             u = w
     else:
         for t in reversed(range(spec.T)):
+            if spec.nsf_1d:
+                q = _context_spline_map(spec, P, t, e).view(-1, 1, 3 * spec.K - 1)
+                u, lad = rq_spline(spec, u, q, inverse=True)
+                logdet = logdet + lad.sum(-1)
+                continue
             idn, tr = spec.nsf_split(t)
             if spec.has_lu:
                 L, U, diag = _lu_mats(spec, P, t)

@@ -38,7 +38,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int PBT = 272;  // floats of a padded B-layout tile: lane l's float4 at 4 l + 4 (l >> 4)
-constexpr int TT = 256;   // floats of a transposed tile
+constexpr int TT = 272;   // floats of a transposed tile: four sample groups of 68 (64 + 4 of padding: conflict-free writes)
 
 __device__ __forceinline__ f32x4 n_ld4(const float* p) {
   const float4 b = *reinterpret_cast<const float4*>(p);
@@ -78,10 +78,13 @@ __device__ __forceinline__ void n_mma1(const float4 w, const f32x4 in, f32x4& a0
   if (kc > 2) a0 = SF_MFMA16(w.z, in[2], a0);
   if (kc > 3) a1 = SF_MFMA16(w.w, in[3], a1);
 }
-// transposed tile: element (row, sample) at (sample >> 2) * 64 + row * 4 + (sample & 3); lane l = 16 kk + i then reads
-// row i, samples 4 kk .. 4 kk + 3 with one ds_read_b128 at l * 4
+// transposed tile: element (row, sample) at (sample >> 2) * 68 + row * 4 + (sample & 3); lane l = 16 kk + i then reads
+// row i, samples 4 kk .. 4 kk + 3 with one ds_read_b128 at kk * 68 + i * 4.  (68, not 64: the four ds_write_b32 of a lane
+// then hit 4 (s >> 2) + 16 g4 + (s & 3) + 4 r -- 64 different banks; with 64 the lanes s, s + 4, s + 8, s + 12 collided, 37 % of
+// the kernel's LDS cycles were bank conflicts.)
+__device__ __forceinline__ int n_T_rd(int lane) { return (lane >> 4) * 68 + (lane & 15) * 4; }
 __device__ __forceinline__ void n_put_T(float* tile, const f32x4 v, int s, int g4) {
-  float* p = tile + (s >> 2) * 64 + (s & 3) + 16 * g4;
+  float* p = tile + (s >> 2) * 68 + (s & 3) + 16 * g4;
   p[0] = v[0]; p[4] = v[1]; p[8] = v[2]; p[12] = v[3];
 }
 __device__ __forceinline__ float n_sel4(int g, float a, float b, float c, float d) { return g == 0 ? a : (g == 1 ? b : (g == 2 ? c : d)); }
@@ -290,8 +293,8 @@ __device__ __forceinline__ void n_dw_jobs(const NJob& A, const NJob& B, bool two
       const float* dB = B.Xd + (B.ot * 2 + q) * PBT + dofs;
       const float dA0 = dA[0], dA1 = dA[4], dA2 = dA[8], dA3 = dA[12];
       const float dB0 = dB[0], dB1 = dB[4], dB2 = dB[8], dB3 = dB[12];
-      const float4 iA = *reinterpret_cast<const float4*>(A.Ti + (A.it * 2 + q) * TT + lane * 4);
-      const float4 iB = *reinterpret_cast<const float4*>(B.Ti + (B.it * 2 + q) * TT + lane * 4);
+      const float4 iA = *reinterpret_cast<const float4*>(A.Ti + (A.it * 2 + q) * TT + n_T_rd(lane));
+      const float4 iB = *reinterpret_cast<const float4*>(B.Ti + (B.it * 2 + q) * TT + n_T_rd(lane));
       a0 = SF_MFMA16(dA0, iA.x, a0);
       b0 = SF_MFMA16(dB0, iB.x, b0);
       a1 = SF_MFMA16(dA1, iA.y, a1);
@@ -312,7 +315,7 @@ __device__ __forceinline__ void n_dw_jobs(const NJob& A, const NJob& B, bool two
     for (int q = 0; q < 2; ++q) {
       const float* dA = A.Xd + (A.ot * 2 + q) * PBT + dofs;
       const float dA0 = dA[0], dA1 = dA[4], dA2 = dA[8], dA3 = dA[12];
-      const float4 iA = *reinterpret_cast<const float4*>(A.Ti + (A.it * 2 + q) * TT + lane * 4);
+      const float4 iA = *reinterpret_cast<const float4*>(A.Ti + (A.it * 2 + q) * TT + n_T_rd(lane));
       a0 = SF_MFMA16(dA0, iA.x, a0);
       a1 = SF_MFMA16(dA1, iA.y, a1);
       a0 = SF_MFMA16(dA2, iA.z, a0);

@@ -84,8 +84,13 @@ __device__ __forceinline__ void c_mma_alt(const float4 w, const f32x4 in, f32x4&
 //   B layout: lane l holds float4 at l*4 (rows 4*(l>>4)+r of sample l&15): the MFMA B operand of a data product
 //   T layout: [sample >> 2][row][sample & 3]: lane l = 16*kk + i reads float4 at l*4 = row i, samples 4kk..4kk+3:
 //             A / B operand of a weight-gradient product (k = sample)
+//   (round 4: sample groups of 68 floats, not 64 -- TTS = 272 floats per tile: the four ds_write_b32 of a lane then hit
+//   4 (s >> 2) + 16 g4 + (s & 3) + 4 r = 64 different banks; with 64 the lanes s, s + 4, s + 8, s + 12 collided and 41 % of the
+//   kernel's LDS cycles were bank conflicts, profiles/r03_pmc_summary.json)
+#define TTS 272
+__device__ __forceinline__ int c_T_rd(int lane) { return (lane >> 4) * 68 + (lane & 15) * 4; }
 __device__ __forceinline__ void c_put_T(float* tile, const f32x4 v, int s, int g4) {
-  float* p = tile + (s >> 2) * 64 + (s & 3) + 16 * g4;
+  float* p = tile + (s >> 2) * 68 + (s & 3) + 16 * g4;
   p[0] = v[0]; p[4] = v[1]; p[8] = v[2]; p[12] = v[3];
 }
 __device__ __forceinline__ float c_scale(int scale_fn, float av, float eps) {
@@ -127,10 +132,10 @@ __device__ __forceinline__ void c_dw_jobs(const CJob& A, const CJob& B, bool two
   if (two) {  // (two blocks at once: their chains alternate, the 40-cycle dependent latency of the MFMA is hidden)
 #pragma unroll 2
     for (int q = 0; q < NQ; ++q) {  // (two subtiles' operands in flight at a time: 32 registers, not 64)
-      const float4 dA = *reinterpret_cast<const float4*>(A.Td + (A.ot * NQ + q) * 256 + lane * 4);
-      const float4 iA = *reinterpret_cast<const float4*>(A.Ti + (A.it * NQ + q) * 256 + lane * 4);
-      const float4 dB = *reinterpret_cast<const float4*>(B.Td + (B.ot * NQ + q) * 256 + lane * 4);
-      const float4 iB = *reinterpret_cast<const float4*>(B.Ti + (B.it * NQ + q) * 256 + lane * 4);
+      const float4 dA = *reinterpret_cast<const float4*>(A.Td + (A.ot * NQ + q) * TTS + c_T_rd(lane));
+      const float4 iA = *reinterpret_cast<const float4*>(A.Ti + (A.it * NQ + q) * TTS + c_T_rd(lane));
+      const float4 dB = *reinterpret_cast<const float4*>(B.Td + (B.ot * NQ + q) * TTS + c_T_rd(lane));
+      const float4 iB = *reinterpret_cast<const float4*>(B.Ti + (B.it * NQ + q) * TTS + c_T_rd(lane));
       accA = SF_MFMA16(dA.x, iA.x, accA);
       accB = SF_MFMA16(dB.x, iB.x, accB);
       accA = SF_MFMA16(dA.y, iA.y, accA);
@@ -147,8 +152,8 @@ __device__ __forceinline__ void c_dw_jobs(const CJob& A, const CJob& B, bool two
   } else {  // one block: two partial accumulators over alternating k-steps, for the same reason
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const float4 dA = *reinterpret_cast<const float4*>(A.Td + (A.ot * NQ + q) * 256 + lane * 4);
-      const float4 iA = *reinterpret_cast<const float4*>(A.Ti + (A.it * NQ + q) * 256 + lane * 4);
+      const float4 dA = *reinterpret_cast<const float4*>(A.Td + (A.ot * NQ + q) * TTS + c_T_rd(lane));
+      const float4 iA = *reinterpret_cast<const float4*>(A.Ti + (A.it * NQ + q) * TTS + c_T_rd(lane));
       accA = SF_MFMA16(dA.x, iA.x, accA);
       accB = SF_MFMA16(dA.y, iA.y, accB);
       accA = SF_MFMA16(dA.z, iA.z, accA);
@@ -259,14 +264,15 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
   constexpr int HSZ = NT * NQ * 256;     // one hidden-size tensor: NT tiles x NQ subtiles x 256
   float* XBa = lds;                      // B layout: h0 (fwd) / dpre2 (bwd); backward partial sums of du
   float* XBb = XBa + HSZ;                // B layout: a1 (fwd) / dpre1 (bwd)
+  constexpr int HST = NT * NQ * TTS;     // ... in the (padded) T layout
   float* TB0 = XBb + HSZ;                // T layout x5: TD2, TA2 (later TD0), TH0, TD1, TA1; forward: head partial sums
-  float* TD2 = TB0, *TA2 = TB0 + HSZ, *TH0 = TB0 + 2 * HSZ, *TD1 = TB0 + 3 * HSZ, *TA1 = TB0 + 4 * HSZ;
+  float* TD2 = TB0, *TA2 = TB0 + HST, *TH0 = TB0 + 2 * HST, *TD1 = TB0 + 3 * HST, *TA1 = TB0 + 4 * HST;
   float* TD0 = TA2;
   float* PBf = TB0;                      // [NP][NQ] tiles
   float* PBb = XBa;                      // [NP][NQ] tiles
-  float* TDF = TB0 + 5 * HSZ;            // T layout: head delta, 1 tile x NQ
-  float* TIN = TDF + NQ * 256;           // T layout: input tiles, NI tiles x NQ
-  float* USt = TIN + NI * NQ * 256;      // [TS][16*NQ samples][8]: u entering transform t
+  float* TDF = TB0 + 5 * HST;            // T layout: head delta, 1 tile x NQ
+  float* TIN = TDF + NQ * TTS;           // T layout: input tiles, NI tiles x NQ
+  float* USt = TIN + NI * NQ * TTS;      // [TS][16*NQ samples][8]: u entering transform t
   float* ASt = USt + TS * NQ * 128;      // [TS][16*NQ][8]: head output a (slots)
   // constants of the whole call: biases of every transform, the weight-gradient block list, per input-row and
   // per-slot standardisation constants (read from LDS in the phases instead of through dependent global loads)
@@ -543,9 +549,9 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
           in0[0] = s0on ? uu.x : in0[0];
           in0[1] = s1on ? uu.y : in0[1];
           if (p == 0) {
-            c_put_T(TDF + q * 256, dfin, s, g4);
-            c_put_T(TIN + q * 256, in0, s, g4);
-            if constexpr (NI > 1) c_put_T(TIN + (NQ + q) * 256, inx[NI - 1], s, g4);
+            c_put_T(TDF + q * TTS, dfin, s, g4);
+            c_put_T(TIN + q * TTS, in0, s, g4);
+            if constexpr (NI > 1) c_put_T(TIN + (NQ + q) * TTS, inx[NI - 1], s, g4);
           }
           if (has0) {
 #pragma unroll
@@ -556,11 +562,11 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dp2[r] *= 1.0f - a2s[t][k][r] * a2s[t][k][r];
                 c_st4(XBa + (tk * NQ + q) * 256 + lane * 4, dp2);
-                c_put_T(TD2 + (tk * NQ + q) * 256, dp2, s, g4);
-                c_put_T(TA2 + (tk * NQ + q) * 256, a2s[t][k], s, g4);
+                c_put_T(TD2 + (tk * NQ + q) * TTS, dp2, s, g4);
+                c_put_T(TA2 + (tk * NQ + q) * TTS, a2s[t][k], s, g4);
                 f32x4 h0 = c_mma(pwinB[k][0], in0, c_ld4(cb + (tk * 4 + g4) * 4));
                 if constexpr (NI > 1) h0 = c_mma(pwinB[k][NI - 1], inx[NI - 1], h0);
-                c_put_T(TH0 + (tk * NQ + q) * 256, h0, s, g4);
+                c_put_T(TH0 + (tk * NQ + q) * TTS, h0, s, g4);
               }
             }
           }
@@ -598,12 +604,12 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
             accB[r] *= 1.0f - a1s[t][1][r] * a1s[t][1][r];
           }
           c_st4(XBb + (tA * NQ + q) * 256 + lane * 4, accA);
-          c_put_T(TD1 + (tA * NQ + q) * 256, accA, s, g4);
-          c_put_T(TA1 + (tA * NQ + q) * 256, a1s[t][0], s, g4);
+          c_put_T(TD1 + (tA * NQ + q) * TTS, accA, s, g4);
+          c_put_T(TA1 + (tA * NQ + q) * TTS, a1s[t][0], s, g4);
           if (has1) {
             c_st4(XBb + (tB_ * NQ + q) * 256 + lane * 4, accB);
-            c_put_T(TD1 + (tB_ * NQ + q) * 256, accB, s, g4);
-            c_put_T(TA1 + (tB_ * NQ + q) * 256, a1s[t][1], s, g4);
+            c_put_T(TD1 + (tB_ * NQ + q) * TTS, accB, s, g4);
+            c_put_T(TA1 + (tB_ * NQ + q) * TTS, a1s[t][1], s, g4);
           }
         }
         };
@@ -637,10 +643,10 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { accA[r] += accA1[r]; accB[r] += accB1[r]; }
           }
-          c_put_T(TD0 + (tA * NQ + q) * 256, accA, s, g4);
+          c_put_T(TD0 + (tA * NQ + q) * TTS, accA, s, g4);
           f32x4 dup = c_mma(wiT[0], accA, c_zero());
           if (has1) {
-            c_put_T(TD0 + (tB_ * NQ + q) * 256, accB, s, g4);
+            c_put_T(TD0 + (tB_ * NQ + q) * TTS, accB, s, g4);
             dup = c_mma(wiT[1], accB, dup);
           }
           c_st4(PBb + (p * NQ + q) * 256 + lane * 4, dup);
@@ -802,7 +808,7 @@ __global__ __launch_bounds__(256) void k_gather_c2(const float* __restrict__ gpa
 
 size_t sf_trainc_lds_bytes(const SfTrcDev& c, int TS, int NG) {
   const size_t NQ = 2 * (size_t)NG;
-  return ((size_t)c.NT * NQ * 256 * 7 + NQ * 256 + (size_t)c.NI * NQ * 256 + (size_t)TS * NQ * 256 +
+  return ((size_t)c.NT * NQ * (256 * 2 + TTS * 5) + NQ * TTS + (size_t)c.NI * NQ * TTS + (size_t)TS * NQ * 256 +
           (size_t)sf_trc_cb_floats(c.NT, c.NI, TS)) * sizeof(float);
 }
 

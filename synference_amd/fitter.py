@@ -517,7 +517,8 @@ class SBI_Fitter:
             seed = posteriors._next_seed(None)
         bounds = np.linspace(0, len(X), n_chunks + 1).astype(int)
         # (uninitialised: every chunk either fills its rows or, on failure, sets them to NaN below)
-        samples = np.empty((len(X), num_samples, len(self.fitted_parameter_names)), dtype=np.float64)
+        from .hostio import result_array
+        samples = result_array((len(X), num_samples, len(self.fitted_parameter_names)))
         times = []
         for ci in range(n_chunks):
             a, b = int(bounds[ci]), int(bounds[ci + 1])

@@ -65,7 +65,41 @@ def _get_ring(n_buf: int, nbytes: int) -> "list[torch.Tensor]":
         return _ring[:n_buf]
 
 
-def to_host_f64(dev: torch.Tensor, out: Optional[np.ndarray] = None, chunk_mb: float = 4.0, n_buf: int = 4,
+# ---- result buffers -------------------------------------------------------------------------------------------------
+# A fresh 80 MB numpy array costs ~6 ms of first-touch page faults (mmap'd by malloc, zeroed by the kernel page by page)
+# -- four times the kernel that draws the samples -- and glibc hands such blocks back to the OS on free (its mmap threshold
+# tops out at 32 MB), so every call would pay again.  The arrays handed to callers are therefore remembered here, and one
+# of them is handed out again ONLY when nothing outside this list refers to it any more (the caller dropped the previous
+# result: reference count of the list entry alone).  A result a caller still holds -- or any view of it -- is never touched.
+_results: "list[np.ndarray]" = []
+_RESULTS_MAX = 3
+_RESULTS_MAX_BYTES = 2 << 30
+
+
+def result_array(shape) -> np.ndarray:
+    """Uninitialised float64 C-contiguous array of ``shape``: a recycled result buffer when one is free, else new."""
+    import sys
+    shape = tuple(int(v) for v in shape)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * 8
+    if os.environ.get("SF_HOSTIO_POOL", "1") == "0" or nbytes < (8 << 20):
+        return np.empty(shape, dtype=np.float64)
+    with _lock:
+        for i in range(len(_results)):
+            # references: the list slot + getrefcount's own argument = 2 when nobody else holds the array or a view of it
+            if _results[i].nbytes == nbytes and sys.getrefcount(_results[i]) == 2:
+                arr = _results.pop(i)
+                arr.shape = shape
+                _results.append(arr)
+                return arr
+        arr = np.empty(shape, dtype=np.float64)
+        if nbytes <= _RESULTS_MAX_BYTES:
+            _results.append(arr)
+            while len(_results) > _RESULTS_MAX or sum(a.nbytes for a in _results) > _RESULTS_MAX_BYTES:
+                _results.pop(0)
+        return arr
+
+
+def to_host_f64(dev: torch.Tensor, out: Optional[np.ndarray] = None, chunk_mb: float = 8.0, n_buf: int = 4,
                 workers: Optional[int] = None) -> np.ndarray:
     """float64 host copy of a float32 tensor (any shape, first axis = rows), bit-identical to
     ``dev.double().cpu().numpy()``.  ``out``: optional float64 C-contiguous array of the same shape to fill."""
@@ -73,7 +107,7 @@ def to_host_f64(dev: torch.Tensor, out: Optional[np.ndarray] = None, chunk_mb: f
         raise ValueError("to_host_f64 takes a float32 tensor")
     shape = tuple(dev.shape)
     if out is None:
-        out = np.empty(shape, dtype=np.float64)
+        out = result_array(shape)
     elif out.shape != shape or out.dtype != np.float64 or not out.flags.c_contiguous:
         raise ValueError("out must be a C-contiguous float64 array of the tensor's shape")
     if dev.numel() == 0:

@@ -66,6 +66,12 @@ class FlowSpec:
     def has_lu(self) -> bool:
         return self.kind == "nsf" and self.D > 1
 
+    @property
+    def nsf_1d(self) -> bool:
+        """One-parameter NSF: sbi's build_nsf transforms the single dimension in every block and takes the spline
+        parameters from a context-only MLP (ContextSplineMap: Linear, ReLU, Linear, ReLU, Linear); no LULinear."""
+        return self.kind == "nsf" and self.D == 1
+
     def to_dict(self) -> dict:
         d = {k: getattr(self, k) for k in ("kind", "D", "C", "H", "T", "K", "NB", "tail_bound", "min_bin_width",
                                            "min_bin_height", "min_derivative", "maf_eps", "lu_eps", "scale_fn", "hidden_bf16")}
@@ -106,6 +112,9 @@ def param_layout(spec: FlowSpec) -> List[Tuple[str, Tuple[int, ...], int]]:
             for k in range(spec.NB):
                 add(p + f"W{k + 1}", (H, H)); add(p + f"b{k + 1}", (H,))
             add(p + "Wf", (2 * D, H)); add(p + "bf", (2 * D,))
+        elif spec.nsf_1d:
+            add(p + "csm.W0", (H, Cc)); add(p + "csm.b0", (H,)); add(p + "csm.W1", (H, H)); add(p + "csm.b1", (H,))
+            add(p + "csm.W2", (3 * spec.K - 1, H)); add(p + "csm.b2", (3 * spec.K - 1,))
         else:
             idn, tr = spec.nsf_split(t)
             nout = len(tr) * (3 * spec.K - 1)
