@@ -436,10 +436,33 @@ def main():
                 unf32 += sample_step(k, False)
             barrier_sync(world)
             t32 = max_over_ranks(time.perf_counter() - t0, world, dev, gloo)
+            # what the split-bf16 hidden blocks cost in the units of the contract: the same seed drawn by both samplers,
+            # both sets re-scored by the fp32 density kernel (sf_flow_log_prob).  Draws whose accepted attempt differs (a
+            # candidate within rounding of the box edge) are different draws and are counted, not compared.
+            ng = min(M, 256)
+            oa = torch.empty((ng, S, D), dtype=torch.float32, device=dev)
+            ob = torch.empty_like(oa)
+            flow.sample(X[:ng], S, lo, hi, seed=4242, out=ob)             # fp32 kernels (switch is on)
+            _sflib.load().sf_set_sampler_fp32(0)
+            flow.sample(X[:ng], S, lo, hi, seed=4242, out=oa)             # default: split-bf16 x3 hidden blocks
+            _sflib.load().sf_set_sampler_fp32(1)
+            sig = torch.as_tensor(np.asarray(est.spec.theta_std), dtype=torch.float32, device=dev)
+            dth = ((oa - ob).abs() / sig).amax(-1)                        # (ng, S) in units of the parameter std
+            same = dth < 1e-3
+            xr = X[:ng].repeat_interleave(S, 0)
+            lpa = flow.log_prob(oa.reshape(-1, D), xr).reshape(ng, S)
+            lpb = flow.log_prob(ob.reshape(-1, D), xr).reshape(ng, S)
+            dlp = (lpa - lpb).abs()[same]
+            split_cost = {"draws_compared": int(same.sum().item()), "draws_with_a_different_accepted_attempt": int((~same).sum().item()),
+                          "max_abs_dlogp": float(dlp.max().item()), "median_abs_dlogp": float(dlp.median().item()),
+                          "p999_abs_dlogp": float(torch.quantile(dlp.float(), 0.999).item()) if dlp.numel() < 16_000_000 else None,
+                          "max_dtheta_over_sigma": float(dth[same].max().item()),
+                          "note": "same seed through the default (split-bf16 x3 hidden blocks) and the all-fp32 sampler kernels; "
+                                  "|d log_prob| of the two draws under the fp32 density kernel; north_star tolerance 1e-4"}
             fp32_leg = {"kernel": ("k_sample_persist<MafOps>" if wl["kind"] == "maf" else "k_sample_persist<NsfOps<..., BF = 0>>") +
                                   " (32-row tiles, v_mfma_f32_32x32x2_f32 everywhere)",
                         "ms_per_step": 1e3 * t32 / n32, "value": (world * n32 * M * S - unf32 * world) / t32,
-                        "unit": "samples/s", "steps": n32}
+                        "unit": "samples/s", "steps": n32, "split_bf16_cost": split_cost}
         finally:
             _sflib.load().sf_set_sampler_fp32(0)
         note(f"fp32 sampler leg: {fp32_leg['ms_per_step']:.3f} ms/step")

@@ -11,6 +11,7 @@
 
 #include "sf_internal.h"
 #include "sf_train.h"
+#include "sf_nsf1.h"
 #include "sf_nsfc.h"
 #include "sf_trainc.h"
 
@@ -32,6 +33,15 @@ int hip_fail(hipError_t e, const char* what) {
 }  // namespace
 
 static int ensure_device(sf_flow* f) {
+  if (f->nsf1) {
+    if (f->dev_ready) return SF_OK;
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd == 0) return fail(SF_ERR_NO_DEVICE, "no HIP device visible");
+    hipError_t e = hipMalloc(&f->d_flat, (size_t)f->L.n_params * sizeof(float));
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(d_flat)");
+    f->dev_ready = true;
+    return SF_OK;
+  }
   if (f->dev_ready) return SF_OK;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
@@ -85,8 +95,21 @@ int sf_device_count(void) {
 
 int sf_flow_create(const sf_flow_desc* desc, sf_flow** out) {
   if (!desc || !out) return fail(SF_ERR_INVALID, "null argument");
-  if (desc->kind == SF_NSF && desc->D < 2)
-    return fail(SF_ERR_INVALID, "NSF needs D >= 2 (the 1-D ContextSplineMap variant is not built)");
+  if (desc->kind == SF_NSF && desc->D == 1) {  // sbi's ContextSplineMap flow (sf_nsf1.hip)
+    sf_flow* f1 = new sf_flow();
+    std::string err;
+    int rc = sf_nsf1_create(*desc, &f1->nsf1, err);
+    if (rc) { delete f1; return fail(rc, err); }
+    std::memset(&f1->L.dev, 0, sizeof(f1->L.dev));
+    std::memset(&f1->L.trc, 0, sizeof(f1->L.trc));
+    std::memset(&f1->L.nsc, 0, sizeof(f1->L.nsc));
+    std::memset(&f1->L.nsfS, 0, sizeof(f1->L.nsfS));
+    SfDev& v = f1->L.dev;
+    v.kind = SF_NSF; v.D = 1; v.C = desc->C; v.H = desc->H; v.T = desc->T; v.K = desc->K; v.NB = desc->NB;
+    f1->L.n_params = (int64_t)desc->T * f1->nsf1->P_mlp;
+    *out = f1;
+    return SF_OK;
+  }
   sf_flow* f = new sf_flow();
   if (!sf_build_layout(*desc, f->L)) {
     std::string e = f->L.error;
@@ -99,6 +122,14 @@ int sf_flow_create(const sf_flow_desc* desc, sf_flow** out) {
 
 void sf_flow_destroy(sf_flow* f) {
   if (!f) return;
+  if (f->nsf1) {
+    sf_nsf1_destroy(f->nsf1);
+    if (f->dev_ready) (void)hipFree(f->d_flat);
+    if (f->ev_train[0]) (void)hipEventDestroy(f->ev_train[0]);
+    if (f->ev_train[1]) (void)hipEventDestroy(f->ev_train[1]);
+    delete f;
+    return;
+  }
   if (f->dev_ready) {
     (void)hipFree(f->d_packed); (void)hipFree(f->d_packedT); (void)hipFree(f->d_cst); (void)hipFree(f->d_packedB); (void)hipFree(f->d_bsrc);
     (void)hipHostFree(f->h_cnt); if (f->ev_train[0]) (void)hipEventDestroy(f->ev_train[0]); if (f->ev_train[1]) (void)hipEventDestroy(f->ev_train[1]); if (f->ev_dense[0]) (void)hipEventDestroy(f->ev_dense[0]); if (f->ev_dense[1]) (void)hipEventDestroy(f->ev_dense[1]);
@@ -229,6 +260,7 @@ int sf_flow_set_params(sf_flow* f, const float* flat, int64_t n, int is_device, 
   SF_HIP(hipMemcpyAsync(f->d_flat, flat, (size_t)n * sizeof(float), is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
   const float* src = f->d_flat;
   f->flat_valid = true;
+  if (f->nsf1) { f->params_set = true; return SF_OK; }   // (the MLP engine re-tiles per call)
   SF_HIP(sf_launch_pack(src, f->d_s1, f->d_s2, f->d_packed, (long)f->L.n_packed, st));
   if (f->d_packed16) SF_HIP(sf_launch_pack(src, f->d_s16a, f->d_s16b, f->d_packed16, (long)f->L.n_packed16, st));
   if (f->d_packed16B) SF_HIP(sf_launch_pack_bf16_split(src, f->d_s16B, f->d_packed16B, (long)f->L.n_packed16B, st));
@@ -257,6 +289,11 @@ int sf_flow_log_prob(sf_flow* f, const float* theta, const float* x, int64_t B, 
   if (!theta || !x || !out) return fail(SF_ERR_INVALID, "null argument");
   if (!f->params_set) return fail(SF_ERR_STATE, "sf_flow_set_params has not been called");
   if (B < 0) return fail(SF_ERR_INVALID, "B < 0");
+  if (f->nsf1) {
+    std::string err;
+    int rc = sf_nsf1_log_prob(f->nsf1, f->d_flat, theta, x, (long)B, out, (hipStream_t)stream, err);
+    return rc ? fail(rc, err) : SF_OK;
+  }
   SF_HIP(sf_launch_logprob(f->dev(), theta, x, (long)B, out, (hipStream_t)stream));
   return SF_OK;
 }
@@ -267,6 +304,11 @@ int sf_flow_inverse_from_noise(sf_flow* f, const float* z, const float* x, int64
   if (B == 0) return SF_OK;
   if (!z || !x || !theta) return fail(SF_ERR_INVALID, "null argument");
   if (!f->params_set) return fail(SF_ERR_STATE, "sf_flow_set_params has not been called");
+  if (f->nsf1) {
+    std::string err;
+    int rc = sf_nsf1_inverse(f->nsf1, f->d_flat, z, x, (long)B, theta, logdet, (hipStream_t)stream, err);
+    return rc ? fail(rc, err) : SF_OK;
+  }
   SfSampleArgsHost a;
   a.x = x; a.z_in = z; a.n_items = (long)B; a.out = theta; a.logdet_out = logdet;
   SF_HIP(sf_launch_inverse(f->dev(), a, (hipStream_t)stream));
@@ -279,6 +321,10 @@ int sf_flow_inverse_from_noise_sampler(sf_flow* f, const float* z, const float* 
   if (B == 0) return SF_OK;
   if (!z || !x || !theta) return fail(SF_ERR_INVALID, "null argument");
   if (!f->params_set) return fail(SF_ERR_STATE, "sf_flow_set_params has not been called");
+  if (f->nsf1) {  // one fp32 path
+    int rc = sf_flow_inverse_from_noise(f, z, x, B, theta, nullptr, stream);
+    return rc ? rc : 1;
+  }
   if (f->L.dev.kind == SF_NSF) {  // NSF: the sampling kernels themselves, on the sampler image when the flow has one
     SfDev ms = f->dev();
     nsf_sampler_view(f, ms);
@@ -305,6 +351,7 @@ int sf_set_sampler_fp32(int on) {
 
 int sf_flow_train_path(const sf_flow* f, int64_t B, int want_dctx) {
   if (!f) return fail(SF_ERR_INVALID, "null handle");
+  if (f->nsf1) return 4;   // MLP engine + scalar spline chain (sf_nsf1.hip)
   if (B > 0 && sf_trainc_eligible(f->L, want_dctx != 0)) return sf_trainc_groups((long)B);
   if (B > 0 && sf_nsfc_eligible(f->L, want_dctx != 0)) return 3;
   return 0;
@@ -333,6 +380,7 @@ int sf_flow_prepare_context(sf_flow* f, const float* x, int64_t M, void* stream)
   if (!x) return fail(SF_ERR_INVALID, "null argument");
   if (M < 0) return fail(SF_ERR_INVALID, "M < 0");
   if (!f->params_set) return fail(SF_ERR_STATE, "sf_flow_set_params has not been called");
+  if (f->nsf1) return SF_OK;   // (its sampler evaluates the conditioner once per row anyway)
   SfDev m = f->dev();
   int R = 0, NV = 0;
   sf_ctab_shape(m, R, NV);
@@ -397,6 +445,7 @@ int sf_flow_sample_round(sf_flow* f, const float* x, int64_t S, const uint32_t* 
                          const float* lo, const float* hi, float* out, uint32_t* rejected,
                          uint32_t* n_rejected, int32_t* n_drawn, void* stream) {
   if (!f || !x || !out || !rejected || !n_rejected) return fail(SF_ERR_INVALID, "null argument");
+  if (f->nsf1) return fail(SF_ERR_INVALID, "sf_flow_sample_round is not offered for the one-parameter NSF: use sf_flow_sample / sf_flow_sample_slots");
   if (!f->params_set) return fail(SF_ERR_STATE, "sf_flow_set_params has not been called");
   if (S < 1 || S > 0x7fffffffll) return fail(SF_ERR_INVALID, "S must be in 1 .. 2^31-1");
   if ((lo == nullptr) != (hi == nullptr)) return fail(SF_ERR_INVALID, "lo and hi must be given together");
@@ -705,6 +754,15 @@ int sf_flow_sample(sf_flow* f, const float* x, int64_t M, int64_t S, const float
   if (M < 0 || S < 1) return fail(SF_ERR_INVALID, "bad M or S");
   if ((lo == nullptr) != (hi == nullptr)) return fail(SF_ERR_INVALID, "lo and hi must be given together");
   hipStream_t st = (hipStream_t)stream;
+  if (f->nsf1) {
+    if (n_drawn) SF_HIP(sf_launch_fill_i32(n_drawn, (long)M, 0, st));
+    uint32_t k0, k1;
+    seed_keys(seed, 0u, k0, k1);
+    std::string err;
+    int rc = sf_nsf1_sample(f->nsf1, f->d_flat, x, (long)M, (long)S, nullptr, (long)(M * S), lo, hi, k0, k1,
+                            (unsigned long long)f->sample_row_offset * (unsigned long long)S, max_attempts, out, n_drawn, n_unfilled, st, err);
+    return rc ? fail(rc, err) : SF_OK;
+  }
   if (n_drawn) SF_HIP(sf_launch_fill_i32(n_drawn, (long)M, (int32_t)S, st));
   return sample_persistent(f, x, M, S, nullptr, M * S, lo, hi, seed, max_attempts, out, n_drawn, n_unfilled, st);
 }
@@ -719,6 +777,15 @@ int sf_flow_sample_slots(sf_flow* f, const float* x, int64_t M, int64_t S, const
   if (!f->params_set) return fail(SF_ERR_STATE, "sf_flow_set_params has not been called");
   if (M < 1 || S < 1 || n_slots < 0 || n_slots > M * S) return fail(SF_ERR_INVALID, "bad M, S or n_slots");
   if ((lo == nullptr) != (hi == nullptr)) return fail(SF_ERR_INVALID, "lo and hi must be given together");
+  if (f->nsf1) {
+    uint32_t k0, k1;
+    seed_keys(seed, 0u, k0, k1);
+    std::string err;
+    int rc = sf_nsf1_sample(f->nsf1, f->d_flat, x, (long)M, (long)S, slots, (long)n_slots, lo, hi, k0, k1,
+                            (unsigned long long)f->sample_row_offset * (unsigned long long)S, max_attempts, out, nullptr, n_unfilled,
+                            (hipStream_t)stream, err);
+    return rc ? fail(rc, err) : SF_OK;
+  }
   return sample_persistent(f, x, M, S, slots, n_slots, lo, hi, seed, max_attempts, out, nullptr, n_unfilled,
                            (hipStream_t)stream);
 }
@@ -737,6 +804,14 @@ int sf_flow_acceptance(sf_flow* f, const float* x, int64_t M, int64_t n, const f
   if ((uint64_t)(M * n) > 0xffffffffull) return fail(SF_ERR_INVALID, "M*n must fit 32 bits");
   hipStream_t st = (hipStream_t)stream;
   SF_HIP(sf_launch_fill_i32(count, (long)M, 0, st));
+  if (f->nsf1) {
+    uint32_t k0, k1;
+    seed_keys(seed, 1u, k0, k1);
+    std::string err;
+    int rc = sf_nsf1_acceptance(f->nsf1, f->d_flat, x, (long)M, (long)n, lo, hi, k0, k1,
+                                (unsigned long long)f->sample_row_offset * (unsigned long long)n, count, st, err);
+    return rc ? fail(rc, err) : SF_OK;
+  }
   SfSampleArgsHost a;
   a.x = x; a.S = (long)n; a.n_items = (long)(M * n); seed_keys(seed, 1u, a.k0, a.k1);
   a.rng_slot_offset = (unsigned long long)f->sample_row_offset * (unsigned long long)n;

@@ -126,8 +126,10 @@ void sf_set_error(const std::string& msg);  // thread-local message behind sf_la
 
 // ---- the handle (shared by sf_api.hip and sf_train.hip) -------------------------------------
 #define SF_MAX_ROUNDS 80
+struct SfNsf1;
 struct sf_flow {
   SfLayout L;
+  SfNsf1* nsf1 = nullptr;       // != null: the one-parameter NSF (sf_nsf1.hip); L then only carries the shape and n_params
   bool dev_ready = false;
   bool params_set = false;
   bool train_ready = false;     // every lazily built training buffer exists (sf_train.hip)

@@ -31,6 +31,7 @@
 #include "sf_device.h"
 #include "sf_internal.h"
 #include "sf_nsfc.h"
+#include "sf_spline_flat.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -88,165 +89,6 @@ __device__ __forceinline__ void n_put_T(float* tile, const f32x4 v, int s, int g
   p[0] = v[0]; p[4] = v[1]; p[8] = v[2]; p[12] = v[3];
 }
 __device__ __forceinline__ float n_sel4(int g, float a, float b, float c, float d) { return g == 0 ? a : (g == 1 ? b : (g == 2 ? c : d)); }
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Rational-quadratic spline with linear tails on a lane-local parameter array ([UPSTREAM] nflows
-// unconstrained_rational_quadratic_spline; the same arithmetic as SfSpline / SfSplineBwd in sf_flows.h, whose numpy twin
-// tests/spline_bwd_model.py is checked against autograd).  Slots: widths [0, KM), heights [KM, 2 KM), derivatives [2 KM, 3 KM - 1).
-// ---------------------------------------------------------------------------------------------------------------------
-struct NSplC {
-  int K;
-  float B, min_w, min_h, min_d, inv_sqrt_h, dconst;
-};
-
-template <int KM, int NQV>
-struct NSpl {
-  // softmax -> knots of one family; p[] = bin probabilities; BY_VALUE: bin = largest k with v >= knot_k, else k == idx
-  template <int OFF, bool BY_VALUE>
-  static __device__ __forceinline__ void family(const NSplC& c, const float (&q)[NQV], float min_size, float v, int& idx,
-                                                float& left, float& size, float (&p)[KM]) {
-    const int K = c.K;
-    float mx = -3.0e38f;
-#pragma unroll
-    for (int k = 0; k < KM; ++k)
-      if (k < K) {
-        p[k] = q[OFF + k] * c.inv_sqrt_h;
-        mx = fmaxf(mx, p[k]);
-      }
-    float sum = 0.f;
-#pragma unroll
-    for (int k = 0; k < KM; ++k)
-      if (k < K) {
-        p[k] = sf_exp(p[k] - mx);
-        sum += p[k];
-      }
-    const float rs = __builtin_amdgcn_rcpf(sum);
-    const float scale = 1.0f - min_size * (float)K;
-    float cs = 0.f, c_lo = -c.B;
-    left = -c.B;
-    size = 1.f;
-    if (BY_VALUE) idx = 0;
-#pragma unroll
-    for (int k = 0; k < KM; ++k)
-      if (k < K) {
-        p[k] *= rs;
-        cs += min_size + scale * p[k];
-        const float c_hi = (k == K - 1) ? c.B : (2.0f * c.B * cs - c.B);
-        const bool sel = BY_VALUE ? (v >= c_lo) : (k == idx);
-        if (sel) {
-          left = c_lo;
-          size = c_hi - c_lo;
-          if (BY_VALUE) idx = k;
-        }
-        c_lo = c_hi;
-      }
-  }
-  // gradient wrt the raw logits of a family given dL/d(left knot) and dL/d(bin size)
-  template <int OFF>
-  static __device__ __forceinline__ void family_bwd(const NSplC& c, const float (&p)[KM], int idx, float L_left, float L_size,
-                                                    float min_size, float (&dq)[NQV]) {
-    const int K = c.K;
-    const float Lc0 = L_left - L_size, Lc1 = L_size;
-    const float f = 2.0f * c.B * (1.0f - min_size * (float)K);
-    const bool c1_interior = idx <= K - 2;
-    float S = 0.f;
-#pragma unroll
-    for (int i = 0; i < KM; ++i)
-      if (i < K) {
-        const float dp = f * ((i < idx ? Lc0 : 0.f) + ((c1_interior && i <= idx) ? Lc1 : 0.f));
-        S += p[i] * dp;
-      }
-#pragma unroll
-    for (int i = 0; i < KM; ++i)
-      if (i < K) {
-        const float dp = f * ((i < idx ? Lc0 : 0.f) + ((c1_interior && i <= idx) ? Lc1 : 0.f));
-        dq[OFF + i] = p[i] * (dp - S) * c.inv_sqrt_h;
-      }
-  }
-  // density direction only: out = spline(v), lad = log |d out / d v|
-  static __device__ __forceinline__ void fwd(const NSplC& c, const float (&q)[NQV], float v, float& out, float& lad) {
-    const int K = c.K;
-    const bool inside = (v >= -c.B) && (v <= c.B);
-    const float vc = fminf(fmaxf(v, -c.B), c.B);
-    int idx = 0;
-    float x_k, w_k, y_k, h_k;
-    float pw[KM], ph[KM];
-    family<0, true>(c, q, c.min_w, vc, idx, x_k, w_k, pw);
-    family<KM, false>(c, q, c.min_h, vc, idx, y_k, h_k, ph);
-    float r_k = c.dconst, r_k1 = c.dconst;
-#pragma unroll
-    for (int j = 1; j < KM; ++j)
-      if (j < K) {
-        const float rj = q[2 * KM + j - 1];
-        r_k = (j == idx) ? rj : r_k;
-        r_k1 = (j == idx + 1) ? rj : r_k1;
-      }
-    const float d_k = c.min_d + sf_softplus(r_k), d_k1 = c.min_d + sf_softplus(r_k1);
-    const float s_k = sf_div(h_k, w_k);
-    const float xi = sf_div(vc - x_k, w_k);
-    const float om = xi * (1.f - xi);
-    const float num = h_k * (s_k * xi * xi + d_k * om);
-    const float den = s_k + (d_k + d_k1 - 2.f * s_k) * om;
-    const float o_in = y_k + sf_div(num, den);
-    const float dnum = s_k * s_k * (d_k1 * xi * xi + 2.f * s_k * om + d_k * (1.f - xi) * (1.f - xi));
-    const float l_in = sf_log(dnum) - 2.f * sf_log(den);
-    out = inside ? o_in : v;
-    lad = inside ? l_in : 0.f;
-  }
-  // L = Go * out + Gl * lad  ->  dv = dL/dv, dq[slot] = dL/d(raw parameter in that slot)
-  static __device__ __forceinline__ void bwd(const NSplC& c, const float (&q)[NQV], float v, float Go, float Gl, float& dv,
-                                             float (&dq)[NQV]) {
-    const int K = c.K;
-#pragma unroll
-    for (int i = 0; i < NQV; ++i) dq[i] = 0.f;
-    const bool inside = (v >= -c.B) && (v <= c.B);
-    const float vc = fminf(fmaxf(v, -c.B), c.B);
-    int idx = 0;
-    float x_k, w_k, y_k, h_k;
-    float pw[KM], ph[KM];
-    family<0, true>(c, q, c.min_w, vc, idx, x_k, w_k, pw);
-    family<KM, false>(c, q, c.min_h, vc, idx, y_k, h_k, ph);
-    float r_k = c.dconst, r_k1 = c.dconst;
-#pragma unroll
-    for (int j = 1; j < KM; ++j)
-      if (j < K) {
-        const float rj = q[2 * KM + j - 1];
-        r_k = (j == idx) ? rj : r_k;
-        r_k1 = (j == idx + 1) ? rj : r_k1;
-      }
-    const float d_k = c.min_d + sf_softplus(r_k), d_k1 = c.min_d + sf_softplus(r_k1);
-    const float inv_w = __builtin_amdgcn_rcpf(w_k);
-    const float s = h_k * inv_w;
-    const float xi = (vc - x_k) * inv_w;
-    const float om = xi * (1.f - xi);
-    const float A = d_k + d_k1 - 2.f * s;
-    const float N = s * xi * xi + d_k * om;
-    const float den = s + A * om;
-    const float Mq = d_k1 * xi * xi + 2.f * s * om + d_k * (1.f - xi) * (1.f - xi);
-    const float dnum = s * s * Mq;
-    const float go = inside ? Go : 0.f, gl = inside ? Gl : 0.f;
-    const float inv_den = __builtin_amdgcn_rcpf(den), inv_dnum = __builtin_amdgcn_rcpf(dnum);
-    const float cN = go * h_k * inv_den;
-    const float cD = -go * h_k * N * inv_den * inv_den - 2.f * gl * inv_den;
-    const float cQ = gl * inv_dnum;
-    const float L_s = cN * (xi * xi) + cD * (1.f - 2.f * om) + cQ * (2.f * s * Mq + 2.f * s * s * om);
-    const float L_dk = cN * om + cD * om + cQ * (s * s * (1.f - xi) * (1.f - xi));
-    const float L_dk1 = cD * om + cQ * (s * s * xi * xi);
-    const float L_xi = cN * (2.f * s * xi + d_k * (1.f - 2.f * xi)) + cD * (A * (1.f - 2.f * xi)) +
-                       cQ * (s * s * (2.f * d_k1 * xi + 2.f * s * (1.f - 2.f * xi) - 2.f * d_k * (1.f - xi)));
-    const float L_y = go;
-    const float L_h = go * N * inv_den + L_s * inv_w;
-    const float L_w = -(L_s * s + L_xi * xi) * inv_w;
-    const float L_x = -L_xi * inv_w;
-    dv = inside ? L_xi * inv_w : Go;
-    family_bwd<0>(c, pw, idx, L_x, L_w, c.min_w, dq);
-    family_bwd<KM>(c, ph, idx, L_y, L_h, c.min_h, dq);
-    const float g_k = L_dk * sf_sigmoid(r_k), g_k1 = L_dk1 * sf_sigmoid(r_k1);
-#pragma unroll
-    for (int j = 1; j < KM; ++j)
-      if (j < K) dq[2 * KM + j - 1] = ((j == idx) ? g_k : 0.f) + ((j == idx + 1) ? g_k1 : 0.f);
-  }
-};
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Weight-gradient blocks: acc[ro][ri] = sum over the 32 samples of delta[ot rows][s] * in[it rows][s].  The delta tile is read

@@ -9,6 +9,7 @@
 
 #include "sf_internal.h"
 #include "sf_train_args.h"
+#include "sf_nsf1.h"
 #include "sf_nsfc.h"
 #include "sf_trainc.h"
 
@@ -259,6 +260,12 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
                        float grad_scale, const float* weights, float* loss, double* loss_sum, float* grad, float* dctx,
                        hipStream_t st, std::string& err) {
   const SfLayout& L = f->L;
+  if (f->nsf1) {  // one-parameter NSF: T context MLPs + a scalar spline chain (sf_nsf1.hip); the handle keeps the vector it was given
+    if (dctx) { err = "the one-parameter NSF has no context-gradient path"; return SF_ERR_INVALID; }
+    hipError_t e = hipMemcpyAsync(f->d_flat, flat, (size_t)L.n_params * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) { err = std::string("hipMemcpyAsync: ") + hipGetErrorString(e); return SF_ERR_HIP; }
+    return sf_nsf1_loss_grad(f->nsf1, flat, theta, x, idx, B, grad_scale, weights, loss, loss_sum, grad, st, err);
+  }
   // ---- cooperative 16-row kernels: MAF (sf_trainc.hip: two blocks, D <= 8, T <= SF_TRC_TS, <= 4 hidden tiles) and
   //      NSF (sf_nsfc.hip: two blocks, D <= 8, H <= 64, K <= 11); they share the image / gather machinery
   const bool coop_maf = B > 0 && sf_trainc_eligible(L, dctx != nullptr);

@@ -127,8 +127,9 @@ def spec_and_flat_from_state_dict(state_dict: Mapping[str, object], num_bins: Op
     blocks = _blocks(sd)
     if not blocks:
         raise KeyError("no '_transform._transforms.*' entries: this is not an nflows Flow state_dict")
+    csm = any("transform_net.spline_predictor.0.weight" in b for b in blocks.values())   # sbi ContextSplineMap: scalar theta
     kind = "maf" if any("autoregressive_net.initial_layer.weight" in b for b in blocks.values()) else \
-           "nsf" if any("transform_net.initial_layer.weight" in b for b in blocks.values()) else None
+           "nsf" if (csm or any("transform_net.initial_layer.weight" in b for b in blocks.values())) else None
     if kind is None:
         raise KeyError("neither MaskedAffineAutoregressiveTransform nor PiecewiseRationalQuadraticCouplingTransform "
                        "parameters found")
@@ -166,6 +167,25 @@ def spec_and_flat_from_state_dict(state_dict: Mapping[str, object], num_bins: Op
             names[f"b{k + 1}"] = f"autoregressive_net.blocks.{k}.linear.bias"
         src = {t: (blocks[i], names) for t, i in enumerate(tidx)}
         _check_connectivity("maf", D, H, NB, blocks, tidx)
+    elif csm:
+        # one-parameter NSF (sbi build_nsf, x_numel == 1): every block is a coupling transform with mask [1] whose
+        # transform_net is ContextSplineMap.spline_predictor = Sequential(Linear, ReLU, Linear, ReLU, Linear); no LULinear
+        tidx = sorted(i for i, b in blocks.items() if "transform_net.spline_predictor.0.weight" in b)
+        T = len(tidx)
+        b0 = blocks[tidx[0]]
+        H, C = b0["transform_net.spline_predictor.0.weight"].shape
+        if "transform_net.spline_predictor.6.weight" in b0:
+            raise KeyError("ContextSplineMap with hidden_layers > 1 (it repeats ONE Linear module) is not built")
+        nout = b0["transform_net.spline_predictor.4.weight"].shape[0]
+        K = num_bins if num_bins is not None else (nout + 1) // 3
+        if 3 * K - 1 != nout:
+            raise KeyError(f"spline_predictor has {nout} outputs: not 3K - 1 for K = {K}")
+        spec = FlowSpec(kind="nsf", D=1, C=C, H=H, T=T, K=K, theta_mean=theta_mean, theta_std=theta_std,
+                        x_mean=x_mean, x_std=x_std, **spec_overrides)
+        names = {"csm.W0": "transform_net.spline_predictor.0.weight", "csm.b0": "transform_net.spline_predictor.0.bias",
+                 "csm.W1": "transform_net.spline_predictor.2.weight", "csm.b1": "transform_net.spline_predictor.2.bias",
+                 "csm.W2": "transform_net.spline_predictor.4.weight", "csm.b2": "transform_net.spline_predictor.4.bias"}
+        src = {t: (blocks[i], names) for t, i in enumerate(tidx)}
     else:
         tidx = sorted(i for i, b in blocks.items() if "transform_net.initial_layer.weight" in b)
         T = len(tidx)
@@ -241,6 +261,10 @@ def state_dict_from_flat(spec: FlowSpec, flat, prefix: str = "") -> Dict[str, np
         for k in range(spec.NB):
             inv[f"W{k + 1}"] = f"autoregressive_net.blocks.{k}.linear.weight"
             inv[f"b{k + 1}"] = f"autoregressive_net.blocks.{k}.linear.bias"
+    elif spec.nsf_1d:
+        inv = {"csm.W0": "transform_net.spline_predictor.0.weight", "csm.b0": "transform_net.spline_predictor.0.bias",
+               "csm.W1": "transform_net.spline_predictor.2.weight", "csm.b1": "transform_net.spline_predictor.2.bias",
+               "csm.W2": "transform_net.spline_predictor.4.weight", "csm.b2": "transform_net.spline_predictor.4.bias"}
     else:
         inv = {"Win": "transform_net.initial_layer.weight", "bin": "transform_net.initial_layer.bias",
                "Wout": "transform_net.final_layer.weight", "bout": "transform_net.final_layer.bias",
@@ -257,7 +281,7 @@ def state_dict_from_flat(spec: FlowSpec, flat, prefix: str = "") -> Dict[str, np
         t = int(name[1:name.index(".")])
         leaf = name[name.index(".") + 1:]
         key = inv[leaf]
-        i = 2 * t + (1 if key.startswith("+") else 0)
+        i = t if spec.nsf_1d else 2 * t + (1 if key.startswith("+") else 0)   # (no LULinear blocks between the 1-D transforms)
         out[f"{p}1._transforms.{i}.{key.lstrip('+')}"] = flat[off:off + int(np.prod(shape))].reshape(shape).copy()
     if spec.kind == "maf":
         M0, Mh, Mf = made_masks(spec.D, spec.H)
@@ -268,6 +292,10 @@ def state_dict_from_flat(spec: FlowSpec, flat, prefix: str = "") -> Dict[str, np
             out[q + "final_layer.mask"] = Mf.astype(np.float32)
             for k in range(spec.NB):
                 out[q + f"blocks.{k}.linear.mask"] = Mh.astype(np.float32)
+    elif spec.nsf_1d:
+        for t in range(spec.T):
+            out[f"{p}1._transforms.{t}.transform_features"] = np.array([0], dtype=np.int64)
+            out[f"{p}1._transforms.{t}.identity_features"] = np.array([], dtype=np.int64)
     else:
         for t in range(spec.T):
             d = np.arange(spec.D)

@@ -29,6 +29,8 @@ CASES = {
     # tiles with a partial last one, 6 parameters; and the smallest coupling (one identity dimension, one input tile)
     "nsf_k10": ("nsf", 6, 12, 40, 2, 10),
     "nsf_d2": ("nsf", 2, 3, 20, 3, 8),
+    # one parameter: sbi builds a ContextSplineMap flow (context-only MLP -> spline parameters, no LULinear): sf_nsf1.hip
+    "nsf_d1": ("nsf", 1, 5, 24, 3, 8),
 }
 
 

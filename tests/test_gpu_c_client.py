@@ -44,6 +44,9 @@ def test_c_program_through_the_abi_matches_the_oracle(name, tmp_path):
     assert np.abs(lp - oracle_log_prob(ospec, flat, theta, x, torch.float64)).max() < 1e-4
     ref, rnd = OP.sample(ospec, torch.as_tensor(flat), x, S, seed, lo, hi, dtype=torch.float32)
     err = np.abs((s - ref) / (hi - lo)).max(-1)
-    assert (err > 5e-4).mean() < 5e-3                       # boundary accept/reject flips only
+    # 1e-4 of the box width on every draw; exempt only what a boundary accept / reject flip explains (the galaxy's attempt
+    # count then differs from the oracle's by at least one per flipped slot -- tests/test_gpu_parity.py)
+    bad_g, off_g = (err > 1e-4).sum(1), np.abs(nd - rnd)
+    assert (bad_g <= off_g).all(), (bad_g, off_g, err.max())
     assert ((s >= lo) & (s <= hi)).all() and (nd >= S).all()
-    assert np.abs(nd - rnd).sum() <= max(3, 0.01 * rnd.sum())
+    assert off_g.sum() <= max(3, 0.01 * rnd.sum())

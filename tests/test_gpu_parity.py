@@ -87,7 +87,7 @@ def test_tiny_and_empty_batches():
     assert f.log_prob(theta[:0], x[:0]).numel() == 0
 
 
-@pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "nsf_odd", "maf_span6", "maf_d2_span", "maf_d4", "maf_d3", "maf_sig2"])
+@pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "nsf_odd", "maf_span6", "maf_d2_span", "maf_d4", "maf_d3", "maf_sig2", "nsf_d1"])
 def test_sampler_matches_oracle_draw_for_draw(name):
     ospec, spec, flat, theta, x = make_case(name, B=6, spread=0.2)
     S, seed = 257, 2025
@@ -105,9 +105,14 @@ def test_sampler_matches_oracle_draw_for_draw(name):
     ref, rnd = OP.sample(ospec, torch.as_tensor(flat), x, S, seed, lo, hi, dtype=torch.float32)
     scale = (hi - lo).astype(np.float64)
     err = np.abs((got - ref) / scale).max(-1)
-    bad = (err > 5e-4).mean()
-    assert bad < 5e-3, (bad, err.max())          # boundary accept/reject flips only
-    assert np.abs(nd - rnd).sum() <= max(3, 0.01 * rnd.sum())
+    # 1e-4 of the box width on EVERY draw.  The only exemption: a candidate that lands within rounding of the box edge can
+    # be accepted by one implementation and rejected by the other; that slot then keeps a later attempt and the galaxy's
+    # attempt count differs -- so a galaxy whose count equals the oracle's has no exempt draw at all, and one whose count
+    # differs may have as many mismatching draws as its count is off (a flip moves the count by at least one).
+    bad_g = (err > 1e-4).sum(1)
+    off_g = np.abs(nd - rnd)
+    assert (bad_g <= off_g).all(), (bad_g, off_g, err.max())
+    assert off_g.sum() <= max(3, 0.01 * rnd.sum())
     assert (nd >= S).all() and nd.sum() > S * len(x)  # the box really rejected something
 
 

@@ -24,7 +24,7 @@ def _rand_params(spec, seed=1, jitter=0.5):
     return torch.tensor(p + jitter * rng.normal(size=p.shape) * np.abs(p).mean())
 
 
-@pytest.mark.parametrize("kind,D,C", [("maf", 5, 10), ("maf", 2, 3), ("nsf", 8, 20), ("nsf", 5, 4), ("nsf", 2, 3)])
+@pytest.mark.parametrize("kind,D,C", [("maf", 5, 10), ("maf", 2, 3), ("nsf", 8, 20), ("nsf", 5, 4), ("nsf", 2, 3), ("nsf", 1, 4)])
 def test_inverse_of_forward_is_identity_and_logdets_cancel(kind, D, C):
     spec = _spec(kind, D, C)
     p = _rand_params(spec)
@@ -37,7 +37,7 @@ def test_inverse_of_forward_is_identity_and_logdets_cancel(kind, D, C):
     assert (ld + ld2).abs().max() < 1e-10
 
 
-@pytest.mark.parametrize("kind,D,C", [("maf", 4, 3), ("nsf", 4, 3), ("nsf", 3, 2)])
+@pytest.mark.parametrize("kind,D,C", [("maf", 4, 3), ("nsf", 4, 3), ("nsf", 3, 2), ("nsf", 1, 2)])
 def test_logdet_equals_autograd_jacobian(kind, D, C):
     spec = _spec(kind, D, C)
     p = _rand_params(spec)
@@ -274,3 +274,42 @@ def test_batched_accept_reject_fills_every_slot_inside_the_box():
     ref = np.stack([OP.accept_reject_sample(ospec, fl, x[g], 400, lo, hi, torch.Generator().manual_seed(10 + g))[0] for g in range(6)])
     sd = ref.std(1) + 1e-9
     assert (np.abs(s.mean(1) - ref.mean(1)) < 5 * sd / np.sqrt(400) * np.sqrt(2)).all()
+
+
+def test_one_parameter_nsf_is_the_context_spline_map_flow():
+    """[UPSTREAM] sbi build_nsf with a scalar theta (``x_numel == 1``): the single dimension is transformed in EVERY block by a
+    spline whose parameters come from the context alone -- ContextSplineMap(hidden_layers=1) = Linear(C,H), ReLU, Linear(H,H),
+    ReLU, Linear(H, 3K-1) -- and there is no LULinear.  Pins: parameter count, independence of the spline parameters from
+    theta, the hand-evaluated conditioner, identity behaviour outside the tail bound, and a density that integrates to one."""
+    D, C, H, T, K = 1, 3, 7, 4, 5
+    spec = OF.FlowSpec(kind="nsf", D=D, C=C, H=H, T=T, K=K)
+    assert spec.nsf_1d and not spec.has_lu
+    per_t = H * C + H + H * H + H + (3 * K - 1) * H + (3 * K - 1)
+    assert OF.num_params(spec) == T * per_t
+    names = [n for n, _, _ in OF.param_layout(spec)]
+    assert names[:6] == ["t0.csm.W0", "t0.csm.b0", "t0.csm.W1", "t0.csm.b1", "t0.csm.W2", "t0.csm.b2"] and not any("lu." in n for n in names)
+    p = _rand_params(spec, seed=3, jitter=2.0)
+    P = OF.views(spec, p)
+    x = torch.tensor([[0.3, -1.2, 0.7]], dtype=torch.float64)
+    # the conditioner by hand
+    h = torch.relu(P["t1.csm.W0"] @ x[0] + P["t1.csm.b0"])
+    h = torch.relu(P["t1.csm.W1"] @ h + P["t1.csm.b1"])
+    q = P["t1.csm.W2"] @ h + P["t1.csm.b2"]
+    assert torch.allclose(OF._context_spline_map(spec, P, 1, x)[0], q, atol=1e-14)
+    # every block transforms the one dimension: a far-out theta passes through all of them unchanged (linear tails), an
+    # interior one is moved, and the map is monotone
+    far = torch.tensor([[25.0]], dtype=torch.float64)
+    z, ld = OF.forward_transform(spec, p, far, x)
+    assert abs(z.item() - 25.0) < 1e-12 and abs(ld.item()) < 1e-12
+    grid = torch.linspace(-2.9, 2.9, 401, dtype=torch.float64)[:, None]
+    zz, _ = OF.forward_transform(spec, p, grid, x.expand(len(grid), -1))
+    assert (zz[1:] > zz[:-1]).all() and (zz - grid).abs().max() > 1e-3
+    # integral of the density over theta
+    g = torch.linspace(-14, 14, 400001, dtype=torch.float64)[:, None]
+    lp = OF.log_prob(spec, p, g, x.expand(len(g), -1))
+    assert abs(torch.trapezoid(lp.exp(), g[:, 0]).item() - 1.0) < 1e-6
+    # z-scoring of the single parameter enters as an affine first layer
+    spec2 = OF.FlowSpec(kind="nsf", D=1, C=C, H=H, T=T, K=K, theta_mean=np.array([2.0]), theta_std=np.array([0.5]))
+    lp2 = OF.log_prob(spec2, p, torch.tensor([[2.3]], dtype=torch.float64), x)
+    lp1 = OF.log_prob(spec, p, torch.tensor([[0.6]], dtype=torch.float64), x)
+    assert abs((lp2 - lp1).item() - math.log(2.0)) < 1e-12
