@@ -13,6 +13,17 @@ dev = torch.device("cuda:0")
 x, th, names = make_catalogue(10000, 10, 5, seed=1234)
 est = build_flow("maf", th[:8000], x[:8000], hidden_features=50, num_transforms=5, device=dev, generator=torch.Generator().manual_seed(1)).to(dev)
 prior = prior_from_parameters(th[:8000], names)
+# a short seeded fit (as bench.py's warm-up fit): an untrained flow is accepted by the prior box once in thousands of draws
+from synference_amd.runner import HipAdam
+flat = est.flat.data; grad = torch.empty_like(flat); opt = HipAdam(flat, lr=1e-3)
+Ttr = torch.as_tensor(th[:8000], dtype=torch.float32).to(dev); Xtr = torch.as_tensor(x[:8000]).to(dev)
+g2 = torch.Generator().manual_seed(7)
+for it in range(3000):
+    bi = torch.randint(0, 8000, (2048,), generator=g2).to(dev)
+    opt.desc.lr = 2e-3 * 0.5 * (1.0 + np.cos(np.pi * it / 3000))
+    est.flow.loss_grad(flat, Ttr[bi], Xtr[bi], 1.0 / 2048, grad_out=grad)
+    opt.step(grad, 5.0)
+est.flow.set_params(flat)
 post = FlowPosterior(est, prior)
 est._sync_params()
 fit = SBI_Fitter("t", names, [f"F{i}" for i in range(10)], feature_array=x, parameter_array=th)

@@ -136,7 +136,7 @@ void sf_flow_destroy(sf_flow* f) {
     (void)hipFree(f->d_ctab); (void)hipFree(f->d_packed16B); (void)hipFree(f->d_s16B); (void)hipFree(f->d_packed16); (void)hipFree(f->d_s16a); (void)hipFree(f->d_s16b);
     (void)hipFree(f->d_s1); (void)hipFree(f->d_s2); (void)hipFree(f->d_t1); (void)hipFree(f->d_t2);
     (void)hipFree(f->d_flat); (void)hipFree(f->d_gpacked); (void)hipFree(f->d_gdst);
-    (void)hipFree(f->d_imgC); (void)hipFree(f->d_sC1); (void)hipFree(f->d_sC2); (void)hipFree(f->d_gdstC); (void)hipFree(f->d_gsrcC); (void)hipFree(f->d_gzeroC); (void)hipFree(f->d_gpartC); (void)hipFree(f->d_ustash);
+    (void)hipFree(f->d_imgC); (void)hipFree(f->d_sC1); (void)hipFree(f->d_sC2); (void)hipFree(f->d_gdstC); (void)hipFree(f->d_gsrcC); (void)hipFree(f->d_gzeroC); (void)hipFree(f->d_gpartC); (void)hipFree(f->d_gfixC); (void)hipFree(f->d_ustash);
     (void)hipFree(f->d_queue); (void)hipFree(f->d_ring); (void)hipFree(f->d_galacc); (void)hipFree(f->d_best); (void)hipHostFree(f->h_queue);
     (void)hipFree(f->d_act); (void)hipFree(f->d_rej[0]); (void)hipFree(f->d_rej[1]); (void)hipFree(f->d_cnt);
   }

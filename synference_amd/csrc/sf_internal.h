@@ -156,6 +156,7 @@ struct sf_flow {
   int32_t* d_gzeroC = nullptr; // parameters without a position (their gradient is 0)
   long n_gzeroC = 0;
   float* d_gpartC = nullptr;
+  long long* d_gfixC = nullptr; // SF_FIX_REPLICAS int64 gradient images (fixed-point accumulation, sf_fixacc.h)
   size_t gpartC_cap = 0;        // floats
   bool trainc_ready = false;
   float* d_ustash = nullptr;    // cooperative NSF training (sf_nsfc.hip): u / u' of every transform, [rows][T][16]

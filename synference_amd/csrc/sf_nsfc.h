@@ -5,7 +5,6 @@
 
 #include "sf_layout.h"
 
-#define SF_NSC_REPLICAS 8   // gradient-image replicas of the atomic mode: one per XCD
 
 struct SfNscArgs {
   SfNscDev c;
@@ -22,13 +21,14 @@ struct SfNscArgs {
   float w;
   float* loss;           // [B] or null
   double* loss_sum;      // optional device scalar
-  // gradient accumulation target: atomic == 0: one partial of gpart_stride floats per workgroup, plain stores (bitwise
-  // reproducible; summed by k_gather_c2 in workgroup order); atomic == 1: SF_NSC_REPLICAS zeroed replicas, the workgroup adds
-  // into the replica of its XCD with f32 atomics that stay in that XCD's L2 (the NSF partial is 0.6 MB: 512 of them per
-  // step would be 300 MB of HBM traffic for a 0.37 MB gradient)
+  // gradient accumulation target: one partial of gpart_stride floats per workgroup (plain stores, summed by k_gather_c2 in
+  // workgroup order), or -- fix != null -- SF_FIX_REPLICAS zeroed int64 images of gpart_stride entries: the workgroup adds
+  // 2^-40 fixed-point contributions into the replica of its XCD with integer atomics that stay in that XCD's L2
+  // (sf_fixacc.h: the NSF partial is 0.6 MB -- 512 of them per step would be 300 MB of HBM traffic for a 0.37 MB gradient).
+  // Bitwise reproducible either way.
   float* gpart;
   long gpart_stride;
-  int atomic;
+  long long* fix;
   float* ustash;         // [n_chunks * 32][T][16]: u entering transform t (8) and the spline's outputs u' (8)
 #ifdef SF_NSC_TRACE
   unsigned long long* trace;  // developer build: [4 waves][512] cycle stamps of workgroup 0

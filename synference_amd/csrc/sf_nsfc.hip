@@ -17,8 +17,8 @@
 //   * weight gradients: the delta tiles stay in the padded B layout they were exchanged in (read transposed: 68-float row
 //     groups make that conflict free), the layer inputs are written transposed once ([sample >> 2][row][sample & 3]) --
 //     products over the 32 samples, spread over the four waves; small batches store into the workgroup's own partial (plain
-//     stores, summed by k_gather_c2: bitwise reproducible), large ones add into the gradient replica of their XCD with f32
-//     atomics that never leave that XCD's L2;
+//     stores, summed by k_gather_c2), large ones add 2^-40 fixed-point contributions into the int64 gradient replica of
+//     their XCD with integer atomics that never leave that XCD's L2 (sf_fixacc.h): bitwise reproducible either way;
 //   * LULinear: forward / backward on replicated registers (every lane of a sample holds all D values); its weight
 //     gradients ride the same 16 x 16 block products (two blocks per transform).
 // Tile = 16 rows x 16 samples in 4 VGPRs: lane l = sample (l & 15) + 16 * row group (l >> 4), register r = row
@@ -29,6 +29,7 @@
 #include <cstdlib>
 
 #include "sf_device.h"
+#include "sf_fixacc.h"
 #include "sf_internal.h"
 #include "sf_nsfc.h"
 #include "sf_spline_flat.h"
@@ -102,13 +103,14 @@ struct NJob {
   float* gb;        // bias gradient rows of tile ot (or null)
   int ot, it;
 };
-__device__ __forceinline__ void n_dw_finish(const NJob& J, f32x4 acc, float bs, int mode, int lane) {
-  // mode 0: plain store, 1: add to the workgroup's partial (later chunks), 2: f32 atomics into the XCD's replica
-  if (mode == 2) {
+__device__ __forceinline__ void n_dw_finish(const NJob& J, f32x4 acc, float bs, const SfAcc& A, int lane) {
+  // A.mode 0: plain store, 1: add to the workgroup's partial (later chunks), 3: fixed-point atomics into the XCD's replica
+  if (A.mode == 3) {
+    long long* q = A.fix + (J.gw - A.base);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) unsafeAtomicAdd(J.gw + r * 64 + lane, acc[r]);
+    for (int r = 0; r < 4; ++r) sf_fix_add(q + r * 64 + lane, acc[r]);
   } else {
-    if (mode == 1) {
+    if (A.mode == 1) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] += J.gw[r * 64 + lane];
     }
@@ -119,12 +121,12 @@ __device__ __forceinline__ void n_dw_finish(const NJob& J, f32x4 acc, float bs, 
     bs += __shfl_xor(bs, 16, 64);
     bs += __shfl_xor(bs, 32, 64);
     if (lane < 16) {
-      if (mode == 2) unsafeAtomicAdd(J.gb + J.ot * 16 + lane, bs);
-      else J.gb[J.ot * 16 + lane] = mode == 1 ? J.gb[J.ot * 16 + lane] + bs : bs;
+      if (A.mode == 3) sf_fix_add(A.fix + (J.gb - A.base) + J.ot * 16 + lane, bs);
+      else J.gb[J.ot * 16 + lane] = A.mode == 1 ? J.gb[J.ot * 16 + lane] + bs : bs;
     }
   }
 }
-__device__ __forceinline__ void n_dw_jobs(const NJob& A, const NJob& B, bool two, int mode, int lane) {
+__device__ __forceinline__ void n_dw_jobs(const NJob& A, const NJob& B, bool two, const SfAcc& mode, int lane) {
   const int dofs = 16 * (lane >> 4) + 68 * ((lane & 15) >> 2) + (lane & 3);
   f32x4 a0 = n_zero(), a1 = n_zero(), b0 = n_zero(), b1 = n_zero();
   float bsA = 0.f, bsB = 0.f;
@@ -226,13 +228,14 @@ __global__ __launch_bounds__(256, 2) void k_nsf_trainc(SfNscArgs a_in) {
   // groups of a sample, they were 24-32 live VGPRs through every matrix phase of every wave.)
   float* SST = LUC + 160;
   const NSplC sc = {a.K, a.tail_bound, a.min_w, a.min_h, a.min_d, a.inv_sqrt_h, a.deriv_const};
-  int xcc = 0;
-  if (a.atomic) asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-  float* gpart = a.gpart + (size_t)(a.atomic ? (xcc & (SF_NSC_REPLICAS - 1)) : (int)blockIdx.x) * a.gpart_stride;
+  // gradient target: this workgroup's partial, or -- a.fix -- the fixed-point replica of its XCD (sf_fixacc.h; the job
+  // descriptors then carry offsets from a.gpart that are never dereferenced as floats)
+  float* gpart = a.fix ? a.gpart : a.gpart + (size_t)blockIdx.x * a.gpart_stride;
+  long long* gfix = a.fix ? a.fix + (size_t)sf_xcc_id() * a.gpart_stride : nullptr;
   auto kc_in = [&](int it) { return it == 0 ? 4 : (it == 1 ? c.kc_in[1] : c.kc_in[2]); };
 
   for (long chunk = blockIdx.x, iter = 0; chunk < a.n_chunks; chunk += gridDim.x, ++iter) {
-    const int mode = a.atomic ? 2 : (iter > 0 ? 1 : 0);
+    const SfAcc mode = {gfix ? 3 : (iter > 0 ? 1 : 0), a.gpart, gfix};
     SF_NC(0);
     // ------------------------------------------------------------------ per-sample inputs (spline waves)
     const long row = chunk * 32 + (spl ? wave : 0) * 16 + s;
@@ -877,13 +880,16 @@ int sf_nsfc_grid(long B) {
   return (int)(chunks < cap ? chunks : cap);
 }
 
-// per-workgroup partials (deterministic) while they stay small; SF_DETERMINISTIC=1 keeps them at any batch size
+// per-workgroup partials while they stay small, the fixed-point replicas above that (SF_GRAD_ACC=partial | fix forces one)
 bool sf_nsfc_atomic(long B, int grid, long n_gradC) {
-  static int force_det = -1;
-  if (force_det < 0) { const char* e = std::getenv("SF_DETERMINISTIC"); force_det = e ? std::atoi(e) : 0; }
+  static int force = -1;
+  if (force < 0) {
+    const char* e = std::getenv("SF_GRAD_ACC");
+    force = !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'f' ? 2 : 0));
+  }
   (void)B;
-  if (force_det == 1) return false;
-  return (size_t)grid * (size_t)n_gradC * sizeof(float) > ((size_t)48 << 20);
+  if (force) return force == 2;
+  return (size_t)grid * (size_t)n_gradC * sizeof(float) > ((size_t)24 << 20);
 }
 
 template <int NT, int OTQ>

@@ -9,6 +9,7 @@
 
 #include "sf_internal.h"
 #include "sf_train_args.h"
+#include "sf_fixacc.h"
 #include "sf_nsf1.h"
 #include "sf_nsfc.h"
 #include "sf_trainc.h"
@@ -320,9 +321,16 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
       f->trainc_ready = true;
     }
     const int grid = coop_maf ? sf_trainc_grid(B) : sf_nsfc_grid(B);
-    // NSF at large batch: the workgroups add into one zeroed replica per XCD (f32 atomics) instead of one partial each
-    const bool nsf_atomic = coop_nsf && sf_nsfc_atomic(B, grid, (long)L.n_gradC);
-    const int n_part = nsf_atomic ? SF_NSC_REPLICAS : grid;
+    // Gradient accumulation (sf_fixacc.h): per-workgroup partials + gather while they are few, above that 2^-40 fixed-point
+    // contributions added with int64 atomics into one zeroed replica per XCD (L2-resident, order independent).  The gather
+    // needs the position -> parameter table (d_gsrcC); SF_GRAD_ACC=partial | fix forces one form.
+    bool use_fix = coop_nsf ? sf_nsfc_atomic(B, grid, (long)L.n_gradC) : sf_trainc_fix(grid, (long)L.n_gradC);
+    if (!f->d_gsrcC) use_fix = false;
+    if (use_fix && !f->d_gfixC) {
+      SF_TRY(hipMalloc(&f->d_gfixC, (size_t)SF_FIX_REPLICAS * (size_t)L.n_gradC * sizeof(long long)));
+    }
+    if (use_fix) SF_TRY(hipMemsetAsync(f->d_gfixC, 0, (size_t)SF_FIX_REPLICAS * (size_t)L.n_gradC * sizeof(long long), st));
+    const int n_part = use_fix ? 1 : grid;   // (fix: d_gpartC is only the base the job descriptors count from)
     const size_t need = (size_t)n_part * (size_t)L.n_gradC;
     if (need > f->gpartC_cap) {
       if (f->d_gpartC) SF_TRY(hipFree(f->d_gpartC));
@@ -353,7 +361,6 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
         SF_TRY(hipMalloc(&f->d_ustash, ust_need * sizeof(float)));
         f->ustash_cap = ust_need;
       }
-      if (nsf_atomic) SF_TRY(hipMemsetAsync(f->d_gpartC, 0, need * sizeof(float), st));
       const SfDev& v = L.dev;
       SfNscArgs a;
       a.c = L.nsc;
@@ -364,7 +371,7 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
       a.c_pscale = v.c_pscale; a.c_pshift = v.c_pshift; a.c_xmean = v.c_xmean; a.c_xstd = v.c_xstd;
       a.theta = theta; a.x = x; a.idx = idx; a.wts = weights; a.B = B; a.n_chunks = n_chunks; a.w = grad_scale;
       a.loss = loss; a.loss_sum = loss_sum;
-      a.gpart = f->d_gpartC; a.gpart_stride = (long)L.n_gradC; a.atomic = nsf_atomic ? 1 : 0;
+      a.gpart = f->d_gpartC; a.gpart_stride = (long)L.n_gradC; a.fix = use_fix ? f->d_gfixC : nullptr;
       a.ustash = f->d_ustash;
 #ifdef SF_NSC_TRACE
       a.trace = nullptr;
@@ -378,7 +385,8 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
         SF_TRY(hipEventRecord(f->ev_train[1], st));
         f->ev_train_valid = true;
       }
-      if (f->d_gsrcC) SF_TRY(sf_launch_gather_c2(f->d_gpartC, (long)L.n_gradC, n_part, f->d_gsrcC, f->d_gzeroC, f->n_gzeroC, grad, st));
+      if (use_fix) SF_TRY(sf_launch_gather_fix(f->d_gfixC, (long)L.n_gradC, SF_FIX_REPLICAS, f->d_gsrcC, f->d_gzeroC, f->n_gzeroC, grad, st));
+      else if (f->d_gsrcC) SF_TRY(sf_launch_gather_c2(f->d_gpartC, (long)L.n_gradC, n_part, f->d_gsrcC, f->d_gzeroC, f->n_gzeroC, grad, st));
       else SF_TRY(sf_launch_gather_c(f->d_gpartC, (long)L.n_gradC, n_part, f->d_gdstC, grad, (long)L.n_params, st));
       return SF_OK;
     }
@@ -390,7 +398,7 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
     a.c_pscale = L.dev.c_pscale; a.c_pshift = L.dev.c_pshift; a.c_tdim = L.dev.c_tdim; a.c_xmean = L.dev.c_xmean; a.c_xstd = L.dev.c_xstd;
     a.theta = theta; a.x = x; a.idx = idx; a.wts = weights; a.B = B; a.n_chunks = (B + 32L * sf_trainc_groups(B) - 1) / (32L * sf_trainc_groups(B)); a.w = grad_scale;
     a.loss = loss; a.loss_sum = loss_sum; a.dctx = dctx;
-    a.gpart = f->d_gpartC; a.gpart_stride = (long)L.n_gradC;
+    a.gpart = f->d_gpartC; a.gpart_stride = (long)L.n_gradC; a.fix = use_fix ? f->d_gfixC : nullptr;
     if (f->profiling) {
       if (!f->ev_train[0]) { SF_TRY(hipEventCreate(&f->ev_train[0])); SF_TRY(hipEventCreate(&f->ev_train[1])); }
       SF_TRY(hipEventRecord(f->ev_train[0], st));
@@ -400,7 +408,8 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
       SF_TRY(hipEventRecord(f->ev_train[1], st));
       f->ev_train_valid = true;
     }
-    if (f->d_gsrcC) SF_TRY(sf_launch_gather_c2(f->d_gpartC, (long)L.n_gradC, grid, f->d_gsrcC, f->d_gzeroC, f->n_gzeroC, grad, st));
+    if (use_fix) SF_TRY(sf_launch_gather_fix(f->d_gfixC, (long)L.n_gradC, SF_FIX_REPLICAS, f->d_gsrcC, f->d_gzeroC, f->n_gzeroC, grad, st));
+    else if (f->d_gsrcC) SF_TRY(sf_launch_gather_c2(f->d_gpartC, (long)L.n_gradC, grid, f->d_gsrcC, f->d_gzeroC, f->n_gzeroC, grad, st));
     else SF_TRY(sf_launch_gather_c(f->d_gpartC, (long)L.n_gradC, grid, f->d_gdstC, grad, (long)L.n_params, st));
     return SF_OK;
   }

@@ -25,6 +25,7 @@ struct SfTrcArgs {
   float* dctx;           // [B, C] or null (only with one input tile)
   float* gpart;          // [grid] gradient partials of gpart_stride floats; plain stores, summed by k_gather_c
   long gpart_stride;
+  long long* fix;        // != null: SF_FIX_REPLICAS zeroed int64 images of gpart_stride entries instead (sf_fixacc.h)
 #ifdef SF_TRC_TRACE
   unsigned long long* trace;  // developer build: [8 waves][256] cycle stamps of workgroup 0
 #endif
@@ -54,7 +55,10 @@ size_t sf_trainc_lds_bytes(const SfTrcDev& c, int TS, int NG);
 int sf_trainc_groups(long B);
 bool sf_trainc_eligible(const SfLayout& L, bool want_dctx);
 int sf_trainc_grid(long B);
+bool sf_trainc_fix(int grid, long n_gradC);
 hipError_t sf_launch_maf_trainc(const SfTrcArgs& a, int grid, hipStream_t st);
 hipError_t sf_launch_gather_c(const float* gpart, long stride, int nwg, const int32_t* gdst, float* grad, long n, hipStream_t st);
+hipError_t sf_launch_gather_fix(const long long* gfix, long stride, int nrep, const int32_t* gsrc, const int32_t* gzero, long n_zero,
+                                float* grad, hipStream_t st);
 hipError_t sf_launch_gather_c2(const float* gpart, long stride, int nwg, const int32_t* gsrc, const int32_t* gzero, long n_zero,
                                float* grad, hipStream_t st);

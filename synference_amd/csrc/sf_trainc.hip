@@ -23,6 +23,7 @@
 #include <cstdlib>
 
 #include "sf_device.h"
+#include "sf_fixacc.h"
 #include "sf_internal.h"
 #include "sf_trainc.h"
 
@@ -112,21 +113,30 @@ struct CJob {
   float* gb;
   int ot, it;
 };
-__device__ __forceinline__ void c_dw_finish(const CJob& J, f32x4 acc, float bs, bool accumulate, int lane) {
-  if (accumulate) {
+__device__ __forceinline__ void c_dw_finish(const CJob& J, f32x4 acc, float bs, const SfAcc& A, int lane) {
+  if (A.mode == 3) {  // fixed-point atomics into the XCD's replica (sf_fixacc.h)
+    long long* q = A.fix + (J.gw - A.base);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] += J.gw[r * 64 + lane];
+    for (int r = 0; r < 4; ++r) sf_fix_add(q + r * 64 + lane, acc[r]);
+  } else {
+    if (A.mode == 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] += J.gw[r * 64 + lane];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) J.gw[r * 64 + lane] = acc[r];
   }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) J.gw[r * 64 + lane] = acc[r];
   if (J.gb) {
     bs += __shfl_xor(bs, 16, 64);
     bs += __shfl_xor(bs, 32, 64);
-    if (lane < 16) J.gb[J.ot * 16 + lane] = accumulate ? J.gb[J.ot * 16 + lane] + bs : bs;
+    if (lane < 16) {
+      if (A.mode == 3) sf_fix_add(A.fix + (J.gb - A.base) + J.ot * 16 + lane, bs);
+      else J.gb[J.ot * 16 + lane] = A.mode == 1 ? J.gb[J.ot * 16 + lane] + bs : bs;
+    }
   }
 }
 template <int NQ>
-__device__ __forceinline__ void c_dw_jobs(const CJob& A, const CJob& B, bool two, bool accumulate, int lane) {
+__device__ __forceinline__ void c_dw_jobs(const CJob& A, const CJob& B, bool two, const SfAcc& accumulate, int lane) {
   f32x4 accA = c_zero(), accB = c_zero();
   float bsA = 0.f, bsB = 0.f;
   if (two) {  // (two blocks at once: their chains alternate, the 40-cycle dependent latency of the MFMA is hidden)
@@ -315,7 +325,6 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
   auto bslot_ot = [&](int i) { const int ii = i < nbT ? i : (nbT > 0 ? nbT - 1 : 0); return ii < nbA ? kbA + ii : kbB + ii - nbA; };
 
   for (long chunk = blockIdx.x, iter = 0; chunk < a.n_chunks; chunk += gridDim.x, ++iter) {
-    const bool accumulate = iter > 0;
     SF_TC(0);
     // first fragments of the forward sweep: in flight behind the input loads
     float4 pwin[2][NI];
@@ -519,7 +528,10 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
     c_barrier();  // the last head sums have been read (PBf is TD2's buffer), the u / a stash is complete
 
     // ------------------------------------------------------------------ backward
-    float* gpart = a.gpart + (size_t)blockIdx.x * a.gpart_stride;
+    // gradient target: this workgroup's partial (plain stores; adds from its second chunk on), or -- a.fix -- the fixed-point
+    // replica of its XCD (the job descriptors then carry offsets from a.gpart that are never dereferenced as floats)
+    float* gpart = a.fix ? a.gpart : a.gpart + (size_t)blockIdx.x * a.gpart_stride;
+    const SfAcc accumulate = {a.fix ? 3 : (iter > 0 ? 1 : 0), a.gpart, a.fix ? a.fix + (size_t)sf_xcc_id() * a.gpart_stride : nullptr};
 #pragma unroll
     for (int tt = 0; tt < TS; ++tt) {
       const int t = TS - 1 - tt;
@@ -806,6 +818,27 @@ __global__ __launch_bounds__(256) void k_gather_c2(const float* __restrict__ gpa
   }
 }
 
+// fixed-point form (sf_fixacc.h): position j of the SF_FIX_REPLICAS int64 images -> the one or two parameters it feeds;
+// integer sum of the replicas, one conversion
+__global__ __launch_bounds__(256) void k_gather_fix(const long long* __restrict__ gfix, long stride, int nrep,
+                                                     const int32_t* __restrict__ gsrc, const int32_t* __restrict__ gzero,
+                                                     long n_zero, float* __restrict__ grad) {
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < stride) {
+    const int p0 = gsrc[2 * j], p1 = gsrc[2 * j + 1];
+    if (p0 >= 0) {
+      long long sacc = 0;
+      for (int r = 0; r < nrep; ++r) sacc += gfix[(size_t)r * stride + j];
+      const float v = (float)((double)sacc * (1.0 / SF_FIX_SCALE));
+      grad[p0] = v;
+      if (p1 >= 0) grad[p1] = v;
+    }
+  } else {
+    const long z = j - stride;
+    if (z < n_zero) grad[gzero[z]] = 0.f;
+  }
+}
+
 size_t sf_trainc_lds_bytes(const SfTrcDev& c, int TS, int NG) {
   const size_t NQ = 2 * (size_t)NG;
   return ((size_t)c.NT * NQ * (256 * 2 + TTS * 5) + NQ * TTS + (size_t)c.NI * NQ * TTS + (size_t)TS * NQ * 256 +
@@ -823,6 +856,17 @@ int sf_trainc_groups(long B) {
   if (forced < 0) { const char* e = std::getenv("SF_TRC_NG"); forced = e ? std::atoi(e) : 0; }
   if (forced == 1 || forced == 2) return forced;
   return B <= 8192 ? 1 : 2;
+}
+
+// fixed-point replicas instead of per-workgroup partials (sf_fixacc.h) once the partials of a step exceed a few MB
+bool sf_trainc_fix(int grid, long n_gradC) {
+  static int force = -1;
+  if (force < 0) {
+    const char* e = std::getenv("SF_GRAD_ACC");
+    force = !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'f' ? 2 : 0));
+  }
+  if (force) return force == 2;
+  return (size_t)grid * (size_t)n_gradC * sizeof(float) > ((size_t)4 << 20);
 }
 
 bool sf_trainc_eligible(const SfLayout& L, bool want_dctx) {
@@ -928,6 +972,12 @@ hipError_t sf_launch_gather_c2(const float* gpart, long stride, int nwg, const i
                                float* grad, hipStream_t st) {
   const long blocks = (stride + 63) / 64 + (n_zero + 255) / 256;  // 64 positions per block, then 256 unmapped parameters per block
   hipLaunchKernelGGL(k_gather_c2, dim3((unsigned)blocks), dim3(256), 0, st, gpart, stride, nwg, gsrc, gzero, n_zero, grad);
+  return hipGetLastError();
+}
+hipError_t sf_launch_gather_fix(const long long* gfix, long stride, int nrep, const int32_t* gsrc, const int32_t* gzero, long n_zero,
+                                float* grad, hipStream_t st) {
+  const long tot = stride + n_zero;
+  hipLaunchKernelGGL(k_gather_fix, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, gfix, stride, nrep, gsrc, gzero, n_zero, grad);
   return hipGetLastError();
 }
 hipError_t sf_launch_gather_c(const float* gpart, long stride, int nwg, const int32_t* gdst, float* grad, long n, hipStream_t st) {
