@@ -861,7 +861,7 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
         }
       }
       // ---- cooperative 16-row training image (sf_layout.h, SfNscDev; sf_nsfc.hip) -----------------------------
-      if (NB == 2 && D >= 2 && D <= 8 && H <= 64 && 3 * K - 1 <= 32 && 8 + C <= 48) {
+      if (NB == 2 && D >= 2 && D <= 8 && H <= 80 && 3 * K - 1 <= 32 && 8 + C <= 48) {
         SfNscDev& c = L.nsc;
         const int NT = ceil_div(H, 16), NI = ceil_div(8 + C, 16);
         const int OTQ = 3 * K - 1 <= 24 ? 6 : 8, KM = OTQ == 6 ? 8 : 11;

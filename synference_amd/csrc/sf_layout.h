@@ -128,8 +128,8 @@ struct SfTrcDev {
   int c_jobs, n_jobs;  // constants image: [n_jobs] float-encoded (ot*4 + it) of the unmasked hidden weight blocks
 };
 
-// ---- cooperative 16-row NSF training image (sf_nsfc.hip; NSF, num_blocks = 2, 2 <= D <= 8, <= 4 hidden tiles) ----
-// One workgroup = 4 waves = 32 samples (two 16-sample subtiles); wave j owns hidden tile j of both subtiles.  Tiles as above
+// ---- cooperative 16-row NSF training image (sf_nsfc.hip; NSF, num_blocks = 2, 2 <= D <= 8, <= 5 hidden tiles: H <= 80) ----
+// One workgroup = 4 (5 for five hidden tiles) waves = 32 samples (two 16-sample subtiles); wave j owns hidden tile j of both subtiles.  Tiles as above
 // (lane l: sample l & 15, rows 4*(l >> 4) + r).  Rows are placed so that the k-components an MFMA step consumes (rows m,
 // 4 + m, 8 + m, 12 + m of a tile for component m) fill up one after the other: a tile with n used rows costs
 // ceil(n / 4) of the four v_mfma_f32_16x16x4_f32 steps.

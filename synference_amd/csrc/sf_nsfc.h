@@ -24,11 +24,12 @@ struct SfNscArgs {
   // gradient accumulation target: one partial of gpart_stride floats per workgroup (plain stores, summed by k_gather_c2 in
   // workgroup order), or -- fix != null -- SF_FIX_REPLICAS zeroed int64 images of gpart_stride entries: the workgroup adds
   // 2^-40 fixed-point contributions into the replica of its XCD with integer atomics that stay in that XCD's L2
-  // (sf_fixacc.h: the NSF partial is 0.6 MB -- 512 of them per step would be 300 MB of HBM traffic for a 0.37 MB gradient).
-  // Bitwise reproducible either way.
+  // (sf_fixacc.h: the NSF partial is 0.6 MB -- 512 of them per step would be 300 MB of HBM traffic for a 0.37 MB gradient),
+  // or float contributions with f32 atomics (fix_mode 2: twice as fast in the L2s, but the order of the adds is the hardware's).
   float* gpart;
   long gpart_stride;
   long long* fix;
+  int fix_mode;          // 3: int64 fixed point (sf_fixacc.h); 2: the replicas are FLOAT images added to with f32 atomics
   float* ustash;         // [n_chunks * 32][T][16]: u entering transform t (8) and the spline's outputs u' (8)
 #ifdef SF_NSC_TRACE
   unsigned long long* trace;  // developer build: [4 waves][512] cycle stamps of workgroup 0
@@ -47,6 +48,6 @@ struct SfNscArgs {
 
 size_t sf_nsfc_lds_bytes(const SfNscDev& c);
 bool sf_nsfc_eligible(const SfLayout& L, bool want_dctx);
-int sf_nsfc_grid(long B);
-bool sf_nsfc_atomic(long B, int grid, long n_gradC);
+int sf_nsfc_grid(long B, int NT);
+int sf_nsfc_acc_mode(long B, int grid, long n_gradC);
 hipError_t sf_launch_nsf_trainc(const SfNscArgs& a, int grid, hipStream_t st);

@@ -104,8 +104,13 @@ struct NJob {
   int ot, it;
 };
 __device__ __forceinline__ void n_dw_finish(const NJob& J, f32x4 acc, float bs, const SfAcc& A, int lane) {
-  // A.mode 0: plain store, 1: add to the workgroup's partial (later chunks), 3: fixed-point atomics into the XCD's replica
-  if (A.mode == 3) {
+  // A.mode 0: plain store, 1: add to the workgroup's partial (later chunks), 2: f32 atomics into the XCD's replica,
+  // 3: fixed-point (int64) atomics into it
+  if (A.mode == 2) {
+    float* q = reinterpret_cast<float*>(A.fix) + (J.gw - A.base);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) unsafeAtomicAdd(q + r * 64 + lane, acc[r]);
+  } else if (A.mode == 3) {
     long long* q = A.fix + (J.gw - A.base);
 #pragma unroll
     for (int r = 0; r < 4; ++r) sf_fix_add(q + r * 64 + lane, acc[r]);
@@ -121,7 +126,8 @@ __device__ __forceinline__ void n_dw_finish(const NJob& J, f32x4 acc, float bs, 
     bs += __shfl_xor(bs, 16, 64);
     bs += __shfl_xor(bs, 32, 64);
     if (lane < 16) {
-      if (A.mode == 3) sf_fix_add(A.fix + (J.gb - A.base) + J.ot * 16 + lane, bs);
+      if (A.mode == 2) unsafeAtomicAdd(reinterpret_cast<float*>(A.fix) + (J.gb - A.base) + J.ot * 16 + lane, bs);
+      else if (A.mode == 3) sf_fix_add(A.fix + (J.gb - A.base) + J.ot * 16 + lane, bs);
       else J.gb[J.ot * 16 + lane] = A.mode == 1 ? J.gb[J.ot * 16 + lane] + bs : bs;
     }
   }
@@ -188,13 +194,18 @@ __device__ __forceinline__ void n_barrier() {
   asm volatile("" ::: "memory");
 }
 
+// NW waves: 4, or 5 when the flow has five hidden tiles (64 < H <= 80: the reference's production NSF has H = 69); one hidden
+// tile per wave.
 template <int NT, int OTQ>
-__global__ __launch_bounds__(256, 2) void k_nsf_trainc(SfNscArgs a_in) {
+__global__ __launch_bounds__(64 * (NT > 4 ? NT : 4), (NT > 4 ? 1 : 2)) void k_nsf_trainc(SfNscArgs a_in) {
   extern __shared__ float lds[];
   constexpr int NQ = 2;
+  constexpr int NW = NT > 4 ? NT : 4;
   constexpr int KM = OTQ == 6 ? 8 : 11, NQV = 4 * OTQ;
-  constexpr int NOWN = OTQ / 4;        // spline-head tiles a wave produces for both subtiles (tile = wave + 4 k)
-  constexpr int NEXT = (OTQ % 4) * 2;  // remaining (tile, subtile) units, one per wave
+  constexpr int NOWN = OTQ / NW;       // spline-head tiles a wave produces for both subtiles (tile = wave + NW k)
+  // the remaining OTQ % NW tiles: four waves split them into (tile, subtile) units, one per wave (OTQ = 6: two tiles = four
+  // units); five waves give whole tiles to the first waves
+  constexpr int NEXT = NW == 4 ? (OTQ % 4) * 2 : OTQ % NW;
   using Spl = NSpl<KM, NQV>;
   const SfNscArgs& a = n_args();
   const SfNscDev& c = a.c;
@@ -203,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void k_nsf_trainc(SfNscArgs a_in) {
   // before it starts a second round) then keep their spline waves -- the waves with the extra VALU phases -- on different
   // SIMD pairs
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) ^ ((2 * blockIdx.x >= gridDim.x && gridDim.x > 1) ? 2 : 0));
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) ^ ((NW == 4 && 2 * blockIdx.x >= gridDim.x && gridDim.x > 1) ? 2 : 0));
   const int s = lane & 15, g4 = lane >> 4;
   const int NI = c.NI, D = a.D, T = a.T;
   const bool has = wave < NT;   // owns hidden tile `wave` of both subtiles
@@ -231,11 +242,14 @@ __global__ __launch_bounds__(256, 2) void k_nsf_trainc(SfNscArgs a_in) {
   // gradient target: this workgroup's partial, or -- a.fix -- the fixed-point replica of its XCD (sf_fixacc.h; the job
   // descriptors then carry offsets from a.gpart that are never dereferenced as floats)
   float* gpart = a.fix ? a.gpart : a.gpart + (size_t)blockIdx.x * a.gpart_stride;
-  long long* gfix = a.fix ? a.fix + (size_t)sf_xcc_id() * a.gpart_stride : nullptr;
+  // (a.fix_mode 2: the replicas are float images of the same stride)
+  long long* gfix = !a.fix ? nullptr
+                           : (a.fix_mode == 2 ? reinterpret_cast<long long*>(reinterpret_cast<float*>(a.fix) + (size_t)sf_xcc_id() * a.gpart_stride)
+                                              : a.fix + (size_t)sf_xcc_id() * a.gpart_stride);
   auto kc_in = [&](int it) { return it == 0 ? 4 : (it == 1 ? c.kc_in[1] : c.kc_in[2]); };
 
   for (long chunk = blockIdx.x, iter = 0; chunk < a.n_chunks; chunk += gridDim.x, ++iter) {
-    const SfAcc mode = {gfix ? 3 : (iter > 0 ? 1 : 0), a.gpart, gfix};
+    const SfAcc mode = {gfix ? a.fix_mode : (iter > 0 ? 1 : 0), a.gpart, gfix};
     SF_NC(0);
     // ------------------------------------------------------------------ per-sample inputs (spline waves)
     const long row = chunk * 32 + (spl ? wave : 0) * 16 + s;
@@ -292,13 +306,13 @@ __global__ __launch_bounds__(256, 2) void k_nsf_trainc(SfNscArgs a_in) {
     // the hidden product).  (Everything one phase ahead: 80 live registers, 200 spilled.)
     f32x4 h0[2], t1[2], t2[2], sg[2], t1b[2], t2b[2], sgb[2];
     auto bias4 = [&](const float* tp, int off, int tile) { return n_ld4(tp + off + tile * 16 + 4 * g4); };
-    auto ld_hid = [&](const float* tp, int o_w, int o_b, float4 (&W)[4], f32x4& b) {   // (unconditional: a wave without a tile
+    auto ld_hid = [&](const float* tp, int o_w, int o_b, float4 (&W)[NT], f32x4& b) {   // (unconditional: a wave without a tile
 #pragma unroll                                                                          //  loads tile 0's and drops them)
       for (int it = 0; it < NT; ++it) W[it] = n_frag(tp + o_w, NT, j, it, lane);
       b = bias4(tp, o_b, j);
     };
     // acc[q] = b + W[j][:] . X[:][q] over the NT hidden input tiles
-    auto go_hid = [&](const float4 (&W)[4], const f32x4 b, const float* X, f32x4& acc0, f32x4& acc1) {
+    auto go_hid = [&](const float4 (&W)[NT], const f32x4 b, const float* X, f32x4& acc0, f32x4& acc1) {
       acc0 = b;
       acc1 = b;
 #pragma unroll
@@ -340,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void k_nsf_trainc(SfNscArgs a_in) {
       const SfNscArgs& a = n_args();
       const SfNscDev& c = a.c;
       const float* tp = img_of(t);
-      float4 wA[4], wB[4];
+      float4 wA[NT], wB[NT];
       f32x4 bA, bB;
       // LU block of this transform -> LDS (read by the spline waves many barriers later)
       if (threadIdx.x < 144) LUC[threadIdx.x] = tp[c.o_lu + threadIdx.x];
@@ -415,9 +429,9 @@ __global__ __launch_bounds__(256, 2) void k_nsf_trainc(SfNscArgs a_in) {
       // F6: q = bout + Wout h2: tiles wave, wave + 4 for both subtiles; the remaining tiles one (tile, subtile) unit per wave
       {
         // second portion of the head's fragments: tile wave + 4 (OTQ = 8) or this wave's extra unit (OTQ = 6)
-        constexpr bool OWN2 = NOWN > 1;
-        const int tile2 = OWN2 ? wave + 4 : 4 * NOWN + (wave >> 1);
-        const bool do2 = OWN2 || (NEXT > 0 && wave < NEXT);
+        constexpr bool OWN2 = NOWN > 1 || NW > 4;   // the second portion is a whole tile (both subtiles)
+        const int tile2 = NOWN > 1 ? wave + NW : (NW > 4 ? NW * NOWN + wave : 4 * NOWN + (wave >> 1));
+        const bool do2 = NOWN > 1 || (NEXT > 0 && wave < NEXT);
         float4 w2[NT];
         f32x4 b2 = n_zero();
         if (do2) {
@@ -657,11 +671,11 @@ __global__ __launch_bounds__(256, 2) void k_nsf_trainc(SfNscArgs a_in) {
       }
       n_barrier();
       SF_NC(42 + 10 * (T - 1 - t));
-      // generic job runner: blocks n = wave, wave + 4, ... of a list, two at a time
+      // generic job runner: blocks n = wave, wave + NW, ... of a list, two at a time
       auto run_jobs = [&](int total, auto mk) {
-        for (int n = wave; n < total; n += 8) {
-          const bool two = n + 4 < total;
-          const NJob A = mk(n), B = mk(two ? n + 4 : n);
+        for (int n = wave; n < total; n += 2 * NW) {
+          const bool two = n + NW < total;
+          const NJob A = mk(n), B = mk(two ? n + NW : n);
           n_dw_jobs(A, B, two, mode, lane);
         }
       };
@@ -864,11 +878,11 @@ bool sf_nsfc_eligible(const SfLayout& L, bool want_dctx) {
   static int env = -1;
   if (env < 0) { const char* e = std::getenv("SF_NSFC"); env = e ? std::atoi(e) : 1; }
   if (!env || !c.ok || want_dctx) return false;
-  if (c.NT < 2 || c.NT > 4 || (c.OTQ != 6 && c.OTQ != 8) || c.NI < 1 || c.NI > 3) return false;
+  if (c.NT < 2 || c.NT > 5 || (c.OTQ != 6 && c.OTQ != 8) || c.NI < 1 || c.NI > 3) return false;
   return sf_nsfc_lds_bytes(c) <= (size_t)160 * 1024;
 }
 
-int sf_nsfc_grid(long B) {
+int sf_nsfc_grid(long B, int NT) {
   static int cus = 0;
   if (!cus) {
     int dev = 0;
@@ -876,20 +890,26 @@ int sf_nsfc_grid(long B) {
     cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
               ? pr.multiProcessorCount : 256;
   }
-  const long chunks = (B + 31) / 32, cap = 2L * cus;
+  const long chunks = (B + 31) / 32, cap = (NT > 4 ? 1L : 2L) * cus;   // (five-wave workgroups: one per CU)
   return (int)(chunks < cap ? chunks : cap);
 }
 
-// per-workgroup partials while they stay small, the fixed-point replicas above that (SF_GRAD_ACC=partial | fix forces one)
-bool sf_nsfc_atomic(long B, int grid, long n_gradC) {
-  static int force = -1;
+// Gradient accumulation of a step: 0 = per-workgroup partials + gather (plain stores; bitwise reproducible) while they stay
+// small; above that one replica per XCD -- 2 = f32 atomics (default: 366 us per 16 384 rows of cfg3, nothing leaves the L2s,
+// but the order of the adds is the hardware's), 3 = 2^-40 fixed-point int64 atomics (sf_fixacc.h: order independent, bitwise
+// reproducible; 64-bit atomics run at half the rate: 520 us) under SF_DETERMINISTIC=1.  SF_GRAD_ACC=partial | atomic | fix forces one.
+int sf_nsfc_acc_mode(long B, int grid, long n_gradC) {
+  static int force = -1, det = -1;
   if (force < 0) {
     const char* e = std::getenv("SF_GRAD_ACC");
-    force = !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'f' ? 2 : 0));
+    force = !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'a' ? 2 : (e[0] == 'f' ? 3 : 0)));
+    const char* d = std::getenv("SF_DETERMINISTIC");
+    det = d ? std::atoi(d) : 0;
   }
   (void)B;
-  if (force) return force == 2;
-  return (size_t)grid * (size_t)n_gradC * sizeof(float) > ((size_t)24 << 20);
+  if (force) return force == 1 ? 0 : force;
+  if ((size_t)grid * (size_t)n_gradC * sizeof(float) <= ((size_t)24 << 20)) return 0;
+  return det == 1 ? 3 : 2;
 }
 
 template <int NT, int OTQ>
@@ -909,7 +929,7 @@ static hipError_t n_launch(const SfNscArgs& a, int grid, hipStream_t st) {
     (void)hipMemsetAsync(d_tr, 0, 4 * 512 * 8, st);
     SfNscArgs b = a;
     b.trace = d_tr;
-    hipLaunchKernelGGL((k_nsf_trainc<NT, OTQ>), dim3((unsigned)grid), dim3(256), sh, st, b);
+    hipLaunchKernelGGL((k_nsf_trainc<NT, OTQ>), dim3((unsigned)grid), dim3(64 * (NT > 4 ? NT : 4)), sh, st, b);
     (void)hipStreamSynchronize(st);
     static unsigned long long h[4 * 512];
     (void)hipMemcpy(h, d_tr, sizeof(h), hipMemcpyDeviceToHost);
@@ -926,7 +946,7 @@ static hipError_t n_launch(const SfNscArgs& a, int grid, hipStream_t st) {
     return hipGetLastError();
   }
 #endif
-  hipLaunchKernelGGL((k_nsf_trainc<NT, OTQ>), dim3((unsigned)grid), dim3(256), sh, st, a);
+  hipLaunchKernelGGL((k_nsf_trainc<NT, OTQ>), dim3((unsigned)grid), dim3(64 * (NT > 4 ? NT : 4)), sh, st, a);
   return hipGetLastError();
 }
 
@@ -938,6 +958,8 @@ hipError_t sf_launch_nsf_trainc(const SfNscArgs& a, int grid, hipStream_t st) {
     case 38: return n_launch<3, 8>(a, grid, st);
     case 46: return n_launch<4, 6>(a, grid, st);
     case 48: return n_launch<4, 8>(a, grid, st);
+    case 56: return n_launch<5, 6>(a, grid, st);
+    case 58: return n_launch<5, 8>(a, grid, st);
   }
   return hipErrorInvalidValue;
 }

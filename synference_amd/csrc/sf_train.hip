@@ -320,11 +320,12 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
 #undef SF_TRY_C
       f->trainc_ready = true;
     }
-    const int grid = coop_maf ? sf_trainc_grid(B) : sf_nsfc_grid(B);
+    const int grid = coop_maf ? sf_trainc_grid(B) : sf_nsfc_grid(B, L.nsc.NT);
     // Gradient accumulation (sf_fixacc.h): per-workgroup partials + gather while they are few, above that 2^-40 fixed-point
     // contributions added with int64 atomics into one zeroed replica per XCD (L2-resident, order independent).  The gather
     // needs the position -> parameter table (d_gsrcC); SF_GRAD_ACC=partial | fix forces one form.
-    bool use_fix = coop_nsf ? sf_nsfc_atomic(B, grid, (long)L.n_gradC) : sf_trainc_fix(grid, (long)L.n_gradC);
+    const int nsf_mode = coop_nsf ? sf_nsfc_acc_mode(B, grid, (long)L.n_gradC) : 0;
+    bool use_fix = coop_nsf ? nsf_mode != 0 : sf_trainc_fix(grid, (long)L.n_gradC);
     if (!f->d_gsrcC) use_fix = false;
     if (use_fix && !f->d_gfixC) {
       SF_TRY(hipMalloc(&f->d_gfixC, (size_t)SF_FIX_REPLICAS * (size_t)L.n_gradC * sizeof(long long)));
@@ -371,7 +372,7 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
       a.c_pscale = v.c_pscale; a.c_pshift = v.c_pshift; a.c_xmean = v.c_xmean; a.c_xstd = v.c_xstd;
       a.theta = theta; a.x = x; a.idx = idx; a.wts = weights; a.B = B; a.n_chunks = n_chunks; a.w = grad_scale;
       a.loss = loss; a.loss_sum = loss_sum;
-      a.gpart = f->d_gpartC; a.gpart_stride = (long)L.n_gradC; a.fix = use_fix ? f->d_gfixC : nullptr;
+      a.gpart = f->d_gpartC; a.gpart_stride = (long)L.n_gradC; a.fix = use_fix ? f->d_gfixC : nullptr; a.fix_mode = nsf_mode;
       a.ustash = f->d_ustash;
 #ifdef SF_NSC_TRACE
       a.trace = nullptr;
@@ -385,7 +386,9 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
         SF_TRY(hipEventRecord(f->ev_train[1], st));
         f->ev_train_valid = true;
       }
-      if (use_fix) SF_TRY(sf_launch_gather_fix(f->d_gfixC, (long)L.n_gradC, SF_FIX_REPLICAS, f->d_gsrcC, f->d_gzeroC, f->n_gzeroC, grad, st));
+      if (use_fix && nsf_mode == 2)   // float replicas: the partial gather over SF_FIX_REPLICAS images
+        SF_TRY(sf_launch_gather_c2(reinterpret_cast<const float*>(f->d_gfixC), (long)L.n_gradC, SF_FIX_REPLICAS, f->d_gsrcC, f->d_gzeroC, f->n_gzeroC, grad, st));
+      else if (use_fix) SF_TRY(sf_launch_gather_fix(f->d_gfixC, (long)L.n_gradC, SF_FIX_REPLICAS, f->d_gsrcC, f->d_gzeroC, f->n_gzeroC, grad, st));
       else if (f->d_gsrcC) SF_TRY(sf_launch_gather_c2(f->d_gpartC, (long)L.n_gradC, n_part, f->d_gsrcC, f->d_gzeroC, f->n_gzeroC, grad, st));
       else SF_TRY(sf_launch_gather_c(f->d_gpartC, (long)L.n_gradC, n_part, f->d_gdstC, grad, (long)L.n_params, st));
       return SF_OK;

@@ -129,9 +129,13 @@ class HipFlow:
         return s1, s2, gd, d, cst
 
     def describe(self) -> dict:
-        buf = C.create_string_buffer(1 << 16)
-        _lib.check(self.lib.sf_flow_describe(self.handle, buf, len(buf)))
-        return json.loads(buf.value.decode())
+        """Layout description of the handle (fixed at creation: parsed once)."""
+        d = getattr(self, "_describe", None)
+        if d is None:
+            buf = C.create_string_buffer(1 << 16)
+            _lib.check(self.lib.sf_flow_describe(self.handle, buf, len(buf)))
+            d = self._describe = json.loads(buf.value.decode())
+        return dict(d)
 
     # ---- device calls -----------------------------------------------------------------------
     def _dev(self):

@@ -131,7 +131,11 @@ class FlowPosterior:
                 unfilled += est.flow.last_unfilled
         finally:
             est.flow.set_sample_row_offset(0)
-        self.last_acceptance = (S / counts.float().clamp_min(1)).mean().item() if N else None
+        # one read-back for everything the host wants to know about the call: mean / worst acceptance, galaxies below 1 %
+        if N:
+            acc_g = S / counts.float().clamp_min(1)
+            summ = torch.stack([acc_g.mean(), acc_g.min(), (acc_g < 0.01).sum().float()]).tolist()
+        self.last_acceptance = summ[0] if N else None
         self.last_unfilled = unfilled
         if unfilled:
             why = (f"after {self.max_sampling_attempts} attempts" if self.max_sampling_attempts
@@ -142,11 +146,10 @@ class FlowPosterior:
             # [UPSTREAM] accept_reject_sample warns per observation once its acceptance rate drops below 1 %
             # ("... It may take a long time to collect the remaining samples"); the in-tree diagnostics of
             # custom_runner.py:1131-1186 name the offending parameters -- CustomIndependentUniform.acceptance_report
-            acc_g = S / counts.float().clamp_min(1)
-            n_low = int((acc_g < 0.01).sum().item())
+            n_low = int(summ[2])
             self.last_low_acceptance = n_low
             if n_low:
-                logger.warning(f"Only {float(acc_g.min()) * 100:.3f}% of the proposed samples were accepted for the worst of "
+                logger.warning(f"Only {summ[1] * 100:.3f}% of the proposed samples were accepted for the worst of "
                                f"{n_low} observation(s) below 1 %: their posterior mass is largely outside the prior support.")
         return (out, counts) if return_counts else out
 

@@ -31,6 +31,9 @@ CASES = {
     "nsf_d2": ("nsf", 2, 3, 20, 3, 8),
     # one parameter: sbi builds a ContextSplineMap flow (context-only MLP -> spline parameters, no LULinear): sf_nsf1.hip
     "nsf_d1": ("nsf", 1, 5, 24, 3, 8),
+    # the width of the reference's production NSF (examples/sbi/configs/best_params.yaml: 69 hidden, K = 10): five hidden tiles
+    # of 16 -> the five-wave form of the cooperative training kernel
+    "nsf_h69": ("nsf", 8, 20, 69, 3, 10),
 }
 
 

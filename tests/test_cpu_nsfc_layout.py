@@ -13,7 +13,7 @@ from cases import make_case, oracle_log_prob
 from oracle import flows as OF
 from test_cpu_trainc_layout import fwd_block, tr_block
 
-NAMES = ["nsf_cfg3", "nsf_odd", "nsf_k10", "nsf_d2"]
+NAMES = ["nsf_cfg3", "nsf_odd", "nsf_k10", "nsf_d2", "nsf_h69"]
 
 
 def _case(name, B):

@@ -43,6 +43,7 @@ BENCH_SHAPES = [
     ("nsf_cfg3", 16384, 3),            # bench --workload nsf_cfg3 `train`: k_nsf_trainc<4,6>, XCD replicas + f32 atomics
     ("nsf_cfg3", 65536 + 37, 3),       # several chunks per workgroup, ragged tail
     ("nsf_k10", 4096 + 5, 3),          # k_nsf_trainc<3,8>
+    ("nsf_h69", 8192 + 3, 3),          # k_nsf_trainc<5,8>: five waves (the production width, bench --workload nsf_prod)
 ]
 
 
@@ -80,3 +81,20 @@ def test_both_workgroup_shapes_on_the_same_rows(name, tmp_path):
         assert int(got[ng]["path"]) == ng, (name, ng, int(got[ng]["path"]))
         check_against_oracle(ospec, flat, theta, x, got[ng]["loss"].astype(np.float64), got[ng]["grad"].astype(np.float64),
                              (name, "NG", ng))
+
+
+@pytest.mark.parametrize("name,B", [("nsf_cfg3", 16384), ("maf_cfg1", 16384)])
+def test_fixed_point_accumulation_is_right_and_order_independent(name, B, tmp_path):
+    """SF_GRAD_ACC=fix (what SF_DETERMINISTIC=1 selects for the NSF kernel at large batch): contributions as 2^-40 fixed point,
+    added with int64 atomics into one replica per XCD (csrc/sf_fixacc.h).  Two fresh processes give the same bits, and the
+    gradient is the oracle's."""
+    got = []
+    for k in range(2):
+        out = tmp_path / f"fix{k}.npz"
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "trc_child.py"), name, str(B), str(out)],
+                           env=dict(os.environ, SF_GRAD_ACC="fix"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        got.append(np.load(out))
+    assert np.array_equal(got[0]["grad"], got[1]["grad"]) and np.array_equal(got[0]["loss"], got[1]["loss"])
+    ospec, spec, flat, theta, x = make_case(name, B=B)
+    check_against_oracle(ospec, flat, theta, x, got[0]["loss"].astype(np.float64), got[0]["grad"].astype(np.float64), (name, "fix"))
