@@ -104,6 +104,10 @@ def parse():
     ap.add_argument("--fit-lr", type=float, default=2e-3)
     ap.add_argument("--hidden-bf16", action="store_true",
                     help="opt-in bf16 MFMA operands for the hidden HxH layers of the sampler (BASELINE configs[4])")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="N > 1 launch logistics without the workload: ranks rendezvous, all-reduce one flat gradient of the workload's "
+                         "size, rank 0 prints the observed world size / backend / all-reduce time (runs without a GPU under "
+                         "SF_BENCH_BACKEND=gloo: the CPU test of the 8-rank launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-api", action="store_true", help="skip the API-level leg (SBI_Fitter.sample_posterior -> host float64)")
     ap.add_argument("--skip-large-catalogue", action="store_true",
@@ -130,6 +134,55 @@ def spawn_ranks(a):
     env.setdefault("OMP_NUM_THREADS", "4")
     p = subprocess.run(cmd, env=env)
     return p.returncode
+
+
+def rendezvous_only(a, world, rank, local):
+    """What can go wrong before any kernel runs at N = 8 -- the launcher's environment, the rendezvous on 127.0.0.1, the
+    process group, the flat-gradient all-reduce and the max-over-ranks timing -- exercised without the workload."""
+    backend = os.environ.get("SF_BENCH_BACKEND", "nccl")
+    use_gpu = torch.cuda.is_available() and backend == "nccl"
+    dev = torch.device("cuda", 0 if os.environ.get("SF_BENCH_ONE_DEVICE") == "1" else local) if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+        assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
+    from synference_amd.spec import FlowSpec, num_params
+    wl = WORKLOADS[a.workload]
+    P = num_params(FlowSpec(kind=wl["kind"], D=wl["D"], C=wl["C"], H=wl.get("H", 50), T=wl.get("T", 5), K=wl["K"]))
+    g = torch.full((P,), float(rank + 1), dtype=torch.float32, device=dev)
+    us = None
+    if world > 1:
+        for _ in range(3):
+            dist.all_reduce(g.clone())
+        if use_gpu:
+            torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            h = g.clone()
+            dist.all_reduce(h)
+        if use_gpu:
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        v = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        us = float(v.item()) * 1e6
+        ok = bool(torch.allclose(h, torch.full_like(h, world * (world + 1) / 2.0)))
+    else:
+        ok = True
+    if rank == 0:
+        print(json.dumps({"rendezvous_only": True, "n_gpus": a.gpus, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                          "backend": dist.get_backend() if world > 1 else "none", "flat_gradient_floats": P,
+                          "allreduce_us": us, "allreduce_sum_correct": ok, "device": str(dev)}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 def all_reduce_(t, op, gloo):
@@ -307,12 +360,14 @@ def note(msg):
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(a))
+        sys.exit(spawn_ranks(a))   # (children start before this process touches the GPU; their exit code is ours)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if a.rendezvous_only:
+        return rendezvous_only(a, world, rank, local)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP flow engine has no CPU fallback)")
     # rehearsal knobs (never set by the driver): all ranks on one device / gloo instead of RCCL
@@ -725,4 +780,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

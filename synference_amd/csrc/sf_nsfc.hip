@@ -894,10 +894,16 @@ int sf_nsfc_grid(long B, int NT) {
   return (int)(chunks < cap ? chunks : cap);
 }
 
-// Gradient accumulation of a step: 0 = per-workgroup partials + gather (plain stores; bitwise reproducible) while they stay
-// small; above that one replica per XCD -- 2 = f32 atomics (default: 366 us per 16 384 rows of cfg3, nothing leaves the L2s,
-// but the order of the adds is the hardware's), 3 = 2^-40 fixed-point int64 atomics (sf_fixacc.h: order independent, bitwise
-// reproducible; 64-bit atomics run at half the rate: 520 us) under SF_DETERMINISTIC=1.  SF_GRAD_ACC=partial | atomic | fix forces one.
+// Gradient accumulation of a step (measured on cfg3, kernel / step):
+//   0 = per-workgroup partials + gather: plain stores, bitwise reproducible.  ONE chunk per workgroup (batch <= 32 x grid =
+//       16 384 rows): 301 / 352 us at 16 384 rows -- the fastest form although 512 partials of 0.6 MB cross the HBM twice
+//       (the L2s take stores at sixteen times the rate of atomics); later chunks of a persistent workgroup would read-modify-
+//       write their partial (3.15 ms per 131 072 rows), so beyond one chunk:
+//   2 = f32 atomics into one replica per XCD (385 / 418 us at 16 384, 2.56 ms per 131 072 rows): nothing leaves the L2s, but
+//       the order of the adds is the hardware's;
+//   3 = the same with 2^-40 fixed-point int64 atomics (sf_fixacc.h): order independent, bitwise reproducible, half the atomic
+//       rate (520 us at 16 384) -- taken instead of 2 under SF_DETERMINISTIC=1.
+// SF_GRAD_ACC=partial | atomic | fix forces one.
 int sf_nsfc_acc_mode(long B, int grid, long n_gradC) {
   static int force = -1, det = -1;
   if (force < 0) {
@@ -906,9 +912,9 @@ int sf_nsfc_acc_mode(long B, int grid, long n_gradC) {
     const char* d = std::getenv("SF_DETERMINISTIC");
     det = d ? std::atoi(d) : 0;
   }
-  (void)B;
   if (force) return force == 1 ? 0 : force;
-  if ((size_t)grid * (size_t)n_gradC * sizeof(float) <= ((size_t)24 << 20)) return 0;
+  const long chunks = (B + 31) / 32;
+  if (chunks <= (long)grid && (size_t)grid * (size_t)n_gradC * sizeof(float) <= ((size_t)1 << 30)) return 0;
   return det == 1 ? 3 : 2;
 }
 

@@ -639,3 +639,30 @@ def test_strided_walk_through_a_slot_list_is_a_permutation(n):
         todo &= ~done
     assert np.array_equal(np.sort(out), np.arange(n))
     assert np.median(np.abs(np.diff(out))) >= n // 256
+
+
+# ------------------------------------------------------------------------------------------------
+# round 4: the N = 8 launch of bench.py, without the workload (what the driver's 8-GPU run does before any kernel)
+# ------------------------------------------------------------------------------------------------
+def test_bench_spawns_eight_ranks_and_all_reduces_a_flat_gradient():
+    """`python bench.py --gpus 8 --rendezvous-only` as ONE process: it spawns its eight ranks through torch.distributed.run on
+    127.0.0.1 (before touching any GPU), every rank joins the process group (gloo here; RCCL on the node), all-reduces a flat
+    gradient of the workload's size and rank 0 prints the OBSERVED world size and the all-reduce time; the children's exit
+    code is the parent's."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SF_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--rendezvous-only", "--workload", "nsf_cfg3"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["rccl_ranks"] == 8 and rec["n_gpus"] == 8 and rec["backend"] == "gloo"
+    assert rec["flat_gradient_floats"] == 91570 and rec["allreduce_sum_correct"]
+    assert np.isfinite(rec["allreduce_us"]) and rec["allreduce_us"] > 0
+    # a launcher that starts the wrong number of ranks is refused, never papered over
+    env2 = dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--rendezvous-only"], env=env2,
+                        capture_output=True, text=True, timeout=120)
+    assert r2.returncode != 0 and "WORLD_SIZE=4" in (r2.stdout + r2.stderr)
