@@ -1,14 +1,14 @@
-"""profiles/r03_pmc_summary.json from the per-kernel counter rows written by scripts/prof_collect_r03.sh
-(profiles/r03_pmc_maf.csv: default bench; profiles/r03_pmc_nsf.csv: bench.py --workload nsf_cfg3; four separate
+"""profiles/rNN_pmc_summary.json (argument: the tag, default r04) from the per-kernel counter rows written by
+scripts/prof_collect.sh (profiles/rNN_pmc_maf.csv: default bench; rNN_pmc_nsf.csv: bench.py --workload nsf_cfg3; four separate
 rocprofv3 --pmc passes each: FETCH_SIZE | WRITE_SIZE | two SQ sets).  Keys of the top level / "train" are the ones
 bench.py reads (hbm_bytes_per_launch, *_busy_frac); "nsf" holds the sampler / log_prob / training kernels of cfg3."""
 import collections, csv, json, os, re, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 
 
 def section(rows, pat, grid=None, alg_bytes=None, note=None):
-    """rows: the aggregated table of prof_collect_r03.sh (one row per kernel x launch shape x counter)."""
+    """rows: the aggregated table of prof_collect.sh (one row per kernel x launch shape x counter)."""
     acc = collections.defaultdict(list); dur = {}; kern = None; meta = None
     # of several launch shapes of one kernel (warm-up fit, bench batch ...) take `grid`, else the one with the longest launches
     cand = [r for r in rows if re.search(pat, r["Kernel_Name"]) and (grid is None or int(r["Grid_Size"]) == grid)]
@@ -59,7 +59,7 @@ maf = list(csv.DictReader(open(os.path.join(P, f"{tag}_pmc_maf.csv"))))
 M, S, D, C, P_ = 2000, 1000, 5, 10, 32300
 out = section(maf, "k_maf_samp16", alg_bytes=4.0 * D * M * S + 4.0 * C * M)
 out["command"] = ("rocprofv3 --pmc <COUNTERS> --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 "
-                  "--no-cpu-baseline (separate passes: FETCH_SIZE | WRITE_SIZE | SQ_* | SQ_*; scripts/prof_collect_r03.sh)")
+                  "--no-cpu-baseline (separate passes: FETCH_SIZE | WRITE_SIZE | SQ_* | SQ_*; scripts/prof_collect.sh)")
 out["note"] = ("busy fractions = counter / (1024 SIMDs x launch time x 2.4 GHz); *_quad counters count quad-cycles.  One sampler "
                "launch = one whole bench step (2000 galaxies x 1000 accepted draws, first attempts + retries).")
 # training kernel at the bench batch: 16 384 rows = 256 workgroups of 512 threads
@@ -77,7 +77,17 @@ if os.path.exists(nsf_path):
         "sampler": section(nsf, r"k_sample_persist<NsfOps<\d+, \d+, \d+, true, 2>", alg_bytes=4.0 * Dn * Mn * 1000 + 4.0 * Cn * Mn),
         "sampler_fp32_leg": section(nsf, r"k_sample_persist<NsfOps<\d+, \d+, \d+, true, 0>", alg_bytes=4.0 * Dn * Mn * 1000 + 4.0 * Cn * Mn),
         "log_prob": section(nsf, "k_logprob"),
-        "train16384": section(nsf, "k_nsf_train", grid=512 * 128, alg_bytes=4.0 * (Dn + Cn) * 16384 + 4.0 * 2 * 91570),
+        "train16384": section(nsf, "k_nsf_trainc", grid=512 * 256, alg_bytes=4.0 * (Dn + Cn) * 16384 + 4.0 * 2 * 91570,
+                              note="cooperative 16-row kernel, batch 16 384, one chunk per workgroup: per-workgroup gradient partials "
+                                   "(512 x 0.6 MB, plain stores) summed by k_gather_c2 -- the fastest form (sf_nsfc.hip, sf_nsfc_acc_mode)"),
+        "train16384_gather": section(nsf, "k_gather_c2"),
     }
+    ap = os.path.join(P, f"{tag}_pmc_nsfatomic.csv")
+    if os.path.exists(ap):
+        na = list(csv.DictReader(open(ap)))
+        out["nsf"]["train16384_xcd_replicas"] = section(
+            na, "k_nsf_trainc", grid=512 * 256, alg_bytes=4.0 * (Dn + Cn) * 16384 + 4.0 * 2 * 91570,
+            note="the same launch with SF_GRAD_ACC=atomic: f32 atomics into one gradient replica per XCD, nothing but inputs and the "
+                 "u stash crosses the HBM")
 json.dump(out, open(os.path.join(P, f"{tag}_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:6000])

@@ -1,14 +1,16 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): everything behind profiles/r03_*.
+# Runs on the GPU box (gpurun): everything behind profiles/rNN_*.      usage: bash scripts/prof_collect.sh r04
 #   1. rocprofv3 --kernel-trace --stats of the default bench command          -> kernel_stats.csv, kernels.txt
 #   2. three separate --pmc passes of the default bench (FETCH_SIZE | WRITE_SIZE | SQ_*)  -> per-kernel counter rows
 #   3. the same for the NSF workload of BASELINE configs[2] (bench.py --workload nsf_cfg3)
 #   4. un-profiled bench lines of both workloads
-# Only small summaries are kept (gpurun_out/prof_r03/); scripts/make_pmc_summary_r03.py turns them into
-# profiles/r03_pmc_summary.json, which bench.py reads `traffic` / `issue_busy` from.
+#   5. (round 4) bench.py --workload nsf_prod: the reference's production NSF (T = 15, H = 69, K = 10)
+# Only small summaries are kept (gpurun_out/prof_rNN/); scripts/make_pmc_summary.py rNN turns them into
+# profiles/rNN_pmc_summary.json, which bench.py reads `traffic` / `issue_busy` from.
 set -e
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/prof_r03; RAW=/tmp/sfprof3; rm -rf $RAW; mkdir -p $OUT $RAW
+OUT=gpurun_out/prof_$TAG; RAW=/tmp/sfprof_$TAG; rm -rf $RAW; mkdir -p $OUT $RAW
 say() { echo "[$(date +%H:%M:%S)] $*" | tee -a $OUT/progress.log; }
 
 trace() {  # tag, bench args
@@ -65,14 +67,20 @@ PY
 say "kernel trace, default bench"
 trace maf ""
 say "PMC passes, default bench"
-pmc maf "--steps 3 --warmup 1 --skip-throughput-regime" "k_maf_samp16|k_maf_trainc|k_gather_c|k_train_prep|k_adam|k_logprob"
+pmc maf "--steps 3 --warmup 1 --skip-throughput-regime --skip-api" "k_maf_samp16|k_maf_trainc|k_gather_c|k_train_prep|k_adam|k_logprob"
 say "kernel trace, nsf_cfg3"
 trace nsf "--workload nsf_cfg3 --steps 3 --warmup 1"
 say "PMC passes, nsf_cfg3"
-pmc nsf "--workload nsf_cfg3 --steps 2 --warmup 1 --skip-throughput-regime" "k_sample_persist|k_logprob|k_nsf_train"
+pmc nsf "--workload nsf_cfg3 --steps 2 --warmup 1 --skip-throughput-regime --skip-api" "k_sample_persist|k_logprob|k_nsf_train|k_gather_c|k_train_prep"
+say "PMC passes, nsf_cfg3 training with the gradient replicas (SF_GRAD_ACC=atomic)"
+export SF_GRAD_ACC=atomic
+pmc nsfatomic "--workload nsf_cfg3 --steps 2 --warmup 1 --skip-throughput-regime --skip-api --fit-steps 50" "k_nsf_train|k_gather_c"
+unset SF_GRAD_ACC
 say "un-profiled bench lines"
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 say "default bench done"
 python3 bench.py --workload nsf_cfg3 --no-cpu-baseline > $OUT/bench_nsf_cfg3.json 2> $OUT/bench_nsf_cfg3.err
+python3 bench.py --workload nsf_prod --no-cpu-baseline --skip-large-catalogue > $OUT/bench_nsf_prod.json 2> $OUT/bench_nsf_prod.err
+say "nsf_prod bench done"
 say "all done"
 ls -la $OUT
