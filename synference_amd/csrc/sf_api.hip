@@ -139,6 +139,12 @@ void sf_flow_destroy(sf_flow* f) {
     (void)hipFree(f->d_imgC); (void)hipFree(f->d_sC1); (void)hipFree(f->d_sC2); (void)hipFree(f->d_gdstC); (void)hipFree(f->d_gsrcC); (void)hipFree(f->d_gzeroC); (void)hipFree(f->d_gpartC); (void)hipFree(f->d_gfixC); (void)hipFree(f->d_ustash);
     (void)hipFree(f->d_queue); (void)hipFree(f->d_ring); (void)hipFree(f->d_galacc); (void)hipFree(f->d_best); (void)hipHostFree(f->h_queue);
     (void)hipFree(f->d_act); (void)hipFree(f->d_rej[0]); (void)hipFree(f->d_rej[1]); (void)hipFree(f->d_cnt);
+    if (f->step_exec) (void)hipGraphExecDestroy(f->step_exec);
+    if (f->step_graph) (void)hipGraphDestroy(f->step_graph);
+    if (f->step_stream) (void)hipStreamDestroy(f->step_stream);
+    if (f->step_ev[0]) (void)hipEventDestroy(f->step_ev[0]);
+    if (f->step_ev[1]) (void)hipEventDestroy(f->step_ev[1]);
+    (void)hipFree(f->d_step_ctr); (void)hipFree(f->d_step_bc); (void)hipFree(f->d_step_rows);
   }
   delete f;
 }
@@ -870,11 +876,92 @@ int sf_flow_train_epoch(sf_flow* f, float* flat, const float* theta, const float
   if (!f || !flat || !theta || !x || !order || !exp_avg || !exp_avg_sq || !d || !scratch || !grad)
     return fail(SF_ERR_INVALID, "null argument");
   if (n_batches < 0 || batch < 1 || step0 < 0) return fail(SF_ERR_INVALID, "bad n_batches, batch or step0");
-  for (int64_t b = 0; b < n_batches; ++b) {
+  auto plain_step = [&](int64_t b) -> int {
     int rc = sf_flow_loss_grad_rows(f, flat, theta, x, order + b * batch, batch, grad_scale, nullptr, nullptr, loss_sum, grad,
                                     nullptr, stream);
     if (rc) return rc;
-    rc = sf_adam_apply(flat, grad, exp_avg, exp_avg_sq, f->L.n_params, d, step0 + b + 1, max_norm, scratch, stream);
+    return sf_adam_apply(flat, grad, exp_avg, exp_avg_sq, f->L.n_params, d, step0 + b + 1, max_norm, scratch, stream);
+  };
+  // ---- the step as ONE captured HIP graph, replayed per batch.  What changes from step to step -- the batch's rows and Adam's
+  // bias correction -- lives on the device: k_step_begin copies rows [ctr[0] * batch, ...) of `order` into a fixed buffer the
+  // training kernels read and computes 1 - beta^(ctr[1] + 1); k_step_end advances both counters.  The first step of a call
+  // runs the plain way (lazy allocations, function attributes); the graph is kept on the handle and captured again only when
+  // an argument changes.  SF_TRAIN_GRAPH=0 switches it off; a flow kind whose step is not capturable (the one-parameter NSF
+  // allocates inside its MLP calls) never uses it.
+  static int use_graph = -1;
+  if (use_graph < 0) { const char* e = std::getenv("SF_TRAIN_GRAPH"); use_graph = e ? std::atoi(e) : 1; }
+  int64_t b0 = 0;
+  if (use_graph && n_batches >= 4 && !f->nsf1 && !f->profiling) {
+    int rc = plain_step(0);
+    if (rc) return rc;
+    b0 = 1;
+    hipStream_t user = (hipStream_t)stream;
+    auto hip_ok = [&](hipError_t e) { return e == hipSuccess; };
+    bool ok = true;
+    if (!f->step_stream) {
+      ok = hip_ok(hipStreamCreateWithFlags(&f->step_stream, hipStreamNonBlocking)) &&
+           hip_ok(hipEventCreateWithFlags(&f->step_ev[0], hipEventDisableTiming)) &&
+           hip_ok(hipEventCreateWithFlags(&f->step_ev[1], hipEventDisableTiming)) &&
+           hip_ok(hipMalloc(&f->d_step_ctr, 2 * sizeof(long long))) && hip_ok(hipMalloc(&f->d_step_bc, 2 * sizeof(float)));
+    }
+    if (ok && f->step_rows_cap < (size_t)batch) {
+      (void)hipFree(f->d_step_rows);
+      f->d_step_rows = nullptr; f->step_rows_cap = 0;
+      ok = hip_ok(hipMalloc(&f->d_step_rows, (size_t)batch * sizeof(long long)));
+      if (ok) f->step_rows_cap = (size_t)batch;
+      if (f->step_exec) { (void)hipGraphExecDestroy(f->step_exec); f->step_exec = nullptr; }   // (the buffer moved)
+    }
+    if (ok) {
+      unsigned long long key[16] = {(unsigned long long)flat, (unsigned long long)theta, (unsigned long long)x, (unsigned long long)order,
+                                    (unsigned long long)batch, 0, (unsigned long long)exp_avg, (unsigned long long)exp_avg_sq, 0, 0, 0,
+                                    (unsigned long long)scratch, (unsigned long long)grad, (unsigned long long)loss_sum, 0, 0};
+      std::memcpy(&key[5], &grad_scale, sizeof(float));
+      std::memcpy(&key[8], d, sizeof(sf_adam_desc) < 24 ? sizeof(sf_adam_desc) : 24);
+      std::memcpy(&key[14], &max_norm, sizeof(float));
+      // the step runs on the handle's own stream, ordered behind the caller's
+      ok = hip_ok(hipEventRecord(f->step_ev[0], user)) && hip_ok(hipStreamWaitEvent(f->step_stream, f->step_ev[0], 0));
+      const long long ctr0[2] = {1, (long long)(step0 + 1)};   // next batch, Adam steps already taken
+      ok = ok && hip_ok(hipMemcpyAsync(f->d_step_ctr, ctr0, sizeof(ctr0), hipMemcpyHostToDevice, f->step_stream)) &&
+           hip_ok(hipStreamSynchronize(f->step_stream));   // (ctr0 is a stack variable)
+      if (ok && (!f->step_exec || std::memcmp(key, f->step_key, sizeof(key)) != 0)) {
+        if (f->step_exec) { (void)hipGraphExecDestroy(f->step_exec); f->step_exec = nullptr; }
+        if (f->step_graph) { (void)hipGraphDestroy(f->step_graph); f->step_graph = nullptr; }
+        hipStream_t cs = f->step_stream;
+        bool cap = hip_ok(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        int rc2 = 0;
+        if (cap) {
+          if (!hip_ok(sf_launch_step_begin(reinterpret_cast<const long long*>(order), f->d_step_ctr, (long)batch, f->d_step_rows, d->beta1,
+                                           d->beta2, f->d_step_bc, cs))) rc2 = SF_ERR_HIP;
+          if (!rc2) rc2 = sf_flow_loss_grad_rows(f, flat, theta, x, reinterpret_cast<const int64_t*>(f->d_step_rows), batch, grad_scale, nullptr,
+                                                 nullptr, loss_sum, grad, nullptr, cs);
+          if (!rc2 && !hip_ok(sf_launch_adam(flat, grad, exp_avg, exp_avg_sq, scratch, (long)f->L.n_params, *d, 1.f, 1.f, max_norm,
+                                             scratch + 1, cs, f->d_step_bc))) rc2 = SF_ERR_HIP;
+          if (!rc2 && !hip_ok(sf_launch_step_end(f->d_step_ctr, cs))) rc2 = SF_ERR_HIP;
+          hipGraph_t g = nullptr;
+          const bool ended = hip_ok(hipStreamEndCapture(cs, &g));
+          if (!rc2 && ended && g && hip_ok(hipGraphInstantiate(&f->step_exec, g, nullptr, nullptr, 0))) {
+            f->step_graph = g;
+            std::memcpy(f->step_key, key, sizeof(key));
+          } else {
+            if (g) (void)hipGraphDestroy(g);
+            f->step_exec = nullptr;
+            (void)hipGetLastError();
+          }
+        }
+      }
+      if (ok && f->step_exec) {
+        for (int64_t b = b0; b < n_batches && ok; ++b) ok = hip_ok(hipGraphLaunch(f->step_exec, f->step_stream));
+        if (!ok) return hip_fail(hipGetLastError(), "hipGraphLaunch (training step)");
+        SF_HIP(hipEventRecord(f->step_ev[1], f->step_stream));
+        SF_HIP(hipStreamWaitEvent(user, f->step_ev[1], 0));
+        f->params_set = true; f->flat_valid = false; f->ctab_x = nullptr;
+        return SF_OK;
+      }
+    }
+    (void)hipGetLastError();   // capture not possible here: the rest of the epoch the plain way
+  }
+  for (int64_t b = b0; b < n_batches; ++b) {
+    int rc = plain_step(b);
     if (rc) return rc;
   }
   return SF_OK;

@@ -159,6 +159,16 @@ struct sf_flow {
   long long* d_gfixC = nullptr; // SF_FIX_REPLICAS int64 gradient images (fixed-point accumulation, sf_fixacc.h)
   size_t gpartC_cap = 0;        // floats
   bool trainc_ready = false;
+  // captured training step of sf_flow_train_epoch (HIP graph: step_begin -> prep -> flow -> gather -> clip + Adam -> step_end)
+  hipGraph_t step_graph = nullptr;
+  hipGraphExec_t step_exec = nullptr;
+  hipStream_t step_stream = nullptr;     // the capture / replay stream (the caller's may be the legacy default stream)
+  hipEvent_t step_ev[2] = {nullptr, nullptr};
+  long long* d_step_ctr = nullptr;       // [2]: batch number within the epoch, Adam steps taken
+  float* d_step_bc = nullptr;            // [2]: Adam's bias corrections of the running step
+  long long* d_step_rows = nullptr;      // the running batch's rows
+  size_t step_rows_cap = 0;
+  unsigned long long step_key[16] = {0}; // what the graph was captured for
   float* d_ustash = nullptr;    // cooperative NSF training (sf_nsfc.hip): u / u' of every transform, [rows][T][16]
   size_t ustash_cap = 0;        // floats
   float* d_act = nullptr;       // activation stash (training)

@@ -14,6 +14,10 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
                        hipStream_t st,
                        std::string& err);
 
+// bc_dev != null: the two bias corrections are read from device memory (captured training step) instead of bc1 / bc2
 hipError_t sf_launch_adam(float* params, const float* grad, float* m, float* v, float* norm_scratch, long n,
                           const sf_adam_desc& d, float bc1, float bc2, float max_norm, float* grad_norm_out,
-                          hipStream_t st);
+                          hipStream_t st, const float* bc_dev = nullptr);
+hipError_t sf_launch_step_begin(const long long* order, long long* ctr, long batch, long long* rows_buf, float beta1, float beta2,
+                                float* bc, hipStream_t st);
+hipError_t sf_launch_step_end(long long* ctr, hipStream_t st);

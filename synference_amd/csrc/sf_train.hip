@@ -36,7 +36,8 @@ __global__ void k_sqnorm(const float* __restrict__ g, long n, float* __restrict_
 
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                        float* __restrict__ v, const float* __restrict__ sq, long n, sf_adam_desc d, float bc1,
-                       float bc2, float max_norm, float* __restrict__ norm_out) {
+                       float bc2, float max_norm, float* __restrict__ norm_out, const float* __restrict__ bc_dev) {
+  if (bc_dev) { bc1 = bc_dev[0]; bc2 = bc_dev[1]; }   // (captured training step: the step counter lives on the device)
   const float total = sqrtf(*sq);
   float coef = 1.f;
   if (max_norm > 0.f) coef = fminf(max_norm / (total + 1e-6f), 1.0f);  // torch clip_grad_norm_
@@ -63,7 +64,8 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
 __global__ __launch_bounds__(1024) void k_adam_fused(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, float* __restrict__ sq_out, long n,
                                                     sf_adam_desc d, float bc1, float bc2, float max_norm,
-                                                    float* __restrict__ norm_out) {
+                                                    float* __restrict__ norm_out, const float* __restrict__ bc_dev) {
+  if (bc_dev) { bc1 = bc_dev[0]; bc2 = bc_dev[1]; }
   // Everything this thread will need is requested before anything is waited for: its own elements of p / m / v / g (one
   // float4 each for n <= 4096 x blocks: the common case) AND its eight float4 of the gradient for the norm -- the kernel
   // is a chain of L2 round trips (32 k parameters: 12 us when the norm took two trips and the update a third).
@@ -138,13 +140,41 @@ __global__ __launch_bounds__(1024) void k_adam_fused(float* __restrict__ p, cons
   }
 }
 
+// start of a captured training step (sf_flow_train_epoch): the rows of batch number ctr[0] of the epoch's order -> rows_buf,
+// the bias corrections of Adam step ctr[1] + 1 -> bc[0..1]; both counters advance
+__global__ void k_step_begin(const long long* __restrict__ order, long long* __restrict__ ctr, long batch, long long* __restrict__ rows_buf,
+                             float beta1, float beta2, float* __restrict__ bc) {
+  const long long b = ctr[0];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < batch; i += (long)gridDim.x * blockDim.x)
+    rows_buf[i] = order[b * batch + i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const double step = (double)(ctr[1] + 1);
+    bc[0] = (float)(1.0 - pow((double)beta1, step));
+    bc[1] = (float)(1.0 - pow((double)beta2, step));
+  }
+}
+__global__ void k_step_end(long long* __restrict__ ctr) {
+  ctr[0] += 1;
+  ctr[1] += 1;
+}
+hipError_t sf_launch_step_begin(const long long* order, long long* ctr, long batch, long long* rows_buf, float beta1, float beta2,
+                                float* bc, hipStream_t st) {
+  const int blocks = (int)((batch + 255) / 256 < 64 ? (batch + 255) / 256 : 64);
+  hipLaunchKernelGGL(k_step_begin, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, order, ctr, batch, rows_buf, beta1, beta2, bc);
+  return hipGetLastError();
+}
+hipError_t sf_launch_step_end(long long* ctr, hipStream_t st) {
+  hipLaunchKernelGGL(k_step_end, dim3(1), dim3(1), 0, st, ctr);
+  return hipGetLastError();
+}
+
 hipError_t sf_launch_adam(float* params, const float* grad, float* m, float* v, float* norm_scratch, long n,
                           const sf_adam_desc& d, float bc1, float bc2, float max_norm, float* grad_norm_out,
-                          hipStream_t st) {
+                          hipStream_t st, const float* bc_dev) {
   if (n <= 131072 && ((uintptr_t)grad & 15) == 0) {  // (the fused kernel reads the gradient as float4)
     const int nb = (int)((n + 4095) / 4096);
     hipLaunchKernelGGL(k_adam_fused, dim3(nb < 1 ? 1 : nb), dim3(1024), 0, st, params, grad, m, v, norm_scratch, n, d, bc1,
-                       bc2, max_norm, grad_norm_out);
+                       bc2, max_norm, grad_norm_out, bc_dev);
     return hipGetLastError();
   }
   hipError_t e = hipMemsetAsync(norm_scratch, 0, sizeof(float), st);
@@ -152,7 +182,7 @@ hipError_t sf_launch_adam(float* params, const float* grad, float* m, float* v, 
   const int blocks = (int)((n + 1023) / 1024 < 256 ? (n + 1023) / 1024 : 256);
   hipLaunchKernelGGL(k_sqnorm, dim3(blocks), dim3(256), 0, st, grad, n, norm_scratch);
   hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, st, params, grad, m, v, norm_scratch, n, d, bc1, bc2,
-                     max_norm, grad_norm_out);
+                     max_norm, grad_norm_out, bc_dev);
   return hipGetLastError();
 }
 

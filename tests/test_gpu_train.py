@@ -208,18 +208,23 @@ def test_fused_epoch_equals_the_per_step_loop(name):
         if fused:
             class E:  # minimal estimator stand-in for HipTrainOps
                 flow = f
-            HipTrainOps(E).train_epoch(flat, T, X, order, nb, bs, 1.0 / bs, opt, 5.0, grad, tl)
+            # two epochs: the second call replays the HIP graph the first one captured (one step = step_begin -> prep -> flow
+            # -> gather -> clip + Adam -> step_end; the batch's rows and Adam's step number live on the device)
+            ops = HipTrainOps(E)
+            ops.train_epoch(flat, T, X, order, nb, bs, 1.0 / bs, opt, 5.0, grad, tl)
+            ops.train_epoch(flat, T, X, order, nb, bs, 1.0 / bs, opt, 5.0, grad, tl)
         else:
-            for b in range(nb):
-                idx = order[b * bs:(b + 1) * bs]
-                loss, _ = f.loss_grad(flat, T[idx], X[idx], 1.0 / bs, grad_out=grad)
-                opt.step(grad, 5.0)
-                tl += loss.double().sum()
+            for ep in range(2):
+                for b in range(nb):
+                    idx = order[b * bs:(b + 1) * bs]
+                    loss, _ = f.loss_grad(flat, T[idx], X[idx], 1.0 / bs, grad_out=grad)
+                    opt.step(grad, 5.0)
+                    tl += loss.double().sum()
         return flat.cpu().double().numpy(), float(tl.item()), opt.step_count
 
     fa, la, sa = run(False)
     fb, lb, sb = run(True)
-    assert sa == sb == nb
+    assert sa == sb == 2 * nb
     assert abs(la - lb) < 1e-3 * max(1.0, abs(la)), (la, lb)
     assert np.abs(fa - np.asarray(flat0, dtype=np.float64)).max() > 1e-3       # the parameters really moved
     assert np.abs(fa - fb).max() < 2e-4, np.abs(fa - fb).max()
