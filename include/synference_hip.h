@@ -195,7 +195,7 @@ int sf_flow_release_context(sf_flow* f);
  *                      the last look, the open slots of a galaxy that got NOT ONE draw accepted since then (counted
  *                      from its 64th attempt on) become NaN rows.
  * The host synchronises the stream once per launch pair (one pinned read-back).  n_drawn [M] may be NULL: attempts
- * consumed per galaxy.  *n_unfilled (host): number of NaN slots. */
+ * consumed per galaxy (int32: pinned at 2^31 - 1 once S x attempts would pass it).  *n_unfilled (host): number of NaN slots. */
 int sf_flow_sample(sf_flow* f, const float* x /*[M,C]*/, int64_t M, int64_t S,
                    const float* lo, const float* hi, uint64_t seed, int32_t max_attempts,
                    float* out /*[M,S,D]*/, int32_t* n_drawn /*[M]*/, int64_t* n_unfilled /*host*/,

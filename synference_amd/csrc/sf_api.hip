@@ -155,6 +155,7 @@ int64_t sf_flow_packed_size(const sf_flow* f) { return f ? f->L.n_packed : 0; }
 int sf_flow_pack_table(const sf_flow* f, int32_t* src1, int32_t* src2, int64_t n_packed) {
   if (!f || !src1 || !src2) return fail(SF_ERR_INVALID, "null argument");
   if (n_packed != f->L.n_packed) return fail(SF_ERR_INVALID, "n_packed mismatch");
+  if (n_packed == 0) return SF_OK;   // (empty tables have no storage to copy from)
   std::memcpy(src1, f->L.src1.data(), (size_t)n_packed * sizeof(int32_t));
   std::memcpy(src2, f->L.src2.data(), (size_t)n_packed * sizeof(int32_t));
   return SF_OK;

@@ -31,6 +31,13 @@ __device__ __forceinline__ float sf_div(float a, float b) { return a * __builtin
 __device__ __forceinline__ float sf_softplus(float x) {  // torch: threshold 20
   return x > 20.0f ? x : sf_log(1.0f + sf_exp(x));
 }
+// attempts-per-galaxy counters (n_drawn): int32, pinned at INT32_MAX once they would wrap (no attempt ceiling + S slots of
+// a galaxy that accepts one draw in a million: S x attempts passes 2^31).  An add that finds the counter too full to take it
+// writes the maximum back; whatever order concurrent adds arrive in, the last write after an overflow is such a write.
+__device__ __forceinline__ void sf_sat_add(int32_t* p, int v) {
+  const int old = atomicAdd(p, v);
+  if (v > 0 && old > 0x7fffffff - v) atomicExch(p, 0x7fffffff);
+}
 __device__ __forceinline__ float sf_xhalf(float v) {  // value held by the other row-half
   return __shfl_xor(v, 32, 64);
 }

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(64 * WPB) void k_sample_persist(SfSampArgs args_in,
         const long gal = (long)(slot / (uint32_t)a.S);
         // (the caller pre-counts ONE attempt per slot; a first attempt that ran with speculation may have used more)
       const int used = (first >= 0 ? first + 1 : (int)tried) - (att_base == 0u ? 1 : 0);
-      if (a.n_drawn && used > 0) atomicAdd(&a.n_drawn[gal], used);
+      if (a.n_drawn && used > 0) sf_sat_add(&a.n_drawn[gal], used);
         if (hit && a.gal_acc && att_base >= 64u) atomicAdd(&a.gal_acc[gal], 1);  // progress past the 64th attempt
       }
       if (retry) {

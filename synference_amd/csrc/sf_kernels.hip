@@ -4,6 +4,7 @@
 
 #include <cstdlib>
 
+#include "sf_device.h"
 #include "sf_internal.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -102,7 +103,7 @@ __global__ void k_account_window(const uint32_t* __restrict__ list, const uint32
   if (i >= n) return;
   const long g = (long)(list[i] / (uint32_t)S);
   const uint32_t b = best[i];
-  if (n_drawn) atomicAdd(&n_drawn[g], b != 0xffffffffu ? (int)(b - a_lo + 1u) : (int)A);
+  if (n_drawn) sf_sat_add(&n_drawn[g], b != 0xffffffffu ? (int)(b - a_lo + 1u) : (int)A);
   if (gal_acc && b != 0xffffffffu) atomicAdd(&gal_acc[g], 1);
 }
 

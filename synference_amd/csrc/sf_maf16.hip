@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16(SfDev m, SfSampleArgsHost 
     const int first = gmask ? (int)__builtin_ctz(gmask) : -1;
     const int me = s - grp0;
     if (valid) {
-      if (g4 == 0 && me == 0 && a.n_drawn && a.attempt > 0) atomicAdd(&a.n_drawn[gal], first >= 0 ? first + 1 : A);
+      if (g4 == 0 && me == 0 && a.n_drawn && a.attempt > 0) sf_sat_add(&a.n_drawn[gal], first >= 0 ? first + 1 : A);
       if (me == first) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -972,7 +972,7 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
         const long gal = (long)(slot / (uint32_t)a.S);
         // (the caller pre-counts ONE attempt per slot; a first attempt that ran with speculation may have used more)
         const int used = (first >= 0 ? first + 1 : (int)tried) - (att_base == 0u ? 1 : 0);
-        if (a.n_drawn && used > 0) atomicAdd(&a.n_drawn[gal], used);
+        if (a.n_drawn && used > 0) sf_sat_add(&a.n_drawn[gal], used);
         if (hit && a.gal_acc && att_base >= 64u) atomicAdd(&a.gal_acc[gal], 1);  // progress past the 64th attempt
       }
       if (retry) {

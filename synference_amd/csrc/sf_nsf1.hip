@@ -158,7 +158,7 @@ __global__ void k_nsf1_sample(const float* __restrict__ qg, long M, long S, cons
     if (ok) th = cand;
   }
   out[slot] = th;
-  if (n_drawn) atomicAdd(n_drawn + g, (int32_t)att);
+  if (n_drawn) sf_sat_add(n_drawn + g, (int32_t)att);
   if (!ok) atomicAdd(n_unfilled, 1u);
 }
 

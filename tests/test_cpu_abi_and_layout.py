@@ -42,6 +42,11 @@ def test_packer_plus_wave_model_reproduce_oracle(name):
     ospec, spec, flat, theta, x = make_case(name, B=32)
     hf = HipFlow(spec)  # creating a handle needs no GPU
     d = hf.describe()
+    if spec.nsf_1d:   # the one-parameter NSF runs on the MLP engine's image (csrc/sf_nsf1.hip): no flow operand image to model
+        assert hf.packed_size() == 0 and hf.n_params == len(flat) == spec.T * (spec.H * spec.C + spec.H + spec.H * spec.H + spec.H
+                                                                                 + (3 * spec.K - 1) * (spec.H + 1))
+        assert len(hf.pack_table()[0]) == 0 and hf.trainc_table() is None
+        return
     s1, s2 = hf.pack_table()
     assert hf.n_params == len(flat) and len(s1) == d["n_packed"] == hf.packed_size()
     used = np.concatenate([s1[s1 >= 0], s2[s2 >= 0]])
@@ -111,8 +116,8 @@ def test_masked_made_entries_are_not_in_the_image():
 def test_unsupported_shapes_are_rejected_with_a_message():
     from synference_amd.engine import HipFlow
     from synference_amd.spec import FlowSpec
-    for kw in (dict(kind="maf", D=17, C=3), dict(kind="maf", D=3, C=3, H=200), dict(kind="nsf", D=1, C=3),
-               dict(kind="nsf", D=3, C=3, K=20)):
+    for kw in (dict(kind="maf", D=17, C=3), dict(kind="maf", D=3, C=3, H=200), dict(kind="nsf", D=1, C=3, T=17),
+               dict(kind="nsf", D=1, C=3, K=20), dict(kind="nsf", D=3, C=3, K=20)):
         with pytest.raises(RuntimeError):
             HipFlow(FlowSpec(**kw))
     with pytest.raises(ValueError):
