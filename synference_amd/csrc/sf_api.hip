@@ -887,10 +887,13 @@ int sf_flow_train_epoch(sf_flow* f, float* flat, const float* theta, const float
   // bias correction -- lives on the device: k_step_begin copies rows [ctr[0] * batch, ...) of `order` into a fixed buffer the
   // training kernels read and computes 1 - beta^(ctr[1] + 1); k_step_end advances both counters.  The first step of a call
   // runs the plain way (lazy allocations, function attributes); the graph is kept on the handle and captured again only when
-  // an argument changes.  SF_TRAIN_GRAPH=0 switches it off; a flow kind whose step is not capturable (the one-parameter NSF
-  // allocates inside its MLP calls) never uses it.
+  // an argument changes.  OPT-IN (SF_TRAIN_GRAPH=1): measured on the bench workloads the replay is SLOWER than the four
+  // back-to-back launches it replaces -- MAF cfg1 at batch 16 384: 0.117 ms per step against 0.091, NSF cfg3: 0.370 against
+  // 0.351 (hipGraphLaunch of a 6-node graph costs more on this runtime than the launches' own overhead, which the GPU hides
+  // behind the previous step anyway).  A flow kind whose step is not capturable (the one-parameter NSF allocates inside its
+  // MLP calls) never uses it.
   static int use_graph = -1;
-  if (use_graph < 0) { const char* e = std::getenv("SF_TRAIN_GRAPH"); use_graph = e ? std::atoi(e) : 1; }
+  if (use_graph < 0) { const char* e = std::getenv("SF_TRAIN_GRAPH"); use_graph = e ? std::atoi(e) : 0; }
   int64_t b0 = 0;
   if (use_graph && n_batches >= 4 && !f->nsf1 && !f->profiling) {
     int rc = plain_step(0);

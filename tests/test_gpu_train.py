@@ -7,6 +7,8 @@ from cases import CASES, make_case
 from oracle import flows as OF
 
 pytestmark = pytest.mark.gpu
+import os as _os
+ROOT_DIR = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
 
 
 def oracle_loss_grad(ospec, flat, theta, x):
@@ -208,8 +210,7 @@ def test_fused_epoch_equals_the_per_step_loop(name):
         if fused:
             class E:  # minimal estimator stand-in for HipTrainOps
                 flow = f
-            # two epochs: the second call replays the HIP graph the first one captured (one step = step_begin -> prep -> flow
-            # -> gather -> clip + Adam -> step_end; the batch's rows and Adam's step number live on the device)
+            # two epochs (the second continues the Adam step count of the first)
             ops = HipTrainOps(E)
             ops.train_epoch(flat, T, X, order, nb, bs, 1.0 / bs, opt, 5.0, grad, tl)
             ops.train_epoch(flat, T, X, order, nb, bs, 1.0 / bs, opt, 5.0, grad, tl)
@@ -272,3 +273,40 @@ def test_small_batch_gradients_are_bitwise_reproducible(name):
     rloss, rgrad = oracle_loss_grad(ospec, flat, theta[:300], x[:300])
     _, g300 = f.loss_grad(fl, theta[:300], x[:300], 1.0 / 300)
     assert np.abs(g300.cpu().double().numpy() - rgrad).max() < 2e-4 * np.abs(rgrad).max()
+
+
+@pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3"])
+def test_captured_graph_epoch_equals_the_plain_epoch(name, tmp_path):
+    """SF_TRAIN_GRAPH=1: sf_flow_train_epoch replays ONE captured HIP graph per step (step_begin -> prep -> flow -> gather ->
+    clip + Adam -> step_end; the batch's rows and Adam's step number live on the device).  Same parameters, bit for bit, as
+    the plain launches (both forms are deterministic at this batch size); the second epoch re-uses the graph with a new step
+    count.  Fresh processes: the switch is read once."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from cases import make_case\n"
+        "from synference_amd.engine import HipFlow\n"
+        "from synference_amd.runner import HipAdam, HipTrainOps\n"
+        "ospec, spec, flat0, theta, x = make_case(%r, B=900)\n"
+        "dev = torch.device('cuda:0')\n"
+        "T = torch.as_tensor(theta, dtype=torch.float32, device=dev); X = torch.as_tensor(x, dtype=torch.float32, device=dev)\n"
+        "order = torch.randperm(900, generator=torch.Generator().manual_seed(3)).to(dev)\n"
+        "f = HipFlow(spec, dev); flat = torch.as_tensor(flat0, dtype=torch.float32, device=dev).clone()\n"
+        "opt = HipAdam(flat, lr=3e-3); grad = torch.empty_like(flat); tl = torch.zeros((), dtype=torch.float64, device=dev)\n"
+        "class E: flow = f\n"
+        "ops = HipTrainOps(E)\n"
+        "for ep in range(2): ops.train_epoch(flat, T, X, order, 9, 96, 1.0 / 96, opt, 5.0, grad, tl)\n"
+        "torch.cuda.synchronize(); np.savez(sys.argv[1], flat=flat.cpu().numpy(), tl=float(tl.item()), steps=opt.step_count)\n"
+    ) % (ROOT_DIR, os.path.join(ROOT_DIR, "tests"), name)
+    got = {}
+    for g in ("0", "1"):
+        out = tmp_path / f"g{g}.npz"
+        r = subprocess.run([sys.executable, "-c", code, str(out)], env=dict(os.environ, SF_TRAIN_GRAPH=g), capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        got[g] = np.load(out)
+    assert int(got["0"]["steps"]) == int(got["1"]["steps"]) == 18
+    assert np.array_equal(got["0"]["flat"], got["1"]["flat"]) and float(got["0"]["tl"]) == float(got["1"]["tl"])
