@@ -44,7 +44,7 @@ class FlowSpec:
     every constant is overridable because upstream versions differ.
     """
 
-    kind: str  # "maf" | "nsf"
+    kind: str  # "maf" | "nsf" | "nsf_ar" (zuko / lampe autoregressive NSF)
     D: int  # theta dimension (flow inputs)
     C: int  # context width seen by the transforms
     H: int = 50  # hidden_features (sbi_runner.py:4402)
@@ -59,6 +59,7 @@ class FlowSpec:
     lu_eps: float = 1e-3
     scale_fn: str = "softplus"  # nflows>=0.14; "sigmoid2" = sigmoid(a+2) (nflows<=0.13)
     hidden_bf16: bool = False  # emulate the HIP bf16 mode: hidden HxH operands rounded to bf16, wide accumulate
+    ar_slope: float = 1e-3  # nsf_ar: zuko MonotonicRQSTransform(slope=...): soft clip of the spline logits
     theta_mean: Optional[np.ndarray] = None
     theta_std: Optional[np.ndarray] = None
     x_mean: Optional[np.ndarray] = None
@@ -66,7 +67,7 @@ class FlowSpec:
     perms: Optional[np.ndarray] = None  # [T, D] int64, MAF RandomPermutation buffers
 
     def __post_init__(self):
-        assert self.kind in ("maf", "nsf")
+        assert self.kind in ("maf", "nsf", "nsf_ar")
         if self.theta_mean is None:
             self.theta_mean = np.zeros(self.D)
         if self.theta_std is None:
@@ -135,6 +136,7 @@ def param_layout(spec: FlowSpec) -> List[Tuple[str, Tuple[int, ...], int]]:
            Wout[d_tr*(3K-1),H] bout[...]  then (D>1) LU: lower[D(D-1)/2]
            upper[D(D-1)/2] udiag[D] lubias[D]
       NSF with D = 1: csm.W0[H,C] b0[H] W1[H,H] b1[H] W2[3K-1,H] b2[3K-1]
+      nsf_ar (zuko): ar.W0[H,D+C] b0[H] {ar.Wk[H,H] bk[H]} x (NB-1)  ar.W_NB[D(3K-1),H] b_NB[D(3K-1)]
     cfg1 MAF: 6460 per transform; cfg3 NSF: 18314 per transform.
     """
     out: List[Tuple[str, Tuple[int, ...], int]] = []
@@ -154,6 +156,13 @@ def param_layout(spec: FlowSpec) -> List[Tuple[str, Tuple[int, ...], int]]:
             for k in range(spec.NB):
                 add(p + f"W{k + 1}", (H, H)); add(p + f"b{k + 1}", (H,))
             add(p + "Wf", (2 * D, H)); add(p + "bf", (2 * D,))
+        elif spec.kind == "nsf_ar":
+            # zuko MaskedMLP hyper-network of one MaskedAutoregressiveTransform: NB hidden MaskedLinear layers of width H
+            # (lampe / ltu-ili: two), then the head with D * (3K - 1) rows -- per dimension [K widths, K heights, K - 1 derivatives]
+            add(p + "ar.W0", (H, D + C)); add(p + "ar.b0", (H,))
+            for k in range(1, spec.NB):
+                add(p + f"ar.W{k}", (H, H)); add(p + f"ar.b{k}", (H,))
+            add(p + f"ar.W{spec.NB}", (D * (3 * spec.K - 1), H)); add(p + f"ar.b{spec.NB}", (D * (3 * spec.K - 1),))
         elif spec.nsf_1d:
             # sbi build_nsf with a scalar theta: ContextSplineMap(hidden_layers=1) -- Linear(C, H), ReLU, Linear(H, H), ReLU,
             # Linear(H, 3K - 1) on the embedded context alone; no LULinear
@@ -300,6 +309,92 @@ def _context_spline_map(spec: FlowSpec, P: Dict[str, torch.Tensor], t: int, e: t
     return F.linear(h, P[p + "W2"], P[p + "b2"])
 
 
+# --------------------------------------------------------------------------------------
+# zuko / lampe autoregressive NSF  (ref: sbi_runner.py:5123-5125 `ili.utils.load_nde_lampe`;
+# examples/sbi/scripts/basic_model.py:31-41 trains a three-member ensemble of them)
+# --------------------------------------------------------------------------------------
+# [UPSTREAM, restated from the published zuko sources (zuko.flows.NSF -> MAF -> MaskedAutoregressiveTransform -> MaskedMLP,
+#  zuko.transforms.MonotonicRQSTransform); parity unpinned like every other flow here]
+#   * transforms t = 0 .. T-1 alternate the ordering: order_t = arange(D) for even t, reversed for odd t (randperm=False);
+#   * hyper-network input [theta ; context], adjacency A[o, i] = order[o // (3K-1)] > in_order[i], in_order = [order, -1 x C]:
+#     the parameters of dimension d see the dimensions ordered before it and the whole context;
+#   * MaskedMLP: the UNIQUE rows of A (one per order value r, sorted: index r) are the unit "types"; hidden unit h of every
+#     hidden layer has type h mod D; first-layer mask = A-row of the type; later masks: type(in) <= type(out) (row inclusion);
+#     head row of a dimension with order value r: hidden types <= r.  ReLU between layers;
+#   * MonotonicRQSTransform(widths, heights, derivatives, bound = 5, slope = 1e-3): logits soft-clipped
+#     w / (1 + |2 w / log slope|) (derivatives: d / (1 + |d / log slope|)), softmax -> knots on [-bound, bound] (no minimum bin
+#     size), knot derivatives exp(.) with 1 at both ends, identity outside the bound; bin = searchsorted(knots, x) - 1.
+def ar_order(spec: FlowSpec, t: int) -> np.ndarray:
+    o = np.arange(spec.D)
+    return o if t % 2 == 0 else o[::-1].copy()
+
+
+def ar_masks(spec: FlowSpec, t: int) -> List[np.ndarray]:
+    """Boolean masks [first hidden (H, D+C), later hidden (H, H) x (NB-1), head (D(3K-1), H)] of transform t."""
+    D, C, H, NP = spec.D, spec.C, spec.H, 3 * spec.K - 1
+    order = ar_order(spec, t)
+    in_order = np.concatenate([order, np.full(C, -1)])
+    typ = np.arange(H) % D                                   # type (= order value) of hidden unit h
+    masks = [typ[:, None] > in_order[None, :]]               # A-row of the type
+    for _ in range(1, spec.NB):
+        masks.append(typ[:, None] >= typ[None, :])           # row inclusion: type(in) <= type(out)
+    out_type = np.repeat(order, NP)
+    masks.append(out_type[:, None] >= typ[None, :])
+    return masks
+
+
+def _ar_hyper(spec: FlowSpec, P: Dict[str, torch.Tensor], t: int, u: torch.Tensor, e: torch.Tensor) -> torch.Tensor:
+    p = f"t{t}.ar."
+    M = [_t(m.astype(np.float64), u) for m in ar_masks(spec, t)]
+    h = torch.cat([u, e], dim=1)
+    for k in range(spec.NB + 1):
+        h = F.linear(h, P[p + f"W{k}"] * M[k], P[p + f"b{k}"])
+        if k < spec.NB:
+            h = F.relu(h)
+    return h.view(-1, spec.D, 3 * spec.K - 1)
+
+
+def _ar_knots(spec: FlowSpec, q: torch.Tensor):
+    """(horizontal, vertical, derivatives) of zuko's MonotonicRQSTransform from the raw head outputs q[..., 3K-1]."""
+    K, B = spec.K, spec.tail_bound
+    ls = math.log(spec.ar_slope)
+    w, hh, d = q[..., :K], q[..., K:2 * K], q[..., 2 * K:]
+    w = w / (1 + torch.abs(2 * w / ls))
+    hh = hh / (1 + torch.abs(2 * hh / ls))
+    d = d / (1 + torch.abs(d / ls))
+    w = F.pad(F.softmax(w, dim=-1), (1, 0), value=0.0)
+    hh = F.pad(F.softmax(hh, dim=-1), (1, 0), value=0.0)
+    d = F.pad(d, (1, 1), value=0.0)
+    return B * (2 * torch.cumsum(w, dim=-1) - 1), B * (2 * torch.cumsum(hh, dim=-1) - 1), torch.exp(d)
+
+
+def ar_spline(spec: FlowSpec, v: torch.Tensor, q: torch.Tensor, inverse: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    """zuko MonotonicRQSTransform._call / ._inverse with log|det|; v [B, d], q [B, d, 3K-1]."""
+    K = spec.K
+    hor, ver, der = _ar_knots(spec, q)
+    seq = (ver if inverse else hor).contiguous()
+    k = torch.searchsorted(seq, v[..., None].contiguous()).squeeze(-1) - 1
+    mask = (k >= 0) & (k < K)
+    k = k % K
+    g = lambda a, kk: a.gather(-1, kk[..., None]).squeeze(-1)
+    x0, x1, y0, y1, d0, d1 = g(hor, k), g(hor, k + 1), g(ver, k), g(ver, k + 1), g(der, k), g(der, k + 1)
+    s = (y1 - y0) / (x1 - x0)
+    if not inverse:
+        z = mask * (v - x0) / (x1 - x0)
+        y = y0 + (y1 - y0) * (s * z ** 2 + d0 * z * (1 - z)) / (s + (d0 + d1 - 2 * s) * z * (1 - z))
+        out = torch.where(mask, y, v)
+    else:
+        y_ = mask * (v - y0)
+        a = (y1 - y0) * (s - d0) + y_ * (d0 + d1 - 2 * s)
+        b = (y1 - y0) * d0 - y_ * (d0 + d1 - 2 * s)
+        c = -s * y_
+        z = 2 * c / (-b - torch.sqrt(b ** 2 - 4 * a * c))
+        out = torch.where(mask, x0 + z * (x1 - x0), v)
+    jac = s ** 2 * (2 * s * z * (1 - z) + d0 * (1 - z) ** 2 + d1 * z ** 2) / (s + (d0 + d1 - 2 * s) * z * (1 - z)) ** 2
+    lad = mask * torch.log(jac)
+    return out, (-lad if inverse else lad)
+
+
 def _knots(spec: FlowSpec, logits: torch.Tensor, min_size: float) -> Tuple[torch.Tensor, torch.Tensor]:
     """softmax -> min size -> cumsum -> [-B, B] knots; returns (knots[...,K+1], sizes[...,K])."""
     K, B = spec.K, spec.tail_bound
@@ -399,6 +494,11 @@ def forward_transform(spec: FlowSpec, flat: torch.Tensor, theta: torch.Tensor, x
             u = s * u + m
             logdet = logdet + torch.log(s).sum(-1)
             u = u[:, torch.as_tensor(spec.perms[t])]
+    elif spec.kind == "nsf_ar":
+        for t in range(spec.T):
+            q = _ar_hyper(spec, P, t, u, e)
+            u, lad = ar_spline(spec, u, q, inverse=False)
+            logdet = logdet + lad.sum(-1)
     else:
         for t in range(spec.T):
             if spec.nsf_1d:
@@ -450,6 +550,17 @@ def inverse_transform(spec: FlowSpec, flat: torch.Tensor, z: torch.Tensor, x: to
                 s = _scale_from_unconstrained(spec, a)
                 w = (v - m) / s
             logdet = logdet - torch.log(s).sum(-1)
+            u = w
+    elif spec.kind == "nsf_ar":
+        for t in reversed(range(spec.T)):
+            # zuko AutoregressiveTransform._inverse: `passes` = D sweeps of the hyper-network, each inverting every dimension
+            # with the parameters of the current iterate; after sweep j the dimensions of order < j are exact
+            v = u
+            w = torch.zeros_like(v)
+            for _ in range(spec.D):
+                q = _ar_hyper(spec, P, t, w, e)
+                w, lad = ar_spline(spec, v, q, inverse=True)
+            logdet = logdet + lad.sum(-1)
             u = w
     else:
         for t in reversed(range(spec.T)):

@@ -21,9 +21,15 @@ struct SfAcc {
   long long* fix;     // mode 3: this workgroup's replica
 };
 
+// Atomics on a replica are issued at WORKGROUP scope: an agent-scope atomic carries sc1 and is forwarded by the L2 to the
+// fabric (measured: WRITE_SIZE = every atomic's bytes, profiles/r04_pmc_nsfatomic.csv), a workgroup-scope one is executed by
+// the XCD's own L2 -- which is the only L2 that ever touches this replica; the end-of-kernel write-back publishes the sums.
+__device__ __forceinline__ void sf_l2_add(float* p, float v) {
+  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __device__ __forceinline__ void sf_fix_add(long long* p, float v) {
   const long long q = __double2ll_rn((double)v * SF_FIX_SCALE);
-  atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)q);
+  (void)__hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(p), (unsigned long long)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ int sf_xcc_id() {
   int xcc;

@@ -109,7 +109,7 @@ __device__ __forceinline__ void n_dw_finish(const NJob& J, f32x4 acc, float bs, 
   if (A.mode == 2) {
     float* q = reinterpret_cast<float*>(A.fix) + (J.gw - A.base);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) unsafeAtomicAdd(q + r * 64 + lane, acc[r]);
+    for (int r = 0; r < 4; ++r) sf_l2_add(q + r * 64 + lane, acc[r]);
   } else if (A.mode == 3) {
     long long* q = A.fix + (J.gw - A.base);
 #pragma unroll
@@ -126,7 +126,7 @@ __device__ __forceinline__ void n_dw_finish(const NJob& J, f32x4 acc, float bs, 
     bs += __shfl_xor(bs, 16, 64);
     bs += __shfl_xor(bs, 32, 64);
     if (lane < 16) {
-      if (A.mode == 2) unsafeAtomicAdd(reinterpret_cast<float*>(A.fix) + (J.gb - A.base) + J.ot * 16 + lane, bs);
+      if (A.mode == 2) sf_l2_add(reinterpret_cast<float*>(A.fix) + (J.gb - A.base) + J.ot * 16 + lane, bs);
       else if (A.mode == 3) sf_fix_add(A.fix + (J.gb - A.base) + J.ot * 16 + lane, bs);
       else J.gb[J.ot * 16 + lane] = A.mode == 1 ? J.gb[J.ot * 16 + lane] + bs : bs;
     }
