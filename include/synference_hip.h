@@ -31,6 +31,8 @@
  *        Wout[d_tr*(3K-1),H] bout[d_tr*(3K-1)]
  *        and, when D > 1: lower[D(D-1)/2] upper[D(D-1)/2] udiag[D] lubias[D]
  *        (tril / triu index order, row-major, as numpy tril_indices(D,-1) / triu_indices(D,1))
+ *   NSF_AR: W0[H,D+C] b0[H] W1[H,H] b1[H] W2[D*(3K-1),H] b2[D*(3K-1)]   (NB = 2 hidden layers; row d*(3K-1)+j of the
+ *        head: j in [0,K) widths, [K,2K) heights, [2K,3K-1) derivatives of dimension d; tail_bound = zuko's `bound` [5])
  * MADE masks are implied by (D, H) and applied inside the library (masked entries of
  * the flat vector are ignored on input and receive zero gradient).
  */
@@ -55,7 +57,9 @@ enum sf_status {
   SF_ERR_STATE = -4        /* e.g. parameters not set */
 };
 
-enum sf_kind { SF_MAF = 0, SF_NSF = 1 };
+/* SF_NSF_AR: the autoregressive NSF of the reference's second backend (backend="lampe" -> zuko.flows.NSF;
+ * ref: src/synference/sbi_runner.py:5123-5125): masked hyper-network + zuko's monotonic rational-quadratic spline */
+enum sf_kind { SF_MAF = 0, SF_NSF = 1, SF_NSF_AR = 2 };
 
 /* Static description of one flow.  Pointer members are HOST arrays read during
  * sf_flow_create only.  Defaults of the upstream stack (sbi/nflows) in brackets. */
@@ -82,6 +86,7 @@ typedef struct sf_flow_desc {
   const float* x_mean;     /* host [C]  (sbi standardizing_net) */
   const float* x_std;      /* host [C] */
   const int32_t* perms;    /* host [T*D] MAF RandomPermutation buffers, NULL = identity */
+  float ar_slope;          /* SF_NSF_AR: slope of zuko's MonotonicRQSTransform [1e-3]; ignored by the other kinds */
 } sf_flow_desc;
 
 /* ---- lifetime ---------------------------------------------------------------------- */

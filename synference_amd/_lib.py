@@ -26,7 +26,7 @@ class sf_flow_desc(C.Structure):
         ("tail_bound", C.c_float), ("min_bin_width", C.c_float), ("min_bin_height", C.c_float),
         ("min_derivative", C.c_float), ("maf_eps", C.c_float), ("lu_eps", C.c_float),
         ("theta_mean", c_f32p), ("theta_std", c_f32p), ("x_mean", c_f32p), ("x_std", c_f32p),
-        ("perms", c_i32p),
+        ("perms", c_i32p), ("ar_slope", C.c_float),
     ]
 
 

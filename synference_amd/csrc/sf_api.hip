@@ -12,6 +12,7 @@
 #include "sf_internal.h"
 #include "sf_train.h"
 #include "sf_nsf1.h"
+#include "sf_nsfar.h"
 #include "sf_nsfc.h"
 #include "sf_trainc.h"
 
@@ -33,7 +34,7 @@ int hip_fail(hipError_t e, const char* what) {
 }  // namespace
 
 static int ensure_device(sf_flow* f) {
-  if (f->nsf1) {
+  if (f->nsf1 || f->nsfar) {
     if (f->dev_ready) return SF_OK;
     int nd = 0;
     if (hipGetDeviceCount(&nd) != hipSuccess || nd == 0) return fail(SF_ERR_NO_DEVICE, "no HIP device visible");
@@ -110,6 +111,21 @@ int sf_flow_create(const sf_flow_desc* desc, sf_flow** out) {
     *out = f1;
     return SF_OK;
   }
+  if (desc->kind == SF_NSF_AR) {  // the autoregressive NSF of the lampe / zuko backend (sf_nsfar.hip)
+    sf_flow* fa = new sf_flow();
+    std::string err;
+    int rc = sf_nsfar_create(*desc, &fa->nsfar, err);
+    if (rc) { delete fa; return fail(rc, err); }
+    std::memset(&fa->L.dev, 0, sizeof(fa->L.dev));
+    std::memset(&fa->L.trc, 0, sizeof(fa->L.trc));
+    std::memset(&fa->L.nsc, 0, sizeof(fa->L.nsc));
+    std::memset(&fa->L.nsfS, 0, sizeof(fa->L.nsfS));
+    SfDev& v = fa->L.dev;
+    v.kind = SF_NSF_AR; v.D = desc->D; v.C = desc->C; v.H = desc->H; v.T = desc->T; v.K = desc->K; v.NB = desc->NB;
+    fa->L.n_params = fa->nsfar->n_params;
+    *out = fa;
+    return SF_OK;
+  }
   sf_flow* f = new sf_flow();
   if (!sf_build_layout(*desc, f->L)) {
     std::string e = f->L.error;
@@ -122,8 +138,9 @@ int sf_flow_create(const sf_flow_desc* desc, sf_flow** out) {
 
 void sf_flow_destroy(sf_flow* f) {
   if (!f) return;
-  if (f->nsf1) {
+  if (f->nsf1 || f->nsfar) {
     sf_nsf1_destroy(f->nsf1);
+    sf_nsfar_destroy(f->nsfar);
     if (f->dev_ready) (void)hipFree(f->d_flat);
     if (f->ev_train[0]) (void)hipEventDestroy(f->ev_train[0]);
     if (f->ev_train[1]) (void)hipEventDestroy(f->ev_train[1]);
@@ -150,10 +167,16 @@ void sf_flow_destroy(sf_flow* f) {
 }
 
 int64_t sf_flow_num_params(const sf_flow* f) { return f ? f->L.n_params : 0; }
-int64_t sf_flow_packed_size(const sf_flow* f) { return f ? f->L.n_packed : 0; }
+int64_t sf_flow_packed_size(const sf_flow* f) { return !f ? 0 : (f->nsfar ? (int64_t)f->nsfar->src.size() : f->L.n_packed); }
 
 int sf_flow_pack_table(const sf_flow* f, int32_t* src1, int32_t* src2, int64_t n_packed) {
   if (!f || !src1 || !src2) return fail(SF_ERR_INVALID, "null argument");
+  if (f->nsfar) {   // one gather table (sf_nsfar.hip); the second is "none" everywhere
+    if (n_packed != (int64_t)f->nsfar->src.size()) return fail(SF_ERR_INVALID, "n_packed mismatch");
+    std::memcpy(src1, f->nsfar->src.data(), (size_t)n_packed * sizeof(int32_t));
+    for (int64_t i = 0; i < n_packed; ++i) src2[i] = -1;
+    return SF_OK;
+  }
   if (n_packed != f->L.n_packed) return fail(SF_ERR_INVALID, "n_packed mismatch");
   if (n_packed == 0) return SF_OK;   // (empty tables have no storage to copy from)
   std::memcpy(src1, f->L.src1.data(), (size_t)n_packed * sizeof(int32_t));
@@ -204,6 +227,22 @@ int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen) {
   const SfDev& v = f->L.dev;
   std::string s = "{";
   auto add = [&](const char* k, long val) { s += "\"" + std::string(k) + "\": " + std::to_string(val) + ", "; };
+  if (f->nsfar) {   // the autoregressive NSF has its own images (sf_nsfar.h)
+    const SfNsfAr& n = *f->nsfar;
+    add("kind", SF_NSF_AR); add("D", n.D); add("C", n.C); add("H", n.H); add("T", n.T); add("K", n.K); add("NB", 2);
+    add("Hp", n.Hp); add("t_stride", n.t_stride); add("n_params", (long)n.n_params); add("n_packed", (long)n.src.size());
+    add("o_L0t", n.o_L0t); add("o_b0", n.o_b0); add("o_L1t", n.o_L1t); add("o_L1m", n.o_L1m); add("o_b1", n.o_b1);
+    add("o_L2t", n.o_L2t); add("o_b2", n.o_b2); add("o_L0m", n.o_L0m); add("lds_bytes_train", (long)sf_nsfar_lds_bytes(n, 3));
+    auto arr = [&](const char* k, const std::vector<int32_t>& a, bool last) {
+      s += "\"" + std::string(k) + "\": [";
+      for (size_t i = 0; i < a.size(); ++i) s += std::to_string(a[i]) + (i + 1 < a.size() ? ", " : "");
+      s += last ? "]}" : "], ";
+    };
+    arr("perm", n.perm, false); arr("ptype", n.ptype, false); arr("tend", n.tend, false); arr("ord", n.ord, false); arr("dimof", n.dimof, true);
+    if (s.size() + 1 > buflen) return fail(SF_ERR_INVALID, "buffer too small");
+    std::memcpy(buf, s.c_str(), s.size() + 1);
+    return SF_OK;
+  }
   add("kind", v.kind); add("D", v.D); add("C", v.C); add("H", v.H); add("T", v.T); add("K", v.K);
   add("NB", v.NB); add("HT", v.HT); add("PT", v.PT); add("KMAX", v.KMAX); add("JP", v.JP);
   add("nGu", v.nGu); add("nGc", v.nGc); add("nGh", v.nGh); add("t_stride", v.t_stride);
@@ -268,6 +307,13 @@ int sf_flow_set_params(sf_flow* f, const float* flat, int64_t n, int is_device, 
   const float* src = f->d_flat;
   f->flat_valid = true;
   if (f->nsf1) { f->params_set = true; return SF_OK; }   // (the MLP engine re-tiles per call)
+  if (f->nsfar) {
+    std::string err;
+    rc = sf_nsfar_pack(f->nsfar, src, st, err);
+    if (rc) return fail(rc, err);
+    f->params_set = true;
+    return SF_OK;
+  }
   SF_HIP(sf_launch_pack(src, f->d_s1, f->d_s2, f->d_packed, (long)f->L.n_packed, st));
   if (f->d_packed16) SF_HIP(sf_launch_pack(src, f->d_s16a, f->d_s16b, f->d_packed16, (long)f->L.n_packed16, st));
   if (f->d_packed16B) SF_HIP(sf_launch_pack_bf16_split(src, f->d_s16B, f->d_packed16B, (long)f->L.n_packed16B, st));
@@ -301,6 +347,11 @@ int sf_flow_log_prob(sf_flow* f, const float* theta, const float* x, int64_t B, 
     int rc = sf_nsf1_log_prob(f->nsf1, f->d_flat, theta, x, (long)B, out, (hipStream_t)stream, err);
     return rc ? fail(rc, err) : SF_OK;
   }
+  if (f->nsfar) {
+    std::string err;
+    int rc = sf_nsfar_log_prob(f->nsfar, theta, x, (long)B, out, (hipStream_t)stream, err);
+    return rc ? fail(rc, err) : SF_OK;
+  }
   SF_HIP(sf_launch_logprob(f->dev(), theta, x, (long)B, out, (hipStream_t)stream));
   return SF_OK;
 }
@@ -316,6 +367,11 @@ int sf_flow_inverse_from_noise(sf_flow* f, const float* z, const float* x, int64
     int rc = sf_nsf1_inverse(f->nsf1, f->d_flat, z, x, (long)B, theta, logdet, (hipStream_t)stream, err);
     return rc ? fail(rc, err) : SF_OK;
   }
+  if (f->nsfar) {
+    std::string err;
+    int rc = sf_nsfar_inverse(f->nsfar, z, x, (long)B, theta, logdet, (hipStream_t)stream, err);
+    return rc ? fail(rc, err) : SF_OK;
+  }
   SfSampleArgsHost a;
   a.x = x; a.z_in = z; a.n_items = (long)B; a.out = theta; a.logdet_out = logdet;
   SF_HIP(sf_launch_inverse(f->dev(), a, (hipStream_t)stream));
@@ -328,7 +384,7 @@ int sf_flow_inverse_from_noise_sampler(sf_flow* f, const float* z, const float* 
   if (B == 0) return SF_OK;
   if (!z || !x || !theta) return fail(SF_ERR_INVALID, "null argument");
   if (!f->params_set) return fail(SF_ERR_STATE, "sf_flow_set_params has not been called");
-  if (f->nsf1) {  // one fp32 path
+  if (f->nsf1 || f->nsfar) {  // one fp32 path
     int rc = sf_flow_inverse_from_noise(f, z, x, B, theta, nullptr, stream);
     return rc ? rc : 1;
   }
@@ -359,6 +415,7 @@ int sf_set_sampler_fp32(int on) {
 int sf_flow_train_path(const sf_flow* f, int64_t B, int want_dctx) {
   if (!f) return fail(SF_ERR_INVALID, "null handle");
   if (f->nsf1) return 4;   // MLP engine + scalar spline chain (sf_nsf1.hip)
+  if (f->nsfar) return 5;  // thread-per-sample masked hyper-network (sf_nsfar.hip)
   if (B > 0 && sf_trainc_eligible(f->L, want_dctx != 0)) return sf_trainc_groups((long)B);
   if (B > 0 && sf_nsfc_eligible(f->L, want_dctx != 0)) return 3;
   return 0;
@@ -387,7 +444,7 @@ int sf_flow_prepare_context(sf_flow* f, const float* x, int64_t M, void* stream)
   if (!x) return fail(SF_ERR_INVALID, "null argument");
   if (M < 0) return fail(SF_ERR_INVALID, "M < 0");
   if (!f->params_set) return fail(SF_ERR_STATE, "sf_flow_set_params has not been called");
-  if (f->nsf1) return SF_OK;   // (its sampler evaluates the conditioner once per row anyway)
+  if (f->nsf1 || f->nsfar) return SF_OK;   // (no per-row table: nsf1 evaluates the conditioner once per row anyway, nsf_ar's depends on theta)
   SfDev m = f->dev();
   int R = 0, NV = 0;
   sf_ctab_shape(m, R, NV);
@@ -452,7 +509,7 @@ int sf_flow_sample_round(sf_flow* f, const float* x, int64_t S, const uint32_t* 
                          const float* lo, const float* hi, float* out, uint32_t* rejected,
                          uint32_t* n_rejected, int32_t* n_drawn, void* stream) {
   if (!f || !x || !out || !rejected || !n_rejected) return fail(SF_ERR_INVALID, "null argument");
-  if (f->nsf1) return fail(SF_ERR_INVALID, "sf_flow_sample_round is not offered for the one-parameter NSF: use sf_flow_sample / sf_flow_sample_slots");
+  if (f->nsf1 || f->nsfar) return fail(SF_ERR_INVALID, "sf_flow_sample_round is not offered for the one-parameter / autoregressive NSF: use sf_flow_sample / sf_flow_sample_slots");
   if (!f->params_set) return fail(SF_ERR_STATE, "sf_flow_set_params has not been called");
   if (S < 1 || S > 0x7fffffffll) return fail(SF_ERR_INVALID, "S must be in 1 .. 2^31-1");
   if ((lo == nullptr) != (hi == nullptr)) return fail(SF_ERR_INVALID, "lo and hi must be given together");
@@ -770,6 +827,15 @@ int sf_flow_sample(sf_flow* f, const float* x, int64_t M, int64_t S, const float
                             (unsigned long long)f->sample_row_offset * (unsigned long long)S, max_attempts, out, n_drawn, n_unfilled, st, err);
     return rc ? fail(rc, err) : SF_OK;
   }
+  if (f->nsfar) {
+    if (n_drawn) SF_HIP(sf_launch_fill_i32(n_drawn, (long)M, 0, st));
+    uint32_t k0, k1;
+    seed_keys(seed, 0u, k0, k1);
+    std::string err;
+    int rc = sf_nsfar_sample(f->nsfar, x, (long)M, (long)S, nullptr, (long)(M * S), lo, hi, k0, k1,
+                             (unsigned long long)f->sample_row_offset * (unsigned long long)S, max_attempts, out, n_drawn, nullptr, n_unfilled, st, err);
+    return rc ? fail(rc, err) : SF_OK;
+  }
   if (n_drawn) SF_HIP(sf_launch_fill_i32(n_drawn, (long)M, (int32_t)S, st));
   return sample_persistent(f, x, M, S, nullptr, M * S, lo, hi, seed, max_attempts, out, n_drawn, n_unfilled, st);
 }
@@ -791,6 +857,15 @@ int sf_flow_sample_slots(sf_flow* f, const float* x, int64_t M, int64_t S, const
     int rc = sf_nsf1_sample(f->nsf1, f->d_flat, x, (long)M, (long)S, slots, (long)n_slots, lo, hi, k0, k1,
                             (unsigned long long)f->sample_row_offset * (unsigned long long)S, max_attempts, out, nullptr, n_unfilled,
                             (hipStream_t)stream, err);
+    return rc ? fail(rc, err) : SF_OK;
+  }
+  if (f->nsfar) {
+    uint32_t k0, k1;
+    seed_keys(seed, 0u, k0, k1);
+    std::string err;
+    int rc = sf_nsfar_sample(f->nsfar, x, (long)M, (long)S, slots, (long)n_slots, lo, hi, k0, k1,
+                             (unsigned long long)f->sample_row_offset * (unsigned long long)S, max_attempts, out, nullptr, nullptr, n_unfilled,
+                             (hipStream_t)stream, err);
     return rc ? fail(rc, err) : SF_OK;
   }
   return sample_persistent(f, x, M, S, slots, n_slots, lo, hi, seed, max_attempts, out, nullptr, n_unfilled,
@@ -817,6 +892,14 @@ int sf_flow_acceptance(sf_flow* f, const float* x, int64_t M, int64_t n, const f
     std::string err;
     int rc = sf_nsf1_acceptance(f->nsf1, f->d_flat, x, (long)M, (long)n, lo, hi, k0, k1,
                                 (unsigned long long)f->sample_row_offset * (unsigned long long)n, count, st, err);
+    return rc ? fail(rc, err) : SF_OK;
+  }
+  if (f->nsfar) {
+    uint32_t k0, k1;
+    seed_keys(seed, 1u, k0, k1);
+    std::string err;
+    int rc = sf_nsfar_sample(f->nsfar, x, (long)M, (long)n, nullptr, (long)(M * n), lo, hi, k0, k1,
+                             (unsigned long long)f->sample_row_offset * (unsigned long long)n, 1, nullptr, nullptr, count, nullptr, st, err);
     return rc ? fail(rc, err) : SF_OK;
   }
   SfSampleArgsHost a;
@@ -895,7 +978,7 @@ int sf_flow_train_epoch(sf_flow* f, float* flat, const float* theta, const float
   static int use_graph = -1;
   if (use_graph < 0) { const char* e = std::getenv("SF_TRAIN_GRAPH"); use_graph = e ? std::atoi(e) : 0; }
   int64_t b0 = 0;
-  if (use_graph && n_batches >= 4 && !f->nsf1 && !f->profiling) {
+  if (use_graph && n_batches >= 4 && !f->nsf1 && !f->nsfar && !f->profiling) {
     int rc = plain_step(0);
     if (rc) return rc;
     b0 = 1;

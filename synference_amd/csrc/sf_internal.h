@@ -129,6 +129,7 @@ void sf_set_error(const std::string& msg);  // thread-local message behind sf_la
 struct SfNsf1;
 struct sf_flow {
   SfLayout L;
+  struct SfNsfAr* nsfar = nullptr;   // != null: the autoregressive NSF (sf_nsfar.hip); L carries the shape and n_params only
   SfNsf1* nsf1 = nullptr;       // != null: the one-parameter NSF (sf_nsf1.hip); L then only carries the shape and n_params
   bool dev_ready = false;
   bool params_set = false;

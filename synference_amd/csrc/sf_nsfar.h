@@ -1,0 +1,46 @@
+// sf_nsfar.h -- the autoregressive NSF of the `backend="lampe"` route (sf_nsfar.hip): state and entry points used by sf_api.hip /
+// sf_train.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/synference_hip.h"
+
+struct SfNsfAr {
+  int D = 0, C = 0, H = 0, Hp = 0, T = 0, K = 0, NP = 0;
+  float bound = 5.f, cw = 0.f, cd = 0.f, logdet0 = 0.f;
+  float th_scale[16], th_shift[16];
+  std::vector<float> h_xmean, h_xstd;
+  // hidden rows sorted by type; perm[p] = logical unit of physical row p (-1: padding), ptype[p] its type, tend[r] = rows of type <= r
+  std::vector<int32_t> perm, ptype, tend, ord, dimof, src;
+  int64_t n_params = 0;
+  long P_t = 0, t_stride = 0;
+  int l_W0 = 0, l_b0 = 0, l_W1 = 0, l_b1 = 0, l_W2 = 0, l_b2 = 0;                             // logical offsets in a transform
+  int o_L0t = 0, o_b0 = 0, o_L1t = 0, o_L1m = 0, o_b1 = 0, o_L2t = 0, o_b2 = 0, o_L0m = 0;   // image offsets in a transform
+  bool dev_ready = false;
+  float* d_img = nullptr;
+  int32_t *d_src = nullptr, *d_none = nullptr, *d_perm = nullptr, *d_ptype = nullptr, *d_tend = nullptr, *d_ord = nullptr, *d_dimof = nullptr;
+  float *d_xmean = nullptr, *d_xstd = nullptr;
+  float* d_ustash = nullptr;
+  size_t ustash_cap = 0;
+  int32_t* d_gal = nullptr;              // [2][M]: attempts / accepted draws per row (progress rule of the uncapped sampler)
+  size_t gal_cap = 0;
+  unsigned long long* d_ctr = nullptr;   // [0] work cursor of the sampler, [1] slots written off
+};
+
+int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err);
+void sf_nsfar_destroy(SfNsfAr* n);
+size_t sf_nsfar_lds_bytes(const SfNsfAr& n, int hidden_buffers);
+// re-tiles the logical vector into the masked images (every entry point below reads the images of the LAST pack)
+int sf_nsfar_pack(SfNsfAr* n, const float* flat, hipStream_t st, std::string& err);
+int sf_nsfar_log_prob(SfNsfAr* n, const float* theta, const float* x, long B, float* out, hipStream_t st, std::string& err);
+int sf_nsfar_inverse(SfNsfAr* n, const float* z, const float* x, long B, float* theta, float* logdet, hipStream_t st, std::string& err);
+// count != null: acceptance counting (one attempt per item, item i belongs to row i / S); else the rejection sampler
+int sf_nsfar_sample(SfNsfAr* n, const float* x, long M, long S, const uint32_t* slots, long n_slots, const float* lo, const float* hi,
+                    uint32_t k0, uint32_t k1, unsigned long long slot_offset, int max_attempts, float* out, int32_t* n_drawn,
+                    int32_t* count, int64_t* n_unfilled, hipStream_t st, std::string& err);
+int sf_nsfar_loss_grad(SfNsfAr* n, const float* flat, const float* theta, const float* x, const long long* idx, long B, float grad_scale,
+                       const float* weights, float* loss, double* loss_sum, float* grad, hipStream_t st, std::string& err);

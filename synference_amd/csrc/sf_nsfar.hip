@@ -1,0 +1,654 @@
+// sf_nsfar.hip -- the autoregressive NSF of the reference's second backend (`backend="lampe"`: ili.utils.load_nde_lampe ->
+// zuko.flows.NSF; ref: src/synference/sbi_runner.py:5123-5125, examples/sbi/scripts/basic_model.py:31-41).
+//
+// [UPSTREAM, restated from the published zuko sources -- oracle/flows.py "nsf_ar" is the CPU twin, parity unpinned]
+//   T MaskedAutoregressiveTransforms with alternating orderings; the hyper-network of a transform is a MaskedMLP
+//   [theta ; context] -> H -> H -> D (3K - 1) (ReLU) whose masks make the spline parameters of a dimension depend on the
+//   dimensions ordered before it and on the context; the univariate map is zuko's MonotonicRQSTransform (sf_spline_flat.h, ZSpl).
+//
+// Built for correctness and a sane speed, not for the roofline (it is the secondary backend): one THREAD per sample, the
+// activations of a wave's 64 samples in LDS (lane-strided rows), the weights re-tiled once per parameter update into images whose
+// rows are read with wave-uniform 32-byte loads -- eight outputs share every activation read (8 FMAs per ds_read + one
+// scalar-cache load).  Hidden units are stored SORTED BY TYPE (zuko: unit h has type h mod D and sees the inputs ordered
+// before its type), every type padded to a multiple of eight rows, so that
+//   * the masked layers are block lower-triangular: an output of type r reads the first tend[r] rows only;
+//   * the SAMPLING direction costs one hyper-network evaluation per transform, not D: the units of type r become final as
+//     soon as the dimensions ordered before r are inverted, so the sweep r = 0 .. D-1 computes the hidden units of type r,
+//     the head of the dimension with order r, inverts that dimension, and goes on (zuko sweeps the whole network D times);
+//   * rejected draws are retried by compaction: a wave keeps taking (slot, attempt) items -- its own rejects first -- until
+//     the catalogue's slot list is exhausted.
+// Training: forward, then per transform (top down) the hyper-network is recomputed from the stashed inputs and
+// back-propagated by hand; weight gradients are wave reductions + one f32 atomic per (weight, wave).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "sf_device.h"
+#include "sf_internal.h"
+#include "sf_nsfar.h"
+#include "sf_rng.h"
+#include "sf_spline_flat.h"
+
+namespace {
+
+constexpr int ARK = 8, ARQ = 24;   // bins capacity / parameter slots per dimension (K <= 8: 3K - 1 <= 23)
+using ZS = ZSpl<ARK, ARQ>;
+
+struct ArArgs {
+  const float* img;       // packed images, all transforms
+  const int32_t* perm;    // [Hp] physical hidden row -> logical unit (-1: padding)
+  const int32_t* ptype;   // [Hp] type of a physical row (padding rows: the type of their block)
+  const int32_t* tend;    // [D]  rows of type <= r
+  const int32_t* ord;     // [T][D] order value of dimension d
+  const int32_t* dimof;   // [T][D] dimension with order value r
+  const float* xmean;     // [C]
+  const float* xstd;      // [C]
+  int D, C, H, Hp, T, K, NP;
+  long t_stride;          // floats per transform in img
+  int o_L0t, o_b0, o_L1t, o_L1m, o_b1, o_L2t, o_b2, o_L0m;
+  long P_t;               // logical parameters per transform
+  int l_W0, l_b0, l_W1, l_b1, l_W2, l_b2;
+  float B, cw, cd, logdet0;
+  float th_scale[16], th_shift[16];
+};
+
+__device__ __forceinline__ float ar_reduce64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// eight consecutive floats at a wave-uniform address
+struct F8 { float v[8]; };
+__device__ __forceinline__ F8 ar_ld8(const float* __restrict__ p) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  F8 r;
+  r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+  return r;
+}
+
+// rows [p0, p0 + 8) of a dense layer: out = relu(b + sum_{k < kend} Wt[k][p] * in[k]); in / out: lane-strided LDS rows
+__device__ __forceinline__ void ar_layer8(const float* __restrict__ wt, int ldo, const float* __restrict__ bias, int p0, int kend,
+                                          const float* in, float* out, int lane) {
+  F8 acc = ar_ld8(bias + p0);
+  for (int k = 0; k < kend; ++k) {
+    const float a = in[k * 64 + lane];
+    const F8 w = ar_ld8(wt + (size_t)k * ldo + p0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc.v[j] += w.v[j] * a;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) out[(p0 + j) * 64 + lane] = fmaxf(acc.v[j], 0.f);
+}
+// the 24 parameter slots of dimension d from the last hidden layer (rows < kend)
+__device__ __forceinline__ void ar_head(const ArArgs& a, const float* __restrict__ tp, int d, int kend, const float* h2, int lane,
+                                        float (&q)[ARQ]) {
+  const int ldo = a.D * ARQ;
+#pragma unroll
+  for (int jb = 0; jb < 3; ++jb) {
+    F8 acc = ar_ld8(tp + a.o_b2 + d * ARQ + jb * 8);
+    for (int k = 0; k < kend; ++k) {
+      const float v = h2[k * 64 + lane];
+      const F8 w = ar_ld8(tp + a.o_L2t + (size_t)k * ldo + d * ARQ + jb * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc.v[j] += w.v[j] * v;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[jb * 8 + j] = acc.v[j];
+  }
+}
+// image slot (zuko order [K widths | K heights | K - 1 derivatives] -> slots [0, 8) | [8, 16) | [16, 23)) is fixed by the packer
+
+// both hidden layers of transform t from the inputs in E0 ([D + C] rows: u, context)
+__device__ __forceinline__ void ar_hidden(const ArArgs& a, const float* __restrict__ tp, const float* E0, float* H1, float* H2, int lane) {
+  for (int p0 = 0; p0 < a.Hp; p0 += 8) ar_layer8(tp + a.o_L0t, a.Hp, tp + a.o_b0, p0, a.D + a.C, E0, H1, lane);
+  for (int p0 = 0; p0 < a.Hp; p0 += 8) ar_layer8(tp + a.o_L1t, a.Hp, tp + a.o_b1, p0, a.tend[a.ptype[p0 + 7]], H1, H2, lane);
+}
+
+__device__ __forceinline__ void ar_load_inputs(const ArArgs& a, const float* __restrict__ theta, const float* __restrict__ x, long row,
+                                               float* E0, int lane) {
+  for (int d = 0; d < a.D; ++d) E0[d * 64 + lane] = theta[row * a.D + d] * a.th_scale[d] + a.th_shift[d];
+  for (int c = 0; c < a.C; ++c) E0[(a.D + c) * 64 + lane] = (x[row * a.C + c] - a.xmean[c]) / a.xstd[c];
+}
+
+__global__ __launch_bounds__(64) void k_ar_logprob(ArArgs a, const float* __restrict__ theta, const float* __restrict__ x, long B,
+                                                    float* __restrict__ out) {
+  extern __shared__ float lds[];
+  float* E0 = lds;
+  float* H1 = E0 + (a.D + a.C) * 64;
+  float* H2 = H1 + a.Hp * 64;
+  const int lane = threadIdx.x;
+  const long b = (long)blockIdx.x * 64 + lane;
+  const long row = b < B ? b : B - 1;
+  ar_load_inputs(a, theta, x, row, E0, lane);
+  const ZSplC sc = {a.K, a.B, a.cw, a.cd};
+  float ld = a.logdet0;
+  for (int t = 0; t < a.T; ++t) {
+    const float* tp = a.img + (size_t)t * a.t_stride;
+    ar_hidden(a, tp, E0, H1, H2, lane);
+    for (int d = 0; d < a.D; ++d) {
+      float q[ARQ];
+      ar_head(a, tp, d, a.tend[a.ord[t * a.D + d]], H2, lane, q);
+      float v, lad;
+      ZS::fwd(sc, q, E0[d * 64 + lane], v, lad);
+      E0[d * 64 + lane] = v;   // (every parameter of this transform has been taken from the inputs already)
+      ld += lad;
+    }
+  }
+  float ss = 0.f;
+  for (int d = 0; d < a.D; ++d) ss += E0[d * 64 + lane] * E0[d * 64 + lane];
+  if (b < B) out[b] = -0.5f * ss - 0.5f * (float)a.D * 1.8378770664093453f + ld;
+}
+
+// the inverse of transform t in ONE sweep over the order values: V = the transform's outputs, E0[0 .. D) receives its inputs
+__device__ __forceinline__ float ar_inverse_transform(const ArArgs& a, const ZSplC& sc, int t, float* E0, const float* V, float* H1,
+                                                      float* H2, int lane) {
+  const float* tp = a.img + (size_t)t * a.t_stride;
+  float ld = 0.f;
+  for (int d = 0; d < a.D; ++d) E0[d * 64 + lane] = 0.f;   // (not yet known: masked weights are zeros, the values must be finite)
+  for (int r = 0; r < a.D; ++r) {
+    const int p_lo = r ? a.tend[r - 1] : 0, p_hi = a.tend[r];
+    for (int p0 = p_lo; p0 < p_hi; p0 += 8) ar_layer8(tp + a.o_L0t, a.Hp, tp + a.o_b0, p0, a.D + a.C, E0, H1, lane);
+    for (int p0 = p_lo; p0 < p_hi; p0 += 8) ar_layer8(tp + a.o_L1t, a.Hp, tp + a.o_b1, p0, p_hi, H1, H2, lane);
+    const int d = a.dimof[t * a.D + r];
+    float q[ARQ];
+    ar_head(a, tp, d, p_hi, H2, lane, q);
+    float w, lad;
+    ZS::inv(sc, q, V[d * 64 + lane], w, lad);
+    E0[d * 64 + lane] = w;
+    ld += lad;
+  }
+  return ld;
+}
+
+__global__ __launch_bounds__(64) void k_ar_inverse(ArArgs a, const float* __restrict__ z, const float* __restrict__ x, long B,
+                                                    float* __restrict__ theta, float* __restrict__ logdet) {
+  extern __shared__ float lds[];
+  float* E0 = lds;
+  float* H1 = E0 + (a.D + a.C) * 64;
+  float* H2 = H1 + a.Hp * 64;
+  float* V = H2 + a.Hp * 64;
+  const int lane = threadIdx.x;
+  const long b = (long)blockIdx.x * 64 + lane;
+  const long row = b < B ? b : B - 1;
+  for (int c = 0; c < a.C; ++c) E0[(a.D + c) * 64 + lane] = (x[row * a.C + c] - a.xmean[c]) / a.xstd[c];
+  for (int d = 0; d < a.D; ++d) V[d * 64 + lane] = z[row * a.D + d];
+  const ZSplC sc = {a.K, a.B, a.cw, a.cd};
+  float ld = -a.logdet0;
+  for (int t = a.T - 1; t >= 0; --t) {
+    ld += ar_inverse_transform(a, sc, t, E0, V, H1, H2, lane);
+    for (int d = 0; d < a.D; ++d) V[d * 64 + lane] = E0[d * 64 + lane];
+  }
+  if (b < B) {
+    for (int d = 0; d < a.D; ++d) theta[b * a.D + d] = (V[d * 64 + lane] - a.th_shift[d]) / a.th_scale[d];
+    if (logdet) logdet[b] = ld;
+  }
+}
+
+// rejection sampler: a wave works (slot, attempt) items until the slot list is exhausted; rejected items come back first
+__global__ __launch_bounds__(64) void k_ar_sample(ArArgs a, const float* __restrict__ x, long S, const uint32_t* __restrict__ slots,
+                                                   long n_slots, const float* __restrict__ lo, const float* __restrict__ hi, uint32_t k0,
+                                                   uint32_t k1, unsigned long long slot_offset, uint32_t max_attempts,
+                                                   float* __restrict__ out, int32_t* __restrict__ n_drawn, int32_t* __restrict__ count,
+                                                   unsigned long long* __restrict__ cursor, unsigned int* __restrict__ n_unfilled,
+                                                   int32_t* __restrict__ g_try, int32_t* __restrict__ g_acc) {
+  extern __shared__ float lds[];
+  float* E0 = lds;
+  float* H1 = E0 + (a.D + a.C) * 64;
+  float* H2 = H1 + a.Hp * 64;
+  float* V = H2 + a.Hp * 64;
+  __shared__ unsigned long long r_slot[64];
+  __shared__ uint32_t r_att[64];
+  const int lane = threadIdx.x;
+  const ZSplC sc = {a.K, a.B, a.cw, a.cd};
+  int n_retry = 0;
+  for (;;) {
+    const int take = 64 - n_retry;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(cursor, (unsigned long long)take);
+    base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    unsigned long long slot = 0;
+    uint32_t att = 0;
+    bool active;
+    if (lane < n_retry) {
+      slot = r_slot[lane]; att = r_att[lane]; active = true;
+    } else {
+      const unsigned long long idx = base + (unsigned)(lane - n_retry);
+      active = idx < (unsigned long long)n_slots;
+      if (active) slot = slots ? (unsigned long long)slots[idx] : idx;
+    }
+    __syncthreads();   // (the retry list has been read)
+    if (__ballot(active) == 0ull) break;
+    const long g = active ? (long)(slot / (unsigned long long)S) : 0;
+    for (int c = 0; c < a.C; ++c) E0[(a.D + c) * 64 + lane] = (x[g * a.C + c] - a.xmean[c]) / a.xstd[c];
+    for (int d0 = 0; d0 < a.D; d0 += 4) {
+      float z4[4];
+      sf_normal4(k0, k1, slot + slot_offset, att, (uint32_t)(d0 >> 2), z4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (d0 + j < a.D) V[(d0 + j) * 64 + lane] = z4[j];
+    }
+    for (int t = a.T - 1; t >= 0; --t) {
+      (void)ar_inverse_transform(a, sc, t, E0, V, H1, H2, lane);
+      for (int d = 0; d < a.D; ++d) V[d * 64 + lane] = E0[d * 64 + lane];
+    }
+    bool ok = active;
+    for (int d = 0; d < a.D; ++d) {
+      const float th = (V[d * 64 + lane] - a.th_shift[d]) / a.th_scale[d];
+      V[d * 64 + lane] = th;
+      ok = ok && (th == th) && fabsf(th) < 3.0e38f && (!lo || (th >= lo[d] && th <= hi[d]));
+    }
+    if (count) {   // acceptance counting (leakage correction): one attempt per item, nothing written
+      if (ok) atomicAdd(count + g, 1);
+      n_retry = 0;
+      continue;
+    }
+    bool give_up = active && !ok && att + 1u >= max_attempts;
+    if (g_try && active) {   // no ceiling asked for: a row whose open slots spent 1e5 attempts without ONE accepted draw is written off
+      const int tried = atomicAdd(g_try + g, 1) + 1;
+      if (ok) atomicAdd(g_acc + g, 1);
+      else if (tried >= 100000 && __hip_atomic_load(g_acc + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) give_up = true;
+    }
+    if (active && (ok || give_up)) {
+      for (int d = 0; d < a.D; ++d) out[slot * a.D + d] = ok ? V[d * 64 + lane] : __builtin_nanf("");
+      if (n_drawn) sf_sat_add(n_drawn + g, (int32_t)(att + 1u));
+      if (give_up) atomicAdd(n_unfilled, 1u);
+    }
+    const bool again = active && !ok && !give_up;
+    const unsigned long long m = __ballot(again);
+    if (again) {
+      const int pos = __popcll(m & ((1ull << lane) - 1ull));
+      r_slot[pos] = slot;
+      r_att[pos] = att + 1u;
+    }
+    n_retry = __popcll(m);
+    __syncthreads();
+  }
+}
+
+// forward (with the inputs of every transform stashed) + loss, then the backward sweep
+__global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restrict__ theta, const float* __restrict__ x,
+                                                  const long long* __restrict__ idx, long B, float w, const float* __restrict__ wts,
+                                                  float* __restrict__ loss, double* __restrict__ loss_sum, float* __restrict__ grad,
+                                                  float* __restrict__ ustash) {
+  extern __shared__ float lds[];
+  float* E0 = lds;                       // [D + C]: u, context
+  float* H1 = E0 + (a.D + a.C) * 64;     // [Hp]
+  float* H2 = H1 + a.Hp * 64;            // [Hp]
+  float* DH = H2 + a.Hp * 64;            // [Hp] deltas
+  float* GG = DH + a.Hp * 64;            // [D] dL/du at the transform's output
+  float* DV = GG + a.D * 64;             // [D] what reaches the transform's input through the splines
+  const int lane = threadIdx.x;
+  const long b = (long)blockIdx.x * 64 + lane;
+  const bool valid = b < B;
+  const long bb = valid ? b : B - 1;
+  const long row = idx ? (long)idx[bb] : bb;
+  ar_load_inputs(a, theta, x, row, E0, lane);
+  const ZSplC sc = {a.K, a.B, a.cw, a.cd};
+  float* ust = ustash + (size_t)bb * a.T * a.D;   // (an invalid lane shares the last row's stash: same values)
+  float ld = a.logdet0;
+  for (int t = 0; t < a.T; ++t) {
+    const float* tp = a.img + (size_t)t * a.t_stride;
+    for (int d = 0; d < a.D; ++d) ust[t * a.D + d] = E0[d * 64 + lane];
+    ar_hidden(a, tp, E0, H1, H2, lane);
+    for (int d = 0; d < a.D; ++d) {
+      float q[ARQ];
+      ar_head(a, tp, d, a.tend[a.ord[t * a.D + d]], H2, lane, q);
+      float v, lad;
+      ZS::fwd(sc, q, E0[d * 64 + lane], v, lad);
+      E0[d * 64 + lane] = v;
+      ld += lad;
+    }
+  }
+  float ss = 0.f;
+  for (int d = 0; d < a.D; ++d) ss += E0[d * 64 + lane] * E0[d * 64 + lane];
+  const float nll = 0.5f * ss + 0.5f * (float)a.D * 1.8378770664093453f - ld;
+  if (loss && valid) loss[b] = nll;
+  if (loss_sum) {
+    const float tsum = ar_reduce64(valid ? nll : 0.f);
+    // values on a 2^-20 grid add exactly in double: the sum does not depend on the order of the atomics
+    if (lane == 0) atomicAdd(loss_sum, (double)rintf(tsum * 1048576.0f) * (1.0 / 1048576.0));
+  }
+  const float wb = valid ? (wts ? w * wts[b] : w) : 0.f;
+  for (int d = 0; d < a.D; ++d) GG[d * 64 + lane] = wb * E0[d * 64 + lane];
+  const int nin = a.D + a.C;
+  for (int t = a.T - 1; t >= 0; --t) {
+    const float* tp = a.img + (size_t)t * a.t_stride;
+    float* gt = grad + (size_t)t * a.P_t;
+    for (int d = 0; d < a.D; ++d) E0[d * 64 + lane] = ust[t * a.D + d];
+    ar_hidden(a, tp, E0, H1, H2, lane);
+    for (int p = 0; p < a.Hp; ++p) DH[p * 64 + lane] = 0.f;
+    // ---- head + splines
+    for (int d = 0; d < a.D; ++d) {
+      const int kend = a.tend[a.ord[t * a.D + d]];
+      float q[ARQ], dq[ARQ];
+      ar_head(a, tp, d, kend, H2, lane, q);
+      float dv;
+      ZS::bwd(sc, q, E0[d * 64 + lane], GG[d * 64 + lane], -wb, dv, dq);
+      DV[d * 64 + lane] = dv;
+      const int ldo = a.D * ARQ;
+      for (int k = 0; k < kend; ++k) {   // delta of the last hidden layer; weight gradients of this dimension's head rows
+        float acc = 0.f;
+#pragma unroll
+        for (int jb = 0; jb < 3; ++jb) {
+          const F8 wv = ar_ld8(tp + a.o_L2t + (size_t)k * ldo + d * ARQ + jb * 8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc += wv.v[j] * dq[jb * 8 + j];
+        }
+        DH[k * 64 + lane] += acc;
+        const int kl = a.perm[k];
+        if (kl >= 0) {
+          const float hv = H2[k * 64 + lane];
+#pragma unroll
+          for (int s = 0; s < ARQ - 1; ++s) {
+            // slot s -> row of the logical head: family s / 8 (widths, heights, derivatives), index s % 8
+            const int fam = s >> 3, kk = s & 7;
+            if (kk < (fam < 2 ? a.K : a.K - 1)) {
+              const float gsum = ar_reduce64(dq[s] * hv);
+              if (lane == 0) unsafeAtomicAdd(gt + a.l_W2 + (size_t)(d * a.NP + fam * a.K + kk) * a.H + kl, gsum);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < ARQ - 1; ++s) {
+        const int fam = s >> 3, kk = s & 7;
+        if (kk < (fam < 2 ? a.K : a.K - 1)) {
+          const float gsum = ar_reduce64(dq[s]);
+          if (lane == 0) unsafeAtomicAdd(gt + a.l_b2 + d * a.NP + fam * a.K + kk, gsum);
+        }
+      }
+    }
+    // ---- second hidden layer: delta through the ReLU, weight gradients, delta of the first hidden layer (into H2's rows)
+    for (int o = 0; o < a.Hp; ++o) DH[o * 64 + lane] = H2[o * 64 + lane] > 0.f ? DH[o * 64 + lane] : 0.f;
+    for (int o = 0; o < a.Hp; ++o) {
+      const int ol = a.perm[o];
+      if (ol < 0) continue;
+      const float dv = DH[o * 64 + lane];
+      const int kend = a.tend[a.ptype[o]];
+      for (int k = 0; k < kend; ++k) {
+        const int kl = a.perm[k];
+        if (kl < 0) continue;
+        const float gsum = ar_reduce64(dv * H1[k * 64 + lane]);
+        if (lane == 0) unsafeAtomicAdd(gt + a.l_W1 + (size_t)ol * a.H + kl, gsum);
+      }
+      const float bsum = ar_reduce64(dv);
+      if (lane == 0) unsafeAtomicAdd(gt + a.l_b1 + ol, bsum);
+    }
+    for (int k0b = 0; k0b < a.Hp; k0b += 8) {   // delta_h1[k] = sum_o W1[o][k] delta_h2[o]  (row-major masked image)
+      F8 acc;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc.v[j] = 0.f;
+      for (int o = 0; o < a.Hp; ++o) {
+        const float dv = DH[o * 64 + lane];
+        const F8 wv = ar_ld8(tp + a.o_L1m + (size_t)o * a.Hp + k0b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc.v[j] += wv.v[j] * dv;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) H2[(k0b + j) * 64 + lane] = H1[(k0b + j) * 64 + lane] > 0.f ? acc.v[j] : 0.f;
+    }
+    // ---- first hidden layer: weight gradients, and what reaches the inputs
+    float din[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) din[d] = 0.f;
+    for (int o = 0; o < a.Hp; ++o) {
+      const int ol = a.perm[o];
+      if (ol < 0) continue;
+      const float dv = H2[o * 64 + lane];
+      const int ty = a.ptype[o];
+      for (int i = 0; i < nin; ++i) {
+        if (i < a.D && a.ord[t * a.D + i] >= ty) continue;   // masked: the unit does not see this dimension
+        const float gsum = ar_reduce64(dv * E0[i * 64 + lane]);
+        if (lane == 0) unsafeAtomicAdd(gt + a.l_W0 + (size_t)ol * nin + i, gsum);
+      }
+      const float bsum = ar_reduce64(dv);
+      if (lane == 0) unsafeAtomicAdd(gt + a.l_b0 + ol, bsum);
+      const F8 w0 = ar_ld8(tp + a.o_L0m + (size_t)o * 16), w1 = ar_ld8(tp + a.o_L0m + (size_t)o * 16 + 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { din[j] += w0.v[j] * dv; din[8 + j] += w1.v[j] * dv; }
+    }
+#pragma unroll
+    for (int d = 0; d < 16; ++d)
+      if (d < a.D) GG[d * 64 + lane] = DV[d * 64 + lane] + din[d];
+  }
+}
+
+#define AR_HIP(call)                                                        \
+  do {                                                                      \
+    hipError_t e_ = (call);                                                 \
+    if (e_ != hipSuccess) {                                                 \
+      err = std::string(#call) + ": " + hipGetErrorString(e_);              \
+      return SF_ERR_HIP;                                                    \
+    }                                                                       \
+  } while (0)
+
+ArArgs args_of(const SfNsfAr& n) {
+  ArArgs a;
+  a.img = n.d_img; a.perm = n.d_perm; a.ptype = n.d_ptype; a.tend = n.d_tend; a.ord = n.d_ord; a.dimof = n.d_dimof;
+  a.xmean = n.d_xmean; a.xstd = n.d_xstd;
+  a.D = n.D; a.C = n.C; a.H = n.H; a.Hp = n.Hp; a.T = n.T; a.K = n.K; a.NP = n.NP;
+  a.t_stride = n.t_stride;
+  a.o_L0t = n.o_L0t; a.o_b0 = n.o_b0; a.o_L1t = n.o_L1t; a.o_L1m = n.o_L1m; a.o_b1 = n.o_b1; a.o_L2t = n.o_L2t; a.o_b2 = n.o_b2; a.o_L0m = n.o_L0m;
+  a.P_t = n.P_t; a.l_W0 = n.l_W0; a.l_b0 = n.l_b0; a.l_W1 = n.l_W1; a.l_b1 = n.l_b1; a.l_W2 = n.l_W2; a.l_b2 = n.l_b2;
+  a.B = n.bound; a.cw = n.cw; a.cd = n.cd; a.logdet0 = n.logdet0;
+  for (int d = 0; d < 16; ++d) { a.th_scale[d] = n.th_scale[d]; a.th_shift[d] = n.th_shift[d]; }
+  return a;
+}
+
+template <typename Kern>
+hipError_t set_lds(Kern k, size_t bytes) {
+  return hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace
+
+int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err) {
+  if (d.D < 1 || d.D > 16) { err = "autoregressive NSF: D must be in 1..16"; return SF_ERR_INVALID; }
+  if (d.K < 2 || d.K > ARK) { err = "autoregressive NSF: K (bins) must be in 2..8"; return SF_ERR_INVALID; }
+  if (d.NB != 2) { err = "autoregressive NSF: two hidden layers (NB = 2: lampe / ltu-ili's hyper-network) are built"; return SF_ERR_INVALID; }
+  if (d.H < d.D || d.H > 192) { err = "autoregressive NSF: H must be in D..192"; return SF_ERR_INVALID; }
+  if (d.C < 1 || d.C > 256 || d.T < 1 || d.T > 64) { err = "autoregressive NSF: C in 1..256, T in 1..64"; return SF_ERR_INVALID; }
+  if (!d.theta_mean || !d.theta_std || !d.x_mean || !d.x_std) { err = "z-score buffers must be given"; return SF_ERR_INVALID; }
+  if (!(d.ar_slope > 0.f && d.ar_slope < 1.f)) { err = "ar_slope must be in (0, 1)"; return SF_ERR_INVALID; }
+  SfNsfAr* n = new SfNsfAr();
+  const int D = d.D, C = d.C, H = d.H, T = d.T, K = d.K, NP = 3 * K - 1;
+  n->D = D; n->C = C; n->H = H; n->T = T; n->K = K; n->NP = NP;
+  n->bound = d.tail_bound;
+  const double ls = std::fabs(std::log((double)d.ar_slope));
+  n->cw = (float)(2.0 / ls); n->cd = (float)(1.0 / ls);
+  double ld0 = 0;
+  for (int i = 0; i < 16; ++i) { n->th_scale[i] = 1.f; n->th_shift[i] = 0.f; }
+  for (int i = 0; i < D; ++i) {
+    n->th_scale[i] = 1.0f / d.theta_std[i];
+    n->th_shift[i] = -d.theta_mean[i] / d.theta_std[i];
+    ld0 += std::log(std::fabs(1.0 / (double)d.theta_std[i]));
+  }
+  n->logdet0 = (float)ld0;
+  n->h_xmean.assign(d.x_mean, d.x_mean + C);
+  n->h_xstd.assign(d.x_std, d.x_std + C);
+  // hidden rows sorted by type (unit h: type h mod D), every type padded to a multiple of eight rows
+  n->perm.clear(); n->ptype.clear(); n->tend.assign(D, 0);
+  for (int r = 0; r < D; ++r) {
+    int cnt = 0;
+    for (int h = r; h < H; h += D) { n->perm.push_back(h); n->ptype.push_back(r); ++cnt; }
+    while (cnt % 8) { n->perm.push_back(-1); n->ptype.push_back(r); ++cnt; }
+    n->tend[r] = (int)n->perm.size();
+  }
+  const int Hp = (int)n->perm.size();
+  n->Hp = Hp;
+  // logical layout of a transform
+  const int nin = D + C;
+  n->l_W0 = 0; n->l_b0 = n->l_W0 + H * nin; n->l_W1 = n->l_b0 + H; n->l_b1 = n->l_W1 + H * H;
+  n->l_W2 = n->l_b1 + H; n->l_b2 = n->l_W2 + D * NP * H; n->P_t = n->l_b2 + D * NP;
+  n->n_params = (int64_t)T * n->P_t;
+  // images of a transform (offsets in floats, every block a multiple of 8)
+  long o = 0;
+  n->o_L0t = (int)o; o += (long)nin * Hp;
+  n->o_b0 = (int)o; o += Hp;
+  n->o_L1t = (int)o; o += (long)Hp * Hp;
+  n->o_L1m = (int)o; o += (long)Hp * Hp;
+  n->o_b1 = (int)o; o += Hp;
+  n->o_L2t = (int)o; o += (long)Hp * D * ARQ;
+  n->o_b2 = (int)o; o += (long)D * ARQ;
+  n->o_L0m = (int)o; o += (long)Hp * 16;
+  n->t_stride = (o + 63) / 64 * 64;
+  if (sf_nsfar_lds_bytes(*n, 3) > (size_t)160 * 1024 - 1024) {
+    err = "autoregressive NSF: (3 D + C + 3 Hp) x 256 bytes of LDS per wave exceed the 160 KB of a CU (Hp = H with every type padded to a multiple of 8)";
+    delete n;
+    return SF_ERR_INVALID;
+  }
+  n->src.assign((size_t)T * n->t_stride, -1);
+  n->ord.assign((size_t)T * D, 0); n->dimof.assign((size_t)T * D, 0);
+  for (int t = 0; t < T; ++t) {
+    int32_t* s = n->src.data() + (size_t)t * n->t_stride;
+    const long base = (long)t * n->P_t;
+    for (int dd = 0; dd < D; ++dd) {
+      const int r = (t % 2 == 0) ? dd : D - 1 - dd;
+      n->ord[(size_t)t * D + dd] = r;
+      n->dimof[(size_t)t * D + r] = dd;
+    }
+    const int32_t* ord = n->ord.data() + (size_t)t * D;
+    for (int p = 0; p < Hp; ++p) {
+      const int h = n->perm[p], ty = n->ptype[p];
+      if (h < 0) continue;
+      for (int i = 0; i < nin; ++i) {
+        const bool on = i >= D || ord[i] < ty;
+        if (!on) continue;
+        s[n->o_L0t + (long)i * Hp + p] = (int32_t)(base + n->l_W0 + (long)h * nin + i);
+        if (i < D) s[n->o_L0m + (long)p * 16 + i] = (int32_t)(base + n->l_W0 + (long)h * nin + i);
+      }
+      s[n->o_b0 + p] = (int32_t)(base + n->l_b0 + h);
+      s[n->o_b1 + p] = (int32_t)(base + n->l_b1 + h);
+      for (int k = 0; k < Hp; ++k) {
+        const int hk = n->perm[k];
+        if (hk < 0 || n->ptype[k] > ty) continue;
+        s[n->o_L1t + (long)k * Hp + p] = (int32_t)(base + n->l_W1 + (long)h * H + hk);
+        s[n->o_L1m + (long)p * Hp + k] = (int32_t)(base + n->l_W1 + (long)h * H + hk);
+      }
+    }
+    for (int dd = 0; dd < D; ++dd)
+      for (int fam = 0; fam < 3; ++fam)
+        for (int kk = 0; kk < (fam < 2 ? K : K - 1); ++kk) {
+          const int slot = dd * ARQ + fam * 8 + kk, lrow = dd * NP + fam * K + kk;
+          s[n->o_b2 + slot] = (int32_t)(base + n->l_b2 + lrow);
+          for (int k = 0; k < Hp; ++k) {
+            const int hk = n->perm[k];
+            if (hk < 0 || n->ptype[k] > ord[dd]) continue;
+            s[n->o_L2t + (long)k * D * ARQ + slot] = (int32_t)(base + n->l_W2 + (long)lrow * H + hk);
+          }
+        }
+  }
+  *out = n;
+  return SF_OK;
+}
+
+void sf_nsfar_destroy(SfNsfAr* n) {
+  if (!n) return;
+  (void)hipFree(n->d_img); (void)hipFree(n->d_src); (void)hipFree(n->d_none); (void)hipFree(n->d_perm); (void)hipFree(n->d_ptype); (void)hipFree(n->d_tend);
+  (void)hipFree(n->d_ord); (void)hipFree(n->d_dimof); (void)hipFree(n->d_xmean); (void)hipFree(n->d_xstd); (void)hipFree(n->d_ustash);
+  (void)hipFree(n->d_ctr); (void)hipFree(n->d_gal);
+  delete n;
+}
+
+static int ar_ensure(SfNsfAr* n, std::string& err) {
+  if (n->dev_ready) return SF_OK;
+  auto up = [&](auto*& dst, const auto& v) -> hipError_t {
+    using T = typename std::remove_reference<decltype(v[0])>::type;
+    hipError_t e = hipMalloc(&dst, v.size() * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipMemcpy(dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+  };
+  AR_HIP(hipMalloc(&n->d_img, n->src.size() * sizeof(float)));
+  AR_HIP(up(n->d_src, n->src)); AR_HIP(up(n->d_perm, n->perm)); AR_HIP(up(n->d_ptype, n->ptype)); AR_HIP(up(n->d_tend, n->tend));
+  AR_HIP(up(n->d_ord, n->ord)); AR_HIP(up(n->d_dimof, n->dimof)); AR_HIP(up(n->d_xmean, n->h_xmean)); AR_HIP(up(n->d_xstd, n->h_xstd));
+  AR_HIP(hipMalloc(&n->d_ctr, 2 * sizeof(unsigned long long)));
+  {
+    const std::vector<int32_t> none(n->src.size(), -1);
+    AR_HIP(up(n->d_none, none));
+  }
+  const size_t lds = sf_nsfar_lds_bytes(*n, 3);
+  AR_HIP(set_lds(k_ar_logprob, lds)); AR_HIP(set_lds(k_ar_inverse, lds)); AR_HIP(set_lds(k_ar_sample, lds)); AR_HIP(set_lds(k_ar_train, lds));
+  n->dev_ready = true;
+  return SF_OK;
+}
+
+size_t sf_nsfar_lds_bytes(const SfNsfAr& n, int hidden_buffers) {
+  return (size_t)(n.D + n.C + hidden_buffers * n.Hp + 2 * n.D) * 64 * sizeof(float);
+}
+
+int sf_nsfar_pack(SfNsfAr* n, const float* flat, hipStream_t st, std::string& err) {
+  int rc = ar_ensure(n, err);
+  if (rc) return rc;
+  // (k_pack sums two gather tables; the second is "none" everywhere)
+  AR_HIP(sf_launch_pack(flat, n->d_src, n->d_none, n->d_img, (long)n->src.size(), st));
+  return SF_OK;
+}
+
+int sf_nsfar_log_prob(SfNsfAr* n, const float* theta, const float* x, long B, float* out, hipStream_t st, std::string& err) {
+  hipLaunchKernelGGL(k_ar_logprob, dim3((unsigned)((B + 63) / 64)), dim3(64), sf_nsfar_lds_bytes(*n, 2), st, args_of(*n), theta, x, B, out);
+  AR_HIP(hipGetLastError());
+  return SF_OK;
+}
+
+int sf_nsfar_inverse(SfNsfAr* n, const float* z, const float* x, long B, float* theta, float* logdet, hipStream_t st, std::string& err) {
+  hipLaunchKernelGGL(k_ar_inverse, dim3((unsigned)((B + 63) / 64)), dim3(64), sf_nsfar_lds_bytes(*n, 2), st, args_of(*n), z, x, B, theta, logdet);
+  AR_HIP(hipGetLastError());
+  return SF_OK;
+}
+
+int sf_nsfar_sample(SfNsfAr* n, const float* x, long M, long S, const uint32_t* slots, long n_slots, const float* lo, const float* hi,
+                    uint32_t k0, uint32_t k1, unsigned long long slot_offset, int max_attempts, float* out, int32_t* n_drawn,
+                    int32_t* count, int64_t* n_unfilled, hipStream_t st, std::string& err) {
+  AR_HIP(hipMemsetAsync(n->d_ctr, 0, 2 * sizeof(unsigned long long), st));
+  int dev = 0, cus = 256;
+  hipDeviceProp_t pr;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+  const size_t lds = sf_nsfar_lds_bytes(*n, 2);
+  const long per_cu = (long)((size_t)160 * 1024 / (lds + 1024));
+  long grid = (long)cus * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
+  if (grid > (n_slots + 63) / 64) grid = (n_slots + 63) / 64;
+  // no ceiling asked for: the row-level progress rule of the kernel, and 2^20 attempts per slot at the very most
+  const uint32_t cap = count ? 1u : (max_attempts > 0 ? (uint32_t)max_attempts : (1u << 20));
+  int32_t* g_try = nullptr;
+  if (!count && max_attempts <= 0 && lo) {
+    if ((size_t)(2 * M) > n->gal_cap) {
+      if (n->d_gal) AR_HIP(hipFree(n->d_gal));
+      n->d_gal = nullptr; n->gal_cap = 0;
+      AR_HIP(hipMalloc(&n->d_gal, (size_t)(2 * M) * sizeof(int32_t)));
+      n->gal_cap = (size_t)(2 * M);
+    }
+    AR_HIP(hipMemsetAsync(n->d_gal, 0, (size_t)(2 * M) * sizeof(int32_t), st));
+    g_try = n->d_gal;
+  }
+  hipLaunchKernelGGL(k_ar_sample, dim3((unsigned)grid), dim3(64), lds, st, args_of(*n), x, S, slots, n_slots, lo, hi, k0, k1, slot_offset, cap, out,
+                     n_drawn, count, n->d_ctr, reinterpret_cast<unsigned int*>(n->d_ctr + 1), g_try, g_try ? g_try + M : nullptr);
+  AR_HIP(hipGetLastError());
+  if (n_unfilled) {
+    unsigned long long h[2] = {0, 0};
+    AR_HIP(hipMemcpyAsync(h, n->d_ctr, sizeof(h), hipMemcpyDeviceToHost, st));
+    AR_HIP(hipStreamSynchronize(st));
+    *n_unfilled = (int64_t)(unsigned int)h[1];
+  }
+  return SF_OK;
+}
+
+int sf_nsfar_loss_grad(SfNsfAr* n, const float* flat, const float* theta, const float* x, const long long* idx, long B, float grad_scale,
+                       const float* weights, float* loss, double* loss_sum, float* grad, hipStream_t st, std::string& err) {
+  int rc = sf_nsfar_pack(n, flat, st, err);
+  if (rc) return rc;
+  AR_HIP(hipMemsetAsync(grad, 0, (size_t)n->n_params * sizeof(float), st));
+  if (B == 0) return SF_OK;
+  const size_t need = (size_t)B * n->T * n->D;
+  if (need > n->ustash_cap) {
+    if (n->d_ustash) AR_HIP(hipFree(n->d_ustash));
+    n->d_ustash = nullptr; n->ustash_cap = 0;
+    AR_HIP(hipMalloc(&n->d_ustash, need * sizeof(float)));
+    n->ustash_cap = need;
+  }
+  hipLaunchKernelGGL(k_ar_train, dim3((unsigned)((B + 63) / 64)), dim3(64), sf_nsfar_lds_bytes(*n, 3), st, args_of(*n), theta, x, idx, B, grad_scale,
+                     weights, loss, loss_sum, grad, n->d_ustash);
+  AR_HIP(hipGetLastError());
+  return SF_OK;
+}

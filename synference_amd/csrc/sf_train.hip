@@ -11,6 +11,7 @@
 #include "sf_train_args.h"
 #include "sf_fixacc.h"
 #include "sf_nsf1.h"
+#include "sf_nsfar.h"
 #include "sf_nsfc.h"
 #include "sf_trainc.h"
 
@@ -296,6 +297,10 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
     hipError_t e = hipMemcpyAsync(f->d_flat, flat, (size_t)L.n_params * sizeof(float), hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) { err = std::string("hipMemcpyAsync: ") + hipGetErrorString(e); return SF_ERR_HIP; }
     return sf_nsf1_loss_grad(f->nsf1, flat, theta, x, idx, B, grad_scale, weights, loss, loss_sum, grad, st, err);
+  }
+  if (f->nsfar) {
+    if (dctx) { err = "the autoregressive NSF has no context-gradient path"; return SF_ERR_INVALID; }
+    return sf_nsfar_loss_grad(f->nsfar, flat, theta, x, idx, B, grad_scale, weights, loss, loss_sum, grad, st, err);
   }
   // ---- cooperative 16-row kernels: MAF (sf_trainc.hip: two blocks, D <= 8, T <= SF_TRC_TS, <= 4 hidden tiles) and
   //      NSF (sf_nsfc.hip: two blocks, D <= 8, H <= 64, K <= 11); they share the image / gather machinery

@@ -58,7 +58,7 @@ class HipFlow:
             theta_std=spec.theta_std.ctypes.data_as(_lib.c_f32p),
             x_mean=spec.x_mean.ctypes.data_as(_lib.c_f32p),
             x_std=spec.x_std.ctypes.data_as(_lib.c_f32p),
-            perms=spec.perms.ctypes.data_as(_lib.c_i32p) if spec.kind == "maf" else None)
+            perms=spec.perms.ctypes.data_as(_lib.c_i32p) if spec.kind == "maf" else None, ar_slope=spec.ar_slope)
         h = C.c_void_p()
         _lib.check(self.lib.sf_flow_create(C.byref(d), C.byref(h)))
         self.handle = h

@@ -146,12 +146,25 @@ class FlowEstimator(nn.Module):
 
 
 def build_flow(model: str, batch_theta, batch_x, hidden_features: int = 50, num_transforms: int = 5,
-               num_bins: int = 10, num_blocks: int = 2, z_score_theta="independent", z_score_x="independent",
+               num_bins: Optional[int] = None, num_blocks: int = 2, z_score_theta="independent", z_score_x="independent",
                embedding_net: Optional[nn.Module] = None, device="cuda:0",
-               generator: Optional[torch.Generator] = None, **extra) -> FlowEstimator:
-    """sbi ``build_maf`` / ``build_nsf`` ([UPSTREAM]) on the HIP engine."""
+               generator: Optional[torch.Generator] = None, backend: str = "sbi", **extra) -> FlowEstimator:
+    """sbi ``build_maf`` / ``build_nsf`` ([UPSTREAM]) on the HIP engine; with ``backend="lampe"``
+    the flow ``ili.utils.load_nde_lampe(model="nsf")`` builds: ``zuko.flows.NSF(D, C, transforms=num_transforms,
+    hidden_features=[hidden_features] * 2)`` -- 8 bins, bound 5, autoregressive -- behind standardising affines."""
     if model not in SUPPORTED_MODELS:
         raise ValueError(f"model '{model}' is not on the HIP path; supported: {SUPPORTED_MODELS}")
+    fixed = {}
+    if backend == "lampe":
+        if model != "nsf":
+            raise ValueError(f"backend 'lampe': only model 'nsf' (zuko.flows.NSF) is on the HIP path, not '{model}'")
+        model = "nsf_ar"
+        num_bins = 8 if num_bins is None else num_bins
+        num_blocks = 2
+        fixed = dict(tail_bound=5.0)
+    elif backend != "sbi":
+        raise ValueError(f"backend '{backend}' is not on the HIP path: 'sbi' or 'lampe'")
+    num_bins = 10 if num_bins is None else num_bins
     theta = torch.as_tensor(np.asarray(batch_theta.detach().cpu() if torch.is_tensor(batch_theta) else batch_theta),
                             dtype=torch.float32)
     x = torch.as_tensor(np.asarray(batch_x.detach().cpu() if torch.is_tensor(batch_x) else batch_x),
@@ -176,28 +189,36 @@ def build_flow(model: str, batch_theta, batch_x, hidden_features: int = 50, num_
                 probe = embedding_net(((x[:2] - torch.as_tensor(st["x_mean"])) / torch.as_tensor(st["x_std"])).to(pdev))
             Ce = int(probe[0].numel())
         spec = FlowSpec(kind=model, D=D, C=Ce, H=int(hidden_features), T=int(num_transforms), K=int(num_bins),
-                        NB=int(num_blocks), perms=perms, theta_mean=st["theta_mean"], theta_std=st["theta_std"])
+                        NB=int(num_blocks), perms=perms, theta_mean=st["theta_mean"], theta_std=st["theta_std"], **fixed)
         return FlowEstimator(spec, device=device, generator=generator, embedding_net=embedding_net,
                              x_mean=st["x_mean"], x_std=st["x_std"])
     spec = FlowSpec(kind=model, D=D, C=C, H=int(hidden_features), T=int(num_transforms), K=int(num_bins),
-                    NB=int(num_blocks), perms=perms, **st)
+                    NB=int(num_blocks), perms=perms, **st, **fixed)
     est = FlowEstimator(spec, device=device, generator=generator)
     return est
 
 
 def load_nde_hip(engine: str = "NPE", model: str = "maf", embedding_net: Optional[nn.Module] = None,
-                 repeats: int = 1, **model_args) -> Union[Callable, List[Callable]]:
-    """Counterpart of ``ili.utils.load_nde_sbi`` (called at ref: sbi_runner.py:5140-5146 and
-    custom_runner.py:320-324): returns ``build_fn(batch_theta=, batch_x=)`` or a list of them."""
+                 repeats: int = 1, backend: str = "sbi", **model_args) -> Union[Callable, List[Callable]]:
+    """Counterpart of ``ili.utils.load_nde_sbi`` -- and, with ``backend="lampe"``, of ``ili.utils.load_nde_lampe`` --
+    (called at ref: sbi_runner.py:5121-5146 and custom_runner.py:320-324): returns ``build_fn(batch_theta=, batch_x=)``
+    or a list of them.  ``device=`` (which the reference passes to the lampe loader) is accepted and ignored: the flow
+    lives on the GPU the builder is called for."""
     if "NPE" not in engine.upper():
         raise ValueError(f"engine '{engine}' is not on the HIP path: only (S)NPE is built")
     if model not in SUPPORTED_MODELS:
         raise ValueError(f"model '{model}' is not on the HIP path; supported: {SUPPORTED_MODELS}")
+    if backend not in ("sbi", "lampe"):
+        raise ValueError(f"backend '{backend}' is not on the HIP path: 'sbi' or 'lampe'")
+    if backend == "lampe" and model != "nsf":
+        raise ValueError(f"backend 'lampe': only model 'nsf' (zuko.flows.NSF) is on the HIP path, not '{model}'")
+    model_args.pop("device", None)
 
     def build_fn(batch_theta=None, batch_x=None, device="cuda:0", generator=None):
         return build_flow(model, batch_theta, batch_x, embedding_net=embedding_net, device=device,
-                          generator=generator, **model_args)
+                          generator=generator, backend=backend, **model_args)
 
     build_fn.model = model
+    build_fn.backend = backend
     build_fn.model_args = dict(model_args)
     return build_fn if repeats == 1 else [build_fn for _ in range(repeats)]

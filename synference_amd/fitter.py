@@ -395,8 +395,12 @@ class SBI_Fitter:
             stop_after_epochs = fp.get("stop_after_epochs", 20)
             clip_max_norm = fp.get("clip_max_norm", 5.0)
             validation_fraction = ta.get("validation_fraction", 0.1)
+        if backend == "lampe":   # the reference's second backend name (sbi_runner.py:5123-5125): its NSF, on the HIP engine
+            additional_model_args = dict(additional_model_args or {}, backend="lampe")
+            backend = "hip"
         if backend != "hip":
-            raise ValueError(f"backend '{backend}' is not available in synference_amd: use backend='hip'")
+            raise ValueError(f"backend '{backend}' is not available in synference_amd: use backend='hip' (or 'lampe' for "
+                             "the autoregressive NSF of the reference's lampe backend)")
         if learning_type != "offline":
             raise ValueError("only learning_type='offline' (amortised NPE) is on the HIP path")
         if prior_method != "ili":

@@ -16,12 +16,12 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 import torch
 
-KIND_ID = {"maf": 0, "nsf": 1}
+KIND_ID = {"maf": 0, "nsf": 1, "nsf_ar": 2}
 
 
 @dataclass
 class FlowSpec:
-    kind: str               # "maf" | "nsf"
+    kind: str               # "maf" | "nsf" | "nsf_ar" (the autoregressive NSF of the lampe / zuko backend)
     D: int                  # theta dimension
     C: int                  # context width seen by the transforms
     H: int = 50             # hidden_features (ref default: sbi_runner.py:4402)
@@ -36,6 +36,7 @@ class FlowSpec:
     lu_eps: float = 1e-3
     scale_fn: str = "softplus"   # "sigmoid2" = sigmoid(a+2) of nflows <= 0.13
     hidden_bf16: bool = False    # bf16 MFMA operands for the hidden HxH layers of the inference kernels
+    ar_slope: float = 1e-3       # nsf_ar: zuko MonotonicRQSTransform(slope=): soft clip of the spline logits
     theta_mean: Optional[np.ndarray] = None
     theta_std: Optional[np.ndarray] = None
     x_mean: Optional[np.ndarray] = None
@@ -45,7 +46,7 @@ class FlowSpec:
     def __post_init__(self):
         if self.kind not in KIND_ID:
             raise ValueError(
-                f"model '{self.kind}' is not built by the HIP backend: only 'maf' and 'nsf' "
+                f"model '{self.kind}' is not built by the HIP backend: only 'maf', 'nsf' and 'nsf_ar' "
                 "(NPE, direct sampling) are on the accelerated path")
         f = lambda a, n, fill: (np.full(n, fill, np.float32) if a is None
                                 else np.ascontiguousarray(np.asarray(a, dtype=np.float32).reshape(n)))
@@ -74,7 +75,7 @@ class FlowSpec:
 
     def to_dict(self) -> dict:
         d = {k: getattr(self, k) for k in ("kind", "D", "C", "H", "T", "K", "NB", "tail_bound", "min_bin_width",
-                                           "min_bin_height", "min_derivative", "maf_eps", "lu_eps", "scale_fn", "hidden_bf16")}
+                                           "min_bin_height", "min_derivative", "maf_eps", "lu_eps", "scale_fn", "hidden_bf16", "ar_slope")}
         for k in ("theta_mean", "theta_std", "x_mean", "x_std", "perms"):
             d[k] = getattr(self, k).tolist()
         return d
@@ -112,6 +113,11 @@ def param_layout(spec: FlowSpec) -> List[Tuple[str, Tuple[int, ...], int]]:
             for k in range(spec.NB):
                 add(p + f"W{k + 1}", (H, H)); add(p + f"b{k + 1}", (H,))
             add(p + "Wf", (2 * D, H)); add(p + "bf", (2 * D,))
+        elif spec.kind == "nsf_ar":   # zuko MaskedMLP hyper-network: [theta ; context] -> H x NB -> D (3K - 1)
+            add(p + "ar.W0", (H, D + Cc)); add(p + "ar.b0", (H,))
+            for k in range(1, spec.NB):
+                add(p + f"ar.W{k}", (H, H)); add(p + f"ar.b{k}", (H,))
+            add(p + f"ar.W{spec.NB}", (D * (3 * spec.K - 1), H)); add(p + f"ar.b{spec.NB}", (D * (3 * spec.K - 1),))
         elif spec.nsf_1d:
             add(p + "csm.W0", (H, Cc)); add(p + "csm.b0", (H,)); add(p + "csm.W1", (H, H)); add(p + "csm.b1", (H,))
             add(p + "csm.W2", (3 * spec.K - 1, H)); add(p + "csm.b2", (3 * spec.K - 1,))

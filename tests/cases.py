@@ -34,6 +34,12 @@ CASES = {
     # the width of the reference's production NSF (examples/sbi/configs/best_params.yaml: 69 hidden, K = 10): five hidden tiles
     # of 16 -> the five-wave form of the cooperative training kernel
     "nsf_h69": ("nsf", 8, 20, 69, 3, 10),
+    # the autoregressive NSF of the reference's lampe backend (zuko.flows.NSF: 8 bins, bound 5; sf_nsfar.hip): the cfg1 parameter
+    # space, a small ragged one (H not a multiple of D, K = 5), one parameter, and a wide one (8 parameters, 64 hidden)
+    "nsfar_cfg1": ("nsf_ar", 5, 10, 50, 5, 8, dict(tail_bound=5.0)),
+    "nsfar_small": ("nsf_ar", 3, 4, 17, 2, 5, dict(tail_bound=5.0)),
+    "nsfar_d1": ("nsf_ar", 1, 6, 16, 3, 8, dict(tail_bound=5.0)),
+    "nsfar_wide": ("nsf_ar", 8, 20, 64, 3, 8, dict(tail_bound=5.0, ar_slope=1e-2)),
 }
 
 

@@ -36,6 +36,79 @@ def test_desc_struct_matches_header_field_order():
     assert names == [f[0] for f in _lib.sf_flow_desc._fields_]
 
 
+def _check_nsfar_images(hf, d, ospec, spec, flat, theta, x):
+    """The autoregressive NSF's masked images (csrc/sf_nsfar.hip): gather them with the library's table and evaluate log_prob in
+    numpy EXACTLY as the kernels walk them -- type-sorted hidden rows, per-type row limits, 24 slots per dimension -- against
+    the oracle; then the one-sweep inverse (hidden rows of type r computed once the dimensions ordered before r are known)."""
+    import torch
+    from oracle import flows as OF
+    s1, s2 = hf.pack_table()
+    assert hf.n_params == len(flat) and len(s1) == d["n_packed"] == hf.packed_size() and (s2 == -1).all()
+    D, C, H, T, K, Hp = spec.D, spec.C, spec.H, spec.T, spec.K, d["Hp"]
+    perm, ptype, tend = np.array(d["perm"]), np.array(d["ptype"]), np.array(d["tend"])
+    ord_, dimof = np.array(d["ord"]).reshape(T, D), np.array(d["dimof"]).reshape(T, D)
+    assert Hp % 8 == 0 and sorted(perm[perm >= 0]) == list(range(H)) and (np.diff(ptype) >= 0).all() and tend[-1] == Hp
+    assert all((perm[p] % D == ptype[p]) for p in range(Hp) if perm[p] >= 0)
+    img = np.where(s1 >= 0, flat.astype(np.float64)[np.maximum(s1, 0)], 0.0)
+
+    def block(t, o, n):
+        return s1[t * d["t_stride"] + o: t * d["t_stride"] + o + n]
+    # every unmasked parameter is in the forward images exactly once (L1m and L0m are second copies for the backward sweep)
+    P_t = len(flat) // T
+    for t in range(T):
+        fwd = np.concatenate([block(t, d["o_L0t"], (D + C) * Hp), block(t, d["o_b0"], Hp), block(t, d["o_L1t"], Hp * Hp),
+                              block(t, d["o_b1"], Hp), block(t, d["o_L2t"], Hp * D * 24), block(t, d["o_b2"], D * 24)])
+        live = np.concatenate([np.concatenate([m.reshape(-1), np.ones(m.shape[0], bool)]) for m in OF.ar_masks(ospec, t)])
+        assert sorted(fwd[fwd >= 0]) == list(np.nonzero(live)[0] + t * P_t)
+    th = (theta.astype(np.float64) - spec.theta_mean) / spec.theta_std
+    e = (x.astype(np.float64) - spec.x_mean) / spec.x_std
+    ld = np.full(len(th), -np.log(spec.theta_std.astype(np.float64)).sum())
+
+    def hidden(tp, inp):
+        L0t = tp[d["o_L0t"]: d["o_L0t"] + (D + C) * Hp].reshape(D + C, Hp)
+        L1t = tp[d["o_L1t"]: d["o_L1t"] + Hp * Hp].reshape(Hp, Hp)
+        h1 = np.maximum(inp @ L0t + tp[d["o_b0"]: d["o_b0"] + Hp], 0.0)
+        h2 = np.zeros_like(h1)
+        for p0 in range(0, Hp, 8):
+            kend = tend[ptype[p0 + 7]]
+            h2[:, p0:p0 + 8] = np.maximum(h1[:, :kend] @ L1t[:kend, p0:p0 + 8] + tp[d["o_b1"] + p0: d["o_b1"] + p0 + 8], 0.0)
+        return h1, h2
+
+    def head(tp, t, dd, h2):
+        L2t = tp[d["o_L2t"]: d["o_L2t"] + Hp * D * 24].reshape(Hp, D * 24)
+        kend = tend[ord_[t, dd]]
+        q24 = h2[:, :kend] @ L2t[:kend, dd * 24: dd * 24 + 24] + tp[d["o_b2"] + dd * 24: d["o_b2"] + dd * 24 + 24]
+        return np.concatenate([q24[:, 0:K], q24[:, 8:8 + K], q24[:, 16:16 + K - 1]], axis=1)
+
+    u = th.copy()
+    stash = []
+    for t in range(T):
+        tp = img[t * d["t_stride"]: (t + 1) * d["t_stride"]]
+        stash.append(u.copy())
+        _, h2 = hidden(tp, np.concatenate([u, e], 1))
+        q = np.stack([head(tp, t, dd, h2) for dd in range(D)], 1)
+        v, lad = OF.ar_spline(ospec, torch.as_tensor(u), torch.as_tensor(q), inverse=False)
+        u = v.numpy(); ld += lad.numpy().sum(1)
+    got = -0.5 * (u ** 2).sum(1) - 0.5 * D * np.log(2 * np.pi) + ld
+    ref = oracle_log_prob(ospec, flat, theta, x)
+    assert np.abs(got - ref).max() < 1e-9
+    # one-sweep inverse of the last transform from its outputs: recovers the stashed inputs
+    t = T - 1
+    tp = img[t * d["t_stride"]: (t + 1) * d["t_stride"]]
+    L0t = tp[d["o_L0t"]: d["o_L0t"] + (D + C) * Hp].reshape(D + C, Hp)
+    L1t = tp[d["o_L1t"]: d["o_L1t"] + Hp * Hp].reshape(Hp, Hp)
+    w = np.zeros_like(u); h1 = np.zeros((len(u), Hp)); h2 = np.zeros((len(u), Hp))
+    for r in range(D):
+        lo, hi = (tend[r - 1] if r else 0), tend[r]
+        h1[:, lo:hi] = np.maximum(np.concatenate([w, e], 1) @ L0t[:, lo:hi] + tp[d["o_b0"] + lo: d["o_b0"] + hi], 0.0)
+        h2[:, lo:hi] = np.maximum(h1[:, :hi] @ L1t[:hi, lo:hi] + tp[d["o_b1"] + lo: d["o_b1"] + hi], 0.0)
+        dd = dimof[t, r]
+        q = head(tp, t, dd, h2)[:, None, :]
+        back, _ = OF.ar_spline(ospec, torch.as_tensor(u[:, dd:dd + 1]), torch.as_tensor(q), inverse=True)
+        w[:, dd] = back.numpy()[:, 0]
+    assert np.abs(w - stash[-1]).max() < 1e-9
+
+
 @pytest.mark.parametrize("name", list(CASES))
 def test_packer_plus_wave_model_reproduce_oracle(name):
     from synference_amd.engine import HipFlow
@@ -46,6 +119,9 @@ def test_packer_plus_wave_model_reproduce_oracle(name):
         assert hf.packed_size() == 0 and hf.n_params == len(flat) == spec.T * (spec.H * spec.C + spec.H + spec.H * spec.H + spec.H
                                                                                  + (3 * spec.K - 1) * (spec.H + 1))
         assert len(hf.pack_table()[0]) == 0 and hf.trainc_table() is None
+        return
+    if spec.kind == "nsf_ar":
+        _check_nsfar_images(hf, d, ospec, spec, flat, theta, x)
         return
     s1, s2 = hf.pack_table()
     assert hf.n_params == len(flat) and len(s1) == d["n_packed"] == hf.packed_size()

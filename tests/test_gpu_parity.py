@@ -87,7 +87,8 @@ def test_tiny_and_empty_batches():
     assert f.log_prob(theta[:0], x[:0]).numel() == 0
 
 
-@pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "nsf_odd", "maf_span6", "maf_d2_span", "maf_d4", "maf_d3", "maf_sig2", "nsf_d1"])
+@pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "nsf_odd", "maf_span6", "maf_d2_span", "maf_d4", "maf_d3", "maf_sig2", "nsf_d1",
+                                  "nsfar_cfg1", "nsfar_small", "nsfar_d1", "nsfar_wide"])
 def test_sampler_matches_oracle_draw_for_draw(name):
     ospec, spec, flat, theta, x = make_case(name, B=6, spread=0.2)
     S, seed = 257, 2025
@@ -128,6 +129,31 @@ def test_sampler_unbounded_and_acceptance():
     acc = f.acceptance(x, 4000, lo, hi, seed=11).cpu().numpy()
     racc = OP.acceptance(ospec, torch.as_tensor(flat), x, 4000, 11, lo, hi)
     assert np.abs(acc - racc).max() < 2e-3, (acc, racc)
+
+
+def test_autoregressive_nsf_slots_acceptance_and_exhaustion():
+    """The lampe-backend flow (sf_nsfar.hip) through the rest of the sampling ABI: listed slots reproduce the whole-catalogue
+    draws, acceptance counts follow the oracle, and a box nothing falls into gives NaN rows + the attempt ceiling."""
+    ospec, spec, flat, theta, x = make_case("nsfar_cfg1", B=5, spread=0.2)
+    f = _flow(spec, flat)
+    S = 96
+    free = f.sample(x, 512, seed=3).cpu().double().numpy()
+    ref_free, _ = OP.sample(ospec, torch.as_tensor(flat), x, 512, 3, dtype=torch.float32)
+    assert np.abs((free - ref_free) / np.asarray(ospec.theta_std)).max() <= 1e-4
+    lo = np.quantile(free.reshape(-1, spec.D), 0.05, axis=0).astype(np.float32)
+    hi = np.quantile(free.reshape(-1, spec.D), 0.95, axis=0).astype(np.float32)
+    whole = f.sample(x, S, lo, hi, seed=21)
+    slots = torch.arange(0, len(x) * S, 7, dtype=torch.int32, device="cuda")
+    part = torch.full_like(whole, float("nan"))
+    assert f.sample_slots(x, S, slots, part, lo, hi, seed=21) == 0
+    idx = slots.long()
+    assert torch.equal(part.reshape(-1, spec.D)[idx], whole.reshape(-1, spec.D)[idx])
+    acc = f.acceptance(x, 4000, lo, hi, seed=11).cpu().numpy()
+    racc = OP.acceptance(ospec, torch.as_tensor(flat), x, 4000, 11, lo, hi)
+    assert np.abs(acc - racc).max() < 2e-3, (acc, racc)
+    far_lo, far_hi = (hi + 50.0).astype(np.float32), (hi + 51.0).astype(np.float32)
+    got, nd = f.sample(x[:2], 8, far_lo, far_hi, seed=1, max_attempts=5, return_counts=True)
+    assert torch.isnan(got).all() and f.last_unfilled == 16 and (nd.cpu().numpy() == 8 * 5).all()
 
 
 @pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "nsf_odd", "maf_wide", "nsf_nb1", "maf_span6", "maf_span_h64"])

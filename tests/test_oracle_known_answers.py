@@ -313,3 +313,108 @@ def test_one_parameter_nsf_is_the_context_spline_map_flow():
     lp2 = OF.log_prob(spec2, p, torch.tensor([[2.3]], dtype=torch.float64), x)
     lp1 = OF.log_prob(spec, p, torch.tensor([[0.6]], dtype=torch.float64), x)
     assert abs((lp2 - lp1).item() - math.log(2.0)) < 1e-12
+
+
+# ---- the autoregressive NSF of the lampe / zuko backend (oracle kind "nsf_ar") ------------------------------
+def _ar_spec(D, C, H=12, T=3, K=5, **kw):
+    return OF.FlowSpec(kind="nsf_ar", D=D, C=C, H=H, T=T, K=K, tail_bound=5.0, **kw)
+
+
+@pytest.mark.parametrize("D,C", [(1, 3), (2, 3), (5, 4), (8, 2)])
+def test_autoregressive_nsf_inverse_logdet_and_jacobian(D, C):
+    spec = _ar_spec(D, C)
+    p = _rand_params(spec)
+    g = torch.Generator().manual_seed(0)
+    th = torch.randn(9, D, generator=g, dtype=torch.float64) * 2.0
+    x = torch.randn(9, C, generator=g, dtype=torch.float64)
+    z, ld = OF.forward_transform(spec, p, th, x)
+    th2, ld2 = OF.inverse_transform(spec, p, z, x)
+    assert (th2 - th).abs().max() < 1e-10 and (ld + ld2).abs().max() < 1e-10
+    for i in range(2):
+        J = torch.autograd.functional.jacobian(lambda t: OF.forward_transform(spec, p, t[None], x[i:i + 1])[0][0], th[i])
+        assert abs(torch.linalg.slogdet(J)[1].item() - ld[i].item()) < 1e-10
+
+
+def test_autoregressive_nsf_masks_orders_and_triangular_jacobian():
+    """zuko MaskedAutoregressiveTransform: transform t orders the dimensions 0..D-1 (t even) or D-1..0 (t odd); output i
+    depends on input j only if order[j] < order[i] -- so ONE transform's Jacobian is triangular in that order with the spline
+    derivative on the diagonal, the first-ordered dimension's spline parameters depend on the context alone, and every mask is
+    the product rule type(out) >= type(in) (strict into the first hidden layer)."""
+    D, C, H, K = 4, 3, 11, 5
+    spec = _ar_spec(D, C, H=H, T=2, K=K)
+    assert list(OF.ar_order(spec, 0)) == [0, 1, 2, 3] and list(OF.ar_order(spec, 1)) == [3, 2, 1, 0]
+    m0, m1, m2 = OF.ar_masks(spec, 0)
+    typ = np.arange(H) % D
+    assert m0.shape == (H, D + C) and m1.shape == (H, H) and m2.shape == (D * (3 * K - 1), H)
+    assert m0[:, D:].all() and not m0[typ == 0, :D].any() and m0[typ == 2, :2].all() and not m0[typ == 2, 2:D].any()
+    assert (m1 == (typ[:, None] >= typ[None, :])).all()
+    # connectivity of the mask product: parameter row of dimension i reaches input j iff order[j] < order[i]
+    reach = (m2.astype(int) @ m1.astype(int) @ m0.astype(int))[:, :D] > 0
+    for t in range(2):
+        order = OF.ar_order(spec, t)
+        mm = OF.ar_masks(spec, t)
+        reach = (mm[2].astype(int) @ mm[1].astype(int) @ mm[0].astype(int))[:, :D] > 0
+        for i in range(D):
+            rows = reach[i * (3 * K - 1):(i + 1) * (3 * K - 1)]
+            assert (rows == (order[None, :] < order[i])).all()
+    one = _ar_spec(D, C, H=H, T=1, K=K)
+    p = _rand_params(one)
+    u = torch.randn(D, dtype=torch.float64)
+    e = torch.randn(1, C, dtype=torch.float64)
+    J = torch.autograd.functional.jacobian(lambda t: OF.forward_transform(one, p, t[None], e)[0][0], u)
+    assert torch.equal(J.triu(1), torch.zeros_like(J.triu(1))) and (torch.diagonal(J) > 0).all()
+    P = OF.views(one, p)
+    q_a = OF._ar_hyper(one, P, 0, u[None], e)
+    q_b = OF._ar_hyper(one, P, 0, u[None] * -3.0 + 1.0, e)
+    assert torch.equal(q_a[0, 0], q_b[0, 0]) and not torch.equal(q_a[0, 1], q_b[0, 1])
+
+
+def test_zuko_spline_known_answers():
+    """MonotonicRQSTransform: all-zero parameters are the identity on [-B, B] (equal bins, unit derivatives); outside the
+    bound the map is the identity with log-derivative 0; logits are soft-clipped to +-|log slope| / 2 (widths, heights) and
+    +-|log slope| (log-derivatives), so NO parameter value gives a bin narrower than 2B / (1 + (K - 1) / slope) or a knot
+    derivative outside [slope, 1 / slope]; C1 at the knots and at +-B."""
+    K, B, slope = 5, 5.0, 1e-3
+    spec = _ar_spec(1, 1, K=K)
+    v = torch.linspace(-4.9, 4.9, 50, dtype=torch.float64)[:, None]
+    out, lad = OF.ar_spline(spec, v, torch.zeros(50, 1, 3 * K - 1, dtype=torch.float64), inverse=False)
+    assert (out - v).abs().max() < 1e-12 and lad.abs().max() < 1e-12
+    g = torch.Generator().manual_seed(2)
+    q = torch.randn(1, 1, 3 * K - 1, generator=g, dtype=torch.float64) * 4
+    vo = torch.tensor([[-5.5], [5.0001], [40.0]], dtype=torch.float64)
+    out, lad = OF.ar_spline(spec, vo, q.expand(3, 1, -1), inverse=False)
+    assert torch.equal(out, vo) and torch.equal(lad, torch.zeros_like(lad))
+    huge = torch.zeros(1, 1, 3 * K - 1, dtype=torch.float64)
+    huge[..., 0] = 1e9; huge[..., K] = -1e9; huge[..., 2 * K] = 1e9; huge[..., 2 * K + 1] = -1e9
+    hor, ver, der = OF._ar_knots(spec, huge)
+    ls = abs(math.log(slope))
+    w = torch.diff(hor[0, 0]) / (2 * B)
+    assert abs(w.max().item() - math.exp(ls / 2) / (math.exp(ls / 2) + (K - 1))) < 1e-6     # logit clipped to +ls/2, the others at 0
+    hgt = torch.diff(ver[0, 0]) / (2 * B)
+    assert abs(hgt.min().item() - math.exp(-ls / 2) / (math.exp(-ls / 2) + (K - 1))) < 1e-6
+    assert abs(der[0, 0, 1].item() - 1 / slope) < 1e-3 / slope and abs(der[0, 0, 2].item() - slope) < 1e-3 * slope
+    assert der[0, 0, 0] == 1 and der[0, 0, -1] == 1
+    vv = torch.linspace(-5, 5, 2001, dtype=torch.float64)[:, None].clone().requires_grad_(True)
+    qq = q.expand(2001, 1, -1)
+    out, lad = OF.ar_spline(spec, vv, qq, inverse=False)
+    (d,) = torch.autograd.grad(out.sum(), vv)
+    assert (out[1:] > out[:-1]).all() and (torch.log(d) - lad).abs().max() < 1e-9
+    hor, _, der = OF._ar_knots(spec, q)
+    kn = hor[0, 0, 1:-1]
+    both = torch.cat([kn - 1e-9, kn + 1e-9])[:, None].clone().requires_grad_(True)
+    o2, _ = OF.ar_spline(spec, both, q.expand(len(both), 1, -1), inverse=False)
+    (d2,) = torch.autograd.grad(o2.sum(), both)
+    knot_d = der[0, 0, 1:-1]
+    assert ((d2[:K - 1, 0] - d2[K - 1:, 0]).abs() / knot_d).max() < 1e-4 and ((d2[:K - 1, 0] - knot_d).abs() / knot_d).max() < 1e-4
+    back, lad2 = OF.ar_spline(spec, out.detach(), qq, inverse=True)
+    assert (back - vv.detach()).abs().max() < 1e-9 and (lad2 + lad.detach()).abs().max() < 1e-9
+
+
+def test_autoregressive_nsf_density_integrates_to_one_2d():
+    spec = _ar_spec(2, 2, H=8, T=2, K=4)
+    p = _rand_params(spec, jitter=0.3)
+    x = torch.tensor([[0.3, -0.4]], dtype=torch.float64)
+    g = torch.linspace(-10, 10, 801, dtype=torch.float64)
+    tt = torch.stack(torch.meshgrid(g, g, indexing="ij"), -1).reshape(-1, 2)
+    lp = OF.log_prob(spec, p, tt, x.expand(len(tt), -1))
+    assert abs(torch.exp(lp).sum().item() * (g[1] - g[0]).item() ** 2 - 1.0) < 2e-3
