@@ -34,6 +34,9 @@
 namespace {
 
 constexpr int ARK = 8, ARQ = 24;   // bins capacity / parameter slots per dimension (K <= 8: 3K - 1 <= 23)
+constexpr int RS = 65;             // floats per LDS row (64 samples + 1: the MFMA operand reads of the training kernel walk rows
+                                   // with the lane index -- a stride of 64 would put sixteen rows on one bank)
+typedef float ar_f32x4 __attribute__((ext_vector_type(4)));
 using ZS = ZSpl<ARK, ARQ>;
 
 struct ArArgs {
@@ -45,7 +48,7 @@ struct ArArgs {
   const int32_t* dimof;   // [T][D] dimension with order value r
   const float* xmean;     // [C]
   const float* xstd;      // [C]
-  int D, C, H, Hp, T, K, NP;
+  int D, C, H, Hp, T, K, NP, NIN16;
   long t_stride;          // floats per transform in img
   int o_L0t, o_b0, o_L1t, o_L1m, o_b1, o_L2t, o_b2, o_L0m;
   long P_t;               // logical parameters per transform
@@ -68,18 +71,38 @@ __device__ __forceinline__ F8 ar_ld8(const float* __restrict__ p) {
   return r;
 }
 
+// 16 x 16 block of a weight gradient: sum over the wave's 64 samples of A[o0 + i][s] * B[k0 + j][s] (v_mfma_f32_16x16x4_f32, sixteen
+// steps of four samples); lane l holds rows 4 (l >> 4) + r, column l & 15
+__device__ __forceinline__ ar_f32x4 ar_dw16(const float* A, int o0, const float* Bm, int k0, int lane) {
+  ar_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* pa = A + (o0 + (lane & 15)) * RS + (lane >> 4);
+  const float* pb = Bm + (k0 + (lane & 15)) * RS + (lane >> 4);
+#pragma unroll
+  for (int s0 = 0; s0 < 64; s0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s0], pb[s0], acc, 0, 0, 0);
+  return acc;
+}
+// the row sums of the same A rows (B = ones): every column holds them
+__device__ __forceinline__ ar_f32x4 ar_rowsum16(const float* A, int o0, int lane) {
+  ar_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* pa = A + (o0 + (lane & 15)) * RS + (lane >> 4);
+#pragma unroll
+  for (int s0 = 0; s0 < 64; s0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s0], 1.0f, acc, 0, 0, 0);
+  return acc;
+}
+
 // rows [p0, p0 + 8) of a dense layer: out = relu(b + sum_{k < kend} Wt[k][p] * in[k]); in / out: lane-strided LDS rows
 __device__ __forceinline__ void ar_layer8(const float* __restrict__ wt, int ldo, const float* __restrict__ bias, int p0, int kend,
                                           const float* in, float* out, int lane) {
   F8 acc = ar_ld8(bias + p0);
+#pragma unroll 4
   for (int k = 0; k < kend; ++k) {
-    const float a = in[k * 64 + lane];
+    const float a = in[k * RS + lane];
     const F8 w = ar_ld8(wt + (size_t)k * ldo + p0);
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc.v[j] += w.v[j] * a;
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) out[(p0 + j) * 64 + lane] = fmaxf(acc.v[j], 0.f);
+  for (int j = 0; j < 8; ++j) out[(p0 + j) * RS + lane] = fmaxf(acc.v[j], 0.f);
 }
 // the 24 parameter slots of dimension d from the last hidden layer (rows < kend)
 __device__ __forceinline__ void ar_head(const ArArgs& a, const float* __restrict__ tp, int d, int kend, const float* h2, int lane,
@@ -88,8 +111,9 @@ __device__ __forceinline__ void ar_head(const ArArgs& a, const float* __restrict
 #pragma unroll
   for (int jb = 0; jb < 3; ++jb) {
     F8 acc = ar_ld8(tp + a.o_b2 + d * ARQ + jb * 8);
+#pragma unroll 4
     for (int k = 0; k < kend; ++k) {
-      const float v = h2[k * 64 + lane];
+      const float v = h2[k * RS + lane];
       const F8 w = ar_ld8(tp + a.o_L2t + (size_t)k * ldo + d * ARQ + jb * 8);
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc.v[j] += w.v[j] * v;
@@ -108,16 +132,16 @@ __device__ __forceinline__ void ar_hidden(const ArArgs& a, const float* __restri
 
 __device__ __forceinline__ void ar_load_inputs(const ArArgs& a, const float* __restrict__ theta, const float* __restrict__ x, long row,
                                                float* E0, int lane) {
-  for (int d = 0; d < a.D; ++d) E0[d * 64 + lane] = theta[row * a.D + d] * a.th_scale[d] + a.th_shift[d];
-  for (int c = 0; c < a.C; ++c) E0[(a.D + c) * 64 + lane] = (x[row * a.C + c] - a.xmean[c]) / a.xstd[c];
+  for (int d = 0; d < a.D; ++d) E0[d * RS + lane] = theta[row * a.D + d] * a.th_scale[d] + a.th_shift[d];
+  for (int c = 0; c < a.C; ++c) E0[(a.D + c) * RS + lane] = (x[row * a.C + c] - a.xmean[c]) / a.xstd[c];
 }
 
 __global__ __launch_bounds__(64) void k_ar_logprob(ArArgs a, const float* __restrict__ theta, const float* __restrict__ x, long B,
                                                     float* __restrict__ out) {
   extern __shared__ float lds[];
   float* E0 = lds;
-  float* H1 = E0 + (a.D + a.C) * 64;
-  float* H2 = H1 + a.Hp * 64;
+  float* H1 = E0 + a.NIN16 * RS;
+  float* H2 = H1 + a.Hp * RS;
   const int lane = threadIdx.x;
   const long b = (long)blockIdx.x * 64 + lane;
   const long row = b < B ? b : B - 1;
@@ -131,13 +155,13 @@ __global__ __launch_bounds__(64) void k_ar_logprob(ArArgs a, const float* __rest
       float q[ARQ];
       ar_head(a, tp, d, a.tend[a.ord[t * a.D + d]], H2, lane, q);
       float v, lad;
-      ZS::fwd(sc, q, E0[d * 64 + lane], v, lad);
-      E0[d * 64 + lane] = v;   // (every parameter of this transform has been taken from the inputs already)
+      ZS::fwd(sc, q, E0[d * RS + lane], v, lad);
+      E0[d * RS + lane] = v;   // (every parameter of this transform has been taken from the inputs already)
       ld += lad;
     }
   }
   float ss = 0.f;
-  for (int d = 0; d < a.D; ++d) ss += E0[d * 64 + lane] * E0[d * 64 + lane];
+  for (int d = 0; d < a.D; ++d) ss += E0[d * RS + lane] * E0[d * RS + lane];
   if (b < B) out[b] = -0.5f * ss - 0.5f * (float)a.D * 1.8378770664093453f + ld;
 }
 
@@ -146,7 +170,7 @@ __device__ __forceinline__ float ar_inverse_transform(const ArArgs& a, const ZSp
                                                       float* H2, int lane) {
   const float* tp = a.img + (size_t)t * a.t_stride;
   float ld = 0.f;
-  for (int d = 0; d < a.D; ++d) E0[d * 64 + lane] = 0.f;   // (not yet known: masked weights are zeros, the values must be finite)
+  for (int d = 0; d < a.D; ++d) E0[d * RS + lane] = 0.f;   // (not yet known: masked weights are zeros, the values must be finite)
   for (int r = 0; r < a.D; ++r) {
     const int p_lo = r ? a.tend[r - 1] : 0, p_hi = a.tend[r];
     for (int p0 = p_lo; p0 < p_hi; p0 += 8) ar_layer8(tp + a.o_L0t, a.Hp, tp + a.o_b0, p0, a.D + a.C, E0, H1, lane);
@@ -155,8 +179,8 @@ __device__ __forceinline__ float ar_inverse_transform(const ArArgs& a, const ZSp
     float q[ARQ];
     ar_head(a, tp, d, p_hi, H2, lane, q);
     float w, lad;
-    ZS::inv(sc, q, V[d * 64 + lane], w, lad);
-    E0[d * 64 + lane] = w;
+    ZS::inv(sc, q, V[d * RS + lane], w, lad);
+    E0[d * RS + lane] = w;
     ld += lad;
   }
   return ld;
@@ -166,22 +190,22 @@ __global__ __launch_bounds__(64) void k_ar_inverse(ArArgs a, const float* __rest
                                                     float* __restrict__ theta, float* __restrict__ logdet) {
   extern __shared__ float lds[];
   float* E0 = lds;
-  float* H1 = E0 + (a.D + a.C) * 64;
-  float* H2 = H1 + a.Hp * 64;
-  float* V = H2 + a.Hp * 64;
+  float* H1 = E0 + a.NIN16 * RS;
+  float* H2 = H1 + a.Hp * RS;
+  float* V = H2 + a.Hp * RS;
   const int lane = threadIdx.x;
   const long b = (long)blockIdx.x * 64 + lane;
   const long row = b < B ? b : B - 1;
-  for (int c = 0; c < a.C; ++c) E0[(a.D + c) * 64 + lane] = (x[row * a.C + c] - a.xmean[c]) / a.xstd[c];
-  for (int d = 0; d < a.D; ++d) V[d * 64 + lane] = z[row * a.D + d];
+  for (int c = 0; c < a.C; ++c) E0[(a.D + c) * RS + lane] = (x[row * a.C + c] - a.xmean[c]) / a.xstd[c];
+  for (int d = 0; d < a.D; ++d) V[d * RS + lane] = z[row * a.D + d];
   const ZSplC sc = {a.K, a.B, a.cw, a.cd};
   float ld = -a.logdet0;
   for (int t = a.T - 1; t >= 0; --t) {
     ld += ar_inverse_transform(a, sc, t, E0, V, H1, H2, lane);
-    for (int d = 0; d < a.D; ++d) V[d * 64 + lane] = E0[d * 64 + lane];
+    for (int d = 0; d < a.D; ++d) V[d * RS + lane] = E0[d * RS + lane];
   }
   if (b < B) {
-    for (int d = 0; d < a.D; ++d) theta[b * a.D + d] = (V[d * 64 + lane] - a.th_shift[d]) / a.th_scale[d];
+    for (int d = 0; d < a.D; ++d) theta[b * a.D + d] = (V[d * RS + lane] - a.th_shift[d]) / a.th_scale[d];
     if (logdet) logdet[b] = ld;
   }
 }
@@ -195,9 +219,9 @@ __global__ __launch_bounds__(64) void k_ar_sample(ArArgs a, const float* __restr
                                                    int32_t* __restrict__ g_try, int32_t* __restrict__ g_acc) {
   extern __shared__ float lds[];
   float* E0 = lds;
-  float* H1 = E0 + (a.D + a.C) * 64;
-  float* H2 = H1 + a.Hp * 64;
-  float* V = H2 + a.Hp * 64;
+  float* H1 = E0 + a.NIN16 * RS;
+  float* H2 = H1 + a.Hp * RS;
+  float* V = H2 + a.Hp * RS;
   __shared__ unsigned long long r_slot[64];
   __shared__ uint32_t r_att[64];
   const int lane = threadIdx.x;
@@ -221,22 +245,22 @@ __global__ __launch_bounds__(64) void k_ar_sample(ArArgs a, const float* __restr
     __syncthreads();   // (the retry list has been read)
     if (__ballot(active) == 0ull) break;
     const long g = active ? (long)(slot / (unsigned long long)S) : 0;
-    for (int c = 0; c < a.C; ++c) E0[(a.D + c) * 64 + lane] = (x[g * a.C + c] - a.xmean[c]) / a.xstd[c];
+    for (int c = 0; c < a.C; ++c) E0[(a.D + c) * RS + lane] = (x[g * a.C + c] - a.xmean[c]) / a.xstd[c];
     for (int d0 = 0; d0 < a.D; d0 += 4) {
       float z4[4];
       sf_normal4(k0, k1, slot + slot_offset, att, (uint32_t)(d0 >> 2), z4);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (d0 + j < a.D) V[(d0 + j) * 64 + lane] = z4[j];
+        if (d0 + j < a.D) V[(d0 + j) * RS + lane] = z4[j];
     }
     for (int t = a.T - 1; t >= 0; --t) {
       (void)ar_inverse_transform(a, sc, t, E0, V, H1, H2, lane);
-      for (int d = 0; d < a.D; ++d) V[d * 64 + lane] = E0[d * 64 + lane];
+      for (int d = 0; d < a.D; ++d) V[d * RS + lane] = E0[d * RS + lane];
     }
     bool ok = active;
     for (int d = 0; d < a.D; ++d) {
-      const float th = (V[d * 64 + lane] - a.th_shift[d]) / a.th_scale[d];
-      V[d * 64 + lane] = th;
+      const float th = (V[d * RS + lane] - a.th_shift[d]) / a.th_scale[d];
+      V[d * RS + lane] = th;
       ok = ok && (th == th) && fabsf(th) < 3.0e38f && (!lo || (th >= lo[d] && th <= hi[d]));
     }
     if (count) {   // acceptance counting (leakage correction): one attempt per item, nothing written
@@ -251,7 +275,7 @@ __global__ __launch_bounds__(64) void k_ar_sample(ArArgs a, const float* __restr
       else if (tried >= 100000 && __hip_atomic_load(g_acc + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) give_up = true;
     }
     if (active && (ok || give_up)) {
-      for (int d = 0; d < a.D; ++d) out[slot * a.D + d] = ok ? V[d * 64 + lane] : __builtin_nanf("");
+      for (int d = 0; d < a.D; ++d) out[slot * a.D + d] = ok ? V[d * RS + lane] : __builtin_nanf("");
       if (n_drawn) sf_sat_add(n_drawn + g, (int32_t)(att + 1u));
       if (give_up) atomicAdd(n_unfilled, 1u);
     }
@@ -274,11 +298,12 @@ __global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restri
                                                   float* __restrict__ ustash) {
   extern __shared__ float lds[];
   float* E0 = lds;                       // [D + C]: u, context
-  float* H1 = E0 + (a.D + a.C) * 64;     // [Hp]
-  float* H2 = H1 + a.Hp * 64;            // [Hp]
-  float* DH = H2 + a.Hp * 64;            // [Hp] deltas
-  float* GG = DH + a.Hp * 64;            // [D] dL/du at the transform's output
-  float* DV = GG + a.D * 64;             // [D] what reaches the transform's input through the splines
+  float* H1 = E0 + a.NIN16 * RS;     // [Hp]
+  float* H2 = H1 + a.Hp * RS;            // [Hp]
+  float* DH = H2 + a.Hp * RS;            // [Hp] deltas
+  float* GG = DH + a.Hp * RS;            // [D] dL/du at the transform's output
+  float* DV = GG + a.D * RS;             // [D] what reaches the transform's input through the splines
+  float* DQ = DV + a.D * RS;             // [32] spline-parameter deltas of ONE dimension (rows >= 23: never read back)
   const int lane = threadIdx.x;
   const long b = (long)blockIdx.x * 64 + lane;
   const bool valid = b < B;
@@ -290,19 +315,19 @@ __global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restri
   float ld = a.logdet0;
   for (int t = 0; t < a.T; ++t) {
     const float* tp = a.img + (size_t)t * a.t_stride;
-    for (int d = 0; d < a.D; ++d) ust[t * a.D + d] = E0[d * 64 + lane];
+    for (int d = 0; d < a.D; ++d) ust[t * a.D + d] = E0[d * RS + lane];
     ar_hidden(a, tp, E0, H1, H2, lane);
     for (int d = 0; d < a.D; ++d) {
       float q[ARQ];
       ar_head(a, tp, d, a.tend[a.ord[t * a.D + d]], H2, lane, q);
       float v, lad;
-      ZS::fwd(sc, q, E0[d * 64 + lane], v, lad);
-      E0[d * 64 + lane] = v;
+      ZS::fwd(sc, q, E0[d * RS + lane], v, lad);
+      E0[d * RS + lane] = v;
       ld += lad;
     }
   }
   float ss = 0.f;
-  for (int d = 0; d < a.D; ++d) ss += E0[d * 64 + lane] * E0[d * 64 + lane];
+  for (int d = 0; d < a.D; ++d) ss += E0[d * RS + lane] * E0[d * RS + lane];
   const float nll = 0.5f * ss + 0.5f * (float)a.D * 1.8378770664093453f - ld;
   if (loss && valid) loss[b] = nll;
   if (loss_sum) {
@@ -311,24 +336,26 @@ __global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restri
     if (lane == 0) atomicAdd(loss_sum, (double)rintf(tsum * 1048576.0f) * (1.0 / 1048576.0));
   }
   const float wb = valid ? (wts ? w * wts[b] : w) : 0.f;
-  for (int d = 0; d < a.D; ++d) GG[d * 64 + lane] = wb * E0[d * 64 + lane];
+  for (int d = 0; d < a.D; ++d) GG[d * RS + lane] = wb * E0[d * RS + lane];
   const int nin = a.D + a.C;
   for (int t = a.T - 1; t >= 0; --t) {
     const float* tp = a.img + (size_t)t * a.t_stride;
     float* gt = grad + (size_t)t * a.P_t;
-    for (int d = 0; d < a.D; ++d) E0[d * 64 + lane] = ust[t * a.D + d];
+    for (int d = 0; d < a.D; ++d) E0[d * RS + lane] = ust[t * a.D + d];
     ar_hidden(a, tp, E0, H1, H2, lane);
-    for (int p = 0; p < a.Hp; ++p) DH[p * 64 + lane] = 0.f;
+    for (int p = 0; p < a.Hp; ++p) DH[p * RS + lane] = 0.f;
     // ---- head + splines
     for (int d = 0; d < a.D; ++d) {
       const int kend = a.tend[a.ord[t * a.D + d]];
       float q[ARQ], dq[ARQ];
       ar_head(a, tp, d, kend, H2, lane, q);
       float dv;
-      ZS::bwd(sc, q, E0[d * 64 + lane], GG[d * 64 + lane], -wb, dv, dq);
-      DV[d * 64 + lane] = dv;
+      ZS::bwd(sc, q, E0[d * RS + lane], GG[d * RS + lane], -wb, dv, dq);
+      DV[d * RS + lane] = dv;
+      dq[ARQ - 1] = 0.f;
       const int ldo = a.D * ARQ;
-      for (int k = 0; k < kend; ++k) {   // delta of the last hidden layer; weight gradients of this dimension's head rows
+#pragma unroll 2
+      for (int k = 0; k < kend; ++k) {   // delta of the last hidden layer
         float acc = 0.f;
 #pragma unroll
         for (int jb = 0; jb < 3; ++jb) {
@@ -336,82 +363,107 @@ __global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restri
 #pragma unroll
           for (int j = 0; j < 8; ++j) acc += wv.v[j] * dq[jb * 8 + j];
         }
-        DH[k * 64 + lane] += acc;
-        const int kl = a.perm[k];
-        if (kl >= 0) {
-          const float hv = H2[k * 64 + lane];
+        DH[k * RS + lane] += acc;
+      }
+      // weight gradients of this dimension's head rows: (24 slots x 64 samples) x (64 samples x kend hidden rows) on the MFMA
+      __syncthreads();   // (the previous dimension's blocks have read DQ)
 #pragma unroll
-          for (int s = 0; s < ARQ - 1; ++s) {
-            // slot s -> row of the logical head: family s / 8 (widths, heights, derivatives), index s % 8
-            const int fam = s >> 3, kk = s & 7;
-            if (kk < (fam < 2 ? a.K : a.K - 1)) {
-              const float gsum = ar_reduce64(dq[s] * hv);
-              if (lane == 0) unsafeAtomicAdd(gt + a.l_W2 + (size_t)(d * a.NP + fam * a.K + kk) * a.H + kl, gsum);
-            }
+      for (int sl = 0; sl < ARQ; ++sl) DQ[sl * RS + lane] = dq[sl];
+      __syncthreads();
+      for (int it = 0; it < 2; ++it) {
+        for (int k0 = 0; k0 < kend; k0 += 16) {
+          const ar_f32x4 g4 = ar_dw16(DQ, it * 16, H2, k0, lane);
+          const int k = k0 + (lane & 15);
+          const int kl = k < kend ? a.perm[k] : -1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int sl = it * 16 + 4 * (lane >> 4) + r, fam = sl >> 3, kk = sl & 7;
+            if (kl >= 0 && sl < ARQ - 1 && kk < (fam < 2 ? a.K : a.K - 1))
+              unsafeAtomicAdd(gt + a.l_W2 + (size_t)(d * a.NP + fam * a.K + kk) * a.H + kl, g4[r]);
           }
         }
-      }
+        const ar_f32x4 b4 = ar_rowsum16(DQ, it * 16, lane);
+        if ((lane & 15) == 0) {
 #pragma unroll
-      for (int s = 0; s < ARQ - 1; ++s) {
-        const int fam = s >> 3, kk = s & 7;
-        if (kk < (fam < 2 ? a.K : a.K - 1)) {
-          const float gsum = ar_reduce64(dq[s]);
-          if (lane == 0) unsafeAtomicAdd(gt + a.l_b2 + d * a.NP + fam * a.K + kk, gsum);
+          for (int r = 0; r < 4; ++r) {
+            const int sl = it * 16 + 4 * (lane >> 4) + r, fam = sl >> 3, kk = sl & 7;
+            if (sl < ARQ - 1 && kk < (fam < 2 ? a.K : a.K - 1)) unsafeAtomicAdd(gt + a.l_b2 + d * a.NP + fam * a.K + kk, b4[r]);
+          }
         }
       }
     }
     // ---- second hidden layer: delta through the ReLU, weight gradients, delta of the first hidden layer (into H2's rows)
-    for (int o = 0; o < a.Hp; ++o) DH[o * 64 + lane] = H2[o * 64 + lane] > 0.f ? DH[o * 64 + lane] : 0.f;
-    for (int o = 0; o < a.Hp; ++o) {
-      const int ol = a.perm[o];
-      if (ol < 0) continue;
-      const float dv = DH[o * 64 + lane];
-      const int kend = a.tend[a.ptype[o]];
-      for (int k = 0; k < kend; ++k) {
-        const int kl = a.perm[k];
-        if (kl < 0) continue;
-        const float gsum = ar_reduce64(dv * H1[k * 64 + lane]);
-        if (lane == 0) unsafeAtomicAdd(gt + a.l_W1 + (size_t)ol * a.H + kl, gsum);
+    for (int o = 0; o < a.Hp; ++o) DH[o * RS + lane] = H2[o * RS + lane] > 0.f ? DH[o * RS + lane] : 0.f;
+    __syncthreads();
+    for (int o0 = 0; o0 < a.Hp; o0 += 16) {
+      const int kend = a.tend[a.ptype[o0 + 15]];
+      int ol[4], oty[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ol[r] = a.perm[o0 + 4 * (lane >> 4) + r]; oty[r] = a.ptype[o0 + 4 * (lane >> 4) + r]; }
+      for (int k0 = 0; k0 < kend; k0 += 16) {
+        const ar_f32x4 g4 = ar_dw16(DH, o0, H1, k0, lane);
+        const int k = k0 + (lane & 15), kl = a.perm[k], kty = a.ptype[k];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (kl >= 0 && ol[r] >= 0 && kty <= oty[r]) unsafeAtomicAdd(gt + a.l_W1 + (size_t)ol[r] * a.H + kl, g4[r]);
       }
-      const float bsum = ar_reduce64(dv);
-      if (lane == 0) unsafeAtomicAdd(gt + a.l_b1 + ol, bsum);
+      const ar_f32x4 b4 = ar_rowsum16(DH, o0, lane);
+      if ((lane & 15) == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (ol[r] >= 0) unsafeAtomicAdd(gt + a.l_b1 + ol[r], b4[r]);
+      }
     }
+    __syncthreads();   // (H2 is overwritten next)
     for (int k0b = 0; k0b < a.Hp; k0b += 8) {   // delta_h1[k] = sum_o W1[o][k] delta_h2[o]  (row-major masked image)
       F8 acc;
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc.v[j] = 0.f;
+#pragma unroll 2
       for (int o = 0; o < a.Hp; ++o) {
-        const float dv = DH[o * 64 + lane];
+        const float dv = DH[o * RS + lane];
         const F8 wv = ar_ld8(tp + a.o_L1m + (size_t)o * a.Hp + k0b);
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc.v[j] += wv.v[j] * dv;
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) H2[(k0b + j) * 64 + lane] = H1[(k0b + j) * 64 + lane] > 0.f ? acc.v[j] : 0.f;
+      for (int j = 0; j < 8; ++j) H2[(k0b + j) * RS + lane] = H1[(k0b + j) * RS + lane] > 0.f ? acc.v[j] : 0.f;
     }
+    __syncthreads();
     // ---- first hidden layer: weight gradients, and what reaches the inputs
+    for (int o0 = 0; o0 < a.Hp; o0 += 16) {
+      int ol[4], oty[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ol[r] = a.perm[o0 + 4 * (lane >> 4) + r]; oty[r] = a.ptype[o0 + 4 * (lane >> 4) + r]; }
+      for (int i0 = 0; i0 < a.NIN16; i0 += 16) {
+        const ar_f32x4 g4 = ar_dw16(H2, o0, E0, i0, lane);
+        const int i = i0 + (lane & 15);
+        const int io = i < a.D ? a.ord[t * a.D + i] : -1;   // (context columns: seen by every unit)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (i < nin && ol[r] >= 0 && io < oty[r]) unsafeAtomicAdd(gt + a.l_W0 + (size_t)ol[r] * nin + i, g4[r]);
+      }
+      const ar_f32x4 b4 = ar_rowsum16(H2, o0, lane);
+      if ((lane & 15) == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (ol[r] >= 0) unsafeAtomicAdd(gt + a.l_b0 + ol[r], b4[r]);
+      }
+    }
     float din[16];
 #pragma unroll
     for (int d = 0; d < 16; ++d) din[d] = 0.f;
+#pragma unroll 2
     for (int o = 0; o < a.Hp; ++o) {
-      const int ol = a.perm[o];
-      if (ol < 0) continue;
-      const float dv = H2[o * 64 + lane];
-      const int ty = a.ptype[o];
-      for (int i = 0; i < nin; ++i) {
-        if (i < a.D && a.ord[t * a.D + i] >= ty) continue;   // masked: the unit does not see this dimension
-        const float gsum = ar_reduce64(dv * E0[i * 64 + lane]);
-        if (lane == 0) unsafeAtomicAdd(gt + a.l_W0 + (size_t)ol * nin + i, gsum);
-      }
-      const float bsum = ar_reduce64(dv);
-      if (lane == 0) unsafeAtomicAdd(gt + a.l_b0 + ol, bsum);
+      const float dv = H2[o * RS + lane];
       const F8 w0 = ar_ld8(tp + a.o_L0m + (size_t)o * 16), w1 = ar_ld8(tp + a.o_L0m + (size_t)o * 16 + 8);
 #pragma unroll
       for (int j = 0; j < 8; ++j) { din[j] += w0.v[j] * dv; din[8 + j] += w1.v[j] * dv; }
     }
+    __syncthreads();   // (the blocks above have read E0; the next transform overwrites it)
 #pragma unroll
     for (int d = 0; d < 16; ++d)
-      if (d < a.D) GG[d * 64 + lane] = DV[d * 64 + lane] + din[d];
+      if (d < a.D) GG[d * RS + lane] = DV[d * RS + lane] + din[d];
   }
 }
 
@@ -428,7 +480,7 @@ ArArgs args_of(const SfNsfAr& n) {
   ArArgs a;
   a.img = n.d_img; a.perm = n.d_perm; a.ptype = n.d_ptype; a.tend = n.d_tend; a.ord = n.d_ord; a.dimof = n.d_dimof;
   a.xmean = n.d_xmean; a.xstd = n.d_xstd;
-  a.D = n.D; a.C = n.C; a.H = n.H; a.Hp = n.Hp; a.T = n.T; a.K = n.K; a.NP = n.NP;
+  a.D = n.D; a.C = n.C; a.H = n.H; a.Hp = n.Hp; a.T = n.T; a.K = n.K; a.NP = n.NP; a.NIN16 = (n.D + n.C + 15) / 16 * 16;
   a.t_stride = n.t_stride;
   a.o_L0t = n.o_L0t; a.o_b0 = n.o_b0; a.o_L1t = n.o_L1t; a.o_L1m = n.o_L1m; a.o_b1 = n.o_b1; a.o_L2t = n.o_L2t; a.o_b2 = n.o_b2; a.o_L0m = n.o_L0m;
   a.P_t = n.P_t; a.l_W0 = n.l_W0; a.l_b0 = n.l_b0; a.l_W1 = n.l_W1; a.l_b1 = n.l_b1; a.l_W2 = n.l_W2; a.l_b2 = n.l_b2;
@@ -476,6 +528,10 @@ int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err) {
     while (cnt % 8) { n->perm.push_back(-1); n->ptype.push_back(r); ++cnt; }
     n->tend[r] = (int)n->perm.size();
   }
+  if (n->perm.size() % 16) {   // whole 16-row tiles for the MFMA blocks of the training kernel: one more padding block of the last type
+    for (int i = 0; i < 8; ++i) { n->perm.push_back(-1); n->ptype.push_back(D - 1); }
+    n->tend[D - 1] = (int)n->perm.size();
+  }
   const int Hp = (int)n->perm.size();
   n->Hp = Hp;
   // logical layout of a transform
@@ -495,7 +551,7 @@ int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err) {
   n->o_L0m = (int)o; o += (long)Hp * 16;
   n->t_stride = (o + 63) / 64 * 64;
   if (sf_nsfar_lds_bytes(*n, 3) > (size_t)160 * 1024 - 1024) {
-    err = "autoregressive NSF: (3 D + C + 3 Hp) x 256 bytes of LDS per wave exceed the 160 KB of a CU (Hp = H with every type padded to a multiple of 8)";
+    err = "autoregressive NSF: (3 D + C + 3 Hp + 32) x 260 bytes of LDS per wave exceed the 160 KB of a CU (Hp = H with every type padded to a multiple of 8, in all a multiple of 16)";
     delete n;
     return SF_ERR_INVALID;
   }
@@ -575,7 +631,8 @@ static int ar_ensure(SfNsfAr* n, std::string& err) {
 }
 
 size_t sf_nsfar_lds_bytes(const SfNsfAr& n, int hidden_buffers) {
-  return (size_t)(n.D + n.C + hidden_buffers * n.Hp + 2 * n.D) * 64 * sizeof(float);
+  // inputs (padded to whole 16-row tiles), hidden buffers, V or GG + DV, and the training kernel's 32 DQ rows
+  return (size_t)((n.D + n.C + 15) / 16 * 16 + hidden_buffers * n.Hp + 2 * n.D + (hidden_buffers == 3 ? 32 : 0)) * RS * sizeof(float);
 }
 
 int sf_nsfar_pack(SfNsfAr* n, const float* flat, hipStream_t st, std::string& err) {
