@@ -567,8 +567,8 @@ def main():
                              "note": "the statistic of sbi_runner.py:6461-6469 (the catalogue call is timed in 16 chunks)"},
                "fit_catalogue_quantiles": {"ms_per_call": 1e3 * t_q, "samples_per_s": M * S / t_q, "columns": int(tab.shape[1]),
                                            "note": "16 / 50 / 84 % per parameter reduced on the device; the draws never leave the GPU"},
-               "host": {"usable_cores": usable_cores(), "pipeline": "D2H of fp32 chunks on a copy stream into a pinned ring, "
-                        "widened to float64 by a thread pool (synference_amd/hostio.py)"}}
+               "host": {"usable_cores": usable_cores(), "pipeline": "sf_copy_to_host_f64: D2H of fp32 pieces on a copy stream into a pinned ring, "
+                        "widened to float64 with streaming stores by a pool of host threads (csrc/sf_hostio.hip)"}}
         note(f"API leg: {api['ms_per_call']:.2f} ms per sample_posterior call = {api['fraction_of_engine_value']:.2f} of the engine-level "
              f"value; fit_catalogue quantiles {1e3 * t_q:.2f} ms")
     # ---------------- train leg: fwd+bwd (+ all-reduce) + clip + Adam at the per-GPU batch

@@ -365,6 +365,16 @@ int sf_scatter_depths(const float* flux /*[N,C]*/, int64_t N, int32_t C, const f
 int sf_pit_ranks(const float* samples /*[N,S,D]*/, const float* truth /*[N,D]*/, int64_t N, int64_t S, int32_t D,
                  float* out /*[N,D]*/, void* stream);
 
+/* ---- hand-over to the host ----------------------------------------------------------------
+ * host_dst[i] = (double) dev_src[i], i < n: the draws of a catalogue call leave HBM as fp32 in pieces through a ring of pinned
+ * staging buffers on a private copy stream and are widened into the caller's float64 array (any host memory, not necessarily
+ * pinned) by a pool of host threads with streaming stores, copy and widening overlapped.  Work queued on `stream` before the
+ * call is waited for; blocking; one call at a time per process.  SF_HOSTIO_PIECE_MB [4], SF_HOSTIO_THREADS [min(8, cgroup
+ * CPU quota)].
+ * Replaces: `samples[i] = posterior.sample(...).detach().cpu().numpy()` into the float64 array (sbi_runner.py:6436-6457). */
+int sf_copy_to_host_f64(const float* dev_src /*device [n]*/, double* host_dst /*host [n]*/, int64_t n, void* stream);
+
+
 /* ---- misc --------------------------------------------------------------------------- */
 const char* sf_last_error(void);
 const char* sf_version(void);

@@ -46,3 +46,10 @@ print(f"FlowPosterior.sample_catalogue            {t(lambda: post.sample_catalog
 print(f"EnsemblePosterior.sample_catalogue (np X) {t(lambda: fit.posteriors.sample_catalogue(torch.as_tensor(X), S, 3)):.3f} ms")
 print(f"to_host_f64 alone                         {t(lambda: hostio.to_host_f64(out)):.3f} ms")
 print(f"SBI_Fitter.sample_posterior               {t(lambda: fit.sample_posterior(X, num_samples=S, seed=3)):.3f} ms")
+import os
+ref = fit.sample_posterior(X, num_samples=S, seed=3).copy()
+for nc in (1, 2, 3, 4, 6):
+    os.environ["SF_API_CHUNKS"] = str(nc)
+    same = np.array_equal(fit.sample_posterior(X, num_samples=S, seed=3), ref, equal_nan=True)
+    print(f"SBI_Fitter.sample_posterior, {nc} chunk(s)    {t(lambda: fit.sample_posterior(X, num_samples=S, seed=3)):.3f} ms   identical draws: {same}")
+os.environ.pop("SF_API_CHUNKS")

@@ -60,6 +60,7 @@ PROTOTYPES = {
     "sf_scatter_depths": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_uint64,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "sf_pit_ranks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sf_copy_to_host_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "sf_flow_packed16_size": (C.c_int64, [C.c_void_p]),
     "sf_flow_pack_table16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "sf_flow_packed16b_size": (C.c_int64, [C.c_void_p]),

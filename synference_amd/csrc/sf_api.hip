@@ -916,6 +916,14 @@ int sf_flow_acceptance(sf_flow* f, const float* x, int64_t M, int64_t n, const f
   return SF_OK;
 }
 
+int sf_copy_to_host_f64(const float* dev_src, double* host_dst, int64_t n, void* stream) {
+  if (n == 0) return SF_OK;
+  if (!dev_src || !host_dst || n < 0) return fail(SF_ERR_INVALID, "null argument or n < 0");
+  std::string err;
+  int rc = sf_hostio_copy_f64(dev_src, host_dst, n, (hipStream_t)stream, err);
+  return rc ? fail(rc, err) : SF_OK;
+}
+
 // ---- training ------------------------------------------------------------------------------
 int sf_flow_loss_grad_weighted(sf_flow* f, const float* flat, const float* theta, const float* x, int64_t B,
                                float grad_scale, const float* weights, float* loss, float* grad,

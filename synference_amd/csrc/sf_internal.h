@@ -210,3 +210,6 @@ struct sf_flow {
     return v;
   }
 };
+
+// device fp32 -> host float64 hand-over (sf_hostio.hip)
+int sf_hostio_copy_f64(const float* dev_src, double* host_dst, int64_t n, hipStream_t stream, std::string& err);

@@ -516,7 +516,11 @@ class SBI_Fitter:
         # log_times: the reference times every object (sbi_runner.py:6438-6469: median and 16th-84th percentile of the
         # per-object wall time); the catalogue call is timed in chunks instead and each chunk's time is shared equally
         # by its objects, so the three statistics keep their meaning without a per-galaxy host loop
-        n_chunks = min(len(X), 16) if log_times else 1
+        # without log_times ONE catalogue call, then the native hand-over.  (Measured: cutting the catalogue in 2 .. 6 chunks so
+        # that chunk k crosses the bus while chunk k + 1 is drawn costs more than it hides -- every chunk pays the sampler's
+        # tail: 3.6 / 3.9 / 4.3 / 4.8 ms for 1 / 2 / 3 / 4 chunks of the cfg2 catalogue.  SF_API_CHUNKS=n forces n.)
+        auto_chunks = int(os.environ.get("SF_API_CHUNKS", "0")) or 1
+        n_chunks = min(len(X), 16) if log_times else max(1, min(len(X), auto_chunks))
         if seed is None and n_chunks > 1:
             seed = posteriors._next_seed(None)
         bounds = np.linspace(0, len(X), n_chunks + 1).astype(int)
@@ -524,6 +528,7 @@ class SBI_Fitter:
         from .hostio import result_array
         samples = result_array((len(X), num_samples, len(self.fitted_parameter_names)))
         times = []
+        pending = []
         for ci in range(n_chunks):
             a, b = int(bounds[ci]), int(bounds[ci + 1])
             if b <= a:
@@ -532,16 +537,24 @@ class SBI_Fitter:
             try:
                 # the reference's per-object timeout (sbi_runner.py:6358) becomes the wall-clock ceiling of the chunk
                 tmo = float(timeout_seconds_per_test) * (b - a) if timeout_seconds_per_test else None
-                # (same seed, rows keyed by their position: the draws do not depend on the timing chunks)
+                # (same seed, rows keyed by their position: the draws do not depend on the chunking)
                 s = posteriors.sample_catalogue(torch.as_tensor(X[a:b]), num_samples, seed, timeout_seconds=tmo, row_offset=a)
                 # D2H in float32 (half the PCIe bytes of a device-side .double()) through a ring of pinned staging buffers
                 # on a copy stream, widened into the reference's float64 container by a thread pool while the next piece
-                # is on the bus (hostio.py)
-                to_host_f64(s, out=samples[a:b])
+                # is on the bus (hostio.py); with log_times the chunk's time includes its hand-over
+                p = to_host_f64(s, out=samples[a:b], wait=bool(log_times))
+                if not log_times:
+                    pending.append((a, b, p))
             except Exception as e:  # sbi_runner.py:6458-6460: failed objects are NaN rows
                 logger.error(f"Error occurred while sampling objects {a}..{b}: {e}")
                 samples[a:b] = np.nan
             times.extend([(time.time() - t0) / (b - a)] * (b - a))
+        for a, b, p in pending:
+            try:
+                p.result()
+            except Exception as e:
+                logger.error(f"Error occurred while copying objects {a}..{b} to the host: {e}")
+                samples[a:b] = np.nan
         if log_times and times:
             self.last_times_per_object = np.asarray(times)
             self.last_time_per_object = float(np.median(times))

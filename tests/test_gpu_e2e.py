@@ -212,6 +212,23 @@ def test_lampe_backend_fits_the_autoregressive_nsf(tmp_path):
     assert np.isfinite(np.asarray(lp)).all()
 
 
+def test_native_host_handover_is_exact():
+    """sf_copy_to_host_f64 (csrc/sf_hostio.hip): float64 host copy of device fp32, bit for bit, for sizes that do not divide into
+    pieces or vector widths, a destination that is not 32-byte aligned, and a second call reusing the ring."""
+    from synference_amd import hostio
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for n, shift in ((1, 0), (7, 1), (1234567, 3), (2 * 1024 * 1024 + 5, 0), (3 * 1048576, 2)):
+        src = torch.randn(n, device="cuda", generator=g)
+        src[::97] = float("nan")
+        dst = np.empty(n + shift, np.float64)[shift:]
+        hostio.to_host_f64(src, out=dst)
+        assert np.array_equal(dst, src.double().cpu().numpy(), equal_nan=True)
+    cube = torch.randn(50, 40, 5, device="cuda", generator=g)
+    pend = hostio.to_host_f64(cube, wait=False)
+    assert np.array_equal(pend.result(), cube.double().cpu().numpy())
+    assert hostio.to_host_f64(cube[:0]).shape == (0, 40, 5)
+
+
 def test_device_quantiles_match_numpy(fitted):
     from synference_amd.posterior import device_quantiles
     rng = np.random.default_rng(0)
