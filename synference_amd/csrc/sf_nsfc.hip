@@ -369,7 +369,9 @@ __global__ __launch_bounds__(64 * (NT > 4 ? NT : 4), (NT > 4 ? 1 : 2)) void k_ns
           put2(XA, n_relu(h0[0]), n_relu(h0[1]));
         }
       }
+      SF_NC(300 + (bw ? 10 : 0) + 0);
       n_barrier();
+      SF_NC(300 + (bw ? 10 : 0) + 1);
       // F2: t1 = b1 + W1 relu(h0)
       ld_hid(tp, c.o_w2[0], c.o_b2[0], wA, bA);
       if (has) {
@@ -377,6 +379,7 @@ __global__ __launch_bounds__(64 * (NT > 4 ? NT : 4), (NT > 4 ? 1 : 2)) void k_ns
         put2(XB, n_relu(t1[0]), n_relu(t1[1]));
       }
       n_barrier();
+      SF_NC(300 + (bw ? 10 : 0) + 2);
       // F3: t2 = b2 + W2 relu(t1); gate = sigmoid(bg + Wg e); h1 = h0 + t2 * gate
       ld_hid(tp, c.o_w1[1], c.o_b1[1], wB, bB);
       if (has) {
@@ -396,6 +399,7 @@ __global__ __launch_bounds__(64 * (NT > 4 ? NT : 4), (NT > 4 ? 1 : 2)) void k_ns
         put2(XA, h1a, h1b);
       }
       n_barrier();
+      SF_NC(300 + (bw ? 10 : 0) + 3);
       // F4: t1' = b1' + W1' relu(h1)
       ld_hid(tp, c.o_w2[1], c.o_b2[1], wA, bA);
       if (has) {
@@ -403,6 +407,7 @@ __global__ __launch_bounds__(64 * (NT > 4 ? NT : 4), (NT > 4 ? 1 : 2)) void k_ns
         put2(XB, n_relu(t1b[0]), n_relu(t1b[1]));
       }
       n_barrier();
+      SF_NC(300 + (bw ? 10 : 0) + 4);
       // F5: t2' = b2' + W2' relu(t1'); gate'; h2 = h1 + t2' * gate'  (no activation in front of the head).  Ahead: the head
       // fragments of tile `wave` (both subtiles)
 #pragma unroll
@@ -426,6 +431,7 @@ __global__ __launch_bounds__(64 * (NT > 4 ? NT : 4), (NT > 4 ? 1 : 2)) void k_ns
         if (bw) putT2(TI2, h2a, h2b);
       }
       n_barrier();
+      SF_NC(300 + (bw ? 10 : 0) + 5);
       // F6: q = bout + Wout h2: tiles wave, wave + 4 for both subtiles; the remaining tiles one (tile, subtile) unit per wave
       {
         // second portion of the head's fragments: tile wave + 4 (OTQ = 8) or this wave's extra unit (OTQ = 6)
@@ -470,7 +476,9 @@ __global__ __launch_bounds__(64 * (NT > 4 ? NT : 4), (NT > 4 ? 1 : 2)) void k_ns
           }
         }
       }
+      SF_NC(300 + (bw ? 10 : 0) + 6);
       n_barrier();
+      SF_NC(300 + (bw ? 10 : 0) + 7);
     };
     // LU constants of the transform whose block sits in LUC
     auto lu_diag = [&](float (&dg)[8]) {
@@ -497,11 +505,13 @@ __global__ __launch_bounds__(64 * (NT > 4 ? NT : 4), (NT > 4 ? 1 : 2)) void k_ns
         q[4 * jt] = v[0]; q[4 * jt + 1] = v[1]; q[4 * jt + 2] = v[2]; q[4 * jt + 3] = v[3];
       }
       ld8(0, u);
+      SF_NC(320 + (keep ? 10 : 0) + 0);
 #pragma unroll
       for (int p = 0; p < 8; ++p) ui[p] = u[p];
       const float vin = start ? n_sel4(g4, u[1], u[3], u[5], u[7]) : n_sel4(g4, u[0], u[2], u[4], u[6]);
       float vout, lad;
       Spl::fwd(sc, q, vin, vout, lad);
+      SF_NC(320 + (keep ? 10 : 0) + 1);
       ld += have ? lad : 0.f;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -518,6 +528,7 @@ __global__ __launch_bounds__(64 * (NT > 4 ? NT : 4), (NT > 4 ? 1 : 2)) void k_ns
         dst[2] = make_float4(up[0], up[1], up[2], up[3]); dst[3] = make_float4(up[4], up[5], up[6], up[7]);
       }
       // y = L (U u') + b
+      SF_NC(320 + (keep ? 10 : 0) + 2);
       float dg[8], tt[8];
       lu_diag(dg);
 #pragma unroll
@@ -534,10 +545,12 @@ __global__ __launch_bounds__(64 * (NT > 4 ? NT : 4), (NT > 4 ? 1 : 2)) void k_ns
         for (int jj = 0; jj < i; ++jj) y += LUC[i * 8 + jj] * tt[jj];
         u[i] = i < D ? y : 0.f;
       }
+      SF_NC(320 + (keep ? 10 : 0) + 3);
       if (!keep) {
         write_in0(u);
         st8(0, u);
       }
+      SF_NC(320 + (keep ? 10 : 0) + 4);
     };
 
     // ------------------------------------------------------------------ forward sweep (all transforms but the top one)
@@ -643,6 +656,7 @@ __global__ __launch_bounds__(64 * (NT > 4 ? NT : 4), (NT > 4 ? 1 : 2)) void k_ns
         for (int p = 0; p < 8; ++p) G[p] = p < D ? Gn[p] : 0.f;
         // (the spline's 2 x (3K - 1) parameter registers are not wanted while the LU arrays above are alive)
         __builtin_amdgcn_sched_barrier(0);
+        SF_NC(340);
         float q[NQV], dq[NQV];
 #pragma unroll
         for (int jt = 0; jt < OTQ; ++jt) {
@@ -653,6 +667,7 @@ __global__ __launch_bounds__(64 * (NT > 4 ? NT : 4), (NT > 4 ? 1 : 2)) void k_ns
         const float Gsel = start ? n_sel4(g4, G[1], G[3], G[5], G[7]) : n_sel4(g4, G[0], G[2], G[4], G[6]);
         float dv;
         Spl::bwd(sc, q, vin, have ? Gsel : 0.f, have ? -wgt : 0.f, dv, dq);
+        SF_NC(341);
 #pragma unroll
         for (int jt = 0; jt < OTQ; ++jt) {
           f32x4 v;
@@ -668,6 +683,7 @@ __global__ __launch_bounds__(64 * (NT > 4 ? NT : 4), (NT > 4 ? 1 : 2)) void k_ns
           G[2 * g + 1] = (on && start == 1) ? vg : G[2 * g + 1];
         }
         st8(0, G);
+        SF_NC(342);
       }
       n_barrier();
       SF_NC(42 + 10 * (T - 1 - t));
@@ -714,6 +730,7 @@ __global__ __launch_bounds__(64 * (NT > 4 ? NT : 4), (NT > 4 ? 1 : 2)) void k_ns
           const int b = n - nw;
           return NJob{XL, TL, gp + c.g_lu + b * 256, b == 0 ? gp + c.g_lu + 512 : nullptr, b, b};
         });
+        SF_NC(350);
         if (has) {
           dh[0] = n_zero();
           dh[1] = n_zero();
@@ -735,6 +752,7 @@ __global__ __launch_bounds__(64 * (NT > 4 ? NT : 4), (NT > 4 ? 1 : 2)) void k_ns
           putT2(TI, n_relu(t1b[0]), n_relu(t1b[1]));
         }
       }
+      SF_NC(351);
       n_barrier();
       SF_NC(43 + 10 * (T - 1 - t));
       // the two residual blocks, top down
@@ -759,6 +777,7 @@ __global__ __launch_bounds__(64 * (NT > 4 ? NT : 4), (NT > 4 ? 1 : 2)) void k_ns
             const int ot = m / NI, it = m - ot * NI;
             return NJob{XG, TIN, gp + g_wg + m * 256, it == 0 ? gp + g_bg : nullptr, ot, it};
           });
+          SF_NC(360 + 10 * kk);
           if (has) {
             f32x4 a0, a1;
             go_hidT(wf, XB, a0, a1);
@@ -777,7 +796,9 @@ __global__ __launch_bounds__(64 * (NT > 4 ? NT : 4), (NT > 4 ? 1 : 2)) void k_ns
             putT2(TI2, hin[0], hin[1]);
           }
         }
+        SF_NC(361 + 10 * kk);
         n_barrier();
+        SF_NC(362 + 10 * kk);
         // B3 / B5: gradient at the block's input; (block 1) deltas of block 0's second layer and gate; weight gradients
         // of the block's first layer
         {
@@ -787,6 +808,7 @@ __global__ __launch_bounds__(64 * (NT > 4 ? NT : 4), (NT > 4 ? 1 : 2)) void k_ns
             const int ot = n / NT, it = n - ot * NT;
             return NJob{XA, TI2, gp + g_w1 + n * 256, it == 0 ? gp + g_b1 : nullptr, ot, it};
           });
+          SF_NC(363 + 10 * kk);
           if (has) {
             f32x4 a0, a1;
             go_hidT(wf, XA, a0, a1);
@@ -815,7 +837,9 @@ __global__ __launch_bounds__(64 * (NT > 4 ? NT : 4), (NT > 4 ? 1 : 2)) void k_ns
             }
           }
         }
+        SF_NC(364 + 10 * kk);
         n_barrier();
+        SF_NC(365 + 10 * kk);
       }
       SF_NC(44 + 10 * (T - 1 - t));
       // B6: partial sums of Win^T delta over my hidden tile (operand straight from registers); weight gradients of Win;

@@ -19,11 +19,15 @@ from cases import make_case, oracle_inverse, oracle_log_prob  # noqa: E402
 from oracle import flows as OF  # noqa: E402
 from oracle import philox  # noqa: E402
 
-GOLDEN_CASES = ["maf_cfg1", "nsf_cfg3", "nsf_odd", "maf_small"]
+GOLDEN_CASES = ["maf_cfg1", "nsf_cfg3", "nsf_odd", "maf_small",
+                # round 4: sbi's one-parameter NSF, the K = 10 coupling NSF, the autoregressive NSF of the lampe backend
+                "nsf_d1", "nsf_k10", "nsfar_cfg1", "nsfar_small"]
 
 
 def main():
     for name in GOLDEN_CASES:
+        if os.path.exists(os.path.join(HERE, f"{name}.npz")) and "--all" not in sys.argv:
+            continue   # frozen: existing vectors are only rewritten on request
         ospec, spec, flat, theta, x = make_case(name, seed=11, B=48)
         z = philox.normal(77, np.arange(48, dtype=np.uint64), 0, spec.D)
         lp = oracle_log_prob(ospec, flat, theta, x, torch.float64)
@@ -34,7 +38,8 @@ def main():
             os.path.join(HERE, f"{name}.npz"), flat=flat, theta=theta, x=x, z=z, log_prob=lp, inv_theta=th_inv,
             inv_logdet=ld_inv, grad_mean_nll=p.grad.numpy().astype(np.float32),
             theta_mean=spec.theta_mean, theta_std=spec.theta_std, x_mean=spec.x_mean, x_std=spec.x_std,
-            perms=spec.perms, meta=np.array([spec.D, spec.C, spec.H, spec.T, spec.K, spec.NB]), kind=spec.kind)
+            perms=spec.perms, meta=np.array([spec.D, spec.C, spec.H, spec.T, spec.K, spec.NB]), kind=spec.kind,
+            tail_bound=np.float64(spec.tail_bound), ar_slope=np.float64(spec.ar_slope))
         print(name, "log_prob[:3]", lp[:3])
 
 
