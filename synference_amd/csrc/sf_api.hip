@@ -232,7 +232,7 @@ int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen) {
     add("kind", SF_NSF_AR); add("D", n.D); add("C", n.C); add("H", n.H); add("T", n.T); add("K", n.K); add("NB", 2);
     add("Hp", n.Hp); add("t_stride", n.t_stride); add("n_params", (long)n.n_params); add("n_packed", (long)n.src.size());
     add("o_L0t", n.o_L0t); add("o_b0", n.o_b0); add("o_L1t", n.o_L1t); add("o_L1m", n.o_L1m); add("o_b1", n.o_b1);
-    add("o_L2t", n.o_L2t); add("o_b2", n.o_b2); add("o_L0m", n.o_L0m); add("lds_bytes_train", (long)sf_nsfar_lds_bytes(n, 3));
+    add("o_L2t", n.o_L2t); add("o_b2", n.o_b2); add("o_L0m", n.o_L0m); add("o_L2m", n.o_L2m); add("lds_bytes_train", (long)sf_nsfar_lds_bytes(n, 3));
     auto arr = [&](const char* k, const std::vector<int32_t>& a, bool last) {
       s += "\"" + std::string(k) + "\": [";
       for (size_t i = 0; i < a.size(); ++i) s += std::to_string(a[i]) + (i + 1 < a.size() ? ", " : "");

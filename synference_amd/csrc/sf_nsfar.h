@@ -19,7 +19,7 @@ struct SfNsfAr {
   int64_t n_params = 0;
   long P_t = 0, t_stride = 0;
   int l_W0 = 0, l_b0 = 0, l_W1 = 0, l_b1 = 0, l_W2 = 0, l_b2 = 0;                             // logical offsets in a transform
-  int o_L0t = 0, o_b0 = 0, o_L1t = 0, o_L1m = 0, o_b1 = 0, o_L2t = 0, o_b2 = 0, o_L0m = 0;   // image offsets in a transform
+  int o_L0t = 0, o_b0 = 0, o_L1t = 0, o_L1m = 0, o_b1 = 0, o_L2t = 0, o_b2 = 0, o_L0m = 0, o_L2m = 0;   // image offsets in a transform
   bool dev_ready = false;
   float* d_img = nullptr;
   int32_t *d_src = nullptr, *d_none = nullptr, *d_perm = nullptr, *d_ptype = nullptr, *d_tend = nullptr, *d_ord = nullptr, *d_dimof = nullptr;

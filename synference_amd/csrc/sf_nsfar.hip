@@ -6,19 +6,22 @@
 //   [theta ; context] -> H -> H -> D (3K - 1) (ReLU) whose masks make the spline parameters of a dimension depend on the
 //   dimensions ordered before it and on the context; the univariate map is zuko's MonotonicRQSTransform (sf_spline_flat.h, ZSpl).
 //
-// Built for correctness and a sane speed, not for the roofline (it is the secondary backend): one THREAD per sample, the
-// activations of a wave's 64 samples in LDS (lane-strided rows), the weights re-tiled once per parameter update into images whose
-// rows are read with wave-uniform 32-byte loads -- eight outputs share every activation read (8 FMAs per ds_read + one
-// scalar-cache load).  Hidden units are stored SORTED BY TYPE (zuko: unit h has type h mod D and sees the inputs ordered
-// before its type), every type padded to a multiple of eight rows, so that
-//   * the masked layers are block lower-triangular: an output of type r reads the first tend[r] rows only;
+// One THREAD per sample for the univariate maps, the wave's 64 samples side by side for the products: activations live in LDS
+// as rows of 65 floats ([unit][sample]), every layer product is a set of 16 x 16 tiles on v_mfma_f32_16x16x4_f32 -- A = sixteen
+// output units x four inputs straight from the k-major masked weight image in L2 (four 64-byte segments per load), B = four
+// input rows x sixteen samples from LDS, four sample tiles per weight load.  The same tile routine runs the backward data
+// products on the transposed images (L1m, L2m, L0m), and the weight gradients are 16 x 16 blocks over the 64 samples (A = delta
+// rows, B = input rows), added with f32 atomics.  Hidden units are stored SORTED BY TYPE (zuko: unit h has type h mod D and sees
+// the inputs ordered before its type), every type padded to a multiple of eight rows (all of them to a multiple of 16), so that
+//   * the masked layers are block lower-triangular: an output tile whose highest type is r reads the first tend[r] rows only
+//     (masked entries of the images are zeros);
 //   * the SAMPLING direction costs one hyper-network evaluation per transform, not D: the units of type r become final as
 //     soon as the dimensions ordered before r are inverted, so the sweep r = 0 .. D-1 computes the hidden units of type r,
 //     the head of the dimension with order r, inverts that dimension, and goes on (zuko sweeps the whole network D times);
 //   * rejected draws are retried by compaction: a wave keeps taking (slot, attempt) items -- its own rejects first -- until
 //     the catalogue's slot list is exhausted.
-// Training: forward, then per transform (top down) the hyper-network is recomputed from the stashed inputs and
-// back-propagated by hand; weight gradients are wave reductions + one f32 atomic per (weight, wave).
+// Training: forward with every transform's inputs stashed, then per transform (top down) the hyper-network is recomputed from
+// the stash and back-propagated by hand.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -48,31 +51,20 @@ struct ArArgs {
   const int32_t* dimof;   // [T][D] dimension with order value r
   const float* xmean;     // [C]
   const float* xstd;      // [C]
-  int D, C, H, Hp, T, K, NP, NIN16;
+  int D, C, H, Hp, T, K, NP, NIN16, NIN4;
   long t_stride;          // floats per transform in img
-  int o_L0t, o_b0, o_L1t, o_L1m, o_b1, o_L2t, o_b2, o_L0m;
+  int o_L0t, o_b0, o_L1t, o_L1m, o_b1, o_L2t, o_b2, o_L0m, o_L2m;
   long P_t;               // logical parameters per transform
   int l_W0, l_b0, l_W1, l_b1, l_W2, l_b2;
   float B, cw, cd, logdet0;
   float th_scale[16], th_shift[16];
+  short tendk[16];        // = tend[] (kernel-argument copy: no dependent global load)
+  short tile_kend[24];    // per 16-row tile of the hidden rows: rows its highest type reads (tend of that type)
+  short tile_kbeg[24];    // ... first row of its lowest type
 };
 
-__device__ __forceinline__ float ar_reduce64(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-// eight consecutive floats at a wave-uniform address
-struct F8 { float v[8]; };
-__device__ __forceinline__ F8 ar_ld8(const float* __restrict__ p) {
-  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-  F8 r;
-  r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
-  return r;
-}
-
-// 16 x 16 block of a weight gradient: sum over the wave's 64 samples of A[o0 + i][s] * B[k0 + j][s] (v_mfma_f32_16x16x4_f32, sixteen
-// steps of four samples); lane l holds rows 4 (l >> 4) + r, column l & 15
+// 16 x 16 block of a weight gradient: sum over the wave's 64 samples of A[o0 + i][s] * B[k0 + j][s] (sixteen steps of four
+// samples); lane l holds rows 4 (l >> 4) + r, column l & 15
 __device__ __forceinline__ ar_f32x4 ar_dw16(const float* A, int o0, const float* Bm, int k0, int lane) {
   ar_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const float* pa = A + (o0 + (lane & 15)) * RS + (lane >> 4);
@@ -90,50 +82,105 @@ __device__ __forceinline__ ar_f32x4 ar_rowsum16(const float* A, int o0, int lane
   return acc;
 }
 
-// rows [p0, p0 + 8) of a dense layer: out = relu(b + sum_{k < kend} Wt[k][p] * in[k]); in / out: lane-strided LDS rows
-__device__ __forceinline__ void ar_layer8(const float* __restrict__ wt, int ldo, const float* __restrict__ bias, int p0, int kend,
-                                          const float* in, float* out, int lane) {
-  F8 acc = ar_ld8(bias + p0);
-#pragma unroll 4
-  for (int k = 0; k < kend; ++k) {
-    const float a = in[k * RS + lane];
-    const F8 w = ar_ld8(wt + (size_t)k * ldo + p0);
+// NTL x sixteen output rows [p0, p0 + 16 NTL) of a product for the wave's 64 samples:
+//   out[p - oshift][s] = act(bias[p] (or the old value: ACC) + sum_{k in [kbeg, kend)} wt[k][p] * in[k][s])
+// wt: k-major image (row k, ldo floats per row); kbeg, kend multiples of four; rows p >= row_lim are not written.  Columns past
+// the image's row end (edge tiles) read the neighbouring floats of the same transform's image: finite, and never written.
+// The tiles of a call share every activation read; the weights come four k-steps at a time, the next four requested before the
+// products of the current ones are issued, and the bias (requested first) is only added at the end: what a call exposes is ONE
+// L2 round trip, not three.
+template <bool RELU, bool ACC, int NTL>
+__device__ __forceinline__ void ar_tiles(const float* __restrict__ wt, int ldo, const float* __restrict__ bias, int p0, int kbeg, int kend,
+                                         const float* in, float* out, int row_lim, int lane, int oshift = 0) {
+  const int i4 = 4 * (lane >> 4), j = lane & 15;
+  float* orow = out + (p0 - oshift + i4) * RS + j;
+  const float* wa = wt + (size_t)(lane >> 4) * ldo + p0 + j;
+  const float* pb = in + (lane >> 4) * RS + j;
+  constexpr int CH = 4;
+  float wq[CH][NTL];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc.v[j] += w.v[j] * a;
-  }
+  for (int c = 0; c < CH; ++c)
 #pragma unroll
-  for (int j = 0; j < 8; ++j) out[(p0 + j) * RS + lane] = fmaxf(acc.v[j], 0.f);
-}
-// the 24 parameter slots of dimension d from the last hidden layer (rows < kend)
-__device__ __forceinline__ void ar_head(const ArArgs& a, const float* __restrict__ tp, int d, int kend, const float* h2, int lane,
-                                        float (&q)[ARQ]) {
-  const int ldo = a.D * ARQ;
+    for (int tl = 0; tl < NTL; ++tl) wq[c][tl] = kbeg + 4 * c < kend ? wa[(size_t)(kbeg + 4 * c) * ldo + 16 * tl] : 0.f;
+  float4 bv[NTL];
 #pragma unroll
-  for (int jb = 0; jb < 3; ++jb) {
-    F8 acc = ar_ld8(tp + a.o_b2 + d * ARQ + jb * 8);
-#pragma unroll 4
-    for (int k = 0; k < kend; ++k) {
-      const float v = h2[k * RS + lane];
-      const F8 w = ar_ld8(tp + a.o_L2t + (size_t)k * ldo + d * ARQ + jb * 8);
+  for (int tl = 0; tl < NTL; ++tl) bv[tl] = bias ? *reinterpret_cast<const float4*>(bias + p0 + 16 * tl + i4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  ar_f32x4 acc[NTL][4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc.v[j] += w.v[j] * v;
+  for (int tl = 0; tl < NTL; ++tl)
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[tl][st][r] = (ACC && p0 + 16 * tl + i4 + r < row_lim) ? orow[(16 * tl + r) * RS + st * 16] : 0.f;
+  for (int k0 = kbeg; k0 < kend; k0 += 4 * CH) {
+    float wn[CH][NTL];
+    const int kn = k0 + 4 * CH;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int tl = 0; tl < NTL; ++tl) wn[c][tl] = kn + 4 * c < kend ? wa[(size_t)(kn + 4 * c) * ldo + 16 * tl] : 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (k0 + 4 * c < kend) {   // (wave-uniform)
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          const float bq = pb[(k0 + 4 * c) * RS + st * 16];
+#pragma unroll
+          for (int tl = 0; tl < NTL; ++tl) acc[tl][st] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[c][tl], bq, acc[tl][st], 0, 0, 0);
+        }
+      }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) q[jb * 8 + j] = acc.v[j];
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int tl = 0; tl < NTL; ++tl) wq[c][tl] = wn[c][tl];
+  }
+#pragma unroll
+  for (int tl = 0; tl < NTL; ++tl) {
+    const float bb[4] = {bv[tl].x, bv[tl].y, bv[tl].z, bv[tl].w};
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (p0 + 16 * tl + i4 + r < row_lim) {
+          const float v = acc[tl][st][r] + bb[r];
+          orow[(16 * tl + r) * RS + st * 16] = RELU ? fmaxf(v, 0.f) : v;
+        }
   }
 }
-// image slot (zuko order [K widths | K heights | K - 1 derivatives] -> slots [0, 8) | [8, 16) | [16, 23)) is fixed by the packer
+// rows [p_lo, p_hi) in pairs of tiles, a single one at the end; kend_of(p0, n): inputs the n tiles from p0 on read
+template <bool RELU, typename KE>
+__device__ __forceinline__ void ar_rows(const float* __restrict__ wt, int ldo, const float* __restrict__ bias, int p_lo, int p_hi, int kbeg,
+                                        KE kend_of, const float* in, float* out, int row_lim, int lane) {
+  int p0 = p_lo;
+  for (; p0 + 16 < p_hi; p0 += 32) ar_tiles<RELU, false, 2>(wt, ldo, bias, p0, kbeg, kend_of(p0, 2), in, out, row_lim, lane);
+  if (p0 < p_hi) ar_tiles<RELU, false, 1>(wt, ldo, bias, p0, kbeg, kend_of(p0, 1), in, out, row_lim, lane);
+}
 
-// both hidden layers of transform t from the inputs in E0 ([D + C] rows: u, context)
+// both hidden layers of a transform from the inputs in E0 (rows [0, NIN4): u, context, zeros)
 __device__ __forceinline__ void ar_hidden(const ArArgs& a, const float* __restrict__ tp, const float* E0, float* H1, float* H2, int lane) {
-  for (int p0 = 0; p0 < a.Hp; p0 += 8) ar_layer8(tp + a.o_L0t, a.Hp, tp + a.o_b0, p0, a.D + a.C, E0, H1, lane);
-  for (int p0 = 0; p0 < a.Hp; p0 += 8) ar_layer8(tp + a.o_L1t, a.Hp, tp + a.o_b1, p0, a.tend[a.ptype[p0 + 7]], H1, H2, lane);
+  __syncthreads();   // (E0 was written sample by sample)
+  ar_rows<true>(tp + a.o_L0t, a.Hp, tp + a.o_b0, 0, a.Hp, 0, [&](int, int) { return a.NIN4; }, E0, H1, a.Hp, lane);
+  __syncthreads();
+  ar_rows<true>(tp + a.o_L1t, a.Hp, tp + a.o_b1, 0, a.Hp, 0, [&](int p0, int n) { return (int)a.tile_kend[(p0 >> 4) + n - 1]; }, H1, H2, a.Hp, lane);
+  __syncthreads();
+}
+// the 24 parameter slots of dimension d from the last hidden layer (rows < kend) -> q (through the 32 rows of QB)
+__device__ __forceinline__ void ar_head(const ArArgs& a, const float* __restrict__ tp, int d, int kend, const float* H2, float* QB, int lane,
+                                        float (&q)[ARQ]) {
+  __syncthreads();   // (earlier readers of QB are done)
+  // rows d * ARQ + i of the head -> QB row i (two tiles: rows 24 .. 31 of the second are the next dimension's, not written)
+  ar_tiles<false, false, 2>(tp + a.o_L2t, a.D * ARQ, tp + a.o_b2, d * ARQ, 0, kend, H2, QB, d * ARQ + ARQ, lane, d * ARQ);
+  __syncthreads();
+#pragma unroll
+  for (int sl = 0; sl < ARQ; ++sl) q[sl] = QB[sl * RS + lane];
 }
 
 __device__ __forceinline__ void ar_load_inputs(const ArArgs& a, const float* __restrict__ theta, const float* __restrict__ x, long row,
                                                float* E0, int lane) {
   for (int d = 0; d < a.D; ++d) E0[d * RS + lane] = theta[row * a.D + d] * a.th_scale[d] + a.th_shift[d];
   for (int c = 0; c < a.C; ++c) E0[(a.D + c) * RS + lane] = (x[row * a.C + c] - a.xmean[c]) / a.xstd[c];
+  for (int r = a.D + a.C; r < a.NIN16; ++r) E0[r * RS + lane] = 0.f;   // (rows the k-steps of four run over)
 }
 
 __global__ __launch_bounds__(64) void k_ar_logprob(ArArgs a, const float* __restrict__ theta, const float* __restrict__ x, long B,
@@ -142,6 +189,7 @@ __global__ __launch_bounds__(64) void k_ar_logprob(ArArgs a, const float* __rest
   float* E0 = lds;
   float* H1 = E0 + a.NIN16 * RS;
   float* H2 = H1 + a.Hp * RS;
+  float* QB = H2 + a.Hp * RS;
   const int lane = threadIdx.x;
   const long b = (long)blockIdx.x * 64 + lane;
   const long row = b < B ? b : B - 1;
@@ -153,7 +201,7 @@ __global__ __launch_bounds__(64) void k_ar_logprob(ArArgs a, const float* __rest
     ar_hidden(a, tp, E0, H1, H2, lane);
     for (int d = 0; d < a.D; ++d) {
       float q[ARQ];
-      ar_head(a, tp, d, a.tend[a.ord[t * a.D + d]], H2, lane, q);
+      ar_head(a, tp, d, (int)a.tendk[a.ord[t * a.D + d]], H2, QB, lane, q);
       float v, lad;
       ZS::fwd(sc, q, E0[d * RS + lane], v, lad);
       E0[d * RS + lane] = v;   // (every parameter of this transform has been taken from the inputs already)
@@ -167,17 +215,19 @@ __global__ __launch_bounds__(64) void k_ar_logprob(ArArgs a, const float* __rest
 
 // the inverse of transform t in ONE sweep over the order values: V = the transform's outputs, E0[0 .. D) receives its inputs
 __device__ __forceinline__ float ar_inverse_transform(const ArArgs& a, const ZSplC& sc, int t, float* E0, const float* V, float* H1,
-                                                      float* H2, int lane) {
+                                                      float* H2, float* QB, int lane) {
   const float* tp = a.img + (size_t)t * a.t_stride;
   float ld = 0.f;
   for (int d = 0; d < a.D; ++d) E0[d * RS + lane] = 0.f;   // (not yet known: masked weights are zeros, the values must be finite)
   for (int r = 0; r < a.D; ++r) {
-    const int p_lo = r ? a.tend[r - 1] : 0, p_hi = a.tend[r];
-    for (int p0 = p_lo; p0 < p_hi; p0 += 8) ar_layer8(tp + a.o_L0t, a.Hp, tp + a.o_b0, p0, a.D + a.C, E0, H1, lane);
-    for (int p0 = p_lo; p0 < p_hi; p0 += 8) ar_layer8(tp + a.o_L1t, a.Hp, tp + a.o_b1, p0, p_hi, H1, H2, lane);
+    const int p_lo = r ? (int)a.tendk[r - 1] : 0, p_hi = (int)a.tendk[r];
+    __syncthreads();   // (E0 row of the dimension inverted last)
+    ar_rows<true>(tp + a.o_L0t, a.Hp, tp + a.o_b0, p_lo, p_hi, 0, [&](int, int) { return a.NIN4; }, E0, H1, p_hi, lane);
+    __syncthreads();
+    ar_rows<true>(tp + a.o_L1t, a.Hp, tp + a.o_b1, p_lo, p_hi, 0, [&](int, int) { return p_hi; }, H1, H2, p_hi, lane);
     const int d = a.dimof[t * a.D + r];
     float q[ARQ];
-    ar_head(a, tp, d, p_hi, H2, lane, q);
+    ar_head(a, tp, d, p_hi, H2, QB, lane, q);
     float w, lad;
     ZS::inv(sc, q, V[d * RS + lane], w, lad);
     E0[d * RS + lane] = w;
@@ -192,16 +242,18 @@ __global__ __launch_bounds__(64) void k_ar_inverse(ArArgs a, const float* __rest
   float* E0 = lds;
   float* H1 = E0 + a.NIN16 * RS;
   float* H2 = H1 + a.Hp * RS;
-  float* V = H2 + a.Hp * RS;
+  float* QB = H2 + a.Hp * RS;
+  float* V = QB + 32 * RS;
   const int lane = threadIdx.x;
   const long b = (long)blockIdx.x * 64 + lane;
   const long row = b < B ? b : B - 1;
   for (int c = 0; c < a.C; ++c) E0[(a.D + c) * RS + lane] = (x[row * a.C + c] - a.xmean[c]) / a.xstd[c];
+  for (int r = a.D + a.C; r < a.NIN16; ++r) E0[r * RS + lane] = 0.f;
   for (int d = 0; d < a.D; ++d) V[d * RS + lane] = z[row * a.D + d];
   const ZSplC sc = {a.K, a.B, a.cw, a.cd};
   float ld = -a.logdet0;
   for (int t = a.T - 1; t >= 0; --t) {
-    ld += ar_inverse_transform(a, sc, t, E0, V, H1, H2, lane);
+    ld += ar_inverse_transform(a, sc, t, E0, V, H1, H2, QB, lane);
     for (int d = 0; d < a.D; ++d) V[d * RS + lane] = E0[d * RS + lane];
   }
   if (b < B) {
@@ -221,11 +273,13 @@ __global__ __launch_bounds__(64) void k_ar_sample(ArArgs a, const float* __restr
   float* E0 = lds;
   float* H1 = E0 + a.NIN16 * RS;
   float* H2 = H1 + a.Hp * RS;
-  float* V = H2 + a.Hp * RS;
+  float* QB = H2 + a.Hp * RS;
+  float* V = QB + 32 * RS;
   __shared__ unsigned long long r_slot[64];
   __shared__ uint32_t r_att[64];
   const int lane = threadIdx.x;
   const ZSplC sc = {a.K, a.B, a.cw, a.cd};
+  for (int r = a.D + a.C; r < a.NIN16; ++r) E0[r * RS + lane] = 0.f;
   int n_retry = 0;
   for (;;) {
     const int take = 64 - n_retry;
@@ -254,7 +308,7 @@ __global__ __launch_bounds__(64) void k_ar_sample(ArArgs a, const float* __restr
         if (d0 + j < a.D) V[(d0 + j) * RS + lane] = z4[j];
     }
     for (int t = a.T - 1; t >= 0; --t) {
-      (void)ar_inverse_transform(a, sc, t, E0, V, H1, H2, lane);
+      (void)ar_inverse_transform(a, sc, t, E0, V, H1, H2, QB, lane);
       for (int d = 0; d < a.D; ++d) V[d * RS + lane] = E0[d * RS + lane];
     }
     bool ok = active;
@@ -297,13 +351,13 @@ __global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restri
                                                   float* __restrict__ loss, double* __restrict__ loss_sum, float* __restrict__ grad,
                                                   float* __restrict__ ustash) {
   extern __shared__ float lds[];
-  float* E0 = lds;                       // [D + C]: u, context
-  float* H1 = E0 + a.NIN16 * RS;     // [Hp]
+  float* E0 = lds;                       // [NIN16]: u, context, zeros
+  float* H1 = E0 + a.NIN16 * RS;         // [Hp]
   float* H2 = H1 + a.Hp * RS;            // [Hp]
-  float* DH = H2 + a.Hp * RS;            // [Hp] deltas
+  float* QB = H2 + a.Hp * RS;            // [32] head outputs of ONE dimension, then their deltas, then the input deltas
+  float* DH = QB + 32 * RS;              // [Hp] deltas
   float* GG = DH + a.Hp * RS;            // [D] dL/du at the transform's output
   float* DV = GG + a.D * RS;             // [D] what reaches the transform's input through the splines
-  float* DQ = DV + a.D * RS;             // [32] spline-parameter deltas of ONE dimension (rows >= 23: never read back)
   const int lane = threadIdx.x;
   const long b = (long)blockIdx.x * 64 + lane;
   const bool valid = b < B;
@@ -319,7 +373,7 @@ __global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restri
     ar_hidden(a, tp, E0, H1, H2, lane);
     for (int d = 0; d < a.D; ++d) {
       float q[ARQ];
-      ar_head(a, tp, d, a.tend[a.ord[t * a.D + d]], H2, lane, q);
+      ar_head(a, tp, d, (int)a.tendk[a.ord[t * a.D + d]], H2, QB, lane, q);
       float v, lad;
       ZS::fwd(sc, q, E0[d * RS + lane], v, lad);
       E0[d * RS + lane] = v;
@@ -331,7 +385,9 @@ __global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restri
   const float nll = 0.5f * ss + 0.5f * (float)a.D * 1.8378770664093453f - ld;
   if (loss && valid) loss[b] = nll;
   if (loss_sum) {
-    const float tsum = ar_reduce64(valid ? nll : 0.f);
+    float tsum = valid ? nll : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tsum += __shfl_xor(tsum, o, 64);
     // values on a 2^-20 grid add exactly in double: the sum does not depend on the order of the atomics
     if (lane == 0) atomicAdd(loss_sum, (double)rintf(tsum * 1048576.0f) * (1.0 / 1048576.0));
   }
@@ -344,35 +400,23 @@ __global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restri
     for (int d = 0; d < a.D; ++d) E0[d * RS + lane] = ust[t * a.D + d];
     ar_hidden(a, tp, E0, H1, H2, lane);
     for (int p = 0; p < a.Hp; ++p) DH[p * RS + lane] = 0.f;
-    // ---- head + splines
+    // ---- head + splines, dimension by dimension
     for (int d = 0; d < a.D; ++d) {
-      const int kend = a.tend[a.ord[t * a.D + d]];
+      const int kend = (int)a.tendk[a.ord[t * a.D + d]];
       float q[ARQ], dq[ARQ];
-      ar_head(a, tp, d, kend, H2, lane, q);
+      ar_head(a, tp, d, kend, H2, QB, lane, q);
       float dv;
       ZS::bwd(sc, q, E0[d * RS + lane], GG[d * RS + lane], -wb, dv, dq);
       DV[d * RS + lane] = dv;
       dq[ARQ - 1] = 0.f;
-      const int ldo = a.D * ARQ;
-#pragma unroll 2
-      for (int k = 0; k < kend; ++k) {   // delta of the last hidden layer
-        float acc = 0.f;
+      __syncthreads();   // (every lane has taken its q)
 #pragma unroll
-        for (int jb = 0; jb < 3; ++jb) {
-          const F8 wv = ar_ld8(tp + a.o_L2t + (size_t)k * ldo + d * ARQ + jb * 8);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) acc += wv.v[j] * dq[jb * 8 + j];
-        }
-        DH[k * RS + lane] += acc;
-      }
-      // weight gradients of this dimension's head rows: (24 slots x 64 samples) x (64 samples x kend hidden rows) on the MFMA
-      __syncthreads();   // (the previous dimension's blocks have read DQ)
-#pragma unroll
-      for (int sl = 0; sl < ARQ; ++sl) DQ[sl * RS + lane] = dq[sl];
+      for (int sl = 0; sl < ARQ; ++sl) QB[sl * RS + lane] = dq[sl];
       __syncthreads();
+      // weight gradients of this dimension's head rows: (24 slots x 64 samples) x (64 samples x kend hidden rows)
       for (int it = 0; it < 2; ++it) {
         for (int k0 = 0; k0 < kend; k0 += 16) {
-          const ar_f32x4 g4 = ar_dw16(DQ, it * 16, H2, k0, lane);
+          const ar_f32x4 g4 = ar_dw16(QB, it * 16, H2, k0, lane);
           const int k = k0 + (lane & 15);
           const int kl = k < kend ? a.perm[k] : -1;
 #pragma unroll
@@ -382,7 +426,7 @@ __global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restri
               unsafeAtomicAdd(gt + a.l_W2 + (size_t)(d * a.NP + fam * a.K + kk) * a.H + kl, g4[r]);
           }
         }
-        const ar_f32x4 b4 = ar_rowsum16(DQ, it * 16, lane);
+        const ar_f32x4 b4 = ar_rowsum16(QB, it * 16, lane);
         if ((lane & 15) == 0) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -391,12 +435,20 @@ __global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restri
           }
         }
       }
+      // delta of the last hidden layer: DH[k] += sum_slots W2[(d, slot)][k] dq[slot]   (k-major image of the head's transpose)
+      {
+        const float* wm = tp + a.o_L2m + (size_t)d * ARQ * a.Hp;
+        int p0 = 0;
+        for (; p0 + 16 < kend; p0 += 32) ar_tiles<false, true, 2>(wm, a.Hp, nullptr, p0, 0, ARQ, QB, DH, a.Hp, lane);
+        if (p0 < kend) ar_tiles<false, true, 1>(wm, a.Hp, nullptr, p0, 0, ARQ, QB, DH, a.Hp, lane);
+      }
     }
     // ---- second hidden layer: delta through the ReLU, weight gradients, delta of the first hidden layer (into H2's rows)
+    __syncthreads();
     for (int o = 0; o < a.Hp; ++o) DH[o * RS + lane] = H2[o * RS + lane] > 0.f ? DH[o * RS + lane] : 0.f;
     __syncthreads();
     for (int o0 = 0; o0 < a.Hp; o0 += 16) {
-      const int kend = a.tend[a.ptype[o0 + 15]];
+      const int kend = (int)a.tile_kend[o0 >> 4];
       int ol[4], oty[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) { ol[r] = a.perm[o0 + 4 * (lane >> 4) + r]; oty[r] = a.ptype[o0 + 4 * (lane >> 4) + r]; }
@@ -415,20 +467,13 @@ __global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restri
       }
     }
     __syncthreads();   // (H2 is overwritten next)
-    for (int k0b = 0; k0b < a.Hp; k0b += 8) {   // delta_h1[k] = sum_o W1[o][k] delta_h2[o]  (row-major masked image)
-      F8 acc;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc.v[j] = 0.f;
-#pragma unroll 2
-      for (int o = 0; o < a.Hp; ++o) {
-        const float dv = DH[o * RS + lane];
-        const F8 wv = ar_ld8(tp + a.o_L1m + (size_t)o * a.Hp + k0b);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc.v[j] += wv.v[j] * dv;
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) H2[(k0b + j) * RS + lane] = H1[(k0b + j) * RS + lane] > 0.f ? acc.v[j] : 0.f;
+    {   // delta_h1[k] = sum_{o: type(o) >= type(k)} W1[o][k] delta_h2[o]
+      int p0 = 0;
+      for (; p0 + 16 < a.Hp; p0 += 32) ar_tiles<false, false, 2>(tp + a.o_L1m, a.Hp, nullptr, p0, (int)a.tile_kbeg[p0 >> 4], a.Hp, DH, H2, a.Hp, lane);
+      if (p0 < a.Hp) ar_tiles<false, false, 1>(tp + a.o_L1m, a.Hp, nullptr, p0, (int)a.tile_kbeg[p0 >> 4], a.Hp, DH, H2, a.Hp, lane);
     }
+    __syncthreads();
+    for (int k = 0; k < a.Hp; ++k) H2[k * RS + lane] = H1[k * RS + lane] > 0.f ? H2[k * RS + lane] : 0.f;
     __syncthreads();
     // ---- first hidden layer: weight gradients, and what reaches the inputs
     for (int o0 = 0; o0 < a.Hp; o0 += 16) {
@@ -450,20 +495,10 @@ __global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restri
           if (ol[r] >= 0) unsafeAtomicAdd(gt + a.l_b0 + ol[r], b4[r]);
       }
     }
-    float din[16];
-#pragma unroll
-    for (int d = 0; d < 16; ++d) din[d] = 0.f;
-#pragma unroll 2
-    for (int o = 0; o < a.Hp; ++o) {
-      const float dv = H2[o * RS + lane];
-      const F8 w0 = ar_ld8(tp + a.o_L0m + (size_t)o * 16), w1 = ar_ld8(tp + a.o_L0m + (size_t)o * 16 + 8);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { din[j] += w0.v[j] * dv; din[8 + j] += w1.v[j] * dv; }
-    }
-    __syncthreads();   // (the blocks above have read E0; the next transform overwrites it)
-#pragma unroll
-    for (int d = 0; d < 16; ++d)
-      if (d < a.D) GG[d * RS + lane] = DV[d * RS + lane] + din[d];
+    // d input[i] = sum_o W0[o][i] delta_h1[o], i < D  (L0m: [o][16])
+    ar_tiles<false, false, 1>(tp + a.o_L0m, 16, nullptr, 0, 0, a.Hp, H2, QB, 16, lane);
+    __syncthreads();
+    for (int d = 0; d < a.D; ++d) GG[d * RS + lane] = DV[d * RS + lane] + QB[d * RS + lane];
   }
 }
 
@@ -480,12 +515,18 @@ ArArgs args_of(const SfNsfAr& n) {
   ArArgs a;
   a.img = n.d_img; a.perm = n.d_perm; a.ptype = n.d_ptype; a.tend = n.d_tend; a.ord = n.d_ord; a.dimof = n.d_dimof;
   a.xmean = n.d_xmean; a.xstd = n.d_xstd;
-  a.D = n.D; a.C = n.C; a.H = n.H; a.Hp = n.Hp; a.T = n.T; a.K = n.K; a.NP = n.NP; a.NIN16 = (n.D + n.C + 15) / 16 * 16;
+  a.D = n.D; a.C = n.C; a.H = n.H; a.Hp = n.Hp; a.T = n.T; a.K = n.K; a.NP = n.NP; a.NIN16 = (n.D + n.C + 15) / 16 * 16; a.NIN4 = (n.D + n.C + 3) / 4 * 4;
   a.t_stride = n.t_stride;
-  a.o_L0t = n.o_L0t; a.o_b0 = n.o_b0; a.o_L1t = n.o_L1t; a.o_L1m = n.o_L1m; a.o_b1 = n.o_b1; a.o_L2t = n.o_L2t; a.o_b2 = n.o_b2; a.o_L0m = n.o_L0m;
+  a.o_L0t = n.o_L0t; a.o_b0 = n.o_b0; a.o_L1t = n.o_L1t; a.o_L1m = n.o_L1m; a.o_b1 = n.o_b1; a.o_L2t = n.o_L2t; a.o_b2 = n.o_b2; a.o_L0m = n.o_L0m; a.o_L2m = n.o_L2m;
   a.P_t = n.P_t; a.l_W0 = n.l_W0; a.l_b0 = n.l_b0; a.l_W1 = n.l_W1; a.l_b1 = n.l_b1; a.l_W2 = n.l_W2; a.l_b2 = n.l_b2;
   a.B = n.bound; a.cw = n.cw; a.cd = n.cd; a.logdet0 = n.logdet0;
-  for (int d = 0; d < 16; ++d) { a.th_scale[d] = n.th_scale[d]; a.th_shift[d] = n.th_shift[d]; }
+  for (int d = 0; d < 16; ++d) { a.th_scale[d] = n.th_scale[d]; a.th_shift[d] = n.th_shift[d]; a.tendk[d] = d < n.D ? (short)n.tend[d] : (short)n.Hp; }
+  for (int i = 0; i < 24; ++i) { a.tile_kend[i] = 0; a.tile_kbeg[i] = 0; }
+  for (int p0 = 0; p0 < n.Hp; p0 += 16) {
+    const int ta = n.ptype[p0], tb = n.ptype[p0 + 15];
+    a.tile_kend[p0 >> 4] = (short)n.tend[tb];
+    a.tile_kbeg[p0 >> 4] = (short)(ta ? n.tend[ta - 1] : 0);
+  }
   return a;
 }
 
@@ -541,7 +582,7 @@ int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err) {
   n->n_params = (int64_t)T * n->P_t;
   // images of a transform (offsets in floats, every block a multiple of 8)
   long o = 0;
-  n->o_L0t = (int)o; o += (long)nin * Hp;
+  n->o_L0t = (int)o; o += (long)((nin + 3) / 4 * 4) * Hp;   // (k-steps of four: zero rows behind the last input)
   n->o_b0 = (int)o; o += Hp;
   n->o_L1t = (int)o; o += (long)Hp * Hp;
   n->o_L1m = (int)o; o += (long)Hp * Hp;
@@ -549,6 +590,7 @@ int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err) {
   n->o_L2t = (int)o; o += (long)Hp * D * ARQ;
   n->o_b2 = (int)o; o += (long)D * ARQ;
   n->o_L0m = (int)o; o += (long)Hp * 16;
+  n->o_L2m = (int)o; o += (long)D * ARQ * Hp;   // the head transposed: row (d, slot), column k
   n->t_stride = (o + 63) / 64 * 64;
   if (sf_nsfar_lds_bytes(*n, 3) > (size_t)160 * 1024 - 1024) {
     err = "autoregressive NSF: (3 D + C + 3 Hp + 32) x 260 bytes of LDS per wave exceed the 160 KB of a CU (Hp = H with every type padded to a multiple of 8, in all a multiple of 16)";
@@ -593,6 +635,7 @@ int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err) {
             const int hk = n->perm[k];
             if (hk < 0 || n->ptype[k] > ord[dd]) continue;
             s[n->o_L2t + (long)k * D * ARQ + slot] = (int32_t)(base + n->l_W2 + (long)lrow * H + hk);
+            s[n->o_L2m + (long)slot * Hp + k] = (int32_t)(base + n->l_W2 + (long)lrow * H + hk);
           }
         }
   }
@@ -631,8 +674,8 @@ static int ar_ensure(SfNsfAr* n, std::string& err) {
 }
 
 size_t sf_nsfar_lds_bytes(const SfNsfAr& n, int hidden_buffers) {
-  // inputs (padded to whole 16-row tiles), hidden buffers, V or GG + DV, and the training kernel's 32 DQ rows
-  return (size_t)((n.D + n.C + 15) / 16 * 16 + hidden_buffers * n.Hp + 2 * n.D + (hidden_buffers == 3 ? 32 : 0)) * RS * sizeof(float);
+  // inputs (padded to whole 16-row tiles), hidden buffers, the 32 rows of one dimension's head, V or GG + DV
+  return (size_t)((n.D + n.C + 15) / 16 * 16 + hidden_buffers * n.Hp + 32 + 2 * n.D) * RS * sizeof(float);
 }
 
 int sf_nsfar_pack(SfNsfAr* n, const float* flat, hipStream_t st, std::string& err) {
