@@ -688,10 +688,14 @@ __global__ __launch_bounds__(64 * (NT > 4 ? NT : 4), (NT > 4 ? 1 : 2)) void k_ns
       n_barrier();
       SF_NC(42 + 10 * (T - 1 - t));
       // generic job runner: blocks n = wave, wave + NW, ... of a list, two at a time
+      // (atomic modes: the i-th workgroup of an XCD starts the list at block i -- the workgroups of an XCD run the same phase at about the same
+      //  time, and in list order all of them would add to the SAME gradient block, i.e. the same few L2 channels, at once)
       auto run_jobs = [&](int total, auto mk) {
+        const int rot = mode.mode >= 2 ? (int)((blockIdx.x >> 3) % (unsigned)total) : 0;   // (blockIdx & 7 = the XCD: its workgroups share a replica)
+        auto at = [&](int n) { const int m = n + rot; return m >= total ? m - total : m; };
         for (int n = wave; n < total; n += 2 * NW) {
           const bool two = n + NW < total;
-          const NJob A = mk(n), B = mk(two ? n + NW : n);
+          const NJob A = mk(at(n)), B = mk(at(two ? n + NW : n));
           n_dw_jobs(A, B, two, mode, lane);
         }
       };
