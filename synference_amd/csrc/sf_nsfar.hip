@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdio>
 #include <string>
 #include <vector>
 
@@ -61,25 +62,53 @@ struct ArArgs {
   short tendk[16];        // = tend[] (kernel-argument copy: no dependent global load)
   short tile_kend[24];    // per 16-row tile of the hidden rows: rows its highest type reads (tend of that type)
   short tile_kbeg[24];    // ... first row of its lowest type
+#ifdef SF_AR_TRACE
+  unsigned long long* trace;   // developer build: cycle stamps of block 0 (k_ar_logprob)
+#endif
 };
+#ifdef SF_AR_TRACE
+#define AR_TS(slot) do { if (a.trace && blockIdx.x == 0 && threadIdx.x == 0 && (slot) < 256) a.trace[slot] = __builtin_readcyclecounter(); } while (0)
+#else
+#define AR_TS(slot) do { } while (0)
+#endif
 
 // 16 x 16 block of a weight gradient: sum over the wave's 64 samples of A[o0 + i][s] * B[k0 + j][s] (sixteen steps of four
 // samples); lane l holds rows 4 (l >> 4) + r, column l & 15
 __device__ __forceinline__ ar_f32x4 ar_dw16(const float* A, int o0, const float* Bm, int k0, int lane) {
-  ar_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const float* pa = A + (o0 + (lane & 15)) * RS + (lane >> 4);
   const float* pb = Bm + (k0 + (lane & 15)) * RS + (lane >> 4);
+  // all 32 operands first, then two interleaved accumulator chains (a dependent 16x16x4 MFMA waits 40 cycles, an independent
+  // one issues after 32): no LDS round trip and no dependent wait between the products
+  float av[16], bw[16];
 #pragma unroll
-  for (int s0 = 0; s0 < 64; s0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s0], pb[s0], acc, 0, 0, 0);
-  return acc;
+  for (int i = 0; i < 16; ++i) { av[i] = pa[4 * i]; bw[i] = pb[4 * i]; }
+  __builtin_amdgcn_sched_barrier(0);
+  ar_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 16; i += 2) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bw[i], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i + 1], bw[i + 1], acc1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc0[r] += acc1[r];
+  return acc0;
 }
 // the row sums of the same A rows (B = ones): every column holds them
 __device__ __forceinline__ ar_f32x4 ar_rowsum16(const float* A, int o0, int lane) {
-  ar_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const float* pa = A + (o0 + (lane & 15)) * RS + (lane >> 4);
+  float av[16];
 #pragma unroll
-  for (int s0 = 0; s0 < 64; s0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s0], 1.0f, acc, 0, 0, 0);
-  return acc;
+  for (int i = 0; i < 16; ++i) av[i] = pa[4 * i];
+  __builtin_amdgcn_sched_barrier(0);
+  ar_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 16; i += 2) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], 1.0f, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i + 1], 1.0f, acc1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc0[r] += acc1[r];
+  return acc0;
 }
 
 // NTL x sixteen output rows [p0, p0 + 16 NTL) of a product for the wave's 64 samples:
@@ -96,12 +125,18 @@ __device__ __forceinline__ void ar_tiles(const float* __restrict__ wt, int ldo, 
   float* orow = out + (p0 - oshift + i4) * RS + j;
   const float* wa = wt + (size_t)(lane >> 4) * ldo + p0 + j;
   const float* pb = in + (lane >> 4) * RS + j;
+  // Four k-steps (sixteen input rows) per round: the next round's weights are requested first -- UNCONDITIONALLY, the row index
+  // clamped to the last valid one, so that the compiler can count them in vmcnt and does not drain them where this round's
+  // weights are waited for -- then all sixteen activation reads of the round, then the products (skipped past kend).
   constexpr int CH = 4;
+  const int klast = kend - 4;
   float wq[CH][NTL];
 #pragma unroll
-  for (int c = 0; c < CH; ++c)
+  for (int c = 0; c < CH; ++c) {
+    const int kc = kbeg + 4 * c < klast ? kbeg + 4 * c : klast;
 #pragma unroll
-    for (int tl = 0; tl < NTL; ++tl) wq[c][tl] = kbeg + 4 * c < kend ? wa[(size_t)(kbeg + 4 * c) * ldo + 16 * tl] : 0.f;
+    for (int tl = 0; tl < NTL; ++tl) wq[c][tl] = wa[(size_t)kc * ldo + 16 * tl];
+  }
   float4 bv[NTL];
 #pragma unroll
   for (int tl = 0; tl < NTL; ++tl) bv[tl] = bias ? *reinterpret_cast<const float4*>(bias + p0 + 16 * tl + i4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -114,20 +149,26 @@ __device__ __forceinline__ void ar_tiles(const float* __restrict__ wt, int ldo, 
       for (int r = 0; r < 4; ++r) acc[tl][st][r] = (ACC && p0 + 16 * tl + i4 + r < row_lim) ? orow[(16 * tl + r) * RS + st * 16] : 0.f;
   for (int k0 = kbeg; k0 < kend; k0 += 4 * CH) {
     float wn[CH][NTL];
-    const int kn = k0 + 4 * CH;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int kn = k0 + 4 * CH + 4 * c;
+      const int kc = kn < klast ? kn : klast;
+#pragma unroll
+      for (int tl = 0; tl < NTL; ++tl) wn[c][tl] = wa[(size_t)kc * ldo + 16 * tl];
+    }
+    float bq[CH][4];
 #pragma unroll
     for (int c = 0; c < CH; ++c)
 #pragma unroll
-      for (int tl = 0; tl < NTL; ++tl) wn[c][tl] = kn + 4 * c < kend ? wa[(size_t)(kn + 4 * c) * ldo + 16 * tl] : 0.f;
+      for (int st = 0; st < 4; ++st) bq[c][st] = pb[(k0 + 4 * c) * RS + st * 16];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       if (k0 + 4 * c < kend) {   // (wave-uniform)
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
-          const float bq = pb[(k0 + 4 * c) * RS + st * 16];
+        for (int st = 0; st < 4; ++st)
 #pragma unroll
-          for (int tl = 0; tl < NTL; ++tl) acc[tl][st] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[c][tl], bq, acc[tl][st], 0, 0, 0);
-        }
+          for (int tl = 0; tl < NTL; ++tl) acc[tl][st] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[c][tl], bq[c][st], acc[tl][st], 0, 0, 0);
       }
     }
 #pragma unroll
@@ -148,6 +189,25 @@ __device__ __forceinline__ void ar_tiles(const float* __restrict__ wt, int ldo, 
         }
   }
 }
+// Warm the vector L1 for a tile pass that comes later: lane l requests the first floats of row kbeg + l (+ 64 ...) of the image
+// at column p0 (and p0 + 16): one load instruction per 64 rows touches the 64-byte segments the pass will read.  The values
+// are only "used" by ar_keep, placed behind the work that is to cover the L2 round trip.
+struct ArPre { float v[6]; };
+__device__ __forceinline__ void ar_touch(ArPre& P, int slot, const float* __restrict__ wt, int ldo, int p0, int kbeg, int kend, int lane) {
+  const int k = kbeg + lane;
+  P.v[slot] = k < kend ? wt[(size_t)k * ldo + p0] : 0.f;
+  P.v[slot + 1] = k < kend ? wt[(size_t)k * ldo + p0 + 16] : 0.f;
+  if (kbeg + 64 < kend) {
+    const int k2 = k + 64;
+    P.v[slot] += k2 < kend ? wt[(size_t)k2 * ldo + p0] : 0.f;
+    P.v[slot + 1] += k2 < kend ? wt[(size_t)k2 * ldo + p0 + 16] : 0.f;
+  }
+}
+__device__ __forceinline__ void ar_keep(const ArPre& P) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) asm volatile("" ::"v"(P.v[i]));
+}
+
 // rows [p_lo, p_hi) in pairs of tiles, a single one at the end; kend_of(p0, n): inputs the n tiles from p0 on read
 template <bool RELU, typename KE>
 __device__ __forceinline__ void ar_rows(const float* __restrict__ wt, int ldo, const float* __restrict__ bias, int p_lo, int p_hi, int kbeg,
@@ -155,6 +215,18 @@ __device__ __forceinline__ void ar_rows(const float* __restrict__ wt, int ldo, c
   int p0 = p_lo;
   for (; p0 + 16 < p_hi; p0 += 32) ar_tiles<RELU, false, 2>(wt, ldo, bias, p0, kbeg, kend_of(p0, 2), in, out, row_lim, lane);
   if (p0 < p_hi) ar_tiles<RELU, false, 1>(wt, ldo, bias, p0, kbeg, kend_of(p0, 1), in, out, row_lim, lane);
+}
+
+// x[r][lane] <- x[r][lane] where gate[r][lane] > 0, rows [0, n) (n a multiple of 8): eight rows per round, every read of a round
+// before its writes (row by row, each write would wait for the LDS round trip of its own reads)
+__device__ __forceinline__ void ar_mask_rows(float* x, const float* gate, int n, int lane) {
+  for (int r0 = 0; r0 < n; r0 += 8) {
+    float xv[8], gv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { xv[i] = x[(r0 + i) * RS + lane]; gv[i] = gate[(r0 + i) * RS + lane]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[(r0 + i) * RS + lane] = gv[i] > 0.f ? xv[i] : 0.f;
+  }
 }
 
 // both hidden layers of a transform from the inputs in E0 (rows [0, NIN4): u, context, zeros)
@@ -193,24 +265,30 @@ __global__ __launch_bounds__(64) void k_ar_logprob(ArArgs a, const float* __rest
   const int lane = threadIdx.x;
   const long b = (long)blockIdx.x * 64 + lane;
   const long row = b < B ? b : B - 1;
+  AR_TS(0);
   ar_load_inputs(a, theta, x, row, E0, lane);
   const ZSplC sc = {a.K, a.B, a.cw, a.cd};
   float ld = a.logdet0;
   for (int t = 0; t < a.T; ++t) {
     const float* tp = a.img + (size_t)t * a.t_stride;
+    AR_TS(1 + t * 40);
     ar_hidden(a, tp, E0, H1, H2, lane);
+    AR_TS(2 + t * 40);
     for (int d = 0; d < a.D; ++d) {
       float q[ARQ];
       ar_head(a, tp, d, (int)a.tendk[a.ord[t * a.D + d]], H2, QB, lane, q);
+      AR_TS(3 + t * 40 + 2 * d);
       float v, lad;
       ZS::fwd(sc, q, E0[d * RS + lane], v, lad);
       E0[d * RS + lane] = v;   // (every parameter of this transform has been taken from the inputs already)
       ld += lad;
+      AR_TS(4 + t * 40 + 2 * d);
     }
   }
   float ss = 0.f;
   for (int d = 0; d < a.D; ++d) ss += E0[d * RS + lane] * E0[d * RS + lane];
   if (b < B) out[b] = -0.5f * ss - 0.5f * (float)a.D * 1.8378770664093453f + ld;
+  AR_TS(250);
 }
 
 // the inverse of transform t in ONE sweep over the order values: V = the transform's outputs, E0[0 .. D) receives its inputs
@@ -226,12 +304,25 @@ __device__ __forceinline__ float ar_inverse_transform(const ArArgs& a, const ZSp
     __syncthreads();
     ar_rows<true>(tp + a.o_L1t, a.Hp, tp + a.o_b1, p_lo, p_hi, 0, [&](int, int) { return p_hi; }, H1, H2, p_hi, lane);
     const int d = a.dimof[t * a.D + r];
+    // the step after this one (the next order value, or the first of the transform below): which rows, which dimension
+    const bool more = r + 1 < a.D || t > 0;
+    const int tn = r + 1 < a.D ? t : t - 1, rn = r + 1 < a.D ? r + 1 : 0;
+    const int dn = more ? a.dimof[tn * a.D + rn] : 0;
     float q[ARQ];
     ar_head(a, tp, d, p_hi, H2, QB, lane, q);
+    ArPre pre = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
+    if (more) {   // its weights are asked for now, under this step's spline
+      const float* tq = a.img + (size_t)tn * a.t_stride;
+      const int q_lo = rn ? (int)a.tendk[rn - 1] : 0, q_hi = (int)a.tendk[rn];
+      ar_touch(pre, 0, tq + a.o_L0t, a.Hp, q_lo, 0, a.NIN4, lane);
+      ar_touch(pre, 2, tq + a.o_L1t, a.Hp, q_lo, 0, q_hi, lane);
+      ar_touch(pre, 4, tq + a.o_L2t, a.D * ARQ, dn * ARQ, 0, q_hi, lane);
+    }
     float w, lad;
     ZS::inv(sc, q, V[d * RS + lane], w, lad);
     E0[d * RS + lane] = w;
     ld += lad;
+    ar_keep(pre);
   }
   return ld;
 }
@@ -358,11 +449,15 @@ __global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restri
   float* DH = QB + 32 * RS;              // [Hp] deltas
   float* GG = DH + a.Hp * RS;            // [D] dL/du at the transform's output
   float* DV = GG + a.D * RS;             // [D] what reaches the transform's input through the splines
+  int* PERM = reinterpret_cast<int*>(DV + a.D * RS);   // [Hp] perm, [Hp] ptype: read per weight-gradient block
+  int* PTYP = PERM + a.Hp;
   const int lane = threadIdx.x;
+  for (int i = lane; i < a.Hp; i += 64) { PERM[i] = a.perm[i]; PTYP[i] = a.ptype[i]; }
   const long b = (long)blockIdx.x * 64 + lane;
   const bool valid = b < B;
   const long bb = valid ? b : B - 1;
   const long row = idx ? (long)idx[bb] : bb;
+  AR_TS(0);
   ar_load_inputs(a, theta, x, row, E0, lane);
   const ZSplC sc = {a.K, a.B, a.cw, a.cd};
   float* ust = ustash + (size_t)bb * a.T * a.D;   // (an invalid lane shares the last row's stash: same values)
@@ -393,20 +488,26 @@ __global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restri
   }
   const float wb = valid ? (wts ? w * wts[b] : w) : 0.f;
   for (int d = 0; d < a.D; ++d) GG[d * RS + lane] = wb * E0[d * RS + lane];
+  AR_TS(98);
   const int nin = a.D + a.C;
   for (int t = a.T - 1; t >= 0; --t) {
     const float* tp = a.img + (size_t)t * a.t_stride;
     float* gt = grad + (size_t)t * a.P_t;
     for (int d = 0; d < a.D; ++d) E0[d * RS + lane] = ust[t * a.D + d];
+    AR_TS(99);
     ar_hidden(a, tp, E0, H1, H2, lane);
+    AR_TS(100);
     for (int p = 0; p < a.Hp; ++p) DH[p * RS + lane] = 0.f;
+    AR_TS(101);
     // ---- head + splines, dimension by dimension
     for (int d = 0; d < a.D; ++d) {
       const int kend = (int)a.tendk[a.ord[t * a.D + d]];
       float q[ARQ], dq[ARQ];
       ar_head(a, tp, d, kend, H2, QB, lane, q);
+      AR_TS(102 + 4 * d);
       float dv;
       ZS::bwd(sc, q, E0[d * RS + lane], GG[d * RS + lane], -wb, dv, dq);
+      AR_TS(103 + 4 * d);
       DV[d * RS + lane] = dv;
       dq[ARQ - 1] = 0.f;
       __syncthreads();   // (every lane has taken its q)
@@ -418,7 +519,7 @@ __global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restri
         for (int k0 = 0; k0 < kend; k0 += 16) {
           const ar_f32x4 g4 = ar_dw16(QB, it * 16, H2, k0, lane);
           const int k = k0 + (lane & 15);
-          const int kl = k < kend ? a.perm[k] : -1;
+          const int kl = k < kend ? PERM[k] : -1;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int sl = it * 16 + 4 * (lane >> 4) + r, fam = sl >> 3, kk = sl & 7;
@@ -435,6 +536,7 @@ __global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restri
           }
         }
       }
+      AR_TS(104 + 4 * d);
       // delta of the last hidden layer: DH[k] += sum_slots W2[(d, slot)][k] dq[slot]   (k-major image of the head's transpose)
       {
         const float* wm = tp + a.o_L2m + (size_t)d * ARQ * a.Hp;
@@ -442,19 +544,21 @@ __global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restri
         for (; p0 + 16 < kend; p0 += 32) ar_tiles<false, true, 2>(wm, a.Hp, nullptr, p0, 0, ARQ, QB, DH, a.Hp, lane);
         if (p0 < kend) ar_tiles<false, true, 1>(wm, a.Hp, nullptr, p0, 0, ARQ, QB, DH, a.Hp, lane);
       }
+      AR_TS(105 + 4 * d);
     }
     // ---- second hidden layer: delta through the ReLU, weight gradients, delta of the first hidden layer (into H2's rows)
     __syncthreads();
-    for (int o = 0; o < a.Hp; ++o) DH[o * RS + lane] = H2[o * RS + lane] > 0.f ? DH[o * RS + lane] : 0.f;
+    ar_mask_rows(DH, H2, a.Hp, lane);   // DH <- DH where H2 > 0
     __syncthreads();
+    AR_TS(130);
     for (int o0 = 0; o0 < a.Hp; o0 += 16) {
       const int kend = (int)a.tile_kend[o0 >> 4];
       int ol[4], oty[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { ol[r] = a.perm[o0 + 4 * (lane >> 4) + r]; oty[r] = a.ptype[o0 + 4 * (lane >> 4) + r]; }
+      for (int r = 0; r < 4; ++r) { ol[r] = PERM[o0 + 4 * (lane >> 4) + r]; oty[r] = PTYP[o0 + 4 * (lane >> 4) + r]; }
       for (int k0 = 0; k0 < kend; k0 += 16) {
         const ar_f32x4 g4 = ar_dw16(DH, o0, H1, k0, lane);
-        const int k = k0 + (lane & 15), kl = a.perm[k], kty = a.ptype[k];
+        const int k = k0 + (lane & 15), kl = PERM[k], kty = PTYP[k];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (kl >= 0 && ol[r] >= 0 && kty <= oty[r]) unsafeAtomicAdd(gt + a.l_W1 + (size_t)ol[r] * a.H + kl, g4[r]);
@@ -467,19 +571,22 @@ __global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restri
       }
     }
     __syncthreads();   // (H2 is overwritten next)
+    AR_TS(131);
     {   // delta_h1[k] = sum_{o: type(o) >= type(k)} W1[o][k] delta_h2[o]
       int p0 = 0;
       for (; p0 + 16 < a.Hp; p0 += 32) ar_tiles<false, false, 2>(tp + a.o_L1m, a.Hp, nullptr, p0, (int)a.tile_kbeg[p0 >> 4], a.Hp, DH, H2, a.Hp, lane);
       if (p0 < a.Hp) ar_tiles<false, false, 1>(tp + a.o_L1m, a.Hp, nullptr, p0, (int)a.tile_kbeg[p0 >> 4], a.Hp, DH, H2, a.Hp, lane);
     }
     __syncthreads();
-    for (int k = 0; k < a.Hp; ++k) H2[k * RS + lane] = H1[k * RS + lane] > 0.f ? H2[k * RS + lane] : 0.f;
+    AR_TS(132);
+    ar_mask_rows(H2, H1, a.Hp, lane);   // H2 (delta_h1) <- where H1 > 0
     __syncthreads();
+    AR_TS(133);
     // ---- first hidden layer: weight gradients, and what reaches the inputs
     for (int o0 = 0; o0 < a.Hp; o0 += 16) {
       int ol[4], oty[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { ol[r] = a.perm[o0 + 4 * (lane >> 4) + r]; oty[r] = a.ptype[o0 + 4 * (lane >> 4) + r]; }
+      for (int r = 0; r < 4; ++r) { ol[r] = PERM[o0 + 4 * (lane >> 4) + r]; oty[r] = PTYP[o0 + 4 * (lane >> 4) + r]; }
       for (int i0 = 0; i0 < a.NIN16; i0 += 16) {
         const ar_f32x4 g4 = ar_dw16(H2, o0, E0, i0, lane);
         const int i = i0 + (lane & 15);
@@ -495,9 +602,11 @@ __global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restri
           if (ol[r] >= 0) unsafeAtomicAdd(gt + a.l_b0 + ol[r], b4[r]);
       }
     }
+    AR_TS(134);
     // d input[i] = sum_o W0[o][i] delta_h1[o], i < D  (L0m: [o][16])
     ar_tiles<false, false, 1>(tp + a.o_L0m, 16, nullptr, 0, 0, a.Hp, H2, QB, 16, lane);
     __syncthreads();
+    AR_TS(135);
     for (int d = 0; d < a.D; ++d) GG[d * RS + lane] = DV[d * RS + lane] + QB[d * RS + lane];
   }
 }
@@ -522,6 +631,9 @@ ArArgs args_of(const SfNsfAr& n) {
   a.B = n.bound; a.cw = n.cw; a.cd = n.cd; a.logdet0 = n.logdet0;
   for (int d = 0; d < 16; ++d) { a.th_scale[d] = n.th_scale[d]; a.th_shift[d] = n.th_shift[d]; a.tendk[d] = d < n.D ? (short)n.tend[d] : (short)n.Hp; }
   for (int i = 0; i < 24; ++i) { a.tile_kend[i] = 0; a.tile_kbeg[i] = 0; }
+#ifdef SF_AR_TRACE
+  a.trace = nullptr;
+#endif
   for (int p0 = 0; p0 < n.Hp; p0 += 16) {
     const int ta = n.ptype[p0], tb = n.ptype[p0 + 15];
     a.tile_kend[p0 >> 4] = (short)n.tend[tb];
@@ -675,7 +787,8 @@ static int ar_ensure(SfNsfAr* n, std::string& err) {
 
 size_t sf_nsfar_lds_bytes(const SfNsfAr& n, int hidden_buffers) {
   // inputs (padded to whole 16-row tiles), hidden buffers, the 32 rows of one dimension's head, V or GG + DV
-  return (size_t)((n.D + n.C + 15) / 16 * 16 + hidden_buffers * n.Hp + 32 + 2 * n.D) * RS * sizeof(float);
+  return (size_t)((n.D + n.C + 15) / 16 * 16 + hidden_buffers * n.Hp + 32 + 2 * n.D) * RS * sizeof(float) +
+         (hidden_buffers == 3 ? (size_t)2 * n.Hp * sizeof(int) : 0);
 }
 
 int sf_nsfar_pack(SfNsfAr* n, const float* flat, hipStream_t st, std::string& err) {
@@ -687,6 +800,26 @@ int sf_nsfar_pack(SfNsfAr* n, const float* flat, hipStream_t st, std::string& er
 }
 
 int sf_nsfar_log_prob(SfNsfAr* n, const float* theta, const float* x, long B, float* out, hipStream_t st, std::string& err) {
+#ifdef SF_AR_TRACE
+  {
+    static unsigned long long* d_tr = nullptr;
+    if (!d_tr) AR_HIP(hipMalloc(&d_tr, 256 * 8));
+    AR_HIP(hipMemsetAsync(d_tr, 0, 256 * 8, st));
+    ArArgs aa = args_of(*n);
+    aa.trace = d_tr;
+    hipLaunchKernelGGL(k_ar_logprob, dim3((unsigned)((B + 63) / 64)), dim3(64), sf_nsfar_lds_bytes(*n, 2), st, aa, theta, x, B, out);
+    AR_HIP(hipStreamSynchronize(st));
+    unsigned long long h[256];
+    AR_HIP(hipMemcpy(h, d_tr, sizeof(h), hipMemcpyDeviceToHost));
+    static int calls = 0;
+    if (++calls % 8 == 0) {
+      fprintf(stderr, "[nsfar trace] B=%ld (units of 100 cycles since stamp 0):", B);
+      for (int i = 0; i < 256; ++i) if (h[i]) fprintf(stderr, " %d:%.1f", i, (double)(long long)(h[i] - h[0]) * 0.01);
+      fprintf(stderr, "\n");
+    }
+    return SF_OK;
+  }
+#endif
   hipLaunchKernelGGL(k_ar_logprob, dim3((unsigned)((B + 63) / 64)), dim3(64), sf_nsfar_lds_bytes(*n, 2), st, args_of(*n), theta, x, B, out);
   AR_HIP(hipGetLastError());
   return SF_OK;
@@ -747,6 +880,27 @@ int sf_nsfar_loss_grad(SfNsfAr* n, const float* flat, const float* theta, const 
     AR_HIP(hipMalloc(&n->d_ustash, need * sizeof(float)));
     n->ustash_cap = need;
   }
+#ifdef SF_AR_TRACE
+  {
+    static unsigned long long* d_tr = nullptr;
+    if (!d_tr) AR_HIP(hipMalloc(&d_tr, 256 * 8));
+    AR_HIP(hipMemsetAsync(d_tr, 0, 256 * 8, st));
+    ArArgs aa = args_of(*n);
+    aa.trace = d_tr;
+    hipLaunchKernelGGL(k_ar_train, dim3((unsigned)((B + 63) / 64)), dim3(64), sf_nsfar_lds_bytes(*n, 3), st, aa, theta, x, idx, B, grad_scale,
+                       weights, loss, loss_sum, grad, n->d_ustash);
+    AR_HIP(hipStreamSynchronize(st));
+    unsigned long long h[256];
+    AR_HIP(hipMemcpy(h, d_tr, sizeof(h), hipMemcpyDeviceToHost));
+    static int calls = 0;
+    if (++calls % 8 == 0) {
+      fprintf(stderr, "[nsfar train trace] B=%ld (units of 100 cycles since stamp 0):", B);
+      for (int i = 0; i < 256; ++i) if (h[i]) fprintf(stderr, " %d:%.1f", i, (double)(long long)(h[i] - h[0]) * 0.01);
+      fprintf(stderr, "\n");
+    }
+    return SF_OK;
+  }
+#endif
   hipLaunchKernelGGL(k_ar_train, dim3((unsigned)((B + 63) / 64)), dim3(64), sf_nsfar_lds_bytes(*n, 3), st, args_of(*n), theta, x, idx, B, grad_scale,
                      weights, loss, loss_sum, grad, n->d_ustash);
   AR_HIP(hipGetLastError());
