@@ -33,7 +33,7 @@ struct SfNsfAr {
 
 int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err);
 void sf_nsfar_destroy(SfNsfAr* n);
-size_t sf_nsfar_lds_bytes(const SfNsfAr& n, int hidden_buffers);
+size_t sf_nsfar_lds_bytes(const SfNsfAr& n, int hidden_buffers, int waves = 1);
 // re-tiles the logical vector into the masked images (every entry point below reads the images of the LAST pack)
 int sf_nsfar_pack(SfNsfAr* n, const float* flat, hipStream_t st, std::string& err);
 int sf_nsfar_log_prob(SfNsfAr* n, const float* theta, const float* x, long B, float* out, hipStream_t st, std::string& err);

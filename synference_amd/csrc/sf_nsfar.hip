@@ -111,6 +111,13 @@ __device__ __forceinline__ ar_f32x4 ar_rowsum16(const float* A, int o0, int lane
   return acc0;
 }
 
+// order the LDS traffic of ONE wave (its LDS operations execute in program order: a read issued after a write of another lane
+// of the same wave sees it; this only keeps the compiler from reordering them)
+__device__ __forceinline__ void ar_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // NTL x sixteen output rows [p0, p0 + 16 NTL) of a product for the wave's 64 samples:
 //   out[p - oshift][s] = act(bias[p] (or the old value: ACC) + sum_{k in [kbeg, kend)} wt[k][p] * in[k][s])
 // wt: k-major image (row k, ldo floats per row); kbeg, kend multiples of four; rows p >= row_lim are not written.  Columns past
@@ -118,7 +125,7 @@ __device__ __forceinline__ ar_f32x4 ar_rowsum16(const float* A, int o0, int lane
 // The tiles of a call share every activation read; the weights come four k-steps at a time, the next four requested before the
 // products of the current ones are issued, and the bias (requested first) is only added at the end: what a call exposes is ONE
 // L2 round trip, not three.
-template <bool RELU, bool ACC, int NTL>
+template <bool RELU, bool ACC, int NTL, bool ATOM = false>
 __device__ __forceinline__ void ar_tiles(const float* __restrict__ wt, int ldo, const float* __restrict__ bias, int p0, int kbeg, int kend,
                                          const float* in, float* out, int row_lim, int lane, int oshift = 0) {
   const int i4 = 4 * (lane >> 4), j = lane & 15;
@@ -146,7 +153,7 @@ __device__ __forceinline__ void ar_tiles(const float* __restrict__ wt, int ldo, 
 #pragma unroll
     for (int st = 0; st < 4; ++st)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[tl][st][r] = (ACC && p0 + 16 * tl + i4 + r < row_lim) ? orow[(16 * tl + r) * RS + st * 16] : 0.f;
+      for (int r = 0; r < 4; ++r) acc[tl][st][r] = (ACC && !ATOM && p0 + 16 * tl + i4 + r < row_lim) ? orow[(16 * tl + r) * RS + st * 16] : 0.f;
   for (int k0 = kbeg; k0 < kend; k0 += 4 * CH) {
     float wn[CH][NTL];
 #pragma unroll
@@ -185,7 +192,8 @@ __device__ __forceinline__ void ar_tiles(const float* __restrict__ wt, int ldo, 
       for (int r = 0; r < 4; ++r)
         if (p0 + 16 * tl + i4 + r < row_lim) {
           const float v = acc[tl][st][r] + bb[r];
-          orow[(16 * tl + r) * RS + st * 16] = RELU ? fmaxf(v, 0.f) : v;
+          if (ATOM) atomicAdd(orow + (16 * tl + r) * RS + st * 16, v);   // (several waves add into these rows: ds_add_f32)
+          else orow[(16 * tl + r) * RS + st * 16] = RELU ? fmaxf(v, 0.f) : v;
         }
   }
 }
@@ -211,16 +219,18 @@ __device__ __forceinline__ void ar_keep(const ArPre& P) {
 // rows [p_lo, p_hi) in pairs of tiles, a single one at the end; kend_of(p0, n): inputs the n tiles from p0 on read
 template <bool RELU, typename KE>
 __device__ __forceinline__ void ar_rows(const float* __restrict__ wt, int ldo, const float* __restrict__ bias, int p_lo, int p_hi, int kbeg,
-                                        KE kend_of, const float* in, float* out, int row_lim, int lane) {
-  int p0 = p_lo;
-  for (; p0 + 16 < p_hi; p0 += 32) ar_tiles<RELU, false, 2>(wt, ldo, bias, p0, kbeg, kend_of(p0, 2), in, out, row_lim, lane);
-  if (p0 < p_hi) ar_tiles<RELU, false, 1>(wt, ldo, bias, p0, kbeg, kend_of(p0, 1), in, out, row_lim, lane);
+                                        KE kend_of, const float* in, float* out, int row_lim, int lane, int wid = 0, int nwv = 1) {
+  // (wave wid of nwv takes every nwv-th pair of tiles)
+  for (int p0 = p_lo + 32 * wid; p0 < p_hi; p0 += 32 * nwv) {
+    if (p0 + 16 < p_hi) ar_tiles<RELU, false, 2>(wt, ldo, bias, p0, kbeg, kend_of(p0, 2), in, out, row_lim, lane);
+    else ar_tiles<RELU, false, 1>(wt, ldo, bias, p0, kbeg, kend_of(p0, 1), in, out, row_lim, lane);
+  }
 }
 
 // x[r][lane] <- x[r][lane] where gate[r][lane] > 0, rows [0, n) (n a multiple of 8): eight rows per round, every read of a round
 // before its writes (row by row, each write would wait for the LDS round trip of its own reads)
-__device__ __forceinline__ void ar_mask_rows(float* x, const float* gate, int n, int lane) {
-  for (int r0 = 0; r0 < n; r0 += 8) {
+__device__ __forceinline__ void ar_mask_rows(float* x, const float* gate, int n, int lane, int wid = 0, int nwv = 1) {
+  for (int r0 = 8 * wid; r0 < n; r0 += 8 * nwv) {
     float xv[8], gv[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { xv[i] = x[(r0 + i) * RS + lane]; gv[i] = gate[(r0 + i) * RS + lane]; }
@@ -230,51 +240,56 @@ __device__ __forceinline__ void ar_mask_rows(float* x, const float* gate, int n,
 }
 
 // both hidden layers of a transform from the inputs in E0 (rows [0, NIN4): u, context, zeros)
-__device__ __forceinline__ void ar_hidden(const ArArgs& a, const float* __restrict__ tp, const float* E0, float* H1, float* H2, int lane) {
+__device__ __forceinline__ void ar_hidden(const ArArgs& a, const float* __restrict__ tp, const float* E0, float* H1, float* H2, int lane,
+                                          int wid = 0, int nwv = 1) {
   __syncthreads();   // (E0 was written sample by sample)
-  ar_rows<true>(tp + a.o_L0t, a.Hp, tp + a.o_b0, 0, a.Hp, 0, [&](int, int) { return a.NIN4; }, E0, H1, a.Hp, lane);
+  ar_rows<true>(tp + a.o_L0t, a.Hp, tp + a.o_b0, 0, a.Hp, 0, [&](int, int) { return a.NIN4; }, E0, H1, a.Hp, lane, wid, nwv);
   __syncthreads();
-  ar_rows<true>(tp + a.o_L1t, a.Hp, tp + a.o_b1, 0, a.Hp, 0, [&](int p0, int n) { return (int)a.tile_kend[(p0 >> 4) + n - 1]; }, H1, H2, a.Hp, lane);
+  ar_rows<true>(tp + a.o_L1t, a.Hp, tp + a.o_b1, 0, a.Hp, 0, [&](int p0, int n) { return (int)a.tile_kend[(p0 >> 4) + n - 1]; }, H1, H2, a.Hp, lane,
+                wid, nwv);
   __syncthreads();
 }
 // the 24 parameter slots of dimension d from the last hidden layer (rows < kend) -> q (through the 32 rows of QB)
 __device__ __forceinline__ void ar_head(const ArArgs& a, const float* __restrict__ tp, int d, int kend, const float* H2, float* QB, int lane,
                                         float (&q)[ARQ]) {
-  __syncthreads();   // (earlier readers of QB are done)
+  // (QB belongs to the calling wave: wave-local ordering is all it needs)
+  ar_wave_sync();
   // rows d * ARQ + i of the head -> QB row i (two tiles: rows 24 .. 31 of the second are the next dimension's, not written)
   ar_tiles<false, false, 2>(tp + a.o_L2t, a.D * ARQ, tp + a.o_b2, d * ARQ, 0, kend, H2, QB, d * ARQ + ARQ, lane, d * ARQ);
-  __syncthreads();
+  ar_wave_sync();
 #pragma unroll
   for (int sl = 0; sl < ARQ; ++sl) q[sl] = QB[sl * RS + lane];
 }
 
 __device__ __forceinline__ void ar_load_inputs(const ArArgs& a, const float* __restrict__ theta, const float* __restrict__ x, long row,
-                                               float* E0, int lane) {
-  for (int d = 0; d < a.D; ++d) E0[d * RS + lane] = theta[row * a.D + d] * a.th_scale[d] + a.th_shift[d];
-  for (int c = 0; c < a.C; ++c) E0[(a.D + c) * RS + lane] = (x[row * a.C + c] - a.xmean[c]) / a.xstd[c];
-  for (int r = a.D + a.C; r < a.NIN16; ++r) E0[r * RS + lane] = 0.f;   // (rows the k-steps of four run over)
+                                               float* E0, int lane, int wid = 0, int nwv = 1) {
+  for (int d = wid; d < a.D; d += nwv) E0[d * RS + lane] = theta[row * a.D + d] * a.th_scale[d] + a.th_shift[d];
+  for (int c = wid; c < a.C; c += nwv) E0[(a.D + c) * RS + lane] = (x[row * a.C + c] - a.xmean[c]) / a.xstd[c];
+  for (int r = a.D + a.C + wid; r < a.NIN16; r += nwv) E0[r * RS + lane] = 0.f;   // (rows the k-steps of four run over)
 }
 
-__global__ __launch_bounds__(64) void k_ar_logprob(ArArgs a, const float* __restrict__ theta, const float* __restrict__ x, long B,
-                                                    float* __restrict__ out) {
+// NWV waves per 64 samples: the tile pairs of a layer and the dimensions of a transform (head + spline) are dealt round robin
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void k_ar_logprob(ArArgs a, const float* __restrict__ theta, const float* __restrict__ x, long B,
+                                                          float* __restrict__ out) {
   extern __shared__ float lds[];
   float* E0 = lds;
   float* H1 = E0 + a.NIN16 * RS;
   float* H2 = H1 + a.Hp * RS;
-  float* QB = H2 + a.Hp * RS;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float* QB = H2 + a.Hp * RS + wid * 32 * RS;   // (one 32-row head buffer per wave)
   const long b = (long)blockIdx.x * 64 + lane;
   const long row = b < B ? b : B - 1;
   AR_TS(0);
-  ar_load_inputs(a, theta, x, row, E0, lane);
+  ar_load_inputs(a, theta, x, row, E0, lane, wid, NWV);
   const ZSplC sc = {a.K, a.B, a.cw, a.cd};
-  float ld = a.logdet0;
+  float ld = 0.f;
   for (int t = 0; t < a.T; ++t) {
     const float* tp = a.img + (size_t)t * a.t_stride;
     AR_TS(1 + t * 40);
-    ar_hidden(a, tp, E0, H1, H2, lane);
+    ar_hidden(a, tp, E0, H1, H2, lane, wid, NWV);
     AR_TS(2 + t * 40);
-    for (int d = 0; d < a.D; ++d) {
+    for (int d = wid; d < a.D; d += NWV) {
       float q[ARQ];
       ar_head(a, tp, d, (int)a.tendk[a.ord[t * a.D + d]], H2, QB, lane, q);
       AR_TS(3 + t * 40 + 2 * d);
@@ -285,9 +300,18 @@ __global__ __launch_bounds__(64) void k_ar_logprob(ArArgs a, const float* __rest
       AR_TS(4 + t * 40 + 2 * d);
     }
   }
-  float ss = 0.f;
-  for (int d = 0; d < a.D; ++d) ss += E0[d * RS + lane] * E0[d * RS + lane];
-  if (b < B) out[b] = -0.5f * ss - 0.5f * (float)a.D * 1.8378770664093453f + ld;
+  __syncthreads();
+  if (NWV > 1) {   // the log-determinants of the waves' dimensions
+    QB[lane] = ld;
+    __syncthreads();
+    if (wid == 0)
+      for (int w2 = 1; w2 < NWV; ++w2) ld += H2[a.Hp * RS + w2 * 32 * RS + lane];
+  }
+  if (wid == 0) {
+    float ss = 0.f;
+    for (int d = 0; d < a.D; ++d) ss += E0[d * RS + lane] * E0[d * RS + lane];
+    if (b < B) out[b] = -0.5f * ss - 0.5f * (float)a.D * 1.8378770664093453f + ld + a.logdet0;
+  }
   AR_TS(250);
 }
 
@@ -437,36 +461,39 @@ __global__ __launch_bounds__(64) void k_ar_sample(ArArgs a, const float* __restr
 }
 
 // forward (with the inputs of every transform stashed) + loss, then the backward sweep
-__global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restrict__ theta, const float* __restrict__ x,
-                                                  const long long* __restrict__ idx, long B, float w, const float* __restrict__ wts,
-                                                  float* __restrict__ loss, double* __restrict__ loss_sum, float* __restrict__ grad,
-                                                  float* __restrict__ ustash) {
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void k_ar_train(ArArgs a, const float* __restrict__ theta, const float* __restrict__ x,
+                                                        const long long* __restrict__ idx, long B, float w, const float* __restrict__ wts,
+                                                        float* __restrict__ loss, double* __restrict__ loss_sum, float* __restrict__ grad,
+                                                        float* __restrict__ ustash) {
   extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   float* E0 = lds;                       // [NIN16]: u, context, zeros
   float* H1 = E0 + a.NIN16 * RS;         // [Hp]
   float* H2 = H1 + a.Hp * RS;            // [Hp]
-  float* QB = H2 + a.Hp * RS;            // [32] head outputs of ONE dimension, then their deltas, then the input deltas
-  float* DH = QB + 32 * RS;              // [Hp] deltas
+  float* QB0 = H2 + a.Hp * RS;           // [NWV][32] per wave: head outputs of ONE dimension, then their deltas; wave 0: the input deltas
+  float* QB = QB0 + wid * 32 * RS;
+  float* DH = QB0 + NWV * 32 * RS;       // [Hp] deltas
   float* GG = DH + a.Hp * RS;            // [D] dL/du at the transform's output
   float* DV = GG + a.D * RS;             // [D] what reaches the transform's input through the splines
   int* PERM = reinterpret_cast<int*>(DV + a.D * RS);   // [Hp] perm, [Hp] ptype: read per weight-gradient block
   int* PTYP = PERM + a.Hp;
-  const int lane = threadIdx.x;
-  for (int i = lane; i < a.Hp; i += 64) { PERM[i] = a.perm[i]; PTYP[i] = a.ptype[i]; }
+  for (int i = threadIdx.x; i < a.Hp; i += 64 * NWV) { PERM[i] = a.perm[i]; PTYP[i] = a.ptype[i]; }
   const long b = (long)blockIdx.x * 64 + lane;
   const bool valid = b < B;
   const long bb = valid ? b : B - 1;
   const long row = idx ? (long)idx[bb] : bb;
   AR_TS(0);
-  ar_load_inputs(a, theta, x, row, E0, lane);
+  ar_load_inputs(a, theta, x, row, E0, lane, wid, NWV);
   const ZSplC sc = {a.K, a.B, a.cw, a.cd};
   float* ust = ustash + (size_t)bb * a.T * a.D;   // (an invalid lane shares the last row's stash: same values)
-  float ld = a.logdet0;
+  float ld = 0.f;
   for (int t = 0; t < a.T; ++t) {
     const float* tp = a.img + (size_t)t * a.t_stride;
-    for (int d = 0; d < a.D; ++d) ust[t * a.D + d] = E0[d * RS + lane];
-    ar_hidden(a, tp, E0, H1, H2, lane);
-    for (int d = 0; d < a.D; ++d) {
+    __syncthreads();   // (E0 complete)
+    for (int d = wid; d < a.D; d += NWV) ust[t * a.D + d] = E0[d * RS + lane];
+    ar_hidden(a, tp, E0, H1, H2, lane, wid, NWV);
+    for (int d = wid; d < a.D; d += NWV) {
       float q[ARQ];
       ar_head(a, tp, d, (int)a.tendk[a.ord[t * a.D + d]], H2, QB, lane, q);
       float v, lad;
@@ -475,32 +502,42 @@ __global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restri
       ld += lad;
     }
   }
-  float ss = 0.f;
-  for (int d = 0; d < a.D; ++d) ss += E0[d * RS + lane] * E0[d * RS + lane];
-  const float nll = 0.5f * ss + 0.5f * (float)a.D * 1.8378770664093453f - ld;
-  if (loss && valid) loss[b] = nll;
-  if (loss_sum) {
-    float tsum = valid ? nll : 0.f;
+  __syncthreads();
+  if (NWV > 1) {   // the log-determinants of the waves' dimensions
+    QB[lane] = ld;
+    __syncthreads();
+    if (wid == 0)
+      for (int w2 = 1; w2 < NWV; ++w2) ld += QB0[w2 * 32 * RS + lane];
+  }
+  if (wid == 0) {
+    float ss = 0.f;
+    for (int d = 0; d < a.D; ++d) ss += E0[d * RS + lane] * E0[d * RS + lane];
+    const float nll = 0.5f * ss + 0.5f * (float)a.D * 1.8378770664093453f - (ld + a.logdet0);
+    if (loss && valid) loss[b] = nll;
+    if (loss_sum) {
+      float tsum = valid ? nll : 0.f;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) tsum += __shfl_xor(tsum, o, 64);
-    // values on a 2^-20 grid add exactly in double: the sum does not depend on the order of the atomics
-    if (lane == 0) atomicAdd(loss_sum, (double)rintf(tsum * 1048576.0f) * (1.0 / 1048576.0));
+      for (int o = 32; o > 0; o >>= 1) tsum += __shfl_xor(tsum, o, 64);
+      // values on a 2^-20 grid add exactly in double: the sum does not depend on the order of the atomics
+      if (lane == 0) atomicAdd(loss_sum, (double)rintf(tsum * 1048576.0f) * (1.0 / 1048576.0));
+    }
   }
   const float wb = valid ? (wts ? w * wts[b] : w) : 0.f;
-  for (int d = 0; d < a.D; ++d) GG[d * RS + lane] = wb * E0[d * RS + lane];
+  for (int d = wid; d < a.D; d += NWV) GG[d * RS + lane] = wb * E0[d * RS + lane];
   AR_TS(98);
   const int nin = a.D + a.C;
   for (int t = a.T - 1; t >= 0; --t) {
     const float* tp = a.img + (size_t)t * a.t_stride;
     float* gt = grad + (size_t)t * a.P_t;
-    for (int d = 0; d < a.D; ++d) E0[d * RS + lane] = ust[t * a.D + d];
+    for (int d = wid; d < a.D; d += NWV) E0[d * RS + lane] = ust[t * a.D + d];
     AR_TS(99);
-    ar_hidden(a, tp, E0, H1, H2, lane);
+    ar_hidden(a, tp, E0, H1, H2, lane, wid, NWV);
     AR_TS(100);
-    for (int p = 0; p < a.Hp; ++p) DH[p * RS + lane] = 0.f;
+    for (int p = wid; p < a.Hp; p += NWV) DH[p * RS + lane] = 0.f;
+    __syncthreads();
     AR_TS(101);
-    // ---- head + splines, dimension by dimension
-    for (int d = 0; d < a.D; ++d) {
+    // ---- head + splines, dimension by dimension (wave wid: dimensions wid, wid + NWV, ...)
+    for (int d = wid; d < a.D; d += NWV) {
       const int kend = (int)a.tendk[a.ord[t * a.D + d]];
       float q[ARQ], dq[ARQ];
       ar_head(a, tp, d, kend, H2, QB, lane, q);
@@ -510,10 +547,10 @@ __global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restri
       AR_TS(103 + 4 * d);
       DV[d * RS + lane] = dv;
       dq[ARQ - 1] = 0.f;
-      __syncthreads();   // (every lane has taken its q)
+      ar_wave_sync();   // (every lane has taken its q)
 #pragma unroll
       for (int sl = 0; sl < ARQ; ++sl) QB[sl * RS + lane] = dq[sl];
-      __syncthreads();
+      ar_wave_sync();
       // weight gradients of this dimension's head rows: (24 slots x 64 samples) x (64 samples x kend hidden rows)
       for (int it = 0; it < 2; ++it) {
         for (int k0 = 0; k0 < kend; k0 += 16) {
@@ -541,17 +578,17 @@ __global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restri
       {
         const float* wm = tp + a.o_L2m + (size_t)d * ARQ * a.Hp;
         int p0 = 0;
-        for (; p0 + 16 < kend; p0 += 32) ar_tiles<false, true, 2>(wm, a.Hp, nullptr, p0, 0, ARQ, QB, DH, a.Hp, lane);
-        if (p0 < kend) ar_tiles<false, true, 1>(wm, a.Hp, nullptr, p0, 0, ARQ, QB, DH, a.Hp, lane);
+        for (; p0 + 16 < kend; p0 += 32) ar_tiles<false, true, 2, (NWV > 1)>(wm, a.Hp, nullptr, p0, 0, ARQ, QB, DH, a.Hp, lane);
+        if (p0 < kend) ar_tiles<false, true, 1, (NWV > 1)>(wm, a.Hp, nullptr, p0, 0, ARQ, QB, DH, a.Hp, lane);
       }
       AR_TS(105 + 4 * d);
     }
     // ---- second hidden layer: delta through the ReLU, weight gradients, delta of the first hidden layer (into H2's rows)
     __syncthreads();
-    ar_mask_rows(DH, H2, a.Hp, lane);   // DH <- DH where H2 > 0
+    ar_mask_rows(DH, H2, a.Hp, lane, wid, NWV);   // DH <- DH where H2 > 0
     __syncthreads();
     AR_TS(130);
-    for (int o0 = 0; o0 < a.Hp; o0 += 16) {
+    for (int o0 = 16 * wid; o0 < a.Hp; o0 += 16 * NWV) {
       const int kend = (int)a.tile_kend[o0 >> 4];
       int ol[4], oty[4];
 #pragma unroll
@@ -572,18 +609,18 @@ __global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restri
     }
     __syncthreads();   // (H2 is overwritten next)
     AR_TS(131);
-    {   // delta_h1[k] = sum_{o: type(o) >= type(k)} W1[o][k] delta_h2[o]
-      int p0 = 0;
-      for (; p0 + 16 < a.Hp; p0 += 32) ar_tiles<false, false, 2>(tp + a.o_L1m, a.Hp, nullptr, p0, (int)a.tile_kbeg[p0 >> 4], a.Hp, DH, H2, a.Hp, lane);
-      if (p0 < a.Hp) ar_tiles<false, false, 1>(tp + a.o_L1m, a.Hp, nullptr, p0, (int)a.tile_kbeg[p0 >> 4], a.Hp, DH, H2, a.Hp, lane);
+    // delta_h1[k] = sum_{o: type(o) >= type(k)} W1[o][k] delta_h2[o]
+    for (int p0 = 32 * wid; p0 < a.Hp; p0 += 32 * NWV) {
+      if (p0 + 16 < a.Hp) ar_tiles<false, false, 2>(tp + a.o_L1m, a.Hp, nullptr, p0, (int)a.tile_kbeg[p0 >> 4], a.Hp, DH, H2, a.Hp, lane);
+      else ar_tiles<false, false, 1>(tp + a.o_L1m, a.Hp, nullptr, p0, (int)a.tile_kbeg[p0 >> 4], a.Hp, DH, H2, a.Hp, lane);
     }
     __syncthreads();
     AR_TS(132);
-    ar_mask_rows(H2, H1, a.Hp, lane);   // H2 (delta_h1) <- where H1 > 0
+    ar_mask_rows(H2, H1, a.Hp, lane, wid, NWV);   // H2 (delta_h1) <- where H1 > 0
     __syncthreads();
     AR_TS(133);
     // ---- first hidden layer: weight gradients, and what reaches the inputs
-    for (int o0 = 0; o0 < a.Hp; o0 += 16) {
+    for (int o0 = 16 * wid; o0 < a.Hp; o0 += 16 * NWV) {
       int ol[4], oty[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) { ol[r] = PERM[o0 + 4 * (lane >> 4) + r]; oty[r] = PTYP[o0 + 4 * (lane >> 4) + r]; }
@@ -603,11 +640,11 @@ __global__ __launch_bounds__(64) void k_ar_train(ArArgs a, const float* __restri
       }
     }
     AR_TS(134);
-    // d input[i] = sum_o W0[o][i] delta_h1[o], i < D  (L0m: [o][16])
-    ar_tiles<false, false, 1>(tp + a.o_L0m, 16, nullptr, 0, 0, a.Hp, H2, QB, 16, lane);
+    // d input[i] = sum_o W0[o][i] delta_h1[o], i < D  (L0m: [o][16]); the last wave has the fewest weight-gradient tiles
+    if (wid == NWV - 1) ar_tiles<false, false, 1>(tp + a.o_L0m, 16, nullptr, 0, 0, a.Hp, H2, QB0, 16, lane);
     __syncthreads();
     AR_TS(135);
-    for (int d = 0; d < a.D; ++d) GG[d * RS + lane] = DV[d * RS + lane] + QB[d * RS + lane];
+    for (int d = wid; d < a.D; d += NWV) GG[d * RS + lane] = DV[d * RS + lane] + QB0[d * RS + lane];
   }
 }
 
@@ -704,7 +741,7 @@ int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err) {
   n->o_L0m = (int)o; o += (long)Hp * 16;
   n->o_L2m = (int)o; o += (long)D * ARQ * Hp;   // the head transposed: row (d, slot), column k
   n->t_stride = (o + 63) / 64 * 64;
-  if (sf_nsfar_lds_bytes(*n, 3) > (size_t)160 * 1024 - 1024) {
+  if (sf_nsfar_lds_bytes(*n, 3, 1) > (size_t)160 * 1024 - 1024) {
     err = "autoregressive NSF: (3 D + C + 3 Hp + 32) x 260 bytes of LDS per wave exceed the 160 KB of a CU (Hp = H with every type padded to a multiple of 8, in all a multiple of 16)";
     delete n;
     return SF_ERR_INVALID;
@@ -779,16 +816,24 @@ static int ar_ensure(SfNsfAr* n, std::string& err) {
     const std::vector<int32_t> none(n->src.size(), -1);
     AR_HIP(up(n->d_none, none));
   }
-  const size_t lds = sf_nsfar_lds_bytes(*n, 3);
-  AR_HIP(set_lds(k_ar_logprob, lds)); AR_HIP(set_lds(k_ar_inverse, lds)); AR_HIP(set_lds(k_ar_sample, lds)); AR_HIP(set_lds(k_ar_train, lds));
+  const size_t lds = (size_t)160 * 1024 - 1024;   // (k_ar_sample also has 768 static bytes)
+  AR_HIP(set_lds(k_ar_logprob<1>, lds)); AR_HIP(set_lds(k_ar_logprob<4>, lds)); AR_HIP(set_lds(k_ar_inverse, lds)); AR_HIP(set_lds(k_ar_sample, lds));
+  AR_HIP(set_lds(k_ar_train<1>, lds)); AR_HIP(set_lds(k_ar_train<4>, lds));
   n->dev_ready = true;
   return SF_OK;
 }
 
-size_t sf_nsfar_lds_bytes(const SfNsfAr& n, int hidden_buffers) {
-  // inputs (padded to whole 16-row tiles), hidden buffers, the 32 rows of one dimension's head, V or GG + DV
-  return (size_t)((n.D + n.C + 15) / 16 * 16 + hidden_buffers * n.Hp + 32 + 2 * n.D) * RS * sizeof(float) +
+size_t sf_nsfar_lds_bytes(const SfNsfAr& n, int hidden_buffers, int waves) {
+  // inputs (padded to whole 16-row tiles), hidden buffers, 32 rows of one dimension's head per wave, V or GG + DV
+  return (size_t)((n.D + n.C + 15) / 16 * 16 + hidden_buffers * n.Hp + 32 * waves + 2 * n.D) * RS * sizeof(float) +
          (hidden_buffers == 3 ? (size_t)2 * n.Hp * sizeof(int) : 0);
+}
+// waves per 64 samples of the density / training kernels: four (tile pairs and dimensions dealt round robin) when the LDS takes it
+static int ar_waves(const SfNsfAr& n, int hidden_buffers) {
+  static int forced = -1;
+  if (forced < 0) { const char* e = std::getenv("SF_NSFAR_WAVES"); forced = e ? std::atoi(e) : 0; }
+  if (forced == 1 || forced == 4) return sf_nsfar_lds_bytes(n, hidden_buffers, forced) <= (size_t)160 * 1024 - 1024 ? forced : 1;
+  return sf_nsfar_lds_bytes(n, hidden_buffers, 4) <= (size_t)160 * 1024 - 1024 ? 4 : 1;
 }
 
 int sf_nsfar_pack(SfNsfAr* n, const float* flat, hipStream_t st, std::string& err) {
@@ -807,7 +852,10 @@ int sf_nsfar_log_prob(SfNsfAr* n, const float* theta, const float* x, long B, fl
     AR_HIP(hipMemsetAsync(d_tr, 0, 256 * 8, st));
     ArArgs aa = args_of(*n);
     aa.trace = d_tr;
-    hipLaunchKernelGGL(k_ar_logprob, dim3((unsigned)((B + 63) / 64)), dim3(64), sf_nsfar_lds_bytes(*n, 2), st, aa, theta, x, B, out);
+    if (ar_waves(*n, 2) == 4)
+      hipLaunchKernelGGL(k_ar_logprob<4>, dim3((unsigned)((B + 63) / 64)), dim3(256), sf_nsfar_lds_bytes(*n, 2, 4), st, aa, theta, x, B, out);
+    else
+      hipLaunchKernelGGL(k_ar_logprob<1>, dim3((unsigned)((B + 63) / 64)), dim3(64), sf_nsfar_lds_bytes(*n, 2, 1), st, aa, theta, x, B, out);
     AR_HIP(hipStreamSynchronize(st));
     unsigned long long h[256];
     AR_HIP(hipMemcpy(h, d_tr, sizeof(h), hipMemcpyDeviceToHost));
@@ -820,13 +868,16 @@ int sf_nsfar_log_prob(SfNsfAr* n, const float* theta, const float* x, long B, fl
     return SF_OK;
   }
 #endif
-  hipLaunchKernelGGL(k_ar_logprob, dim3((unsigned)((B + 63) / 64)), dim3(64), sf_nsfar_lds_bytes(*n, 2), st, args_of(*n), theta, x, B, out);
+  if (ar_waves(*n, 2) == 4)
+    hipLaunchKernelGGL(k_ar_logprob<4>, dim3((unsigned)((B + 63) / 64)), dim3(256), sf_nsfar_lds_bytes(*n, 2, 4), st, args_of(*n), theta, x, B, out);
+  else
+    hipLaunchKernelGGL(k_ar_logprob<1>, dim3((unsigned)((B + 63) / 64)), dim3(64), sf_nsfar_lds_bytes(*n, 2, 1), st, args_of(*n), theta, x, B, out);
   AR_HIP(hipGetLastError());
   return SF_OK;
 }
 
 int sf_nsfar_inverse(SfNsfAr* n, const float* z, const float* x, long B, float* theta, float* logdet, hipStream_t st, std::string& err) {
-  hipLaunchKernelGGL(k_ar_inverse, dim3((unsigned)((B + 63) / 64)), dim3(64), sf_nsfar_lds_bytes(*n, 2), st, args_of(*n), z, x, B, theta, logdet);
+  hipLaunchKernelGGL(k_ar_inverse, dim3((unsigned)((B + 63) / 64)), dim3(64), sf_nsfar_lds_bytes(*n, 2, 1), st, args_of(*n), z, x, B, theta, logdet);
   AR_HIP(hipGetLastError());
   return SF_OK;
 }
@@ -838,7 +889,7 @@ int sf_nsfar_sample(SfNsfAr* n, const float* x, long M, long S, const uint32_t* 
   int dev = 0, cus = 256;
   hipDeviceProp_t pr;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
-  const size_t lds = sf_nsfar_lds_bytes(*n, 2);
+  const size_t lds = sf_nsfar_lds_bytes(*n, 2, 1);
   const long per_cu = (long)((size_t)160 * 1024 / (lds + 1024));
   long grid = (long)cus * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
   if (grid > (n_slots + 63) / 64) grid = (n_slots + 63) / 64;
@@ -887,8 +938,12 @@ int sf_nsfar_loss_grad(SfNsfAr* n, const float* flat, const float* theta, const 
     AR_HIP(hipMemsetAsync(d_tr, 0, 256 * 8, st));
     ArArgs aa = args_of(*n);
     aa.trace = d_tr;
-    hipLaunchKernelGGL(k_ar_train, dim3((unsigned)((B + 63) / 64)), dim3(64), sf_nsfar_lds_bytes(*n, 3), st, aa, theta, x, idx, B, grad_scale,
-                       weights, loss, loss_sum, grad, n->d_ustash);
+    if (ar_waves(*n, 3) == 4)
+      hipLaunchKernelGGL(k_ar_train<4>, dim3((unsigned)((B + 63) / 64)), dim3(256), sf_nsfar_lds_bytes(*n, 3, 4), st, aa, theta, x, idx, B, grad_scale,
+                         weights, loss, loss_sum, grad, n->d_ustash);
+    else
+      hipLaunchKernelGGL(k_ar_train<1>, dim3((unsigned)((B + 63) / 64)), dim3(64), sf_nsfar_lds_bytes(*n, 3, 1), st, aa, theta, x, idx, B, grad_scale,
+                         weights, loss, loss_sum, grad, n->d_ustash);
     AR_HIP(hipStreamSynchronize(st));
     unsigned long long h[256];
     AR_HIP(hipMemcpy(h, d_tr, sizeof(h), hipMemcpyDeviceToHost));
@@ -901,8 +956,12 @@ int sf_nsfar_loss_grad(SfNsfAr* n, const float* flat, const float* theta, const 
     return SF_OK;
   }
 #endif
-  hipLaunchKernelGGL(k_ar_train, dim3((unsigned)((B + 63) / 64)), dim3(64), sf_nsfar_lds_bytes(*n, 3), st, args_of(*n), theta, x, idx, B, grad_scale,
-                     weights, loss, loss_sum, grad, n->d_ustash);
+  if (ar_waves(*n, 3) == 4)
+    hipLaunchKernelGGL(k_ar_train<4>, dim3((unsigned)((B + 63) / 64)), dim3(256), sf_nsfar_lds_bytes(*n, 3, 4), st, args_of(*n), theta, x, idx, B,
+                       grad_scale, weights, loss, loss_sum, grad, n->d_ustash);
+  else
+    hipLaunchKernelGGL(k_ar_train<1>, dim3((unsigned)((B + 63) / 64)), dim3(64), sf_nsfar_lds_bytes(*n, 3, 1), st, args_of(*n), theta, x, idx, B,
+                       grad_scale, weights, loss, loss_sum, grad, n->d_ustash);
   AR_HIP(hipGetLastError());
   return SF_OK;
 }
