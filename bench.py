@@ -70,6 +70,22 @@ def nsf_flops(D, C, H, T, K, NB=2):
 
 _d, _g = nsf_flops(8, 20, 69, 15, 10)
 WORKLOADS["nsf_prod"].update(f_draw=_d, f_gal=_g, f_lp=_d + _g)
+
+
+def nsfar_flops(D, C, H, T, K):
+    """(f_lp, f_draw of the reference algorithm, per galaxy) of zuko's autoregressive NSF: mask-aware MACs x 2 of the hyper-network
+    [theta; context] -> H -> H -> D (3K - 1), hidden unit h of type h mod D (csrc/sf_nsfar.hip); zuko inverts a transform with D
+    passes over the whole network (f_draw), the context columns of the first layer are the same for every draw of a galaxy."""
+    typ = np.arange(H) % D
+    per_t = int(typ.sum()) + int((typ[:, None] >= typ[None, :]).sum()) + (3 * K - 1) * sum(int((typ <= r).sum()) for r in range(D))
+    ctx = C * H
+    return 2.0 * T * (per_t + ctx), 2.0 * T * D * per_t, 2.0 * T * ctx
+
+
+_lp, _dr, _g = nsfar_flops(5, 10, 50, 5, 8)
+# the flow ili.utils.load_nde_lampe(model="nsf") builds (backend="lampe": zuko.flows.NSF, 8 bins) on the cfg1 / cfg2 mock
+WORKLOADS["nsfar_cfg2"] = dict(kind="nsf_ar", D=5, C=10, K=8, n_lib=10_000, galaxies=2000, f_lp=_lp, f_draw=_dr, f_gal=_g,
+                               label="backend='lampe' NSF (zuko autoregressive, T=5 H=50 K=8) on the 10k-galaxy 10-filter mock")
 PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA (= vector) dense peak
 
 
@@ -256,6 +272,7 @@ def cpu_baseline(spec, flat, x_rows, th_rows, lo, hi, S, budget_s, train_theta, 
     usable = min(usable, 32)   # torch CPU ops of this size stop scaling long before that
     note(f"CPU baseline on {model}: host {cores} logical cores, cgroup quota {quota}, using {usable} threads")
     ospec = OF.FlowSpec(kind=spec.kind, D=spec.D, C=spec.C, H=spec.H, T=spec.T, K=spec.K, NB=spec.NB,
+                        tail_bound=spec.tail_bound, ar_slope=spec.ar_slope,
                         perms=spec.perms, theta_mean=spec.theta_mean.astype(np.float64),
                         theta_std=spec.theta_std.astype(np.float64), x_mean=spec.x_mean.astype(np.float64),
                         x_std=spec.x_std.astype(np.float64))
@@ -404,8 +421,9 @@ def main():
     tr = idx[: int(0.8 * len(idx))]
     prior = prior_from_parameters(th_lib[tr], names)
     gen = torch.Generator().manual_seed(42)
-    est = build_flow(wl["kind"], th_lib[tr], x_lib[tr], hidden_features=wl.get("H", 50),
-                     num_transforms=wl.get("T", 5), num_bins=wl["K"], device=dev, generator=gen).to(dev)
+    est = build_flow("nsf" if wl["kind"] == "nsf_ar" else wl["kind"], th_lib[tr], x_lib[tr], hidden_features=wl.get("H", 50),
+                     num_transforms=wl.get("T", 5), num_bins=wl["K"], device=dev, generator=gen,
+                     backend="lampe" if wl["kind"] == "nsf_ar" else "sbi").to(dev)
     if a.hidden_bf16:
         import dataclasses
         est.spec = dataclasses.replace(est.spec, hidden_bf16=True)
@@ -467,7 +485,8 @@ def main():
     desc = flow.describe()
     accepted_per_launch = M * S - unfilled / float(a.steps)
     evals_per_launch = evals[0] / float(a.steps)
-    f_min = wl["f_lp"] if wl["kind"] == "maf" else wl["f_draw"]   # one conditioner evaluation per transform
+    # one conditioner evaluation per transform (the coupling NSF's inverse IS one; the autoregressive flows' reference inverse is D)
+    f_min = wl["f_lp"] if wl["kind"] in ("maf", "nsf_ar") else wl["f_draw"]
     useful = f_min * accepted_per_launch / (k_ms * 1e-3) / 1e12
     contract = wl["f_draw"] * accepted_per_launch / (k_ms * 1e-3) / 1e12
     default_wl = a.workload == "maf_cfg2" and M == 2000 and S == 1000
@@ -700,7 +719,8 @@ def main():
     f_train = 3.0 * wl["f_lp"]   # a training step costs 3x the log_prob figure per row
     train_tf = f_train * B / (train_kernel_ms * 1e-3) / 1e12
     ttraffic, ttraffic_src = pmc_traffic("train") if a.workload == "maf_cfg2" else (None, None)
-    kname = (("k_maf_samp16<NB,SPAN,HM,TPW,DD>" if desc.get("m16_ok") and not a.hidden_bf16 else "k_sample_persist<MafOps>")
+    kname = "k_ar_sample (one wave per 64 draws, one hyper-network sweep per transform)" if wl["kind"] == "nsf_ar" else \
+            (("k_maf_samp16<NB,SPAN,HM,TPW,DD>" if desc.get("m16_ok") and not a.hidden_bf16 else "k_sample_persist<MafOps>")
              if wl["kind"] == "maf" else
              ("k_sample_persist<NsfOps<..., BF = 2>> (sampler image, split-bf16 hidden blocks)" if desc.get("nsf_split_sampler") and
               not a.hidden_bf16 else "k_sample_persist<NsfOps>"))
@@ -708,7 +728,9 @@ def main():
     tpath = flow.train_path(B)
     tkname = ({1: "k_maf_trainc<TS,NI,NT,1> (cooperative 16-row tiles, 4 waves per 32 samples)",
                2: "k_maf_trainc<TS,NI,NT,2> (cooperative 16-row tiles, 8 waves per 64 samples)",
-               3: "k_nsf_trainc<NT,OTQ> (cooperative 16-row tiles, 4 waves per 32 samples, conditioner recomputed in the backward sweep)"}.get(tpath)
+               3: "k_nsf_trainc<NT,OTQ> (cooperative 16-row tiles, 4 waves per 32 samples, conditioner recomputed in the backward sweep)",
+               4: "sf_nsf1: context MLPs (k_mlp_*) + k_nsf1_train",
+               5: "k_ar_train<NWV> (64 samples per workgroup, MFMA tiles on masked images)"}.get(tpath)
               or ("k_maf_train<HT>" if wl["kind"] == "maf" else "k_nsf_train<HT,PT>"))
     observed_world = dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1
     observed_backend = dist.get_backend() if (world > 1 and dist.is_initialized()) else "none (single process, no process group)"

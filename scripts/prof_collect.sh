@@ -4,7 +4,8 @@
 #   2. three separate --pmc passes of the default bench (FETCH_SIZE | WRITE_SIZE | SQ_*)  -> per-kernel counter rows
 #   3. the same for the NSF workload of BASELINE configs[2] (bench.py --workload nsf_cfg3)
 #   4. un-profiled bench lines of both workloads
-#   5. (round 4) bench.py --workload nsf_prod: the reference's production NSF (T = 15, H = 69, K = 10)
+#   5. (round 4) bench.py --workload nsf_prod: the reference's production NSF (T = 15, H = 69, K = 10);
+#      bench.py --workload nsfar_cfg2: the lampe backend's autoregressive NSF on the cfg2 mock (with its CPU baseline)
 # Only small summaries are kept (gpurun_out/prof_rNN/); scripts/make_pmc_summary.py rNN turns them into
 # profiles/rNN_pmc_summary.json, which bench.py reads `traffic` / `issue_busy` from.
 set -e
@@ -82,5 +83,7 @@ say "default bench done"
 python3 bench.py --workload nsf_cfg3 --no-cpu-baseline > $OUT/bench_nsf_cfg3.json 2> $OUT/bench_nsf_cfg3.err
 python3 bench.py --workload nsf_prod --no-cpu-baseline --skip-large-catalogue > $OUT/bench_nsf_prod.json 2> $OUT/bench_nsf_prod.err
 say "nsf_prod bench done"
+python3 bench.py --workload nsfar_cfg2 --skip-large-catalogue > $OUT/bench_nsfar_cfg2.json 2> $OUT/bench_nsfar_cfg2.err
+say "nsfar_cfg2 bench done"
 say "all done"
 ls -la $OUT

@@ -144,6 +144,8 @@ void sf_flow_destroy(sf_flow* f) {
     if (f->dev_ready) (void)hipFree(f->d_flat);
     if (f->ev_train[0]) (void)hipEventDestroy(f->ev_train[0]);
     if (f->ev_train[1]) (void)hipEventDestroy(f->ev_train[1]);
+    if (f->ev_dense[0]) (void)hipEventDestroy(f->ev_dense[0]);
+    if (f->ev_dense[1]) (void)hipEventDestroy(f->ev_dense[1]);
     delete f;
     return;
   }
@@ -832,9 +834,17 @@ int sf_flow_sample(sf_flow* f, const float* x, int64_t M, int64_t S, const float
     uint32_t k0, k1;
     seed_keys(seed, 0u, k0, k1);
     std::string err;
+    if (!f->ev_dense[0]) { SF_HIP(hipEventCreate(&f->ev_dense[0])); SF_HIP(hipEventCreate(&f->ev_dense[1])); }
+    int64_t unf = 0;
     int rc = sf_nsfar_sample(f->nsfar, x, (long)M, (long)S, nullptr, (long)(M * S), lo, hi, k0, k1,
-                             (unsigned long long)f->sample_row_offset * (unsigned long long)S, max_attempts, out, n_drawn, nullptr, n_unfilled, st, err);
-    return rc ? fail(rc, err) : SF_OK;
+                             (unsigned long long)f->sample_row_offset * (unsigned long long)S, max_attempts, out, n_drawn, nullptr, &unf, st, err,
+                             f->ev_dense[0], f->ev_dense[1]);
+    if (rc) return fail(rc, err);
+    if (n_unfilled) *n_unfilled = unf;
+    float ms = 0.f;   // (the counters' read-back has synchronised the stream)
+    SF_HIP(hipEventElapsedTime(&ms, f->ev_dense[0], f->ev_dense[1]));
+    f->last_stats[0] = ms; f->last_stats[1] = 1.f; f->last_stats[2] = (float)f->nsfar->last_rej0; f->last_stats[3] = (float)f->nsfar->last_evals;
+    return SF_OK;
   }
   if (n_drawn) SF_HIP(sf_launch_fill_i32(n_drawn, (long)M, (int32_t)S, st));
   return sample_persistent(f, x, M, S, nullptr, M * S, lo, hi, seed, max_attempts, out, n_drawn, n_unfilled, st);

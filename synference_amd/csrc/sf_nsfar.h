@@ -28,7 +28,8 @@ struct SfNsfAr {
   size_t ustash_cap = 0;
   int32_t* d_gal = nullptr;              // [2][M]: attempts / accepted draws per row (progress rule of the uncapped sampler)
   size_t gal_cap = 0;
-  unsigned long long* d_ctr = nullptr;   // [0] work cursor of the sampler, [1] slots written off
+  unsigned long long* d_ctr = nullptr;   // [0] work cursor of the sampler, [1] slots written off, [2] evaluations, [3] first attempts rejected
+  double last_evals = 0.0, last_rej0 = 0.0;   // of the last sampling call that read the counters back
 };
 
 int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err);
@@ -41,6 +42,7 @@ int sf_nsfar_inverse(SfNsfAr* n, const float* z, const float* x, long B, float* 
 // count != null: acceptance counting (one attempt per item, item i belongs to row i / S); else the rejection sampler
 int sf_nsfar_sample(SfNsfAr* n, const float* x, long M, long S, const uint32_t* slots, long n_slots, const float* lo, const float* hi,
                     uint32_t k0, uint32_t k1, unsigned long long slot_offset, int max_attempts, float* out, int32_t* n_drawn,
-                    int32_t* count, int64_t* n_unfilled, hipStream_t st, std::string& err);
+                    int32_t* count, int64_t* n_unfilled, hipStream_t st, std::string& err, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 int sf_nsfar_loss_grad(SfNsfAr* n, const float* flat, const float* theta, const float* x, const long long* idx, long B, float grad_scale,
-                       const float* weights, float* loss, double* loss_sum, float* grad, hipStream_t st, std::string& err);
+                       const float* weights, float* loss, double* loss_sum, float* grad, hipStream_t st, std::string& err, hipEvent_t ev0 = nullptr,
+                       hipEvent_t ev1 = nullptr);

@@ -384,6 +384,7 @@ __global__ __launch_bounds__(64) void k_ar_sample(ArArgs a, const float* __restr
                                                    float* __restrict__ out, int32_t* __restrict__ n_drawn, int32_t* __restrict__ count,
                                                    unsigned long long* __restrict__ cursor, unsigned int* __restrict__ n_unfilled,
                                                    int32_t* __restrict__ g_try, int32_t* __restrict__ g_acc) {
+  // cursor[2]: evaluations (items worked), cursor[3]: first attempts rejected -- statistics for sf_flow_sample_stats
   extern __shared__ float lds[];
   float* E0 = lds;
   float* H1 = E0 + a.NIN16 * RS;
@@ -395,25 +396,51 @@ __global__ __launch_bounds__(64) void k_ar_sample(ArArgs a, const float* __restr
   const int lane = threadIdx.x;
   const ZSplC sc = {a.K, a.B, a.cw, a.cd};
   for (int r = a.D + a.C; r < a.NIN16; ++r) E0[r * RS + lane] = 0.f;
+  // Whole-catalogue calls walk the slots ACROSS the rows (item i = draw i / M of row i % M): the 64 items of a wave belong to 64
+  // rows, so a row that accepts one draw in hundreds leaves ONE stubborn entry in many waves instead of 64 in a few.  Once the
+  // list has run dry a wave spends its idle lanes on its open entries: W = 2^k <= 64 / entries attempts of each side by side,
+  // the LOWEST accepted attempt wins (what the one-at-a-time order would have kept), the rest is discarded.
+  const unsigned long long Mrows = (unsigned long long)n_slots / (unsigned long long)S;
+  const bool interleave = !slots && !count && Mrows > 1 && Mrows * (unsigned long long)S == (unsigned long long)n_slots;
   int n_retry = 0;
+  bool list_done = false;
   for (;;) {
-    const int take = 64 - n_retry;
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(cursor, (unsigned long long)take);
-    base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-    unsigned long long slot = 0;
-    uint32_t att = 0;
-    bool active;
-    if (lane < n_retry) {
-      slot = r_slot[lane]; att = r_att[lane]; active = true;
-    } else {
-      const unsigned long long idx = base + (unsigned)(lane - n_retry);
-      active = idx < (unsigned long long)n_slots;
-      if (active) slot = slots ? (unsigned long long)slots[idx] : idx;
+    const int take = list_done ? 0 : 64 - n_retry;
+    unsigned long long base = (unsigned long long)n_slots;
+    if (take > 0) {
+      if (lane == 0) base = atomicAdd(cursor, (unsigned long long)take);
+      base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)base);
     }
+    int n_fresh = 0;
+    if (take > 0) {
+      if (base >= (unsigned long long)n_slots) list_done = true;
+      else {
+        const unsigned long long left = (unsigned long long)n_slots - base;
+        n_fresh = left < (unsigned long long)take ? (int)left : take;
+        if (n_fresh < take) list_done = true;
+      }
+    }
+    const int n_ent = n_retry + n_fresh;
+    if (n_ent == 0) break;
+    int lw = 0;   // log2 of the speculation width
+    if (list_done && !count)
+      while ((n_ent << (lw + 1)) <= 64) ++lw;
+    const int W = 1 << lw;
+    const int e = lane >> lw, sub = lane & (W - 1);
+    unsigned long long slot = 0;
+    uint32_t att0 = 0;
+    bool active = e < n_ent;
+    if (active) {
+      if (e < n_retry) { slot = r_slot[e]; att0 = r_att[e]; }
+      else {
+        const unsigned long long idx = base + (unsigned)(e - n_retry);
+        slot = slots ? (unsigned long long)slots[idx] : (interleave ? (idx % Mrows) * (unsigned long long)S + idx / Mrows : idx);
+      }
+    }
+    const uint32_t att = att0 + (uint32_t)sub;
+    active = active && att < max_attempts;
     __syncthreads();   // (the retry list has been read)
-    if (__ballot(active) == 0ull) break;
-    const long g = active ? (long)(slot / (unsigned long long)S) : 0;
+    const long g = (e < n_ent) ? (long)(slot / (unsigned long long)S) : 0;
     for (int c = 0; c < a.C; ++c) E0[(a.D + c) * RS + lane] = (x[g * a.C + c] - a.xmean[c]) / a.xstd[c];
     for (int d0 = 0; d0 < a.D; d0 += 4) {
       float z4[4];
@@ -432,28 +459,46 @@ __global__ __launch_bounds__(64) void k_ar_sample(ArArgs a, const float* __restr
       V[d * RS + lane] = th;
       ok = ok && (th == th) && fabsf(th) < 3.0e38f && (!lo || (th >= lo[d] && th <= hi[d]));
     }
+    const unsigned long long m_ok = __ballot(ok);
+    {
+      const unsigned long long ma = __ballot(active), mr = __ballot(active && !ok && att == 0u);
+      if (lane == 0) {
+        atomicAdd(cursor + 2, (unsigned long long)__popcll(ma));
+        if (mr) atomicAdd(cursor + 3, (unsigned long long)__popcll(mr));
+      }
+    }
     if (count) {   // acceptance counting (leakage correction): one attempt per item, nothing written
       if (ok) atomicAdd(count + g, 1);
       n_retry = 0;
       continue;
     }
-    bool give_up = active && !ok && att + 1u >= max_attempts;
-    if (g_try && active) {   // no ceiling asked for: a row whose open slots spent 1e5 attempts without ONE accepted draw is written off
-      const int tried = atomicAdd(g_try + g, 1) + 1;
-      if (ok) atomicAdd(g_acc + g, 1);
+    // the entry's lanes: [e W, e W + W); its lowest accepted attempt
+    const unsigned long long grp = W == 64 ? m_ok : ((m_ok >> (e * W)) & ((1ull << W) - 1ull));
+    const bool resolved = grp != 0ull;
+    const int win = resolved ? __builtin_ctzll(grp) : 0;
+    const bool leader = e < n_ent && sub == 0;
+    const uint32_t tried_now = att0 + (uint32_t)W < max_attempts ? (uint32_t)W : max_attempts - att0;   // attempts of this round that count
+    bool give_up = leader && !resolved && att0 + (uint32_t)W >= max_attempts;
+    if (g_try && leader) {   // no ceiling asked for: a row whose open slots spent 1e5 attempts without ONE accepted draw is written off
+      const int tried = atomicAdd(g_try + g, (int)(resolved ? win + 1 : (int)tried_now)) + (int)(resolved ? win + 1 : (int)tried_now);
+      if (resolved) atomicAdd(g_acc + g, 1);
       else if (tried >= 100000 && __hip_atomic_load(g_acc + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) give_up = true;
     }
-    if (active && (ok || give_up)) {
-      for (int d = 0; d < a.D; ++d) out[slot * a.D + d] = ok ? V[d * RS + lane] : __builtin_nanf("");
+    if (ok && sub == win) {   // the winner writes the draw
+      for (int d = 0; d < a.D; ++d) out[slot * a.D + d] = V[d * RS + lane];
       if (n_drawn) sf_sat_add(n_drawn + g, (int32_t)(att + 1u));
-      if (give_up) atomicAdd(n_unfilled, 1u);
     }
-    const bool again = active && !ok && !give_up;
+    if (give_up) {
+      for (int d = 0; d < a.D; ++d) out[slot * a.D + d] = __builtin_nanf("");
+      if (n_drawn) sf_sat_add(n_drawn + g, (int32_t)(att0 + tried_now));
+      atomicAdd(n_unfilled, 1u);
+    }
+    const bool again = leader && !resolved && !give_up;
     const unsigned long long m = __ballot(again);
     if (again) {
       const int pos = __popcll(m & ((1ull << lane) - 1ull));
       r_slot[pos] = slot;
-      r_att[pos] = att + 1u;
+      r_att[pos] = att0 + (uint32_t)W;
     }
     n_retry = __popcll(m);
     __syncthreads();
@@ -811,7 +856,7 @@ static int ar_ensure(SfNsfAr* n, std::string& err) {
   AR_HIP(hipMalloc(&n->d_img, n->src.size() * sizeof(float)));
   AR_HIP(up(n->d_src, n->src)); AR_HIP(up(n->d_perm, n->perm)); AR_HIP(up(n->d_ptype, n->ptype)); AR_HIP(up(n->d_tend, n->tend));
   AR_HIP(up(n->d_ord, n->ord)); AR_HIP(up(n->d_dimof, n->dimof)); AR_HIP(up(n->d_xmean, n->h_xmean)); AR_HIP(up(n->d_xstd, n->h_xstd));
-  AR_HIP(hipMalloc(&n->d_ctr, 2 * sizeof(unsigned long long)));
+  AR_HIP(hipMalloc(&n->d_ctr, 4 * sizeof(unsigned long long)));
   {
     const std::vector<int32_t> none(n->src.size(), -1);
     AR_HIP(up(n->d_none, none));
@@ -884,8 +929,8 @@ int sf_nsfar_inverse(SfNsfAr* n, const float* z, const float* x, long B, float* 
 
 int sf_nsfar_sample(SfNsfAr* n, const float* x, long M, long S, const uint32_t* slots, long n_slots, const float* lo, const float* hi,
                     uint32_t k0, uint32_t k1, unsigned long long slot_offset, int max_attempts, float* out, int32_t* n_drawn,
-                    int32_t* count, int64_t* n_unfilled, hipStream_t st, std::string& err) {
-  AR_HIP(hipMemsetAsync(n->d_ctr, 0, 2 * sizeof(unsigned long long), st));
+                    int32_t* count, int64_t* n_unfilled, hipStream_t st, std::string& err, hipEvent_t ev0, hipEvent_t ev1) {
+  AR_HIP(hipMemsetAsync(n->d_ctr, 0, 4 * sizeof(unsigned long long), st));
   int dev = 0, cus = 256;
   hipDeviceProp_t pr;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
@@ -906,20 +951,25 @@ int sf_nsfar_sample(SfNsfAr* n, const float* x, long M, long S, const uint32_t* 
     AR_HIP(hipMemsetAsync(n->d_gal, 0, (size_t)(2 * M) * sizeof(int32_t), st));
     g_try = n->d_gal;
   }
+  if (ev0) AR_HIP(hipEventRecord(ev0, st));
   hipLaunchKernelGGL(k_ar_sample, dim3((unsigned)grid), dim3(64), lds, st, args_of(*n), x, S, slots, n_slots, lo, hi, k0, k1, slot_offset, cap, out,
                      n_drawn, count, n->d_ctr, reinterpret_cast<unsigned int*>(n->d_ctr + 1), g_try, g_try ? g_try + M : nullptr);
   AR_HIP(hipGetLastError());
+  if (ev1) AR_HIP(hipEventRecord(ev1, st));
   if (n_unfilled) {
-    unsigned long long h[2] = {0, 0};
+    unsigned long long h[4] = {0, 0, 0, 0};
     AR_HIP(hipMemcpyAsync(h, n->d_ctr, sizeof(h), hipMemcpyDeviceToHost, st));
     AR_HIP(hipStreamSynchronize(st));
     *n_unfilled = (int64_t)(unsigned int)h[1];
+    n->last_evals = (double)h[2];
+    n->last_rej0 = (double)h[3];
   }
   return SF_OK;
 }
 
 int sf_nsfar_loss_grad(SfNsfAr* n, const float* flat, const float* theta, const float* x, const long long* idx, long B, float grad_scale,
-                       const float* weights, float* loss, double* loss_sum, float* grad, hipStream_t st, std::string& err) {
+                       const float* weights, float* loss, double* loss_sum, float* grad, hipStream_t st, std::string& err, hipEvent_t ev0,
+                       hipEvent_t ev1) {
   int rc = sf_nsfar_pack(n, flat, st, err);
   if (rc) return rc;
   AR_HIP(hipMemsetAsync(grad, 0, (size_t)n->n_params * sizeof(float), st));
@@ -956,6 +1006,7 @@ int sf_nsfar_loss_grad(SfNsfAr* n, const float* flat, const float* theta, const 
     return SF_OK;
   }
 #endif
+  if (ev0) AR_HIP(hipEventRecord(ev0, st));
   if (ar_waves(*n, 3) == 4)
     hipLaunchKernelGGL(k_ar_train<4>, dim3((unsigned)((B + 63) / 64)), dim3(256), sf_nsfar_lds_bytes(*n, 3, 4), st, args_of(*n), theta, x, idx, B,
                        grad_scale, weights, loss, loss_sum, grad, n->d_ustash);
@@ -963,5 +1014,6 @@ int sf_nsfar_loss_grad(SfNsfAr* n, const float* flat, const float* theta, const 
     hipLaunchKernelGGL(k_ar_train<1>, dim3((unsigned)((B + 63) / 64)), dim3(64), sf_nsfar_lds_bytes(*n, 3, 1), st, args_of(*n), theta, x, idx, B,
                        grad_scale, weights, loss, loss_sum, grad, n->d_ustash);
   AR_HIP(hipGetLastError());
+  if (ev1) AR_HIP(hipEventRecord(ev1, st));
   return SF_OK;
 }

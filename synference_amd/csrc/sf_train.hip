@@ -300,7 +300,14 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
   }
   if (f->nsfar) {
     if (dctx) { err = "the autoregressive NSF has no context-gradient path"; return SF_ERR_INVALID; }
-    return sf_nsfar_loss_grad(f->nsfar, flat, theta, x, idx, B, grad_scale, weights, loss, loss_sum, grad, st, err);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (f->profiling) {
+      if (!f->ev_train[0]) { SF_TRY(hipEventCreate(&f->ev_train[0])); SF_TRY(hipEventCreate(&f->ev_train[1])); }
+      e0 = f->ev_train[0]; e1 = f->ev_train[1];
+    }
+    const int rc = sf_nsfar_loss_grad(f->nsfar, flat, theta, x, idx, B, grad_scale, weights, loss, loss_sum, grad, st, err, e0, e1);
+    if (!rc && f->profiling) f->ev_train_valid = true;
+    return rc;
   }
   // ---- cooperative 16-row kernels: MAF (sf_trainc.hip: two blocks, D <= 8, T <= SF_TRC_TS, <= 4 hidden tiles) and
   //      NSF (sf_nsfc.hip: two blocks, D <= 8, H <= 64, K <= 11); they share the image / gather machinery
