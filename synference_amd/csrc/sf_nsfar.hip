@@ -383,7 +383,8 @@ __global__ __launch_bounds__(64) void k_ar_sample(ArArgs a, const float* __restr
                                                    uint32_t k1, unsigned long long slot_offset, uint32_t max_attempts,
                                                    float* __restrict__ out, int32_t* __restrict__ n_drawn, int32_t* __restrict__ count,
                                                    unsigned long long* __restrict__ cursor, unsigned int* __restrict__ n_unfilled,
-                                                   int32_t* __restrict__ g_try, int32_t* __restrict__ g_acc) {
+                                                   int32_t* __restrict__ g_try, int32_t* __restrict__ g_acc, unsigned long long walk_R,
+                                                   unsigned long long walk_C) {
   // cursor[2]: evaluations (items worked), cursor[3]: first attempts rejected -- statistics for sf_flow_sample_stats
   extern __shared__ float lds[];
   float* E0 = lds;
@@ -396,26 +397,27 @@ __global__ __launch_bounds__(64) void k_ar_sample(ArArgs a, const float* __restr
   const int lane = threadIdx.x;
   const ZSplC sc = {a.K, a.B, a.cw, a.cd};
   for (int r = a.D + a.C; r < a.NIN16; ++r) E0[r * RS + lane] = 0.f;
-  // Whole-catalogue calls walk the slots ACROSS the rows (item i = draw i / M of row i % M): the 64 items of a wave belong to 64
-  // rows, so a row that accepts one draw in hundreds leaves ONE stubborn entry in many waves instead of 64 in a few.  Once the
-  // list has run dry a wave spends its idle lanes on its open entries: W = 2^k <= 64 / entries attempts of each side by side,
-  // the LOWEST accepted attempt wins (what the one-at-a-time order would have kept), the rest is discarded.
-  const unsigned long long Mrows = (unsigned long long)n_slots / (unsigned long long)S;
-  const bool interleave = !slots && !count && Mrows > 1 && Mrows * (unsigned long long)S == (unsigned long long)n_slots;
+  // The slot list is walked ACROSS its rows: item i is entry (i % R) * C + i / R of the list seen as R x C (whole catalogue:
+  // R = rows, C = draws per row, i.e. draw i / M of row i % M; an explicit list, sorted by slot: R = 4096 pieces) -- the 64 items
+  // of a wave then belong to 64 different rows, so a row that accepts one draw in hundreds leaves ONE stubborn entry in many
+  // waves instead of 64 in a few.  Once the list has run dry a wave spends its idle lanes on its open entries: W = 2^k <= 64 /
+  // entries attempts of each side by side, the LOWEST accepted attempt wins (what the one-at-a-time order would have kept).
+  const bool interleave = walk_R > 1;
+  const unsigned long long n_index = interleave ? walk_R * walk_C : (unsigned long long)n_slots;   // (>= n_slots: holes are skipped)
   int n_retry = 0;
   bool list_done = false;
   for (;;) {
     const int take = list_done ? 0 : 64 - n_retry;
-    unsigned long long base = (unsigned long long)n_slots;
+    unsigned long long base = n_index;
     if (take > 0) {
       if (lane == 0) base = atomicAdd(cursor, (unsigned long long)take);
       base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)base);
     }
     int n_fresh = 0;
     if (take > 0) {
-      if (base >= (unsigned long long)n_slots) list_done = true;
+      if (base >= n_index) list_done = true;
       else {
-        const unsigned long long left = (unsigned long long)n_slots - base;
+        const unsigned long long left = n_index - base;
         n_fresh = left < (unsigned long long)take ? (int)left : take;
         if (n_fresh < take) list_done = true;
       }
@@ -429,18 +431,20 @@ __global__ __launch_bounds__(64) void k_ar_sample(ArArgs a, const float* __restr
     const int e = lane >> lw, sub = lane & (W - 1);
     unsigned long long slot = 0;
     uint32_t att0 = 0;
-    bool active = e < n_ent;
-    if (active) {
+    bool exists = e < n_ent;   // (an entry of this round: a carried one, or a fresh item that is not a hole of the cover)
+    if (exists) {
       if (e < n_retry) { slot = r_slot[e]; att0 = r_att[e]; }
       else {
         const unsigned long long idx = base + (unsigned)(e - n_retry);
-        slot = slots ? (unsigned long long)slots[idx] : (interleave ? (idx % Mrows) * (unsigned long long)S + idx / Mrows : idx);
+        const unsigned long long pos = interleave ? (idx % walk_R) * walk_C + idx / walk_R : idx;
+        if (pos >= (unsigned long long)n_slots) exists = false;   // (a hole of the R x C cover)
+        else slot = slots ? (unsigned long long)slots[pos] : pos;
       }
     }
     const uint32_t att = att0 + (uint32_t)sub;
-    active = active && att < max_attempts;
+    const bool active = exists && att < max_attempts;
     __syncthreads();   // (the retry list has been read)
-    const long g = (e < n_ent) ? (long)(slot / (unsigned long long)S) : 0;
+    const long g = exists ? (long)(slot / (unsigned long long)S) : 0;
     for (int c = 0; c < a.C; ++c) E0[(a.D + c) * RS + lane] = (x[g * a.C + c] - a.xmean[c]) / a.xstd[c];
     for (int d0 = 0; d0 < a.D; d0 += 4) {
       float z4[4];
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(64) void k_ar_sample(ArArgs a, const float* __restr
     const unsigned long long grp = W == 64 ? m_ok : ((m_ok >> (e * W)) & ((1ull << W) - 1ull));
     const bool resolved = grp != 0ull;
     const int win = resolved ? __builtin_ctzll(grp) : 0;
-    const bool leader = e < n_ent && sub == 0;
+    const bool leader = exists && sub == 0;
     const uint32_t tried_now = att0 + (uint32_t)W < max_attempts ? (uint32_t)W : max_attempts - att0;   // attempts of this round that count
     bool give_up = leader && !resolved && att0 + (uint32_t)W >= max_attempts;
     if (g_try && leader) {   // no ceiling asked for: a row whose open slots spent 1e5 attempts without ONE accepted draw is written off
@@ -931,9 +935,12 @@ int sf_nsfar_sample(SfNsfAr* n, const float* x, long M, long S, const uint32_t* 
                     uint32_t k0, uint32_t k1, unsigned long long slot_offset, int max_attempts, float* out, int32_t* n_drawn,
                     int32_t* count, int64_t* n_unfilled, hipStream_t st, std::string& err, hipEvent_t ev0, hipEvent_t ev1) {
   AR_HIP(hipMemsetAsync(n->d_ctr, 0, 4 * sizeof(unsigned long long), st));
-  int dev = 0, cus = 256;
-  hipDeviceProp_t pr;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+  static int cus = 0;   // (asked once: the query costs more than a small sampling call)
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+  }
   const size_t lds = sf_nsfar_lds_bytes(*n, 2, 1);
   const long per_cu = (long)((size_t)160 * 1024 / (lds + 1024));
   long grid = (long)cus * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
@@ -952,8 +959,13 @@ int sf_nsfar_sample(SfNsfAr* n, const float* x, long M, long S, const uint32_t* 
     g_try = n->d_gal;
   }
   if (ev0) AR_HIP(hipEventRecord(ev0, st));
+  unsigned long long walk_R = 0, walk_C = 0;
+  if (!count && n_slots >= 4096) {
+    if (!slots && M > 1 && (long)(M * S) == n_slots) { walk_R = (unsigned long long)M; walk_C = (unsigned long long)S; }
+    else { walk_R = 4096; walk_C = ((unsigned long long)n_slots + walk_R - 1) / walk_R; }
+  }
   hipLaunchKernelGGL(k_ar_sample, dim3((unsigned)grid), dim3(64), lds, st, args_of(*n), x, S, slots, n_slots, lo, hi, k0, k1, slot_offset, cap, out,
-                     n_drawn, count, n->d_ctr, reinterpret_cast<unsigned int*>(n->d_ctr + 1), g_try, g_try ? g_try + M : nullptr);
+                     n_drawn, count, n->d_ctr, reinterpret_cast<unsigned int*>(n->d_ctr + 1), g_try, g_try ? g_try + M : nullptr, walk_R, walk_C);
   AR_HIP(hipGetLastError());
   if (ev1) AR_HIP(hipEventRecord(ev1, st));
   if (n_unfilled) {

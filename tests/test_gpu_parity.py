@@ -151,6 +151,16 @@ def test_autoregressive_nsf_slots_acceptance_and_exhaustion():
     acc = f.acceptance(x, 4000, lo, hi, seed=11).cpu().numpy()
     racc = OP.acceptance(ospec, torch.as_tensor(flat), x, 4000, 11, lo, hi)
     assert np.abs(acc - racc).max() < 2e-3, (acc, racc)
+    # a long list (>= 4096 entries: walked across 4096 pieces, the cover has holes) against the whole-catalogue call
+    xb = np.tile(x, (13, 1))[:64]
+    big = f.sample(xb, 256, lo, hi, seed=33)
+    lst = torch.arange(1, 64 * 256, 3, dtype=torch.int32, device="cuda")
+    part = torch.full_like(big, float("nan"))
+    assert f.sample_slots(xb, 256, lst, part, lo, hi, seed=33) == 0
+    assert torch.equal(part.reshape(-1, spec.D)[lst.long()], big.reshape(-1, spec.D)[lst.long()])
+    untouched = torch.ones(64 * 256, dtype=torch.bool, device="cuda")
+    untouched[lst.long()] = False
+    assert torch.isnan(part.reshape(-1, spec.D)[untouched]).all()
     far_lo, far_hi = (hi + 50.0).astype(np.float32), (hi + 51.0).astype(np.float32)
     got, nd = f.sample(x[:2], 8, far_lo, far_hi, seed=1, max_attempts=5, return_counts=True)
     assert torch.isnan(got).all() and f.last_unfilled == 16 and (nd.cpu().numpy() == 8 * 5).all()
