@@ -781,6 +781,7 @@ def main():
                   "batch64_pairs_per_s_1gpu": pairs64, "batch64_ms_per_step": 1e3 * t64 / 200,
                   "allreduce_us": allreduce_us,
                   "step_as_hip_graph": graph_used, "ms_per_step_python_loop": 1e3 * t_plain / tsteps,
+                  "ms_per_step_epoch_call": (1e3 * t_epoch / tsteps) if (world == 1 and tsteps >= 4) else None,
                   "throughput_regime": {"per_gpu_batch": Bbig, "kernel_ms": big_kernel_ms,
                                         "achieved_tflops": f_train * Bbig / (big_kernel_ms * 1e-3) / 1e12,
                                         "frac": f_train * Bbig / (big_kernel_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS},

@@ -156,7 +156,7 @@ void sf_flow_destroy(sf_flow* f) {
     (void)hipFree(f->d_s1); (void)hipFree(f->d_s2); (void)hipFree(f->d_t1); (void)hipFree(f->d_t2);
     (void)hipFree(f->d_flat); (void)hipFree(f->d_gpacked); (void)hipFree(f->d_gdst);
     (void)hipFree(f->d_imgC); (void)hipFree(f->d_sC1); (void)hipFree(f->d_sC2); (void)hipFree(f->d_gdstC); (void)hipFree(f->d_gsrcC); (void)hipFree(f->d_gzeroC); (void)hipFree(f->d_gpartC); (void)hipFree(f->d_gfixC); (void)hipFree(f->d_ustash);
-    (void)hipFree(f->d_queue); (void)hipFree(f->d_ring); (void)hipFree(f->d_galacc); (void)hipFree(f->d_best); (void)hipHostFree(f->h_queue);
+    (void)hipFree(f->d_queue); (void)hipFree(f->d_ring); (void)hipFree(f->d_galacc); (void)hipFree(f->d_sqpart); (void)hipFree(f->d_losspart_mem); (void)hipFree(f->d_best); (void)hipHostFree(f->h_queue);
     (void)hipFree(f->d_act); (void)hipFree(f->d_rej[0]); (void)hipFree(f->d_rej[1]); (void)hipFree(f->d_cnt);
     if (f->step_exec) (void)hipGraphExecDestroy(f->step_exec);
     if (f->step_graph) (void)hipGraphDestroy(f->step_graph);
@@ -978,11 +978,40 @@ int sf_flow_train_epoch(sf_flow* f, float* flat, const float* theta, const float
   if (!f || !flat || !theta || !x || !order || !exp_avg || !exp_avg_sq || !d || !scratch || !grad)
     return fail(SF_ERR_INVALID, "null argument");
   if (n_batches < 0 || batch < 1 || step0 < 0) return fail(SF_ERR_INVALID, "bad n_batches, batch or step0");
+  // (the gather of the step leaves |grad|^2 in per-block shares for the clip: the optimiser kernel then skips its pass over the
+  //  whole gradient -- one L2 round trip less in a step that is a chain of them)
+  struct WantSq { sf_flow* f; explicit WantSq(sf_flow* f_) : f(f_) { f->want_sq = true; } ~WantSq() { f->want_sq = false; f->n_sqpart = 0; } } want_sq(f);
+  // ... and the kernels add their loss sums to one of SF_LOSS_PARTS scalars instead of all to the caller's (folded in below)
+  if (loss_sum && !f->d_losspart_mem) {
+    if (hipMalloc(&f->d_losspart_mem, SF_LOSS_PARTS * sizeof(double)) == hipSuccess)
+      (void)hipMemsetAsync(f->d_losspart_mem, 0, SF_LOSS_PARTS * sizeof(double), (hipStream_t)stream);
+    else { f->d_losspart_mem = nullptr; (void)hipGetLastError(); }
+  }
+  struct Spread {
+    sf_flow* f; double* out; hipStream_t st;
+    Spread(sf_flow* f_, double* o, hipStream_t s) : f(f_), out(o), st(s) { f->d_losspart = o ? f->d_losspart_mem : nullptr; f->losspart_used = false; }
+    ~Spread() {
+      if (f->d_losspart && f->losspart_used) (void)sf_launch_fold_loss(f->d_losspart, SF_LOSS_PARTS, out, st);
+      f->d_losspart = nullptr;
+    }
+  } spread(f, loss_sum, (hipStream_t)stream);
   auto plain_step = [&](int64_t b) -> int {
+    f->n_sqpart = 0;
+    f->prep_lite = b + 1 < n_batches;   // (the last step of the call re-tiles every image)
     int rc = sf_flow_loss_grad_rows(f, flat, theta, x, order + b * batch, batch, grad_scale, nullptr, nullptr, loss_sum, grad,
                                     nullptr, stream);
-    if (rc) return rc;
-    return sf_adam_apply(flat, grad, exp_avg, exp_avg_sq, f->L.n_params, d, step0 + b + 1, max_norm, scratch, stream);
+    if (rc) {   // (the density / sampler images may lag behind: nothing may use them before the next sf_flow_set_params)
+      f->prep_lite = false;
+      if (f->packed_stale) f->params_set = false;
+      return rc;
+    }
+    const int64_t step = step0 + b + 1;
+    const double bc1 = 1.0 - std::pow((double)d->beta1, (double)step), bc2 = 1.0 - std::pow((double)d->beta2, (double)step);
+    hipError_t e = sf_launch_adam(flat, grad, exp_avg, exp_avg_sq, scratch, (long)f->L.n_params, *d, (float)bc1, (float)bc2, max_norm,
+                                  scratch + 1, (hipStream_t)stream, nullptr, f->n_sqpart > 0 ? f->d_sqpart : nullptr, f->n_sqpart);
+    f->prep_lite = false;
+    if (e != hipSuccess) return hip_fail(e, "sf_launch_adam");
+    return SF_OK;
   };
   // ---- the step as ONE captured HIP graph, replayed per batch.  What changes from step to step -- the batch's rows and Adam's
   // bias correction -- lives on the device: k_step_begin copies rows [ctr[0] * batch, ...) of `order` into a fixed buffer the
@@ -1040,7 +1069,7 @@ int sf_flow_train_epoch(sf_flow* f, float* flat, const float* theta, const float
           if (!rc2) rc2 = sf_flow_loss_grad_rows(f, flat, theta, x, reinterpret_cast<const int64_t*>(f->d_step_rows), batch, grad_scale, nullptr,
                                                  nullptr, loss_sum, grad, nullptr, cs);
           if (!rc2 && !hip_ok(sf_launch_adam(flat, grad, exp_avg, exp_avg_sq, scratch, (long)f->L.n_params, *d, 1.f, 1.f, max_norm,
-                                             scratch + 1, cs, f->d_step_bc))) rc2 = SF_ERR_HIP;
+                                             scratch + 1, cs, f->d_step_bc, f->n_sqpart > 0 ? f->d_sqpart : nullptr, f->n_sqpart))) rc2 = SF_ERR_HIP;
           if (!rc2 && !hip_ok(sf_launch_step_end(f->d_step_ctr, cs))) rc2 = SF_ERR_HIP;
           hipGraph_t g = nullptr;
           const bool ended = hip_ok(hipStreamEndCapture(cs, &g));

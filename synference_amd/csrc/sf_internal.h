@@ -125,6 +125,7 @@ struct SfResidentCache {
 void sf_set_error(const std::string& msg);  // thread-local message behind sf_last_error()
 
 // ---- the handle (shared by sf_api.hip and sf_train.hip) -------------------------------------
+#define SF_LOSS_PARTS 64
 #define SF_MAX_ROUNDS 80
 struct SfNsf1;
 struct sf_flow {
@@ -185,6 +186,18 @@ struct sf_flow {
   uint32_t* d_best = nullptr;    // deep-tail windows: lowest accepted attempt per survivor (find launch -> resolve launch)
   size_t best_cap = 0;
   size_t galacc_cap = 0;
+  // per-block shares of |grad|^2 from the gather of the last loss_grad (epoch loop only: want_sq); n_sqpart = 0: none
+  float* d_sqpart = nullptr;
+  size_t sqpart_cap = 0;
+  int n_sqpart = 0;
+  bool want_sq = false;
+  bool prep_lite = false;     // epoch call, not its last step: only the cooperative training image is re-tiled per step
+  bool packed_stale = false;  // the density / sampler images lag behind the training image (cleared by the next full re-tiling)
+  // loss sums of an epoch call spread over SF_LOSS_PARTS device scalars (non-null only inside sf_flow_train_epoch), folded into
+  // the caller's scalar at its end
+  double* d_losspart = nullptr;
+  double* d_losspart_mem = nullptr;
+  bool losspart_used = false;
   uint32_t* d_cnt = nullptr;     // SF_MAX_ROUNDS rejected-slot counters (one per round of a sf_flow_sample call)
   uint32_t* h_cnt = nullptr;     // pinned host mirror for the per-round read-back
   long long sample_row_offset = 0;   // sf_flow_set_sample_row_offset: first row of the next sampling calls in its catalogue

@@ -20,7 +20,8 @@ struct SfNscArgs {
   long B, n_chunks;      // n_chunks = ceil(B / 32)
   float w;
   float* loss;           // [B] or null
-  double* loss_sum;      // optional device scalar
+  double* loss_sum;      // optional device scalar -- or, loss_mask != 0, loss_mask + 1 scalars: workgroup i adds to [i & loss_mask]
+  int loss_mask;
   // gradient accumulation target: one partial of gpart_stride floats per workgroup (plain stores, summed by k_gather_c2 in
   // workgroup order), or -- fix != null -- SF_FIX_REPLICAS zeroed int64 images of gpart_stride entries: the workgroup adds
   // 2^-40 fixed-point contributions into the replica of its XCD with integer atomics that stay in that XCD's L2

@@ -599,7 +599,7 @@ __global__ __launch_bounds__(64 * (NT > 4 ? NT : 4), (NT > 4 ? 1 : 2)) void k_ns
 #pragma unroll
           for (int o = 8; o > 0; o >>= 1) tsum += __shfl_xor(tsum, o, 64);
           // values on a 2^-20 grid add exactly in double: the sum does not depend on the order of the atomics
-          if (lane == 0) atomicAdd(a.loss_sum, (double)rintf(tsum * 1048576.0f) * (1.0 / 1048576.0));
+          if (lane == 0) atomicAdd(a.loss_sum + (blockIdx.x & a.loss_mask), (double)rintf(tsum * 1048576.0f) * (1.0 / 1048576.0));
         }
 #pragma unroll
         for (int p = 0; p < 8; ++p) G[p] = wgt * u[p];

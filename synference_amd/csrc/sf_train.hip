@@ -65,7 +65,8 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
 __global__ __launch_bounds__(1024) void k_adam_fused(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, float* __restrict__ sq_out, long n,
                                                     sf_adam_desc d, float bc1, float bc2, float max_norm,
-                                                    float* __restrict__ norm_out, const float* __restrict__ bc_dev) {
+                                                    float* __restrict__ norm_out, const float* __restrict__ bc_dev,
+                                                    const float* __restrict__ sq_part, int n_sq) {
   if (bc_dev) { bc1 = bc_dev[0]; bc2 = bc_dev[1]; }
   // Everything this thread will need is requested before anything is waited for: its own elements of p / m / v / g (one
   // float4 each for n <= 4096 x blocks: the common case) AND its eight float4 of the gradient for the norm -- the kernel
@@ -81,7 +82,9 @@ __global__ __launch_bounds__(1024) void k_adam_fused(float* __restrict__ p, cons
     vo = reinterpret_cast<const float4*>(v)[own]; go = g4[own];
   }
   float s = 0.f;
-  {
+  if (sq_part) {   // the gather left the norm in n_sq shares: one short strided read instead of the whole gradient
+    for (int i = threadIdx.x; i < n_sq; i += 1024) s += sq_part[i];
+  } else {
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (long i = threadIdx.x; i < n4; i += 8 * 1024) {
       float4 q[8];
@@ -141,6 +144,20 @@ __global__ __launch_bounds__(1024) void k_adam_fused(float* __restrict__ p, cons
   }
 }
 
+// the spread loss sums of an epoch call (SfTrcArgs::loss_mask) -> the caller's scalar; the parts are zeroed for the next call
+// (values on a 2^-20 grid: the double adds are exact in any order)
+__global__ void k_fold_loss(double* __restrict__ part, int n, double* __restrict__ out) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) { s += part[i]; part[i] = 0.0; }
+    *out += s;
+  }
+}
+hipError_t sf_launch_fold_loss(double* part, int n, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_fold_loss, dim3(1), dim3(64), 0, st, part, n, out);
+  return hipGetLastError();
+}
+
 // start of a captured training step (sf_flow_train_epoch): the rows of batch number ctr[0] of the epoch's order -> rows_buf,
 // the bias corrections of Adam step ctr[1] + 1 -> bc[0..1]; both counters advance
 __global__ void k_step_begin(const long long* __restrict__ order, long long* __restrict__ ctr, long batch, long long* __restrict__ rows_buf,
@@ -171,11 +188,11 @@ hipError_t sf_launch_step_end(long long* ctr, hipStream_t st) {
 
 hipError_t sf_launch_adam(float* params, const float* grad, float* m, float* v, float* norm_scratch, long n,
                           const sf_adam_desc& d, float bc1, float bc2, float max_norm, float* grad_norm_out,
-                          hipStream_t st, const float* bc_dev) {
+                          hipStream_t st, const float* bc_dev, const float* sq_part, int n_sq) {
   if (n <= 131072 && ((uintptr_t)grad & 15) == 0) {  // (the fused kernel reads the gradient as float4)
     const int nb = (int)((n + 4095) / 4096);
     hipLaunchKernelGGL(k_adam_fused, dim3(nb < 1 ? 1 : nb), dim3(1024), 0, st, params, grad, m, v, norm_scratch, n, d, bc1,
-                       bc2, max_norm, grad_norm_out, bc_dev);
+                       bc2, max_norm, grad_norm_out, bc_dev, sq_part, n_sq);
     return hipGetLastError();
   }
   hipError_t e = hipMemsetAsync(norm_scratch, 0, sizeof(float), st);
@@ -288,6 +305,22 @@ SF_TDECL(1) SF_TDECL(2) SF_TDECL(3) SF_TDECL(4)
     }                                                                        \
   } while (0)
 
+// The epoch loop (sf_flow_train_epoch) asks the gather for the per-block shares of |grad|^2: returns the buffer (grown on demand)
+// and notes how many shares the gradient of THIS call comes with; null when nobody asked or the buffer cannot be had.
+static float* sq_for(sf_flow* f, const SfLayout& L) {
+  f->n_sqpart = 0;
+  if (!f->want_sq) return nullptr;
+  const long nb = sf_gather_c2_blocks((long)L.n_gradC, f->n_gzeroC);
+  if ((size_t)nb > f->sqpart_cap) {
+    (void)hipFree(f->d_sqpart);
+    f->d_sqpart = nullptr; f->sqpart_cap = 0;
+    if (hipMalloc(&f->d_sqpart, (size_t)nb * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    f->sqpart_cap = (size_t)nb;
+  }
+  f->n_sqpart = (int)nb;
+  return f->d_sqpart;
+}
+
 int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const float* x, const long long* idx, long B,
                        float grad_scale, const float* weights, float* loss, double* loss_sum, float* grad, float* dctx,
                        hipStream_t st, std::string& err) {
@@ -382,18 +415,23 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
       f->gpartC_cap = need;
     }
     {
+      // inside an epoch call (sf_flow_train_epoch, all steps but its last) only the cooperative image is re-tiled: the density
+      // and sampler images are not read by the training kernels, and nobody can look at them before the call returns
+      const bool lite = f->prep_lite;
+      const long n1 = lite ? 0 : (long)L.n_packed;
       const long n4 = dctx ? B * (long)L.dev.C : 0;
-      const long n5 = f->d_packed16 ? (long)L.n_packed16 : 0;
-      const long n6 = f->d_packed16B ? (long)L.n_packed16B : 0;
+      const long n5 = (!lite && f->d_packed16) ? (long)L.n_packed16 : 0;
+      const long n6 = (!lite && f->d_packed16B) ? (long)L.n_packed16B : 0;
       const long n7 = (long)L.n_imgC;
-      const long tot = (long)L.n_packed + n4 + n5 + n6 + n7;
+      const long tot = n1 + n4 + n5 + n6 + n7;
       hipLaunchKernelGGL(k_train_prep, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, flat, f->d_s1, f->d_s2, f->d_packed,
-                         (long)L.n_packed, (const int32_t*)nullptr, (const int32_t*)nullptr, (float*)nullptr, 0L, (float*)nullptr, 0,
+                         n1, (const int32_t*)nullptr, (const int32_t*)nullptr, (float*)nullptr, 0L, (float*)nullptr, 0,
                          dctx, n4, f->d_s16a, f->d_s16b, f->d_packed16, n5, f->d_s16B, f->d_packed16B, n6, f->d_sC1, f->d_sC2,
                          f->d_imgC, n7);
       SF_TRY(hipGetLastError());
+      f->packed16_stale = lite;
+      f->packed_stale = lite;
     }
-    f->packed16_stale = false;
     if (L.n_packedB > 0) SF_TRY(sf_launch_pack_bf16(flat, f->d_bsrc, f->d_packedB, (long)L.n_packedB, st));
     if (coop_nsf) {
       const long n_chunks = (B + 31) / 32;
@@ -413,7 +451,8 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
       a.inv_sqrt_h = v.inv_sqrt_h; a.deriv_const = v.deriv_const; a.logdet0 = v.logdet0;
       a.c_pscale = v.c_pscale; a.c_pshift = v.c_pshift; a.c_xmean = v.c_xmean; a.c_xstd = v.c_xstd;
       a.theta = theta; a.x = x; a.idx = idx; a.wts = weights; a.B = B; a.n_chunks = n_chunks; a.w = grad_scale;
-      a.loss = loss; a.loss_sum = loss_sum;
+      a.loss = loss; a.loss_sum = loss_sum; a.loss_mask = 0;
+      if (loss_sum && f->d_losspart) { a.loss_sum = f->d_losspart; a.loss_mask = SF_LOSS_PARTS - 1; f->losspart_used = true; }
       a.gpart = f->d_gpartC; a.gpart_stride = (long)L.n_gradC; a.fix = use_fix ? f->d_gfixC : nullptr; a.fix_mode = nsf_mode;
       a.ustash = f->d_ustash;
 #ifdef SF_NSC_TRACE
@@ -429,9 +468,9 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
         f->ev_train_valid = true;
       }
       if (use_fix && nsf_mode == 2)   // float replicas: the partial gather over SF_FIX_REPLICAS images
-        SF_TRY(sf_launch_gather_c2(reinterpret_cast<const float*>(f->d_gfixC), (long)L.n_gradC, SF_FIX_REPLICAS, f->d_gsrcC, f->d_gzeroC, f->n_gzeroC, grad, st));
+        SF_TRY(sf_launch_gather_c2(reinterpret_cast<const float*>(f->d_gfixC), (long)L.n_gradC, SF_FIX_REPLICAS, f->d_gsrcC, f->d_gzeroC, f->n_gzeroC, grad, st, sq_for(f, L)));
       else if (use_fix) SF_TRY(sf_launch_gather_fix(f->d_gfixC, (long)L.n_gradC, SF_FIX_REPLICAS, f->d_gsrcC, f->d_gzeroC, f->n_gzeroC, grad, st));
-      else if (f->d_gsrcC) SF_TRY(sf_launch_gather_c2(f->d_gpartC, (long)L.n_gradC, n_part, f->d_gsrcC, f->d_gzeroC, f->n_gzeroC, grad, st));
+      else if (f->d_gsrcC) SF_TRY(sf_launch_gather_c2(f->d_gpartC, (long)L.n_gradC, n_part, f->d_gsrcC, f->d_gzeroC, f->n_gzeroC, grad, st, sq_for(f, L)));
       else SF_TRY(sf_launch_gather_c(f->d_gpartC, (long)L.n_gradC, n_part, f->d_gdstC, grad, (long)L.n_params, st));
       return SF_OK;
     }
@@ -442,7 +481,8 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
     a.eps = L.dev.eps; a.logdet0 = L.dev.logdet0;
     a.c_pscale = L.dev.c_pscale; a.c_pshift = L.dev.c_pshift; a.c_tdim = L.dev.c_tdim; a.c_xmean = L.dev.c_xmean; a.c_xstd = L.dev.c_xstd;
     a.theta = theta; a.x = x; a.idx = idx; a.wts = weights; a.B = B; a.n_chunks = (B + 32L * sf_trainc_groups(B) - 1) / (32L * sf_trainc_groups(B)); a.w = grad_scale;
-    a.loss = loss; a.loss_sum = loss_sum; a.dctx = dctx;
+    a.loss = loss; a.loss_sum = loss_sum; a.dctx = dctx; a.loss_mask = 0;
+    if (loss_sum && f->d_losspart) { a.loss_sum = f->d_losspart; a.loss_mask = SF_LOSS_PARTS - 1; f->losspart_used = true; }
     a.gpart = f->d_gpartC; a.gpart_stride = (long)L.n_gradC; a.fix = use_fix ? f->d_gfixC : nullptr;
     if (f->profiling) {
       if (!f->ev_train[0]) { SF_TRY(hipEventCreate(&f->ev_train[0])); SF_TRY(hipEventCreate(&f->ev_train[1])); }
@@ -454,7 +494,7 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
       f->ev_train_valid = true;
     }
     if (use_fix) SF_TRY(sf_launch_gather_fix(f->d_gfixC, (long)L.n_gradC, SF_FIX_REPLICAS, f->d_gsrcC, f->d_gzeroC, f->n_gzeroC, grad, st));
-    else if (f->d_gsrcC) SF_TRY(sf_launch_gather_c2(f->d_gpartC, (long)L.n_gradC, grid, f->d_gsrcC, f->d_gzeroC, f->n_gzeroC, grad, st));
+    else if (f->d_gsrcC) SF_TRY(sf_launch_gather_c2(f->d_gpartC, (long)L.n_gradC, grid, f->d_gsrcC, f->d_gzeroC, f->n_gzeroC, grad, st, sq_for(f, L)));
     else SF_TRY(sf_launch_gather_c(f->d_gpartC, (long)L.n_gradC, grid, f->d_gdstC, grad, (long)L.n_params, st));
     return SF_OK;
   }

@@ -21,7 +21,8 @@ struct SfTrcArgs {
   long B, n_chunks;      // n_chunks = ceil(B / (32 * groups per workgroup))
   float w;
   float* loss;           // [B] or null
-  double* loss_sum;      // optional device scalar
+  double* loss_sum;      // optional device scalar -- or, loss_mask != 0, loss_mask + 1 scalars: workgroup i adds to [i & loss_mask]
+  int loss_mask;         // (hundreds of same-address double atomics serialise in one L2 channel: ~6 us of a 90 us step)
   float* dctx;           // [B, C] or null (only with one input tile)
   float* gpart;          // [grid] gradient partials of gpart_stride floats; plain stores, summed by k_gather_c
   long gpart_stride;
@@ -60,5 +61,7 @@ hipError_t sf_launch_maf_trainc(const SfTrcArgs& a, int grid, hipStream_t st);
 hipError_t sf_launch_gather_c(const float* gpart, long stride, int nwg, const int32_t* gdst, float* grad, long n, hipStream_t st);
 hipError_t sf_launch_gather_fix(const long long* gfix, long stride, int nrep, const int32_t* gsrc, const int32_t* gzero, long n_zero,
                                 float* grad, hipStream_t st);
+// sq_part (optional, sf_gather_c2_blocks floats): per-block shares of |grad|^2 for the optimiser step (sf_launch_adam)
+long sf_gather_c2_blocks(long stride, long n_zero);
 hipError_t sf_launch_gather_c2(const float* gpart, long stride, int nwg, const int32_t* gsrc, const int32_t* gzero, long n_zero,
-                               float* grad, hipStream_t st);
+                               float* grad, hipStream_t st, float* sq_part = nullptr);

@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
 #pragma unroll
           for (int o = 8; o > 0; o >>= 1) tsum += __shfl_xor(tsum, o, 64);
           // values on a 2^-20 grid add exactly in double: the sum does not depend on the order of the atomics
-          if (lane == 0) atomicAdd(a.loss_sum, (double)rintf(tsum * 1048576.0f) * (1.0 / 1048576.0));
+          if (lane == 0) atomicAdd(a.loss_sum + (blockIdx.x & a.loss_mask), (double)rintf(tsum * 1048576.0f) * (1.0 / 1048576.0));
         }
       }
       G0 = wgt * u0;
@@ -780,9 +780,11 @@ __global__ __launch_bounds__(1024) void k_gather_c(const float* __restrict__ gpa
 // consecutive floats of every partial (k_gather_c's parameter order scatters its 4-byte reads over the fragment layout:
 // 15 us for 33 MB at batch 16 384) -- and writes the one or two parameters that position feeds; the tail of the grid zeroes
 // the parameters without a position.  Order of the sum: partial 0, 1, 2 ... through eight interleaved accumulators.
+// sq_part (optional): the block's share of |grad|^2 -> sq_part[blockIdx.x], so that the optimiser step that follows need not read
+// the whole gradient again for the clipping norm (sf_launch_adam sums the shares in block order: deterministic).
 __global__ __launch_bounds__(256) void k_gather_c2(const float* __restrict__ gpart, long stride, int nwg,
                                                     const int32_t* __restrict__ gsrc, const int32_t* __restrict__ gzero,
-                                                    long n_zero, float* __restrict__ grad) {
+                                                    long n_zero, float* __restrict__ grad, float* __restrict__ sq_part) {
   // block = 64 consecutive positions x 4 groups of partials (every CU gets blocks: 33 k positions alone are 130 blocks)
   __shared__ float part[4][64];
   const int px = threadIdx.x & 63, qy = threadIdx.x >> 6;
@@ -790,6 +792,7 @@ __global__ __launch_bounds__(256) void k_gather_c2(const float* __restrict__ gpa
   if ((long)blockIdx.x * 64 >= stride) {  // the tail of the grid: parameters without a position
     const long z = ((long)blockIdx.x * 64 - (stride + 63) / 64 * 64) * 4 + threadIdx.x;
     if (z < n_zero) grad[gzero[z]] = 0.f;
+    if (sq_part && threadIdx.x == 0) sq_part[blockIdx.x] = 0.f;
     return;
   }
   const int p0 = j < stride ? gsrc[2 * j] : -1, p1 = j < stride ? gsrc[2 * j + 1] : -1;
@@ -811,10 +814,17 @@ __global__ __launch_bounds__(256) void k_gather_c2(const float* __restrict__ gpa
   }
   part[qy][px] = v;
   __syncthreads();
+  float sq = 0.f;
   if (qy == 0 && p0 >= 0) {
     const float t = (part[0][px] + part[1][px]) + (part[2][px] + part[3][px]);
     grad[p0] = t;
     if (p1 >= 0) grad[p1] = t;
+    sq = p1 >= 0 ? 2.f * t * t : t * t;   // (a position that feeds two parameters counts twice in the norm)
+  }
+  if (sq_part && qy == 0) {   // wave 0 holds the block's 64 positions
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    if (px == 0) sq_part[blockIdx.x] = sq;
   }
 }
 
@@ -970,10 +980,11 @@ hipError_t sf_launch_maf_trainc(const SfTrcArgs& a, int grid, hipStream_t st) {
   return sf_trainc_groups(a.B) == 1 ? c_dispatch<1>(a, grid, st) : c_dispatch<2>(a, grid, st);
 }
 
+long sf_gather_c2_blocks(long stride, long n_zero) { return (stride + 63) / 64 + (n_zero + 255) / 256; }
 hipError_t sf_launch_gather_c2(const float* gpart, long stride, int nwg, const int32_t* gsrc, const int32_t* gzero, long n_zero,
-                               float* grad, hipStream_t st) {
-  const long blocks = (stride + 63) / 64 + (n_zero + 255) / 256;  // 64 positions per block, then 256 unmapped parameters per block
-  hipLaunchKernelGGL(k_gather_c2, dim3((unsigned)blocks), dim3(256), 0, st, gpart, stride, nwg, gsrc, gzero, n_zero, grad);
+                               float* grad, hipStream_t st, float* sq_part) {
+  const long blocks = sf_gather_c2_blocks(stride, n_zero);  // 64 positions per block, then 256 unmapped parameters per block
+  hipLaunchKernelGGL(k_gather_c2, dim3((unsigned)blocks), dim3(256), 0, st, gpart, stride, nwg, gsrc, gzero, n_zero, grad, sq_part);
   return hipGetLastError();
 }
 hipError_t sf_launch_gather_fix(const long long* gfix, long stride, int nrep, const int32_t* gsrc, const int32_t* gzero, long n_zero,
