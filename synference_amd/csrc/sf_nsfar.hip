@@ -377,6 +377,32 @@ __global__ __launch_bounds__(64) void k_ar_inverse(ArArgs a, const float* __rest
   }
 }
 
+// one candidate per lane: noise of (slot, attempt) through the inverse flow, box test; the candidate is left in V rows [0, D)
+__device__ __forceinline__ bool ar_candidate(const ArArgs& a, const ZSplC& sc, const float* __restrict__ x, long g, unsigned long long slot,
+                                             uint32_t att, uint32_t k0, uint32_t k1, unsigned long long slot_offset,
+                                             const float* __restrict__ lo, const float* __restrict__ hi, float* E0, float* V, float* H1, float* H2,
+                                             float* QB, int lane, bool active) {
+  for (int c = 0; c < a.C; ++c) E0[(a.D + c) * RS + lane] = (x[g * a.C + c] - a.xmean[c]) / a.xstd[c];
+  for (int d0 = 0; d0 < a.D; d0 += 4) {
+    float z4[4];
+    sf_normal4(k0, k1, slot + slot_offset, att, (uint32_t)(d0 >> 2), z4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (d0 + j < a.D) V[(d0 + j) * RS + lane] = z4[j];
+  }
+  for (int t = a.T - 1; t >= 0; --t) {
+    (void)ar_inverse_transform(a, sc, t, E0, V, H1, H2, QB, lane);
+    for (int d = 0; d < a.D; ++d) V[d * RS + lane] = E0[d * RS + lane];
+  }
+  bool ok = active;
+  for (int d = 0; d < a.D; ++d) {
+    const float th = (V[d * RS + lane] - a.th_shift[d]) / a.th_scale[d];
+    V[d * RS + lane] = th;
+    ok = ok && (th == th) && fabsf(th) < 3.0e38f && (!lo || (th >= lo[d] && th <= hi[d]));
+  }
+  return ok;
+}
+
 // rejection sampler: a wave works (slot, attempt) items until the slot list is exhausted; rejected items come back first
 __global__ __launch_bounds__(64) void k_ar_sample(ArArgs a, const float* __restrict__ x, long S, const uint32_t* __restrict__ slots,
                                                    long n_slots, const float* __restrict__ lo, const float* __restrict__ hi, uint32_t k0,
@@ -384,7 +410,10 @@ __global__ __launch_bounds__(64) void k_ar_sample(ArArgs a, const float* __restr
                                                    float* __restrict__ out, int32_t* __restrict__ n_drawn, int32_t* __restrict__ count,
                                                    unsigned long long* __restrict__ cursor, unsigned int* __restrict__ n_unfilled,
                                                    int32_t* __restrict__ g_try, int32_t* __restrict__ g_acc, unsigned long long walk_R,
-                                                   unsigned long long walk_C) {
+                                                   unsigned long long walk_C, uint32_t window_end, uint32_t* __restrict__ surv,
+                                                   unsigned int* __restrict__ n_surv) {
+  // window_end < max_attempts: an entry that has used up attempts [0, window_end) is appended to surv[] -- the find / resolve
+  // launches of sf_nsfar_sample spread its further attempts over the whole chip -- instead of being carried on by this wave
   // cursor[2]: evaluations (items worked), cursor[3]: first attempts rejected -- statistics for sf_flow_sample_stats
   extern __shared__ float lds[];
   float* E0 = lds;
@@ -442,27 +471,10 @@ __global__ __launch_bounds__(64) void k_ar_sample(ArArgs a, const float* __restr
       }
     }
     const uint32_t att = att0 + (uint32_t)sub;
-    const bool active = exists && att < max_attempts;
+    const bool active = exists && att < window_end;
     __syncthreads();   // (the retry list has been read)
     const long g = exists ? (long)(slot / (unsigned long long)S) : 0;
-    for (int c = 0; c < a.C; ++c) E0[(a.D + c) * RS + lane] = (x[g * a.C + c] - a.xmean[c]) / a.xstd[c];
-    for (int d0 = 0; d0 < a.D; d0 += 4) {
-      float z4[4];
-      sf_normal4(k0, k1, slot + slot_offset, att, (uint32_t)(d0 >> 2), z4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (d0 + j < a.D) V[(d0 + j) * RS + lane] = z4[j];
-    }
-    for (int t = a.T - 1; t >= 0; --t) {
-      (void)ar_inverse_transform(a, sc, t, E0, V, H1, H2, QB, lane);
-      for (int d = 0; d < a.D; ++d) V[d * RS + lane] = E0[d * RS + lane];
-    }
-    bool ok = active;
-    for (int d = 0; d < a.D; ++d) {
-      const float th = (V[d * RS + lane] - a.th_shift[d]) / a.th_scale[d];
-      V[d * RS + lane] = th;
-      ok = ok && (th == th) && fabsf(th) < 3.0e38f && (!lo || (th >= lo[d] && th <= hi[d]));
-    }
+    const bool ok = ar_candidate(a, sc, x, g, slot, att, k0, k1, slot_offset, lo, hi, E0, V, H1, H2, QB, lane, active);
     const unsigned long long m_ok = __ballot(ok);
     {
       const unsigned long long ma = __ballot(active), mr = __ballot(active && !ok && att == 0u);
@@ -481,8 +493,9 @@ __global__ __launch_bounds__(64) void k_ar_sample(ArArgs a, const float* __restr
     const bool resolved = grp != 0ull;
     const int win = resolved ? __builtin_ctzll(grp) : 0;
     const bool leader = exists && sub == 0;
-    const uint32_t tried_now = att0 + (uint32_t)W < max_attempts ? (uint32_t)W : max_attempts - att0;   // attempts of this round that count
-    bool give_up = leader && !resolved && att0 + (uint32_t)W >= max_attempts;
+    const uint32_t tried_now = att0 + (uint32_t)W < window_end ? (uint32_t)W : window_end - att0;   // attempts of this round that count
+    const bool window_out = leader && !resolved && att0 + (uint32_t)W >= window_end;
+    bool give_up = window_out && window_end >= max_attempts;
     if (g_try && leader) {   // no ceiling asked for: a row whose open slots spent 1e5 attempts without ONE accepted draw is written off
       const int tried = atomicAdd(g_try + g, (int)(resolved ? win + 1 : (int)tried_now)) + (int)(resolved ? win + 1 : (int)tried_now);
       if (resolved) atomicAdd(g_acc + g, 1);
@@ -497,7 +510,8 @@ __global__ __launch_bounds__(64) void k_ar_sample(ArArgs a, const float* __restr
       if (n_drawn) sf_sat_add(n_drawn + g, (int32_t)(att0 + tried_now));
       atomicAdd(n_unfilled, 1u);
     }
-    const bool again = leader && !resolved && !give_up;
+    if (window_out && !give_up) surv[atomicAdd(n_surv, 1u)] = (uint32_t)slot;   // (hand-over; a row written off by the progress rule is not)
+    const bool again = leader && !resolved && !give_up && !window_out;
     const unsigned long long m = __ballot(again);
     if (again) {
       const int pos = __popcll(m & ((1ull << lane) - 1ull));
@@ -506,6 +520,77 @@ __global__ __launch_bounds__(64) void k_ar_sample(ArArgs a, const float* __restr
     }
     n_retry = __popcll(m);
     __syncthreads();
+  }
+}
+
+// FIND: attempts [base, base + A) of every survivor side by side -- workgroup (e, j) tries attempts base + 64 j + lane of
+// survivor e; an accepted attempt only lowers best[e].  RESOLVE re-evaluates exactly attempt best[e] and writes the draw: the
+// slot keeps its LOWEST accepted attempt, whatever A and the schedule were.
+__global__ __launch_bounds__(64) void k_ar_find(ArArgs a, const float* __restrict__ x, long S, const uint32_t* __restrict__ surv,
+                                                 unsigned int n_surv, uint32_t base, uint32_t chunks, uint32_t att_end,
+                                                 const float* __restrict__ lo, const float* __restrict__ hi, uint32_t k0, uint32_t k1,
+                                                 unsigned long long slot_offset, uint32_t* __restrict__ best, unsigned long long* __restrict__ ctr) {
+  extern __shared__ float lds[];
+  float* E0 = lds;
+  float* H1 = E0 + a.NIN16 * RS;
+  float* H2 = H1 + a.Hp * RS;
+  float* QB = H2 + a.Hp * RS;
+  float* V = QB + 32 * RS;
+  const int lane = threadIdx.x;
+  const ZSplC sc = {a.K, a.B, a.cw, a.cd};
+  for (int r = a.D + a.C; r < a.NIN16; ++r) E0[r * RS + lane] = 0.f;
+  const unsigned int e = blockIdx.x / chunks, j = blockIdx.x - e * chunks;
+  if (e >= n_surv) return;
+  const unsigned long long slot = surv[e];
+  const uint32_t att = base + 64u * j + (uint32_t)lane;
+  const bool active = att < att_end;
+  const long g = (long)(slot / (unsigned long long)S);
+  const bool ok = ar_candidate(a, sc, x, g, slot, att, k0, k1, slot_offset, lo, hi, E0, V, H1, H2, QB, lane, active);
+  if (ok) atomicMin(best + e, att);
+  const unsigned long long ma = __ballot(active);
+  if (lane == 0) atomicAdd(ctr + 2, (unsigned long long)__popcll(ma));
+}
+__global__ __launch_bounds__(64) void k_ar_resolve(ArArgs a, const float* __restrict__ x, long S, const uint32_t* __restrict__ surv,
+                                                    unsigned int n_surv, const uint32_t* __restrict__ best, uint32_t tried_end,
+                                                    uint32_t max_attempts, const float* __restrict__ lo, const float* __restrict__ hi,
+                                                    uint32_t k0, uint32_t k1, unsigned long long slot_offset, float* __restrict__ out,
+                                                    int32_t* __restrict__ n_drawn, int32_t* __restrict__ g_try, int32_t* __restrict__ g_acc,
+                                                    uint32_t tried_now, uint32_t* __restrict__ next, unsigned int* __restrict__ n_next,
+                                                    unsigned int* __restrict__ n_unfilled) {
+  extern __shared__ float lds[];
+  float* E0 = lds;
+  float* H1 = E0 + a.NIN16 * RS;
+  float* H2 = H1 + a.Hp * RS;
+  float* QB = H2 + a.Hp * RS;
+  float* V = QB + 32 * RS;
+  const int lane = threadIdx.x;
+  const ZSplC sc = {a.K, a.B, a.cw, a.cd};
+  for (int r = a.D + a.C; r < a.NIN16; ++r) E0[r * RS + lane] = 0.f;
+  const unsigned int e = blockIdx.x * 64u + (unsigned)lane;
+  const bool exists = e < n_surv;
+  const unsigned long long slot = exists ? surv[e] : 0ull;
+  const uint32_t b = exists ? best[e] : 0xffffffffu;
+  const bool found = exists && b != 0xffffffffu;
+  const long g = exists ? (long)(slot / (unsigned long long)S) : 0;
+  const bool ok = ar_candidate(a, sc, x, g, slot, found ? b : 0u, k0, k1, slot_offset, lo, hi, E0, V, H1, H2, QB, lane, found);
+  if (found) {   // (ok by construction: the find launch accepted this very attempt)
+    for (int d = 0; d < a.D; ++d) out[slot * a.D + d] = ok ? V[d * RS + lane] : __builtin_nanf("");
+    if (n_drawn) sf_sat_add(n_drawn + g, (int32_t)(b + 1u));
+    if (g_acc) atomicAdd(g_acc + g, 1);
+    if (g_try) atomicAdd(g_try + g, (int)tried_now);
+  } else if (exists) {
+    bool give_up = tried_end >= max_attempts;
+    if (g_try) {   // (uncapped: the progress rule, as in k_ar_sample)
+      const int tried = atomicAdd(g_try + g, (int)tried_now) + (int)tried_now;
+      if (tried >= 100000 && __hip_atomic_load(g_acc + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) give_up = true;
+    }
+    if (give_up) {
+      for (int d = 0; d < a.D; ++d) out[slot * a.D + d] = __builtin_nanf("");
+      if (n_drawn) sf_sat_add(n_drawn + g, (int32_t)tried_end);
+      atomicAdd(n_unfilled, 1u);
+    } else {
+      next[atomicAdd(n_next, 1u)] = (uint32_t)slot;
+    }
   }
 }
 
@@ -845,7 +930,7 @@ void sf_nsfar_destroy(SfNsfAr* n) {
   if (!n) return;
   (void)hipFree(n->d_img); (void)hipFree(n->d_src); (void)hipFree(n->d_none); (void)hipFree(n->d_perm); (void)hipFree(n->d_ptype); (void)hipFree(n->d_tend);
   (void)hipFree(n->d_ord); (void)hipFree(n->d_dimof); (void)hipFree(n->d_xmean); (void)hipFree(n->d_xstd); (void)hipFree(n->d_ustash);
-  (void)hipFree(n->d_ctr); (void)hipFree(n->d_gal);
+  (void)hipFree(n->d_ctr); (void)hipFree(n->d_gal); (void)hipFree(n->d_surv[0]); (void)hipFree(n->d_surv[1]); (void)hipFree(n->d_best);
   delete n;
 }
 
@@ -860,7 +945,7 @@ static int ar_ensure(SfNsfAr* n, std::string& err) {
   AR_HIP(hipMalloc(&n->d_img, n->src.size() * sizeof(float)));
   AR_HIP(up(n->d_src, n->src)); AR_HIP(up(n->d_perm, n->perm)); AR_HIP(up(n->d_ptype, n->ptype)); AR_HIP(up(n->d_tend, n->tend));
   AR_HIP(up(n->d_ord, n->ord)); AR_HIP(up(n->d_dimof, n->dimof)); AR_HIP(up(n->d_xmean, n->h_xmean)); AR_HIP(up(n->d_xstd, n->h_xstd));
-  AR_HIP(hipMalloc(&n->d_ctr, 4 * sizeof(unsigned long long)));
+  AR_HIP(hipMalloc(&n->d_ctr, 8 * sizeof(unsigned long long)));   // [0] cursor [1] unfilled [2] evaluations [3] rejected first attempts [4], [5] survivor counts
   {
     const std::vector<int32_t> none(n->src.size(), -1);
     AR_HIP(up(n->d_none, none));
@@ -868,6 +953,7 @@ static int ar_ensure(SfNsfAr* n, std::string& err) {
   const size_t lds = (size_t)160 * 1024 - 1024;   // (k_ar_sample also has 768 static bytes)
   AR_HIP(set_lds(k_ar_logprob<1>, lds)); AR_HIP(set_lds(k_ar_logprob<4>, lds)); AR_HIP(set_lds(k_ar_inverse, lds)); AR_HIP(set_lds(k_ar_sample, lds));
   AR_HIP(set_lds(k_ar_train<1>, lds)); AR_HIP(set_lds(k_ar_train<4>, lds));
+  AR_HIP(set_lds(k_ar_find, lds)); AR_HIP(set_lds(k_ar_resolve, lds));
   n->dev_ready = true;
   return SF_OK;
 }
@@ -934,7 +1020,7 @@ int sf_nsfar_inverse(SfNsfAr* n, const float* z, const float* x, long B, float* 
 int sf_nsfar_sample(SfNsfAr* n, const float* x, long M, long S, const uint32_t* slots, long n_slots, const float* lo, const float* hi,
                     uint32_t k0, uint32_t k1, unsigned long long slot_offset, int max_attempts, float* out, int32_t* n_drawn,
                     int32_t* count, int64_t* n_unfilled, hipStream_t st, std::string& err, hipEvent_t ev0, hipEvent_t ev1) {
-  AR_HIP(hipMemsetAsync(n->d_ctr, 0, 4 * sizeof(unsigned long long), st));
+  AR_HIP(hipMemsetAsync(n->d_ctr, 0, 8 * sizeof(unsigned long long), st));
   static int cus = 0;   // (asked once: the query costs more than a small sampling call)
   if (!cus) {
     int dev = 0;
@@ -964,18 +1050,71 @@ int sf_nsfar_sample(SfNsfAr* n, const float* x, long M, long S, const uint32_t* 
     if (!slots && M > 1 && (long)(M * S) == n_slots) { walk_R = (unsigned long long)M; walk_C = (unsigned long long)S; }
     else { walk_R = 4096; walk_C = ((unsigned long long)n_slots + walk_R - 1) / walk_R; }
   }
+  // The persistent launch takes every slot through attempts [0, 256); what is still open then (rows that accept less than
+  // about one draw in a hundred) goes on in FIND / RESOLVE rounds that spread ONE slot's attempts over the whole chip -- as many new
+  // attempts per round as the slot has already failed, within 4 M candidates per launch.  In one wave a slot of a row with
+  // acceptance 7e-4 needed ~150 rounds of 64 attempts while the chip idled (the bench flow: 90 ms instead of 25).
+  uint32_t window = cap;
+  const bool rounds = !count && lo && cap > 256u && n_slots <= (1l << 31) && (unsigned long long)M * (unsigned long long)S < (1ull << 32);
+  if (rounds) {
+    window = 256u;
+    if ((size_t)n_slots > n->surv_cap) {
+      (void)hipFree(n->d_surv[0]); (void)hipFree(n->d_surv[1]); (void)hipFree(n->d_best);
+      n->d_surv[0] = n->d_surv[1] = n->d_best = nullptr; n->surv_cap = 0;
+      AR_HIP(hipMalloc(&n->d_surv[0], (size_t)n_slots * sizeof(uint32_t)));
+      AR_HIP(hipMalloc(&n->d_surv[1], (size_t)n_slots * sizeof(uint32_t)));
+      AR_HIP(hipMalloc(&n->d_best, (size_t)n_slots * sizeof(uint32_t)));
+      n->surv_cap = (size_t)n_slots;
+    }
+  }
+  unsigned int* d_ns = reinterpret_cast<unsigned int*>(n->d_ctr + 4);   // [0], [1]: survivor counts of the two lists
   hipLaunchKernelGGL(k_ar_sample, dim3((unsigned)grid), dim3(64), lds, st, args_of(*n), x, S, slots, n_slots, lo, hi, k0, k1, slot_offset, cap, out,
-                     n_drawn, count, n->d_ctr, reinterpret_cast<unsigned int*>(n->d_ctr + 1), g_try, g_try ? g_try + M : nullptr, walk_R, walk_C);
+                     n_drawn, count, n->d_ctr, reinterpret_cast<unsigned int*>(n->d_ctr + 1), g_try, g_try ? g_try + M : nullptr, walk_R, walk_C,
+                     window, n->d_surv[0], d_ns);
   AR_HIP(hipGetLastError());
   if (ev1) AR_HIP(hipEventRecord(ev1, st));
-  if (n_unfilled) {
-    unsigned long long h[4] = {0, 0, 0, 0};
+  unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (rounds) {
+    int cur = 0;
+    uint32_t base = window;
+    for (;;) {
+      AR_HIP(hipMemcpyAsync(h, n->d_ctr, sizeof(h), hipMemcpyDeviceToHost, st));
+      AR_HIP(hipStreamSynchronize(st));
+      const unsigned int ns = reinterpret_cast<const unsigned int*>(h + 4)[cur];
+      if (ns == 0 || base >= cap) break;
+      uint32_t A = 64;
+      while (2u * A <= base && (uint64_t)(2u * A) * ns <= (1ull << 22) && 2u * A <= 65536u) A *= 2;
+      if ((uint64_t)base + A > cap) A = (uint32_t)(((uint64_t)cap - base + 63u) / 64u * 64u);
+      const uint32_t att_end = (uint64_t)base + A > cap ? cap : base + A;
+      const uint32_t chunks = A / 64u;
+      AR_HIP(hipMemsetAsync(n->d_best, 0xff, (size_t)ns * sizeof(uint32_t), st));
+      AR_HIP(hipMemsetAsync(d_ns + (cur ^ 1), 0, sizeof(unsigned int), st));
+      hipLaunchKernelGGL(k_ar_find, dim3(ns * chunks), dim3(64), lds, st, args_of(*n), x, S, n->d_surv[cur], ns, base, chunks, att_end, lo, hi, k0, k1,
+                         slot_offset, n->d_best, n->d_ctr);
+      hipLaunchKernelGGL(k_ar_resolve, dim3((ns + 63u) / 64u), dim3(64), lds, st, args_of(*n), x, S, n->d_surv[cur], ns, n->d_best, att_end, cap, lo, hi,
+                         k0, k1, slot_offset, out, n_drawn, g_try, g_try ? g_try + M : nullptr, att_end - base, n->d_surv[cur ^ 1], d_ns + (cur ^ 1),
+                         reinterpret_cast<unsigned int*>(n->d_ctr + 1));
+      AR_HIP(hipGetLastError());
+      base = att_end;
+      cur ^= 1;
+    }
+    const unsigned int left = reinterpret_cast<const unsigned int*>(h + 4)[cur];
+    if (left > 0) {   // (the ceiling was reached with slots still open: NaN rows)
+      AR_HIP(hipMemsetAsync(n->d_best, 0xff, (size_t)left * sizeof(uint32_t), st));
+      hipLaunchKernelGGL(k_ar_resolve, dim3((left + 63u) / 64u), dim3(64), lds, st, args_of(*n), x, S, n->d_surv[cur], left, n->d_best, cap, cap, lo, hi,
+                         k0, k1, slot_offset, out, n_drawn, (int32_t*)nullptr, (int32_t*)nullptr, 0u, n->d_surv[cur ^ 1], d_ns + (cur ^ 1),
+                         reinterpret_cast<unsigned int*>(n->d_ctr + 1));
+      AR_HIP(hipGetLastError());
+    }
     AR_HIP(hipMemcpyAsync(h, n->d_ctr, sizeof(h), hipMemcpyDeviceToHost, st));
     AR_HIP(hipStreamSynchronize(st));
-    *n_unfilled = (int64_t)(unsigned int)h[1];
-    n->last_evals = (double)h[2];
-    n->last_rej0 = (double)h[3];
+  } else if (n_unfilled) {
+    AR_HIP(hipMemcpyAsync(h, n->d_ctr, sizeof(h), hipMemcpyDeviceToHost, st));
+    AR_HIP(hipStreamSynchronize(st));
   }
+  if (n_unfilled) *n_unfilled = (int64_t)(unsigned int)h[1];
+  n->last_evals = (double)h[2];
+  n->last_rej0 = (double)h[3];
   return SF_OK;
 }
 

@@ -166,6 +166,28 @@ def test_autoregressive_nsf_slots_acceptance_and_exhaustion():
     assert torch.isnan(got).all() and f.last_unfilled == 16 and (nd.cpu().numpy() == 8 * 5).all()
 
 
+def test_autoregressive_nsf_deep_tail_rounds_keep_the_lowest_accepted_attempt():
+    """A box that accepts about one draw in a thousand: every slot outlives the persistent launch's 256-attempt window and is
+    finished by the chip-wide FIND / RESOLVE rounds (sf_nsfar_sample) -- the draws and the attempt counts must still be the
+    oracle's, which tries a slot's attempts one after the other and keeps the first accepted one."""
+    ospec, spec, flat, theta, x = make_case("nsfar_small", B=3, spread=0.2)
+    f = _flow(spec, flat)
+    S, seed = 24, 77
+    free, _ = OP.sample(ospec, torch.as_tensor(flat), x, 4000, 5, dtype=torch.float32)
+    lo = np.quantile(free.reshape(-1, spec.D), 0.45, axis=0).astype(np.float32)
+    hi = np.quantile(free.reshape(-1, spec.D), 0.55, axis=0).astype(np.float32)
+    got, nd = f.sample(x, S, lo, hi, seed=seed, return_counts=True)
+    got, nd = got.cpu().double().numpy(), nd.cpu().numpy()
+    ref, rnd = OP.sample(ospec, torch.as_tensor(flat), x, S, seed, lo, hi, dtype=torch.float32)
+    assert f.last_unfilled == 0 and np.isfinite(got).all() and ((got >= lo) & (got <= hi)).all()
+    assert rnd.sum() > 300 * S * len(x)          # (the oracle really needed hundreds of attempts per slot)
+    err = np.abs((got - ref) / (hi - lo).astype(np.float64)).max(-1)
+    bad_g, off_g = (err > 1e-3).sum(1), np.abs(nd - rnd)
+    # (a candidate within rounding of the box edge may be accepted by one side only: such a slot keeps another attempt and
+    #  its row's attempt count differs; a narrow box has a long edge, so allow a few of the 72 slots)
+    assert (bad_g <= np.minimum(off_g, 3)).all() and bad_g.sum() <= 4, (bad_g, off_g)
+
+
 @pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "nsf_odd", "maf_wide", "nsf_nb1", "maf_span6", "maf_span_h64"])
 def test_context_table_round_equals_per_draw_round(name):
     """sf_flow_prepare_context only moves the context products out of the per-draw work: a dense round and a
