@@ -53,3 +53,11 @@ for nc in (1, 2, 3, 4, 6):
     same = np.array_equal(fit.sample_posterior(X, num_samples=S, seed=3), ref, equal_nan=True)
     print(f"SBI_Fitter.sample_posterior, {nc} chunk(s)    {t(lambda: fit.sample_posterior(X, num_samples=S, seed=3)):.3f} ms   identical draws: {same}")
 os.environ.pop("SF_API_CHUNKS")
+if os.environ.get("SF_API_PROFILE"):
+    import cProfile, pstats, io
+    pr = cProfile.Profile()
+    for _ in range(3): fit.sample_posterior(X, num_samples=S, seed=3)
+    pr.enable()
+    for _ in range(20): fit.sample_posterior(X, num_samples=S, seed=3)
+    pr.disable()
+    sio = io.StringIO(); pstats.Stats(pr, stream=sio).sort_stats("cumulative").print_stats(28); print(sio.getvalue()[:6000])

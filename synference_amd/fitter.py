@@ -542,9 +542,12 @@ class SBI_Fitter:
                 # D2H in float32 (half the PCIe bytes of a device-side .double()) through a ring of pinned staging buffers
                 # on a copy stream, widened into the reference's float64 container by a thread pool while the next piece
                 # is on the bus (hostio.py); with log_times the chunk's time includes its hand-over
-                p = to_host_f64(s, out=samples[a:b], wait=bool(log_times))
-                if not log_times:
-                    pending.append((a, b, p))
+                # (one chunk, or timed chunks: the call itself; several untimed chunks: a helper thread, so that the next
+                #  chunk's kernels are launched meanwhile)
+                if log_times or n_chunks == 1:
+                    to_host_f64(s, out=samples[a:b])
+                else:
+                    pending.append((a, b, to_host_f64(s, out=samples[a:b], wait=False)))
             except Exception as e:  # sbi_runner.py:6458-6460: failed objects are NaN rows
                 logger.error(f"Error occurred while sampling objects {a}..{b}: {e}")
                 samples[a:b] = np.nan
