@@ -666,3 +666,52 @@ def test_bench_spawns_eight_ranks_and_all_reduces_a_flat_gradient():
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--rendezvous-only"], env=env2,
                         capture_output=True, text=True, timeout=120)
     assert r2.returncode != 0 and "WORLD_SIZE=4" in (r2.stdout + r2.stderr)
+
+
+def test_bench_flop_model_of_the_autoregressive_nsf_counts_the_oracle_masks():
+    """bench.py's nsfar_flops = 2 x the non-zeros of the oracle's masks (the context columns of the first layer separately:
+    they are the same for every draw of a row), and D passes for the reference's inverse."""
+    import importlib.util
+    from oracle import flows as OF
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    for D, C, H, T, K in ((5, 10, 50, 5, 8), (3, 4, 17, 2, 5), (8, 20, 64, 3, 8)):
+        o = OF.FlowSpec(kind="nsf_ar", D=D, C=C, H=H, T=T, K=K, tail_bound=5.0)
+        theta_nnz = ctx_nnz = 0
+        for t in range(T):
+            m0, m1, m2 = OF.ar_masks(o, t)
+            theta_nnz += int(m0[:, :D].sum()) + int(m1.sum()) + int(m2.sum())
+            ctx_nnz += int(m0[:, D:].sum())
+        f_lp, f_draw, f_gal = b.nsfar_flops(D, C, H, T, K)
+        assert f_lp == 2.0 * (theta_nnz + ctx_nnz) and f_gal == 2.0 * ctx_nnz and f_draw == 2.0 * D * theta_nnz
+    w = b.WORKLOADS["nsfar_cfg2"]
+    assert w["kind"] == "nsf_ar" and w["K"] == 8 and w["f_lp"] == b.nsfar_flops(5, 10, 50, 5, 8)[0]
+
+
+def test_result_buffers_are_recycled_only_when_nobody_holds_them():
+    """hostio.result_array: a large float64 result is handed out again once the caller has dropped it (and every view of it);
+    a result that is still referenced is never touched; small arrays are not pooled."""
+    from synference_amd import hostio
+    shape = (300, 1000, 5)   # 12 MB
+    a = hostio.result_array(shape)
+    a[:] = 1.0
+    ida = a.ctypes.data
+    b = hostio.result_array(shape)          # a is still held: a different buffer
+    assert b.ctypes.data != ida
+    view = a[:10]
+    del a
+    c = hostio.result_array(shape)          # a view of a is still alive
+    assert c.ctypes.data != ida and float(view[0, 0, 0]) == 1.0
+    del view, c
+    d = hostio.result_array((1000, 300, 5))  # same size, another shape: one of the dropped buffers comes back
+    assert d.shape == (1000, 300, 5) and d.flags.c_contiguous and d.dtype == np.float64
+    small = hostio.result_array((10, 10))
+    assert small.nbytes < (8 << 20) and small.shape == (10, 10)
+    os.environ["SF_HOSTIO_POOL"] = "0"
+    try:
+        e1 = hostio.result_array(shape); p1 = e1.ctypes.data; del e1
+        e2 = hostio.result_array(shape)
+        assert e2.shape == shape     # (pool off: a plain allocation each time -- nothing to assert about addresses)
+    finally:
+        del os.environ["SF_HOSTIO_POOL"]
