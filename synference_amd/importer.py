@@ -302,3 +302,113 @@ def state_dict_from_flat(spec: FlowSpec, flat, prefix: str = "") -> Dict[str, np
             out[f"{p}1._transforms.{2 * t}.transform_features"] = d[d % 2 == t % 2].astype(np.int64)
             out[f"{p}1._transforms.{2 * t}.identity_features"] = d[d % 2 != t % 2].astype(np.int64)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# the lampe backend's flow: zuko.flows.NSF  (SURVEY.md 8f row f4; ref: src/synference/sbi_runner.py:5123-5125)
+# ------------------------------------------------------------------------------------------------------------------------
+# [UPSTREAM, module paths restated from the published zuko sources -- zuko is not installed here, the names are unpinned like
+# everything else upstream]: ``zuko.flows.NSF(features=D, context=C, transforms=T, hidden_features=[H, H], bins=K)`` holds
+#     transform.transforms.{t}.hyper.{0,2,4}.{weight,bias}     MaskedLinear layers of the MaskedMLP (ReLU at 1, 3)
+#     transform.transforms.{t}.hyper.{0,2,4}.mask              their masks (buffers)
+#     transform.transforms.{t}.order                           the ordering of transform t (buffer)
+# (lampe's NPE prefixes ``flow.``, ltu-ili's wrapper its own: names are matched by suffix).  The checkpoint's masks and orders
+# are COMPARED with what this engine builds from (D, C, H, t) -- unit h of a hidden layer has type h mod D, an output of type r
+# sees inputs / units of type < r (first layer) / <= r (later layers), orders alternate 0..D-1 / D-1..0 -- and a difference
+# raises: a flow that would be wired differently is not imported.  Standardising constants are not part of a zuko flow: they
+# are taken from the keyword arguments (the z-scores ltu-ili's lampe loader applies around the flow), identity by default.
+_ZUKO_RE = re.compile(r"transforms\.(\d+)\.hyper\.(\d+)\.(weight|bias|mask)$")
+_ZUKO_ORDER_RE = re.compile(r"transforms\.(\d+)\.order$")
+
+
+def zuko_masks(D: int, C: int, H: int, NP: int, order: np.ndarray):
+    """[first hidden (H, D + C), second hidden (H, H), head (D * NP, H)] boolean masks of one transform (oracle/flows.py ar_masks)."""
+    in_order = np.concatenate([np.asarray(order), np.full(C, -1)])
+    typ = np.arange(H) % D
+    out_type = np.repeat(np.asarray(order), NP)
+    return [typ[:, None] > in_order[None, :], typ[:, None] >= typ[None, :], out_type[:, None] >= typ[None, :]]
+
+
+def spec_and_flat_from_zuko_state_dict(state_dict: Mapping[str, object], tail_bound: float = 5.0, ar_slope: float = 1e-3,
+                                       theta_mean=None, theta_std=None, x_mean=None, x_std=None) -> Tuple[FlowSpec, np.ndarray]:
+    """(FlowSpec(kind="nsf_ar"), flat float32 vector) of a ``zuko.flows.NSF`` ``state_dict``."""
+    layers: Dict[int, Dict[int, Dict[str, np.ndarray]]] = {}
+    orders: Dict[int, np.ndarray] = {}
+    for k, v in state_dict.items():
+        m = _ZUKO_RE.search(k)
+        if m:
+            layers.setdefault(int(m.group(1)), {}).setdefault(int(m.group(2)), {})[m.group(3)] = _np(v)
+            continue
+        m = _ZUKO_ORDER_RE.search(k)
+        if m:
+            orders[int(m.group(1))] = _np(v).astype(np.int64).reshape(-1)
+    if not layers:
+        raise KeyError("no 'transforms.N.hyper.M.weight' entries: this is not a zuko autoregressive flow state_dict")
+    tidx = sorted(layers)
+    if tidx != list(range(len(tidx))):
+        raise KeyError(f"transform indices {tidx} are not 0..T-1 (an element-wise transform between them is not supported)")
+    T = len(tidx)
+    lidx = sorted(layers[0])
+    if len(lidx) != 3:
+        raise ValueError(f"{len(lidx) - 1} hidden layers: the HIP engine builds the two-hidden-layer hyper-network of the lampe loader")
+    W0, W1, W2 = (layers[0][i]["weight"] for i in lidx)
+    H = W0.shape[0]
+    if W1.shape != (H, H) or W2.shape[1] != H:
+        raise ValueError("hidden layers of different widths are not supported")
+    if 0 not in orders:
+        raise KeyError("transforms.0.order is missing")
+    D = int(orders[0].size)
+    C = W0.shape[1] - D
+    if C < 1 or W2.shape[0] % D:
+        raise ValueError(f"shapes do not fit an autoregressive NSF with context: W0 {W0.shape}, head {W2.shape}, D = {D}")
+    NP = W2.shape[0] // D
+    if (NP + 1) % 3:
+        raise ValueError(f"{NP} parameters per dimension are not 3 K - 1")
+    K = (NP + 1) // 3
+    f = lambda a, n, fill: np.full(n, fill, np.float32) if a is None else np.asarray(a, np.float32).reshape(n)
+    spec = FlowSpec(kind="nsf_ar", D=D, C=C, H=H, T=T, K=K, NB=2, tail_bound=float(tail_bound), ar_slope=float(ar_slope),
+                    theta_mean=f(theta_mean, D, 0.0), theta_std=f(theta_std, D, 1.0), x_mean=f(x_mean, C, 0.0), x_std=f(x_std, C, 1.0))
+    flat = np.zeros(num_params(spec), np.float32)
+    lay = {n: (s, o) for n, s, o in param_layout(spec)}
+    for t in tidx:
+        want = np.arange(D) if t % 2 == 0 else np.arange(D)[::-1]
+        if t not in orders or not np.array_equal(orders[t], want):
+            raise ValueError(f"transform {t}: order {orders.get(t)} is not the alternating {want.tolist()} this engine builds")
+        if sorted(layers[t]) != lidx:
+            raise KeyError(f"transform {t}: layer indices {sorted(layers[t])} differ from transform 0's {lidx}")
+        masks = zuko_masks(D, C, H, NP, want)
+        for j, li in enumerate(lidx):
+            ent = layers[t][li]
+            if "weight" not in ent or "bias" not in ent:
+                raise KeyError(f"transforms.{t}.hyper.{li}: weight / bias missing")
+            shape, off = lay[f"t{t}.ar.W{j}"]
+            if ent["weight"].shape != shape:
+                raise ValueError(f"transforms.{t}.hyper.{li}.weight has shape {ent['weight'].shape}, expected {shape}")
+            if "mask" in ent and not np.array_equal(ent["mask"].astype(bool), masks[j]):
+                raise ValueError(f"transforms.{t}.hyper.{li}.mask differs from the connectivity this engine builds from (D, C, H): "
+                                 "the checkpoint would be wired differently")
+            flat[off:off + int(np.prod(shape))] = (ent["weight"].astype(np.float32) * masks[j]).reshape(-1)
+            bshape, boff = lay[f"t{t}.ar.b{j}"]
+            flat[boff:boff + bshape[0]] = ent["bias"].astype(np.float32).reshape(-1)
+    return spec, flat
+
+
+def zuko_state_dict_from_flat(spec: FlowSpec, flat, prefix: str = "") -> Dict[str, np.ndarray]:
+    """The inverse mapping: zuko's module paths with the mask and order buffers (for handing weights back, and for the tests)."""
+    if spec.kind != "nsf_ar" or spec.NB != 2:
+        raise ValueError("zuko_state_dict_from_flat takes an nsf_ar spec with two hidden layers")
+    flat = _np(flat).astype(np.float32)
+    out: Dict[str, np.ndarray] = {}
+    NP = 3 * spec.K - 1
+    lay = {n: (s, o) for n, s, o in param_layout(spec)}
+    for t in range(spec.T):
+        order = np.arange(spec.D) if t % 2 == 0 else np.arange(spec.D)[::-1]
+        out[f"{prefix}transform.transforms.{t}.order"] = order.astype(np.int64).copy()
+        masks = zuko_masks(spec.D, spec.C, spec.H, NP, order)
+        for j, li in enumerate((0, 2, 4)):
+            shape, off = lay[f"t{t}.ar.W{j}"]
+            out[f"{prefix}transform.transforms.{t}.hyper.{li}.weight"] = flat[off:off + int(np.prod(shape))].reshape(shape).copy()
+            bshape, boff = lay[f"t{t}.ar.b{j}"]
+            out[f"{prefix}transform.transforms.{t}.hyper.{li}.bias"] = flat[boff:boff + bshape[0]].copy()
+            out[f"{prefix}transform.transforms.{t}.hyper.{li}.mask"] = masks[j].copy()
+    return out

@@ -715,3 +715,47 @@ def test_result_buffers_are_recycled_only_when_nobody_holds_them():
         assert e2.shape == shape     # (pool off: a plain allocation each time -- nothing to assert about addresses)
     finally:
         del os.environ["SF_HOSTIO_POOL"]
+
+
+def test_zuko_state_dict_importer_round_trip_and_connectivity_checks():
+    """The lampe backend's flow (zuko.flows.NSF) in and out of the flat vector: module paths, mask / order buffers compared with
+    the engine's own connectivity (and with the oracle's masks), masked weights dropped, wrong wiring refused."""
+    from oracle import flows as OF
+    from synference_amd.importer import spec_and_flat_from_zuko_state_dict, zuko_masks, zuko_state_dict_from_flat
+    from synference_amd.spec import FlowSpec, init_params
+    rng = np.random.default_rng(0)
+    spec = FlowSpec(kind="nsf_ar", D=5, C=7, H=23, T=3, K=8, tail_bound=5.0, theta_mean=rng.normal(size=5), theta_std=rng.uniform(0.5, 2, 5),
+                    x_mean=rng.normal(size=7), x_std=rng.uniform(0.5, 2, 7))
+    flat = init_params(spec, torch.Generator().manual_seed(1)).numpy()
+    sd = zuko_state_dict_from_flat(spec, flat, prefix="flow.")
+    assert sd["flow.transform.transforms.1.order"].tolist() == [4, 3, 2, 1, 0] and sd["flow.transform.transforms.0.hyper.4.weight"].shape == (5 * 23, 23)
+    o = OF.FlowSpec(kind="nsf_ar", D=5, C=7, H=23, T=3, K=8, tail_bound=5.0)
+    for t in range(3):   # the product's masks are the oracle's
+        for a, b in zip(zuko_masks(5, 7, 23, 23, OF.ar_order(o, t)), OF.ar_masks(o, t)):
+            assert np.array_equal(a, b)
+    spec2, flat2 = spec_and_flat_from_zuko_state_dict(sd, theta_mean=spec.theta_mean, theta_std=spec.theta_std, x_mean=spec.x_mean,
+                                                      x_std=spec.x_std)
+    assert (spec2.kind, spec2.D, spec2.C, spec2.H, spec2.T, spec2.K, spec2.tail_bound) == ("nsf_ar", 5, 7, 23, 3, 8, 5.0)
+    # masked entries of the flat vector are dropped on the way (the kernels never read them), everything else survives
+    lay = {n: (s, off) for n, s, off in OF.param_layout(o)}
+    for t in range(3):
+        for j, m in enumerate(OF.ar_masks(o, t)):
+            s_, off = lay[f"t{t}.ar.W{j}"]
+            n = int(np.prod(s_))
+            assert np.array_equal(flat2[off:off + n].reshape(s_), flat[off:off + n].reshape(s_) * m)
+            bs, boff = lay[f"t{t}.ar.b{j}"]
+            assert np.array_equal(flat2[boff:boff + bs[0]], flat[boff:boff + bs[0]])
+    bad = dict(sd)
+    bad["flow.transform.transforms.2.hyper.2.mask"] = ~sd["flow.transform.transforms.2.hyper.2.mask"]
+    with pytest.raises(ValueError, match="wired differently"):
+        spec_and_flat_from_zuko_state_dict(bad)
+    bad = dict(sd)
+    bad["flow.transform.transforms.1.order"] = np.array([0, 1, 2, 3, 4])
+    with pytest.raises(ValueError, match="alternating"):
+        spec_and_flat_from_zuko_state_dict(bad)
+    with pytest.raises(KeyError, match="not a zuko"):
+        spec_and_flat_from_zuko_state_dict({"_transform._transforms.0._scale": np.ones(3)})
+    three = dict(sd)
+    three["flow.transform.transforms.0.hyper.6.weight"] = np.zeros((4, 23), np.float32)
+    with pytest.raises(ValueError, match="hidden layers"):
+        spec_and_flat_from_zuko_state_dict(three)
