@@ -5,6 +5,7 @@ Run this where ``sbi`` is installed (it is NOT in the build image, and the GPU b
 
     pip install "sbi>=0.22"            # pulls pyknos / nflows
     python scripts/export_upstream_golden.py --out tests/golden
+    pip install zuko && python scripts/export_upstream_golden.py --out tests/golden --zuko     # the lampe backend's NSF
 
 For each of {maf, nsf} it builds the estimator exactly the way the reference does
 (ref: src/synference/sbi_runner.py:5123-5146 -> ili.utils.load_nde_sbi -> sbi ``posterior_nn(model, hidden_features,
@@ -56,11 +57,49 @@ def pip_freeze():
     return [ln for ln in txt.splitlines() if ln.split("==")[0].split(" @")[0].lower() in keep]
 
 
+def export_zuko(out_dir, seed):
+    """The lampe backend's flow (ref: src/synference/sbi_runner.py:5123-5125 -> ili.utils.load_nde_lampe -> zuko.flows.NSF): needs
+    only ``pip install zuko``.  No standardisation is applied here (identity z-scores): the vectors pin the flow arithmetic --
+    masks, hidden-unit types, the monotonic rational-quadratic spline -- of oracle/flows.py kind "nsf_ar" and of csrc/sf_nsfar.hip.
+    Files: tests/golden/upstream_zuko_<case>.npz, picked up by tests/test_golden.py through
+    synference_amd.importer.spec_and_flat_from_zuko_state_dict."""
+    import zuko
+    for tag, D, C, H, T, K in (("nsf_cfg1", 5, 10, 50, 5, 8), ("nsf_small", 3, 4, 17, 2, 5), ("nsf_d1", 1, 6, 16, 3, 8)):
+        torch.manual_seed(seed)
+        flow = zuko.flows.NSF(features=D, context=C, transforms=T, hidden_features=[H, H], bins=K)
+        with torch.no_grad():
+            for p in flow.parameters():
+                p.add_(0.3 * p.abs().mean().clamp_min(0.05) * torch.randn_like(p))
+        flow.eval()
+        rng = np.random.default_rng(seed)
+        te = torch.as_tensor(rng.normal(size=(256, D)) * 1.5, dtype=torch.float32)
+        xe = torch.as_tensor(rng.normal(size=(256, C)), dtype=torch.float32)
+        z = torch.randn(256, D)
+        with torch.no_grad():
+            dist = flow(xe)                                  # NormalizingFlow(transform, base) conditioned on xe
+            lp = dist.log_prob(te)
+            th, lad = dist.transform.inv.call_and_ladj(z)    # base noise -> theta, log |d theta / d z|
+        out = {"sd/" + k: v.detach().cpu().numpy() for k, v in flow.state_dict().items()}
+        out.update(theta=te.numpy(), x=xe.numpy(), log_prob=lp.numpy().astype(np.float64), z=z.numpy(),
+                   theta_from_z=th.numpy().astype(np.float64), logabsdet_inv=lad.numpy().astype(np.float64),
+                   meta=np.array(json.dumps(dict(model="zuko_nsf", case=tag, zuko=getattr(zuko, "__version__", "?"), torch=torch.__version__,
+                                                 numpy=np.__version__, pip_freeze=pip_freeze(),
+                                                 builder_kwargs=dict(features=D, context=C, transforms=T, hidden_features=[H, H], bins=K)))))
+        os.makedirs(out_dir, exist_ok=True)
+        path = os.path.join(out_dir, f"upstream_zuko_{tag}.npz")
+        np.savez_compressed(path, **out)
+        print("wrote", path, "log_prob[:3] =", lp[:3].tolist())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="tests/golden")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--zuko", action="store_true", help="export the lampe backend's zuko.flows.NSF instead of the sbi flows")
     a = ap.parse_args()
+    if a.zuko:
+        export_zuko(a.out, a.seed)
+        return
     import sbi
     try:
         import pyknos.nflows as nf
