@@ -765,7 +765,10 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
       // average: doubling wastes at most half of a launch, a launch over the whole window up to 15/16 of it), within a
       // budget of 4M items per launch
       uint32_t A = 32;
-      while ((uint64_t)(2u * A) * (uint64_t)pending <= (1ull << 22) && 2u * A <= 65536u && 2u * A <= (attempt < 64u ? 64u : attempt)) A *= 2;
+      static int find_div = -1;  // developer knob: SF_FIND_DIV=<d>: a round tries at most attempt / d new attempts per survivor
+      if (find_div < 0) { const char* e = std::getenv("SF_FIND_DIV"); find_div = e ? std::atoi(e) : 1; if (find_div < 1) find_div = 1; }
+      const uint32_t a_max = attempt / (uint32_t)find_div < 64u ? 64u : attempt / (uint32_t)find_div;
+      while ((uint64_t)(2u * A) * (uint64_t)pending <= (1ull << 22) && 2u * A <= 65536u && 2u * A <= a_max) A *= 2;
       while (A > 1 && (uint64_t)attempt + A > (uint64_t)window_end) A /= 2;  // windows (and the caller's ceiling) are exact
       SF_HIP(hipMemsetAsync(f->d_best, 0xff, (size_t)pending * sizeof(uint32_t), st));
       p.slots = cur; p.slot_base = 0; p.n_items = (long)pending * A; p.attempts_per_slot = (int)A; p.attempt = attempt;
