@@ -494,32 +494,36 @@ def main():
     busy, _ = pmc_traffic("sample_busy") if default_wl else (None, None)
 
     note(f"sampling done: {1e3 * t_samp / a.steps:.3f} ms/step, kernel {k_ms:.3f} ms, unfilled {unfilled_all}")
-    # the same step with the all-fp32 sampler kernels (sf_set_sampler_fp32), quoted beside the default: the default MAF
-    # sampler runs its hidden H x H blocks as split-bf16 x3 products with fp32 accumulation
-    fp32_leg = None
-    if not a.hidden_bf16 and (desc.get("m16_ok") if wl["kind"] == "maf" else desc.get("nsf_split_sampler")):
+    # the same step in the OTHER arithmetic mode of the samplers' hidden blocks (sf_set_sampler_fp32), quoted beside the default.
+    # Default (round 5): a MAF samples in fp32 throughout (k_maf_samp16<.., PREC = 1>: v_mfma_f32_16x16x4_f32), the opt-in fast
+    # mode runs the hidden H x H blocks as split-bf16 x3 products; a coupling NSF's default is its split-bf16 sampler image and the
+    # other mode is the all-fp32 image.  mode_cost: the same seed drawn in both modes, both sets re-scored by the fp32 density kernel.
+    alt_leg = None
+    default_split = (not a.hidden_bf16) and wl["kind"] == "nsf" and bool(desc.get("nsf_split_sampler"))
+    has_alt = (not a.hidden_bf16) and (bool(desc.get("m16_ok")) if wl["kind"] == "maf" else bool(desc.get("nsf_split_sampler")))
+    if has_alt:
         from synference_amd import _lib as _sflib
-        _sflib.load().sf_set_sampler_fp32(1)
+        alt_mode = 1 if default_split else 0
+        _sflib.load().sf_set_sampler_fp32(alt_mode)
         try:
             sample_step(0, False)
             barrier_sync(world)
             t0 = time.perf_counter()
             n32 = max(2, min(a.steps, 5))
-            unf32 = 0
+            unf32, k32 = 0, []
             for k in range(n32):
                 unf32 += sample_step(k, False)
+                k32.append(flow.last_sample_stats["dense_ms"])
             barrier_sync(world)
             t32 = max_over_ranks(time.perf_counter() - t0, world, dev, gloo)
-            # what the split-bf16 hidden blocks cost in the units of the contract: the same seed drawn by both samplers,
-            # both sets re-scored by the fp32 density kernel (sf_flow_log_prob).  Draws whose accepted attempt differs (a
-            # candidate within rounding of the box edge) are different draws and are counted, not compared.
+            # Draws whose accepted attempt differs (a candidate within rounding of the box edge) are different draws and are
+            # counted, not compared.
             ng = min(M, 256)
             oa = torch.empty((ng, S, D), dtype=torch.float32, device=dev)
             ob = torch.empty_like(oa)
-            flow.sample(X[:ng], S, lo, hi, seed=4242, out=ob)             # fp32 kernels (switch is on)
-            _sflib.load().sf_set_sampler_fp32(0)
-            flow.sample(X[:ng], S, lo, hi, seed=4242, out=oa)             # default: split-bf16 x3 hidden blocks
-            _sflib.load().sf_set_sampler_fp32(1)
+            flow.sample(X[:ng], S, lo, hi, seed=4242, out=ob)             # the other mode (switch is on)
+            _sflib.load().sf_set_sampler_fp32(-1)
+            flow.sample(X[:ng], S, lo, hi, seed=4242, out=oa)             # default
             sig = torch.as_tensor(np.asarray(est.spec.theta_std), dtype=torch.float32, device=dev)
             dth = ((oa - ob).abs() / sig).amax(-1)                        # (ng, S) in units of the parameter std
             same = dth < 1e-3
@@ -531,15 +535,23 @@ def main():
                           "max_abs_dlogp": float(dlp.max().item()), "median_abs_dlogp": float(dlp.median().item()),
                           "p999_abs_dlogp": float(torch.quantile(dlp.float(), 0.999).item()) if dlp.numel() < 16_000_000 else None,
                           "max_dtheta_over_sigma": float(dth[same].max().item()),
-                          "note": "same seed through the default (split-bf16 x3 hidden blocks) and the all-fp32 sampler kernels; "
-                                  "|d log_prob| of the two draws under the fp32 density kernel; north_star tolerance 1e-4"}
-            fp32_leg = {"kernel": ("k_sample_persist<MafOps>" if wl["kind"] == "maf" else "k_sample_persist<NsfOps<..., BF = 0>>") +
-                                  " (32-row tiles, v_mfma_f32_32x32x2_f32 everywhere)",
-                        "ms_per_step": 1e3 * t32 / n32, "value": (world * n32 * M * S - unf32 * world) / t32,
-                        "unit": "samples/s", "steps": n32, "split_bf16_cost": split_cost}
+                          "note": "same seed through the split-bf16 x3 and the all-fp32 sampler kernels; |d log_prob| of the two "
+                                  "draws under the fp32 density kernel; north_star tolerance 1e-4"}
+            if wl["kind"] == "maf":
+                alt_kernel = "k_maf_samp16<.., PREC = 0> (hidden H x H blocks as split-bf16 x3 products on v_mfma_f32_16x16x32_bf16, fp32 accumulate)"
+            else:
+                alt_kernel = "k_sample_persist<NsfOps<..., BF = 0>> (32-row tiles, v_mfma_f32_32x32x2_f32 everywhere)"
+            k32_ms = float(np.mean(k32))
+            alt_leg = {"mode": "fp32" if alt_mode == 1 else "split-bf16 x3 hidden blocks (opt-in: sf_set_sampler_fp32(0) / SF_SAMPLER_FP32=0)",
+                       "kernel": alt_kernel, "ms_per_step": 1e3 * t32 / n32, "value": (world * n32 * M * S - unf32 * world) / t32,
+                       "unit": "samples/s", "steps": n32, "launch_ms": k32_ms,
+                       "roofline": {"bound": "mfma", "achieved": f_min * (M * S - unf32 / n32) / (k32_ms * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS,
+                                    "unit": "TFLOP/s", "frac": f_min * (M * S - unf32 / n32) / (k32_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                                    "traffic": None},
+                       "split_bf16_cost": split_cost}
         finally:
-            _sflib.load().sf_set_sampler_fp32(0)
-        note(f"fp32 sampler leg: {fp32_leg['ms_per_step']:.3f} ms/step")
+            _sflib.load().sf_set_sampler_fp32(-1)
+        note(f"{alt_leg['mode'].split()[0]} sampler leg: {alt_leg['ms_per_step']:.3f} ms/step")
     # ---------------- API level: the reference's own call, SBI_Fitter.sample_posterior(X, num_samples) -> HOST float64 (N, S, D)
     # (sbi_runner.py:6436-6442; `log_times` statistic of 6461-6469; examples/paper/model_testing.ipynb:1543-1553), and
     # fit_catalogue's quantile-only path (device quantiles, only (N, D, Q) leaves the GPU).  Rank-local (shard=False): every
@@ -720,11 +732,11 @@ def main():
     train_tf = f_train * B / (train_kernel_ms * 1e-3) / 1e12
     ttraffic, ttraffic_src = pmc_traffic("train") if a.workload == "maf_cfg2" else (None, None)
     kname = "k_ar_sample (one wave per 64 draws, one hyper-network sweep per transform)" if wl["kind"] == "nsf_ar" else \
-            (("k_maf_samp16<NB,SPAN,HM,TPW,DD>" if desc.get("m16_ok") and not a.hidden_bf16 else "k_sample_persist<MafOps>")
+            (("k_maf_samp16<NB,SPAN,HM,TPW,DD,PREC=1> (16-row tiles, every product on v_mfma_f32_16x16x4_f32)" if desc.get("m16_ok") and not a.hidden_bf16 else "k_sample_persist<MafOps>")
              if wl["kind"] == "maf" else
              ("k_sample_persist<NsfOps<..., BF = 2>> (sampler image, split-bf16 hidden blocks)" if desc.get("nsf_split_sampler") and
               not a.hidden_bf16 else "k_sample_persist<NsfOps>"))
-    split = (not a.hidden_bf16) and bool(desc.get("m16_ok") if wl["kind"] == "maf" else desc.get("nsf_split_sampler"))
+    split = default_split
     tpath = flow.train_path(B)
     tkname = ({1: "k_maf_trainc<TS,NI,NT,1> (cooperative 16-row tiles, 4 waves per 32 samples)",
                2: "k_maf_trainc<TS,NI,NT,2> (cooperative 16-row tiles, 8 waves per 64 samples)",
@@ -761,10 +773,9 @@ def main():
                              "transform (SURVEY 8d; MAF cfg1 40030 FLOP/draw -- the least any algorithm needs; the "
                              "reference's D-pass inverse spends 175150) x ACCEPTED draws; rejected evaluations, tile "
                              "padding and the per-galaxy context kernel are overhead.  issue_busy = SQ counters "
-                             "of the committed PMC summary (the hidden blocks run as three bf16 MFMAs, so MFMA FLOPs are no "
-                             "longer comparable with the fp32 peak; what binds is vector ISSUE: VALU + the MFMAs' issue slots, DESIGN.md section 3); contract_* = SURVEY "
+                             "of the committed PMC summary; contract_* = SURVEY "
                              "8d's figure for the reference algorithm x accepted draws (an algorithmic ratio, can exceed 1).",
-                     "issue_busy": busy, "fp32_sampler": fp32_leg,
+                     "issue_busy": busy, ("fp32_sampler" if default_split else "split_bf16_sampler"): alt_leg,
                      "contract_tflops": contract, "contract_ratio": contract / PEAK_FP32_TFLOPS},
         "roofline_train": {"bound": "mfma", "kernel": tkname,
                            "achieved": train_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",

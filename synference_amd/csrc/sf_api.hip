@@ -142,6 +142,7 @@ void sf_flow_destroy(sf_flow* f) {
     sf_nsf1_destroy(f->nsf1);
     sf_nsfar_destroy(f->nsfar);
     if (f->dev_ready) (void)hipFree(f->d_flat);
+    (void)hipFree(f->d_losspart_mem);   // (sf_flow_train_epoch allocates it for every kind)
     if (f->ev_train[0]) (void)hipEventDestroy(f->ev_train[0]);
     if (f->ev_train[1]) (void)hipEventDestroy(f->ev_train[1]);
     if (f->ev_dense[0]) (void)hipEventDestroy(f->ev_dense[0]);
@@ -399,14 +400,14 @@ int sf_flow_inverse_from_noise_sampler(sf_flow* f, const float* z, const float* 
     return ms.hidden_bf16 == 2 ? SF_OK : 1;
   }
   const SfDev m = f->dev();
-  if (!sf_maf16b_available(m) || sf_sampler_fp32_get()) {  // the sampler of this flow is the fp32 path
+  if (!sf_maf16b_available(m)) {  // the sampler of this flow is the 32-row fp32 path
     SfSampleArgsHost a;
     a.x = x; a.z_in = z; a.n_items = (long)B; a.out = theta;
     SF_HIP(sf_launch_inverse(m, a, (hipStream_t)stream));
     return 1;  // (positive: "fp32 path", not an error)
   }
   SF_HIP(sf_launch_maf_inv16b_hook(m, z, x, (long)B, theta, (hipStream_t)stream));
-  return SF_OK;
+  return sf_sampler_fp32_for(SF_MAF) ? 2 : SF_OK;   // 2: the 16-row sampler's fp32 pass functions
 }
 
 int sf_set_sampler_fp32(int on) {
@@ -479,7 +480,7 @@ int sf_flow_release_context(sf_flow* f) {
 // hidden_bf16 == 2.  sf_set_sampler_fp32(1) / SF_SAMPLER_FP32=1 keeps the all-fp32 image.
 static void nsf_sampler_view(const sf_flow* f, SfDev& m) {
   const SfNsfSamp& s = f->L.nsfS;
-  if (m.kind != SF_NSF || !s.ok || m.hidden_bf16 || !f->d_packed16 || !f->d_packed16B || f->packed16_stale || sf_sampler_fp32_get()) return;
+  if (m.kind != SF_NSF || !s.ok || m.hidden_bf16 || !f->d_packed16 || !f->d_packed16B || f->packed16_stale || sf_sampler_fp32_for(SF_NSF)) return;
   m.packed = f->d_packed16;
   m.t_stride = s.t_stride;
   m.o_winu = s.o_winu; m.o_winc = s.o_winc; m.o_bin = s.o_bin; m.o_wout = s.o_wout; m.o_bout = s.o_bout; m.o_lu = s.o_lu;
@@ -1049,9 +1050,13 @@ int sf_flow_train_epoch(sf_flow* f, float* flat, const float* theta, const float
       if (f->step_exec) { (void)hipGraphExecDestroy(f->step_exec); f->step_exec = nullptr; }   // (the buffer moved)
     }
     if (ok) {
-      unsigned long long key[16] = {(unsigned long long)flat, (unsigned long long)theta, (unsigned long long)x, (unsigned long long)order,
+      // (the handle's lazily grown buffers are baked into the captured kernels' arguments: a loss_grad call at a larger batch
+      //  between two epoch calls moves them, and the key must notice)
+      unsigned long long key[20] = {(unsigned long long)flat, (unsigned long long)theta, (unsigned long long)x, (unsigned long long)order,
                                     (unsigned long long)batch, 0, (unsigned long long)exp_avg, (unsigned long long)exp_avg_sq, 0, 0, 0,
-                                    (unsigned long long)scratch, (unsigned long long)grad, (unsigned long long)loss_sum, 0, 0};
+                                    (unsigned long long)scratch, (unsigned long long)grad, (unsigned long long)loss_sum, 0, 0,
+                                    (unsigned long long)f->d_gpartC, (unsigned long long)f->d_ustash, (unsigned long long)f->d_sqpart,
+                                    (unsigned long long)f->d_gfixC};
       std::memcpy(&key[5], &grad_scale, sizeof(float));
       std::memcpy(&key[8], d, sizeof(sf_adam_desc) < 24 ? sizeof(sf_adam_desc) : 24);
       std::memcpy(&key[14], &max_norm, sizeof(float));
@@ -1092,6 +1097,7 @@ int sf_flow_train_epoch(sf_flow* f, float* flat, const float* theta, const float
         SF_HIP(hipEventRecord(f->step_ev[1], f->step_stream));
         SF_HIP(hipStreamWaitEvent(user, f->step_ev[1], 0));
         f->params_set = true; f->flat_valid = false; f->ctab_x = nullptr;
+        f->packed_stale = false; f->packed16_stale = false;   // (the captured step re-tiles every image)
         return SF_OK;
       }
     }

@@ -78,7 +78,8 @@ hipError_t sf_launch_maf_inv16(const SfDev& m, const SfSampleArgsHost& a, hipStr
 bool sf_maf16b_available(const SfDev& m);
 hipError_t sf_launch_maf_inv16b_hook(const SfDev& m, const float* z, const float* x, long n, float* out, hipStream_t st);
 void sf_sampler_fp32_set(int on);
-int sf_sampler_fp32_get();
+int sf_sampler_fp32_get();        // 1 fp32, 0 split bf16 x3, -1 unset: per flow kind
+int sf_sampler_fp32_for(int kind);  // the mode a flow of this kind samples in (unset: MAF fp32, NSF split)
 // per-galaxy context table: rows/variants for this flow (0 = the flow has no table path), builder
 void sf_ctab_shape(const SfDev& m, int& R, int& NV);
 hipError_t sf_launch_ctab(const SfDev& m, const float* x, long M, float* tab, hipStream_t st);
@@ -170,7 +171,7 @@ struct sf_flow {
   float* d_step_bc = nullptr;            // [2]: Adam's bias corrections of the running step
   long long* d_step_rows = nullptr;      // the running batch's rows
   size_t step_rows_cap = 0;
-  unsigned long long step_key[16] = {0}; // what the graph was captured for
+  unsigned long long step_key[20] = {0}; // what the graph was captured for
   float* d_ustash = nullptr;    // cooperative NSF training (sf_nsfc.hip): u / u' of every transform, [rows][T][16]
   size_t ustash_cap = 0;        // floats
   float* d_act = nullptr;       // activation stash (training)

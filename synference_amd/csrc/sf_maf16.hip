@@ -444,13 +444,27 @@ struct SfPass16B {
                        // L2 round trip is over before the pass that starts its dependent chain with it
   bool tab;            // wave-uniform: the table exists (c0p is per lane, the decision is not)
 };
+// The same state with the hidden blocks' inputs in fp32 (PREC = 1: v_mfma_f32_16x16x4_f32 everywhere, see sf_pass16f)
+struct SfPass16F {
+  f32x4 act[2][4];     // inputs of hidden block k ([0] = initial layer, [1] = output of block 0); [tile]: C/D layout of the MFMA
+                       // that wrote them = B-operand order of the one that reads them
+  f32x4 head[4];       // output of the last block; [tile]   (HM = false)
+  f32x4 hdone;         // HM: see SfPass16B
+  f32x4 ut;
+  const float* c0p;
+  const float* xr;
+  f32x4 c0n;
+  bool tab;
+};
 // request c0 of tile `ot` of the current transform (table path only)
-__device__ __forceinline__ void sf_c0_prefetch(SfPass16B& S, int ot, int g4) {
+template <typename ST>
+__device__ __forceinline__ void sf_c0_prefetch(ST& S, int ot, int g4) {
   S.c0n = *reinterpret_cast<const f32x4*>(S.c0p + ot * 16 + 4 * g4);
 }
 // c0 of tile ot = b0 + bc + Wc e(x): from the per-galaxy table, else evaluated on the spot (rare: tables above the
 // size cap); either way it is not kept in registers across the passes
-__device__ __forceinline__ f32x4 sf_c0_16(const SfDev& m, const float* tp, const SfPass16B& S, int ot, int lane, int g4) {
+template <typename ST>
+__device__ __forceinline__ f32x4 sf_c0_16(const SfDev& m, const float* tp, const ST& S, int ot, int lane, int g4) {
   if (S.c0p) return *reinterpret_cast<const f32x4*>(S.c0p + ot * 16 + 4 * g4);
   f32x4 c = sf_ld4(tp + m.o16_b0 + (ot * 4 + g4) * 4);
   for (int ic = 0; ic < m.nC16; ++ic) {
@@ -628,6 +642,257 @@ __device__ __forceinline__ void sf_pass16b_span(const SfDev& m, const float* tp,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// fp32 hidden blocks (PREC = 1): the passes of the persistent sampler with EVERY product on v_mfma_f32_16x16x4_f32 -- the
+// arithmetic of BASELINE configs[1] ("fp32"), draw for draw the fmaf chains of the density kernel.  Same incremental
+// inverse, same tiles, same queue; what changes is the operand form of the H x H blocks: 16 x 16 fp32 fragments
+// (float4[block * 64 + lane], the layout of part A) instead of split-bf16 pairs, and the activation state is the
+// accumulator tile itself (no conversion between layers).  The blocks are copied into LDS behind part A from the full
+// fp32 image (packed16 + o16_wk): aligned placement (CP) only the blocks on and below the diagonal -- a tile never reads
+// tiles above its own -- as entries ot (ot + 1) / 2 + it; contiguous placement all NT x NT.
+// Cost: (OT + 1) x 4 MFMAs of 32 cycles per block row instead of (OT / 2 + 1) x 3 of 16: the matrix pipe, not the
+// vector issue port, bounds this kernel's dense phase ("fp32 sampler").
+// ---------------------------------------------------------------------------------------------------------------
+template <bool CP>
+__device__ __forceinline__ float4 sf_w16f(const float* wF, int NT, int ot, int it, int lane) {
+  const int e = CP ? (ot * (ot + 1)) / 2 + it : ot * NT + it;
+  return reinterpret_cast<const float4*>(wF)[e * 64 + lane];
+}
+template <bool CP>
+__device__ __forceinline__ int sf_f16_block_floats(int NT) { return (CP ? NT * (NT + 1) / 2 : NT * NT) * 256; }
+
+template <int OT, int NB, bool CP, bool HM = false>
+__device__ __forceinline__ void sf_pass16f(const SfDev& m, const float* tp, const float* tpF, SfPass16F& S, int NT, int sl,
+                                           float u_sl, int lane, int g4, int next_ot = -1) {
+  const int BF = sf_f16_block_floats<CP>(NT);
+  f32x4 c0;
+  if (CP && HM && S.tab) {
+    c0 = S.c0n;
+    if (next_ot >= 0) sf_c0_prefetch(S, next_ot, g4);
+  } else {
+    c0 = sf_c0_16(m, tp, S, OT, lane, g4);
+  }
+  const float* hv = tp + m.o16_hv + sl * 128 + g4 * 32;
+  const float4 w0 = sf_w16(tp + m.o16_w0, 1, OT, 0, lane);
+  f32x2 pam = {0.f, 0.f};
+  if (!HM) {
+#pragma unroll
+    for (int tl = 0; tl < OT; ++tl)
+      pam = sf_head_acc(pam, *reinterpret_cast<const float4*>(hv + tl * 8), *reinterpret_cast<const float4*>(hv + tl * 8 + 4), S.head[tl]);
+  }
+  f32x4 last;
+  float4 wh;
+  // One block row's fragments are in flight at a time.  The products with the tiles finished in earlier passes (it < OT)
+  // do not depend on this pass: they are issued under the initial layer's chain (block 0) and under the tanh of block k
+  // (block k + 1), so that the dependent chain of a pass is w0 -> W0[OT, OT] -> tanh -> W1[OT, OT] -> tanh -> head.
+  float4 fw[OT + 1];
+  f32x4 b = sf_ld4(tp + m.o16_bk[0] + (OT * 4 + g4) * 4);
+#pragma unroll
+  for (int it = 0; it <= OT; ++it) fw[it] = sf_w16f<CP>(tpF, NT, OT, it, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  S.act[0][OT] = sf_mma16(w0, S.ut, c0);
+#pragma unroll
+  for (int it = 0; it < OT; ++it) b = sf_mma16(fw[it], S.act[0][it], b);
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    b = sf_mma16(fw[OT], S.act[k][OT], b);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 bn;
+    if (k + 1 < NB) {
+      bn = sf_ld4(tp + m.o16_bk[k + 1 < NB ? k + 1 : k] + (OT * 4 + g4) * 4);
+#pragma unroll
+      for (int it = 0; it <= OT; ++it) fw[it] = sf_w16f<CP>(tpF + (k + 1 < NB ? k + 1 : k) * BF, NT, OT, it, lane);
+    } else if (HM) {
+      wh = sf_w16(tp + m.o16_wh, NT, 0, OT, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x4 th = sf_tanh4(b);
+    if (k + 1 < NB) {
+#pragma unroll
+      for (int it = 0; it < OT; ++it) bn = sf_mma16(fw[it], S.act[k + 1][it], bn);
+      S.act[k + 1][OT] = th;
+      b = bn;
+    } else {
+      last = th;
+    }
+  }
+  float av, mv;
+  if (HM) {
+    const f32x4 fresh = sf_mma16(wh, last, S.hdone);
+    if (next_ot != OT) S.hdone = fresh;
+    const bool odd = (sl & 1) != 0;
+    const int src = (lane & 15) + 16 * (sl >> 1);
+    av = __shfl(odd ? fresh[2] : fresh[0], src, 64);
+    mv = __shfl(odd ? fresh[3] : fresh[1], src, 64);
+  } else {
+    S.head[OT] = last;
+    pam = sf_head_acc(pam, *reinterpret_cast<const float4*>(hv + OT * 8), *reinterpret_cast<const float4*>(hv + OT * 8 + 4), S.head[OT]);
+    av = tp[m.o16_hvb + 2 * sl] + sf_sum4groups(pam[0]);
+    mv = tp[m.o16_hvb + 2 * sl + 1] + sf_sum4groups(pam[1]);
+  }
+  const float sc = (m.scale_fn == 0 ? sf_softplus(av) : sf_sigmoid(av + 2.0f)) + m.eps;
+  const float wv = sf_div(u_sl - mv, sc);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) S.ut[r] = (g4 == (sl >> 2) && r == (sl & 3)) ? wv : S.ut[r];
+}
+
+// The fp32 pass when the degree group straddles tiles LO..HI (contiguous packing; see sf_pass16_span).
+template <int LO, int HI, int NB>
+__device__ __forceinline__ void sf_pass16f_span(const SfDev& m, const float* tp, const float* tpF, SfPass16F& S, int NT, int sl,
+                                                float u_sl, int lane, int g4) {
+  const int BF = sf_f16_block_floats<false>(NT);
+  const float* hv = tp + m.o16_hv + sl * 128 + g4 * 32;
+#pragma unroll
+  for (int ot = LO; ot <= HI; ++ot) S.act[0][ot] = sf_mma16(sf_w16(tp + m.o16_w0, 1, ot, 0, lane), S.ut, sf_c0_16(m, tp, S, ot, lane, g4));
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    f32x4 nb[HI - LO + 1];
+#pragma unroll
+    for (int ot = LO; ot <= HI; ++ot) {
+      f32x4 b = sf_ld4(tp + m.o16_bk[k] + (ot * 4 + g4) * 4);
+#pragma unroll
+      for (int it = 0; it <= HI; ++it) b = sf_mma16(sf_w16f<false>(tpF + k * BF, NT, ot, it, lane), S.act[k][it], b);
+      nb[ot - LO] = sf_tanh4(b);
+    }
+#pragma unroll
+    for (int ot = LO; ot <= HI; ++ot) {
+      if (k + 1 < NB) S.act[k + 1][ot] = nb[ot - LO];
+      else S.head[ot] = nb[ot - LO];
+    }
+  }
+  f32x2 pam = {0.f, 0.f};
+#pragma unroll
+  for (int tl = 0; tl <= HI; ++tl)
+    pam = sf_head_acc(pam, *reinterpret_cast<const float4*>(hv + tl * 8), *reinterpret_cast<const float4*>(hv + tl * 8 + 4),
+                      S.head[tl]);
+  const float av = tp[m.o16_hvb + 2 * sl] + sf_sum4groups(pam[0]);
+  const float mv = tp[m.o16_hvb + 2 * sl + 1] + sf_sum4groups(pam[1]);
+  const float sc = (m.scale_fn == 0 ? sf_softplus(av) : sf_sigmoid(av + 2.0f)) + m.eps;
+  const float wv = sf_div(u_sl - mv, sc);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) S.ut[r] = (g4 == (sl >> 2) && r == (sl & 3)) ? wv : S.ut[r];
+}
+
+// ---- what the kernels below see of the two operand forms (PREC: 0 = split bf16 x3, 1 = fp32)
+template <int PREC> struct SfHid16;
+template <> struct SfHid16<0> {
+  using State = SfPass16B;
+  template <int OT, int NB, bool CP, bool HM>
+  static __device__ __forceinline__ void pass(const SfDev& m, const float* tp, const void* tpH, State& S, int NT, int sl, float u_sl,
+                                              int lane, int g4, int next_ot) {
+    sf_pass16b<OT, NB, CP, HM>(m, tp, static_cast<const unsigned int*>(tpH), S, NT, sl, u_sl, lane, g4, next_ot);
+  }
+  template <int LO, int HI, int NB>
+  static __device__ __forceinline__ void span(const SfDev& m, const float* tp, const void* tpH, State& S, int NT, int sl, float u_sl,
+                                              int lane, int g4) {
+    sf_pass16b_span<LO, HI, NB>(m, tp, static_cast<const unsigned int*>(tpH), S, NT, sl, u_sl, lane, g4);
+  }
+  // cleared per tile and transform: a non-finite value left behind by one draw must not reach another one through a
+  // structural zero (a pass only reads tiles that an earlier pass of the SAME tile and transform wrote, or zeros).
+  // SEQ (unrolled kernels: passes in tile order 0, 1, 2, 3): the only operands read before this tile and transform wrote
+  // them are the odd tiles (the second half of a pair, read with all-zero weights by the pass of the even tile)
+  template <bool SEQ, bool HM>
+  static __device__ __forceinline__ void clear(State& S) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int c = SEQ ? 2 : 0; c < 4; ++c) { S.ph[k][pr][c] = 0u; S.pl[k][pr][c] = 0u; }
+    if (!HM) {
+#pragma unroll
+      for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S.head[ot][r] = 0.f;
+    }
+  }
+  // LDS floats behind part A
+  static __host__ __device__ int lds_floats(const SfDev& m, bool /*cp*/) { return m.t16B_stride; }
+};
+template <> struct SfHid16<1> {
+  using State = SfPass16F;
+  template <int OT, int NB, bool CP, bool HM>
+  static __device__ __forceinline__ void pass(const SfDev& m, const float* tp, const void* tpH, State& S, int NT, int sl, float u_sl,
+                                              int lane, int g4, int next_ot) {
+    sf_pass16f<OT, NB, CP, HM>(m, tp, static_cast<const float*>(tpH), S, NT, sl, u_sl, lane, g4, next_ot);
+  }
+  template <int LO, int HI, int NB>
+  static __device__ __forceinline__ void span(const SfDev& m, const float* tp, const void* tpH, State& S, int NT, int sl, float u_sl,
+                                              int lane, int g4) {
+    sf_pass16f_span<LO, HI, NB>(m, tp, static_cast<const float*>(tpH), S, NT, sl, u_sl, lane, g4);
+  }
+  // SEQ: a pass reads tiles 0 .. OT of its own tile and transform only, all written by then -- nothing to clear
+  template <bool SEQ, bool HM>
+  static __device__ __forceinline__ void clear(State& S) {
+    if (!SEQ) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) S.act[k][ot][r] = 0.f;
+    }
+    if (!HM) {
+#pragma unroll
+      for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S.head[ot][r] = 0.f;
+    }
+  }
+  static __host__ __device__ int lds_floats(const SfDev& m, bool cp) {
+    const int nb = m.NB < 2 ? m.NB : 2;
+    return nb * (cp ? m.nT16 * (m.nT16 + 1) / 2 : m.nT16 * m.nT16) * 256;
+  }
+};
+
+// Staging of one transform's operands (all four waves; the caller brackets it with barriers): part A of the fp32 image
+// (`a_floats` floats: input layer, biases, head rows; + the context block without a table) in 4 KiB groups -- ONE address, four
+// immediate offsets -- and behind it the hidden blocks: PREC 0 the split-bf16 image (4 KiB groups), PREC 1 the fp32 blocks
+// of the full image, 1 KiB (one 16 x 16 block) per wave-instruction.  Direct global -> LDS copies.
+template <int PREC, bool CP>
+__device__ __forceinline__ void sf_stage16(const SfDev& m, int t, int a_floats, int wave) {
+  const int lane_ = threadIdx.x & 63;
+  const int ga = a_floats >> 10;
+  const float4* __restrict__ sa = reinterpret_cast<const float4*>(m.packed16 + (size_t)t * m.t16_stride);
+  float4* __restrict__ d4 = reinterpret_cast<float4*>(sf_lds16);
+  if constexpr (PREC == 0) {
+    const int gb = m.t16B_stride >> 10;
+    const float4* __restrict__ sb = reinterpret_cast<const float4*>(m.packed16B + (size_t)t * m.t16B_stride);
+    for (int gi = __builtin_amdgcn_readfirstlane(wave); gi < ga + gb; gi += 4) {
+      const float4* g = (gi < ga ? sa + gi * 256 : sb + (gi - ga) * 256) + lane_;
+      float4* l = d4 + gi * 256;
+      __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 1024, 0);
+      __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 2048, 0);
+      __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 3072, 0);
+    }
+  } else {
+    for (int gi = __builtin_amdgcn_readfirstlane(wave); gi < ga; gi += 4) {
+      const float4* g = sa + gi * 256 + lane_;
+      float4* l = d4 + gi * 256;
+      __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 1024, 0);
+      __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 2048, 0);
+      __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 3072, 0);
+    }
+    const int NT = m.nT16, nb = m.NB < 2 ? m.NB : 2;
+    const int per = CP ? NT * (NT + 1) / 2 : NT * NT;
+    float4* __restrict__ dF = d4 + (a_floats >> 2);
+    for (int e = __builtin_amdgcn_readfirstlane(wave); e < nb * per; e += 4) {
+      const int k = e >= per ? 1 : 0, ee = e - k * per;
+      int src_blk = ee;
+      if (CP) {  // entry ot (ot + 1) / 2 + it  ->  block ot * NT + it   (NT <= 4)
+        const int ot = ee >= 6 ? 3 : (ee >= 3 ? 2 : (ee >= 1 ? 1 : 0));
+        src_blk = ot * NT + (ee - ot * (ot + 1) / 2);
+      }
+      const int owk = k ? m.o16_wk[1] : m.o16_wk[0];  // (no dynamic index into the descriptor)
+      const float4* g = sa + ((owk >> 2) + src_blk * 64) + lane_;
+      __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)(dF + e * 64), 16, 0, 0);
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the copies have landed
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Persistent sampler: the same tile pipeline as k_maf_inv16, driven by the device work queue of sf_queue.h.  One
 // launch resolves every slot of the dense list (first attempts AND retries); sampler only (no parity hook, no
 // acceptance mode, no log-determinant).
@@ -671,14 +936,16 @@ struct SfFix16 {
 // DD > 0 (HM, aligned placement with ONE degree group per tile, D == DD <= 5): the passes of a transform are unrolled
 // with the tile of each known at compile time (pass p works on tile p - 2) -- no dispatch, and the per-tile state is
 // updated in place instead of being copied into the registers every arm of the switch has to agree on.
-template <int NB, bool SPAN, bool HM, int TPW, int DD = 0>
+// PREC: operand form of the hidden H x H blocks (SfHid16): 0 = split bf16 x3, 1 = fp32.
+template <int NB, bool SPAN, bool HM, int TPW, int DD = 0, int PREC = 0>
 __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args args_in) {
   static_assert(DD == 0 || (HM && !SPAN && DD >= 2 && DD <= 5), "unrolled passes: head tile, aligned placement, D <= 5");
+  using HID = SfHid16<PREC>;
   constexpr int IPW = 64 * TPW;
   const int wave = threadIdx.x >> 6;
   // with the per-galaxy context table the context block Wc is never read: only the prefix of part A before it is staged
   unsigned int* ctrl = reinterpret_cast<unsigned int*>(
-      sf_lds16 + (args_in.m.ctab ? args_in.m.t16_a_tab : args_in.m.t16_a) + args_in.m.t16B_stride);
+      sf_lds16 + (args_in.m.ctab ? args_in.m.t16_a_tab : args_in.m.t16_a) + HID::lds_floats(args_in.m, !SPAN));
   unsigned int pf;
   sf_q_begin<IPW>(args_in.a, ctrl, pf);
   // per-slot constants of the epilogue, once per workgroup: {shift, 1 / scale, lo, hi, theta column} of physical slot p.
@@ -776,7 +1043,7 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
         lo_bits |= (uint32_t)(m.g16_lo[q] & 3) << (2 * q);
       }
     }
-    SfPass16B S;
+    typename HID::State S;
     S.tab = DD > 0 ? true : m.ctab != nullptr;  // (the unrolled kernels are only launched with the context table)
     for (int t = m.T - 1; t >= 0; --t) {
       // requested before the staging barriers so that their round trips overlap with the image copy: the degree ->
@@ -788,31 +1055,14 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
       { const unsigned long long n = __builtin_amdgcn_s_memrealtime(); qs_ph[qs_o + (t == m.T - 1 ? 1 : 3)] += n - qs_t_mark; qs_t_mark = n; }
 #endif
       __syncthreads();
-      {
-        // part A of the fp32 image (input layer, biases, head rows; + the context block without a table) and the
-        // split-bf16 hidden blocks, one behind the other in LDS: direct global -> LDS copies, 4 KiB groups (ONE
-        // address, four immediate offsets)
-        const int lane_ = threadIdx.x & 63;
-        const int ga = (S.tab ? m.t16_a_tab : m.t16_a) >> 10, gb = m.t16B_stride >> 10;
-        const float4* __restrict__ sa = reinterpret_cast<const float4*>(m.packed16 + (size_t)t * m.t16_stride);
-        const float4* __restrict__ sb = reinterpret_cast<const float4*>(m.packed16B + (size_t)t * m.t16B_stride);
-        float4* __restrict__ d4 = reinterpret_cast<float4*>(sf_lds16);
-        for (int gi = __builtin_amdgcn_readfirstlane(wave); gi < ga + gb; gi += 4) {
-          const float4* g = (gi < ga ? sa + gi * 256 : sb + (gi - ga) * 256) + lane_;
-          float4* l = d4 + gi * 256;
-          __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 0, 0);
-          __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 1024, 0);
-          __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 2048, 0);
-          __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 3072, 0);
-        }
-        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the copies have landed
-      }
+      // part A of the fp32 image and the hidden blocks, one behind the other in LDS
+      sf_stage16<PREC, !SPAN>(m, t, S.tab ? m.t16_a_tab : m.t16_a, wave);
       __syncthreads();
 #ifdef SF_Q_STATS
       { const unsigned long long n = __builtin_amdgcn_s_memrealtime(); qs_ph[qs_o + 2] += n - qs_t_mark; qs_t_mark = n; }
 #endif
       const float* tp = sf_lds16;
-      const unsigned int* tpB = reinterpret_cast<const unsigned int*>(sf_lds16 + (S.tab ? m.t16_a_tab : m.t16_a));
+      const void* tpB = sf_lds16 + (S.tab ? m.t16_a_tab : m.t16_a);
 #pragma unroll 1
       for (int j = 0; j < TPW; ++j) {
         // a wave whose tile holds no item (tail iterations with few entries) skips the flow: its issue slots go to the
@@ -824,32 +1074,7 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
             if (HM && S.tab) sf_c0_prefetch(S, (int)((tile_bits >> 2) & 3u), g4);
           }
           S.xr = a.x + gal_cur * m.C;
-          // cleared per tile and transform: a non-finite value left behind by one draw must not reach another one
-          // through a structural zero (a pass only reads tiles that an earlier pass of the SAME tile and transform wrote,
-          // or zeros)
-          if constexpr (DD > 0) {
-            // passes run in tile order 0, 1, 2, 3: the only operands read before this tile and transform wrote them are
-            // the odd tiles (the second half of a pair, read with all-zero weights by the pass of the even tile)
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-#pragma unroll
-              for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-                for (int c = 2; c < 4; ++c) { S.ph[k][pr][c] = 0u; S.pl[k][pr][c] = 0u; }
-          } else {
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-#pragma unroll
-              for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { S.ph[k][pr][c] = 0u; S.pl[k][pr][c] = 0u; }
-          }
-          if (!HM) {
-#pragma unroll
-            for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) S.head[ot][r] = 0.f;
-          }
+          HID::template clear<(DD > 0), HM>(S);
 #pragma unroll
           for (int r = 0; r < 4; ++r) S.ut[r] = 0.f;
           if (HM) S.hdone = sf_ld4(tp + m.o16_bh + g4 * 4);
@@ -865,7 +1090,7 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
             auto seq_pass = [&](auto otc) {
               constexpr int OT = decltype(otc)::value;
               const int sl = __builtin_amdgcn_readlane(dsl, OT + 1);
-              sf_pass16b<OT, NB, true, true>(m, tp, tpB, S, NT, sl, sf_slot16_own(u_cur, sl), lane, g4, OT + 2 < DD ? OT + 1 : -1);
+              HID::template pass<OT, NB, true, true>(m, tp, tpB, S, NT, sl, sf_slot16_own(u_cur, sl), lane, g4, OT + 2 < DD ? OT + 1 : -1);
             };
             seq_pass(std::integral_constant<int, 0>{});
             if constexpr (DD >= 3) seq_pass(std::integral_constant<int, 1>{});
@@ -879,16 +1104,16 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
             const uint32_t lo_t = SPAN ? (lo_bits >> (2 * (p - 1))) & 3u : hi_t;
             const int nx = p < m.D ? (int)((tile_bits >> (2 * p)) & 3u) : -1;  // tile of the next pass (aligned placement)
             switch (lo_t * 4 + hi_t) {
-              case 0: sf_pass16b<0, NB, !SPAN, HM>(m, tp, tpB, S, NT, sl, u_sl, lane, g4, nx); break;
-              case 5: sf_pass16b<1, NB, !SPAN, HM>(m, tp, tpB, S, NT, sl, u_sl, lane, g4, nx); break;
-              case 10: sf_pass16b<2, NB, !SPAN, HM>(m, tp, tpB, S, NT, sl, u_sl, lane, g4, nx); break;
-              case 15: sf_pass16b<3, NB, !SPAN, HM>(m, tp, tpB, S, NT, sl, u_sl, lane, g4, nx); break;
-              case 1: if (SPAN) sf_pass16b_span<0, 1, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
-              case 2: if (SPAN) sf_pass16b_span<0, 2, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
-              case 3: if (SPAN) sf_pass16b_span<0, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
-              case 6: if (SPAN) sf_pass16b_span<1, 2, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
-              case 7: if (SPAN) sf_pass16b_span<1, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
-              default: if (SPAN) sf_pass16b_span<2, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+              case 0: HID::template pass<0, NB, !SPAN, HM>(m, tp, tpB, S, NT, sl, u_sl, lane, g4, nx); break;
+              case 5: HID::template pass<1, NB, !SPAN, HM>(m, tp, tpB, S, NT, sl, u_sl, lane, g4, nx); break;
+              case 10: HID::template pass<2, NB, !SPAN, HM>(m, tp, tpB, S, NT, sl, u_sl, lane, g4, nx); break;
+              case 15: HID::template pass<3, NB, !SPAN, HM>(m, tp, tpB, S, NT, sl, u_sl, lane, g4, nx); break;
+              case 1: if constexpr (SPAN) HID::template span<0, 1, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+              case 2: if constexpr (SPAN) HID::template span<0, 2, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+              case 3: if constexpr (SPAN) HID::template span<0, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+              case 6: if constexpr (SPAN) HID::template span<1, 2, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+              case 7: if constexpr (SPAN) HID::template span<1, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+              default: if constexpr (SPAN) HID::template span<2, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
             }
           }
           u_cur = S.ut;
@@ -1015,12 +1240,13 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
 // A catalogue of 1e5 galaxies spends two thirds of its evaluations here (a few galaxies of acceptance ~1e-4 x 1 000 slots x
 // ~1e4 attempts); on the fp32 kernel k_maf_inv16 those ran at 0.6 of the sampler's rate.  Table path, aligned placement with
 // one degree group per tile (the shapes of the unrolled sampler); two tiles of 16 items per wave and staged transform.
-template <int NB, int DD>
+template <int NB, int DD, int PREC = 0>
 __global__ __launch_bounds__(256, 4) void k_maf_find16s(SfDev m, SfSampleArgsHost a) {
+  using HID = SfHid16<PREC>;
   SfFix16<NB, DD>::apply(m);  // (the launcher only picks this kernel when the packer's offsets are these)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int s = lane & 15, g4 = lane >> 4;
-  float* ecb = sf_lds16 + m.t16_a_tab + m.t16B_stride;
+  float* ecb = sf_lds16 + m.t16_a_tab + HID::lds_floats(m, true);
   if (threadIdx.x < 16) {  // per-slot constants of the epilogue (see k_maf_samp16)
     const int p = threadIdx.x;
     const bool on = p < m.D;
@@ -1049,7 +1275,7 @@ __global__ __launch_bounds__(256, 4) void k_maf_find16s(SfDev m, SfSampleArgsHos
     if (j == 1) { u_oth = u; gal_oth = (long)(slot / (uint32_t)a.S); }
     else { u_cur = u; gal_cur = (long)(slot / (uint32_t)a.S); }
   }
-  SfPass16B S;
+  typename HID::State S;
   S.tab = true;
   S.xr = nullptr;
   for (int t = m.T - 1; t >= 0; --t) {
@@ -1057,24 +1283,10 @@ __global__ __launch_bounds__(256, 4) void k_maf_find16s(SfDev m, SfSampleArgsHos
     S.c0p = m.ctab + ((size_t)gal_cur * m.T + t) * m.ctab_R;
     sf_c0_prefetch(S, 0, g4);
     __syncthreads();
-    {
-      const int ga = m.t16_a_tab >> 10, gb = m.t16B_stride >> 10;
-      const float4* __restrict__ sa = reinterpret_cast<const float4*>(m.packed16 + (size_t)t * m.t16_stride);
-      const float4* __restrict__ sb = reinterpret_cast<const float4*>(m.packed16B + (size_t)t * m.t16B_stride);
-      float4* __restrict__ d4 = reinterpret_cast<float4*>(sf_lds16);
-      for (int gi = __builtin_amdgcn_readfirstlane(wave); gi < ga + gb; gi += 4) {
-        const float4* g = (gi < ga ? sa + gi * 256 : sb + (gi - ga) * 256) + (threadIdx.x & 63);
-        float4* l = d4 + gi * 256;
-        __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 1024, 0);
-        __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 2048, 0);
-        __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 3072, 0);
-      }
-      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
-    }
+    sf_stage16<PREC, true>(m, t, m.t16_a_tab, wave);
     __syncthreads();
     const float* tp = sf_lds16;
-    const unsigned int* tpB = reinterpret_cast<const unsigned int*>(sf_lds16 + m.t16_a_tab);
+    const void* tpB = sf_lds16 + m.t16_a_tab;
 #pragma unroll 1
     for (int j = 0; j < 2; ++j) {
       if (((long)blockIdx.x * 8 + j * 4 + wave) * 16 < a.n_items) {  // (wave-uniform: the tile holds an item)
@@ -1082,12 +1294,7 @@ __global__ __launch_bounds__(256, 4) void k_maf_find16s(SfDev m, SfSampleArgsHos
           S.c0p = m.ctab + ((size_t)gal_cur * m.T + t) * m.ctab_R;
           sf_c0_prefetch(S, 0, g4);
         }
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-          for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-            for (int c = 2; c < 4; ++c) { S.ph[k][pr][c] = 0u; S.pl[k][pr][c] = 0u; }
+        HID::template clear<true, true>(S);
 #pragma unroll
         for (int r = 0; r < 4; ++r) S.ut[r] = 0.f;
         S.hdone = sf_ld4(tp + m.o16_bh + g4 * 4);
@@ -1102,7 +1309,7 @@ __global__ __launch_bounds__(256, 4) void k_maf_find16s(SfDev m, SfSampleArgsHos
         auto seq_pass = [&](auto otc) {
           constexpr int OT = decltype(otc)::value;
           const int sl = __builtin_amdgcn_readlane(dsl, OT + 1);
-          sf_pass16b<OT, NB, true, true>(m, tp, tpB, S, NT, sl, sf_slot16_own(u_cur, sl), lane, g4, OT + 2 < DD ? OT + 1 : -1);
+          HID::template pass<OT, NB, true, true>(m, tp, tpB, S, NT, sl, sf_slot16_own(u_cur, sl), lane, g4, OT + 2 < DD ? OT + 1 : -1);
         };
         seq_pass(std::integral_constant<int, 0>{});
         if constexpr (DD >= 3) seq_pass(std::integral_constant<int, 1>{});
@@ -1160,17 +1367,17 @@ __global__ __launch_bounds__(256, 4) void k_maf_find16s(SfDev m, SfSampleArgsHos
   }
 }
 
-template <int NB, int DD>
+template <int NB, int DD, int PREC>
 static hipError_t sf_launch_find16s(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
   static SfAttrCache attr;
-  const size_t sh = ((size_t)m.t16_a_tab + (size_t)m.t16B_stride) * sizeof(float) + 80 * sizeof(float);
+  const size_t sh = ((size_t)m.t16_a_tab + (size_t)SfHid16<PREC>::lds_floats(m, true)) * sizeof(float) + 80 * sizeof(float);
   int attr_dev;
   if (attr.need(attr_dev)) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_maf_find16s<NB, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)k_maf_find16s<NB, DD, PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr.set(attr_dev);
   }
-  hipLaunchKernelGGL((k_maf_find16s<NB, DD>), dim3((unsigned)((a.n_items + 127) / 128)), dim3(256), sh, st, m, a);
+  hipLaunchKernelGGL((k_maf_find16s<NB, DD, PREC>), dim3((unsigned)((a.n_items + 127) / 128)), dim3(256), sh, st, m, a);
   return hipGetLastError();
 }
 
@@ -1178,9 +1385,10 @@ static hipError_t sf_launch_find16s(const SfDev& m, const SfSampleArgsHost& a, h
 // functions k_maf_samp16 runs (sf_pass16b / sf_pass16b_span: hidden H x H blocks as split-bf16 x3, everything else
 // fp32), so that the sampler's precision can be asserted against the fp64 oracle draw for draw, with no Philox and no
 // rejection in between (sf_flow_inverse_from_noise_sampler; tests/test_gpu_parity.py).  One wave = 16 rows of z.
-template <int NB, bool SPAN, bool HM>
+template <int NB, bool SPAN, bool HM, int PREC = 0>
 __global__ __launch_bounds__(256, 3) void k_maf_inv16b(SfDev m, const float* __restrict__ z, const float* __restrict__ x,
                                                        long n, float* __restrict__ out) {
+  using HID = SfHid16<PREC>;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int s = lane & 15, g4 = lane >> 4;
   const long item = ((long)blockIdx.x * 4 + wave) * 16 + s;
@@ -1196,38 +1404,14 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16b(SfDev m, const float* __r
     tile_bits |= (uint32_t)(m.g16_tile[q] & 3) << (2 * q);
     lo_bits |= (uint32_t)(m.g16_lo[q] & 3) << (2 * q);
   }
-  SfPass16B S;
-#pragma unroll
-  for (int k = 0; k < 2; ++k)
-#pragma unroll
-    for (int pr = 0; pr < 2; ++pr)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { S.ph[k][pr][c] = 0u; S.pl[k][pr][c] = 0u; }
-#pragma unroll
-  for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) S.head[ot][r] = 0.f;
+  typename HID::State S;
+  HID::template clear<false, false>(S);
   for (int t = m.T - 1; t >= 0; --t) {
     __syncthreads();
-    {
-      const int lane_ = threadIdx.x & 63;
-      const int ga = m.t16_a >> 10, gb = m.t16B_stride >> 10;
-      const float4* __restrict__ sa = reinterpret_cast<const float4*>(m.packed16 + (size_t)t * m.t16_stride);
-      const float4* __restrict__ sb = reinterpret_cast<const float4*>(m.packed16B + (size_t)t * m.t16B_stride);
-      float4* __restrict__ d4 = reinterpret_cast<float4*>(sf_lds16);
-      for (int gi = __builtin_amdgcn_readfirstlane(wave); gi < ga + gb; gi += 4) {
-        const float4* g = (gi < ga ? sa + gi * 256 : sb + (gi - ga) * 256) + lane_;
-        float4* l = d4 + gi * 256;
-        __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 1024, 0);
-        __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 2048, 0);
-        __builtin_amdgcn_global_load_lds((const void*)g, (void __attribute__((address_space(3)))*)l, 16, 3072, 0);
-      }
-      __builtin_amdgcn_s_waitcnt(0x0f70);
-    }
+    sf_stage16<PREC, !SPAN>(m, t, m.t16_a, wave);
     __syncthreads();
     const float* tp = sf_lds16;
-    const unsigned int* tpB = reinterpret_cast<const unsigned int*>(sf_lds16 + m.t16_a);
+    const void* tpB = sf_lds16 + m.t16_a;
     S.c0p = nullptr;
     S.tab = false;
     S.xr = x + it * m.C;
@@ -1250,16 +1434,16 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16b(SfDev m, const float* __r
       const uint32_t lo_t = SPAN ? (lo_bits >> (2 * (p - 1))) & 3u : hi_t;
       const int nx = p < m.D ? (int)((tile_bits >> (2 * p)) & 3u) : -1;
       switch (lo_t * 4 + hi_t) {
-        case 0: sf_pass16b<0, NB, !SPAN, HM>(m, tp, tpB, S, NT, sl, u_sl, lane, g4, nx); break;
-        case 5: sf_pass16b<1, NB, !SPAN, HM>(m, tp, tpB, S, NT, sl, u_sl, lane, g4, nx); break;
-        case 10: sf_pass16b<2, NB, !SPAN, HM>(m, tp, tpB, S, NT, sl, u_sl, lane, g4, nx); break;
-        case 15: sf_pass16b<3, NB, !SPAN, HM>(m, tp, tpB, S, NT, sl, u_sl, lane, g4, nx); break;
-        case 1: if (SPAN) sf_pass16b_span<0, 1, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
-        case 2: if (SPAN) sf_pass16b_span<0, 2, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
-        case 3: if (SPAN) sf_pass16b_span<0, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
-        case 6: if (SPAN) sf_pass16b_span<1, 2, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
-        case 7: if (SPAN) sf_pass16b_span<1, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
-        default: if (SPAN) sf_pass16b_span<2, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+        case 0: HID::template pass<0, NB, !SPAN, HM>(m, tp, tpB, S, NT, sl, u_sl, lane, g4, nx); break;
+        case 5: HID::template pass<1, NB, !SPAN, HM>(m, tp, tpB, S, NT, sl, u_sl, lane, g4, nx); break;
+        case 10: HID::template pass<2, NB, !SPAN, HM>(m, tp, tpB, S, NT, sl, u_sl, lane, g4, nx); break;
+        case 15: HID::template pass<3, NB, !SPAN, HM>(m, tp, tpB, S, NT, sl, u_sl, lane, g4, nx); break;
+        case 1: if constexpr (SPAN) HID::template span<0, 1, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+        case 2: if constexpr (SPAN) HID::template span<0, 2, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+        case 3: if constexpr (SPAN) HID::template span<0, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+        case 6: if constexpr (SPAN) HID::template span<1, 2, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+        case 7: if constexpr (SPAN) HID::template span<1, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
+        default: if constexpr (SPAN) HID::template span<2, 3, NB>(m, tp, tpB, S, NT, sl, u_sl, lane, g4); break;
       }
     }
     u = S.ut;
@@ -1273,18 +1457,23 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16b(SfDev m, const float* __r
   }
 }
 
-template <int NB, bool SPAN, bool HM>
-static hipError_t sf_launch16b_hook(const SfDev& m, const float* z, const float* x, long n, float* out, hipStream_t st) {
+template <int NB, bool SPAN, bool HM, int PREC>
+static hipError_t sf_launch16b_hook_p(const SfDev& m, const float* z, const float* x, long n, float* out, hipStream_t st) {
   static SfAttrCache attr;
-  const size_t sh = ((size_t)m.t16_a + (size_t)m.t16B_stride) * sizeof(float);
+  const size_t sh = ((size_t)m.t16_a + (size_t)SfHid16<PREC>::lds_floats(m, !SPAN)) * sizeof(float);
   int attr_dev;
   if (attr.need(attr_dev)) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_maf_inv16b<NB, SPAN, HM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)k_maf_inv16b<NB, SPAN, HM, PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr.set(attr_dev);
   }
-  hipLaunchKernelGGL((k_maf_inv16b<NB, SPAN, HM>), dim3((unsigned)((n + 63) / 64)), dim3(256), sh, st, m, z, x, n, out);
+  hipLaunchKernelGGL((k_maf_inv16b<NB, SPAN, HM, PREC>), dim3((unsigned)((n + 63) / 64)), dim3(256), sh, st, m, z, x, n, out);
   return hipGetLastError();
+}
+template <int NB, bool SPAN, bool HM>
+static hipError_t sf_launch16b_hook(const SfDev& m, const float* z, const float* x, long n, float* out, hipStream_t st) {
+  return sf_sampler_fp32_for(SF_MAF) ? sf_launch16b_hook_p<NB, SPAN, HM, 1>(m, z, x, n, out, st)
+                                     : sf_launch16b_hook_p<NB, SPAN, HM, 0>(m, z, x, n, out, st);
 }
 // head rows on the matrix pipe (aligned placement with the head tile in the image: D <= 8); SF_HEAD_MFMA=0 keeps the
 // per-lane dot products (A-B runs)
@@ -1293,9 +1482,11 @@ static bool sf_maf16_head_mfma(const SfDev& m) {
   if (env < 0) { const char* e = std::getenv("SF_HEAD_MFMA"); env = e ? std::atoi(e) : 1; }
   return env != 0 && !m.m16_span && m.o16_wh >= 0;
 }
-// false when the flow has no split-bf16 sampler (then the sampler IS the fp32 path and sf_flow_inverse_from_noise covers it)
+// false when the flow has no 16-row persistent sampler (then the sampler IS the 32-row fp32 path and sf_flow_inverse_from_noise
+// covers it)
 bool sf_maf16b_available(const SfDev& m) {
-  return m.kind == SF_MAF && m.m16_ok && !m.hidden_bf16 && m.packed16 != nullptr && m.packed16B != nullptr;
+  return m.kind == SF_MAF && m.m16_ok && !m.hidden_bf16 && m.packed16 != nullptr &&
+         (m.packed16B != nullptr || sf_sampler_fp32_for(SF_MAF));
 }
 hipError_t sf_launch_maf_inv16b_hook(const SfDev& m, const float* z, const float* x, long n, float* out, hipStream_t st) {
   if (m.m16_span) return m.NB == 1 ? sf_launch16b_hook<1, true, false>(m, z, x, n, out, st) : sf_launch16b_hook<2, true, false>(m, z, x, n, out, st);
@@ -1347,14 +1538,21 @@ hipError_t sf_launch_maf_ctab16(const SfDev& m, const float* x, long M, float* t
 }
 
 // SF_MAF16=0 disables the path (diagnostics / A-B runs).  A = 32 retry rounds stay on the 32-row kernel.
-// SF_SAMPLER_FP32=1 (or sf_set_sampler_fp32(1)): the PERSISTENT sampler takes the all-fp32 32-row kernel
-// (k_sample_persist<MafOps>) instead of k_maf_samp16's split-bf16 hidden blocks -- the pure-fp32 number quoted beside
-// the default one in bench.py.
-static int g_sampler_fp32 = -1;
-void sf_sampler_fp32_set(int on) { g_sampler_fp32 = on ? 1 : 0; }
+// Arithmetic of the samplers' hidden blocks (process-wide; sf_set_sampler_fp32 / environment SF_SAMPLER_FP32):
+//   1  fp32 everywhere: MAF k_maf_samp16<.., PREC = 1> (v_mfma_f32_16x16x4_f32), NSF the fp32 image
+//   0  split bf16 x3 where the flow has such an image (the opt-in fast mode of round 2-4)
+//  -1  (unset) per flow kind: MAF fp32 -- BASELINE configs[1] says fp32, and the split products move log p(draw) by up to
+//      1.3e-3 against the north-star tolerance of 1e-4 -- NSF split (its draws meet the fp64 oracle as closely as the
+//      all-fp32 kernels do: tests/test_gpu_parity.py::test_sampler_arithmetic_from_given_noise)
+static int g_sampler_fp32 = -2;
+void sf_sampler_fp32_set(int on) { g_sampler_fp32 = on < 0 ? -1 : (on ? 1 : 0); }
 int sf_sampler_fp32_get() {
-  if (g_sampler_fp32 < 0) { const char* e = std::getenv("SF_SAMPLER_FP32"); g_sampler_fp32 = (e && std::atoi(e) != 0) ? 1 : 0; }
+  if (g_sampler_fp32 == -2) { const char* e = std::getenv("SF_SAMPLER_FP32"); g_sampler_fp32 = (e && *e) ? (std::atoi(e) != 0 ? 1 : 0) : -1; }
   return g_sampler_fp32;
+}
+int sf_sampler_fp32_for(int kind) {
+  const int g = sf_sampler_fp32_get();
+  return g < 0 ? (kind == SF_MAF ? 1 : 0) : g;
 }
 bool sf_maf16_enabled(const SfDev& m, const SfSampleArgsHost& a) {
   static int env = -1;
@@ -1362,7 +1560,6 @@ bool sf_maf16_enabled(const SfDev& m, const SfSampleArgsHost& a) {
     const char* e = std::getenv("SF_MAF16");
     env = e ? std::atoi(e) : 1;
   }
-  if (a.q && sf_sampler_fp32_get()) return false;
   return env != 0 && m.kind == SF_MAF && m.m16_ok && !m.hidden_bf16 && m.packed16 != nullptr &&
          (a.attempts_per_slot <= 16 || a.best != nullptr);  // (find mode has no in-tile attempt groups)
 }
@@ -1381,22 +1578,23 @@ static int sf_resident_blocks16(const void* fn, size_t sh, int cap) {
 }
 
 // persistent sampler: no more workgroups than the chip holds (more would only queue behind the spinning ones)
-template <int NB, bool SPAN, bool HM, int TPW, int DD = 0>
-static hipError_t sf_launch16q(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
+template <int NB, bool SPAN, bool HM, int TPW, int DD, int PREC>
+static hipError_t sf_launch16q_p(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
   static SfAttrCache attr;
   static SfResidentCache rcache;
-  const size_t sh = ((size_t)(m.ctab ? m.t16_a_tab : m.t16_a) + (size_t)m.t16B_stride) * sizeof(float) +
+  const size_t sh = ((size_t)(m.ctab ? m.t16_a_tab : m.t16_a) + (size_t)SfHid16<PREC>::lds_floats(m, !SPAN)) * sizeof(float) +
                     (SF_Q_WORDS(64 * TPW) + 80) * sizeof(unsigned int);
+  if (sh > 160 * 1024) return hipErrorInvalidValue;
   int attr_dev;
   if (attr.need(attr_dev)) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_maf_samp16<NB, SPAN, HM, TPW, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)k_maf_samp16<NB, SPAN, HM, TPW, DD, PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr.set(attr_dev);
   }
   int resident = 0, cur_dev = 0;
   (void)hipGetDevice(&cur_dev);
   if (!rcache.get(cur_dev, sh, resident)) {
-    resident = sf_resident_blocks16((const void*)k_maf_samp16<NB, SPAN, HM, TPW, DD>, sh, SPAN ? 3 : 4);
+    resident = sf_resident_blocks16((const void*)k_maf_samp16<NB, SPAN, HM, TPW, DD, PREC>, sh, SPAN ? 3 : 4);
     rcache.put(cur_dev, sh, resident);
   }
   long grid = (a.n_items + 64 * TPW - 1) / (64 * TPW);
@@ -1404,8 +1602,14 @@ static hipError_t sf_launch16q(const SfDev& m, const SfSampleArgsHost& a, hipStr
   SfSamp16Args args;
   args.m = m;
   args.a = a;
-  hipLaunchKernelGGL((k_maf_samp16<NB, SPAN, HM, TPW, DD>), dim3((unsigned)grid), dim3(256), sh, st, args);
+  hipLaunchKernelGGL((k_maf_samp16<NB, SPAN, HM, TPW, DD, PREC>), dim3((unsigned)grid), dim3(256), sh, st, args);
   return hipGetLastError();
+}
+template <int NB, bool SPAN, bool HM, int TPW, int DD = 0>
+static hipError_t sf_launch16q(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
+  if (sf_sampler_fp32_for(SF_MAF)) return sf_launch16q_p<NB, SPAN, HM, TPW, DD, 1>(m, a, st);
+  if (!m.packed16B) return hipErrorInvalidValue;
+  return sf_launch16q_p<NB, SPAN, HM, TPW, DD, 0>(m, a, st);
 }
 template <int NB, bool SPAN>
 static hipError_t sf_launch16(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
@@ -1460,19 +1664,16 @@ hipError_t sf_launch_maf_inv16(const SfDev& m, const SfSampleArgsHost& a, hipStr
   }
   // find / resolve launches of the deep tail: the unrolled split-bf16 kernel where the sampler itself runs one
   // (SF_FIND16S=0: the fp32 kernel, A-B runs)
-  if ((a.best || a.att_list || a.count) && !a.z_in && m.ctab && m.packed16B && !sf_sampler_fp32_get() && sf_maf16_head_mfma(m)) {
+  const bool f32 = sf_sampler_fp32_for(SF_MAF) != 0;
+  if ((a.best || a.att_list || a.count) && !a.z_in && m.ctab && (f32 || m.packed16B) && sf_maf16_head_mfma(m)) {
     static int env = -1;
     if (env < 0) { const char* e = std::getenv("SF_FIND16S"); env = e ? std::atoi(e) : 1; }
     const int dd = env ? sf_maf16_seq_d(m) : 0;
-    if (m.NB == 1) {
-      if (dd == 3) return sf_launch_find16s<1, 3>(m, a, st);
-      if (dd == 4) return sf_launch_find16s<1, 4>(m, a, st);
-      if (dd == 5) return sf_launch_find16s<1, 5>(m, a, st);
-    } else {
-      if (dd == 3) return sf_launch_find16s<2, 3>(m, a, st);
-      if (dd == 4) return sf_launch_find16s<2, 4>(m, a, st);
-      if (dd == 5) return sf_launch_find16s<2, 5>(m, a, st);
-    }
+#define SF_FIND_CASE(NBV, DDV) \
+    if (m.NB == NBV && dd == DDV) return f32 ? sf_launch_find16s<NBV, DDV, 1>(m, a, st) : sf_launch_find16s<NBV, DDV, 0>(m, a, st);
+    SF_FIND_CASE(1, 3) SF_FIND_CASE(1, 4) SF_FIND_CASE(1, 5)
+    SF_FIND_CASE(2, 3) SF_FIND_CASE(2, 4) SF_FIND_CASE(2, 5)
+#undef SF_FIND_CASE
   }
   if (m.m16_span) return m.NB == 1 ? sf_launch16<1, true>(m, a, st) : sf_launch16<2, true>(m, a, st);
   return m.NB == 1 ? sf_launch16<1, false>(m, a, st) : sf_launch16<2, false>(m, a, st);

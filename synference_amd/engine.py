@@ -191,6 +191,7 @@ class HipFlow:
         rc = self.lib.sf_flow_inverse_from_noise_sampler(self.handle, _ptr(z), _ptr(x), B, _ptr(th), _stream(self.device))
         if rc < 0:
             _lib.check(rc)
+        self.last_sampler_rc = int(rc)   # 0 split-bf16 x3 pass functions, 2 the 16-row sampler's fp32 ones, 1 the generic fp32 path
         return th, rc == 0
 
     def set_sample_row_offset(self, row_offset: int) -> None:

@@ -884,7 +884,8 @@ class SBI_Fitter:
         if (~obs_mask).any():
             samples[~obs_mask] = self.sample_posterior(feats[~obs_mask], sample_method=sample_method,
                                                        num_samples=num_samples, log_times=log_times, seed=seed,
-                                                       timeout_seconds_per_test=timeout_seconds_per_row)
+                                                       timeout_seconds_per_test=timeout_seconds_per_row,
+                                                       gather="all")   # every rank fills the whole table
         samples_quant = samples.transpose(2, 0, 1)
         table = df.copy() if append_to_input else pd.DataFrame({"ID": np.arange(len(df)) + 1})
         for i, param in enumerate(self.simple_fitted_parameter_names):

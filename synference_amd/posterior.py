@@ -402,6 +402,29 @@ def all_gather_rows(local: torch.Tensor, bounds):
     return out.to(local.device)
 
 
+_GATHER_OK = {}
+
+
+def _backend_has_gather(device) -> bool:
+    """Whether the process group's backend implements ``gather``: probed ONCE per backend with a one-element collective that
+    every rank enters together, and the outcome agreed on by an all-reduce(MIN) -- so that no rank can take the all-gather
+    fallback while another sits in a gather (an error inside a LATER collective is an error, never a reason to switch)."""
+    import torch.distributed as dist
+    key = dist.get_backend()
+    if key not in _GATHER_OK:
+        rank, world = dist_world()
+        ok = 1
+        try:
+            t = torch.zeros(1, device=device)
+            dist.gather(t, [torch.empty_like(t) for _ in range(world)] if rank == 0 else None, dst=0)
+        except (RuntimeError, NotImplementedError):
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        _GATHER_OK[key] = bool(int(flag.item()))
+    return _GATHER_OK[key]
+
+
 def gather_rows(local: torch.Tensor, bounds, dst: int = 0):
     """Rank ``dst`` receives the whole array (rows [bounds[r], bounds[r+1]) from rank r) and returns it; every other rank
     returns None.  For the big outputs -- (N, S, D) draws: 3.2 GB for BASELINE configs[4] -- of which one copy on one rank is
@@ -420,14 +443,10 @@ def gather_rows(local: torch.Tensor, bounds, dst: int = 0):
     else:
         pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=src.device)
         pad[: sizes[rank]] = src
-    parts = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    try:
+    if _backend_has_gather(pad.device):
+        parts = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
         dist.gather(pad, parts, dst=dst)
-    except (RuntimeError, NotImplementedError) as e:
-        # (a backend build without the gather collective: every rank raises at the same point, before any communication; the
-        #  all-gather every backend has does the job at world x the traffic)
-        if "gather" not in str(e).lower() and "support" not in str(e).lower():
-            raise
+    else:   # (the all-gather every backend has does the job at world x the traffic)
         parts = [torch.empty_like(pad) for _ in range(world)]
         dist.all_gather(parts, pad)
     if rank != dst:

@@ -49,7 +49,13 @@ def run(f, x, theta):
     lp = f.log_prob(X, Y, num_rejection_samples=512)
     import pandas as pd
     tab = f.fit_catalogue(pd.DataFrame(X, columns=list(f.feature_names)), num_samples=128, seed=9, append_to_input=False)
+    # the host-quantile branches of fit_catalogue (return_samples / device_quantiles=False): every rank fills the whole table
+    tab2, samp2 = f.fit_catalogue(pd.DataFrame(X, columns=list(f.feature_names)), num_samples=32, seed=9, append_to_input=False,
+                                  return_samples=True)
+    tab3 = f.fit_catalogue(pd.DataFrame(X[:3], columns=list(f.feature_names)), num_samples=32, seed=9, append_to_input=False,
+                           device_quantiles=False)     # 3 rows over 2 ranks: one rank's block is a single row
     return {"samples": s, "samples_all": s_all, "lp": lp, "table": tab.to_numpy(float),
+            "table_rs": tab2.to_numpy(float), "samples_rs": samp2, "table_hq": tab3.to_numpy(float),
             "rows": getattr(f, "last_shard_rows", (0, len(X)))}
 
 

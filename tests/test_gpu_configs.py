@@ -208,8 +208,9 @@ def test_rank_sharded_catalogue_evaluation_equals_the_single_process_call(tmp_pa
         a1, b1 = r1[kind]["rows"]
         assert (a1, b1) == (50, 101) and np.array_equal(r1[kind]["samples"], ref["samples"][a1:b1], equal_nan=True)
         # ... and the small outputs, and gather="all", are the whole thing on every rank
-        for k in ("lp", "table"):
+        for k in ("lp", "table", "table_rs", "samples_rs", "table_hq"):
             assert np.array_equal(r1[kind][k], ref[k], equal_nan=True), (kind, k, "rank 1 vs single process")
+            assert np.array_equal(r0[kind][k], ref[k], equal_nan=True), (kind, k, "rank 0 vs single process")
         for r in (r0, r1):
             assert np.array_equal(r[kind]["samples_all"], ref["samples"], equal_nan=True)
     # and the draws of a block do not depend on how the catalogue is cut: rows 40..60 alone, keyed by their position
