@@ -295,12 +295,41 @@ int sf_adam_apply(float* params, const float* grad, float* exp_avg, float* exp_a
  * (ref: the batch loop of custom_runner.py:585-618): for b < n_batches:
  *   rows = order[b*batch .. (b+1)*batch);  grad = d/dflat sum_rows grad_scale * (-log p);  clip + Adam(W) step
  *   number step0 + b + 1 on flat (state exp_avg / exp_avg_sq, scratch [2] as in sf_adam_apply).
- * order: DEVICE int64 [n_batches*batch] (the epoch's shuffled training rows); grad: DEVICE scratch [P].
- * Data-parallel training keeps using sf_flow_loss_grad_rows + all-reduce + sf_adam_apply per step. */
+ * order: DEVICE int64 [n_batches*batch] (the epoch's shuffled training rows); grad: DEVICE scratch [P]. */
 int sf_flow_train_epoch(sf_flow* f, float* flat, const float* theta, const float* x, const int64_t* order,
                         int64_t n_batches, int64_t batch, float grad_scale, float* exp_avg, float* exp_avg_sq,
                         const sf_adam_desc* d, int64_t step0, float max_norm, float* scratch /*[2]*/,
                         float* grad /*[P]*/, double* loss_sum, void* stream);
+
+/* ---- data-parallel training: the gradient exchange --------------------------------
+ * One process per GPU; every rank holds the same parameters and optimiser state and its own shard of the training rows.
+ * Per optimiser step ONE sum all-reduce of the flat fp32 gradient (P floats: 129 KB for the cfg1 MAF) over RCCL -- xGMI
+ * inside a node -- on the caller's stream, between the gradient gather and clip + Adam, so that the clip norm and the
+ * update are those of the GLOBAL batch on every rank (grad_scale = 1 / (batch x ranks)).
+ * Replaces nothing in the reference, which trains on CPU threads only (examples/sbi/slurm/train_final_model.slurm:26): the
+ * call sits between `loss.backward()` and `optimizer.step()` of custom_runner.py:585-618.
+ * RCCL is bound at run time (dlopen): sf_comm_set_library(path) before the first sf_comm_* call (or the environment variable
+ * SF_RCCL_LIB) names the library -- a host that runs PyTorch passes torch's own librccl.so so that the process holds ONE
+ * RCCL --, otherwise an already loaded librccl is used, then the loader's search path, then /opt/rocm/lib.
+ * Bootstrap as in NCCL: rank 0 calls sf_comm_unique_id, the host ships the SF_COMM_ID_BYTES to every rank by its own means
+ * (the torch.distributed store, MPI, a file), every rank calls sf_comm_create (collective) with its HIP device current. */
+#define SF_COMM_ID_BYTES 128
+typedef struct sf_comm sf_comm;
+int sf_comm_set_library(const char* path);
+int sf_comm_library(char* path_out, int64_t cap, int* version_out);    /* what was bound (loads it if necessary) */
+int sf_comm_unique_id(void* id_out, int64_t bytes);
+int sf_comm_create(const void* id, int64_t bytes, int nranks, int rank, sf_comm** out);
+void sf_comm_destroy(sf_comm* c);
+int sf_comm_info(const sf_comm* c, int* nranks, int* rank);
+int sf_comm_all_reduce_sum(sf_comm* c, float* buf /*[n], in place*/, int64_t n, void* stream);
+/* sf_flow_train_epoch with the exchange inside: per step  rows -> grad (this rank's shard, grad_scale = 1 / (batch x ranks))
+ * -> all-reduce(SUM) over `comm` -> clip + Adam(W), all on `stream`, no host round trip per step.  `order` holds THIS rank's
+ * rows; every rank must call it with the same n_batches.  loss_sum stays rank-local (the host reduces it once per epoch with
+ * the validation sums, custom_runner.py:655-660).  comm == NULL is sf_flow_train_epoch. */
+int sf_flow_train_epoch_dp(sf_flow* f, float* flat, const float* theta, const float* x, const int64_t* order,
+                           int64_t n_batches, int64_t batch, float grad_scale, float* exp_avg, float* exp_avg_sq,
+                           const sf_adam_desc* d, int64_t step0, float max_norm, float* scratch /*[2]*/,
+                           float* grad /*[P]*/, double* loss_sum, sf_comm* comm, void* stream);
 /* optimizer state access for checkpoints (custom_runner.py:693-704): exp_avg, exp_avg_sq
  * device pointers [n] and the step counter. */
 int sf_opt_state(sf_opt* o, float** exp_avg, float** exp_avg_sq, int64_t** step_host);

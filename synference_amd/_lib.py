@@ -93,6 +93,16 @@ PROTOTYPES = {
     "sf_flow_train_epoch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                       C.c_float, C.c_void_p, C.c_void_p, C.POINTER(sf_adam_desc), C.c_int64, C.c_float,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sf_flow_train_epoch_dp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                         C.c_float, C.c_void_p, C.c_void_p, C.POINTER(sf_adam_desc), C.c_int64, C.c_float,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sf_comm_set_library": (C.c_int, [C.c_char_p]),
+    "sf_comm_library": (C.c_int, [C.c_char_p, C.c_int64, C.POINTER(C.c_int)]),
+    "sf_comm_unique_id": (C.c_int, [C.c_void_p, C.c_int64]),
+    "sf_comm_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "sf_comm_destroy": (None, [C.c_void_p]),
+    "sf_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sf_comm_all_reduce_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "sf_flow_loss_grad_weighted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                              C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p]),

@@ -979,12 +979,21 @@ int sf_flow_train_epoch(sf_flow* f, float* flat, const float* theta, const float
                         int64_t n_batches, int64_t batch, float grad_scale, float* exp_avg, float* exp_avg_sq,
                         const sf_adam_desc* d, int64_t step0, float max_norm, float* scratch, float* grad,
                         double* loss_sum, void* stream) {
+  return sf_flow_train_epoch_dp(f, flat, theta, x, order, n_batches, batch, grad_scale, exp_avg, exp_avg_sq, d, step0, max_norm,
+                                scratch, grad, loss_sum, nullptr, stream);
+}
+
+int sf_flow_train_epoch_dp(sf_flow* f, float* flat, const float* theta, const float* x, const int64_t* order,
+                           int64_t n_batches, int64_t batch, float grad_scale, float* exp_avg, float* exp_avg_sq,
+                           const sf_adam_desc* d, int64_t step0, float max_norm, float* scratch, float* grad,
+                           double* loss_sum, sf_comm* comm, void* stream) {
   if (!f || !flat || !theta || !x || !order || !exp_avg || !exp_avg_sq || !d || !scratch || !grad)
     return fail(SF_ERR_INVALID, "null argument");
   if (n_batches < 0 || batch < 1 || step0 < 0) return fail(SF_ERR_INVALID, "bad n_batches, batch or step0");
   // (the gather of the step leaves |grad|^2 in per-block shares for the clip: the optimiser kernel then skips its pass over the
   //  whole gradient -- one L2 round trip less in a step that is a chain of them)
-  struct WantSq { sf_flow* f; explicit WantSq(sf_flow* f_) : f(f_) { f->want_sq = true; } ~WantSq() { f->want_sq = false; f->n_sqpart = 0; } } want_sq(f);
+  //  (data parallel: the norm that clips is the REDUCED gradient's, so the optimiser kernel takes its own pass over it)
+  struct WantSq { sf_flow* f; WantSq(sf_flow* f_, bool on) : f(f_) { f->want_sq = on; } ~WantSq() { f->want_sq = false; f->n_sqpart = 0; } } want_sq(f, comm == nullptr);
   // ... and the kernels add their loss sums to one of SF_LOSS_PARTS scalars instead of all to the caller's (folded in below)
   if (loss_sum && !f->d_losspart_mem) {
     if (hipMalloc(&f->d_losspart_mem, SF_LOSS_PARTS * sizeof(double)) == hipSuccess)
@@ -1009,6 +1018,11 @@ int sf_flow_train_epoch(sf_flow* f, float* flat, const float* theta, const float
       if (f->packed_stale) f->params_set = false;
       return rc;
     }
+    if (comm) {   // the exchange step: sum of the ranks' shard gradients, in place, on the same stream
+      rc = sf_comm_all_reduce_impl(comm, grad, (long)f->L.n_params, (hipStream_t)stream);
+      if (rc) { f->prep_lite = false; if (f->packed_stale) f->params_set = false; return rc; }
+      f->n_sqpart = 0;
+    }
     const int64_t step = step0 + b + 1;
     const double bc1 = 1.0 - std::pow((double)d->beta1, (double)step), bc2 = 1.0 - std::pow((double)d->beta2, (double)step);
     hipError_t e = sf_launch_adam(flat, grad, exp_avg, exp_avg_sq, scratch, (long)f->L.n_params, *d, (float)bc1, (float)bc2, max_norm,
@@ -1029,7 +1043,7 @@ int sf_flow_train_epoch(sf_flow* f, float* flat, const float* theta, const float
   static int use_graph = -1;
   if (use_graph < 0) { const char* e = std::getenv("SF_TRAIN_GRAPH"); use_graph = e ? std::atoi(e) : 0; }
   int64_t b0 = 0;
-  if (use_graph && n_batches >= 4 && !f->nsf1 && !f->nsfar && !f->profiling) {
+  if (use_graph && !comm && n_batches >= 4 && !f->nsf1 && !f->nsfar && !f->profiling) {
     int rc = plain_step(0);
     if (rc) return rc;
     b0 = 1;

@@ -123,7 +123,9 @@ struct SfResidentCache {
   }
   void put(int d, size_t s, int v) { dev[n & 7] = d; sh[n & 7] = s; val[n & 7] = v; ++n; }
 };
-void sf_set_error(const std::string& msg);  // thread-local message behind sf_last_error()
+void sf_set_error(const std::string& msg);
+struct sf_comm;
+int sf_comm_all_reduce_impl(sf_comm* c, float* buf, long n, hipStream_t st);  // sf_comm.hip: ncclAllReduce(SUM, fp32) in place  // thread-local message behind sf_last_error()
 
 // ---- the handle (shared by sf_api.hip and sf_train.hip) -------------------------------------
 #define SF_LOSS_PARTS 64

@@ -293,19 +293,21 @@ class HipFlow:
     def train_epoch(self, flat: torch.Tensor, theta: torch.Tensor, x: torch.Tensor, order: torch.Tensor,
                     n_batches: int, batch: int, grad_scale: float, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
                     adam_desc, step0: int, max_norm: float, scratch: torch.Tensor, grad: torch.Tensor,
-                    loss_sum: torch.Tensor) -> None:
+                    loss_sum: torch.Tensor, comm=None) -> None:
         """One epoch of (fused-gather loss_grad + clip + Adam) steps driven from C (sf_flow_train_epoch):
-        ``order`` int64 [n_batches*batch] device rows into ``theta`` / ``x``; ``loss_sum`` float64 device scalar."""
+        ``order`` int64 [n_batches*batch] device rows into ``theta`` / ``x``; ``loss_sum`` float64 device scalar.
+        ``comm`` (a ``synference_amd.comm.RcclComm``): data parallel -- every step's gradient is summed over the ranks by one
+        RCCL all-reduce inside the call (sf_flow_train_epoch_dp); ``order`` then holds this rank's rows."""
         self._dev()
         for t in (flat, theta, x, exp_avg, exp_avg_sq, grad):
             if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
                 raise ValueError("train_epoch needs contiguous float32 tensors on the flow's device")
         if order.dtype != torch.int64 or order.numel() < n_batches * batch or loss_sum.dtype != torch.float64:
             raise ValueError("order must be int64 with n_batches*batch entries, loss_sum float64")
-        _lib.check(self.lib.sf_flow_train_epoch(
+        _lib.check(self.lib.sf_flow_train_epoch_dp(
             self.handle, _ptr(flat), _ptr(theta), _ptr(x), _ptr(order), n_batches, batch, C.c_float(grad_scale),
             _ptr(exp_avg), _ptr(exp_avg_sq), C.byref(adam_desc), step0, C.c_float(max_norm), _ptr(scratch), _ptr(grad),
-            _ptr(loss_sum), _stream(self.device)))
+            _ptr(loss_sum), C.c_void_p(comm.handle if comm is not None else None), _stream(self.device)))
 
     def loss_grad_rows(self, flat: torch.Tensor, theta: torch.Tensor, x: torch.Tensor, rows: torch.Tensor,
                        grad_scale: float, grad_out: torch.Tensor, loss_sum: Optional[torch.Tensor] = None,

@@ -16,6 +16,7 @@ from __future__ import annotations
 import logging
 import os
 import time
+import warnings
 from typing import Callable, List, Optional, Union
 
 import numpy as np
@@ -27,9 +28,47 @@ from .runner import HIPRunner, NumpyLoader
 
 logger = logging.getLogger("synference_amd")
 
+# the reference's default model directory is f"{code_path}/models/" with code_path = the directory above the package
+# (sbi_runner.py:87-89, 4413)
+DEFAULT_MODEL_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "models") + "/"
+
+
+def _warn_unknown(fn: str, unknown: dict) -> None:
+    """Keywords outside the mirrored signature are named in a warning instead of vanishing."""
+    if unknown:
+        warnings.warn(f"{fn}: unknown keyword argument(s) {sorted(unknown)} ignored", stacklevel=3)
+
+
+class StandardScaler:
+    """The two-method subset of sklearn.preprocessing.StandardScaler that ``prior_method="manual"`` uses (``feature_scalar`` /
+    ``target_scalar`` defaults of run_single_sbi, sbi_runner.py:4416-4417, 4664-4671), with sklearn's attribute names
+    (``mean_``, ``scale_``: population std, zeros replaced by 1) so that the product does not import scikit-learn; any class with
+    fit / transform / inverse_transform can be passed instead."""
+
+    def fit(self, X, y=None):
+        X = np.asarray(X, dtype=np.float64)
+        self.mean_ = X.mean(axis=0)
+        self.scale_ = X.std(axis=0)
+        self.scale_[self.scale_ == 0.0] = 1.0
+        return self
+
+    def transform(self, X):
+        return (np.asarray(X, dtype=np.float64) - self.mean_) / self.scale_
+
+    def fit_transform(self, X, y=None):
+        return self.fit(X).transform(X)
+
+    def inverse_transform(self, X):
+        return np.asarray(X, dtype=np.float64) * self.scale_ + self.mean_
+
 
 class SBI_Fitter:
     device = "cuda"
+
+    @property
+    def _timestamp(self):
+        """Current date and time as a string (ref: sbi_runner.py:7640-7643)."""
+        return time.strftime("%Y%m%d_%H%M%S")
 
     def __init__(self, name: str, parameter_names: list, raw_observation_names: list = None,
                  raw_observation_grid: np.ndarray = None, parameter_array: np.ndarray = None,
@@ -72,6 +111,8 @@ class SBI_Fitter:
             if self.fitted_parameter_array.shape[1] != len(self.parameter_names):
                 raise ValueError("parameter_array must be (N, len(parameter_names))")
         self.has_simulator = False
+        self._feature_scalar = None      # prior_method="manual" (sbi_runner.py:287-288)
+        self._target_scalar = None
         self.posteriors = None
         self.stats = None
         self._prior = None
@@ -125,7 +166,7 @@ class SBI_Fitter:
                                                  parameters_to_add: Optional[list] = None, drop_dropouts: bool = False,
                                                  drop_dropout_fraction: float = 1.0, max_rows: int = -1,
                                                  parameter_transformations: Optional[dict] = None,
-                                                 asinh_softening_parameters=None, seed: int = 0, **unused):
+                                                 asinh_softening_parameters=None, seed: int = 0, **unknown):
         """The AB-magnitude branch of the reference's feature engineering (ref: sbi_runner.py:1429-2222) with the
         arithmetic on the device: the library's (C, N) fluxes in nJy become the (N', F) float32 feature array.
 
@@ -148,6 +189,7 @@ class SBI_Fitter:
         Outside the accelerated path (``ValueError``): other flux units, extra feature expressions, empirical noise
         models, simulated missing fluxes, normalisation by a supplementary parameter or of asinh magnitudes.  ``seed``
         replaces numpy's global generator for the scatter noise and the ``max_rows`` draw."""
+        _warn_unknown("create_feature_array_from_raw_photometry", unknown)
         if self.raw_observation_grid is None:
             raise ValueError("no raw observation grid: build the fitter with init_from_hdf5 or pass feature_array")
         if extra_features or normed_flux_units not in ("AB", "asinh") or empirical_noise_models is not None or simulate_missing_fluxes:
@@ -352,26 +394,52 @@ class SBI_Fitter:
 
     # ---------------------------------------------------------------------------------------
     def run_single_sbi(self, train_test_fraction: float = 0.8, random_seed: Optional[int] = None,
-                       backend: str = "hip", engine: Union[str, List[str]] = "NPE",
+                       backend: str = "sbi", engine: Union[str, List[str]] = "NPE",
                        train_indices: Optional[np.ndarray] = None, test_indices: Optional[np.ndarray] = None,
-                       n_nets: int = 1, model_type: Union[str, List[str]] = "maf",
+                       n_nets: int = 1, model_type: Union[str, List[str]] = "mdn",
                        hidden_features: Union[int, List[int]] = 50, num_components: Union[int, List[int]] = 4,
                        num_transforms: Union[int, List[int]] = 4, training_batch_size: int = 64,
                        learning_rate: float = 1e-4, validation_fraction: float = 0.2, stop_after_epochs: int = 15,
                        clip_max_norm: float = 5.0, additional_model_args: dict = {}, save_model: bool = True,
-                       verbose: bool = True, prior_method: str = "ili", out_dir: str = None, plot: bool = False,
-                       name_append: str = "timestamp", set_self: bool = True, learning_type: str = "offline",
-                       override_prior_ranges: dict = {}, evaluate_model: bool = False,
-                       num_posterior_draws_per_sample: int = 1000, embedding_net=None,
-                       max_num_epochs: Optional[int] = None, custom_config_yaml: Optional[str] = None,
-                       optimizer_choice: str = "Adam", **unused) -> tuple:
+                       verbose: bool = True, prior_method: str = "ili", out_dir: str = DEFAULT_MODEL_DIR, plot: bool = True,
+                       name_append: str = "timestamp", feature_scalar: Callable = StandardScaler,
+                       target_scalar: Callable = StandardScaler, set_self: bool = True, learning_type: str = "offline",
+                       simulator: Optional[Callable] = None, num_simulations: int = 1000, num_online_rounds: int = 5,
+                       initial_training_from_library: bool = False, override_prior_ranges: dict = {},
+                       online_training_xobs: Optional[np.ndarray] = None, load_existing_model: bool = True,
+                       use_existing_indices: bool = True, evaluate_model: bool = True, save_method: str = "joblib",
+                       num_posterior_draws_per_sample: int = 1000, embedding_net: Optional[torch.nn.Module] = None,
+                       custom_config_yaml: Optional[str] = None, sql_db_path: Optional[str] = None, *,
+                       max_num_epochs: Optional[int] = None, optimizer_choice: str = "Adam", **unknown) -> tuple:
         """Train an ensemble of n_nets flows; returns (posteriors, stats) like the reference.
 
         ``custom_config_yaml`` (ref: sbi_runner.py:4570-4597, custom_runner.py:226-244, 298-365): a YAML file whose
         ``train_args`` has ``skip_optimization: True`` and ``fixed_params`` (``model_choice``, ``optimizer_choice``,
         ``learning_rate``, ``training_batch_size``, ``stop_after_epochs``, ``clip_max_norm`` and the model's own
         ``<model>_hidden_features`` / ``<model>_num_transforms`` / ``<model>_num_bins`` ...) trains ONE model with those
-        values, ``validation_fraction`` from ``train_args`` (default 0.1); the Optuna search branch is out of scope."""
+        values, ``validation_fraction`` from ``train_args`` (default 0.1); the Optuna search branch is out of scope.
+
+        Positional order, names and defaults are the reference's (sbi_runner.py:4392-4435); ``max_num_epochs`` and
+        ``optimizer_choice`` are keyword-only additions.  What the defaults mean here: ``backend="sbi"`` (alias ``"hip"``) = the
+        nflows-style MAF / NSF that ili's sbi backend builds, on the HIP engine; ``"lampe"`` = its zuko-style NSF;
+        ``model_type="mdn"`` -- the reference's default -- is NOT on the HIP path and raises, so a caller names "maf" or "nsf";
+        ``plot=True`` is accepted and skipped with one log line (plotting is out of scope); ``evaluate_model=True`` runs
+        ``evaluate_model`` on the test split.  ``out_dir`` gets the fitter's name appended (4541), an existing
+        ``{out_dir}/{name}_{name_append}_params.pkl`` is loaded instead of training when ``load_existing_model`` (4546-4563:
+        returns None when it is False), ``use_existing_indices`` re-uses a stored split that covers the feature array
+        (4617-4636).  ``prior_method="manual"`` (4664-4690): ``feature_scalar()`` / ``target_scalar()`` are fit on the training
+        rows, the flow is trained on the SCALED arrays and the box prior is min / max -+ 3 sigma of the scaled parameters --
+        like the reference, nothing un-scales the draws afterwards: ``self._feature_scalar`` / ``self._target_scalar`` are the
+        caller's tools for that.  Online learning (``simulator`` ...), ``sql_db_path`` and unknown keywords are refused or
+        warned about, never silently dropped."""
+        _warn_unknown("run_single_sbi", unknown)
+        if simulator is not None or learning_type == "online" or initial_training_from_library or online_training_xobs is not None:
+            raise ValueError("only learning_type='offline' (amortised NPE on a fixed library) is on the HIP path; simulator / "
+                             "online rounds are not built")
+        if sql_db_path is not None:
+            raise ValueError("sql_db_path (the Optuna study database) belongs to the hyper-parameter search, which is outside the HIP path")
+        if plot:
+            logger.info("run_single_sbi(plot=True): plotting is outside the HIP path and is skipped")
         if custom_config_yaml is not None:
             import yaml
             with open(custom_config_yaml) as fh:
@@ -398,15 +466,30 @@ class SBI_Fitter:
         if backend == "lampe":   # the reference's second backend name (sbi_runner.py:5123-5125): its NSF, on the HIP engine
             additional_model_args = dict(additional_model_args or {}, backend="lampe")
             backend = "hip"
+        if backend == "sbi":     # ili's sbi backend = nflows-style flows: what the HIP engine implements
+            backend = "hip"
         if backend != "hip":
-            raise ValueError(f"backend '{backend}' is not available in synference_amd: use backend='hip' (or 'lampe' for "
-                             "the autoregressive NSF of the reference's lampe backend)")
+            raise ValueError(f"backend '{backend}' is not available in synference_amd: use backend='sbi' (alias 'hip': nflows-style "
+                             "MAF / NSF) or 'lampe' (the zuko-style autoregressive NSF of the reference's lampe backend)")
         if learning_type != "offline":
             raise ValueError("only learning_type='offline' (amortised NPE) is on the HIP path")
-        if prior_method != "ili":
-            raise ValueError("only prior_method='ili' (box prior from the training parameters) is built")
-        if not self.has_features or self.fitted_parameter_array is None:
-            raise ValueError("feature_array and parameter_array must be set before training")
+        if prior_method not in ("ili", "manual"):
+            raise ValueError("Invalid prior method. Use 'manual' or 'ili'.")   # sbi_runner.py:4700-4701
+        if not self.has_features:
+            raise ValueError("Feature array not created. Please create the feature array first.")
+        if self.fitted_parameter_array is None:
+            raise ValueError("Parameter grid not created. Please create the parameter grid first.")
+        run_out_dir = None
+        if out_dir is not None:
+            run_out_dir = os.path.join(os.path.abspath(out_dir), self.name)      # sbi_runner.py:4541
+        stamp = self._timestamp if name_append == "timestamp" else str(name_append)
+        if run_out_dir is not None and save_model and os.path.exists(f"{run_out_dir}/{self.name}_{stamp}_params.pkl"):
+            if load_existing_model:   # sbi_runner.py:4546-4557
+                logger.info(f"Loading existing model from {run_out_dir}/{self.name}_{stamp}_params.pkl")
+                posteriors, stats, _params = self.load_model_from_pkl(f"{run_out_dir}/{self.name}_{stamp}_posterior.pkl", set_self=set_self)
+                return posteriors, stats
+            logger.info("Model with same name already exists. Please change the name of this model or delete the existing one.")
+            return None
         engines = [engine] * n_nets if isinstance(engine, str) else list(engine)
         models = [model_type] * n_nets if isinstance(model_type, str) else list(model_type)
         hf = [hidden_features] * n_nets if isinstance(hidden_features, int) else list(hidden_features)
@@ -414,15 +497,34 @@ class SBI_Fitter:
         for m in models:
             if m not in SUPPORTED_MODELS:
                 raise ValueError(f"model_type '{m}' is not on the HIP path; supported: {SUPPORTED_MODELS}")
-        if train_indices is None:
-            train_indices, test_indices = self.split_dataset(train_test_fraction, random_seed, verbose)
+        if train_indices is None:   # sbi_runner.py:4617-4636
+            have = getattr(self, "_train_indices", None) is not None and getattr(self, "_test_indices", None) is not None
+            if (not have or not use_existing_indices or
+                    len(self._train_indices) + len(self._test_indices) != self.feature_array.shape[0]):
+                train_indices, test_indices = self.split_dataset(train_test_fraction, random_seed, verbose)
+            else:
+                logger.info("Using existing train and test indices.")
+                train_indices, test_indices = self._train_indices, self._test_indices
         X_train = self.feature_array[train_indices]
         y_train = self.fitted_parameter_array[train_indices]
         X_test = self.feature_array[test_indices] if test_indices is not None else None
         y_test = self.fitted_parameter_array[test_indices] if test_indices is not None else None
-        # the prior box spans the WHOLE parameter array (train + test rows), as in the reference's create_priors
-        # (sbi_runner.py:3519-3520)
-        prior = self.create_priors(override_prior_ranges, verbose=verbose)
+        if prior_method == "manual":   # sbi_runner.py:4664-4690
+            self._feature_scalar, self._target_scalar = feature_scalar(), target_scalar()
+            X_train = np.asarray(self._feature_scalar.fit(X_train).transform(X_train), dtype=np.float32)
+            y_train = np.asarray(self._target_scalar.fit(y_train).transform(y_train))
+            if X_test is not None:
+                X_test = np.asarray(self._feature_scalar.transform(X_test), dtype=np.float32)
+                y_test = np.asarray(self._target_scalar.transform(y_test))
+            y_std, y_min, y_max = np.std(y_train, axis=0), np.min(y_train, axis=0), np.max(y_train, axis=0)
+            from .priors import CustomIndependentUniform
+            prior = CustomIndependentUniform(low=torch.tensor(y_min - 3 * y_std, dtype=torch.float32),
+                                             high=torch.tensor(y_max + 3 * y_std, dtype=torch.float32),
+                                             name_list=self.fitted_parameter_names, device="cpu")
+        else:
+            # the prior box spans the WHOLE parameter array (train + test rows), as in the reference's create_priors
+            # (sbi_runner.py:3519-3520)
+            prior = self.create_priors(override_prior_ranges, verbose=verbose)
         nets = []
         for i in range(n_nets):
             args = dict(hidden_features=hf[i], num_transforms=nt[i])
@@ -434,10 +536,9 @@ class SBI_Fitter:
                           optimizer_choice=optimizer_choice)
         if max_num_epochs is not None:
             train_args["max_num_epochs"] = max_num_epochs
-        stamp = time.strftime("%Y%m%d_%H%M%S") if name_append == "timestamp" else str(name_append)
         run_name = f"{self.name}_{stamp}_"
         trainer = HIPRunner.load(backend="hip", engine=engines[0], prior=prior, nets=nets, train_args=train_args,
-                                 out_dir=(out_dir if save_model else None), device=self.device, name=run_name)
+                                 out_dir=(run_out_dir if save_model else None), device=self.device, name=run_name)
         t0 = time.time()
         try:
             posteriors, stats = trainer(NumpyLoader(X_train, y_train), seed=random_seed)
@@ -449,11 +550,11 @@ class SBI_Fitter:
             self._train_indices, self._test_indices = train_indices, test_indices
             self._X_train, self._y_train, self._X_test, self._y_test = X_train, y_train, X_test, y_test
             self.fitted_model_name = run_name
-        if save_model and out_dir is not None:  # sbi_runner.py:4973-5014: the fitter's state next to the posterior pickle
+        if save_model and run_out_dir is not None:  # sbi_runner.py:4973-5014: the fitter's state next to the posterior pickle
             prior_was = self._prior
             self._prior = prior
             try:
-                self.save_state(out_dir=out_dir, name_append=stamp, has_grid=True, engine=engine, learning_type=learning_type,
+                self.save_state(out_dir=run_out_dir, name_append=stamp, save_method=save_method, has_grid=True, engine=engine, learning_type=learning_type,
                                 ensemble_model_types=list(models), ensemble_model_args=[dict(hidden_features=hf[i],
                                 num_transforms=nt[i], **additional_model_args) for i in range(n_nets)], n_nets=n_nets,
                                 train_args=train_args, stats=stats, training_time=self.training_time,
@@ -807,7 +908,7 @@ class SBI_Fitter:
                       return_samples: bool = False, log_times: bool = False, seed: Optional[int] = None,
                       device_quantiles: bool = True, flux_units=None, missing_data_flag=-99,
                       override_transformations: dict = {}, timeout_seconds_per_row: float = 5,
-                      return_feature_array: bool = False, return_full_samples: bool = False, **unused):
+                      return_feature_array: bool = False, return_full_samples: bool = False, **unknown):
         """Sampling + quantile section of the reference's fit_catalogue (sbi_runner.py:3230-3282).
 
         ``observations`` is a pandas DataFrame / dict of columns / (N, C) array.  With ``flux_units`` given and a feature
@@ -818,6 +919,7 @@ class SBI_Fitter:
         (sbi_runner.py:3246-3253); ``return_feature_array`` returns (feature_array, mask) like line 3092-3094;
         ``return_full_samples`` is the reference's name for ``return_samples``."""
         import pandas as pd
+        _warn_unknown("fit_catalogue", unknown)
         return_samples = return_samples or return_full_samples
         if flux_units is not None and getattr(self, "feature_array_flags", None):
             df0 = pd.DataFrame(observations) if isinstance(observations, dict) else observations
@@ -900,13 +1002,14 @@ class SBI_Fitter:
 
     def evaluate_model(self, posteriors=None, X_test=None, y_test=None, num_samples: int = 1000,
                        independent_metrics: bool = True, seed: Optional[int] = None, samples=None,
-                       verbose: bool = False, **unused) -> dict:
+                       verbose: bool = False, **unknown) -> dict:
         """The reference's evaluate_model for flow posteriors (sbi_runner.py:6484-6735), same keys and arithmetic:
         ``MSE``, ``RMSE``, ``mean_ae``, ``median_ae``, ``R_squared`` (total sum of squares about the GLOBAL mean of
         y_test, as there), ``RMSE_norm`` / ``mean_ae_norm`` (divided by the global std), ``log_dpit_max``
         (-0.5 log max |PIT - uniform|, 6613-6616) and ``mean_log_prob``; per parameter with ``independent_metrics``, else
         pooled.  ``tarp`` needs the third-party ``tarp`` package and is left out.  The draws stay on the device: means,
         medians and PIT ranks are reduced there and only (N, D) summaries cross PCIe."""
+        _warn_unknown("evaluate_model", unknown)
         posteriors = posteriors if posteriors is not None else self.posteriors
         X_test = self._X_test if X_test is None else X_test
         y_test = self._y_test if y_test is None else y_test

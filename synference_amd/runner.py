@@ -158,10 +158,11 @@ class HipTrainOps:
         """Batch = rows of the training arrays, gathered inside the kernel; the loss is summed into ``loss_sum``."""
         self.flow.loss_grad_rows(flat, theta, x, rows, scale, grad_out, loss_sum=loss_sum)
 
-    def train_epoch(self, flat, theta, x, order, n_batches, batch, scale, opt, max_norm, grad, loss_sum):
-        """All steps of an epoch in one library call (no host round trip per step); single device only."""
+    def train_epoch(self, flat, theta, x, order, n_batches, batch, scale, opt, max_norm, grad, loss_sum, comm=None):
+        """All steps of an epoch in one library call (no host round trip per step); with ``comm`` (RcclComm) every step's
+        gradient is all-reduced over the ranks inside the call."""
         self.flow.train_epoch(flat, theta, x, order, n_batches, batch, scale, opt.exp_avg, opt.exp_avg_sq, opt.desc,
-                              opt.step_count, max_norm if max_norm is not None else 0.0, opt.scratch, grad, loss_sum)
+                              opt.step_count, max_norm if max_norm is not None else 0.0, opt.scratch, grad, loss_sum, comm=comm)
         opt.step_count += n_batches
 
     def refresh(self, flat):
@@ -278,9 +279,17 @@ def train_flow(estimator: FlowEstimator, theta: torch.Tensor, x: torch.Tensor, *
                              optimizer_choice == "AdamW")
     grad = torch.empty_like(flat.data)
     gscale = 1.0 / (bs_tr * world)
-    # single device, flow-only parameters, library optimiser: run each epoch's batch loop inside the library
+    # flow-only parameters, library optimiser: run each epoch's batch loop inside the library -- on one device as it is, under
+    # an RCCL process group with the per-step gradient all-reduce inside the call (sf_flow_train_epoch_dp: prep -> flow ->
+    # gather -> ncclAllReduce -> clip + Adam on one stream, no host round trip per step).  Other groups (gloo rehearsals, several
+    # ranks on one device) keep the per-step path: loss_grad_rows -> c10d all_reduce -> optimiser step.
     plain_f32 = (theta.dtype == torch.float32 and x.dtype == torch.float32 and theta.is_contiguous() and x.is_contiguous())
-    fused_epoch = world == 1 and not embedded and hasattr(ops, "train_epoch") and isinstance(opt, HipAdam) and plain_f32
+    can_fuse = not embedded and hasattr(ops, "train_epoch") and isinstance(opt, HipAdam) and plain_f32
+    comm = None
+    if world > 1 and can_fuse and isinstance(ops, HipTrainOps):
+        from .comm import default_comm
+        comm = default_comm(dev)
+    fused_epoch = can_fuse and (world == 1 or comm is not None)
     fused_rows = not fused_epoch and not embedded and hasattr(ops, "loss_grad_rows") and plain_f32
 
     best_val, since, best_state = float("inf"), 0, None
@@ -316,7 +325,10 @@ def train_flow(estimator: FlowEstimator, theta: torch.Tensor, x: torch.Tensor, *
         tl = torch.zeros((), dtype=torch.float64, device=dev)
         if fused_epoch:
             # the whole batch loop in one library call: row gather fused into the kernel, loss summed on the device
-            ops.train_epoch(flat.data, theta, x, order.contiguous(), nb_tr, bs_tr, gscale, opt, clip_max_norm, grad, tl)
+            if comm is not None:
+                ops.train_epoch(flat.data, theta, x, order.contiguous(), nb_tr, bs_tr, gscale, opt, clip_max_norm, grad, tl, comm=comm)
+            else:
+                ops.train_epoch(flat.data, theta, x, order.contiguous(), nb_tr, bs_tr, gscale, opt, clip_max_norm, grad, tl)
         elif fused_rows:
             # data parallel: fused-gather loss_grad, ONE all-reduce of the flat gradient, identical step on every rank
             order = order.contiguous()

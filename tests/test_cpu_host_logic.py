@@ -332,7 +332,7 @@ def test_custom_config_yaml_maps_fixed_params(tmp_path, monkeypatch):
     rng = np.random.default_rng(0)
     f = SBI_Fitter("y", ["a", "b"], ["F0", "F1", "F2"], feature_array=rng.normal(size=(50, 3)),
                    parameter_array=rng.normal(size=(50, 2)))
-    post, stats = f.run_single_sbi(custom_config_yaml=str(cfg), verbose=False, save_model=False, random_seed=1)
+    post, stats = f.run_single_sbi(custom_config_yaml=str(cfg), verbose=False, save_model=False, random_seed=1, evaluate_model=False)
     ta = seen["train_args"]
     assert ta["training_batch_size"] == 52 and ta["stop_after_epochs"] == 47 and ta["optimizer_choice"] == "AdamW"
     assert abs(ta["learning_rate"] - 3e-4) < 1e-12 and abs(ta["clip_max_norm"] - 4.7) < 1e-12 and ta["validation_fraction"] == 0.1
@@ -342,6 +342,91 @@ def test_custom_config_yaml_maps_fixed_params(tmp_path, monkeypatch):
     bad.write_text("train_args:\n  optuna: {n_trials: 3}\n")
     with pytest.raises(ValueError, match="Optuna"):
         f.run_single_sbi(custom_config_yaml=str(bad), verbose=False)
+
+
+# the reference's run_single_sbi parameters, in order, with their defaults (sbi_runner.py:4392-4435; callables / objects by name)
+REF_RUN_SINGLE_SBI = [
+    ("train_test_fraction", 0.8), ("random_seed", None), ("backend", "sbi"), ("engine", "NPE"), ("train_indices", None),
+    ("test_indices", None), ("n_nets", 1), ("model_type", "mdn"), ("hidden_features", 50), ("num_components", 4),
+    ("num_transforms", 4), ("training_batch_size", 64), ("learning_rate", 1e-4), ("validation_fraction", 0.2),
+    ("stop_after_epochs", 15), ("clip_max_norm", 5.0), ("additional_model_args", {}), ("save_model", True), ("verbose", True),
+    ("prior_method", "ili"), ("out_dir", "<code_path>/models/"), ("plot", True), ("name_append", "timestamp"),
+    ("feature_scalar", "StandardScaler"), ("target_scalar", "StandardScaler"), ("set_self", True), ("learning_type", "offline"),
+    ("simulator", None), ("num_simulations", 1000), ("num_online_rounds", 5), ("initial_training_from_library", False),
+    ("override_prior_ranges", {}), ("online_training_xobs", None), ("load_existing_model", True), ("use_existing_indices", True),
+    ("evaluate_model", True), ("save_method", "joblib"), ("num_posterior_draws_per_sample", 1000), ("embedding_net", "Identity"),
+    ("custom_config_yaml", None), ("sql_db_path", None)]
+
+
+def test_run_single_sbi_signature_is_the_references():
+    """Positional order, names and defaults of SBI_Fitter.run_single_sbi."""
+    import inspect
+    from synference_amd import SBI_Fitter
+    sig = inspect.signature(SBI_Fitter.run_single_sbi)
+    pos = [p for p in sig.parameters.values() if p.kind == p.POSITIONAL_OR_KEYWORD and p.name != "self"]
+    assert [p.name for p in pos] == [n for n, _ in REF_RUN_SINGLE_SBI]
+    for p, (name, default) in zip(pos, REF_RUN_SINGLE_SBI):
+        if name == "out_dir":
+            assert p.default.endswith("/models/")
+        elif name in ("feature_scalar", "target_scalar"):
+            assert p.default.__name__ == "StandardScaler"
+        elif name == "embedding_net":
+            assert p.default is None or type(p.default).__name__ == "Identity"   # (None = identity here: no module built at import)
+        else:
+            assert p.default == default, (name, p.default, default)
+    extra = [p.name for p in sig.parameters.values() if p.kind == p.KEYWORD_ONLY]
+    assert extra == ["max_num_epochs", "optimizer_choice"]
+
+
+def test_run_single_sbi_existing_model_indices_and_manual_prior(tmp_path, monkeypatch):
+    """load_existing_model / use_existing_indices / prior_method='manual' (sbi_runner.py:4543-4563, 4617-4636, 4664-4690),
+    with a stand-in for the trainer (the host logic only)."""
+    from synference_amd import SBI_Fitter
+    import synference_amd.fitter as fitter_mod
+    seen = {"calls": 0}
+
+    class FakeRunner:
+        @classmethod
+        def load(cls, **kw):
+            seen.update(kw)
+            return cls()
+
+        def __call__(self, loader, seed=None):
+            seen["calls"] += 1
+            seen["x"], seen["theta"] = np.asarray(loader.get_all_data()), np.asarray(loader.get_all_parameters())
+            return "posterior", [{"ok": True}]
+
+    monkeypatch.setattr(fitter_mod, "HIPRunner", FakeRunner)
+    rng = np.random.default_rng(0)
+    x, th = rng.normal(2.0, 3.0, size=(60, 3)), rng.normal(-1.0, 0.5, size=(60, 2))
+    f = SBI_Fitter("m", ["a", "b"], ["F0", "F1", "F2"], feature_array=x, parameter_array=th)
+    f.run_single_sbi(model_type="maf", save_model=False, evaluate_model=False, verbose=False, random_seed=4, plot=False)
+    tr0 = np.array(f._train_indices)
+    f.run_single_sbi(model_type="maf", save_model=False, evaluate_model=False, verbose=False, random_seed=5, plot=False)
+    assert np.array_equal(tr0, f._train_indices)                      # the stored split is re-used ...
+    f.run_single_sbi(model_type="maf", save_model=False, evaluate_model=False, verbose=False, random_seed=5, plot=False,
+                     use_existing_indices=False)
+    assert not np.array_equal(tr0, f._train_indices)                  # ... unless the caller says otherwise
+    # manual prior: the trainer sees standardised arrays, the box is min / max -+ 3 sigma of the scaled parameters
+    f.run_single_sbi(model_type="maf", save_model=False, evaluate_model=False, verbose=False, plot=False, prior_method="manual")
+    assert np.abs(seen["x"].mean(0)).max() < 1e-5 and np.abs(seen["x"].std(0) - 1).max() < 1e-5
+    assert np.abs(seen["theta"].mean(0)).max() < 1e-6
+    ys = seen["theta"]
+    assert np.allclose(seen["prior"].low.cpu().numpy(), ys.min(0) - 3 * ys.std(0), atol=1e-5)
+    assert np.allclose(seen["prior"].high.cpu().numpy(), ys.max(0) + 3 * ys.std(0), atol=1e-5)
+    back = f._target_scalar.inverse_transform(ys)
+    assert np.allclose(back, th[f._train_indices], atol=1e-9)
+    with pytest.raises(ValueError, match="Invalid prior method"):
+        f.run_single_sbi(model_type="maf", prior_method="other", save_model=False)
+    # an existing {out_dir}/{name}/{name}_{append}_params.pkl: refused (None) or loaded, never silently retrained
+    d = tmp_path / "m"
+    d.mkdir()
+    (d / "m_v1_params.pkl").write_bytes(b"")
+    n = seen["calls"]
+    assert f.run_single_sbi(model_type="maf", out_dir=str(tmp_path), name_append="v1", load_existing_model=False, plot=False) is None
+    monkeypatch.setattr(SBI_Fitter, "load_model_from_pkl", lambda self, path, set_self=True: ("loaded:" + path, ["s"], {}))
+    post, stats = f.run_single_sbi(model_type="maf", out_dir=str(tmp_path), name_append="v1", plot=False)
+    assert post == "loaded:" + str(d / "m_v1_posterior.pkl") and seen["calls"] == n
 
 
 @pytest.mark.parametrize("kind,D,C,K,NB", [("maf", 5, 10, 10, 2), ("nsf", 8, 20, 8, 2), ("nsf", 5, 3, 10, 1), ("maf", 3, 4, 10, 3)])

@@ -18,8 +18,8 @@ def fitted(tmp_path_factory):
     post, stats = f.run_single_sbi(model_type="maf", hidden_features=50, num_transforms=5, n_nets=2,
                                    training_batch_size=256, learning_rate=2e-3, stop_after_epochs=3,
                                    max_num_epochs=12, random_seed=3, out_dir=str(out), verbose=False,
-                                   name_append="t")
-    return f, post, stats, out
+                                   name_append="t", evaluate_model=False)
+    return f, post, stats, out / "e2e"     # (out_dir gets the fitter's name appended: sbi_runner.py:4541)
 
 
 def test_training_reduces_loss_and_fills_stats(fitted):
@@ -126,10 +126,15 @@ def test_saved_state_reloads_into_a_fresh_fitter(fitted):
 
 def test_unsupported_requests_fail_loudly(fitted):
     f, *_ = fitted
+    with pytest.raises(ValueError, match="not on the HIP path"):
+        f.run_single_sbi()                                        # the reference's default model_type is "mdn"
     with pytest.raises(ValueError):
-        f.run_single_sbi(model_type="mdn")
-    with pytest.raises(ValueError):
-        f.run_single_sbi(backend="sbi")
+        f.run_single_sbi(backend="pydelfi", model_type="maf")
+    with pytest.raises(ValueError, match="online"):
+        f.run_single_sbi(model_type="maf", learning_type="online")
+    with pytest.warns(UserWarning, match="unknown keyword"):
+        with pytest.raises(ValueError):
+            f.run_single_sbi(model_type="mdn", not_a_reference_argument=1)
     with pytest.raises(ValueError):
         f.sample_posterior(f._X_test[:2], sample_method="emcee")
 
