@@ -213,6 +213,14 @@ int sf_flow_sample(sf_flow* f, const float* x /*[M,C]*/, int64_t M, int64_t S,
  * catalogue with the same seed.  Stays in force until changed; 0 after sf_flow_create.
  * Replaces: nothing in the reference (its per-galaxy loop, sbi_runner.py:6438-6442, has no batching to be independent of). */
 int sf_flow_set_sample_row_offset(sf_flow* f, int64_t row_offset);
+/* Output dtype of the next sf_flow_sample / sf_flow_sample_slots calls on this handle: on != 0 -- `out` is a DOUBLE array
+ * [M,S,D] (passed through the float* parameter) and every accepted draw is widened fp32 -> float64 in its store (exact).
+ * float64 is the container dtype of the reference's sample_posterior (sbi_runner.py:6436: np.zeros((N, S, D))); `out` may be
+ * PINNED HOST memory mapped into the device's address space (hipHostMalloc): the draws then cross PCIe while the sampler
+ * runs and the reference's host array is complete when the stream is -- no D2H copy and no widening pass afterwards
+ * (measured on the cfg2 catalogue: +0.3 ms on a 2.6 ms launch against 1.0 ms for copy + widening).  Not offered for the
+ * one-parameter / autoregressive NSF (fp32 + sf_copy_to_host_f64 there). */
+int sf_flow_set_sample_output_f64(sf_flow* f, int on);
 /* Wall-clock ceiling of later sf_flow_sample / sf_flow_sample_slots calls on this handle (seconds; <= 0 = none, the
  * default): once it is exceeded no further attempt window is opened and the slots still empty become NaN rows.
  * Replaces: the per-object timeout of sample_posterior (timeout_seconds_per_test, ref: sbi_runner.py:6358, 6443-6452). */

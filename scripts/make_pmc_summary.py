@@ -3,7 +3,7 @@ scripts/prof_collect.sh (profiles/rNN_pmc_maf.csv: default bench; rNN_pmc_nsf.cs
 rocprofv3 --pmc passes each: FETCH_SIZE | WRITE_SIZE | two SQ sets).  Keys of the top level / "train" are the ones
 bench.py reads (hbm_bytes_per_launch, *_busy_frac); "nsf" holds the sampler / log_prob / training kernels of cfg3."""
 import collections, csv, json, os, re, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 
 
@@ -57,7 +57,10 @@ def section(rows, pat, grid=None, alg_bytes=None, note=None):
 
 maf = list(csv.DictReader(open(os.path.join(P, f"{tag}_pmc_maf.csv"))))
 M, S, D, C, P_ = 2000, 1000, 5, 10, 32300
-out = section(maf, "k_maf_samp16", alg_bytes=4.0 * D * M * S + 4.0 * C * M)
+# the default sampler (round 5): every product in fp32 -- template argument PREC = 1 is the last one of the kernel name
+out = section(maf, r"k_maf_samp16<.*, 1>", alg_bytes=4.0 * D * M * S + 4.0 * C * M)
+if out is None:
+    out = section(maf, "k_maf_samp16", alg_bytes=4.0 * D * M * S + 4.0 * C * M)
 out["command"] = ("rocprofv3 --pmc <COUNTERS> --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 "
                   "--no-cpu-baseline (separate passes: FETCH_SIZE | WRITE_SIZE | SQ_* | SQ_*; scripts/prof_collect.sh)")
 out["note"] = ("busy fractions = counter / (1024 SIMDs x launch time x 2.4 GHz); *_quad counters count quad-cycles.  One sampler "
@@ -66,6 +69,8 @@ out["note"] = ("busy fractions = counter / (1024 SIMDs x launch time x 2.4 GHz);
 out["train"] = section(maf, "k_maf_trainc", grid=256 * 512, alg_bytes=4.0 * (D + C) * 16384 + 4.0 * 2 * P_,
                        note="cooperative 16-row kernel, batch 16 384: per-workgroup gradient partials are written with plain stores "
                             "(256 x 145 KB) and summed by k_gather_c")
+out["sampler_split_bf16_leg"] = section(maf, r"k_maf_samp16<.*, 0>", alg_bytes=4.0 * D * M * S + 4.0 * C * M,
+                                        note="the opt-in fast mode (sf_set_sampler_fp32(0)): hidden H x H blocks as split-bf16 x3 products")
 out["train_gather"] = section(maf, "k_gather_c")
 out["train_prep"] = section(maf, "k_train_prep")
 nsf_path = os.path.join(P, f"{tag}_pmc_nsf.csv")

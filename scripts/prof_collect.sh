@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): everything behind profiles/rNN_*.      usage: bash scripts/prof_collect.sh r04
+# Runs on the GPU box (gpurun): everything behind profiles/rNN_*.      usage: bash scripts/prof_collect.sh r05
 #   1. rocprofv3 --kernel-trace --stats of the default bench command          -> kernel_stats.csv, kernels.txt
 #   2. three separate --pmc passes of the default bench (FETCH_SIZE | WRITE_SIZE | SQ_*)  -> per-kernel counter rows
 #   3. the same for the NSF workload of BASELINE configs[2] (bench.py --workload nsf_cfg3)
@@ -9,13 +9,13 @@
 # Only small summaries are kept (gpurun_out/prof_rNN/); scripts/make_pmc_summary.py rNN turns them into
 # profiles/rNN_pmc_summary.json, which bench.py reads `traffic` / `issue_busy` from.
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG; RAW=/tmp/sfprof_$TAG; rm -rf $RAW; mkdir -p $OUT $RAW
 say() { echo "[$(date +%H:%M:%S)] $*" | tee -a $OUT/progress.log; }
 
 trace() {  # tag, bench args
-  rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/stats_$1 -- python3 bench.py $2 --no-cpu-baseline --skip-large-catalogue > $OUT/bench_under_rocprof_$1.json 2> $RAW/stats_$1.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/stats_$1 -- python3 bench.py $2 --no-cpu-baseline --skip-large-catalogue --skip-nsf-leg --skip-per-object --repeats 1 > $OUT/bench_under_rocprof_$1.json 2> $RAW/stats_$1.err
   cp $RAW/stats_$1/*/*_kernel_stats.csv $OUT/kernel_stats_$1.csv
   python3 - "$RAW/stats_$1" "$OUT/kernels_$1.txt" <<'PY'
 import csv, glob, sys, statistics, collections
@@ -39,7 +39,7 @@ pmc() {  # tag, bench args, kernel regex
               "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_ANY" \
               "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VMEM"; do
     t=$(echo $pass | cut -d' ' -f1)
-    rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $RAW/pmc_$1_$t -- python3 bench.py $2 --no-cpu-baseline --skip-large-catalogue > /dev/null 2> $RAW/pmc_$1_$t.err
+    rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $RAW/pmc_$1_$t -- python3 bench.py $2 --no-cpu-baseline --skip-large-catalogue --skip-nsf-leg --skip-per-object --skip-dp --repeats 1 > /dev/null 2> $RAW/pmc_$1_$t.err
     say "pmc $1 $t done"
   done
   python3 - "$RAW" "$1" "$3" "$OUT/pmc_$1.csv" <<'PY'
@@ -68,7 +68,7 @@ PY
 say "kernel trace, default bench"
 trace maf ""
 say "PMC passes, default bench"
-pmc maf "--steps 3 --warmup 1 --skip-throughput-regime --skip-api" "k_maf_samp16|k_maf_trainc|k_gather_c|k_train_prep|k_adam|k_logprob"
+pmc maf "--steps 3 --warmup 1 --skip-throughput-regime --skip-api" "k_maf_samp16|k_maf_find16s|k_maf_ctab16|k_maf_trainc|k_gather_c|k_train_prep|k_adam|k_logprob"
 say "kernel trace, nsf_cfg3"
 trace nsf "--workload nsf_cfg3 --steps 3 --warmup 1"
 say "PMC passes, nsf_cfg3"

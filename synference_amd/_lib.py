@@ -107,6 +107,7 @@ PROTOTYPES = {
                                              C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p]),
     "sf_flow_set_sample_time_limit": (C.c_int, [C.c_void_p, C.c_double]),
+    "sf_flow_set_sample_output_f64": (C.c_int, [C.c_void_p, C.c_int]),
     "sf_flow_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "sf_flow_train_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "sf_opt_create": (C.c_int, [C.c_int64, C.POINTER(sf_adam_desc), C.POINTER(C.c_void_p)]),

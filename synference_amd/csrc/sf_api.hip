@@ -590,7 +590,7 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
   SfSampleArgsHost a;
   a.x = x; a.S = (long)S; seed_keys(seed, 0, a.k0, a.k1);
   a.rng_slot_offset = (unsigned long long)f->sample_row_offset * (unsigned long long)S;
-  a.lo = lo; a.hi = hi; a.out = out; a.n_drawn = n_drawn;
+  a.lo = lo; a.hi = hi; a.out = out; a.n_drawn = n_drawn; a.out_f64 = f->sample_out_f64 ? 1 : 0;
   a.q = f->d_queue; a.ring = f->d_ring; a.ring_mask = (uint32_t)(f->ring_cap - 1);
   a.out_slots = (uint32_t)(M * S);
   const uint32_t* cur = slots;
@@ -694,7 +694,7 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
     if (e != hipSuccess) { f->ctab_x = nullptr; return hip_fail(e, "persistent sampler launch"); }
     if (stage == 0) SF_HIP(hipEventRecord(f->ev_dense[1], st));
     if (limit >= 1024u && rule_due(limit)) {  // drop the open slots of galaxies that made no progress (NaN rows), in place
-      SF_HIP(sf_launch_filter_survivors(f->d_rej[buf], &f->d_queue->n_surv, (long)S, f->d_galacc, out, f->L.dev.D, st));
+      SF_HIP(sf_launch_filter_survivors(f->d_rej[buf], &f->d_queue->n_surv, (long)S, f->d_galacc, out, f->L.dev.D, st, a.out_f64));
       SF_HIP(hipMemsetAsync(f->d_galacc, 0, (size_t)M * sizeof(int32_t), st));
       acc_from = limit;
     }
@@ -788,7 +788,7 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
       const bool window_done = attempt >= window_end || attempt >= ceiling;
       const bool look = window_done && rule_due(attempt);
       if (look) {
-        SF_HIP(sf_launch_filter_survivors(f->d_rej[buf], &f->d_queue->n_surv, (long)S, f->d_galacc, out, f->L.dev.D, st));
+        SF_HIP(sf_launch_filter_survivors(f->d_rej[buf], &f->d_queue->n_surv, (long)S, f->d_galacc, out, f->L.dev.D, st, a.out_f64));
         SF_HIP(hipMemsetAsync(f->d_galacc, 0, (size_t)M * sizeof(int32_t), st));
         acc_from = attempt;
       }
@@ -808,7 +808,7 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
     f->last_stats[0] = ms; f->last_stats[1] = (float)stage; f->last_stats[2] = rej0; f->last_stats[3] = (float)evals;
   }
   f->ctab_x = nullptr;
-  if (pending > 0) SF_HIP(sf_launch_fill_nan_rows(out, cur, (long)pending, f->L.dev.D, st));
+  if (pending > 0) SF_HIP(sf_launch_fill_nan_rows(out, cur, (long)pending, f->L.dev.D, st, a.out_f64));
   if (n_unfilled) *n_unfilled = pending + dropped;
   return SF_OK;
 }
@@ -1128,6 +1128,15 @@ int sf_flow_set_sample_row_offset(sf_flow* f, int64_t row_offset) {
   if (!f) return fail(SF_ERR_INVALID, "null handle");
   if (row_offset < 0) return fail(SF_ERR_INVALID, "row_offset < 0");
   f->sample_row_offset = (long long)row_offset;
+  return SF_OK;
+}
+
+int sf_flow_set_sample_output_f64(sf_flow* f, int on) {
+  if (!f) return fail(SF_ERR_INVALID, "null handle");
+  if (on && (f->nsf1 || f->nsfar))
+    return fail(SF_ERR_INVALID, "float64 sampler output is not offered for the one-parameter / autoregressive NSF: sample fp32 and "
+                                "use sf_copy_to_host_f64");
+  f->sample_out_f64 = on != 0;
   return SF_OK;
 }
 

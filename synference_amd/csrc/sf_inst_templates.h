@@ -163,7 +163,7 @@ __global__ __launch_bounds__(LDSW ? 512 : 256) void k_inverse(SfDev m, SfSampleA
         if (ok && me == first) {
 #pragma unroll
           for (int p = 0; p < SF_DMAX; ++p)
-            if (p < m.D) a.out[slot[ns] * m.D + (int)m.cst[m.c_tdim + p]] = th[p];
+            if (p < m.D) sf_out_store(a, (size_t)slot[ns] * m.D + (int)m.cst[m.c_tdim + p], th[p]);
         } else if (first < 0 && me == 0) {
           const uint32_t pos = atomicAdd(a.n_rejected, 1u);
           a.rejected[pos] = (uint32_t)slot[ns];
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64 * WPB) void k_sample_persist(SfSampArgs args_in,
       if (valid && h == 0 && ok && me == first) {
 #pragma unroll
         for (int p = 0; p < SF_DMAX; ++p)
-          if (p < m.D) a.out[(size_t)slot * m.D + (int)m.cst[m.c_tdim + p]] = th[p];
+          if (p < m.D) sf_out_store(a, (size_t)slot * m.D + (int)m.cst[m.c_tdim + p], th[p]);
       }
       const bool leader = entry_ok && h == 0 && me == 0;
       const uint32_t room = a.attempt_limit > att_base ? a.attempt_limit - att_base : 0u;

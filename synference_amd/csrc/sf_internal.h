@@ -22,6 +22,7 @@ struct SfSampleArgsHost {
   const float* lo = nullptr;
   const float* hi = nullptr;
   float* out = nullptr;
+  int out_f64 = 0;            // != 0: `out` is a double array (sf_flow_set_sample_output_f64): accepted draws are widened in the store
   float* logdet_out = nullptr;
   uint32_t* rejected = nullptr;
   uint32_t* n_rejected = nullptr;
@@ -69,6 +70,14 @@ struct SfSampleArgsHost {
   uint32_t* qtrace = nullptr;
 #endif
 };
+#ifdef __HIPCC__
+// one value of an accepted draw: fp32 into a float array or -- out_f64 -- widened into a double array (wave-uniform choice)
+__device__ __forceinline__ void sf_out_store(const SfSampleArgsHost& a, size_t idx, float v) {
+  if (a.out_f64) reinterpret_cast<double*>(a.out)[idx] = (double)v;
+  else a.out[idx] = v;
+}
+#endif
+
 
 hipError_t sf_launch_logprob(const SfDev& m, const float* theta, const float* x, long B, float* out,
                              hipStream_t st);
@@ -88,13 +97,13 @@ hipError_t sf_launch_pack(const float* flat, const int32_t* s1, const int32_t* s
                           hipStream_t st);
 hipError_t sf_launch_pack_bf16(const float* flat, const int32_t* src, unsigned short* out, long n, hipStream_t st);
 hipError_t sf_launch_pack_bf16_split(const float* flat, const int32_t* src, unsigned short* out, long n, hipStream_t st);
-hipError_t sf_launch_fill_nan_rows(float* out, const uint32_t* slots, long n, int D, hipStream_t st);
+hipError_t sf_launch_fill_nan_rows(float* out, const uint32_t* slots, long n, int D, hipStream_t st, int out_f64 = 0);
 hipError_t sf_launch_fill_i32(int32_t* p, long n, int32_t v, hipStream_t st);
 hipError_t sf_launch_account_window(const uint32_t* list, const uint32_t* best, long n, long S, uint32_t a_lo, uint32_t A,
                                     int32_t* n_drawn, int32_t* gal_acc, hipStream_t st);
 // survivors of galaxies with gal_acc == 0 become NaN rows; the others are compacted in place; *n_surv updated
 hipError_t sf_launch_filter_survivors(uint32_t* list, unsigned int* n_surv, long S, const int32_t* gal_acc, float* out,
-                                      int D, hipStream_t st);
+                                      int D, hipStream_t st, int out_f64 = 0);
 
 #include <string>
 // per-device "attribute already set" cache for hipFuncSetAttribute(MaxDynamicSharedMemorySize): function attributes are
@@ -203,6 +212,7 @@ struct sf_flow {
   bool losspart_used = false;
   uint32_t* d_cnt = nullptr;     // SF_MAX_ROUNDS rejected-slot counters (one per round of a sf_flow_sample call)
   uint32_t* h_cnt = nullptr;     // pinned host mirror for the per-round read-back
+  bool sample_out_f64 = false;       // sf_flow_set_sample_output_f64: `out` of sf_flow_sample / _slots is a double array
   long long sample_row_offset = 0;   // sf_flow_set_sample_row_offset: first row of the next sampling calls in its catalogue
   double sample_time_limit_s = 0.0;  // > 0: sf_flow_sample* stop opening new attempt windows after this much wall time
   bool profiling = false;         // sf_flow_set_profiling: bracket the training flow kernel with HIP events

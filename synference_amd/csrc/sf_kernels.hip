@@ -47,10 +47,13 @@ __global__ void k_pack_bf16_split(const float* __restrict__ flat, const int32_t*
   out[i] = r;
 }
 
-__global__ void k_fill_nan_rows(float* __restrict__ out, const uint32_t* __restrict__ slots, long n, int D) {
+__global__ void k_fill_nan_rows(float* __restrict__ out, const uint32_t* __restrict__ slots, long n, int D, int out_f64) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  for (int d = 0; d < D; ++d) out[(long)slots[i] * D + d] = __builtin_nanf("");
+  for (int d = 0; d < D; ++d) {
+    if (out_f64) reinterpret_cast<double*>(out)[(long)slots[i] * D + d] = __builtin_nan("");
+    else out[(long)slots[i] * D + d] = __builtin_nanf("");
+  }
 }
 
 // Progress rule between the stages of an uncapped sampling call (sf_api.hip): one workgroup walks the survivor list;
@@ -58,7 +61,7 @@ __global__ void k_fill_nan_rows(float* __restrict__ out, const uint32_t* __restr
 // (stable order), and the survivor count is updated.  The list is short (it is what more than 64 attempts left over).
 __global__ __launch_bounds__(1024) void k_filter_survivors(uint32_t* __restrict__ list, unsigned int* __restrict__ n_surv,
                                                           long S, const int32_t* __restrict__ gal_acc,
-                                                          float* __restrict__ out, int D) {
+                                                          float* __restrict__ out, int D, int out_f64) {
   __shared__ unsigned int warp_cnt[16];
   __shared__ unsigned int base_s;
   const unsigned int n = *n_surv;
@@ -73,7 +76,10 @@ __global__ __launch_bounds__(1024) void k_filter_survivors(uint32_t* __restrict_
       slot = list[i];
       keep = gal_acc[(long)(slot / (uint32_t)S)] > 0;
       if (!keep)
-        for (int d = 0; d < D; ++d) out[(size_t)slot * D + d] = __builtin_nanf("");
+        for (int d = 0; d < D; ++d) {
+          if (out_f64) reinterpret_cast<double*>(out)[(size_t)slot * D + d] = __builtin_nan("");
+          else out[(size_t)slot * D + d] = __builtin_nanf("");
+        }
     }
     const unsigned long long bal = __ballot(keep);
     if (lane == 0) warp_cnt[w] = (unsigned)__popcll(bal);
@@ -215,14 +221,14 @@ hipError_t sf_launch_pack_bf16_split(const float* flat, const int32_t* src, unsi
   hipLaunchKernelGGL(k_pack_bf16_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, flat, src, out, n);
   return hipGetLastError();
 }
-hipError_t sf_launch_fill_nan_rows(float* out, const uint32_t* slots, long n, int D, hipStream_t st) {
+hipError_t sf_launch_fill_nan_rows(float* out, const uint32_t* slots, long n, int D, hipStream_t st, int out_f64) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_fill_nan_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, slots, n, D);
+  hipLaunchKernelGGL(k_fill_nan_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, slots, n, D, out_f64);
   return hipGetLastError();
 }
 hipError_t sf_launch_filter_survivors(uint32_t* list, unsigned int* n_surv, long S, const int32_t* gal_acc, float* out,
-                                      int D, hipStream_t st) {
-  hipLaunchKernelGGL(k_filter_survivors, dim3(1), dim3(1024), 0, st, list, n_surv, S, gal_acc, out, D);
+                                      int D, hipStream_t st, int out_f64) {
+  hipLaunchKernelGGL(k_filter_survivors, dim3(1), dim3(1024), 0, st, list, n_surv, S, gal_acc, out, D, out_f64);
   return hipGetLastError();
 }
 hipError_t sf_launch_account_window(const uint32_t* list, const uint32_t* best, long n, long S, uint32_t a_lo, uint32_t A,

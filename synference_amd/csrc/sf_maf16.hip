@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256, 3) void k_maf_inv16(SfDev m, SfSampleArgsHost 
       if (me == first) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (4 * g4 + r < m.D) a.out[slot * m.D + (int)m.cst[m.c_tdim + 4 * g4 + r]] = th[r];
+          if (4 * g4 + r < m.D) sf_out_store(a, (size_t)slot * m.D + (int)m.cst[m.c_tdim + 4 * g4 + r], th[r]);
       } else if (first < 0 && me == 0 && g4 == 0) {
         const uint32_t pos = atomicAdd(a.n_rejected, 1u);
         a.rejected[pos] = (uint32_t)slot;
@@ -960,6 +960,7 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
     ecb[p * 5 + 2] = (on && args_in.a.lo) ? args_in.a.lo[td] : -3.4e38f;
     ecb[p * 5 + 3] = (on && args_in.a.lo) ? args_in.a.hi[td] : 3.4e38f;
     reinterpret_cast<int*>(ecb)[p * 5 + 4] = td;
+    if (on) reinterpret_cast<int*>(ecb)[80 + td] = p;   // theta column -> physical slot (the row-linear stores of the epilogue)
   }
   // (the first sf_q_fetch begins with a barrier: the block is visible to every wave before its first epilogue)
 #ifdef SF_Q_STATS
@@ -1180,10 +1181,29 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
         me = wi - (int)(e << lgA);
         if (TPW == 2) __syncthreads();  // the four words are rewritten for the other tile
       }
-      if (valid && me == first) {
+      // A tile of first attempts is 16 CONSECUTIVE slots (one run of a galaxy's draws: dense_run): its accepted rows are one
+      // contiguous piece of the output, so the 16 x D block is handed to the lanes LINEARLY (lane L stores element L, L + 64,
+      // ...: whole 64-byte segments per wave-instruction instead of five 4-byte pieces per draw from two row groups -- half the
+      // write traffic in HBM, and a third of the PCIe packets when `out` is the host's float64 array).  The value of element
+      // (draw se, column c) sits in lane se + 16 (p >> 2), register p & 3, p = the column's physical slot.
+      const uint32_t slot0 = (uint32_t)__shfl((int)slot, 0, 64);
+      const bool lin = lgA == 0 && __ballot(!entry_ok || slot == slot0 + (uint32_t)s) == ~0ull;
+      if (lin) {
+        const int Dn = DD > 0 ? DD : m.D;
+        const int* c2s = reinterpret_cast<const int*>(ecb) + 80;
+        for (int e0 = 0; e0 < 16 * Dn; e0 += 64) {
+          const int e = e0 + (lane & 63);
+          const int se = (e / Dn) & 15, c = e - (e / Dn) * Dn;
+          const int p = c2s[c];
+          const int src = se + 16 * (p >> 2), rr = p & 3;
+          const float v0 = __shfl(th[0], src, 64), v1 = __shfl(th[1], src, 64), v2 = __shfl(th[2], src, 64), v3 = __shfl(th[3], src, 64);
+          const float v = rr == 0 ? v0 : (rr == 1 ? v1 : (rr == 2 ? v2 : v3));
+          if (e < 16 * Dn && ((acc16 >> se) & 1u)) sf_out_store(a, (size_t)slot0 * Dn + e, v);
+        }
+      } else if (valid && me == first) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (4 * g4 + r < m.D) a.out[(size_t)slot * m.D + tdc[r]] = th[r];
+          if (4 * g4 + r < m.D) sf_out_store(a, (size_t)slot * m.D + tdc[r], th[r]);
       }
       // accepted -> resolved; rejected -> staged for the retry ring, or for the survivor list once the launch's attempt
       // limit is reached; wave 0 publishes everything the workgroup staged at the top of the next sf_q_fetch
@@ -1357,7 +1377,7 @@ __global__ __launch_bounds__(256, 4) void k_maf_find16s(SfDev m, SfSampleArgsHos
       if (accepted) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (4 * g4 + r < m.D) a.out[(size_t)slot * m.D + tdc[r]] = th[r];
+          if (4 * g4 + r < m.D) sf_out_store(a, (size_t)slot * m.D + tdc[r], th[r]);
       } else if (g4 == 0) {
         const uint32_t pos = atomicAdd(a.n_rejected, 1u);
         a.rejected[pos] = slot;
@@ -1583,7 +1603,7 @@ static hipError_t sf_launch16q_p(const SfDev& m, const SfSampleArgsHost& a, hipS
   static SfAttrCache attr;
   static SfResidentCache rcache;
   const size_t sh = ((size_t)(m.ctab ? m.t16_a_tab : m.t16_a) + (size_t)SfHid16<PREC>::lds_floats(m, !SPAN)) * sizeof(float) +
-                    (SF_Q_WORDS(64 * TPW) + 80) * sizeof(unsigned int);
+                    (SF_Q_WORDS(64 * TPW) + 96) * sizeof(unsigned int);
   if (sh > 160 * 1024) return hipErrorInvalidValue;
   int attr_dev;
   if (attr.need(attr_dev)) {

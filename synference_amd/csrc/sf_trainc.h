@@ -5,7 +5,10 @@
 
 #include "sf_layout.h"
 
-#define SF_TRC_TS 5  // transforms whose a1 / a2 tiles a wave keeps in registers (flows with more take k_maf_train)
+#define SF_TRC_TS 5       // transforms whose a1 / a2 tiles a wave keeps in registers without spilling
+#define SF_TRC_TS_MAX 8   // flows with more transforms take k_maf_train
+// the instantiation (stash depth) a flow of T transforms runs
+inline int sf_trc_ts(int T) { return T <= 5 ? 5 : (T <= 6 ? 6 : 8); }
 
 struct SfTrcArgs {
   SfTrcDev c;

@@ -886,7 +886,7 @@ bool sf_trainc_eligible(const SfLayout& L, bool want_dctx) {
   static int env = -1;
   if (env < 0) { const char* e = std::getenv("SF_TRAINC"); env = e ? std::atoi(e) : 1; }
   if (!env || !c.ok) return false;
-  if (L.dev.T > SF_TRC_TS || c.NI > 2 || c.NT < 1 || c.NT > 4) return false;
+  if (L.dev.T > SF_TRC_TS_MAX || c.NI > 2 || c.NT < 1 || c.NT > 4) return false;
   if (want_dctx && c.NI > 1) return false;
   {
     bool ok = false;
@@ -905,7 +905,7 @@ bool sf_trainc_eligible(const SfLayout& L, bool want_dctx) {
     const int nb = (c.NT - c.kbeg[tA]) + (tB > tA ? c.NT - c.kbeg[tB] : 0);
     if (nf > 5 || nb > 5) return false;
   }
-  return sf_trainc_lds_bytes(c, SF_TRC_TS, 2) <= (size_t)160 * 1024;
+  return sf_trainc_lds_bytes(c, sf_trc_ts(L.dev.T), 2) <= (size_t)160 * 1024;
 }
 
 int sf_trainc_grid(long B) {
@@ -922,16 +922,16 @@ int sf_trainc_grid(long B) {
   return (int)(chunks < cap ? chunks : cap);
 }
 
-template <int NI, int NT, int NG>
-static hipError_t c_launch(const SfTrcArgs& a, int grid, hipStream_t st) {
+template <int NI, int NT, int NG, int TS>
+static hipError_t c_launch_ts(const SfTrcArgs& a, int grid, hipStream_t st) {
   static SfAttrCache attr;
   int attr_dev;
   if (attr.need(attr_dev)) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_maf_trainc<SF_TRC_TS, NI, NT, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)k_maf_trainc<TS, NI, NT, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr.set(attr_dev);
   }
-  const size_t sh = sf_trainc_lds_bytes(a.c, SF_TRC_TS, NG);
+  const size_t sh = sf_trainc_lds_bytes(a.c, TS, NG);
 #ifdef SF_TRC_TRACE
   {
     static unsigned long long* d_tr = nullptr;
@@ -939,7 +939,7 @@ static hipError_t c_launch(const SfTrcArgs& a, int grid, hipStream_t st) {
     (void)hipMemsetAsync(d_tr, 0, 8 * 256 * 8, st);
     SfTrcArgs b = a;
     b.trace = d_tr;
-    hipLaunchKernelGGL((k_maf_trainc<SF_TRC_TS, NI, NT, NG>), dim3((unsigned)grid), dim3(256 * NG), sh, st, b);
+    hipLaunchKernelGGL((k_maf_trainc<TS, NI, NT, NG>), dim3((unsigned)grid), dim3(256 * NG), sh, st, b);
     (void)hipStreamSynchronize(st);
     static unsigned long long h[8 * 256];
     (void)hipMemcpy(h, d_tr, sizeof(h), hipMemcpyDeviceToHost);
@@ -956,8 +956,19 @@ static hipError_t c_launch(const SfTrcArgs& a, int grid, hipStream_t st) {
     return hipGetLastError();
   }
 #endif
-  hipLaunchKernelGGL((k_maf_trainc<SF_TRC_TS, NI, NT, NG>), dim3((unsigned)grid), dim3(256 * NG), sh, st, a);
+  hipLaunchKernelGGL((k_maf_trainc<TS, NI, NT, NG>), dim3((unsigned)grid), dim3(256 * NG), sh, st, a);
   return hipGetLastError();
+}
+// T <= 5: every transform's a1 / a2 tiles in registers (80 VGPRs of stash); T = 6 and T = 7..8 are instantiations of their own --
+// the reference's example CLI trains num_transforms = 6 (examples/sbi/scripts/train_model.py:56-57) -- whose longer stash the
+// compiler parks partly in scratch: slower per transform than TS = 5, still the cooperative decomposition (no activation in HBM)
+template <int NI, int NT, int NG>
+static hipError_t c_launch(const SfTrcArgs& a, int grid, hipStream_t st) {
+  switch (sf_trc_ts(a.T)) {
+    case 5: return c_launch_ts<NI, NT, NG, 5>(a, grid, st);
+    case 6: return c_launch_ts<NI, NT, NG, 6>(a, grid, st);
+    default: return c_launch_ts<NI, NT, NG, 8>(a, grid, st);
+  }
 }
 
 template <int NG>

@@ -206,7 +206,9 @@ class HipFlow:
     def sample(self, x, S: int, lo=None, hi=None, seed: int = 0, max_attempts: Optional[int] = None,
                out: Optional[torch.Tensor] = None, return_counts: bool = False):
         """samples[M,S,D].  ``max_attempts`` None / 0: no ceiling -- a slot is retried while its galaxy still gets
-        draws accepted (sf_flow_sample); a positive value is a hard ceiling per slot, after which the slot is a NaN row."""
+        draws accepted (sf_flow_sample); a positive value is a hard ceiling per slot, after which the slot is a NaN row.
+        ``out``: float32 on the flow's device, or FLOAT64 -- on the device or in pinned host memory (a ``pin_memory`` CPU
+        tensor: the kernels then write the reference's host container directly, sf_flow_set_sample_output_f64)."""
         max_attempts = int(max_attempts or 0)
         self._dev()
         x = _f32c(x, self.device)
@@ -219,9 +221,20 @@ class HipFlow:
             out = torch.empty((M, S, self.spec.D), dtype=torch.float32, device=self.device)
         nd = torch.empty(M, dtype=torch.int32, device=self.device) if return_counts else None
         unfilled = C.c_int64(0)
-        _lib.check(self.lib.sf_flow_sample(self.handle, _ptr(x), M, S, _ptr(lo_t), _ptr(hi_t),
-                                           C.c_uint64(seed & (2 ** 64 - 1)), max_attempts, _ptr(out), _ptr(nd),
-                                           C.byref(unfilled), _stream(self.device)))
+        f64 = out.dtype == torch.float64
+        if out.shape != (M, S, self.spec.D) or not out.is_contiguous() or out.dtype not in (torch.float32, torch.float64):
+            raise ValueError("out must be a contiguous (M,S,D) float32 / float64 tensor")
+        if out.device.type != "cuda" and not (out.device.type == "cpu" and out.is_pinned()):
+            raise ValueError("out must live on the flow's device or in pinned host memory")
+        if f64:
+            _lib.check(self.lib.sf_flow_set_sample_output_f64(self.handle, 1))
+        try:
+            _lib.check(self.lib.sf_flow_sample(self.handle, _ptr(x), M, S, _ptr(lo_t), _ptr(hi_t),
+                                               C.c_uint64(seed & (2 ** 64 - 1)), max_attempts, _ptr(out), _ptr(nd),
+                                               C.byref(unfilled), _stream(self.device)))
+        finally:
+            if f64:
+                self.lib.sf_flow_set_sample_output_f64(self.handle, 0)
         self.last_unfilled = int(unfilled.value)
         st4 = (C.c_float * 4)()
         _lib.check(self.lib.sf_flow_sample_stats(self.handle, st4))
@@ -249,6 +262,12 @@ class HipFlow:
                                                  C.byref(unfilled), _stream(self.device)))
         self.last_unfilled = int(unfilled.value)
         return self.last_unfilled
+
+    def supports_f64_out(self) -> bool:
+        """Whether sample() takes a float64 ``out`` (device or pinned host): every flow but the one-parameter / autoregressive NSF."""
+        ok = self.lib.sf_flow_set_sample_output_f64(self.handle, 1) == 0
+        self.lib.sf_flow_set_sample_output_f64(self.handle, 0)
+        return ok
 
     def set_sample_time_limit(self, seconds: Optional[float]) -> None:
         """Wall-clock ceiling of later sample() / sample_slots() calls (None / 0 = none); see sf_flow_set_sample_time_limit."""

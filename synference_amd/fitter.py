@@ -626,8 +626,22 @@ class SBI_Fitter:
             seed = posteriors._next_seed(None)
         bounds = np.linspace(0, len(X), n_chunks + 1).astype(int)
         # (uninitialised: every chunk either fills its rows or, on failure, sets them to NaN below)
-        from .hostio import result_array
-        samples = result_array((len(X), num_samples, len(self.fitted_parameter_names)))
+        from .hostio import pinned_result, result_array
+        # ONE catalogue call on a one-member flow posterior: the sampler writes the float64 host container itself (pinned memory
+        # mapped into the device's address space; sf_flow_set_sample_output_f64) -- the draws cross PCIe while the kernel runs
+        # instead of in a copy + widening pass afterwards (cfg2 catalogue: 2.9 ms against 2.6 + 1.0)
+        direct = None
+        if n_chunks == 1 and not log_times and os.environ.get("SF_API_DIRECT", "1") != "0":
+            members = getattr(posteriors, "posteriors", [posteriors])
+            try:
+                if len(members) == 1 and members[0].posterior_estimator.flow.supports_f64_out():
+                    direct = pinned_result((len(X), num_samples, len(self.fitted_parameter_names)))
+            except AttributeError:
+                direct = None
+        if direct is not None:
+            pin_t, samples = direct
+        else:
+            samples = result_array((len(X), num_samples, len(self.fitted_parameter_names)))
         times = []
         pending = []
         for ci in range(n_chunks):
@@ -639,6 +653,12 @@ class SBI_Fitter:
                 # the reference's per-object timeout (sbi_runner.py:6358) becomes the wall-clock ceiling of the chunk
                 tmo = float(timeout_seconds_per_test) * (b - a) if timeout_seconds_per_test else None
                 # (same seed, rows keyed by their position: the draws do not depend on the chunking)
+                if direct is not None:
+                    posteriors.sample_catalogue(torch.as_tensor(X[a:b]), num_samples, seed, timeout_seconds=tmo, row_offset=a,
+                                                out=pin_t[a:b])
+                    torch.cuda.synchronize()     # the host array is complete when the stream is
+                    times.extend([(time.time() - t0) / (b - a)] * (b - a))
+                    continue
                 s = posteriors.sample_catalogue(torch.as_tensor(X[a:b]), num_samples, seed, timeout_seconds=tmo, row_offset=a)
                 # D2H in float32 (half the PCIe bytes of a device-side .double()) through a ring of pinned staging buffers
                 # on a copy stream, widened into the reference's float64 container by a thread pool while the next piece

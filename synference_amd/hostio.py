@@ -72,6 +72,42 @@ def result_array(shape) -> np.ndarray:
         return arr
 
 
+# ---- pinned result buffers: the sampler writes the reference's float64 host container itself (sf_flow_set_sample_output_f64) ----
+# hipHostMalloc of 80 MB costs milliseconds, so the pinned buffers are recycled by the same rule as the plain ones: a buffer
+# is handed out again only when neither the array nor a view of it is referenced outside this list.
+_pinned: "list[tuple[torch.Tensor, np.ndarray]]" = []
+_PINNED_MAX_BYTES = 1 << 30      # larger results (configs[4]: 4 GB) take the staged copy instead of pinning that much host memory
+
+
+def pinned_result(shape):
+    """(pinned float64 CPU tensor, numpy view of it) of ``shape``, or None when the result is too large / too small to be worth
+    pinning or the pool is switched off (``SF_HOSTIO_PINNED=0``).  The numpy array keeps the tensor's storage alive."""
+    import sys
+    shape = tuple(int(v) for v in shape)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * 8
+    if os.environ.get("SF_HOSTIO_PINNED", "1") == "0" or nbytes < (1 << 20) or nbytes > _PINNED_MAX_BYTES or not torch.cuda.is_available():
+        return None
+    with _lock:
+        for i in range(len(_pinned)):
+            t, arr = _pinned[i]
+            # references to the array: the tuple in the list + getrefcount's argument (+ this loop's `arr`) = 3 when free
+            if t.numel() * 8 == nbytes and sys.getrefcount(arr) == 3:
+                _pinned.pop(i)
+                t = t.view(shape)
+                arr = t.numpy()
+                _pinned.append((t, arr))
+                return t, arr
+        try:
+            t = torch.empty(shape, dtype=torch.float64, pin_memory=True)
+        except RuntimeError:
+            return None
+        arr = t.numpy()
+        _pinned.append((t, arr))
+        while len(_pinned) > _RESULTS_MAX or sum(p[0].numel() * 8 for p in _pinned) > 2 * _PINNED_MAX_BYTES:
+            _pinned.pop(0)
+        return t, arr
+
+
 class PendingCopy:
     """Hand-over in flight (``to_host_f64(..., wait=False)``): ``result()`` blocks until the host array is complete."""
 

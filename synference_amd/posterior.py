@@ -95,8 +95,10 @@ class FlowPosterior:
 
     # ---- catalogue-wide fast paths ----------------------------------------------------------
     def sample_catalogue(self, X, num_samples: int, seed: Optional[int] = None, return_counts=False,
-                         timeout_seconds: Optional[float] = None, row_offset: int = 0):
+                         timeout_seconds: Optional[float] = None, row_offset: int = 0, out: Optional[torch.Tensor] = None):
         """(N,S,D) float32 device tensor of accepted draws for every row of X (NaN rows on failure).
+        ``out``: optional result tensor to fill instead -- float32 on the device, or float64 on the device / in pinned host
+        memory (HipFlow.sample: the kernels then write the host container of SBI_Fitter.sample_posterior directly).
         ``timeout_seconds``: wall-clock ceiling of the call (the reference's ``timeout_seconds_per_test`` x objects).
         ``row_offset``: X holds rows [row_offset, row_offset + N) of a larger catalogue (a rank's shard): with the same
         seed the draws are those of a single call over the whole catalogue, whatever the chunking or the sharding."""
@@ -110,7 +112,10 @@ class FlowPosterior:
         # runs its first launch and reports NaN rows instead of raising)
         import time as _time
         t_call = _time.monotonic()
-        out = torch.empty((N, S, self.spec.D), dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty((N, S, self.spec.D), dtype=torch.float32, device=self.device)
+        elif tuple(out.shape) != (N, S, self.spec.D):
+            raise ValueError("out must be (N, S, D)")
         counts = torch.empty(N, dtype=torch.int32, device=self.device)
         rows_per = max(1, _MAX_SLOTS_PER_CALL // max(S, 1))
         # keep the per-galaxy context table of a chunk within 2 GiB so that it is always built
@@ -273,12 +278,14 @@ class EnsemblePosterior:
         return (self._seed * 0x9E3779B97F4A7C15 + 0x51ED27 + self._calls) & (2 ** 63 - 1)
 
     def sample_catalogue(self, X, num_samples: int, seed: Optional[int] = None, timeout_seconds: Optional[float] = None,
-                         row_offset: int = 0):
+                         row_offset: int = 0, out: Optional[torch.Tensor] = None):
         """Per row: multinomial(weights, S) split; member e fills positions [cum_{e-1}, cum_e).  ``row_offset``: X holds
         rows [row_offset, ...) of a larger catalogue (see FlowPosterior.sample_catalogue)."""
         if len(self.posteriors) == 1:
             return self.posteriors[0].sample_catalogue(X, num_samples, self._next_seed(seed), timeout_seconds=timeout_seconds,
-                                                       row_offset=row_offset)
+                                                       row_offset=row_offset, out=out)
+        if out is not None:
+            raise ValueError("a caller-provided result tensor is only taken by a one-member posterior")
         for p in self.posteriors:
             p.posterior_estimator.flow.set_sample_time_limit(timeout_seconds)
         p0 = self.posteriors[0]

@@ -292,6 +292,15 @@ def train_flow(estimator: FlowEstimator, theta: torch.Tensor, x: torch.Tensor, *
     fused_epoch = can_fuse and (world == 1 or comm is not None)
     fused_rows = not fused_epoch and not embedded and hasattr(ops, "loss_grad_rows") and plain_f32
 
+    if isinstance(ops, HipTrainOps) and rank == 0:
+        try:    # shape cliffs are not silent: the generic kernels run at well under half the cooperative kernels' rate
+            if ops.flow.train_path(bs_tr) == 0:
+                sp = estimator.spec
+                logger.warning(f"{sp.kind} D={sp.D} C={sp.C} H={sp.H} T={sp.T} K={sp.K}: this shape trains on the generic kernels "
+                               "(k_maf_train / k_nsf_train, sf_flow_train_path = 0), not on the cooperative 16-row kernels "
+                               "(MAF: two blocks, D <= 8, aligned degree groups; NSF: two blocks, D 2..12, H <= 80, 3K - 1 <= 32)")
+        except Exception:
+            pass
     best_val, since, best_state = float("inf"), 0, None
     train_log, val_log, epoch = [], [], 0
     ckpt = f"{save_dir}checkpoint_posterior.pt" if save_dir else None

@@ -25,6 +25,10 @@ CASES = {
     "maf_d2_span": ("maf", 2, 4, 40, 2, 10),   # one group of 40 units over 3 tiles
     "maf_d4": ("maf", 4, 6, 40, 3, 10),        # 3 groups of 13-14, one per tile: the unrolled sampler kernel with DD = 4
     "maf_d3": ("maf", 3, 5, 26, 3, 10),        # 2 groups of 13, one per tile: DD = 3
+    # the reference's example CLI trains 6 transforms (examples/sbi/scripts/train_model.py:56-57): the TS = 6 / TS = 8 instantiations
+    # of the cooperative MAF training kernel (the a1 / a2 stash of transforms beyond five is partly in scratch)
+    "maf_t6": ("maf", 5, 10, 50, 6, 10),
+    "maf_t8": ("maf", 4, 6, 40, 8, 10),
     "maf_nb1": ("maf", 4, 6, 48, 2, 10, dict(NB=1)),   # one hidden block, 3 full tiles: the NB = 1 instantiations of the 16-row sampler
     # cooperative NSF training kernel (sf_nsfc.hip) beyond cfg3: 8 spline-head tiles (K = 10: sbi's default), three hidden
     # tiles with a partial last one, 6 parameters; and the smallest coupling (one identity dimension, one input tile)

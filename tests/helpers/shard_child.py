@@ -45,6 +45,7 @@ def build(kind):
 def run(f, x, theta):
     X, Y = x[2000:2101], theta[2000:2101]            # 101 rows: the blocks of two ranks differ in length
     s = f.sample_posterior(X, num_samples=64, seed=17)     # under a process group: rank 0 the whole array, others their block
+    rows = getattr(f, "last_shard_rows", (0, len(X)))
     s_all = f.sample_posterior(X, num_samples=64, seed=17, gather="all") if dist.is_initialized() else s
     lp = f.log_prob(X, Y, num_rejection_samples=512)
     import pandas as pd
@@ -56,7 +57,7 @@ def run(f, x, theta):
                            device_quantiles=False)     # 3 rows over 2 ranks: one rank's block is a single row
     return {"samples": s, "samples_all": s_all, "lp": lp, "table": tab.to_numpy(float),
             "table_rs": tab2.to_numpy(float), "samples_rs": samp2, "table_hq": tab3.to_numpy(float),
-            "rows": getattr(f, "last_shard_rows", (0, len(X)))}
+            "rows": rows}
 
 
 def main():

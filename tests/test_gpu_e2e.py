@@ -217,6 +217,56 @@ def test_lampe_backend_fits_the_autoregressive_nsf(tmp_path):
     assert np.isfinite(np.asarray(lp)).all()
 
 
+@pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "maf_span6", "maf_wide"])
+def test_sampler_writes_the_float64_host_container_directly(name, monkeypatch):
+    """sf_flow_set_sample_output_f64: the sampling kernels widen every accepted draw in its store, into a float64 array on the
+    device or in PINNED HOST memory (the reference's container, sbi_runner.py:6436) -- same draws, bit for bit, as fp32 output
+    widened afterwards, NaN rows included; and SBI_Fitter.sample_posterior takes that path for a one-member posterior."""
+    import sys
+    sys.path.insert(0, __import__("os").path.dirname(__file__))
+    from cases import make_case
+    from synference_amd.engine import HipFlow
+    ospec, spec, flat, theta, x = make_case(name, B=40, spread=0.2)
+    f = HipFlow(spec, "cuda:0")
+    f.set_params(torch.as_tensor(flat))
+    assert f.supports_f64_out()
+    X = torch.as_tensor(x, dtype=torch.float32, device="cuda:0")
+    free = f.sample(X[:4], 300, seed=1).cpu().numpy().reshape(-1, spec.D)
+    lo, hi = np.quantile(free, 0.04, axis=0).astype(np.float32), np.quantile(free, 0.96, axis=0).astype(np.float32)
+    S = 333
+    ref = f.sample(X, S, lo, hi, seed=9).double().cpu()
+    d64 = torch.empty((40, S, spec.D), dtype=torch.float64, device="cuda:0")
+    f.sample(X, S, lo, hi, seed=9, out=d64)
+    h64 = torch.full((40, S, spec.D), -7.0, dtype=torch.float64).pin_memory()
+    f.sample(X, S, lo, hi, seed=9, out=h64)
+    torch.cuda.synchronize()
+    assert torch.equal(d64.cpu(), ref) and torch.equal(h64, ref)
+    # a hard attempt ceiling leaves NaN rows: written as float64 NaNs too
+    tight_hi = (lo + 0.02 * (hi - lo)).astype(np.float32)
+    r32 = f.sample(X, 64, lo, tight_hi, seed=3, max_attempts=4).double().cpu()
+    h2 = torch.zeros((40, 64, spec.D), dtype=torch.float64).pin_memory()
+    f.sample(X, 64, lo, tight_hi, seed=3, max_attempts=4, out=h2)
+    torch.cuda.synchronize()
+    assert torch.isnan(r32).any() and torch.equal(torch.nan_to_num(h2, nan=-1.0), torch.nan_to_num(r32, nan=-1.0))
+    with pytest.raises(ValueError):
+        f.sample(X, S, lo, hi, seed=9, out=torch.empty((40, S, spec.D), dtype=torch.float64))      # unpinned host memory
+
+
+def test_sample_posterior_direct_host_output_equals_the_staged_copy(fitted, monkeypatch):
+    f, post, stats, _ = fitted
+    from synference_amd.posterior import EnsemblePosterior
+    one = EnsemblePosterior([post.posteriors[0]], weights=[1.0])
+    X = f._X_test[:300]
+    a = f.sample_posterior(X, num_samples=500, seed=21, posteriors=one)            # direct: pinned float64 written by the kernels
+    monkeypatch.setenv("SF_API_DIRECT", "0")
+    b = f.sample_posterior(X, num_samples=500, seed=21, posteriors=one)            # fp32 on the device, copied + widened
+    assert a.dtype == np.float64 and a.shape == (300, 500, 5) and np.array_equal(a, b, equal_nan=True)
+    monkeypatch.delenv("SF_API_DIRECT")
+    keep = a.copy()
+    c = f.sample_posterior(X, num_samples=500, seed=22, posteriors=one)            # a held result is never recycled
+    assert np.array_equal(a, keep) and not np.array_equal(a, c)
+
+
 def test_native_host_handover_is_exact():
     """sf_copy_to_host_f64 (csrc/sf_hostio.hip): float64 host copy of device fp32, bit for bit, for sizes that do not divide into
     pieces or vector widths, a destination that is not 32-byte aligned, and a second call reusing the ring."""

@@ -40,6 +40,9 @@ BENCH_SHAPES = [
     ("maf_span6", 131072 + 37, None),
     ("maf_d4", 16384, None),
     ("maf_d4", 131072 + 37, None),
+    ("maf_t6", 16384, 2),              # T = 6 (the reference's example CLI): k_maf_trainc<6,1,4,2>
+    ("maf_t6", 2048 + 37, 1),
+    ("maf_t8", 16384 + 5, 2),          # T = 8: k_maf_trainc<8,1,3,2>
     ("nsf_cfg3", 16384, 3),            # bench --workload nsf_cfg3 `train`: k_nsf_trainc<4,6>, XCD replicas + f32 atomics
     ("nsf_cfg3", 65536 + 37, 3),       # several chunks per workgroup, ragged tail
     ("nsf_k10", 4096 + 5, 3),          # k_nsf_trainc<3,8>
