@@ -419,7 +419,7 @@ int sf_flow_train_path(const sf_flow* f, int64_t B, int want_dctx) {
   if (!f) return fail(SF_ERR_INVALID, "null handle");
   if (f->nsf1) return 4;   // MLP engine + scalar spline chain (sf_nsf1.hip)
   if (f->nsfar) return 5;  // thread-per-sample masked hyper-network (sf_nsfar.hip)
-  if (B > 0 && sf_trainc_eligible(f->L, want_dctx != 0)) return sf_trainc_groups((long)B);
+  if (B > 0 && sf_trainc_eligible(f->L, want_dctx != 0)) return sf_trainc_groups((long)B, &f->L.trc, f->L.dev.T);
   if (B > 0 && sf_nsfc_eligible(f->L, want_dctx != 0)) return 3;
   return 0;
 }

@@ -239,6 +239,36 @@ __device__ __forceinline__ void ar_mask_rows(float* x, const float* gate, int n,
   }
 }
 
+// bits[r] = lanes (samples) with x[r][lane] > 0, rows [0, n): two 32-bit words per row
+__device__ __forceinline__ void ar_sign_bits(const float* x, unsigned int* bits, int n, int lane, int wid = 0, int nwv = 1) {
+  for (int r0 = 8 * wid; r0 < n; r0 += 8 * nwv) {
+    float xv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xv[i] = x[(r0 + i) * RS + lane];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const unsigned long long b = __ballot(xv[i] > 0.f);
+      if (lane == 0) { bits[2 * (r0 + i)] = (unsigned int)b; bits[2 * (r0 + i) + 1] = (unsigned int)(b >> 32); }
+    }
+  }
+}
+// x[r][lane] <- x[r][lane] where bit `lane` of bits[r] is set
+__device__ __forceinline__ void ar_mask_bits(float* x, const unsigned int* bits, int n, int lane, int wid = 0, int nwv = 1) {
+  for (int r0 = 8 * wid; r0 < n; r0 += 8 * nwv) {
+    float xv[8];
+    unsigned int bw[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { xv[i] = x[(r0 + i) * RS + lane]; bw[i] = bits[2 * (r0 + i) + (lane >> 5)]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[(r0 + i) * RS + lane] = ((bw[i] >> (lane & 31)) & 1u) ? xv[i] : 0.f;
+  }
+}
+// the first hidden layer alone (the training sweep recomputes it where it needs it again: it is the cheap one, NIN4 inputs)
+__device__ __forceinline__ void ar_hidden0(const ArArgs& a, const float* __restrict__ tp, const float* E0, float* H1, int lane, int wid = 0,
+                                           int nwv = 1) {
+  ar_rows<true>(tp + a.o_L0t, a.Hp, tp + a.o_b0, 0, a.Hp, 0, [&](int, int) { return a.NIN4; }, E0, H1, a.Hp, lane, wid, nwv);
+}
+
 // both hidden layers of a transform from the inputs in E0 (rows [0, NIN4): u, context, zeros)
 __device__ __forceinline__ void ar_hidden(const ArArgs& a, const float* __restrict__ tp, const float* E0, float* H1, float* H2, int lane,
                                           int wid = 0, int nwv = 1) {
@@ -607,11 +637,18 @@ __global__ __launch_bounds__(64 * NWV) void k_ar_train(ArArgs a, const float* __
   float* H2 = H1 + a.Hp * RS;            // [Hp]
   float* QB0 = H2 + a.Hp * RS;           // [NWV][32] per wave: head outputs of ONE dimension, then their deltas; wave 0: the input deltas
   float* QB = QB0 + wid * 32 * RS;
-  float* DH = QB0 + NWV * 32 * RS;       // [Hp] deltas
-  float* GG = DH + a.Hp * RS;            // [D] dL/du at the transform's output
+  // TWO hidden buffers serve the backward sweep (round 5; three before: 102 KB for cfg1's shape, one workgroup per CU, and the
+  // reference's own lampe example -- 180 hidden units, examples/sbi/scripts/basic_model.py:31-41 -- did not fit at all):
+  //   head phase     H2 = last hidden layer (operand of the head's weight gradients), DH = its delta, accumulated in H1's rows
+  //                  (H1 is dead once H2 exists; the samples where it was positive are kept as BITS, two words per row);
+  //   second layer   H1 is RECOMPUTED into H2's rows (dead after it has gated DH): weight gradients DH x H1;
+  //   first layer    delta_h1 = L1m^T DH overwrites the recomputed H1, gated by the bits.
+  float* DH = H1;                        // (alias: see above)
+  float* GG = QB0 + NWV * 32 * RS;       // [D] dL/du at the transform's output
   float* DV = GG + a.D * RS;             // [D] what reaches the transform's input through the splines
   int* PERM = reinterpret_cast<int*>(DV + a.D * RS);   // [Hp] perm, [Hp] ptype: read per weight-gradient block
   int* PTYP = PERM + a.Hp;
+  unsigned int* M1 = reinterpret_cast<unsigned int*>(PTYP + a.Hp);   // [Hp][2] samples with H1 > 0
   for (int i = threadIdx.x; i < a.Hp; i += 64 * NWV) { PERM[i] = a.perm[i]; PTYP[i] = a.ptype[i]; }
   const long b = (long)blockIdx.x * 64 + lane;
   const bool valid = b < B;
@@ -667,7 +704,10 @@ __global__ __launch_bounds__(64 * NWV) void k_ar_train(ArArgs a, const float* __
     AR_TS(99);
     ar_hidden(a, tp, E0, H1, H2, lane, wid, NWV);
     AR_TS(100);
-    for (int p = wid; p < a.Hp; p += NWV) DH[p * RS + lane] = 0.f;
+    ar_sign_bits(H1, M1, a.Hp, lane, wid, NWV);   // (same rows per wave as the clearing below: no barrier between the two)
+    for (int r0 = 8 * wid; r0 < a.Hp; r0 += 8 * NWV)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) DH[(r0 + i) * RS + lane] = 0.f;
     __syncthreads();
     AR_TS(101);
     // ---- head + splines, dimension by dimension (wave wid: dimensions wid, wid + NWV, ...)
@@ -721,6 +761,9 @@ __global__ __launch_bounds__(64 * NWV) void k_ar_train(ArArgs a, const float* __
     __syncthreads();
     ar_mask_rows(DH, H2, a.Hp, lane, wid, NWV);   // DH <- DH where H2 > 0
     __syncthreads();
+    float* H1r = H2;                              // H2 is dead: the first hidden layer once more, into its rows
+    ar_hidden0(a, tp, E0, H1r, lane, wid, NWV);
+    __syncthreads();
     AR_TS(130);
     for (int o0 = 16 * wid; o0 < a.Hp; o0 += 16 * NWV) {
       const int kend = (int)a.tile_kend[o0 >> 4];
@@ -728,7 +771,7 @@ __global__ __launch_bounds__(64 * NWV) void k_ar_train(ArArgs a, const float* __
 #pragma unroll
       for (int r = 0; r < 4; ++r) { ol[r] = PERM[o0 + 4 * (lane >> 4) + r]; oty[r] = PTYP[o0 + 4 * (lane >> 4) + r]; }
       for (int k0 = 0; k0 < kend; k0 += 16) {
-        const ar_f32x4 g4 = ar_dw16(DH, o0, H1, k0, lane);
+        const ar_f32x4 g4 = ar_dw16(DH, o0, H1r, k0, lane);
         const int k = k0 + (lane & 15), kl = PERM[k], kty = PTYP[k];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -741,7 +784,7 @@ __global__ __launch_bounds__(64 * NWV) void k_ar_train(ArArgs a, const float* __
           if (ol[r] >= 0) unsafeAtomicAdd(gt + a.l_b1 + ol[r], b4[r]);
       }
     }
-    __syncthreads();   // (H2 is overwritten next)
+    __syncthreads();   // (the recomputed H1 is overwritten next)
     AR_TS(131);
     // delta_h1[k] = sum_{o: type(o) >= type(k)} W1[o][k] delta_h2[o]
     for (int p0 = 32 * wid; p0 < a.Hp; p0 += 32 * NWV) {
@@ -750,7 +793,7 @@ __global__ __launch_bounds__(64 * NWV) void k_ar_train(ArArgs a, const float* __
     }
     __syncthreads();
     AR_TS(132);
-    ar_mask_rows(H2, H1, a.Hp, lane, wid, NWV);   // H2 (delta_h1) <- where H1 > 0
+    ar_mask_bits(H2, M1, a.Hp, lane, wid, NWV);   // H2 (delta_h1) <- where H1 > 0 (the bits taken before DH took its rows)
     __syncthreads();
     AR_TS(133);
     // ---- first hidden layer: weight gradients, and what reaches the inputs
@@ -876,7 +919,7 @@ int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err) {
   n->o_L2m = (int)o; o += (long)D * ARQ * Hp;   // the head transposed: row (d, slot), column k
   n->t_stride = (o + 63) / 64 * 64;
   if (sf_nsfar_lds_bytes(*n, 3, 1) > (size_t)160 * 1024 - 1024) {
-    err = "autoregressive NSF: (3 D + C + 3 Hp + 32) x 260 bytes of LDS per wave exceed the 160 KB of a CU (Hp = H with every type padded to a multiple of 8, in all a multiple of 16)";
+    err = "autoregressive NSF: (3 D + C + 2 Hp + 32) x 260 bytes of LDS per wave exceed the 160 KB of a CU (Hp = H with every type padded to a multiple of 8, in all a multiple of 16)";
     delete n;
     return SF_ERR_INVALID;
   }
@@ -960,8 +1003,11 @@ static int ar_ensure(SfNsfAr* n, std::string& err) {
 
 size_t sf_nsfar_lds_bytes(const SfNsfAr& n, int hidden_buffers, int waves) {
   // inputs (padded to whole 16-row tiles), hidden buffers, 32 rows of one dimension's head per wave, V or GG + DV
-  return (size_t)((n.D + n.C + 15) / 16 * 16 + hidden_buffers * n.Hp + 32 * waves + 2 * n.D) * RS * sizeof(float) +
-         (hidden_buffers == 3 ? (size_t)2 * n.Hp * sizeof(int) : 0);
+  // (hidden_buffers == 3 names the TRAINING kernel: it runs on two hidden buffers too since round 5, plus the row tables and the
+  //  sign bits of the first hidden layer)
+  const int hb = hidden_buffers == 3 ? 2 : hidden_buffers;
+  return (size_t)((n.D + n.C + 15) / 16 * 16 + hb * n.Hp + 32 * waves + 2 * n.D) * RS * sizeof(float) +
+         (hidden_buffers == 3 ? (size_t)4 * n.Hp * sizeof(int) : 0);
 }
 // waves per 64 samples of the density / training kernels: four (tile pairs and dimensions dealt round robin) when the LDS takes it
 static int ar_waves(const SfNsfAr& n, int hidden_buffers) {

@@ -395,7 +395,7 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
 #undef SF_TRY_C
       f->trainc_ready = true;
     }
-    const int grid = coop_maf ? sf_trainc_grid(B) : sf_nsfc_grid(B, L.nsc.NT);
+    const int grid = coop_maf ? sf_trainc_grid(B, &L.trc, L.dev.T) : sf_nsfc_grid(B, L.nsc.NT);
     // Gradient accumulation (sf_fixacc.h): per-workgroup partials + gather while they are few, above that 2^-40 fixed-point
     // contributions added with int64 atomics into one zeroed replica per XCD (L2-resident, order independent).  The gather
     // needs the position -> parameter table (d_gsrcC); SF_GRAD_ACC=partial | fix forces one form.
@@ -480,7 +480,7 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
     a.D = L.dev.D; a.C = L.dev.C; a.T = L.dev.T; a.scale_fn = L.dev.scale_fn;
     a.eps = L.dev.eps; a.logdet0 = L.dev.logdet0;
     a.c_pscale = L.dev.c_pscale; a.c_pshift = L.dev.c_pshift; a.c_tdim = L.dev.c_tdim; a.c_xmean = L.dev.c_xmean; a.c_xstd = L.dev.c_xstd;
-    a.theta = theta; a.x = x; a.idx = idx; a.wts = weights; a.B = B; a.n_chunks = (B + 32L * sf_trainc_groups(B) - 1) / (32L * sf_trainc_groups(B)); a.w = grad_scale;
+    a.theta = theta; a.x = x; a.idx = idx; a.wts = weights; a.B = B; a.n_chunks = (B + 32L * sf_trainc_groups(B, &L.trc, L.dev.T) - 1) / (32L * sf_trainc_groups(B, &L.trc, L.dev.T)); a.w = grad_scale;
     a.loss = loss; a.loss_sum = loss_sum; a.dctx = dctx; a.loss_mask = 0;
     if (loss_sum && f->d_losspart) { a.loss_sum = f->d_losspart; a.loss_mask = SF_LOSS_PARTS - 1; f->losspart_used = true; }
     a.gpart = f->d_gpartC; a.gpart_stride = (long)L.n_gradC; a.fix = use_fix ? f->d_gfixC : nullptr;

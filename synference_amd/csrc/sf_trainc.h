@@ -56,9 +56,9 @@ struct SfTrcArgs {
 #endif
 
 size_t sf_trainc_lds_bytes(const SfTrcDev& c, int TS, int NG);
-int sf_trainc_groups(long B);
+int sf_trainc_groups(long B, const SfTrcDev* c = nullptr, int T = 0);
 bool sf_trainc_eligible(const SfLayout& L, bool want_dctx);
-int sf_trainc_grid(long B);
+int sf_trainc_grid(long B, const SfTrcDev* c = nullptr, int T = 0);
 bool sf_trainc_fix(int grid, long n_gradC);
 hipError_t sf_launch_maf_trainc(const SfTrcArgs& a, int grid, hipStream_t st);
 hipError_t sf_launch_gather_c(const float* gpart, long stride, int nwg, const int32_t* gdst, float* grad, long n, hipStream_t st);

@@ -27,6 +27,12 @@
 #include "sf_internal.h"
 #include "sf_trainc.h"
 
+// One translation unit per stash depth (Makefile: -DSF_TRC_TU=5 | 6 | 8): sixteen instantiations of the kernel each -- all 48 in
+// one unit compile for ten minutes on one core.  Unit 5 also holds the host side and the gather kernels.
+#ifndef SF_TRC_TU
+#define SF_TRC_TU 5
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
@@ -741,6 +747,7 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
   }
 }
 
+#if SF_TRC_TU == 5
 // sum of the workgroups' gradient partials in a fixed order: block = 64 parameters x 16 groups of partials (1024 threads);
 // a thread has up to eight of its group's loads in flight (the kernel is a chain of L2 / HBM round trips over 33 MB at
 // batch 16 384: 15 us with 64 partials per thread four at a time, a third of that with 16 per thread eight at a time)
@@ -861,7 +868,9 @@ size_t sf_trainc_lds_bytes(const SfTrcDev& c, int TS, int NG) {
 // 16 384 the flow kernel alone is faster with 4-wave workgroups, two per CU (67.6 us against 73.4: two independent
 // workgroups overlap better than two groups that meet at every barrier), but the 512 partials cost the gather kernel more
 // than that (step 107 us against 97): the step decides.  SF_TRC_NG=1|2 overrides.
-int sf_trainc_groups(long B) {
+int sf_trainc_groups(long B, const SfTrcDev* c, int T) {
+  // (a deep stash -- T = 7, 8 with four hidden tiles -- leaves LDS for one group of four waves only)
+  if (c && sf_trainc_lds_bytes(*c, sf_trc_ts(T), 2) > (size_t)160 * 1024) return 1;
   static int forced = -1;
   if (forced < 0) { const char* e = std::getenv("SF_TRC_NG"); forced = e ? std::atoi(e) : 0; }
   if (forced == 1 || forced == 2) return forced;
@@ -905,10 +914,10 @@ bool sf_trainc_eligible(const SfLayout& L, bool want_dctx) {
     const int nb = (c.NT - c.kbeg[tA]) + (tB > tA ? c.NT - c.kbeg[tB] : 0);
     if (nf > 5 || nb > 5) return false;
   }
-  return sf_trainc_lds_bytes(c, sf_trc_ts(L.dev.T), 2) <= (size_t)160 * 1024;
+  return sf_trainc_lds_bytes(c, sf_trc_ts(L.dev.T), 1) <= (size_t)160 * 1024;
 }
 
-int sf_trainc_grid(long B) {
+int sf_trainc_grid(long B, const SfTrcDev* c, int T) {
   static int cus = 0;
   if (!cus) {
     int dev = 0;
@@ -916,11 +925,13 @@ int sf_trainc_grid(long B) {
     cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
               ? pr.multiProcessorCount : 256;
   }
-  const int ng = sf_trainc_groups(B);
+  const int ng = sf_trainc_groups(B, c, T);
   const long per = 32L * ng, chunks = (B + per - 1) / per;
   const long cap = (long)cus * (ng == 1 ? 2 : 1);
   return (int)(chunks < cap ? chunks : cap);
 }
+
+#endif  // SF_TRC_TU == 5
 
 template <int NI, int NT, int NG, int TS>
 static hipError_t c_launch_ts(const SfTrcArgs& a, int grid, hipStream_t st) {
@@ -959,36 +970,42 @@ static hipError_t c_launch_ts(const SfTrcArgs& a, int grid, hipStream_t st) {
   hipLaunchKernelGGL((k_maf_trainc<TS, NI, NT, NG>), dim3((unsigned)grid), dim3(256 * NG), sh, st, a);
   return hipGetLastError();
 }
-// T <= 5: every transform's a1 / a2 tiles in registers (80 VGPRs of stash); T = 6 and T = 7..8 are instantiations of their own --
-// the reference's example CLI trains num_transforms = 6 (examples/sbi/scripts/train_model.py:56-57) -- whose longer stash the
-// compiler parks partly in scratch: slower per transform than TS = 5, still the cooperative decomposition (no activation in HBM)
-template <int NI, int NT, int NG>
-static hipError_t c_launch(const SfTrcArgs& a, int grid, hipStream_t st) {
-  switch (sf_trc_ts(a.T)) {
-    case 5: return c_launch_ts<NI, NT, NG, 5>(a, grid, st);
-    case 6: return c_launch_ts<NI, NT, NG, 6>(a, grid, st);
-    default: return c_launch_ts<NI, NT, NG, 8>(a, grid, st);
-  }
-}
-
 template <int NG>
 static hipError_t c_dispatch(const SfTrcArgs& a, int grid, hipStream_t st) {
   const int key = a.c.NI * 10 + a.c.NT;
   switch (key) {
-    case 11: return c_launch<1, 1, NG>(a, grid, st);
-    case 12: return c_launch<1, 2, NG>(a, grid, st);
-    case 13: return c_launch<1, 3, NG>(a, grid, st);
-    case 14: return c_launch<1, 4, NG>(a, grid, st);
-    case 21: return c_launch<2, 1, NG>(a, grid, st);
-    case 22: return c_launch<2, 2, NG>(a, grid, st);
-    case 23: return c_launch<2, 3, NG>(a, grid, st);
-    case 24: return c_launch<2, 4, NG>(a, grid, st);
+    case 11: return c_launch_ts<1, 1, NG, SF_TRC_TU>(a, grid, st);
+    case 12: return c_launch_ts<1, 2, NG, SF_TRC_TU>(a, grid, st);
+    case 13: return c_launch_ts<1, 3, NG, SF_TRC_TU>(a, grid, st);
+    case 14: return c_launch_ts<1, 4, NG, SF_TRC_TU>(a, grid, st);
+    case 21: return c_launch_ts<2, 1, NG, SF_TRC_TU>(a, grid, st);
+    case 22: return c_launch_ts<2, 2, NG, SF_TRC_TU>(a, grid, st);
+    case 23: return c_launch_ts<2, 3, NG, SF_TRC_TU>(a, grid, st);
+    case 24: return c_launch_ts<2, 4, NG, SF_TRC_TU>(a, grid, st);
   }
   return hipErrorInvalidValue;
 }
+#define SF_TRC_CAT2(a, b) a##b
+#define SF_TRC_CAT(a, b) SF_TRC_CAT2(a, b)
+// this unit's launcher: sf_trainc_launch_ts5 / _ts6 / _ts8
+hipError_t SF_TRC_CAT(sf_trainc_launch_ts, SF_TRC_TU)(const SfTrcArgs& a, int grid, int ng, hipStream_t st) {
+  return ng == 1 ? c_dispatch<1>(a, grid, st) : c_dispatch<2>(a, grid, st);
+}
 
+#if SF_TRC_TU == 5
+hipError_t sf_trainc_launch_ts6(const SfTrcArgs& a, int grid, int ng, hipStream_t st);
+hipError_t sf_trainc_launch_ts8(const SfTrcArgs& a, int grid, int ng, hipStream_t st);
+// T <= 5: every transform's a1 / a2 tiles in registers (80 VGPRs of stash); T = 6 and T = 7..8 are instantiations of their own --
+// the reference's example CLI trains num_transforms = 6 (examples/sbi/scripts/train_model.py:56-57) -- whose longer stash the
+// compiler parks partly in scratch: same cooperative decomposition (no activation in HBM), measured 0.173 of the fp32 roof at
+// T = 6 and batch 16 384 (86.9 us; the generic kernel: 187.5 us)
 hipError_t sf_launch_maf_trainc(const SfTrcArgs& a, int grid, hipStream_t st) {
-  return sf_trainc_groups(a.B) == 1 ? c_dispatch<1>(a, grid, st) : c_dispatch<2>(a, grid, st);
+  const int ng = sf_trainc_groups(a.B, &a.c, a.T);
+  switch (sf_trc_ts(a.T)) {
+    case 5: return sf_trainc_launch_ts5(a, grid, ng, st);
+    case 6: return sf_trainc_launch_ts6(a, grid, ng, st);
+    default: return sf_trainc_launch_ts8(a, grid, ng, st);
+  }
 }
 
 long sf_gather_c2_blocks(long stride, long n_zero) { return (stride + 63) / 64 + (n_zero + 255) / 256; }
@@ -1008,3 +1025,4 @@ hipError_t sf_launch_gather_c(const float* gpart, long stride, int nwg, const in
   hipLaunchKernelGGL(k_gather_c, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, st, gpart, stride, nwg, gdst, grad, n);
   return hipGetLastError();
 }
+#endif  // SF_TRC_TU == 5

@@ -45,6 +45,9 @@ CASES = {
     "nsfar_small": ("nsf_ar", 3, 4, 17, 2, 5, dict(tail_bound=5.0)),
     "nsfar_d1": ("nsf_ar", 1, 6, 16, 3, 8, dict(tail_bound=5.0)),
     "nsfar_wide": ("nsf_ar", 8, 20, 64, 3, 8, dict(tail_bound=5.0, ar_slope=1e-2)),
+    # the widest member of the reference's own lampe example (examples/sbi/scripts/basic_model.py:31-41: hidden_features 180): seven
+    # types of 25-26 units padded to 32 rows each; fits since the training sweep runs on two hidden buffers
+    "nsfar_h180": ("nsf_ar", 7, 12, 180, 2, 8, dict(tail_bound=5.0)),
 }
 
 

@@ -217,6 +217,31 @@ def test_lampe_backend_fits_the_autoregressive_nsf(tmp_path):
     assert np.isfinite(np.asarray(lp)).all()
 
 
+def test_lampe_reference_example_ensemble_fits(tmp_path):
+    """The reference's own backend="lampe" example (examples/sbi/scripts/basic_model.py:31-41): an ensemble of three NSFs with
+    hidden_features [180, 150, 120] and num_transforms [16, 10, 6] -- its defining arguments verbatim, the run bounded by
+    max_num_epochs.  Round 4 refused the 180-unit member (three hidden buffers of LDS); the training sweep now runs on two."""
+    from synference_amd import SBI_Fitter
+    from synference_amd.synthetic import make_catalogue
+    x, theta, names = make_catalogue(3000, 12, 7, seed=6)
+    f = SBI_Fitter("basic", names, [f"F{i}" for i in range(12)], feature_array=x, parameter_array=theta)
+    post, stats = f.run_single_sbi(n_nets=3, backend="lampe", engine="NPE", name_append="_ensemble_lampe_nsf", stop_after_epochs=15,
+                                   hidden_features=[180, 150, 120], learning_rate=0.0004, num_transforms=[16, 10, 6], model_type="nsf",
+                                   max_num_epochs=3, training_batch_size=256, out_dir=str(tmp_path), verbose=False, plot=False,
+                                   evaluate_model=False, random_seed=2)
+    assert len(post.posteriors) == 3 and len(stats) == 3
+    shapes = [(p.spec.kind, p.spec.H, p.spec.T, p.spec.K) for p in post.posteriors]
+    assert shapes == [("nsf_ar", 180, 16, 8), ("nsf_ar", 150, 10, 8), ("nsf_ar", 120, 6, 8)]
+    for s in stats:
+        assert np.isfinite(s["training_loss"]).all() and s["training_loss"][-1] < s["training_loss"][0]
+    s = f.sample_posterior(f._X_test[:6], num_samples=200, seed=3)
+    lo, hi = theta.min(0), theta.max(0)
+    assert s.shape == (6, 200, 7) and np.isfinite(s).all() and (s >= lo - 1e-6).all() and (s <= hi + 1e-6).all()
+    lp = f.log_prob(f._X_test[:6], f._y_test[:6], norm_posterior=False)
+    assert np.isfinite(np.asarray(lp)).all()
+    assert (tmp_path / "basic" / "basic__ensemble_lampe_nsf_posterior.pkl").exists()
+
+
 @pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "maf_span6", "maf_wide"])
 def test_sampler_writes_the_float64_host_container_directly(name, monkeypatch):
     """sf_flow_set_sample_output_f64: the sampling kernels widen every accepted draw in its store, into a float64 array on the
