@@ -660,7 +660,9 @@ static int sample_persistent(sf_flow* f, const float* x, int64_t M, int64_t S, c
         static int env_run = -1;  // developer knob: SF_DENSE_RUN=<draws> (0 = the kernel's tile: 16 / 32)
         if (env_run < 0) { const char* e = std::getenv("SF_DENSE_RUN"); env_run = e ? std::atoi(e) : 0; }
         uint32_t run = env_run > 0 ? (uint32_t)env_run : (fast16 ? 16u : 32u);
-        if (S % (int64_t)run != 0) run = 1;
+        // (S = 1000 does not divide into tiles of 16 / 32: the largest power of two that divides S -- 8 -- still gives every
+        //  tile runs of consecutive draws of few galaxies; round 4 fell back to draw-by-draw order there)
+        while (run > 1 && S % (int64_t)run != 0) run >>= 1;
         a.dense_run = run;
       }
       a.list_mul = 0; a.list_log2 = 0;

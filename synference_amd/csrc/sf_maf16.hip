@@ -1181,14 +1181,13 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
         me = wi - (int)(e << lgA);
         if (TPW == 2) __syncthreads();  // the four words are rewritten for the other tile
       }
-      // A tile of first attempts is 16 CONSECUTIVE slots (one run of a galaxy's draws: dense_run): its accepted rows are one
-      // contiguous piece of the output, so the 16 x D block is handed to the lanes LINEARLY (lane L stores element L, L + 64,
-      // ...: whole 64-byte segments per wave-instruction instead of five 4-byte pieces per draw from two row groups -- half the
-      // write traffic in HBM, and a third of the PCIe packets when `out` is the host's float64 array).  The value of element
-      // (draw se, column c) sits in lane se + 16 (p >> 2), register p & 3, p = the column's physical slot.
-      const uint32_t slot0 = (uint32_t)__shfl((int)slot, 0, 64);
-      const bool lin = lgA == 0 && __ballot(!entry_ok || slot == slot0 + (uint32_t)s) == ~0ull;
-      if (lin) {
+      // One attempt per entry (every dense iteration): the tile's 16 x D block of draws is handed to the lanes LINEARLY -- lane L
+      // stores element L, L + 64, ... = (draw se = e / D, column c = e % D) at out[slot(se) D + c] -- so that a wave-instruction
+      // covers the rows of consecutive draws side by side (the dense order deals RUNS of consecutive draws of a galaxy:
+      // dense_run) instead of five 4-byte pieces per draw from two row groups: whole 64-byte segments in HBM, and fewer PCIe
+      // packets when `out` is the host's float64 array.  The value sits in lane se + 16 (p >> 2), register p & 3, p = the
+      // column's physical slot; the slot id in lane se.
+      if (lgA == 0) {
         const int Dn = DD > 0 ? DD : m.D;
         const int* c2s = reinterpret_cast<const int*>(ecb) + 80;
         for (int e0 = 0; e0 < 16 * Dn; e0 += 64) {
@@ -1198,7 +1197,8 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
           const int src = se + 16 * (p >> 2), rr = p & 3;
           const float v0 = __shfl(th[0], src, 64), v1 = __shfl(th[1], src, 64), v2 = __shfl(th[2], src, 64), v3 = __shfl(th[3], src, 64);
           const float v = rr == 0 ? v0 : (rr == 1 ? v1 : (rr == 2 ? v2 : v3));
-          if (e < 16 * Dn && ((acc16 >> se) & 1u)) sf_out_store(a, (size_t)slot0 * Dn + e, v);
+          const uint32_t sl_e = (uint32_t)__shfl((int)slot, se, 64);
+          if (e < 16 * Dn && ((acc16 >> se) & 1u)) sf_out_store(a, (size_t)sl_e * Dn + c, v);
         }
       } else if (valid && me == first) {
 #pragma unroll
