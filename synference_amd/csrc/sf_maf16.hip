@@ -1013,8 +1013,11 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
     const unsigned int n_items = ctrl[0] << ctrl[1];  // items of this iteration (entries x attempts per entry)
     // the wave's tiles: tile j covers items (j * 4 + wave) * 16 .. + 15.  Between transforms a tile is its u registers
     // and its galaxy; `cur` is the tile being worked on, `oth` the other one (TPW = 2), swapped after every tile.
-    f32x4 u_cur, u_oth;
-    long gal_cur = 0, gal_oth = 0;
+    // (the tile being worked on is always entry 0: the entries rotate after every tile, TPW turns restore the order)
+    f32x4 u_t[TPW];
+    unsigned int g_t[TPW];
+#define u_cur u_t[0]
+#define gal_cur g_t[0]
 #pragma unroll
     for (int j = TPW - 1; j >= 0; --j) {  // (j = 0 last: it is the first `cur`)
       const int wi = (j * 4 + wave) * 16 + s;
@@ -1026,15 +1029,9 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
       const uint32_t att = ctrl[SF_Q_HDR + IPW + ee] + ((unsigned)wi & ((1u << lgA) - 1u));
       float z4[4];
       sf_normal4(a.k0, a.k1, (uint64_t)slot + a.rng_slot_offset, att, (uint32_t)g4, z4);  // Philox block g4 = dimensions 4*g4 .. 4*g4+3
-      if (TPW == 2 && j == 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) u_oth[r] = (4 * g4 + r < m.D) ? z4[r] : 0.f;
-        gal_oth = (long)(slot / (uint32_t)a.S);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) u_cur[r] = (4 * g4 + r < m.D) ? z4[r] : 0.f;
-        gal_cur = (long)(slot / (uint32_t)a.S);
-      }
+      for (int r = 0; r < 4; ++r) u_t[j][r] = (4 * g4 + r < m.D) ? z4[r] : 0.f;
+      g_t[j] = slot / (uint32_t)a.S;
     }
     uint32_t tile_bits = 0, lo_bits = 0;  // g16_tile / g16_lo packed 2 bits per degree
     if constexpr (DD == 0) {                // (the unrolled kernels know the tile of every pass: p - 2)
@@ -1119,9 +1116,13 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
           }
           u_cur = S.ut;
         }
-        if (TPW == 2) {  // the other tile's turn (after TPW turns every tile is `cur` under its own name again)
-          const f32x4 tu = u_cur; u_cur = u_oth; u_oth = tu;
-          const long tg = gal_cur; gal_cur = gal_oth; gal_oth = tg;
+        if (TPW > 1) {  // the next tile's turn (after TPW turns every tile is entry 0 under its own index again)
+          const f32x4 tu = u_t[0];
+          const unsigned int tg = g_t[0];
+#pragma unroll
+          for (int q = 0; q + 1 < TPW; ++q) { u_t[q] = u_t[q + 1]; g_t[q] = g_t[q + 1]; }
+          u_t[TPW - 1] = tu;
+          g_t[TPW - 1] = tg;
         }
       }
     }
@@ -1179,7 +1180,7 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
           if (w >= gw0 && w < gw0 + gwn && cw < 16u) first = (w - gw0) * 16 + (int)cw;
         }
         me = wi - (int)(e << lgA);
-        if (TPW == 2) __syncthreads();  // the four words are rewritten for the other tile
+        if (TPW > 1) __syncthreads();  // the four words are rewritten for the next tile
       }
       // One attempt per entry (every dense iteration): the tile's 16 x D block of draws is handed to the lanes LINEARLY -- lane L
       // stores element L, L + 64, ... = (draw se = e / D, column c = e % D) at out[slot(se) D + c] -- so that a wave-instruction
@@ -1237,8 +1238,11 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
         if (n_ev) atomicAdd(&ctrl[5], n_ev);
         if (n_r0) atomicAdd(&ctrl[6], n_r0);
       }
-      if (TPW == 2) {
-        const f32x4 tu = u_cur; u_cur = u_oth; u_oth = tu;
+      if (TPW > 1) {
+        const f32x4 tu = u_t[0];
+#pragma unroll
+        for (int q = 0; q + 1 < TPW; ++q) u_t[q] = u_t[q + 1];
+        u_t[TPW - 1] = tu;
       }
     }
 #ifdef SF_Q_STATS
@@ -1249,6 +1253,8 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
 #endif
   }
 }
+#undef u_cur
+#undef gal_cur
 
 // Find / resolve launches of the deep tail (sf_api.hip: the slots that used up the persistent windows) on the sampler's OWN
 // arithmetic and cost per evaluation: the unrolled split-bf16 pass sequence of k_maf_samp16<.., DD> without the queue.
@@ -1667,6 +1673,8 @@ template <int NB, bool SPAN, bool HM>
 static hipError_t sf_launch16q_t(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
   if (sf_maf16_tpw() == 1) return sf_launch16q<NB, SPAN, HM, 1>(m, a, st);
   if constexpr (HM && !SPAN) {
+    // (round 5, fp32 kernels: FOUR tiles per wave and staged transform -- fetch, staging and prologue once per 256 draws -- measured
+    //  2.74 ms per catalogue against 2.62 with two: the coarser iterations cost the tail more than the dense phase saves)
     switch (sf_maf16_seq_d(m)) {
       case 3: return sf_launch16q<NB, SPAN, HM, 2, 3>(m, a, st);
       case 4: return sf_launch16q<NB, SPAN, HM, 2, 4>(m, a, st);
