@@ -8,6 +8,12 @@ With ``--gpus N > 1`` and no launcher environment (WORLD_SIZE unset) the script 
 before this process touches the GPU) and forwards rank 0's JSON line; started under ``torch.distributed.run`` it is one
 rank.  Either way it asserts that the process group really has ``--gpus`` ranks and reports that number.
 
+The default run prints ONE JSON line with: the configs[1] sampling leg (`value`, `roofline`, five timed blocks in `repeats`), the other
+arithmetic mode of the sampler beside it (`roofline.split_bf16_sampler`), the API level (`api`: SBI_Fitter.sample_posterior -> host
+float64), the per-object call the reference itself times (`per_object_call`), the training leg (`train`, `roofline_train`, `train.dp` =
+the same epoch loop with the RCCL all-reduce inside, a one-rank communicator at N = 1), `log_prob`, the configs[4]-shaped catalogue
+(`large_catalogue`), the configs[2] workload (`nsf_cfg3`: its own sampling / training / roofline objects) and the CPU baseline.
+
 Workload (BASELINE.json configs[1]): NPE MAF (5 transforms, 50 hidden) on the 10k-galaxy 10-filter NIRCam-like mock;
 one "step" = ``sample_posterior`` over the 2 000-galaxy test catalogue with 1 000 accepted draws per galaxy (the
 reference's published benchmark loop, ref: src/synference/sbi_runner.py:6438-6442, S=1000 as in
