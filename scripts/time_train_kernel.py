@@ -8,8 +8,9 @@ from synference_amd.engine import HipFlow
 g = torch.Generator().manual_seed(0)
 KIND = os.environ.get("SF_PROBE_KIND", "maf")   # maf: BASELINE cfg1 shape; nsf: cfg3 shape
 D, C = (5, 10) if KIND == "maf" else (8, 20)
+D, C = int(os.environ.get("SF_PROBE_D", D)), int(os.environ.get("SF_PROBE_C", C))
 TM = int(os.environ.get("SF_PROBE_T", "5"))
-spec = (FlowSpec(kind="maf", D=D, C=C, H=50, T=TM, K=10, perms=random_perms(D, TM, g)) if KIND == "maf" else
+spec = (FlowSpec(kind="maf", D=D, C=C, H=int(os.environ.get("SF_PROBE_H", "50")), T=TM, K=10, perms=random_perms(D, TM, g)) if KIND == "maf" else
         FlowSpec(kind="nsf", D=D, C=C, H=int(os.environ.get("SF_PROBE_H", "50")), T=int(os.environ.get("SF_PROBE_T", "5")),
                  K=int(os.environ.get("SF_PROBE_K", "8"))))
 F_LP = 40030 * TM / 5 if KIND == "maf" else 178640

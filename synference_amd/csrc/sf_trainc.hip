@@ -27,11 +27,14 @@
 #include "sf_internal.h"
 #include "sf_trainc.h"
 
-// One translation unit per stash depth (Makefile: -DSF_TRC_TU=5 | 6 | 8): sixteen instantiations of the kernel each -- all 48 in
-// one unit compile for ten minutes on one core.  Unit 5 also holds the host side and the gather kernels.
+// One translation unit per (stash depth, fragment slots) (Makefile: -DSF_TRC_TU=5 | 6 | 8 for five slots, 15 | 16 | 18 for eight):
+// up to sixteen instantiations of the kernel each -- all of them in one unit compile for a quarter of an hour on one core.  Unit 5
+// also holds the host side and the gather kernels.
 #ifndef SF_TRC_TU
 #define SF_TRC_TU 5
 #endif
+#define SF_TRC_TS_OF_TU (SF_TRC_TU % 10)
+#define SF_TRC_NFS_OF_TU (SF_TRC_TU >= 10 ? 8 : 5)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SF_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -247,7 +250,10 @@ __host__ __device__ inline int sf_trc_cb_floats(int NT, int NI, int TS) { return
 // hidden tiles p and NT-1-p of subtile qq: with the block-triangular MADE layers that is (p + 1) + (NT - p) = NT + 1
 // blocks per layer for EVERY wave (round 3's first version gave wave j tile j for both subtiles: the wave with the
 // last tile ran four blocks while the first ran one, and every barrier waited for it).
-template <int TS, int NI, int NT, int NG>
+// NFS = fragment slots per masked layer and wave: 5 covers the aligned degree placement ((p + 1) + (NT - p) = NT + 1 blocks), 8 the
+// contiguous ("span") placements, whose degree groups straddle tiles and unmask more blocks (up to NT per tile: D = 6 with H = 50,
+// H = 64 with D >= 6 -- the width of the reference's example CLI); the three extra fragments per layer cost registers (scratch).
+template <int TS, int NI, int NT, int NG, int NFS = 5>
 __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
   extern __shared__ float lds[];
   constexpr int NQ = 2 * NG, NW = 4 * NG, NTH = 256 * NG;
@@ -382,11 +388,11 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
         const float* cb = CBb + t * NBIAS;
         // F1: h0 = b0 + bc + Win . [u ; e(x)]
         SF_TC(1 + 5 * t);
-        float4 w1f[5], w2f[5];
+        float4 w1f[NFS], w2f[NFS];
         if (has0) {
           // next phase's fragments: in flight across the barrier
 #pragma unroll
-          for (int i = 0; i < 5; ++i) w1f[i] = c_frag(tp + L::o_w1, NT, fslot_tile(i), fslot_it(i), lane);
+          for (int i = 0; i < NFS; ++i) w1f[i] = c_frag(tp + L::o_w1, NT, fslot_tile(i), fslot_it(i), lane);
           f32x4 in0 = inx[0];
           in0[0] = s0on ? u0 : in0[0];
           in0[1] = s1on ? u1 : in0[1];
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
         SF_TCX(t == 1, 200, u0);
         if (has0) {
 #pragma unroll
-          for (int i = 0; i < 5; ++i) w2f[i] = c_frag(tp + L::o_w2, NT, fslot_tile(i), fslot_it(i), lane);
+          for (int i = 0; i < NFS; ++i) w2f[i] = c_frag(tp + L::o_w2, NT, fslot_tile(i), fslot_it(i), lane);
           wff[0] = c_frag(tp + L::o_wf, NT, 0, tA, lane);
           wff[1] = c_frag(tp + L::o_wf, NT, 0, tB_, lane);
           f32x4 accA = c_ld4(cb + NT * 16 + (tA * 4 + g4) * 4), accB = c_ld4(cb + NT * 16 + (tB_ * 4 + g4) * 4);
@@ -417,7 +423,7 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
 {
             f32x4 accA1 = c_zero(), accB1 = c_zero();
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
+            for (int i = 0; i < NFS; ++i) {
               if (i < nfT) {
                 const f32x4 tv = c_ld4(XBa + (fslot_it(i) * NQ + q) * 256 + lane * 4);
                 if (i < nfA) c_mma_alt(w1f[i], tv, accA, accA1);
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
 {
             f32x4 accA1 = c_zero(), accB1 = c_zero();
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
+            for (int i = 0; i < NFS; ++i) {
               if (i < nfT) {
                 const f32x4 tv = c_ld4(XBb + (fslot_it(i) * NQ + q) * 256 + lane * 4);
                 if (i < nfA) c_mma_alt(w2f[i], tv, accA, accA1);
@@ -494,7 +500,7 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
       }
     }
     // first fragments of the backward sweep (top transform): in flight behind the loss
-    float4 pwfT[2], pw2T[5], pwinB[2][NI];
+    float4 pwfT[2], pw2T[NFS], pwinB[2][NI];
     {
       const SfTrcArgs& a = c_args();
       const SfTrcDev& c = a.c;
@@ -507,7 +513,7 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
         pwinB[1][it] = c_frag(tpl + L::o_win, NI, tB_, it, lane);
       }
 #pragma unroll
-      for (int i = 0; i < 5; ++i) pw2T[i] = c_frag(tpl + L::o_w2T, NT, bslot_tile(i), bslot_ot(i), lane);
+      for (int i = 0; i < NFS; ++i) pw2T[i] = c_frag(tpl + L::o_w2T, NT, bslot_tile(i), bslot_ot(i), lane);
     }
     // ------------------------------------------------------------------ loss, dL/du_T
     float G0, G1;
@@ -595,18 +601,18 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
         // B2: delta of block 1; weight gradients of the head.  The two halves of a backward phase (data path, weight-
         // gradient blocks) are independent: odd groups run them in the opposite order, so that the two waves that share
         // a SIMD are not in the same kind of work at the same time (MFMA chain + tanh' epilogue vs LDS-fed block products)
-        float4 w1T[5], wiT[2];
+        float4 w1T[NFS], wiT[2];
         auto b2_data = [&]() {
         if (has0) {
 #pragma unroll
-          for (int i = 0; i < 5; ++i) w1T[i] = c_frag(tp + L::o_w1T, NT, bslot_tile(i), bslot_ot(i), lane);
+          for (int i = 0; i < NFS; ++i) w1T[i] = c_frag(tp + L::o_w1T, NT, bslot_tile(i), bslot_ot(i), lane);
           wiT[0] = c_frag(tp + L::o_winT, NT, 0, tA, lane);
           wiT[1] = c_frag(tp + L::o_winT, NT, 0, tB_, lane);
           f32x4 accA = c_zero(), accB = c_zero();
 {
             f32x4 accA1 = c_zero(), accB1 = c_zero();
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
+            for (int i = 0; i < NFS; ++i) {
               if (i < nbT) {
                 const f32x4 tv = c_ld4(XBa + (bslot_ot(i) * NQ + q) * 256 + lane * 4);
                 if (i < nbA) c_mma_alt(pw2T[i], tv, accA, accA1);
@@ -651,7 +657,7 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
 {
             f32x4 accA1 = c_zero(), accB1 = c_zero();
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
+            for (int i = 0; i < NFS; ++i) {
               if (i < nbT) {
                 const f32x4 tv = c_ld4(XBb + (bslot_ot(i) * NQ + q) * 256 + lane * 4);
                 if (i < nbA) c_mma_alt(w1T[i], tv, accA, accA1);
@@ -696,7 +702,7 @@ __global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
             pwinB[1][it] = c_frag(tpn + L::o_win, NI, tB_, it, lane);
           }
 #pragma unroll
-          for (int i = 0; i < 5; ++i) pw2T[i] = c_frag(tpn + L::o_w2T, NT, bslot_tile(i), bslot_ot(i), lane);
+          for (int i = 0; i < NFS; ++i) pw2T[i] = c_frag(tpn + L::o_w2T, NT, bslot_tile(i), bslot_ot(i), lane);
         }
         {
           f32x4 du = c_zero();
@@ -912,7 +918,7 @@ bool sf_trainc_eligible(const SfLayout& L, bool want_dctx) {
     const int tA = p, tB = c.NT - 1 - p;
     const int nf = (c.kend[tA] + 1) + (tB > tA ? c.kend[tB] + 1 : 0);
     const int nb = (c.NT - c.kbeg[tA]) + (tB > tA ? c.NT - c.kbeg[tB] : 0);
-    if (nf > 5 || nb > 5) return false;
+    if (nf > 8 || nb > 8) return false;
   }
   return sf_trainc_lds_bytes(c, sf_trc_ts(L.dev.T), 1) <= (size_t)160 * 1024;
 }
@@ -933,12 +939,12 @@ int sf_trainc_grid(long B, const SfTrcDev* c, int T) {
 
 #endif  // SF_TRC_TU == 5
 
-template <int NI, int NT, int NG, int TS>
+template <int NI, int NT, int NG, int TS, int NFS>
 static hipError_t c_launch_ts(const SfTrcArgs& a, int grid, hipStream_t st) {
   static SfAttrCache attr;
   int attr_dev;
   if (attr.need(attr_dev)) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_maf_trainc<TS, NI, NT, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)k_maf_trainc<TS, NI, NT, NG, NFS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr.set(attr_dev);
   }
@@ -950,7 +956,7 @@ static hipError_t c_launch_ts(const SfTrcArgs& a, int grid, hipStream_t st) {
     (void)hipMemsetAsync(d_tr, 0, 8 * 256 * 8, st);
     SfTrcArgs b = a;
     b.trace = d_tr;
-    hipLaunchKernelGGL((k_maf_trainc<TS, NI, NT, NG>), dim3((unsigned)grid), dim3(256 * NG), sh, st, b);
+    hipLaunchKernelGGL((k_maf_trainc<TS, NI, NT, NG, NFS>), dim3((unsigned)grid), dim3(256 * NG), sh, st, b);
     (void)hipStreamSynchronize(st);
     static unsigned long long h[8 * 256];
     (void)hipMemcpy(h, d_tr, sizeof(h), hipMemcpyDeviceToHost);
@@ -967,27 +973,30 @@ static hipError_t c_launch_ts(const SfTrcArgs& a, int grid, hipStream_t st) {
     return hipGetLastError();
   }
 #endif
-  hipLaunchKernelGGL((k_maf_trainc<TS, NI, NT, NG>), dim3((unsigned)grid), dim3(256 * NG), sh, st, a);
+  hipLaunchKernelGGL((k_maf_trainc<TS, NI, NT, NG, NFS>), dim3((unsigned)grid), dim3(256 * NG), sh, st, a);
   return hipGetLastError();
 }
 template <int NG>
 static hipError_t c_dispatch(const SfTrcArgs& a, int grid, hipStream_t st) {
   const int key = a.c.NI * 10 + a.c.NT;
+  constexpr int TS_ = SF_TRC_TS_OF_TU, NFS_ = SF_TRC_NFS_OF_TU;
   switch (key) {
-    case 11: return c_launch_ts<1, 1, NG, SF_TRC_TU>(a, grid, st);
-    case 12: return c_launch_ts<1, 2, NG, SF_TRC_TU>(a, grid, st);
-    case 13: return c_launch_ts<1, 3, NG, SF_TRC_TU>(a, grid, st);
-    case 14: return c_launch_ts<1, 4, NG, SF_TRC_TU>(a, grid, st);
-    case 21: return c_launch_ts<2, 1, NG, SF_TRC_TU>(a, grid, st);
-    case 22: return c_launch_ts<2, 2, NG, SF_TRC_TU>(a, grid, st);
-    case 23: return c_launch_ts<2, 3, NG, SF_TRC_TU>(a, grid, st);
-    case 24: return c_launch_ts<2, 4, NG, SF_TRC_TU>(a, grid, st);
+#if SF_TRC_TU < 10   // (one or two hidden tiles never need more than five slots)
+    case 11: return c_launch_ts<1, 1, NG, TS_, NFS_>(a, grid, st);
+    case 12: return c_launch_ts<1, 2, NG, TS_, NFS_>(a, grid, st);
+    case 21: return c_launch_ts<2, 1, NG, TS_, NFS_>(a, grid, st);
+    case 22: return c_launch_ts<2, 2, NG, TS_, NFS_>(a, grid, st);
+#endif
+    case 13: return c_launch_ts<1, 3, NG, TS_, NFS_>(a, grid, st);
+    case 14: return c_launch_ts<1, 4, NG, TS_, NFS_>(a, grid, st);
+    case 23: return c_launch_ts<2, 3, NG, TS_, NFS_>(a, grid, st);
+    case 24: return c_launch_ts<2, 4, NG, TS_, NFS_>(a, grid, st);
   }
   return hipErrorInvalidValue;
 }
 #define SF_TRC_CAT2(a, b) a##b
 #define SF_TRC_CAT(a, b) SF_TRC_CAT2(a, b)
-// this unit's launcher: sf_trainc_launch_ts5 / _ts6 / _ts8
+// this unit's launcher: sf_trainc_launch_ts5 / _ts6 / _ts8 (five fragment slots), _ts15 / _ts16 / _ts18 (eight)
 hipError_t SF_TRC_CAT(sf_trainc_launch_ts, SF_TRC_TU)(const SfTrcArgs& a, int grid, int ng, hipStream_t st) {
   return ng == 1 ? c_dispatch<1>(a, grid, st) : c_dispatch<2>(a, grid, st);
 }
@@ -995,12 +1004,34 @@ hipError_t SF_TRC_CAT(sf_trainc_launch_ts, SF_TRC_TU)(const SfTrcArgs& a, int gr
 #if SF_TRC_TU == 5
 hipError_t sf_trainc_launch_ts6(const SfTrcArgs& a, int grid, int ng, hipStream_t st);
 hipError_t sf_trainc_launch_ts8(const SfTrcArgs& a, int grid, int ng, hipStream_t st);
+hipError_t sf_trainc_launch_ts15(const SfTrcArgs& a, int grid, int ng, hipStream_t st);
+hipError_t sf_trainc_launch_ts16(const SfTrcArgs& a, int grid, int ng, hipStream_t st);
+hipError_t sf_trainc_launch_ts18(const SfTrcArgs& a, int grid, int ng, hipStream_t st);
+// fragment slots a flow's placement needs per masked layer and wave (sf_trainc_eligible admits up to eight)
+static int c_slots_needed(const SfTrcDev& c) {
+  int mx = 0;
+  for (int p = 0; 2 * p < c.NT; ++p) {
+    const int tA = p, tB = c.NT - 1 - p;
+    const int nf = (c.kend[tA] + 1) + (tB > tA ? c.kend[tB] + 1 : 0);
+    const int nb = (c.NT - c.kbeg[tA]) + (tB > tA ? c.NT - c.kbeg[tB] : 0);
+    mx = nf > mx ? nf : mx;
+    mx = nb > mx ? nb : mx;
+  }
+  return mx;
+}
 // T <= 5: every transform's a1 / a2 tiles in registers (80 VGPRs of stash); T = 6 and T = 7..8 are instantiations of their own --
 // the reference's example CLI trains num_transforms = 6 (examples/sbi/scripts/train_model.py:56-57) -- whose longer stash the
 // compiler parks partly in scratch: same cooperative decomposition (no activation in HBM), measured 0.173 of the fp32 roof at
 // T = 6 and batch 16 384 (86.9 us; the generic kernel: 187.5 us)
 hipError_t sf_launch_maf_trainc(const SfTrcArgs& a, int grid, hipStream_t st) {
   const int ng = sf_trainc_groups(a.B, &a.c, a.T);
+  if (c_slots_needed(a.c) > 5) {   // contiguous ("span") placement: the eight-slot instantiations
+    switch (sf_trc_ts(a.T)) {
+      case 5: return sf_trainc_launch_ts15(a, grid, ng, st);
+      case 6: return sf_trainc_launch_ts16(a, grid, ng, st);
+      default: return sf_trainc_launch_ts18(a, grid, ng, st);
+    }
+  }
   switch (sf_trc_ts(a.T)) {
     case 5: return sf_trainc_launch_ts5(a, grid, ng, st);
     case 6: return sf_trainc_launch_ts6(a, grid, ng, st);

@@ -298,7 +298,7 @@ def train_flow(estimator: FlowEstimator, theta: torch.Tensor, x: torch.Tensor, *
                 sp = estimator.spec
                 logger.warning(f"{sp.kind} D={sp.D} C={sp.C} H={sp.H} T={sp.T} K={sp.K}: this shape trains on the generic kernels "
                                "(k_maf_train / k_nsf_train, sf_flow_train_path = 0), not on the cooperative 16-row kernels "
-                               "(MAF: two blocks, D <= 8, aligned degree groups; NSF: two blocks, D 2..12, H <= 80, 3K - 1 <= 32)")
+                               "(MAF: two blocks, D <= 8, H <= 64, T <= 8; NSF: two blocks, D 2..8, H <= 80, 3K - 1 <= 32, C <= 40)")
         except Exception:
             pass
     best_val, since, best_state = float("inf"), 0, None

@@ -27,6 +27,10 @@ CASES = {
     "maf_d3": ("maf", 3, 5, 26, 3, 10),        # 2 groups of 13, one per tile: DD = 3
     # the reference's example CLI trains 6 transforms (examples/sbi/scripts/train_model.py:56-57): the TS = 6 / TS = 8 instantiations
     # of the cooperative MAF training kernel (the a1 / a2 stash of transforms beyond five is partly in scratch)
+    # the reference's example CLI shape itself (hidden_features=64, num_transforms=6: examples/sbi/scripts/train_model.py:56-57) on a
+    # 7-parameter / 16-filter problem: SPAN placement (six degree groups of 10-11 units over four tiles) and T = 6 -- the eight-slot
+    # instantiation of the cooperative training kernel with the deeper stash
+    "maf_cli": ("maf", 7, 16, 64, 6, 10),
     "maf_t6": ("maf", 5, 10, 50, 6, 10),
     "maf_t8": ("maf", 4, 6, 40, 8, 10),
     "maf_nb1": ("maf", 4, 6, 48, 2, 10, dict(NB=1)),   # one hidden block, 3 full tiles: the NB = 1 instantiations of the 16-row sampler

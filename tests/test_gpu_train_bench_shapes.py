@@ -36,8 +36,11 @@ def check_against_oracle(ospec, flat, theta, x, loss, grad, tag):
 BENCH_SHAPES = [
     ("maf_cfg1", 16384, 2),            # bench `train`: k_maf_trainc<5,1,4,2>, one chunk per workgroup
     ("maf_cfg1", 131072 + 37, 2),      # bench `throughput_regime`: NG = 2, 8+ chunks per workgroup, ragged tail
-    ("maf_span6", 16384, None),
-    ("maf_span6", 131072 + 37, None),
+    ("maf_span6", 16384, 2),           # span placement: the eight-slot instantiations (k_maf_trainc<5,1,4,2,8>)
+    ("maf_span6", 131072 + 37, 2),
+    ("maf_span_h64", 16384, 2),        # (8,12,64): seven degree groups over four tiles
+    ("maf_cli", 16384, 2),             # (7,16,64,6): the reference's example CLI (span + T = 6 + two input tiles)
+    ("maf_cli", 2048 + 37, 1),
     ("maf_d4", 16384, None),
     ("maf_d4", 131072 + 37, None),
     ("maf_t6", 16384, 2),              # T = 6 (the reference's example CLI): k_maf_trainc<6,1,4,2>
