@@ -488,9 +488,10 @@ static void nsf_sampler_view(const sf_flow* f, SfDev& m) {
     m.o_wg[k] = s.o_wg[k]; m.o_bg[k] = s.o_bg[k]; m.o_b1[k] = s.o_b1[k]; m.o_b2[k] = s.o_b2[k];
     m.o_w1[k] = 0; m.o_w2[k] = 0;  // (not in this image)
     m.oB_w1[k] = s.oB_w1[k]; m.oB_w2[k] = s.oB_w2[k];
-    m.blk_part[k] = 0;
   }
-  m.n_parts = 1; m.part_off[0] = 0; m.part_off[1] = s.t_stride; m.part_max = s.t_stride; m.head_part = 0;
+  m.n_parts = s.n_parts; m.part_max = s.part_floats_max; m.part_bytes_max = s.part_bytes_max; m.head_part = s.head_part;
+  for (int p = 0; p < 5; ++p) { m.part_off[p] = s.part_off[p]; m.partB_off[p] = s.partB_off[p]; }
+  for (int k = 0; k < SF_NBMAX; ++k) m.blk_part[k] = s.blk_part[k];
   m.packedB = f->d_packed16B;
   m.tB_stride = s.tB_stride;
   m.hidden_bf16 = 2;

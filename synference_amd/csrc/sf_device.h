@@ -68,10 +68,13 @@ __device__ __forceinline__ const float* sf_stage_part(const SfDev& m, int t, int
   const float* src = m.packed + (size_t)t * m.t_stride + sf_opaque_zero();
   if (!LDSW) return src;
   int lo = 0, hi = 0;  // part_off[part], part_off[part + 1] without a runtime-indexed load (keeps the descriptor in SGPRs)
+  int blo = 0, bhi = 0;  // ... and the part's slice of the bf16 image
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     lo = (q == part) ? m.part_off[q] : lo;
     hi = (q == part) ? m.part_off[q + 1] : hi;
+    blo = (q == part) ? m.partB_off[q] : blo;
+    bhi = (q == part) ? m.partB_off[q + 1] : bhi;
   }
   __syncthreads();  // previous image no longer in use
   const float4* __restrict__ s4 = reinterpret_cast<const float4*>(src + lo);
@@ -82,10 +85,10 @@ __device__ __forceinline__ const float* sf_stage_part(const SfDev& m, int t, int
   const int lane_ = threadIdx.x & 63;
   for (int i = threadIdx.x; i < n4; i += blockDim.x)
     __builtin_amdgcn_global_load_lds((const void*)(s4 + i), (void __attribute__((address_space(3)))*)(d4 + (i - lane_)), 16, 0, 0);
-  if (m.hidden_bf16) {  // single-part images only (sf_layout.cpp): bf16 hidden operands right behind the fp32 image
-    const uint4* __restrict__ sb = reinterpret_cast<const uint4*>(m.packedB + (size_t)t * m.tB_stride);
-    uint4* __restrict__ db = reinterpret_cast<uint4*>(lds + m.t_stride);
-    const int nb = m.tB_stride >> 3;
+  if (m.hidden_bf16) {  // the part's bf16 hidden operands right behind its fp32 slice
+    const uint4* __restrict__ sb = reinterpret_cast<const uint4*>(m.packedB + (size_t)t * m.tB_stride + blo);
+    uint4* __restrict__ db = reinterpret_cast<uint4*>(lds + (hi - lo));
+    const int nb = (bhi - blo) >> 3;
     for (int i = threadIdx.x; i < nb; i += blockDim.x)
       __builtin_amdgcn_global_load_lds((const void*)(sb + i), (void __attribute__((address_space(3)))*)(db + (i - lane_)), 16, 0, 0);
   }
@@ -280,9 +283,19 @@ __device__ __forceinline__ void sf_mm_acc_bf16_tile(f32x16 (&acc)[NS], const f32
 }
 
 // bf16 image base of transform t (LDS copy right behind the fp32 image, or global)
+// (LDS: such that base + an element offset of the bf16 image lands inside the slice staged with `part`)
 template <bool LDSW>
-__device__ __forceinline__ const unsigned short* sf_bf16_base(const SfDev& m, int t, float* lds) {
-  if (LDSW) return reinterpret_cast<const unsigned short*>(lds + m.t_stride);
+__device__ __forceinline__ const unsigned short* sf_bf16_base(const SfDev& m, int t, float* lds, int part = 0) {
+  if (LDSW) {
+    int lo = 0, hi = 0, blo = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      lo = (q == part) ? m.part_off[q] : lo;
+      hi = (q == part) ? m.part_off[q + 1] : hi;
+      blo = (q == part) ? m.partB_off[q] : blo;
+    }
+    return reinterpret_cast<const unsigned short*>(lds + (hi - lo)) - blo;
+  }
   return m.packedB + (size_t)t * m.tB_stride;
 }
 

@@ -567,7 +567,7 @@ struct NsfOps {
           sf_init_bias<HT, NS>(t1, tp + m.o_b1[k], h);
           sf_init_bias<HT, NS>(t2, tp + m.o_b2[k], h);
           if (BF == 2) {
-            const unsigned short* tpB = sf_bf16_base<LDSW>(m, t, lds);
+            const unsigned short* tpB = sf_bf16_base<LDSW>(m, t, lds, part);
             sf_mm_acc_bf16_split<HT, NS, HT, true>(t1, hid, tpB + m.oB_w1[k], m.nKS, m.nKS, lane);
             sf_mm_acc_bf16_split<HT, NS, HT, true>(t2, t1, tpB + m.oB_w2[k], m.nKS, m.nKS, lane);
           } else if (BF == 1) {

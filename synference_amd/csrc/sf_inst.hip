@@ -80,7 +80,7 @@ template <class OpsB>
 static hipError_t launch_logprob_bf16(const SfDev& m, const float* theta, const float* x, long B, float* out,
                                       hipStream_t st) {
   static SfAttrCache attr;
-  const size_t sh = (size_t)m.part_max * sizeof(float) + (size_t)m.tB_stride * sizeof(unsigned short);
+  const size_t sh = (size_t)m.part_bytes_max;
   hipError_t e = set_shmem(k_logprob<OpsB, 1, true>, sh, attr);
   if (e != hipSuccess) return e;
   const int wpb = sf_lds_wpb(sh);
@@ -91,7 +91,7 @@ static hipError_t launch_logprob_bf16(const SfDev& m, const float* theta, const 
 template <class OpsB>
 static hipError_t launch_inverse_bf16(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
   static SfAttrCache attr;
-  const size_t sh = (size_t)m.part_max * sizeof(float) + (size_t)m.tB_stride * sizeof(unsigned short);
+  const size_t sh = (size_t)m.part_bytes_max;
   if (a.q) return launch_persist_lds<OpsB>(m, a, sh, st);
   hipError_t e = set_shmem(k_inverse<OpsB, 1, true>, sh, attr);
   if (e != hipSuccess) return e;

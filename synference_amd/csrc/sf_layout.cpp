@@ -1014,8 +1014,46 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
     while (L.src16a.size() % 64) { L.src16a.push_back(-1); L.src16b.push_back(-1); }
     while (L.src16B.size() % 64) L.src16B.push_back(-1);
     if (T == 1) { L.nsfS.t_stride = (int)L.src16a.size(); L.nsfS.tB_stride = (int)L.src16B.size(); }
-    // one transform's fp32 part + split part must fit the LDS budget next to the sampler's control block
-    if ((size_t)L.nsfS.t_stride * 4 + (size_t)L.nsfS.tB_stride * 2 > (size_t)152 * 1024 || (L.nsfS.tB_stride & 7)) L.nsfS.ok = 0;
+    // staging plan: whole items (input layer | block k: fp32 pieces + split W1 / W2 | head) packed into the LDS budget next to the
+    // sampler's control block; at most three parts, no item larger than the budget
+    if (L.nsfS.tB_stride & 7) L.nsfS.ok = 0;
+    if (L.nsfS.ok) {
+      SfNsfSamp& sS = L.nsfS;
+      const size_t budget = (size_t)152 * 1024;
+      std::vector<int> cf{0}, cb{0};   // item boundaries: fp32 floats, bf16 elements
+      for (int k = 0; k < NB; ++k) { cf.push_back(sS.o_wg[k]); cb.push_back(sS.oB_w1[k]); }
+      cf.push_back(sS.o_wout); cb.push_back(sS.tB_stride);
+      cf.push_back(sS.t_stride); cb.push_back(sS.tB_stride);
+      sS.n_parts = 0; sS.part_off[0] = 0; sS.partB_off[0] = 0;
+      std::vector<int> item_part(cf.size() - 1, 0);
+      int sf0 = 0, sb0 = 0;
+      bool okp = true;
+      for (size_t i = 0; i + 1 < cf.size() && okp; ++i) {
+        const size_t item = (size_t)(cf[i + 1] - cf[i]) * 4 + (size_t)(cb[i + 1] - cb[i]) * 2;
+        if (item > budget) { okp = false; break; }
+        if ((size_t)(cf[i + 1] - sf0) * 4 + (size_t)(cb[i + 1] - sb0) * 2 > budget) {   // close the current part before this item
+          if (sS.n_parts >= 3) { okp = false; break; }
+          ++sS.n_parts;
+          sS.part_off[sS.n_parts] = cf[i]; sS.partB_off[sS.n_parts] = cb[i];
+          sf0 = cf[i]; sb0 = cb[i];
+        }
+        item_part[i] = sS.n_parts;
+      }
+      if (okp) {
+        ++sS.n_parts;
+        sS.part_off[sS.n_parts] = cf.back(); sS.partB_off[sS.n_parts] = cb.back();
+        sS.part_floats_max = 0; sS.part_bytes_max = 0;
+        for (int p = 0; p < sS.n_parts; ++p) {
+          const int pf = sS.part_off[p + 1] - sS.part_off[p], pb = sS.partB_off[p + 1] - sS.partB_off[p];
+          sS.part_floats_max = std::max(sS.part_floats_max, pf);
+          sS.part_bytes_max = std::max(sS.part_bytes_max, pf * 4 + pb * 2);
+          if ((sS.partB_off[p] & 7) || (sS.part_off[p] & 3)) okp = false;   // 16-byte pieces of the direct-to-LDS copies
+        }
+        for (int k = 0; k < NB; ++k) sS.blk_part[k] = item_part[1 + k];
+        sS.head_part = item_part[1 + NB];
+      }
+      if (!okp) sS.ok = 0;
+    }
     if (!L.nsfS.ok) { L.src16a.clear(); L.src16b.clear(); L.src16B.clear(); }
   }
   L.n_packed16 = (int64_t)L.src16a.size();
@@ -1063,6 +1101,8 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
     } else {
       v.n_parts = 0;
     }
+    for (int p = 0; p < 5; ++p) v.partB_off[p] = p == 0 ? 0 : v.tB_stride;   // (single-part bf16 images: everything with part 0)
+    v.part_bytes_max = v.part_max * 4 + (v.hidden_bf16 ? v.tB_stride * 2 : 0);
     if (v.hidden_bf16) {
       const int need = v.t_stride + (v.tB_stride + 1) / 2;  // floats: fp32 image + bf16 image of one transform
       if (v.n_parts != 1 || need > budget)

@@ -38,6 +38,9 @@ struct SfDev {
   // whole layer blocks in execution order; n_parts == 0 -> some block exceeds the LDS budget (stream from L2)
   int n_parts, part_off[5], part_max;
   int blk_part[SF_NBMAX], head_part;  // NSF: part holding block k / the spline head
+  // bf16 operand image (hidden_bf16 != 0): part p also stages elements [partB_off[p], partB_off[p+1]) of it, right behind its
+  // fp32 slice in LDS; part_bytes_max = the largest part, both slices (a single-part image: {0, tB_stride})
+  int partB_off[5], part_bytes_max;
   // offsets in floats relative to the transform base -------------------------------------
   int o_w0, o_wc, o_b0;                  // MAF initial (u part, context part, b0+bc)
   int o_wk[SF_NBMAX], o_bk[SF_NBMAX];    // MAF hidden blocks
@@ -164,6 +167,10 @@ struct SfNsfSamp {
   int o_winu, o_winc, o_bin, o_wg[SF_NBMAX], o_bg[SF_NBMAX], o_b1[SF_NBMAX], o_b2[SF_NBMAX], o_wout, o_bout, o_lu;
   int tB_stride;  // bf16 elements per transform of the split part
   int oB_w1[SF_NBMAX], oB_w2[SF_NBMAX];
+  // LDS staging plan (round 5): parts = whole items in execution order -- the input layer, block k (its fp32 pieces AND its
+  // split W1 / W2), the spline head -- packed greedily into the 152 KiB budget; the production width H = 69 (three hidden
+  // tiles) needs two parts, cfg3 one
+  int n_parts, part_off[5], partB_off[5], blk_part[SF_NBMAX], head_part, part_floats_max, part_bytes_max;
 };
 
 struct SfLayout {

@@ -63,7 +63,7 @@ def sampler_mode():
     lib.sf_set_sampler_fp32(-1)
 
 
-@pytest.mark.parametrize("name", ["maf_cfg1", "maf_span6", "maf_span_h64", "maf_d4", "maf_d3", "maf_nb1", "nsf_cfg3", "nsf_odd", "nsf_k16"])
+@pytest.mark.parametrize("name", ["maf_cfg1", "maf_span6", "maf_span_h64", "maf_d4", "maf_d3", "maf_nb1", "nsf_cfg3", "nsf_odd", "nsf_k16", "nsf_h69"])
 def test_sampler_arithmetic_from_given_noise(name, sampler_mode):
     """The persistent sampler's OWN pass functions, fed GIVEN noise (sf_flow_inverse_from_noise_sampler), must meet the fp64
     oracle within 1e-4 of the parameter scale on EVERY row -- no exempt fraction, no Philox, no rejection in between -- in
@@ -102,7 +102,7 @@ def test_tiny_and_empty_batches():
     assert f.log_prob(theta[:0], x[:0]).numel() == 0
 
 
-@pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "nsf_odd", "maf_span6", "maf_d2_span", "maf_d4", "maf_d3", "maf_sig2", "nsf_d1",
+@pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "nsf_odd", "nsf_h69", "maf_span6", "maf_d2_span", "maf_d4", "maf_d3", "maf_sig2", "nsf_d1",
                                   "nsfar_cfg1", "nsfar_small", "nsfar_d1", "nsfar_wide", "nsfar_h180"])
 def test_sampler_matches_oracle_draw_for_draw(name):
     _draw_for_draw(name)
