@@ -277,9 +277,25 @@ __global__ __launch_bounds__(64 * WPB) void k_sample_persist(SfSampArgs args_in,
       const int first = gmask ? (int)__builtin_ctz(gmask) : -1;
       const int me = c - grp0;
       if (valid && h == 0 && ok && me == first) {
+        if (m.kind == SF_NSF && (m.D & 3) == 0) {
+          // a coupling NSF keeps theta's column order (no permutations): the draw's row leaves as 16-byte pieces -- with the
+          // dense order's runs of consecutive draws on consecutive lanes, whole 64-byte segments per wave-instruction
+          if (a.out_f64) {
+            double2* o2 = reinterpret_cast<double2*>(reinterpret_cast<double*>(a.out) + (size_t)slot * m.D);
 #pragma unroll
-        for (int p = 0; p < SF_DMAX; ++p)
-          if (p < m.D) sf_out_store(a, (size_t)slot * m.D + (int)m.cst[m.c_tdim + p], th[p]);
+            for (int p = 0; p < SF_DMAX; p += 2)
+              if (p < m.D) o2[p >> 1] = make_double2((double)th[p], (double)th[p + 1]);
+          } else {
+            float4* o4 = reinterpret_cast<float4*>(a.out + (size_t)slot * m.D);
+#pragma unroll
+            for (int p = 0; p < SF_DMAX; p += 4)
+              if (p < m.D) o4[p >> 2] = make_float4(th[p], th[p + 1], th[p + 2], th[p + 3]);
+          }
+        } else {
+#pragma unroll
+          for (int p = 0; p < SF_DMAX; ++p)
+            if (p < m.D) sf_out_store(a, (size_t)slot * m.D + (int)m.cst[m.c_tdim + p], th[p]);
+        }
       }
       const bool leader = entry_ok && h == 0 && me == 0;
       const uint32_t room = a.attempt_limit > att_base ? a.attempt_limit - att_base : 0u;
