@@ -59,7 +59,10 @@ enum sf_status {
 
 /* SF_NSF_AR: the autoregressive NSF of the reference's second backend (backend="lampe" -> zuko.flows.NSF;
  * ref: src/synference/sbi_runner.py:5123-5125): masked hyper-network + zuko's monotonic rational-quadratic spline */
-enum sf_kind { SF_MAF = 0, SF_NSF = 1, SF_NSF_AR = 2 };
+/* SF_MAF_AR: the MAF of the same backend (backend="lampe", model "maf" -> zuko.flows.MAF, sbi_runner.py:5123-5125): the same masked
+ * hyper-network with two outputs per dimension and zuko's MonotonicAffineTransform as the univariate map
+ * (y = x exp(s / (1 + |s / log slope|)) + shift); K, tail_bound and the spline fields are ignored. */
+enum sf_kind { SF_MAF = 0, SF_NSF = 1, SF_NSF_AR = 2, SF_MAF_AR = 3 };
 
 /* Static description of one flow.  Pointer members are HOST arrays read during
  * sf_flow_create only.  Defaults of the upstream stack (sbi/nflows) in brackets. */

@@ -44,7 +44,7 @@ class FlowSpec:
     every constant is overridable because upstream versions differ.
     """
 
-    kind: str  # "maf" | "nsf" | "nsf_ar" (zuko / lampe autoregressive NSF)
+    kind: str  # "maf" | "nsf" | "nsf_ar" (zuko / lampe autoregressive NSF) | "maf_ar" (zuko / lampe MAF)
     D: int  # theta dimension (flow inputs)
     C: int  # context width seen by the transforms
     H: int = 50  # hidden_features (sbi_runner.py:4402)
@@ -67,7 +67,7 @@ class FlowSpec:
     perms: Optional[np.ndarray] = None  # [T, D] int64, MAF RandomPermutation buffers
 
     def __post_init__(self):
-        assert self.kind in ("maf", "nsf", "nsf_ar")
+        assert self.kind in ("maf", "nsf", "nsf_ar", "maf_ar")
         if self.theta_mean is None:
             self.theta_mean = np.zeros(self.D)
         if self.theta_std is None:
@@ -91,6 +91,11 @@ class FlowSpec:
         tr = list(range(start, self.D, 2))
         idn = [d for d in range(self.D) if d not in tr]
         return idn, tr
+
+    @property
+    def ar_np(self) -> int:
+        """Parameters per dimension of the zuko-style autoregressive flows: 3K - 1 spline slots (nsf_ar), shift + scale (maf_ar)."""
+        return 2 if self.kind == "maf_ar" else 3 * self.K - 1
 
     @property
     def has_lu(self) -> bool:
@@ -137,6 +142,7 @@ def param_layout(spec: FlowSpec) -> List[Tuple[str, Tuple[int, ...], int]]:
            upper[D(D-1)/2] udiag[D] lubias[D]
       NSF with D = 1: csm.W0[H,C] b0[H] W1[H,H] b1[H] W2[3K-1,H] b2[3K-1]
       nsf_ar (zuko): ar.W0[H,D+C] b0[H] {ar.Wk[H,H] bk[H]} x (NB-1)  ar.W_NB[D(3K-1),H] b_NB[D(3K-1)]
+      maf_ar (zuko): the same with 2 rows per dimension in the head ([shift, scale] of MonotonicAffineTransform)
     cfg1 MAF: 6460 per transform; cfg3 NSF: 18314 per transform.
     """
     out: List[Tuple[str, Tuple[int, ...], int]] = []
@@ -156,13 +162,14 @@ def param_layout(spec: FlowSpec) -> List[Tuple[str, Tuple[int, ...], int]]:
             for k in range(spec.NB):
                 add(p + f"W{k + 1}", (H, H)); add(p + f"b{k + 1}", (H,))
             add(p + "Wf", (2 * D, H)); add(p + "bf", (2 * D,))
-        elif spec.kind == "nsf_ar":
+        elif spec.kind in ("nsf_ar", "maf_ar"):
             # zuko MaskedMLP hyper-network of one MaskedAutoregressiveTransform: NB hidden MaskedLinear layers of width H
-            # (lampe / ltu-ili: two), then the head with D * (3K - 1) rows -- per dimension [K widths, K heights, K - 1 derivatives]
+            # (lampe / ltu-ili: two), then the head with D * ar_np rows -- per dimension [K widths, K heights, K - 1 derivatives]
+            # (NSF) or [shift, scale] (MAF)
             add(p + "ar.W0", (H, D + C)); add(p + "ar.b0", (H,))
             for k in range(1, spec.NB):
                 add(p + f"ar.W{k}", (H, H)); add(p + f"ar.b{k}", (H,))
-            add(p + f"ar.W{spec.NB}", (D * (3 * spec.K - 1), H)); add(p + f"ar.b{spec.NB}", (D * (3 * spec.K - 1),))
+            add(p + f"ar.W{spec.NB}", (D * spec.ar_np, H)); add(p + f"ar.b{spec.NB}", (D * spec.ar_np,))
         elif spec.nsf_1d:
             # sbi build_nsf with a scalar theta: ContextSplineMap(hidden_layers=1) -- Linear(C, H), ReLU, Linear(H, H), ReLU,
             # Linear(H, 3K - 1) on the embedded context alone; no LULinear
@@ -331,7 +338,7 @@ def ar_order(spec: FlowSpec, t: int) -> np.ndarray:
 
 def ar_masks(spec: FlowSpec, t: int) -> List[np.ndarray]:
     """Boolean masks [first hidden (H, D+C), later hidden (H, H) x (NB-1), head (D(3K-1), H)] of transform t."""
-    D, C, H, NP = spec.D, spec.C, spec.H, 3 * spec.K - 1
+    D, C, H, NP = spec.D, spec.C, spec.H, spec.ar_np
     order = ar_order(spec, t)
     in_order = np.concatenate([order, np.full(C, -1)])
     typ = np.arange(H) % D                                   # type (= order value) of hidden unit h
@@ -351,7 +358,18 @@ def _ar_hyper(spec: FlowSpec, P: Dict[str, torch.Tensor], t: int, u: torch.Tenso
         h = F.linear(h, P[p + f"W{k}"] * M[k], P[p + f"b{k}"])
         if k < spec.NB:
             h = F.relu(h)
-    return h.view(-1, spec.D, 3 * spec.K - 1)
+    return h.view(-1, spec.D, spec.ar_np)
+
+
+def ar_affine(spec: FlowSpec, v: torch.Tensor, q: torch.Tensor, inverse: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[UPSTREAM, restated from the published zuko sources] zuko.transforms.MonotonicAffineTransform(shift, scale, slope) -- the
+    univariate map of zuko.flows.MAF (`backend="lampe"`, model "maf": ref sbi_runner.py:5123-5125): the scale logit is soft-clipped,
+    log_scale = s / (1 + |s / log slope|), y = x exp(log_scale) + shift, log|dy/dx| = log_scale; v [B, d], q [B, d, 2] = [shift, s]."""
+    shift, sraw = q[..., 0], q[..., 1]
+    ls = sraw / (1 + torch.abs(sraw / math.log(spec.ar_slope)))
+    if inverse:
+        return (v - shift) * torch.exp(-ls), -ls
+    return v * torch.exp(ls) + shift, ls
 
 
 def _ar_knots(spec: FlowSpec, q: torch.Tensor):
@@ -494,10 +512,11 @@ def forward_transform(spec: FlowSpec, flat: torch.Tensor, theta: torch.Tensor, x
             u = s * u + m
             logdet = logdet + torch.log(s).sum(-1)
             u = u[:, torch.as_tensor(spec.perms[t])]
-    elif spec.kind == "nsf_ar":
+    elif spec.kind in ("nsf_ar", "maf_ar"):
+        uni = ar_spline if spec.kind == "nsf_ar" else ar_affine
         for t in range(spec.T):
             q = _ar_hyper(spec, P, t, u, e)
-            u, lad = ar_spline(spec, u, q, inverse=False)
+            u, lad = uni(spec, u, q, inverse=False)
             logdet = logdet + lad.sum(-1)
     else:
         for t in range(spec.T):
@@ -551,7 +570,8 @@ def inverse_transform(spec: FlowSpec, flat: torch.Tensor, z: torch.Tensor, x: to
                 w = (v - m) / s
             logdet = logdet - torch.log(s).sum(-1)
             u = w
-    elif spec.kind == "nsf_ar":
+    elif spec.kind in ("nsf_ar", "maf_ar"):
+        uni = ar_spline if spec.kind == "nsf_ar" else ar_affine
         for t in reversed(range(spec.T)):
             # zuko AutoregressiveTransform._inverse: `passes` = D sweeps of the hyper-network, each inverting every dimension
             # with the parameters of the current iterate; after sweep j the dimensions of order < j are exact
@@ -559,7 +579,7 @@ def inverse_transform(spec: FlowSpec, flat: torch.Tensor, z: torch.Tensor, x: to
             w = torch.zeros_like(v)
             for _ in range(spec.D):
                 q = _ar_hyper(spec, P, t, w, e)
-                w, lad = ar_spline(spec, v, q, inverse=True)
+                w, lad = uni(spec, v, q, inverse=True)
             logdet = logdet + lad.sum(-1)
             u = w
     else:

@@ -64,9 +64,11 @@ def export_zuko(out_dir, seed):
     Files: tests/golden/upstream_zuko_<case>.npz, picked up by tests/test_golden.py through
     synference_amd.importer.spec_and_flat_from_zuko_state_dict."""
     import zuko
-    for tag, D, C, H, T, K in (("nsf_cfg1", 5, 10, 50, 5, 8), ("nsf_small", 3, 4, 17, 2, 5), ("nsf_d1", 1, 6, 16, 3, 8)):
+    for tag, D, C, H, T, K in (("nsf_cfg1", 5, 10, 50, 5, 8), ("nsf_small", 3, 4, 17, 2, 5), ("nsf_d1", 1, 6, 16, 3, 8),
+                               ("maf_cfg1", 5, 10, 50, 5, 0), ("maf_small", 3, 4, 17, 2, 0)):   # K = 0: zuko.flows.MAF (kind "maf_ar")
         torch.manual_seed(seed)
-        flow = zuko.flows.NSF(features=D, context=C, transforms=T, hidden_features=[H, H], bins=K)
+        flow = (zuko.flows.NSF(features=D, context=C, transforms=T, hidden_features=[H, H], bins=K) if K else
+                zuko.flows.MAF(features=D, context=C, transforms=T, hidden_features=[H, H]))
         with torch.no_grad():
             for p in flow.parameters():
                 p.add_(0.3 * p.abs().mean().clamp_min(0.05) * torch.randn_like(p))
@@ -82,9 +84,9 @@ def export_zuko(out_dir, seed):
         out = {"sd/" + k: v.detach().cpu().numpy() for k, v in flow.state_dict().items()}
         out.update(theta=te.numpy(), x=xe.numpy(), log_prob=lp.numpy().astype(np.float64), z=z.numpy(),
                    theta_from_z=th.numpy().astype(np.float64), logabsdet_inv=lad.numpy().astype(np.float64),
-                   meta=np.array(json.dumps(dict(model="zuko_nsf", case=tag, zuko=getattr(zuko, "__version__", "?"), torch=torch.__version__,
+                   meta=np.array(json.dumps(dict(model="zuko_nsf" if K else "zuko_maf", case=tag, zuko=getattr(zuko, "__version__", "?"), torch=torch.__version__,
                                                  numpy=np.__version__, pip_freeze=pip_freeze(),
-                                                 builder_kwargs=dict(features=D, context=C, transforms=T, hidden_features=[H, H], bins=K)))))
+                                                 builder_kwargs=dict(features=D, context=C, transforms=T, hidden_features=[H, H], **({"bins": K} if K else {}))))))
         os.makedirs(out_dir, exist_ok=True)
         path = os.path.join(out_dir, f"upstream_zuko_{tag}.npz")
         np.savez_compressed(path, **out)

@@ -111,7 +111,7 @@ int sf_flow_create(const sf_flow_desc* desc, sf_flow** out) {
     *out = f1;
     return SF_OK;
   }
-  if (desc->kind == SF_NSF_AR) {  // the autoregressive NSF of the lampe / zuko backend (sf_nsfar.hip)
+  if (desc->kind == SF_NSF_AR || desc->kind == SF_MAF_AR) {  // the autoregressive flows of the lampe / zuko backend (sf_nsfar.hip)
     sf_flow* fa = new sf_flow();
     std::string err;
     int rc = sf_nsfar_create(*desc, &fa->nsfar, err);
@@ -121,7 +121,7 @@ int sf_flow_create(const sf_flow_desc* desc, sf_flow** out) {
     std::memset(&fa->L.nsc, 0, sizeof(fa->L.nsc));
     std::memset(&fa->L.nsfS, 0, sizeof(fa->L.nsfS));
     SfDev& v = fa->L.dev;
-    v.kind = SF_NSF_AR; v.D = desc->D; v.C = desc->C; v.H = desc->H; v.T = desc->T; v.K = desc->K; v.NB = desc->NB;
+    v.kind = desc->kind; v.D = desc->D; v.C = desc->C; v.H = desc->H; v.T = desc->T; v.K = desc->K; v.NB = desc->NB;
     fa->L.n_params = fa->nsfar->n_params;
     *out = fa;
     return SF_OK;
@@ -232,7 +232,7 @@ int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen) {
   auto add = [&](const char* k, long val) { s += "\"" + std::string(k) + "\": " + std::to_string(val) + ", "; };
   if (f->nsfar) {   // the autoregressive NSF has its own images (sf_nsfar.h)
     const SfNsfAr& n = *f->nsfar;
-    add("kind", SF_NSF_AR); add("D", n.D); add("C", n.C); add("H", n.H); add("T", n.T); add("K", n.K); add("NB", 2);
+    add("kind", n.affine ? SF_MAF_AR : SF_NSF_AR); add("D", n.D); add("C", n.C); add("H", n.H); add("T", n.T); add("K", n.K); add("NB", 2);
     add("Hp", n.Hp); add("t_stride", n.t_stride); add("n_params", (long)n.n_params); add("n_packed", (long)n.src.size());
     add("o_L0t", n.o_L0t); add("o_b0", n.o_b0); add("o_L1t", n.o_L1t); add("o_L1m", n.o_L1m); add("o_b1", n.o_b1);
     add("o_L2t", n.o_L2t); add("o_b2", n.o_b2); add("o_L0m", n.o_L0m); add("o_L2m", n.o_L2m); add("lds_bytes_train", (long)sf_nsfar_lds_bytes(n, 3));

@@ -24,6 +24,7 @@ struct SfNsfAr {
   float* d_img = nullptr;
   int32_t *d_src = nullptr, *d_none = nullptr, *d_perm = nullptr, *d_ptype = nullptr, *d_tend = nullptr, *d_ord = nullptr, *d_dimof = nullptr;
   float *d_xmean = nullptr, *d_xstd = nullptr;
+  int affine = 0;               // SF_MAF_AR (zuko MAF): MonotonicAffineTransform instead of the spline
   float* d_ustash = nullptr;
   size_t ustash_cap = 0;
   int32_t* d_gal = nullptr;              // [2][M]: attempts / accepted draws per row (progress rule of the uncapped sampler)

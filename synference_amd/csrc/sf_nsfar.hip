@@ -53,6 +53,7 @@ struct ArArgs {
   const float* xmean;     // [C]
   const float* xstd;      // [C]
   int D, C, H, Hp, T, K, NP, NIN16, NIN4;
+  int affine;             // SF_MAF_AR: the univariate map is zuko's MonotonicAffineTransform (slots 0 = shift, 1 = log-scale logit)
   long t_stride;          // floats per transform in img
   int o_L0t, o_b0, o_L1t, o_L1m, o_b1, o_L2t, o_b2, o_L0m, o_L2m;
   long P_t;               // logical parameters per transform
@@ -109,6 +110,47 @@ __device__ __forceinline__ ar_f32x4 ar_rowsum16(const float* A, int o0, int lane
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc0[r] += acc1[r];
   return acc0;
+}
+
+// The univariate map of dimension d from its parameter slots q: the rational-quadratic spline (zuko NSF), or -- a.affine, zuko
+// MAF -- MonotonicAffineTransform: out = v exp(ls) + q[0], ls = q[1] / (1 + |q[1] / log slope|), log|d out / d v| = ls.
+__device__ __forceinline__ void ar_uni_fwd(const ArArgs& a, const ZSplC& sc, const float (&q)[ARQ], float v, float& out, float& lad) {
+  if (a.affine) {
+    const float ls = ZS::clip(q[1], sc.cd);
+    out = v * sf_exp(ls) + q[0];
+    lad = ls;
+  } else {
+    ZS::fwd(sc, q, v, out, lad);
+  }
+}
+__device__ __forceinline__ void ar_uni_inv(const ArArgs& a, const ZSplC& sc, const float (&q)[ARQ], float v, float& out, float& lad) {
+  if (a.affine) {
+    const float ls = ZS::clip(q[1], sc.cd);
+    out = (v - q[0]) * sf_exp(-ls);
+    lad = -ls;
+  } else {
+    ZS::inv(sc, q, v, out, lad);
+  }
+}
+// Go = dL / d out, Gl = dL / d lad  ->  dv = dL / d v, dq = dL / d q
+__device__ __forceinline__ void ar_uni_bwd(const ArArgs& a, const ZSplC& sc, const float (&q)[ARQ], float v, float Go, float Gl, float& dv,
+                                           float (&dq)[ARQ]) {
+  if (a.affine) {
+#pragma unroll
+    for (int i = 0; i < ARQ; ++i) dq[i] = 0.f;
+    const float e = sf_exp(ZS::clip(q[1], sc.cd));
+    dv = Go * e;
+    dq[0] = Go;
+    dq[1] = (Go * v * e + Gl) * ZS::dclip(q[1], sc.cd);
+  } else {
+    ZS::bwd(sc, q, v, Go, Gl, dv, dq);
+  }
+}
+// parameter slot sl of a dimension (family sl >> 3, index sl & 7) -> row of the dimension's block in the logical head, -1 = none
+__device__ __forceinline__ int ar_slot_row(const ArArgs& a, int sl) {
+  const int fam = sl >> 3, kk = sl & 7;
+  if (a.affine) return (fam == 0 && kk < 2) ? kk : -1;
+  return (sl < ARQ - 1 && kk < (fam < 2 ? a.K : a.K - 1)) ? fam * a.K + kk : -1;
 }
 
 // order the LDS traffic of ONE wave (its LDS operations execute in program order: a read issued after a write of another lane
@@ -324,7 +366,7 @@ __global__ __launch_bounds__(64 * NWV) void k_ar_logprob(ArArgs a, const float* 
       ar_head(a, tp, d, (int)a.tendk[a.ord[t * a.D + d]], H2, QB, lane, q);
       AR_TS(3 + t * 40 + 2 * d);
       float v, lad;
-      ZS::fwd(sc, q, E0[d * RS + lane], v, lad);
+      ar_uni_fwd(a, sc, q, E0[d * RS + lane], v, lad);
       E0[d * RS + lane] = v;   // (every parameter of this transform has been taken from the inputs already)
       ld += lad;
       AR_TS(4 + t * 40 + 2 * d);
@@ -373,7 +415,7 @@ __device__ __forceinline__ float ar_inverse_transform(const ArArgs& a, const ZSp
       ar_touch(pre, 4, tq + a.o_L2t, a.D * ARQ, dn * ARQ, 0, q_hi, lane);
     }
     float w, lad;
-    ZS::inv(sc, q, V[d * RS + lane], w, lad);
+    ar_uni_inv(a, sc, q, V[d * RS + lane], w, lad);
     E0[d * RS + lane] = w;
     ld += lad;
     ar_keep(pre);
@@ -668,7 +710,7 @@ __global__ __launch_bounds__(64 * NWV) void k_ar_train(ArArgs a, const float* __
       float q[ARQ];
       ar_head(a, tp, d, (int)a.tendk[a.ord[t * a.D + d]], H2, QB, lane, q);
       float v, lad;
-      ZS::fwd(sc, q, E0[d * RS + lane], v, lad);
+      ar_uni_fwd(a, sc, q, E0[d * RS + lane], v, lad);
       E0[d * RS + lane] = v;
       ld += lad;
     }
@@ -717,7 +759,7 @@ __global__ __launch_bounds__(64 * NWV) void k_ar_train(ArArgs a, const float* __
       ar_head(a, tp, d, kend, H2, QB, lane, q);
       AR_TS(102 + 4 * d);
       float dv;
-      ZS::bwd(sc, q, E0[d * RS + lane], GG[d * RS + lane], -wb, dv, dq);
+      ar_uni_bwd(a, sc, q, E0[d * RS + lane], GG[d * RS + lane], -wb, dv, dq);
       AR_TS(103 + 4 * d);
       DV[d * RS + lane] = dv;
       dq[ARQ - 1] = 0.f;
@@ -733,17 +775,16 @@ __global__ __launch_bounds__(64 * NWV) void k_ar_train(ArArgs a, const float* __
           const int kl = k < kend ? PERM[k] : -1;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int sl = it * 16 + 4 * (lane >> 4) + r, fam = sl >> 3, kk = sl & 7;
-            if (kl >= 0 && sl < ARQ - 1 && kk < (fam < 2 ? a.K : a.K - 1))
-              unsafeAtomicAdd(gt + a.l_W2 + (size_t)(d * a.NP + fam * a.K + kk) * a.H + kl, g4[r]);
+            const int lr = ar_slot_row(a, it * 16 + 4 * (lane >> 4) + r);
+            if (kl >= 0 && lr >= 0) unsafeAtomicAdd(gt + a.l_W2 + (size_t)(d * a.NP + lr) * a.H + kl, g4[r]);
           }
         }
         const ar_f32x4 b4 = ar_rowsum16(QB, it * 16, lane);
         if ((lane & 15) == 0) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int sl = it * 16 + 4 * (lane >> 4) + r, fam = sl >> 3, kk = sl & 7;
-            if (sl < ARQ - 1 && kk < (fam < 2 ? a.K : a.K - 1)) unsafeAtomicAdd(gt + a.l_b2 + d * a.NP + fam * a.K + kk, b4[r]);
+            const int lr = ar_slot_row(a, it * 16 + 4 * (lane >> 4) + r);
+            if (lr >= 0) unsafeAtomicAdd(gt + a.l_b2 + d * a.NP + lr, b4[r]);
           }
         }
       }
@@ -838,6 +879,7 @@ ArArgs args_of(const SfNsfAr& n) {
   ArArgs a;
   a.img = n.d_img; a.perm = n.d_perm; a.ptype = n.d_ptype; a.tend = n.d_tend; a.ord = n.d_ord; a.dimof = n.d_dimof;
   a.xmean = n.d_xmean; a.xstd = n.d_xstd;
+  a.affine = n.affine;
   a.D = n.D; a.C = n.C; a.H = n.H; a.Hp = n.Hp; a.T = n.T; a.K = n.K; a.NP = n.NP; a.NIN16 = (n.D + n.C + 15) / 16 * 16; a.NIN4 = (n.D + n.C + 3) / 4 * 4;
   a.t_stride = n.t_stride;
   a.o_L0t = n.o_L0t; a.o_b0 = n.o_b0; a.o_L1t = n.o_L1t; a.o_L1m = n.o_L1m; a.o_b1 = n.o_b1; a.o_L2t = n.o_L2t; a.o_b2 = n.o_b2; a.o_L0m = n.o_L0m; a.o_L2m = n.o_L2m;
@@ -865,15 +907,17 @@ hipError_t set_lds(Kern k, size_t bytes) {
 
 int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err) {
   if (d.D < 1 || d.D > 16) { err = "autoregressive NSF: D must be in 1..16"; return SF_ERR_INVALID; }
-  if (d.K < 2 || d.K > ARK) { err = "autoregressive NSF: K (bins) must be in 2..8"; return SF_ERR_INVALID; }
+  const bool affine = d.kind == SF_MAF_AR;
+  if (!affine && (d.K < 2 || d.K > ARK)) { err = "autoregressive NSF: K (bins) must be in 2..8"; return SF_ERR_INVALID; }
   if (d.NB != 2) { err = "autoregressive NSF: two hidden layers (NB = 2: lampe / ltu-ili's hyper-network) are built"; return SF_ERR_INVALID; }
   if (d.H < d.D || d.H > 192) { err = "autoregressive NSF: H must be in D..192"; return SF_ERR_INVALID; }
   if (d.C < 1 || d.C > 256 || d.T < 1 || d.T > 64) { err = "autoregressive NSF: C in 1..256, T in 1..64"; return SF_ERR_INVALID; }
   if (!d.theta_mean || !d.theta_std || !d.x_mean || !d.x_std) { err = "z-score buffers must be given"; return SF_ERR_INVALID; }
   if (!(d.ar_slope > 0.f && d.ar_slope < 1.f)) { err = "ar_slope must be in (0, 1)"; return SF_ERR_INVALID; }
   SfNsfAr* n = new SfNsfAr();
-  const int D = d.D, C = d.C, H = d.H, T = d.T, K = d.K, NP = 3 * K - 1;
-  n->D = D; n->C = C; n->H = H; n->T = T; n->K = K; n->NP = NP;
+  // (affine = zuko MAF: two parameters per dimension, carried in slots 0 and 1 of family 0 -- "K = 2, widths only")
+  const int D = d.D, C = d.C, H = d.H, T = d.T, K = affine ? 2 : d.K, NP = affine ? 2 : 3 * K - 1;
+  n->D = D; n->C = C; n->H = H; n->T = T; n->K = K; n->NP = NP; n->affine = affine ? 1 : 0;
   n->bound = d.tail_bound;
   const double ls = std::fabs(std::log((double)d.ar_slope));
   n->cw = (float)(2.0 / ls); n->cd = (float)(1.0 / ls);
@@ -953,7 +997,7 @@ int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err) {
       }
     }
     for (int dd = 0; dd < D; ++dd)
-      for (int fam = 0; fam < 3; ++fam)
+      for (int fam = 0; fam < (affine ? 1 : 3); ++fam)
         for (int kk = 0; kk < (fam < 2 ? K : K - 1); ++kk) {
           const int slot = dd * ARQ + fam * 8 + kk, lrow = dd * NP + fam * K + kk;
           s[n->o_b2 + slot] = (int32_t)(base + n->l_b2 + lrow);

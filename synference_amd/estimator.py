@@ -151,14 +151,15 @@ def build_flow(model: str, batch_theta, batch_x, hidden_features: int = 50, num_
                generator: Optional[torch.Generator] = None, backend: str = "sbi", **extra) -> FlowEstimator:
     """sbi ``build_maf`` / ``build_nsf`` ([UPSTREAM]) on the HIP engine; with ``backend="lampe"``
     the flow ``ili.utils.load_nde_lampe(model="nsf")`` builds: ``zuko.flows.NSF(D, C, transforms=num_transforms,
-    hidden_features=[hidden_features] * 2)`` -- 8 bins, bound 5, autoregressive -- behind standardising affines."""
+    hidden_features=[hidden_features] * 2)`` -- 8 bins, bound 5, autoregressive -- behind standardising affines; ``model="maf"`` there
+    is ``zuko.flows.MAF``: the same hyper-network with zuko's MonotonicAffineTransform as the univariate map (kind ``maf_ar``)."""
     if model not in SUPPORTED_MODELS:
         raise ValueError(f"model '{model}' is not on the HIP path; supported: {SUPPORTED_MODELS}")
     fixed = {}
     if backend == "lampe":
-        if model != "nsf":
-            raise ValueError(f"backend 'lampe': only model 'nsf' (zuko.flows.NSF) is on the HIP path, not '{model}'")
-        model = "nsf_ar"
+        if model not in ("nsf", "maf"):
+            raise ValueError(f"backend 'lampe': models 'nsf' (zuko.flows.NSF) and 'maf' (zuko.flows.MAF) are on the HIP path, not '{model}'")
+        model = "nsf_ar" if model == "nsf" else "maf_ar"
         num_bins = 8 if num_bins is None else num_bins
         num_blocks = 2
         fixed = dict(tail_bound=5.0)
@@ -210,8 +211,8 @@ def load_nde_hip(engine: str = "NPE", model: str = "maf", embedding_net: Optiona
         raise ValueError(f"model '{model}' is not on the HIP path; supported: {SUPPORTED_MODELS}")
     if backend not in ("sbi", "lampe"):
         raise ValueError(f"backend '{backend}' is not on the HIP path: 'sbi' or 'lampe'")
-    if backend == "lampe" and model != "nsf":
-        raise ValueError(f"backend 'lampe': only model 'nsf' (zuko.flows.NSF) is on the HIP path, not '{model}'")
+    if backend == "lampe" and model not in ("nsf", "maf"):
+        raise ValueError(f"backend 'lampe': models 'nsf' (zuko.flows.NSF) and 'maf' (zuko.flows.MAF) are on the HIP path, not '{model}'")
     model_args.pop("device", None)
 
     def build_fn(batch_theta=None, batch_x=None, device="cuda:0", generator=None):

@@ -331,7 +331,8 @@ def zuko_masks(D: int, C: int, H: int, NP: int, order: np.ndarray):
 
 def spec_and_flat_from_zuko_state_dict(state_dict: Mapping[str, object], tail_bound: float = 5.0, ar_slope: float = 1e-3,
                                        theta_mean=None, theta_std=None, x_mean=None, x_std=None) -> Tuple[FlowSpec, np.ndarray]:
-    """(FlowSpec(kind="nsf_ar"), flat float32 vector) of a ``zuko.flows.NSF`` ``state_dict``."""
+    """(FlowSpec(kind="nsf_ar"), flat float32 vector) of a ``zuko.flows.NSF`` ``state_dict``; a head with TWO rows per dimension is a
+    ``zuko.flows.MAF`` (MonotonicAffineTransform: [shift, scale]) and gives kind ``maf_ar``."""
     layers: Dict[int, Dict[int, Dict[str, np.ndarray]]] = {}
     orders: Dict[int, np.ndarray] = {}
     for k, v in state_dict.items():
@@ -362,11 +363,11 @@ def spec_and_flat_from_zuko_state_dict(state_dict: Mapping[str, object], tail_bo
     if C < 1 or W2.shape[0] % D:
         raise ValueError(f"shapes do not fit an autoregressive NSF with context: W0 {W0.shape}, head {W2.shape}, D = {D}")
     NP = W2.shape[0] // D
-    if (NP + 1) % 3:
-        raise ValueError(f"{NP} parameters per dimension are not 3 K - 1")
-    K = (NP + 1) // 3
+    if NP != 2 and (NP + 1) % 3:
+        raise ValueError(f"{NP} parameters per dimension are neither 2 (zuko MAF) nor 3 K - 1 (zuko NSF)")
+    K = 8 if NP == 2 else (NP + 1) // 3
     f = lambda a, n, fill: np.full(n, fill, np.float32) if a is None else np.asarray(a, np.float32).reshape(n)
-    spec = FlowSpec(kind="nsf_ar", D=D, C=C, H=H, T=T, K=K, NB=2, tail_bound=float(tail_bound), ar_slope=float(ar_slope),
+    spec = FlowSpec(kind="maf_ar" if NP == 2 else "nsf_ar", D=D, C=C, H=H, T=T, K=K, NB=2, tail_bound=float(tail_bound), ar_slope=float(ar_slope),
                     theta_mean=f(theta_mean, D, 0.0), theta_std=f(theta_std, D, 1.0), x_mean=f(x_mean, C, 0.0), x_std=f(x_std, C, 1.0))
     flat = np.zeros(num_params(spec), np.float32)
     lay = {n: (s, o) for n, s, o in param_layout(spec)}
@@ -395,11 +396,11 @@ def spec_and_flat_from_zuko_state_dict(state_dict: Mapping[str, object], tail_bo
 
 def zuko_state_dict_from_flat(spec: FlowSpec, flat, prefix: str = "") -> Dict[str, np.ndarray]:
     """The inverse mapping: zuko's module paths with the mask and order buffers (for handing weights back, and for the tests)."""
-    if spec.kind != "nsf_ar" or spec.NB != 2:
-        raise ValueError("zuko_state_dict_from_flat takes an nsf_ar spec with two hidden layers")
+    if spec.kind not in ("nsf_ar", "maf_ar") or spec.NB != 2:
+        raise ValueError("zuko_state_dict_from_flat takes an nsf_ar / maf_ar spec with two hidden layers")
     flat = _np(flat).astype(np.float32)
     out: Dict[str, np.ndarray] = {}
-    NP = 3 * spec.K - 1
+    NP = spec.ar_np
     lay = {n: (s, o) for n, s, o in param_layout(spec)}
     for t in range(spec.T):
         order = np.arange(spec.D) if t % 2 == 0 else np.arange(spec.D)[::-1]

@@ -16,12 +16,12 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 import torch
 
-KIND_ID = {"maf": 0, "nsf": 1, "nsf_ar": 2}
+KIND_ID = {"maf": 0, "nsf": 1, "nsf_ar": 2, "maf_ar": 3}
 
 
 @dataclass
 class FlowSpec:
-    kind: str               # "maf" | "nsf" | "nsf_ar" (the autoregressive NSF of the lampe / zuko backend)
+    kind: str               # "maf" | "nsf" | "nsf_ar" / "maf_ar" (the autoregressive NSF / MAF of the lampe / zuko backend)
     D: int                  # theta dimension
     C: int                  # context width seen by the transforms
     H: int = 50             # hidden_features (ref default: sbi_runner.py:4402)
@@ -46,7 +46,7 @@ class FlowSpec:
     def __post_init__(self):
         if self.kind not in KIND_ID:
             raise ValueError(
-                f"model '{self.kind}' is not built by the HIP backend: only 'maf', 'nsf' and 'nsf_ar' "
+                f"model '{self.kind}' is not built by the HIP backend: only 'maf', 'nsf', 'nsf_ar' and 'maf_ar' "
                 "(NPE, direct sampling) are on the accelerated path")
         f = lambda a, n, fill: (np.full(n, fill, np.float32) if a is None
                                 else np.ascontiguousarray(np.asarray(a, dtype=np.float32).reshape(n)))
@@ -62,6 +62,11 @@ class FlowSpec:
         start = 0 if t % 2 == 0 else 1
         tr = list(range(start, self.D, 2))
         return [d for d in range(self.D) if d not in tr], tr
+
+    @property
+    def ar_np(self) -> int:
+        """Head rows per dimension of the zuko-style flows: 3K - 1 spline slots (nsf_ar), [shift, scale] (maf_ar)."""
+        return 2 if self.kind == "maf_ar" else 3 * self.K - 1
 
     @property
     def has_lu(self) -> bool:
@@ -113,11 +118,11 @@ def param_layout(spec: FlowSpec) -> List[Tuple[str, Tuple[int, ...], int]]:
             for k in range(spec.NB):
                 add(p + f"W{k + 1}", (H, H)); add(p + f"b{k + 1}", (H,))
             add(p + "Wf", (2 * D, H)); add(p + "bf", (2 * D,))
-        elif spec.kind == "nsf_ar":   # zuko MaskedMLP hyper-network: [theta ; context] -> H x NB -> D (3K - 1)
+        elif spec.kind in ("nsf_ar", "maf_ar"):   # zuko MaskedMLP hyper-network: [theta ; context] -> H x NB -> D (3K - 1) | D x 2
             add(p + "ar.W0", (H, D + Cc)); add(p + "ar.b0", (H,))
             for k in range(1, spec.NB):
                 add(p + f"ar.W{k}", (H, H)); add(p + f"ar.b{k}", (H,))
-            add(p + f"ar.W{spec.NB}", (D * (3 * spec.K - 1), H)); add(p + f"ar.b{spec.NB}", (D * (3 * spec.K - 1),))
+            add(p + f"ar.W{spec.NB}", (D * spec.ar_np, H)); add(p + f"ar.b{spec.NB}", (D * spec.ar_np,))
         elif spec.nsf_1d:
             add(p + "csm.W0", (H, Cc)); add(p + "csm.b0", (H,)); add(p + "csm.W1", (H, H)); add(p + "csm.b1", (H,))
             add(p + "csm.W2", (3 * spec.K - 1, H)); add(p + "csm.b2", (3 * spec.K - 1,))

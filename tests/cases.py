@@ -52,6 +52,9 @@ CASES = {
     # the widest member of the reference's own lampe example (examples/sbi/scripts/basic_model.py:31-41: hidden_features 180): seven
     # types of 25-26 units padded to 32 rows each; fits since the training sweep runs on two hidden buffers
     "nsfar_h180": ("nsf_ar", 7, 12, 180, 2, 8, dict(tail_bound=5.0)),
+    # zuko.flows.MAF -- `backend="lampe"`, model "maf" (ref: sbi_runner.py:5123-5125): the same masked hyper-network, affine univariate
+    "mafar_cfg1": ("maf_ar", 5, 10, 50, 5, 8, dict(tail_bound=5.0)),
+    "mafar_small": ("maf_ar", 3, 4, 17, 2, 8, dict(tail_bound=5.0, ar_slope=1e-2)),
 }
 
 

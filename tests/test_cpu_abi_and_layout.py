@@ -78,7 +78,11 @@ def _check_nsfar_images(hf, d, ospec, spec, flat, theta, x):
         L2t = tp[d["o_L2t"]: d["o_L2t"] + Hp * D * 24].reshape(Hp, D * 24)
         kend = tend[ord_[t, dd]]
         q24 = h2[:, :kend] @ L2t[:kend, dd * 24: dd * 24 + 24] + tp[d["o_b2"] + dd * 24: d["o_b2"] + dd * 24 + 24]
+        if spec.kind == "maf_ar":   # zuko MAF: [shift, scale] in slots 0, 1
+            return q24[:, 0:2]
         return np.concatenate([q24[:, 0:K], q24[:, 8:8 + K], q24[:, 16:16 + K - 1]], axis=1)
+
+    uni = OF.ar_affine if spec.kind == "maf_ar" else OF.ar_spline
 
     u = th.copy()
     stash = []
@@ -87,7 +91,7 @@ def _check_nsfar_images(hf, d, ospec, spec, flat, theta, x):
         stash.append(u.copy())
         _, h2 = hidden(tp, np.concatenate([u, e], 1))
         q = np.stack([head(tp, t, dd, h2) for dd in range(D)], 1)
-        v, lad = OF.ar_spline(ospec, torch.as_tensor(u), torch.as_tensor(q), inverse=False)
+        v, lad = uni(ospec, torch.as_tensor(u), torch.as_tensor(q), inverse=False)
         u = v.numpy(); ld += lad.numpy().sum(1)
     got = -0.5 * (u ** 2).sum(1) - 0.5 * D * np.log(2 * np.pi) + ld
     ref = oracle_log_prob(ospec, flat, theta, x)
@@ -104,7 +108,7 @@ def _check_nsfar_images(hf, d, ospec, spec, flat, theta, x):
         h2[:, lo:hi] = np.maximum(h1[:, :hi] @ L1t[:hi, lo:hi] + tp[d["o_b1"] + lo: d["o_b1"] + hi], 0.0)
         dd = dimof[t, r]
         q = head(tp, t, dd, h2)[:, None, :]
-        back, _ = OF.ar_spline(ospec, torch.as_tensor(u[:, dd:dd + 1]), torch.as_tensor(q), inverse=True)
+        back, _ = uni(ospec, torch.as_tensor(u[:, dd:dd + 1]), torch.as_tensor(q), inverse=True)
         w[:, dd] = back.numpy()[:, 0]
     assert np.abs(w - stash[-1]).max() < 1e-9
 
@@ -120,7 +124,7 @@ def test_packer_plus_wave_model_reproduce_oracle(name):
                                                                                  + (3 * spec.K - 1) * (spec.H + 1))
         assert len(hf.pack_table()[0]) == 0 and hf.trainc_table() is None
         return
-    if spec.kind == "nsf_ar":
+    if spec.kind in ("nsf_ar", "maf_ar"):
         _check_nsfar_images(hf, d, ospec, spec, flat, theta, x)
         return
     s1, s2 = hf.pack_table()

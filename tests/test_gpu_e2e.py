@@ -203,8 +203,12 @@ def test_lampe_backend_fits_the_autoregressive_nsf(tmp_path):
     net = load_nde_hip("NPE", model="nsf", backend="lampe", hidden_features=32, num_transforms=3, device="cuda")
     est = net(batch_theta=theta[:500], batch_x=x[:500])
     assert est.spec.kind == "nsf_ar" and est.spec.K == 8 and est.spec.tail_bound == 5.0 and est.flow.train_path(256) == 5
-    with pytest.raises(ValueError, match="lampe"):
-        load_nde_hip("NPE", model="maf", backend="lampe")
+    with pytest.raises(ValueError, match="not on the HIP path"):
+        load_nde_hip("NPE", model="mdn", backend="lampe")
+    # model "maf" of the same backend = zuko.flows.MAF (affine univariate map on the same hyper-network)
+    est_m = load_nde_hip("NPE", model="maf", backend="lampe", hidden_features=32, num_transforms=3, device="cuda")(batch_theta=theta[:500],
+                                                                                                                 batch_x=x[:500])
+    assert est_m.spec.kind == "maf_ar" and est_m.flow.train_path(256) == 5
     f = SBI_Fitter("lampe_nsf", names, [f"F{i}" for i in range(10)], feature_array=x, parameter_array=theta)
     post, stats = f.run_single_sbi(backend="lampe", model_type="nsf", hidden_features=32, num_transforms=3, training_batch_size=256,
                                    learning_rate=2e-3, stop_after_epochs=2, max_num_epochs=6, random_seed=1,
@@ -215,6 +219,13 @@ def test_lampe_backend_fits_the_autoregressive_nsf(tmp_path):
     assert s.shape == (10, 100, 5) and np.isfinite(s).all() and (s >= lo - 1e-6).all() and (s <= hi + 1e-6).all()
     lp = f.log_prob(f._X_test[:10], f._y_test[:10], norm_posterior=False)
     assert np.isfinite(np.asarray(lp)).all()
+    fm = SBI_Fitter("lampe_maf", names, [f"F{i}" for i in range(10)], feature_array=x, parameter_array=theta)
+    postm, statsm = fm.run_single_sbi(backend="lampe", model_type="maf", hidden_features=32, num_transforms=3, training_batch_size=256,
+                                      learning_rate=2e-3, stop_after_epochs=2, max_num_epochs=6, random_seed=1, save_model=False,
+                                      verbose=False, plot=False, evaluate_model=False)
+    assert postm.posteriors[0].spec.kind == "maf_ar" and statsm[0]["training_loss"][-1] < statsm[0]["training_loss"][0] - 0.5
+    sm = fm.sample_posterior(fm._X_test[:10], num_samples=100, seed=3)
+    assert sm.shape == (10, 100, 5) and np.isfinite(sm).all() and (sm >= lo - 1e-6).all() and (sm <= hi + 1e-6).all()
 
 
 def test_lampe_reference_example_ensemble_fits(tmp_path):

@@ -103,7 +103,7 @@ def test_tiny_and_empty_batches():
 
 
 @pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "nsf_odd", "nsf_h69", "maf_span6", "maf_d2_span", "maf_d4", "maf_d3", "maf_sig2", "nsf_d1",
-                                  "nsfar_cfg1", "nsfar_small", "nsfar_d1", "nsfar_wide", "nsfar_h180"])
+                                  "nsfar_cfg1", "nsfar_small", "nsfar_d1", "nsfar_wide", "nsfar_h180", "mafar_cfg1", "mafar_small"])
 def test_sampler_matches_oracle_draw_for_draw(name):
     _draw_for_draw(name)
 

@@ -85,6 +85,8 @@ def _configs_other_kinds():
         out.append(("nsf", 1, int(rng.choice([1, 3, 8, 33, 70])), int(rng.choice([4, 17, 50, 64, 128])), int(rng.integers(1, 7)),
                     int(rng.integers(2, 17)), 300 + i))
     out += [("nsf_ar", 16, 64, 128, 1, 8, 400), ("nsf_ar", 2, 1, 2, 3, 2, 401), ("nsf_ar", 3, 5, 192, 1, 8, 402)]
+    # zuko.flows.MAF (backend="lampe", model "maf"): the same engine with the affine univariate map
+    out += [("maf_ar", 5, 10, 50, 5, 8, 500), ("maf_ar", 1, 3, 16, 2, 8, 501), ("maf_ar", 16, 31, 100, 2, 8, 502), ("maf_ar", 7, 9, 33, 3, 8, 503)]
     return out
 
 
@@ -94,7 +96,7 @@ def test_random_config_of_the_other_flow_kinds_matches_oracle(kind, D, C, H, T, 
     rng = np.random.default_rng(seed)
     st = dict(theta_mean=rng.normal(size=D).astype(np.float32), theta_std=rng.uniform(0.5, 2, size=D).astype(np.float32),
               x_mean=rng.normal(size=C).astype(np.float32), x_std=rng.uniform(0.5, 2, size=C).astype(np.float32))
-    extra = dict(tail_bound=5.0, ar_slope=float(rng.choice([1e-3, 1e-2]))) if kind == "nsf_ar" else {}
+    extra = dict(tail_bound=5.0, ar_slope=float(rng.choice([1e-3, 1e-2]))) if kind in ("nsf_ar", "maf_ar") else {}
     ospec = OF.FlowSpec(kind=kind, D=D, C=C, H=H, T=T, K=K, **extra, **{k: v.astype(np.float64) for k, v in st.items()})
     spec = FlowSpec(kind=kind, D=D, C=C, H=H, T=T, K=K, **extra, **st)
     flat = OF.init_params(ospec, seed + 1)
@@ -103,7 +105,7 @@ def test_random_config_of_the_other_flow_kinds_matches_oracle(kind, D, C, H, T, 
     theta = (rng.normal(size=(B, D)) * st["theta_std"] * 1.2 + st["theta_mean"]).astype(np.float32)
     x = (rng.normal(size=(B, C)) * st["x_std"] + st["x_mean"]).astype(np.float32)
     z = rng.normal(size=(B, D)).astype(np.float32)
-    if kind == "nsf_ar":   # a wave's rows must fit the CU's LDS: shapes beyond that are refused at creation, by name
+    if kind in ("nsf_ar", "maf_ar"):   # a wave's rows must fit the CU's LDS: shapes beyond that are refused at creation, by name
         Hp = sum((len(range(r, H, D)) + 7) // 8 * 8 for r in range(D))
         Hp = (Hp + 15) // 16 * 16
         rows = (D + C + 15) // 16 * 16 + 2 * Hp + 32 + 2 * D     # (two hidden buffers since round 5: training included)

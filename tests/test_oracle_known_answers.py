@@ -418,3 +418,39 @@ def test_autoregressive_nsf_density_integrates_to_one_2d():
     tt = torch.stack(torch.meshgrid(g, g, indexing="ij"), -1).reshape(-1, 2)
     lp = OF.log_prob(spec, p, tt, x.expand(len(tt), -1))
     assert abs(torch.exp(lp).sum().item() * (g[1] - g[0]).item() ** 2 - 1.0) < 2e-3
+
+
+# ---- the MAF of the lampe / zuko backend (oracle kind "maf_ar": zuko.flows.MAF) -------------------------------------------------
+@pytest.mark.parametrize("D,C", [(1, 3), (3, 2), (6, 4)])
+def test_zuko_maf_inverse_logdet_jacobian_and_affine_known_answers(D, C):
+    """zuko.flows.MAF = the same MaskedAutoregressiveTransform with MonotonicAffineTransform(shift, scale, slope): the scale logit
+    is soft-clipped -- log_scale = s / (1 + |s / log slope|), so |log_scale| < |log slope| whatever the network says --, zero
+    parameters are the identity, a transform's Jacobian is triangular in its order with exp(log_scale) on the diagonal, the
+    inverse undoes the forward pass to 1e-10 and the log-determinants agree with autograd's."""
+    spec = OF.FlowSpec(kind="maf_ar", D=D, C=C, H=12, T=3, K=8, tail_bound=5.0)
+    assert spec.ar_np == 2 and OF.num_params(spec) == 3 * (12 * (D + C) + 12 + 12 * 12 + 12 + 2 * D * 12 + 2 * D)
+    p = _rand_params(spec)
+    g = torch.Generator().manual_seed(0)
+    th = torch.randn(9, D, generator=g, dtype=torch.float64) * 2.0
+    x = torch.randn(9, C, generator=g, dtype=torch.float64)
+    z, ld = OF.forward_transform(spec, p, th, x)
+    th2, ld2 = OF.inverse_transform(spec, p, z, x)
+    assert (th2 - th).abs().max() < 1e-10 and (ld + ld2).abs().max() < 1e-10
+    for i in range(2):
+        J = torch.autograd.functional.jacobian(lambda t: OF.forward_transform(spec, p, t[None], x[i:i + 1])[0][0], th[i])
+        assert abs(torch.linalg.slogdet(J)[1].item() - ld[i].item()) < 1e-10
+    v = torch.linspace(-3, 3, 7, dtype=torch.float64)[:, None]
+    out, lad = OF.ar_affine(spec, v, torch.zeros(7, 1, 2, dtype=torch.float64), inverse=False)
+    assert torch.equal(out, v) and torch.equal(lad, torch.zeros_like(lad))
+    q = torch.tensor([[[0.7, 1e9]], [[-0.2, -1e9]]], dtype=torch.float64)
+    out, lad = OF.ar_affine(spec, torch.ones(2, 1, dtype=torch.float64), q, inverse=False)
+    ls = abs(math.log(spec.ar_slope))
+    assert abs(lad[0, 0].item() - ls) < 1e-6 and abs(lad[1, 0].item() + ls) < 1e-6        # clipped to +-|log slope|
+    assert abs(out[0, 0].item() - (math.exp(lad[0, 0].item()) + 0.7)) < 1e-9
+    one = OF.FlowSpec(kind="maf_ar", D=max(D, 2), C=C, H=12, T=1, K=8)
+    p1 = _rand_params(one)
+    u = torch.randn(one.D, dtype=torch.float64)
+    e = torch.randn(1, C, dtype=torch.float64)
+    J = torch.autograd.functional.jacobian(lambda t: OF.forward_transform(one, p1, t[None], e)[0][0], u)
+    assert torch.equal(J.triu(1), torch.zeros_like(J.triu(1))) and (torch.diagonal(J) > 0).all()
+
