@@ -272,7 +272,7 @@ int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen) {
   }
   add("o16_w0", v.o16_w0); add("o16_wc", v.o16_wc); add("o16_b0", v.o16_b0); add("o16_wk0", v.o16_wk[0]);
   add("o16_wk1", v.o16_wk[1]); add("o16_bk0", v.o16_bk[0]); add("o16_bk1", v.o16_bk[1]); add("o16_hv", v.o16_hv);
-  add("o16_hvb", v.o16_hvb); add("o16_wh", v.o16_wh); add("o16_bh", v.o16_bh); add("t16_a_tab", v.t16_a_tab);
+  add("o16_hvb", v.o16_hvb); add("o16_wh", v.o16_wh); add("o16_bh", v.o16_bh); add("o16_wp", v.o16_wp); add("t16_a_tab", v.t16_a_tab);
   add("t16_a", v.t16_a); add("t16B_stride", v.t16B_stride); add("nP16", v.nP16); add("o16B_wk0", v.o16B_wk[0]); add("o16B_wk1", v.o16B_wk[1]);
   add("m16_ok", v.m16_ok); add("m16_span", v.m16_span); add("nT16", v.nT16); add("nC16", v.nC16); add("t16_stride", v.t16_stride);
   s += "\"g16_tile\": [";
@@ -319,6 +319,7 @@ int sf_flow_set_params(sf_flow* f, const float* flat, int64_t n, int is_device, 
   }
   SF_HIP(sf_launch_pack(src, f->d_s1, f->d_s2, f->d_packed, (long)f->L.n_packed, st));
   if (f->d_packed16) SF_HIP(sf_launch_pack(src, f->d_s16a, f->d_s16b, f->d_packed16, (long)f->L.n_packed16, st));
+  f->wp_stale = true;
   if (f->d_packed16B) SF_HIP(sf_launch_pack_bf16_split(src, f->d_s16B, f->d_packed16B, (long)f->L.n_packed16B, st));
   f->packed16_stale = false;
   if (f->L.n_packedB > 0) SF_HIP(sf_launch_pack_bf16(src, f->d_bsrc, f->d_packedB, (long)f->L.n_packedB, st));
@@ -382,6 +383,7 @@ int sf_flow_inverse_from_noise(sf_flow* f, const float* z, const float* x, int64
 }
 
 static void nsf_sampler_view(const sf_flow* f, SfDev& m);
+static SfDev sampler_dev(const sf_flow* f, const float* x);
 int sf_flow_inverse_from_noise_sampler(sf_flow* f, const float* z, const float* x, int64_t B, float* theta, void* stream) {
   if (!f) return fail(SF_ERR_INVALID, "null handle");
   if (B == 0) return SF_OK;
@@ -405,6 +407,22 @@ int sf_flow_inverse_from_noise_sampler(sf_flow* f, const float* z, const float* 
     a.x = x; a.z_in = z; a.n_items = (long)B; a.out = theta;
     SF_HIP(sf_launch_inverse(m, a, (hipStream_t)stream));
     return 1;  // (positive: "fp32 path", not an error)
+  }
+  if (sf_sampler_fp32_for(SF_MAF)) {
+    // the default sampler of a flow with the unrolled kernels runs the FUSED first layer off the context table: the hook builds
+    // the table for these rows and runs the find kernel's pass functions on the given noise
+    int rc = sf_flow_prepare_context(f, x, B, stream);
+    if (rc) return rc;
+    const SfDev mt = sampler_dev(f, x);
+    if (sf_maf16_fused_d(mt) > 0) {
+      SfSampleArgsHost a;
+      a.x = x; a.z_in = z; a.n_items = (long)B; a.out = theta; a.S = 1;
+      hipError_t e = sf_launch_maf_find16_zin(mt, a, (hipStream_t)stream);
+      (void)sf_flow_release_context(f);
+      if (e != hipSuccess) return hip_fail(e, "sf_launch_maf_find16_zin");
+      return 3;   // 3: the 16-row sampler's fp32 pass functions with the fused first layer
+    }
+    (void)sf_flow_release_context(f);
   }
   SF_HIP(sf_launch_maf_inv16b_hook(m, z, x, (long)B, theta, (hipStream_t)stream));
   return sf_sampler_fp32_for(SF_MAF) ? 2 : SF_OK;   // 2: the 16-row sampler's fp32 pass functions
@@ -461,6 +479,10 @@ int sf_flow_prepare_context(sf_flow* f, const float* x, int64_t M, void* stream)
     f->ctab_cap = need;
   }
   m.ctab_R = R; m.ctab_NV = NV;
+  if (f->wp_stale && m.kind == SF_MAF && m.m16_ok && m.packed16 && m.o16_wp >= 0) {   // the fused first layer follows the parameters
+    SF_HIP(sf_launch_maf_fuse16(m, (hipStream_t)stream));
+    f->wp_stale = false;
+  }
   SF_HIP(sf_launch_ctab(m, x, (long)M, f->d_ctab, (hipStream_t)stream));
   f->ctab_x = x;
   f->ctab_M = M;

@@ -93,6 +93,9 @@ int sf_sampler_fp32_for(int kind);  // the mode a flow of this kind samples in (
 void sf_ctab_shape(const SfDev& m, int& R, int& NV);
 hipError_t sf_launch_ctab(const SfDev& m, const float* x, long M, float* tab, hipStream_t st);
 hipError_t sf_launch_maf_ctab16(const SfDev& m, const float* x, long M, float* tab, hipStream_t st);
+hipError_t sf_launch_maf_fuse16(const SfDev& m, hipStream_t st);
+int sf_maf16_fused_d(const SfDev& m);   // D (3..5) when the fused-first-layer fp32 kernels apply to this view (table with c0' rows), else 0
+hipError_t sf_launch_maf_find16_zin(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st);   // W' = (W1 o M)(W0 o M0) into o16_wp of every transform
 hipError_t sf_launch_pack(const float* flat, const int32_t* s1, const int32_t* s2, float* packed, long n,
                           hipStream_t st);
 hipError_t sf_launch_pack_bf16(const float* flat, const int32_t* src, unsigned short* out, long n, hipStream_t st);
@@ -212,6 +215,7 @@ struct sf_flow {
   bool losspart_used = false;
   uint32_t* d_cnt = nullptr;     // SF_MAX_ROUNDS rejected-slot counters (one per round of a sf_flow_sample call)
   uint32_t* h_cnt = nullptr;     // pinned host mirror for the per-round read-back
+  bool wp_stale = true;              // the fused first-layer blocks (o16_wp) lag behind packed16: recomputed before the next context table
   bool sample_out_f64 = false;       // sf_flow_set_sample_output_f64: `out` of sf_flow_sample / _slots is a double array
   long long sample_row_offset = 0;   // sf_flow_set_sample_row_offset: first row of the next sampling calls in its catalogue
   double sample_time_limit_s = 0.0;  // > 0: sf_flow_sample* stop opening new attempt windows after this much wall time

@@ -193,7 +193,8 @@ void sf_ctab_shape(const SfDev& m, int& R, int& NV) {
   R = 0; NV = 0;
   if (m.hidden_bf16 == 1) return;
   if (m.kind == SF_NSF) { R = m.HT * 32; NV = 1 + m.NB; }
-  else if (m.kind == SF_MAF && m.m16_ok && m.packed16 != nullptr) { R = m.nT16 * 16; NV = 1; }
+  // (MAF with the fused first layer: a row holds c0 and, behind it, c0' = b1 + (W1 o M) c0)
+  else if (m.kind == SF_MAF && m.m16_ok && m.packed16 != nullptr) { R = m.nT16 * 16 * (m.o16_wp >= 0 ? 2 : 1); NV = 1; }
 }
 hipError_t sf_launch_ctab(const SfDev& m, const float* x, long M, float* tab, hipStream_t st) {
   if (M <= 0) return hipSuccess;

@@ -468,8 +468,12 @@ bool sf_build_layout(const sf_flow_desc& d, SfLayout& L) {
           linear16(1, NT, hrow16, h16row, lWf, H, [&](int oo, int unit) { return (oo / 2 + 1) > deg_h(unit); });
           if (t == 0) v.o16_bh = here();
           bias16(1, hrow16, lbf, -1);
+          while (L.src16a.size() % 4) push16(-1, -1);
+          if (t == 0) v.o16_wp = here();
+          for (int i = 0; i < NT * 256; ++i) push16(-1, -1);   // (computed on the device: k_maf_fuse16)
         } else if (t == 0) {
           v.o16_wh = v.o16_bh = -1;
+          v.o16_wp = -1;
         }
         // what the sampler stages when the per-galaxy context table exists (it then never reads Wc) ends here
         while (L.src16a.size() % 1024) push16(-1, -1);

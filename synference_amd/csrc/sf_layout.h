@@ -78,6 +78,11 @@ struct SfDev {
   int t16_a;     // floats of part A of the 16-row image (everything but the fp32 hidden blocks): what k_maf_samp16 stages
   int t16_a_tab; // ... and of its prefix without the context block Wc: what it stages when the context table exists
   int o16_wh, o16_bh;  // head rows as one MFMA output tile (row 2q + ab of slot q; D <= 8, else -1) and their biases
+  // fused first layer (round 5; D <= 8, else -1): W' = (W1 o M)(W0 o M0) as NT 16 x 16 fragments like o16_w0 -- there is no
+  // activation between the initial layer and the first block's linear, so the two collapse into one product with the finished
+  // dimensions; filled by k_maf_fuse16 from the packed image (not by the gather table), read by the fp32 sampler kernels
+  // together with the table rows c0' = b1 + (W1 o M) c0
+  int o16_wp;
   // split-bf16 hidden blocks of the 16-row sampler: 32-bit words (2 bf16 each), [ot][pair][hi|lo][64 lanes][4 words]
   const uint32_t* packed16B;
   int t16B_stride, nP16, o16B_wk[2];  // words per transform, in-tile pairs, block offsets in words

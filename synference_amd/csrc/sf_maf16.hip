@@ -844,6 +844,76 @@ template <> struct SfHid16<1> {
   }
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused first layer (PREC = 2; fp32, unrolled kernels with the context table).  nflows' MADE has NO activation between the
+// initial layer and the first block's linear (oracle/flows.py::_made: h = W0 u + b0 + Wc e + bc; then h = tanh(W1 h + b1), ...),
+// so the two are one affine map of the finished dimensions:
+//     W1 (W0 u + c0) + b1  =  W' u + c0',     W' = (W1 o M)(W0 o M0)  [H x D],     c0' = b1 + (W1 o M) c0  [per galaxy and transform]
+// W' is computed once per parameter update (k_maf_fuse16, in fp64, rounded to fp32: image block o16_wp), c0' once per galaxy
+// behind c0 in the context table (k_maf_ctab16).  A pass then costs 4 + 4 (OT + 1) + 4 fp32 MFMAs instead of 4 + 8 (OT + 1) + 4
+// (72 instead of 112 per tile and transform for cfg1), the first block's fragments and the state of its inputs disappear
+// (LDS 22 KB instead of 32 KB per transform, 16 registers), and the dependent chain of a pass is one layer shorter.  Same
+// function of the same parameters as the two-layer form to fp32 rounding (parity rows: given noise, draw for draw).
+// ---------------------------------------------------------------------------------------------------------------
+struct SfPass16G {
+  f32x4 act[4];        // output of block 0 = input of block 1; [tile]
+  f32x4 hdone, ut;
+  const float* c0p;    // this draw's c0' rows of the transform
+  const float* xr;
+  f32x4 c0n;
+  bool tab;
+};
+template <int OT, int NB>
+__device__ __forceinline__ void sf_pass16g(const SfDev& m, const float* tp, const float* tpF, SfPass16G& S, int NT, int sl, float u_sl,
+                                           int lane, int g4, int next_ot) {
+  const f32x4 c0 = S.c0n;
+  if (next_ot >= 0) sf_c0_prefetch(S, next_ot, g4);
+  const float4 wp = sf_w16(tp + m.o16_wp, 1, OT, 0, lane);
+  const float4 wh = sf_w16(tp + m.o16_wh, NT, 0, OT, lane);
+  float4 fw[OT + 1];
+  f32x4 b1;
+  if (NB == 2) {
+    b1 = sf_ld4(tp + m.o16_bk[1] + (OT * 4 + g4) * 4);
+#pragma unroll
+    for (int it = 0; it <= OT; ++it) fw[it] = sf_w16f<true>(tpF, NT, OT, it, lane);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const f32x4 b = sf_mma16(wp, S.ut, c0);   // the first block's pre-activation (tanh pre-scale folded in like every hidden block)
+  if (NB == 2) {
+#pragma unroll
+    for (int it = 0; it < OT; ++it) b1 = sf_mma16(fw[it], S.act[it], b1);   // tiles finished in earlier passes: not on the chain
+  }
+  f32x4 last = sf_tanh4(b);
+  if (NB == 2) {
+    S.act[OT] = last;
+    b1 = sf_mma16(fw[OT], last, b1);
+    last = sf_tanh4(b1);
+  }
+  const f32x4 fresh = sf_mma16(wh, last, S.hdone);
+  if (next_ot != OT) S.hdone = fresh;
+  const bool odd = (sl & 1) != 0;
+  const int src = (lane & 15) + 16 * (sl >> 1);
+  const float av = __shfl(odd ? fresh[2] : fresh[0], src, 64);
+  const float mv = __shfl(odd ? fresh[3] : fresh[1], src, 64);
+  const float sc = (m.scale_fn == 0 ? sf_softplus(av) : sf_sigmoid(av + 2.0f)) + m.eps;
+  const float wv = sf_div(u_sl - mv, sc);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) S.ut[r] = (g4 == (sl >> 2) && r == (sl & 3)) ? wv : S.ut[r];
+}
+template <> struct SfHid16<2> {
+  using State = SfPass16G;
+  template <int OT, int NB, bool CP, bool HM>
+  static __device__ __forceinline__ void pass(const SfDev& m, const float* tp, const void* tpH, State& S, int NT, int sl, float u_sl,
+                                              int lane, int g4, int next_ot) {
+    static_assert(CP && HM, "fused first layer: unrolled kernels only (aligned placement, head tile)");
+    sf_pass16g<OT, NB>(m, tp, static_cast<const float*>(tpH), S, NT, sl, u_sl, lane, g4, next_ot);
+  }
+  template <bool SEQ, bool HM>
+  static __device__ __forceinline__ void clear(State&) {}   // (a pass reads tiles 0 .. OT of its own tile and transform only)
+  // LDS floats behind part A: the SECOND block's fragments on and below the diagonal (the first block lives in W')
+  static __host__ __device__ int lds_floats(const SfDev& m, bool /*cp*/) { return m.NB >= 2 ? m.nT16 * (m.nT16 + 1) / 2 * 256 : 0; }
+};
+
 // Staging of one transform's operands (all four waves; the caller brackets it with barriers): part A of the fp32 image
 // (`a_floats` floats: input layer, biases, head rows; + the context block without a table) in 4 KiB groups -- ONE address, four
 // immediate offsets -- and behind it the hidden blocks: PREC 0 the split-bf16 image (4 KiB groups), PREC 1 the fp32 blocks
@@ -876,9 +946,10 @@ __device__ __forceinline__ void sf_stage16(const SfDev& m, int t, int a_floats, 
     }
     const int NT = m.nT16, nb = m.NB < 2 ? m.NB : 2;
     const int per = CP ? NT * (NT + 1) / 2 : NT * NT;
+    constexpr int K0 = PREC == 2 ? 1 : 0;   // (fused first layer: the first block is not staged)
     float4* __restrict__ dF = d4 + (a_floats >> 2);
-    for (int e = __builtin_amdgcn_readfirstlane(wave); e < nb * per; e += 4) {
-      const int k = e >= per ? 1 : 0, ee = e - k * per;
+    for (int e = __builtin_amdgcn_readfirstlane(wave); e < (nb - K0) * per; e += 4) {
+      const int k = K0 + (e >= per ? 1 : 0), ee = e - (k - K0) * per;
       int src_blk = ee;
       if (CP) {  // entry ot (ot + 1) / 2 + it  ->  block ot * NT + it   (NT <= 4)
         const int ot = ee >= 6 ? 3 : (ee >= 3 ? 2 : (ee >= 1 ? 1 : 0));
@@ -919,17 +990,18 @@ struct SfFix16 {
   static constexpr int o_w0 = 0, o_b0 = NT * 256, o_bk0 = o_b0 + NT * 16, o_bk1 = o_bk0 + NT * 16;
   static constexpr int o_hv = o_b0 + NT * 16 * (1 + NB), o_hvb = o_hv + DD * 128;
   static constexpr int o_wh = (o_hvb + 2 * DD + 3) / 4 * 4, o_bh = o_wh + NT * 256;
-  static constexpr int a_tab = (o_bh + 16 + 1023) / 1024 * 1024;
+  static constexpr int o_wp = (o_bh + 16 + 3) / 4 * 4;
+  static constexpr int a_tab = (o_wp + NT * 256 + 1023) / 1024 * 1024;
   static constexpr int entries = NT == 4 ? 6 : (NT == 3 ? 4 : 2);   // (ot, pair) fragments a block keeps: sum of ot / 2 + 1
   static constexpr int oB_wk1 = entries * 512, B_stride = (NB * entries * 512 + 1023) / 1024 * 1024;
   static bool matches(const SfDev& m) {
     return m.nT16 == NT && m.o16_w0 == o_w0 && m.o16_b0 == o_b0 && m.o16_bk[0] == o_bk0 && (NB < 2 || m.o16_bk[1] == o_bk1) &&
-           m.o16_hv == o_hv && m.o16_hvb == o_hvb && m.o16_wh == o_wh && m.o16_bh == o_bh && m.t16_a_tab == a_tab &&
+           m.o16_hv == o_hv && m.o16_hvb == o_hvb && m.o16_wh == o_wh && m.o16_bh == o_bh && m.o16_wp == o_wp && m.t16_a_tab == a_tab &&
            m.o16B_wk[0] == 0 && (NB < 2 || m.o16B_wk[1] == oB_wk1) && m.t16B_stride == B_stride;
   }
   static __device__ __forceinline__ void apply(SfDev& m) {
     m.nT16 = NT; m.o16_w0 = o_w0; m.o16_b0 = o_b0; m.o16_bk[0] = o_bk0; m.o16_bk[1] = o_bk1; m.o16_hv = o_hv; m.o16_hvb = o_hvb;
-    m.o16_wh = o_wh; m.o16_bh = o_bh; m.t16_a_tab = a_tab; m.o16B_wk[0] = 0; m.o16B_wk[1] = oB_wk1; m.t16B_stride = B_stride;
+    m.o16_wh = o_wh; m.o16_bh = o_bh; m.o16_wp = o_wp; m.t16_a_tab = a_tab; m.o16B_wk[0] = 0; m.o16B_wk[1] = oB_wk1; m.t16B_stride = B_stride;
   }
 };
 
@@ -1047,7 +1119,7 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
       // requested before the staging barriers so that their round trips overlap with the image copy: the degree ->
       // slot table of the transform and (table path) c0 of the first tile's first MFMA pass
       const int dsl = (int)m.cst[m.c_dslot + t * SF_DMAX + s];
-      S.c0p = S.tab ? m.ctab + ((size_t)gal_cur * m.T + t) * m.ctab_R : nullptr;
+      S.c0p = S.tab ? m.ctab + ((size_t)gal_cur * m.T + t) * m.ctab_R + (PREC == 2 ? m.nT16 * 16 : 0) : nullptr;
       if (HM && S.tab) sf_c0_prefetch(S, (int)((tile_bits >> 2) & 3u), g4);
 #ifdef SF_Q_STATS
       { const unsigned long long n = __builtin_amdgcn_s_memrealtime(); qs_ph[qs_o + (t == m.T - 1 ? 1 : 3)] += n - qs_t_mark; qs_t_mark = n; }
@@ -1068,7 +1140,7 @@ __global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args
         const bool tile_has_work = (unsigned)((j * 4 + wave) * 16) < n_items;
         if (tile_has_work) {
           if (j > 0) {  // (tile 0's requests went out before the staging barriers)
-            S.c0p = S.tab ? m.ctab + ((size_t)gal_cur * m.T + t) * m.ctab_R : nullptr;
+            S.c0p = S.tab ? m.ctab + ((size_t)gal_cur * m.T + t) * m.ctab_R + (PREC == 2 ? m.nT16 * 16 : 0) : nullptr;
             if (HM && S.tab) sf_c0_prefetch(S, (int)((tile_bits >> 2) & 3u), g4);
           }
           S.xr = a.x + gal_cur * m.C;
@@ -1291,22 +1363,27 @@ __global__ __launch_bounds__(256, 4) void k_maf_find16s(SfDev m, SfSampleArgsHos
     const long item = ((long)blockIdx.x * 8 + j * 4 + wave) * 16 + s;
     const long it = item < a.n_items ? item : a.n_items - 1;
     const long ps = it >> a.log2_attempts;
-    const uint32_t slot = a.slots ? a.slots[ps] : (uint32_t)(a.slot_base + ps);
+    const uint32_t slot = a.z_in ? (uint32_t)it : (a.slots ? a.slots[ps] : (uint32_t)(a.slot_base + ps));
     const uint32_t att = a.att_list ? a.att_list[ps] : a.attempt + (uint32_t)(it & ((1L << a.log2_attempts) - 1));
     float z4[4];
-    sf_normal4(a.k0, a.k1, (uint64_t)slot + a.rng_slot_offset, att, (uint32_t)g4, z4);
+    if (a.z_in) {   // parity hook: given noise, item = row of z / x (the context table was built for those rows)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) z4[r] = (4 * g4 + r < m.D) ? a.z_in[it * m.D + 4 * g4 + r] : 0.f;
+    } else {
+      sf_normal4(a.k0, a.k1, (uint64_t)slot + a.rng_slot_offset, att, (uint32_t)g4, z4);
+    }
     f32x4 u;
 #pragma unroll
     for (int r = 0; r < 4; ++r) u[r] = (4 * g4 + r < m.D) ? z4[r] : 0.f;
-    if (j == 1) { u_oth = u; gal_oth = (long)(slot / (uint32_t)a.S); }
-    else { u_cur = u; gal_cur = (long)(slot / (uint32_t)a.S); }
+    if (j == 1) { u_oth = u; gal_oth = a.z_in ? it : (long)(slot / (uint32_t)a.S); }
+    else { u_cur = u; gal_cur = a.z_in ? it : (long)(slot / (uint32_t)a.S); }
   }
   typename HID::State S;
   S.tab = true;
   S.xr = nullptr;
   for (int t = m.T - 1; t >= 0; --t) {
     const int dsl = (int)m.cst[m.c_dslot + t * SF_DMAX + s];
-    S.c0p = m.ctab + ((size_t)gal_cur * m.T + t) * m.ctab_R;
+    S.c0p = m.ctab + ((size_t)gal_cur * m.T + t) * m.ctab_R + (PREC == 2 ? m.nT16 * 16 : 0);
     sf_c0_prefetch(S, 0, g4);
     __syncthreads();
     sf_stage16<PREC, true>(m, t, m.t16_a_tab, wave);
@@ -1317,7 +1394,7 @@ __global__ __launch_bounds__(256, 4) void k_maf_find16s(SfDev m, SfSampleArgsHos
     for (int j = 0; j < 2; ++j) {
       if (((long)blockIdx.x * 8 + j * 4 + wave) * 16 < a.n_items) {  // (wave-uniform: the tile holds an item)
         if (j > 0) {
-          S.c0p = m.ctab + ((size_t)gal_cur * m.T + t) * m.ctab_R;
+          S.c0p = m.ctab + ((size_t)gal_cur * m.T + t) * m.ctab_R + (PREC == 2 ? m.nT16 * 16 : 0);
           sf_c0_prefetch(S, 0, g4);
         }
         HID::template clear<true, true>(S);
@@ -1368,7 +1445,13 @@ __global__ __launch_bounds__(256, 4) void k_maf_find16s(SfDev m, SfSampleArgsHos
     const unsigned long long okb = __ballot(ok);
     const uint32_t acc16 = (uint32_t)(okb & (okb >> 16) & (okb >> 32) & (okb >> 48) & 0xffffull) & (uint32_t)(__ballot(valid) & 0xffffull);
     const bool accepted = (acc16 >> s) & 1u;
-    if (a.best) {
+    if (a.z_in) {   // every row is written (no box: lo / hi are null)
+      if (valid) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * g4 + r < m.D) a.out[item * m.D + tdc[r]] = th[r];
+      }
+    } else if (a.best) {
       if (accepted && g4 == 0) atomicMin(&a.best[ps], att);
     } else if (a.count) {  // acceptance counts (leakage correction): item = draw item % S of galaxy item / S
       const long gal = (long)((uint32_t)(a.slots ? a.slots[ps] : (uint32_t)(a.slot_base + ps)) / (uint32_t)a.S);
@@ -1556,7 +1639,48 @@ __global__ __launch_bounds__(256) void k_maf_ctab16(SfDev m, const float* __rest
         if (ot < NT)
           *reinterpret_cast<f32x4*>(tab + ((size_t)gal * m.T + t) * m.ctab_R + ot * 16 + 4 * g4) = c0[ot];
     }
+    if (m.o16_wp >= 0) {   // fused first layer (sf_pass16g): c0' = b1 + (W1 o M) c0, behind c0 in the row
+      f32x4 c1[4];
+#pragma unroll
+      for (int ot = 0; ot < 4; ++ot)
+        if (ot < NT) {
+          c1[ot] = sf_ld4(tp + m.o16_bk[0] + (ot * 4 + g4) * 4);
+#pragma unroll
+          for (int it = 0; it < 4; ++it)
+            if (it < NT) c1[ot] = sf_mma16(sf_w16(tp + m.o16_wk[0], NT, ot, it, lane), c0[it], c1[ot]);
+        }
+      if (valid) {
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot)
+          if (ot < NT)
+            *reinterpret_cast<f32x4*>(tab + ((size_t)gal * m.T + t) * m.ctab_R + NT * 16 + ot * 16 + 4 * g4) = c1[ot];
+      }
+    }
   }
+}
+// W' = (W1 o M)(W0 o M0) of every transform, from the packed fp32 image into its o16_wp block (fp64 sums, one rounding): lane l of
+// tile ot holds W'[ot*16 + (l & 15)][4 (l >> 4) + r], the fragment layout of o16_w0.  Masked weights are structural zeros of the
+// image, and the packed first block carries the tanh pre-scale (SF_PACK_TANH_SCALE): W' and c0' inherit both.
+__global__ __launch_bounds__(256) void k_maf_fuse16(SfDev m) {
+  const int t = blockIdx.x, ot = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int NT = m.nT16;
+  if (ot >= NT) return;
+  float* tp = const_cast<float*>(m.packed16) + (size_t)t * m.t16_stride;
+  const int row = l & 15, sg = l >> 4;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int it = 0; it < NT; ++it)
+    for (int kk = 0; kk < 16; ++kk) {
+      const float wk = tp[m.o16_wk[0] + ((ot * NT + it) * 64 + row + 16 * (kk >> 2)) * 4 + (kk & 3)];   // W1[ot*16 + row][it*16 + kk]
+      const float* w0 = tp + m.o16_w0 + (it * 64 + kk + 16 * sg) * 4;                                    // W0[it*16 + kk][4 sg + r]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] += (double)wk * (double)w0[r];
+    }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tp[m.o16_wp + (ot * 64 + l) * 4 + r] = (float)acc[r];
+}
+hipError_t sf_launch_maf_fuse16(const SfDev& m, hipStream_t st) {
+  hipLaunchKernelGGL(k_maf_fuse16, dim3((unsigned)m.T), dim3(256), 0, st, m);
+  return hipGetLastError();
 }
 hipError_t sf_launch_maf_ctab16(const SfDev& m, const float* x, long M, float* tab, hipStream_t st) {
   hipLaunchKernelGGL(k_maf_ctab16, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, st, m, x, M, tab);
@@ -1669,10 +1793,24 @@ static int sf_maf16_seq_d(const SfDev& m) {
   else if (m.NB == 2) fits = m.D == 3 ? SfFix16<2, 3>::matches(m) : (m.D == 4 ? SfFix16<2, 4>::matches(m) : SfFix16<2, 5>::matches(m));
   return fits ? m.D : 0;
 }
+// The fused first layer (PREC = 2, sf_pass16g) applies where the fp32 unrolled kernels do and the context table carries the c0'
+// rows (SF_FUSE=0: the two-layer fp32 form, A-B runs).  Returns D (3..5) or 0.
+int sf_maf16_fused_d(const SfDev& m) {
+  static int env = -1;
+  if (env < 0) { const char* e = std::getenv("SF_FUSE"); env = e ? std::atoi(e) : 1; }
+  if (!env || !sf_sampler_fp32_for(SF_MAF) || !m.ctab || m.o16_wp < 0 || m.ctab_R != 2 * m.nT16 * 16 || !sf_maf16_head_mfma(m)) return 0;
+  return sf_maf16_seq_d(m);
+}
 template <int NB, bool SPAN, bool HM>
 static hipError_t sf_launch16q_t(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
   if (sf_maf16_tpw() == 1) return sf_launch16q<NB, SPAN, HM, 1>(m, a, st);
   if constexpr (HM && !SPAN) {
+    switch (sf_maf16_fused_d(m)) {
+      case 3: return sf_launch16q_p<NB, SPAN, HM, 2, 3, 2>(m, a, st);
+      case 4: return sf_launch16q_p<NB, SPAN, HM, 2, 4, 2>(m, a, st);
+      case 5: return sf_launch16q_p<NB, SPAN, HM, 2, 5, 2>(m, a, st);
+      default: break;
+    }
     // (round 5, fp32 kernels: FOUR tiles per wave and staged transform -- fetch, staging and prologue once per 256 draws -- measured
     //  2.74 ms per catalogue against 2.62 with two: the coarser iterations cost the tail more than the dense phase saves)
     switch (sf_maf16_seq_d(m)) {
@@ -1683,6 +1821,15 @@ static hipError_t sf_launch16q_t(const SfDev& m, const SfSampleArgsHost& a, hipS
     }
   }
   return sf_launch16q<NB, SPAN, HM, 2>(m, a, st);
+}
+// parity hook of the fused pass functions: theta = inverse(z | x) through k_maf_find16s<.., PREC = 2> in its given-noise mode (the
+// context table must have been built for the rows of x: item i reads table row i)
+hipError_t sf_launch_maf_find16_zin(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
+  const int dd = sf_maf16_fused_d(m);
+#define SF_ZIN_CASE(NBV, DDV) if (m.NB == NBV && dd == DDV) return sf_launch_find16s<NBV, DDV, 2>(m, a, st);
+  SF_ZIN_CASE(1, 3) SF_ZIN_CASE(1, 4) SF_ZIN_CASE(1, 5) SF_ZIN_CASE(2, 3) SF_ZIN_CASE(2, 4) SF_ZIN_CASE(2, 5)
+#undef SF_ZIN_CASE
+  return hipErrorInvalidValue;
 }
 hipError_t sf_launch_maf_inv16(const SfDev& m, const SfSampleArgsHost& a, hipStream_t st) {
   if (a.q) {
@@ -1697,8 +1844,9 @@ hipError_t sf_launch_maf_inv16(const SfDev& m, const SfSampleArgsHost& a, hipStr
     static int env = -1;
     if (env < 0) { const char* e = std::getenv("SF_FIND16S"); env = e ? std::atoi(e) : 1; }
     const int dd = env ? sf_maf16_seq_d(m) : 0;
+    const bool fused = env && sf_maf16_fused_d(m) > 0;
 #define SF_FIND_CASE(NBV, DDV) \
-    if (m.NB == NBV && dd == DDV) return f32 ? sf_launch_find16s<NBV, DDV, 1>(m, a, st) : sf_launch_find16s<NBV, DDV, 0>(m, a, st);
+    if (m.NB == NBV && dd == DDV) return fused ? sf_launch_find16s<NBV, DDV, 2>(m, a, st) : (f32 ? sf_launch_find16s<NBV, DDV, 1>(m, a, st) : sf_launch_find16s<NBV, DDV, 0>(m, a, st));
     SF_FIND_CASE(1, 3) SF_FIND_CASE(1, 4) SF_FIND_CASE(1, 5)
     SF_FIND_CASE(2, 3) SF_FIND_CASE(2, 4) SF_FIND_CASE(2, 5)
 #undef SF_FIND_CASE

@@ -431,6 +431,7 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
       SF_TRY(hipGetLastError());
       f->packed16_stale = lite;
       f->packed_stale = lite;
+      f->wp_stale = true;
     }
     if (L.n_packedB > 0) SF_TRY(sf_launch_pack_bf16(flat, f->d_bsrc, f->d_packedB, (long)L.n_packedB, st));
     if (coop_nsf) {
@@ -564,6 +565,7 @@ int sf_train_loss_grad(sf_flow* f, const float* flat, const float* theta, const 
     SF_TRY(hipGetLastError());
   }
   f->packed16_stale = false;
+  f->wp_stale = true;
   if (L.n_packedB > 0) SF_TRY(sf_launch_pack_bf16(flat, f->d_bsrc, f->d_packedB, (long)L.n_packedB, st));
   if (B > 0) {
     SfTrainArgs a;

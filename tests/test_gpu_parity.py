@@ -77,7 +77,10 @@ def test_sampler_arithmetic_from_given_noise(name, sampler_mode):
     rth, _ = oracle_inverse(ospec, flat, z, x, torch.float64)
     scale = np.asarray(ospec.theta_std)
     errs = {}
-    for mode, want_rc in ((-1, 2 if name.startswith("maf") else 0), (0, 0), (1, 2 if name.startswith("maf") else 1)):
+    # return codes: 3 = the fp32 unrolled kernels with the fused first layer (aligned placement, D 3..5: cfg1, d4, d3, nb1),
+    # 2 = the two-layer fp32 pass functions (span placements), 0 = split-bf16 x3, 1 = the generic fp32 path
+    maf_rc = 3 if name in ("maf_cfg1", "maf_d4", "maf_d3", "maf_nb1") else 2
+    for mode, want_rc in ((-1, maf_rc if name.startswith("maf") else 0), (0, 0), (1, maf_rc if name.startswith("maf") else 1)):
         sampler_mode(mode)
         th, _ = f.inverse_sampler(z, x)
         assert f.last_sampler_rc == want_rc, (name, mode, f.last_sampler_rc)

@@ -99,10 +99,9 @@ def test_draws_do_not_depend_on_the_dense_order(name, M, S):
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1]
         digests.append(line)
     assert digests[0] == digests[1] == digests[2], digests
-    if name.startswith("maf"):
-        assert digests[3] == digests[0], digests       # the MAF table holds exactly the sums the kernel would form
-    else:                                              # NSF: the table's products are summed in another order (fp32 rounding)
-        assert abs(float(digests[3].split()[3]) - float(digests[0].split()[3])) <= 1e-6 * abs(float(digests[0].split()[3]))
+    # without the table the products are summed in another order (NSF: the table's context products; MAF since round 5: the table
+    # path runs the FUSED first layer W' u + c0', the no-table path the two layers): equal to fp32 rounding, not bit for bit
+    assert abs(float(digests[3].split()[3]) - float(digests[0].split()[3])) <= 1e-6 * abs(float(digests[0].split()[3]))
     assert digests[0].split()[2] == "0"   # every slot filled
 
 
