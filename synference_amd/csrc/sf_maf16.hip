@@ -1009,8 +1009,13 @@ struct SfFix16 {
 // with the tile of each known at compile time (pass p works on tile p - 2) -- no dispatch, and the per-tile state is
 // updated in place instead of being copied into the registers every arm of the switch has to agree on.
 // PREC: operand form of the hidden H x H blocks (SfHid16): 0 = split bf16 x3, 1 = fp32.
+// Workgroups per CU of the fused-first-layer kernel (PREC 2: 25 KB of LDS, 106 VGPRs).  Five fit once the compiler is held
+// to 96 VGPRs (94 used, no scratch), and measured SLOWER on the headline workload: 2.11-2.15 ms against 2.06 ms with four.
+#ifndef SF_SAMP16_WG_FUSED
+#define SF_SAMP16_WG_FUSED 4
+#endif
 template <int NB, bool SPAN, bool HM, int TPW, int DD = 0, int PREC = 0>
-__global__ __launch_bounds__(256, (SPAN ? 3 : 4)) void k_maf_samp16(SfSamp16Args args_in) {
+__global__ __launch_bounds__(256, (SPAN ? 3 : (PREC == 2 ? SF_SAMP16_WG_FUSED : 4))) void k_maf_samp16(SfSamp16Args args_in) {
   static_assert(DD == 0 || (HM && !SPAN && DD >= 2 && DD <= 5), "unrolled passes: head tile, aligned placement, D <= 5");
   using HID = SfHid16<PREC>;
   constexpr int IPW = 64 * TPW;
@@ -1744,7 +1749,7 @@ static hipError_t sf_launch16q_p(const SfDev& m, const SfSampleArgsHost& a, hipS
   int resident = 0, cur_dev = 0;
   (void)hipGetDevice(&cur_dev);
   if (!rcache.get(cur_dev, sh, resident)) {
-    resident = sf_resident_blocks16((const void*)k_maf_samp16<NB, SPAN, HM, TPW, DD, PREC>, sh, SPAN ? 3 : 4);
+    resident = sf_resident_blocks16((const void*)k_maf_samp16<NB, SPAN, HM, TPW, DD, PREC>, sh, SPAN ? 3 : (PREC == 2 ? SF_SAMP16_WG_FUSED : 4));
     rcache.put(cur_dev, sh, resident);
   }
   long grid = (a.n_items + 64 * TPW - 1) / (64 * TPW);
