@@ -58,7 +58,7 @@ def section(rows, pat, grid=None, alg_bytes=None, note=None):
 maf = list(csv.DictReader(open(os.path.join(P, f"{tag}_pmc_maf.csv"))))
 M, S, D, C, P_ = 2000, 1000, 5, 10, 32300
 # the default sampler (round 5): every product in fp32 -- template argument PREC = 1 is the last one of the kernel name
-out = section(maf, r"k_maf_samp16<.*, 1>", alg_bytes=4.0 * D * M * S + 4.0 * C * M)
+out = section(maf, r"k_maf_samp16<.*, [12]>", alg_bytes=4.0 * D * M * S + 4.0 * C * M)
 if out is None:
     out = section(maf, "k_maf_samp16", alg_bytes=4.0 * D * M * S + 4.0 * C * M)
 out["command"] = ("rocprofv3 --pmc <COUNTERS> --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 "
