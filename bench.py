@@ -844,8 +844,10 @@ def run_workload(a, world, rank, dev, gloo):
     f_train = 3.0 * wl["f_lp"]   # a training step costs 3x the log_prob figure per row
     train_tf = f_train * B / (train_kernel_ms * 1e-3) / 1e12
     ttraffic, ttraffic_src = pmc_traffic("train") if a.workload == "maf_cfg2" else (None, None)
-    kname = "k_ar_sample (one wave per 64 draws, one hyper-network sweep per transform)" if wl["kind"] == "nsf_ar" else \
-            (("k_maf_samp16<NB,SPAN,HM,TPW,DD,PREC=1> (16-row tiles, every product on v_mfma_f32_16x16x4_f32)" if desc.get("m16_ok") and not a.hidden_bf16 else "k_sample_persist<MafOps>")
+    kname = ("k_ar_samp16<D,NI> (16-candidate register tiles, one hyper-network sweep per transform; find / resolve rounds on the same routine)"
+             if wl["kind"] == "nsf_ar" and desc.get("sampler_tiles16") else
+             "k_ar_sample (one wave per 64 draws, one hyper-network sweep per transform)") if wl["kind"] == "nsf_ar" else \
+            (("k_maf_samp16<NB,SPAN,HM,TPW,DD,PREC=2> (16-row tiles, every product on v_mfma_f32_16x16x4_f32, first block layer folded into the input layer)" if desc.get("m16_ok") and not a.hidden_bf16 else "k_sample_persist<MafOps>")
              if wl["kind"] == "maf" else
              ("k_sample_persist<NsfOps<..., BF = 2>> (sampler image, split-bf16 hidden blocks)" if desc.get("nsf_split_sampler") and
               not a.hidden_bf16 else "k_sample_persist<NsfOps>"))

@@ -20,6 +20,10 @@ struct SfNsfAr {
   long P_t = 0, t_stride = 0;
   int l_W0 = 0, l_b0 = 0, l_W1 = 0, l_b1 = 0, l_W2 = 0, l_b2 = 0;                             // logical offsets in a transform
   int o_L0t = 0, o_b0 = 0, o_L1t = 0, o_L1m = 0, o_b1 = 0, o_L2t = 0, o_b2 = 0, o_L0m = 0, o_L2m = 0;   // image offsets in a transform
+  // 16-sample register-tile sampler (sf_nsfar16.hip): s16_nt = hidden tiles (= D: type r IS tile r) or 0 when the shape does not take it;
+  // fragment-ordered blocks of a transform (lane l of block (ot, kt): W[16 ot + (l & 15)][16 kt + 4 (l >> 4) + 0..3]) in the sampler's
+  // own hidden order, biases in that order
+  int s16_nt = 0, s16_ni = 0, o_F0 = 0, o_fb0 = 0, o_F1 = 0, o_fb1 = 0, o_F2 = 0;
   bool dev_ready = false;
   float* d_img = nullptr;
   int32_t *d_src = nullptr, *d_none = nullptr, *d_perm = nullptr, *d_ptype = nullptr, *d_tend = nullptr, *d_ord = nullptr, *d_dimof = nullptr;
@@ -46,6 +50,19 @@ int sf_nsfar_inverse(SfNsfAr* n, const float* z, const float* x, long B, float* 
 int sf_nsfar_sample(SfNsfAr* n, const float* x, long M, long S, const uint32_t* slots, long n_slots, const float* lo, const float* hi,
                     uint32_t k0, uint32_t k1, unsigned long long slot_offset, int max_attempts, float* out, int32_t* n_drawn,
                     int32_t* count, int64_t* n_unfilled, hipStream_t st, std::string& err, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+// sf_nsfar16.hip: the persistent first launch of sf_nsfar_sample on 16-sample register tiles (same arguments and hand-over as k_ar_sample)
+struct SfAr16Launch {
+  const float* x; long S; const uint32_t* slots; long n_slots; const float* lo; const float* hi; uint32_t k0, k1; unsigned long long slot_offset;
+  uint32_t max_attempts; float* out; int32_t* n_drawn; int32_t* count; unsigned long long* cursor; unsigned int* n_unfilled; int32_t* g_try;
+  int32_t* g_acc; unsigned long long walk_R, walk_C; uint32_t window_end; uint32_t* surv; unsigned int* n_surv;
+};
+bool sf_nsfar16_eligible(const SfNsfAr& n);
+hipError_t sf_nsfar16_launch(const SfNsfAr& n, const SfAr16Launch& L, int cus, hipStream_t st);
+// the chip-wide rounds on the same candidate routine (arguments of k_ar_find / k_ar_resolve; L carries x, S, the box, the keys and the outputs)
+hipError_t sf_nsfar16_find(const SfNsfAr& n, const SfAr16Launch& L, const uint32_t* surv, unsigned int n_surv, uint32_t base, uint32_t chunks,
+                           uint32_t att_end, uint32_t* best, unsigned long long* ctr, hipStream_t st);
+hipError_t sf_nsfar16_resolve(const SfNsfAr& n, const SfAr16Launch& L, const uint32_t* surv, unsigned int n_surv, const uint32_t* best,
+                              uint32_t tried_end, uint32_t tried_now, uint32_t* next, unsigned int* n_next, hipStream_t st);
 int sf_nsfar_loss_grad(SfNsfAr* n, const float* flat, const float* theta, const float* x, const long long* idx, long B, float grad_scale,
                        const float* weights, float* loss, double* loss_sum, float* grad, hipStream_t st, std::string& err, hipEvent_t ev0 = nullptr,
                        hipEvent_t ev1 = nullptr);

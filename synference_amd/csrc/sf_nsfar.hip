@@ -961,6 +961,17 @@ int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err) {
   n->o_b2 = (int)o; o += (long)D * ARQ;
   n->o_L0m = (int)o; o += (long)Hp * 16;
   n->o_L2m = (int)o; o += (long)D * ARQ * Hp;   // the head transposed: row (d, slot), column k
+  // the 16-sample sampler's blocks (sf_nsfar16.hip): every type fits one 16-row tile, D steps, one or two input tiles
+  n->s16_nt = ((H + D - 1) / D <= 16 && D >= 2 && D <= 8 && (nin + 15) / 16 <= 2) ? D : 0;
+  n->s16_ni = (nin + 15) / 16;
+  if (n->s16_nt) {
+    const long NTs = n->s16_nt, NI = n->s16_ni;
+    n->o_F0 = (int)o; o += NTs * NI * 256;
+    n->o_fb0 = (int)o; o += NTs * 16;
+    n->o_F1 = (int)o; o += NTs * NTs * 256;
+    n->o_fb1 = (int)o; o += NTs * 16;
+    n->o_F2 = (int)o; o += (long)D * 2 * NTs * 256;
+  }
   n->t_stride = (o + 63) / 64 * 64;
   if (sf_nsfar_lds_bytes(*n, 3, 1) > (size_t)160 * 1024 - 1024) {
     err = "autoregressive NSF: (3 D + C + 2 Hp + 32) x 260 bytes of LDS per wave exceed the 160 KB of a CU (Hp = H with every type padded to a multiple of 8, in all a multiple of 16)";
@@ -1008,6 +1019,43 @@ int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err) {
             s[n->o_L2m + (long)slot * Hp + k] = (int32_t)(base + n->l_W2 + (long)lrow * H + hk);
           }
         }
+    if (n->s16_nt) {   // fragment blocks in the sampler's hidden order: row 16 r + i = unit r + i D (type r), -1 past the type's units
+      const int NTs = n->s16_nt, NI = n->s16_ni;
+      auto unit = [&](int p) { const int h = (p >> 4) + (p & 15) * D; return h < H ? h : -1; };
+      for (int ot = 0; ot < NTs; ++ot)
+        for (int l = 0; l < 64; ++l) {
+          const int p = 16 * ot + (l & 15), h = unit(p);
+          if (h < 0) continue;
+          if (l < 16) {
+            s[n->o_fb0 + p] = (int32_t)(base + n->l_b0 + h);
+            s[n->o_fb1 + p] = (int32_t)(base + n->l_b1 + h);
+          }
+          for (int j = 0; j < 4; ++j) {
+            for (int ti = 0; ti < NI; ++ti) {
+              const int i = 16 * ti + 4 * (l >> 4) + j;
+              if (i < nin && (i >= D || ord[i] < ot)) s[n->o_F0 + (long)(ot * NI + ti) * 256 + l * 4 + j] = (int32_t)(base + n->l_W0 + (long)h * nin + i);
+            }
+            for (int kt = 0; kt <= ot; ++kt) {   // (type of row k = kt <= type of row p = ot)
+              const int hk = unit(16 * kt + 4 * (l >> 4) + j);
+              if (hk >= 0) s[n->o_F1 + (long)(ot * NTs + kt) * 256 + l * 4 + j] = (int32_t)(base + n->l_W1 + (long)h * H + hk);
+            }
+          }
+        }
+      for (int dd = 0; dd < D; ++dd)
+        for (int o2 = 0; o2 < 2; ++o2)
+          for (int l = 0; l < 64; ++l) {
+            const int slot = 16 * o2 + (l & 15), fam = slot >> 3, kk = slot & 7;
+            if (slot >= ARQ || fam >= (affine ? 1 : 3) || kk >= (fam < 2 ? K : K - 1)) continue;
+            const int lrow = dd * NP + fam * K + kk;
+            for (int kt = 0; kt < NTs; ++kt) {
+              if (kt > ord[dd]) continue;
+              for (int j = 0; j < 4; ++j) {
+                const int hk = unit(16 * kt + 4 * (l >> 4) + j);
+                if (hk >= 0) s[n->o_F2 + (long)((dd * 2 + o2) * NTs + kt) * 256 + l * 4 + j] = (int32_t)(base + n->l_W2 + (long)lrow * H + hk);
+              }
+            }
+          }
+    }
   }
   *out = n;
   return SF_OK;
@@ -1147,7 +1195,14 @@ int sf_nsfar_sample(SfNsfAr* n, const float* x, long M, long S, const uint32_t* 
   uint32_t window = cap;
   const bool rounds = !count && lo && cap > 256u && n_slots <= (1l << 31) && (unsigned long long)M * (unsigned long long)S < (1ull << 32);
   if (rounds) {
-    window = 256u;
+    // (16-sample waves: an open entry costs a whole 16-candidate round of ONE wave per 16 attempts once the list has run dry, so the
+    //  hand-over comes early -- measured on the bench flow: window 256 / 64 / 32 / 16 -> 8.35 / 7.84 / 6.93 / 7.29 ms per catalogue)
+    window = sf_nsfar16_eligible(*n) ? 32u : 256u;
+    {   // (developer knob: attempts of a slot inside the persistent launch before the chip-wide rounds take it)
+      static int w_env = -1;
+      if (w_env < 0) { const char* e = std::getenv("SF_AR_WINDOW"); w_env = e ? std::atoi(e) : 0; }
+      if (w_env >= 16 && (uint32_t)w_env < cap) window = (uint32_t)w_env / 16u * 16u;
+    }
     if ((size_t)n_slots > n->surv_cap) {
       (void)hipFree(n->d_surv[0]); (void)hipFree(n->d_surv[1]); (void)hipFree(n->d_best);
       n->d_surv[0] = n->d_surv[1] = n->d_best = nullptr; n->surv_cap = 0;
@@ -1158,9 +1213,16 @@ int sf_nsfar_sample(SfNsfAr* n, const float* x, long M, long S, const uint32_t* 
     }
   }
   unsigned int* d_ns = reinterpret_cast<unsigned int*>(n->d_ctr + 4);   // [0], [1]: survivor counts of the two lists
-  hipLaunchKernelGGL(k_ar_sample, dim3((unsigned)grid), dim3(64), lds, st, args_of(*n), x, S, slots, n_slots, lo, hi, k0, k1, slot_offset, cap, out,
-                     n_drawn, count, n->d_ctr, reinterpret_cast<unsigned int*>(n->d_ctr + 1), g_try, g_try ? g_try + M : nullptr, walk_R, walk_C,
-                     window, n->d_surv[0], d_ns);
+  const bool tiles16 = sf_nsfar16_eligible(*n);   // 16-sample register tiles, four independent waves per workgroup (sf_nsfar16.hip)
+  const SfAr16Launch L = {x, S, slots, n_slots, lo, hi, k0, k1, slot_offset, cap, out, n_drawn, count, n->d_ctr,
+                          reinterpret_cast<unsigned int*>(n->d_ctr + 1), g_try, g_try ? g_try + M : nullptr, walk_R, walk_C, window, n->d_surv[0], d_ns};
+  if (tiles16) {
+    AR_HIP(sf_nsfar16_launch(*n, L, cus, st));
+  } else {
+    hipLaunchKernelGGL(k_ar_sample, dim3((unsigned)grid), dim3(64), lds, st, args_of(*n), x, S, slots, n_slots, lo, hi, k0, k1, slot_offset, cap, out,
+                       n_drawn, count, n->d_ctr, reinterpret_cast<unsigned int*>(n->d_ctr + 1), g_try, g_try ? g_try + M : nullptr, walk_R, walk_C,
+                       window, n->d_surv[0], d_ns);
+  }
   AR_HIP(hipGetLastError());
   if (ev1) AR_HIP(hipEventRecord(ev1, st));
   unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1171,19 +1233,31 @@ int sf_nsfar_sample(SfNsfAr* n, const float* x, long M, long S, const uint32_t* 
       AR_HIP(hipMemcpyAsync(h, n->d_ctr, sizeof(h), hipMemcpyDeviceToHost, st));
       AR_HIP(hipStreamSynchronize(st));
       const unsigned int ns = reinterpret_cast<const unsigned int*>(h + 4)[cur];
+      {
+        static int dbg = -1;
+        if (dbg < 0) dbg = std::getenv("SF_AR_DEBUG") ? 1 : 0;
+        if (dbg) fprintf(stderr, "[nsfar rounds] base %u survivors %u evaluations %llu\n", base, ns, h[2]);
+      }
       if (ns == 0 || base >= cap) break;
       uint32_t A = 64;
-      while (2u * A <= base && (uint64_t)(2u * A) * ns <= (1ull << 22) && 2u * A <= 65536u) A *= 2;
+      static int grow = -1;
+      if (grow < 0) { const char* e = std::getenv("SF_AR_GROW"); grow = e ? std::atoi(e) : 1; if (grow < 1) grow = 1; }
+      while (2u * A <= (uint32_t)grow * base && (uint64_t)(2u * A) * ns <= (1ull << 22) && 2u * A <= 65536u) A *= 2;
       if ((uint64_t)base + A > cap) A = (uint32_t)(((uint64_t)cap - base + 63u) / 64u * 64u);
       const uint32_t att_end = (uint64_t)base + A > cap ? cap : base + A;
       const uint32_t chunks = A / 64u;
       AR_HIP(hipMemsetAsync(n->d_best, 0xff, (size_t)ns * sizeof(uint32_t), st));
       AR_HIP(hipMemsetAsync(d_ns + (cur ^ 1), 0, sizeof(unsigned int), st));
-      hipLaunchKernelGGL(k_ar_find, dim3(ns * chunks), dim3(64), lds, st, args_of(*n), x, S, n->d_surv[cur], ns, base, chunks, att_end, lo, hi, k0, k1,
-                         slot_offset, n->d_best, n->d_ctr);
-      hipLaunchKernelGGL(k_ar_resolve, dim3((ns + 63u) / 64u), dim3(64), lds, st, args_of(*n), x, S, n->d_surv[cur], ns, n->d_best, att_end, cap, lo, hi,
-                         k0, k1, slot_offset, out, n_drawn, g_try, g_try ? g_try + M : nullptr, att_end - base, n->d_surv[cur ^ 1], d_ns + (cur ^ 1),
-                         reinterpret_cast<unsigned int*>(n->d_ctr + 1));
+      if (tiles16) {
+        AR_HIP(sf_nsfar16_find(*n, L, n->d_surv[cur], ns, base, chunks, att_end, n->d_best, n->d_ctr, st));
+        AR_HIP(sf_nsfar16_resolve(*n, L, n->d_surv[cur], ns, n->d_best, att_end, att_end - base, n->d_surv[cur ^ 1], d_ns + (cur ^ 1), st));
+      } else {
+        hipLaunchKernelGGL(k_ar_find, dim3(ns * chunks), dim3(64), lds, st, args_of(*n), x, S, n->d_surv[cur], ns, base, chunks, att_end, lo, hi, k0, k1,
+                           slot_offset, n->d_best, n->d_ctr);
+        hipLaunchKernelGGL(k_ar_resolve, dim3((ns + 63u) / 64u), dim3(64), lds, st, args_of(*n), x, S, n->d_surv[cur], ns, n->d_best, att_end, cap, lo, hi,
+                           k0, k1, slot_offset, out, n_drawn, g_try, g_try ? g_try + M : nullptr, att_end - base, n->d_surv[cur ^ 1], d_ns + (cur ^ 1),
+                           reinterpret_cast<unsigned int*>(n->d_ctr + 1));
+      }
       AR_HIP(hipGetLastError());
       base = att_end;
       cur ^= 1;
@@ -1191,9 +1265,15 @@ int sf_nsfar_sample(SfNsfAr* n, const float* x, long M, long S, const uint32_t* 
     const unsigned int left = reinterpret_cast<const unsigned int*>(h + 4)[cur];
     if (left > 0) {   // (the ceiling was reached with slots still open: NaN rows)
       AR_HIP(hipMemsetAsync(n->d_best, 0xff, (size_t)left * sizeof(uint32_t), st));
-      hipLaunchKernelGGL(k_ar_resolve, dim3((left + 63u) / 64u), dim3(64), lds, st, args_of(*n), x, S, n->d_surv[cur], left, n->d_best, cap, cap, lo, hi,
-                         k0, k1, slot_offset, out, n_drawn, (int32_t*)nullptr, (int32_t*)nullptr, 0u, n->d_surv[cur ^ 1], d_ns + (cur ^ 1),
-                         reinterpret_cast<unsigned int*>(n->d_ctr + 1));
+      if (tiles16) {
+        SfAr16Launch Lf = L;
+        Lf.g_try = nullptr; Lf.g_acc = nullptr;
+        AR_HIP(sf_nsfar16_resolve(*n, Lf, n->d_surv[cur], left, n->d_best, cap, 0u, n->d_surv[cur ^ 1], d_ns + (cur ^ 1), st));
+      } else {
+        hipLaunchKernelGGL(k_ar_resolve, dim3((left + 63u) / 64u), dim3(64), lds, st, args_of(*n), x, S, n->d_surv[cur], left, n->d_best, cap, cap, lo, hi,
+                           k0, k1, slot_offset, out, n_drawn, (int32_t*)nullptr, (int32_t*)nullptr, 0u, n->d_surv[cur ^ 1], d_ns + (cur ^ 1),
+                           reinterpret_cast<unsigned int*>(n->d_ctr + 1));
+      }
       AR_HIP(hipGetLastError());
     }
     AR_HIP(hipMemcpyAsync(h, n->d_ctr, sizeof(h), hipMemcpyDeviceToHost, st));
