@@ -18,13 +18,25 @@ X = torch.randn(M, C, device="cuda")
 out = torch.empty(M, S, D, device="cuda")
 free = f.sample(X[:64], 512, seed=1).reshape(-1, D)
 lo = torch.quantile(free, 0.03, dim=0).cpu().numpy(); hi = torch.quantile(free, 0.97, dim=0).cpu().numpy()
-for name, box in (("no box", (None, None)), ("box 3..97 %", (lo, hi))):
-    for _ in range(2): f.sample(X, S, *box, seed=5, out=out)
+big = 1e30 * np.ones(D, np.float32)
+for name, box, kw in (("no box", (None, None), {}), ("box that accepts everything", (-big, big), {}), ("box 3..97 %", (lo, hi), {}),
+                      ("box 3..97 %, max_attempts 1000", (lo, hi), dict(max_attempts=1000))):
+    for _ in range(2): f.sample(X, S, *box, seed=5, out=out, **kw)
     ks, ws, ev, rd = [], [], 0, 0
     for k in range(5):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        f.sample(X, S, *box, seed=10 + k, out=out)
+        f.sample(X, S, *box, seed=10 + k, out=out, **kw)
         torch.cuda.synchronize(); ws.append(time.perf_counter() - t0)
         st = f.last_sample_stats; ks.append(st["dense_ms"]); ev = st["evaluations"]; rd = st["rounds"]
     print(f"{KIND} D{D} C{C} H{H} T{T} K{K} {name}: launch {np.median(ks):.3f} ms, call {1e3*np.median(ws):.3f} ms, evaluations {ev:.0f} "
           f"({ev/(M*S):.3f} per draw), rounds {rd}, {M*S/np.median(ws)/1e6:.1f} M draws/s", flush=True)
+# acceptance counting: one attempt per item, the box test, no retries and no draws written
+for _ in range(2): f.acceptance(X, S, lo, hi, seed=3)
+ws = []
+for k in range(5):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    acc = f.acceptance(X, S, lo, hi, seed=20 + k)
+    torch.cuda.synchronize(); ws.append(time.perf_counter() - t0)
+a_ = acc.float().cpu().numpy()
+print(f"acceptance counting, box 3..97 %: call {1e3*np.median(ws):.3f} ms per {M*S} evaluations; acceptance per row: mean {a_.mean():.3f}, "
+      f"min {a_.min():.4f}, 1 % quantile {np.quantile(a_, 0.01):.4f}, rows below 0.1: {(a_ < 0.1).sum()}", flush=True)

@@ -507,6 +507,7 @@ __global__ __launch_bounds__(64) void k_ar_sample(ArArgs a, const float* __restr
   const unsigned long long n_index = interleave ? walk_R * walk_C : (unsigned long long)n_slots;   // (>= n_slots: holes are skipped)
   int n_retry = 0;
   bool list_done = false;
+  unsigned int n_ev = 0, n_rej0 = 0;
   for (;;) {
     const int take = list_done ? 0 : 64 - n_retry;
     unsigned long long base = n_index;
@@ -524,7 +525,13 @@ __global__ __launch_bounds__(64) void k_ar_sample(ArArgs a, const float* __restr
       }
     }
     const int n_ent = n_retry + n_fresh;
-    if (n_ent == 0) break;
+    if (n_ent == 0) {
+      if (lane == 0) {
+        if (n_ev) atomicAdd(cursor + 2, (unsigned long long)n_ev);
+        if (n_rej0) atomicAdd(cursor + 3, (unsigned long long)n_rej0);
+      }
+      break;
+    }
     int lw = 0;   // log2 of the speculation width
     if (list_done && !count)
       while ((n_ent << (lw + 1)) <= 64) ++lw;
@@ -548,13 +555,9 @@ __global__ __launch_bounds__(64) void k_ar_sample(ArArgs a, const float* __restr
     const long g = exists ? (long)(slot / (unsigned long long)S) : 0;
     const bool ok = ar_candidate(a, sc, x, g, slot, att, k0, k1, slot_offset, lo, hi, E0, V, H1, H2, QB, lane, active);
     const unsigned long long m_ok = __ballot(ok);
-    {
-      const unsigned long long ma = __ballot(active), mr = __ballot(active && !ok && att == 0u);
-      if (lane == 0) {
-        atomicAdd(cursor + 2, (unsigned long long)__popcll(ma));
-        if (mr) atomicAdd(cursor + 3, (unsigned long long)__popcll(mr));
-      }
-    }
+    // (statistics stay in the wave until it leaves: per round they were two more atomics on the cache line of the queue head)
+    n_ev += (unsigned)__popcll(__ballot(active));
+    n_rej0 += (unsigned)__popcll(__ballot(active && !ok && att == 0u));
     if (count) {   // acceptance counting (leakage correction): one attempt per item, nothing written
       if (ok) atomicAdd(count + g, 1);
       n_retry = 0;
@@ -964,6 +967,7 @@ int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err) {
   // the 16-sample sampler's blocks (sf_nsfar16.hip): every type fits one 16-row tile, D steps, one or two input tiles
   n->s16_nt = ((H + D - 1) / D <= 16 && D >= 2 && D <= 8 && (nin + 15) / 16 <= 2) ? D : 0;
   n->s16_ni = (nin + 15) / 16;
+  n->s16_ks = ((H + D - 1) / D + 3) / 4 < 2 ? 2 : ((H + D - 1) / D + 3) / 4;
   if (n->s16_nt) {
     const long NTs = n->s16_nt, NI = n->s16_ni;
     n->o_F0 = (int)o; o += NTs * NI * 256;
@@ -1019,9 +1023,15 @@ int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err) {
             s[n->o_L2m + (long)slot * Hp + k] = (int32_t)(base + n->l_W2 + (long)lrow * H + hk);
           }
         }
-    if (n->s16_nt) {   // fragment blocks in the sampler's hidden order: row 16 r + i = unit r + i D (type r), -1 past the type's units
+    if (n->s16_nt) {   // fragment blocks in the sampler's hidden order (type r = tile r), -1 on the rows that hold no unit
       const int NTs = n->s16_nt, NI = n->s16_ni;
-      auto unit = [&](int p) { const int h = (p >> 4) + (p & 15) * D; return h < H ? h : -1; };
+      const int KS = n->s16_ks;   // the n-th unit of type r sits on row 16 r + 4 (n / KS) + n % KS
+      auto unit = [&](int p) {
+        const int i = p & 15, j = i & 3;
+        if (j >= KS) return -1;
+        const int h = (p >> 4) + ((i >> 2) * KS + j) * D;
+        return h < H ? h : -1;
+      };
       for (int ot = 0; ot < NTs; ++ot)
         for (int l = 0; l < 64; ++l) {
           const int p = 16 * ot + (l & 15), h = unit(p);

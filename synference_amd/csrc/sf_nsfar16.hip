@@ -9,7 +9,8 @@
 //     l & 15), which IS the B-operand order of the next product when the weight block is stored lane-major with the same
 //     k-permutation (lane l: W[16 ot + (l & 15)][16 kt + 4 (l >> 4) + j], one 16-byte load per block, four products);
 //   * the sampler has its own hidden order: type r (the units that become final once the dimensions ordered before r are known)
-//     IS tile r, so step r of the sweep is static code -- L0 block(s) of tile r, blocks (r, 0..r) of the masked layer, blocks
+//     IS tile r -- its units on the rows with (row & 3) < KS = ceil(units / 4), so that the k-steps KS..3 of a block over a hidden
+//     tile are zeros and are not issued --, so step r of the sweep is static code -- L0 block(s) of tile r, blocks (r, 0..r) of the masked layer, blocks
 //     (0..r) of the two head tiles of the dimension ordered r -- with no masks, selects or row bounds; the steps of a transform
 //     are the cases of a switch inside the rolled loops over transforms and order values (one copy of the spline);
 //   * the 24 parameter slots of the step's dimension are gathered from the four row groups with ds_bpermute and the univariate
@@ -65,23 +66,33 @@ __device__ __forceinline__ f32x4 a16_ld4(const float* p) {
   r[0] = b.x; r[1] = b.y; r[2] = b.z; r[3] = b.w;
   return r;
 }
+// KS k-steps of a block: the sampler's hidden order puts a type's units on rows with (row & 3) < KS of its tile (KS = ceil(units / 4)),
+// so the k-steps KS..3 of every block whose INPUT is a hidden tile multiply zeros and are not issued (ten units per type: three of four)
+template <int KS = 4>
 __device__ __forceinline__ f32x4 a16_mma(const float4 w, const f32x4 in, f32x4 acc) {
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, in[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, in[1], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, in[2], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, in[3], acc, 0, 0, 0);
+  if constexpr (KS > 1) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, in[1], acc, 0, 0, 0);
+  if constexpr (KS > 2) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, in[2], acc, 0, 0, 0);
+  if constexpr (KS > 3) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, in[3], acc, 0, 0, 0);
   return acc;
 }
 // two independent products, alternating (a dependent 16x16x4 MFMA waits 40 cycles, an independent one issues after 32)
+template <int KS>
 __device__ __forceinline__ void a16_mma2(const float4 wa, const float4 wb, const f32x4 in, f32x4& acca, f32x4& accb) {
   acca = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, in[0], acca, 0, 0, 0);
   accb = __builtin_amdgcn_mfma_f32_16x16x4f32(wb.x, in[0], accb, 0, 0, 0);
-  acca = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, in[1], acca, 0, 0, 0);
-  accb = __builtin_amdgcn_mfma_f32_16x16x4f32(wb.y, in[1], accb, 0, 0, 0);
-  acca = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, in[2], acca, 0, 0, 0);
-  accb = __builtin_amdgcn_mfma_f32_16x16x4f32(wb.z, in[2], accb, 0, 0, 0);
-  acca = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.w, in[3], acca, 0, 0, 0);
-  accb = __builtin_amdgcn_mfma_f32_16x16x4f32(wb.w, in[3], accb, 0, 0, 0);
+  if constexpr (KS > 1) {
+    acca = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, in[1], acca, 0, 0, 0);
+    accb = __builtin_amdgcn_mfma_f32_16x16x4f32(wb.y, in[1], accb, 0, 0, 0);
+  }
+  if constexpr (KS > 2) {
+    acca = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, in[2], acca, 0, 0, 0);
+    accb = __builtin_amdgcn_mfma_f32_16x16x4f32(wb.z, in[2], accb, 0, 0, 0);
+  }
+  if constexpr (KS > 3) {
+    acca = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.w, in[3], acca, 0, 0, 0);
+    accb = __builtin_amdgcn_mfma_f32_16x16x4f32(wb.w, in[3], accb, 0, 0, 0);
+  }
 }
 __device__ __forceinline__ f32x4 a16_relu(f32x4 v) {
 #pragma unroll
@@ -91,7 +102,7 @@ __device__ __forceinline__ f32x4 a16_relu(f32x4 v) {
 
 // Step R of the sweep of one transform: the hidden units of type R (tile R) from the inputs known so far, then the two head tiles
 // (slots 0..15 / 16..23) of dimension d, the one ordered R.  Every fragment of the step is requested before the first product.
-template <int R, int DD, int NI>
+template <int R, int DD, int NI, int KS>
 __device__ __forceinline__ void a16_step(const Ar16Args& a, const float* __restrict__ tp, int d, int lane, const f32x4 (&E)[NI], f32x4 (&H1)[DD],
                                          f32x4 (&H2)[DD], f32x4& q0, f32x4& q1) {
   const int g4 = lane >> 4;
@@ -110,22 +121,22 @@ __device__ __forceinline__ void a16_step(const Ar16Args& a, const float* __restr
   q0 = a16_ld4(tp + a.o_b2 + d * ARQ + 4 * g4);
   q1 = a16_ld4(tp + a.o_b2 + d * ARQ + 16 + 4 * (g4 & 1));   // (slots 16..23; the upper row groups repeat them: never read)
 #pragma unroll
-  for (int ti = 0; ti < NI; ++ti) h = a16_mma(w0[ti], E[ti], h);
+  for (int ti = 0; ti < NI; ++ti) h = a16_mma<4>(w0[ti], E[ti], h);
   // what does not depend on this step's tile: the lower blocks of the masked layer and of the head
   f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int kt = 0; kt < R; ++kt) {
-    if (kt & 1) acc1 = a16_mma(w1[kt], H1[kt], acc1);
-    else acc = a16_mma(w1[kt], H1[kt], acc);
+    if (kt & 1) acc1 = a16_mma<KS>(w1[kt], H1[kt], acc1);
+    else acc = a16_mma<KS>(w1[kt], H1[kt], acc);
   }
 #pragma unroll
-  for (int kt = 0; kt < R; ++kt) a16_mma2(wa[kt], wb[kt], H2[kt], q0, q1);
+  for (int kt = 0; kt < R; ++kt) a16_mma2<KS>(wa[kt], wb[kt], H2[kt], q0, q1);
   H1[R] = a16_relu(h);
-  acc = a16_mma(w1[R], H1[R], acc);
+  acc = a16_mma<KS>(w1[R], H1[R], acc);
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] += acc1[r];
   H2[R] = a16_relu(acc);
-  a16_mma2(wa[R], wb[R], H2[R], q0, q1);
+  a16_mma2<KS>(wa[R], wb[R], H2[R], q0, q1);
 }
 
 // The inverse of zuko's MonotonicRQSTransform (ZSpl::inv, sf_spline_flat.h) on the head tiles AS THE MFMA LEFT THEM: of a sample's
@@ -211,7 +222,7 @@ __device__ __forceinline__ float a16_spline_inv(const ZSplC& c, const f32x4 q0, 
 }
 
 // one candidate per lane group member: noise of (slot, attempt) through the inverse flow, prior-box test; th = the candidate
-template <int DD, int NI>
+template <int DD, int NI, int KS>
 __device__ __forceinline__ bool a16_candidate(const Ar16Args& a, const ZSplC& sc, long g, unsigned long long slot, uint32_t att, int lane,
                                               bool active, float (&th)[DD]) {
   const int g4 = lane >> 4;
@@ -255,14 +266,14 @@ __device__ __forceinline__ bool a16_candidate(const Ar16Args& a, const ZSplC& sc
       f32x4 q0, q1;
       A16_TS(2 + ((a.T - 1 - t) * DD + r) * 3);
       switch (r) {
-        case 0: a16_step<0, DD, NI>(a, tp, d, lane, E, H1, H2, q0, q1); break;
-        case 1: if constexpr (DD > 1) a16_step<1, DD, NI>(a, tp, d, lane, E, H1, H2, q0, q1); break;
-        case 2: if constexpr (DD > 2) a16_step<2, DD, NI>(a, tp, d, lane, E, H1, H2, q0, q1); break;
-        case 3: if constexpr (DD > 3) a16_step<3, DD, NI>(a, tp, d, lane, E, H1, H2, q0, q1); break;
-        case 4: if constexpr (DD > 4) a16_step<4, DD, NI>(a, tp, d, lane, E, H1, H2, q0, q1); break;
-        case 5: if constexpr (DD > 5) a16_step<5, DD, NI>(a, tp, d, lane, E, H1, H2, q0, q1); break;
-        case 6: if constexpr (DD > 6) a16_step<6, DD, NI>(a, tp, d, lane, E, H1, H2, q0, q1); break;
-        default: if constexpr (DD > 7) a16_step<7, DD, NI>(a, tp, d, lane, E, H1, H2, q0, q1); break;
+        case 0: a16_step<0, DD, NI, KS>(a, tp, d, lane, E, H1, H2, q0, q1); break;
+        case 1: if constexpr (DD > 1) a16_step<1, DD, NI, KS>(a, tp, d, lane, E, H1, H2, q0, q1); break;
+        case 2: if constexpr (DD > 2) a16_step<2, DD, NI, KS>(a, tp, d, lane, E, H1, H2, q0, q1); break;
+        case 3: if constexpr (DD > 3) a16_step<3, DD, NI, KS>(a, tp, d, lane, E, H1, H2, q0, q1); break;
+        case 4: if constexpr (DD > 4) a16_step<4, DD, NI, KS>(a, tp, d, lane, E, H1, H2, q0, q1); break;
+        case 5: if constexpr (DD > 5) a16_step<5, DD, NI, KS>(a, tp, d, lane, E, H1, H2, q0, q1); break;
+        case 6: if constexpr (DD > 6) a16_step<6, DD, NI, KS>(a, tp, d, lane, E, H1, H2, q0, q1); break;
+        default: if constexpr (DD > 7) a16_step<7, DD, NI, KS>(a, tp, d, lane, E, H1, H2, q0, q1); break;
       }
       float v = 0.f;
 #pragma unroll
@@ -311,7 +322,7 @@ __device__ __forceinline__ void a16_wave_sync() {
 #ifndef SF_A16_WGS
 #define SF_A16_WGS 3
 #endif
-template <int DD, int NI>
+template <int DD, int NI, int KS>
 __global__ __launch_bounds__(256, SF_A16_WGS) void k_ar_samp16(Ar16Args a) {
   __shared__ unsigned long long r_slot[4][16];
   __shared__ uint32_t r_att[4][16];
@@ -323,9 +334,18 @@ __global__ __launch_bounds__(256, SF_A16_WGS) void k_ar_samp16(Ar16Args a) {
   const long S = L.S;
   const bool interleave = L.walk_R > 1;
   const unsigned long long n_index = interleave ? L.walk_R * L.walk_C : (unsigned long long)L.n_slots;
+  const bool small = n_index <= 0xffffffffull && (unsigned long long)L.n_slots <= 0xffffffffull && (unsigned long long)S <= 0xffffffffull;
   int n_retry = 0;
   bool list_done = false;
+  unsigned int n_ev = 0, n_rej0 = 0;
+#ifdef SF_A16_TRACE
+  if (a.trace && lane == 0) atomicMin(a.trace + 509, (unsigned long long)wall_clock64());
+  bool stamped = false;
+#endif
   for (;;) {
+#ifdef SF_A16_TRACE
+    if (a.trace && lane == 0 && list_done && !stamped) { atomicMin(a.trace + 510, (unsigned long long)wall_clock64()); atomicMax(a.trace + 508, (unsigned long long)wall_clock64()); stamped = true; }
+#endif
     const int take = list_done ? 0 : 16 - n_retry;
     unsigned long long base = n_index;
     if (take > 0) {
@@ -342,7 +362,16 @@ __global__ __launch_bounds__(256, SF_A16_WGS) void k_ar_samp16(Ar16Args a) {
       }
     }
     const int n_ent = n_retry + n_fresh;
-    if (n_ent == 0) break;
+#ifdef SF_A16_TRACE
+    if (n_ent == 0 && a.trace && lane == 0) atomicMax(a.trace + 511, (unsigned long long)wall_clock64());
+#endif
+    if (n_ent == 0) {
+      if (lane == 0) {
+        if (n_ev) atomicAdd(L.cursor + 2, (unsigned long long)n_ev);
+        if (n_rej0) atomicAdd(L.cursor + 3, (unsigned long long)n_rej0);
+      }
+      break;
+    }
     int lw = 0;   // log2 of the speculation width
     if (list_done && !L.count)
       while ((n_ent << (lw + 1)) <= 16) ++lw;
@@ -355,7 +384,11 @@ __global__ __launch_bounds__(256, SF_A16_WGS) void k_ar_samp16(Ar16Args a) {
       if (e < n_retry) { slot = r_slot[wv][e]; att0 = r_att[wv][e]; }
       else {
         const unsigned long long idx = base + (unsigned)(e - n_retry);
-        const unsigned long long pos = interleave ? (idx % L.walk_R) * L.walk_C + idx / L.walk_R : idx;
+        unsigned long long pos = idx;
+        if (interleave) {   // (32-bit division where the cover fits: a 64-bit one is ~200 instructions)
+          if (small) { const uint32_t i32 = (uint32_t)idx, r32 = (uint32_t)L.walk_R; pos = (unsigned long long)(i32 % r32) * L.walk_C + i32 / r32; }
+          else pos = (idx % L.walk_R) * L.walk_C + idx / L.walk_R;
+        }
         if (pos >= (unsigned long long)L.n_slots) exists = false;   // (a hole of the R x C cover)
         else slot = L.slots ? (unsigned long long)L.slots[pos] : pos;
       }
@@ -363,19 +396,22 @@ __global__ __launch_bounds__(256, SF_A16_WGS) void k_ar_samp16(Ar16Args a) {
     const uint32_t att = att0 + (uint32_t)sub;
     const bool active = exists && att < L.window_end;
     a16_wave_sync();   // (the retry list has been read)
-    const long g = exists ? (long)(slot / (unsigned long long)S) : 0;
+    const long g = !exists ? 0 : (small ? (long)((uint32_t)slot / (uint32_t)S) : (long)(slot / (unsigned long long)S));
     float th[DD];
-    const bool ok = a16_candidate<DD, NI>(a, sc, g, slot, att, lane, active, th);
+    const bool ok = a16_candidate<DD, NI, KS>(a, sc, g, slot, att, lane, active, th);
     const unsigned long long m_ok = __ballot(ok && lead);
-    {
-      const unsigned long long ma = __ballot(active && lead), mr = __ballot(active && lead && !ok && att == 0u);
-      if (lane == 0) {
-        atomicAdd(L.cursor + 2, (unsigned long long)__popcll(ma));
-        if (mr) atomicAdd(L.cursor + 3, (unsigned long long)__popcll(mr));
-      }
-    }
+    // (statistics: kept in the wave and added once when it leaves -- per round they were two more atomics on the cache line of the
+    //  queue head that every wave's next fetch waits for)
+    n_ev += (unsigned)__popcll(__ballot(active && lead));
+    n_rej0 += (unsigned)__popcll(__ballot(active && lead && !ok && att == 0u));
     if (L.count) {   // acceptance counting (leakage correction): one attempt per item, nothing written
-      if (ok && lead) atomicAdd(L.count + g, 1);
+      // (items are consecutive slots: the sixteen of a wave belong to one row, two at a row boundary -- one add for the first
+      //  row's hits instead of up to sixteen same-address atomics, the others on their own)
+      const long g0 = ((long)__builtin_amdgcn_readfirstlane((int)(g >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)g);
+      const unsigned long long same = __ballot(lead && g == g0);
+      const int c0 = __popcll(m_ok & same);
+      if (lane == 0 && c0) atomicAdd(L.count + g0, c0);
+      if (ok && lead && g != g0) atomicAdd(L.count + g, 1);
       n_retry = 0;
       continue;
     }
@@ -419,7 +455,7 @@ __global__ __launch_bounds__(256, SF_A16_WGS) void k_ar_samp16(Ar16Args a) {
 // FIND / RESOLVE of the chip-wide rounds (k_ar_find / k_ar_resolve of sf_nsfar.hip, same arguments) on the 16-sample candidate:
 // workgroup (e, j) of FIND tries attempts base + 64 j + 16 wave + (lane & 15) of survivor e and lowers best[e]; RESOLVE re-evaluates
 // exactly attempt best[e] of sixteen survivors per wave and writes the draw.
-template <int DD, int NI>
+template <int DD, int NI, int KS>
 __global__ __launch_bounds__(256, SF_A16_WGS) void k_ar_find16(Ar16Args a, const uint32_t* __restrict__ surv, unsigned int n_surv, uint32_t base,
                                                                uint32_t chunks, uint32_t att_end, uint32_t* __restrict__ best,
                                                                unsigned long long* __restrict__ ctr) {
@@ -432,12 +468,12 @@ __global__ __launch_bounds__(256, SF_A16_WGS) void k_ar_find16(Ar16Args a, const
   const bool active = att < att_end;
   const long g = (long)(slot / (unsigned long long)a.L.S);
   float th[DD];
-  const bool ok = a16_candidate<DD, NI>(a, sc, g, slot, att, lane, active, th);
+  const bool ok = a16_candidate<DD, NI, KS>(a, sc, g, slot, att, lane, active, th);
   if (ok && lane < 16) atomicMin(best + e, att);
   const unsigned long long ma = __ballot(active && lane < 16);
   if (lane == 0) atomicAdd(ctr + 2, (unsigned long long)__popcll(ma));
 }
-template <int DD, int NI>
+template <int DD, int NI, int KS>
 __global__ __launch_bounds__(256, SF_A16_WGS) void k_ar_resolve16(Ar16Args a, const uint32_t* __restrict__ surv, unsigned int n_surv,
                                                                   const uint32_t* __restrict__ best, uint32_t tried_end, uint32_t tried_now,
                                                                   uint32_t* __restrict__ next, unsigned int* __restrict__ n_next) {
@@ -451,7 +487,7 @@ __global__ __launch_bounds__(256, SF_A16_WGS) void k_ar_resolve16(Ar16Args a, co
   const bool found = exists && b != 0xffffffffu;
   const long g = exists ? (long)(slot / (unsigned long long)L.S) : 0;
   float th[DD];
-  const bool ok = a16_candidate<DD, NI>(a, sc, g, slot, found ? b : 0u, lane, found, th);
+  const bool ok = a16_candidate<DD, NI, KS>(a, sc, g, slot, found ? b : 0u, lane, found, th);
   if (!lead) return;
   if (found) {   // (ok by construction: the find launch accepted this very attempt)
 #pragma unroll
@@ -476,19 +512,19 @@ __global__ __launch_bounds__(256, SF_A16_WGS) void k_ar_resolve16(Ar16Args a, co
   }
 }
 
-template <int DD, int NI>
+template <int DD, int NI, int KS>
 hipError_t launch16(const Ar16Args& a, int cus, hipStream_t st) {
   static int occ = 0;
   if (!occ) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_ar_samp16<DD, NI>, 256, 0) != hipSuccess || nb < 1) nb = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_ar_samp16<DD, NI, KS>, 256, 0) != hipSuccess || nb < 1) nb = 2;
     occ = nb > 8 ? 8 : nb;
   }
   long grid = (long)cus * occ;
   const long need = (a.L.n_slots + 63) / 64;
   if (grid > need) grid = need;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((k_ar_samp16<DD, NI>), dim3((unsigned)grid), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((k_ar_samp16<DD, NI, KS>), dim3((unsigned)grid), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
@@ -514,13 +550,20 @@ static Ar16Args a16_args(const SfNsfAr& n, const SfAr16Launch& L) {
 #endif
   return a;
 }
-// (DD, NI) of a flow -> the instantiation: F is called with two integral constants
+// (DD, NI, KS) of a flow -> the instantiation: F is called with three integral constants
 template <typename F>
 static hipError_t a16_dispatch(const SfNsfAr& n, F f) {
+  auto with_ks = [&](auto dd, auto ni) {
+    switch (n.s16_ks) {
+      case 2: return f(dd, ni, std::integral_constant<int, 2>());
+      case 3: return f(dd, ni, std::integral_constant<int, 3>());
+      default: return f(dd, ni, std::integral_constant<int, 4>());
+    }
+  };
 #define A16_CASE(DD)                                                                                                             \
   case DD:                                                                                                                       \
-    return n.s16_ni == 1 ? f(std::integral_constant<int, DD>(), std::integral_constant<int, 1>())                               \
-                         : f(std::integral_constant<int, DD>(), std::integral_constant<int, 2>());
+    return n.s16_ni == 1 ? with_ks(std::integral_constant<int, DD>(), std::integral_constant<int, 1>())                         \
+                         : with_ks(std::integral_constant<int, DD>(), std::integral_constant<int, 2>());
   switch (n.D) {
     A16_CASE(2) A16_CASE(3) A16_CASE(4) A16_CASE(5) A16_CASE(6) A16_CASE(7) A16_CASE(8)
     default: return hipErrorInvalidValue;
@@ -534,24 +577,27 @@ hipError_t sf_nsfar16_launch(const SfNsfAr& n, const SfAr16Launch& L, int cus, h
   static unsigned long long* d_tr = nullptr;
   if (!d_tr && hipMalloc(&d_tr, 512 * 8) != hipSuccess) return hipErrorOutOfMemory;
   (void)hipMemsetAsync(d_tr, 0, 512 * 8, st);
+  (void)hipMemsetAsync(d_tr + 509, 0xff, 2 * 8, st);
   a.trace = d_tr;
   struct Dump { unsigned long long* p; hipStream_t st; ~Dump() {
     (void)hipStreamSynchronize(st);
     unsigned long long h[512];
     (void)hipMemcpy(h, p, sizeof(h), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[a16 timeline] first wave sees the list dry at %.1f us, last wave sees it at %.1f us, last wave leaves at %.1f us (100 MHz clock, from the first wave's start)\n",
+            (double)(long long)(h[510] - h[509]) * 0.01, (double)(long long)(h[508] - h[509]) * 0.01, (double)(long long)(h[511] - h[509]) * 0.01);
     fprintf(stderr, "[a16 trace] cycles since stamp 0:");
     for (int i = 0; i < 512; ++i) if (h[i]) fprintf(stderr, " %d:%lld", i, (long long)(h[i] - h[0]));
     fprintf(stderr, "\n");
   } } dump{d_tr, st};
 #endif
-  return a16_dispatch(n, [&](auto dd, auto ni) { return launch16<decltype(dd)::value, decltype(ni)::value>(a, cus, st); });
+  return a16_dispatch(n, [&](auto dd, auto ni, auto ks) { return launch16<decltype(dd)::value, decltype(ni)::value, decltype(ks)::value>(a, cus, st); });
 }
 
 hipError_t sf_nsfar16_find(const SfNsfAr& n, const SfAr16Launch& L, const uint32_t* surv, unsigned int n_surv, uint32_t base, uint32_t chunks,
                            uint32_t att_end, uint32_t* best, unsigned long long* ctr, hipStream_t st) {
   const Ar16Args a = a16_args(n, L);
-  return a16_dispatch(n, [&](auto dd, auto ni) {
-    hipLaunchKernelGGL((k_ar_find16<decltype(dd)::value, decltype(ni)::value>), dim3(n_surv * chunks), dim3(256), 0, st, a, surv, n_surv, base, chunks,
+  return a16_dispatch(n, [&](auto dd, auto ni, auto ks) {
+    hipLaunchKernelGGL((k_ar_find16<decltype(dd)::value, decltype(ni)::value, decltype(ks)::value>), dim3(n_surv * chunks), dim3(256), 0, st, a, surv, n_surv, base, chunks,
                        att_end, best, ctr);
     return hipGetLastError();
   });
@@ -560,8 +606,8 @@ hipError_t sf_nsfar16_find(const SfNsfAr& n, const SfAr16Launch& L, const uint32
 hipError_t sf_nsfar16_resolve(const SfNsfAr& n, const SfAr16Launch& L, const uint32_t* surv, unsigned int n_surv, const uint32_t* best,
                               uint32_t tried_end, uint32_t tried_now, uint32_t* next, unsigned int* n_next, hipStream_t st) {
   const Ar16Args a = a16_args(n, L);
-  return a16_dispatch(n, [&](auto dd, auto ni) {
-    hipLaunchKernelGGL((k_ar_resolve16<decltype(dd)::value, decltype(ni)::value>), dim3((n_surv + 63u) / 64u), dim3(256), 0, st, a, surv, n_surv, best,
+  return a16_dispatch(n, [&](auto dd, auto ni, auto ks) {
+    hipLaunchKernelGGL((k_ar_resolve16<decltype(dd)::value, decltype(ni)::value, decltype(ks)::value>), dim3((n_surv + 63u) / 64u), dim3(256), 0, st, a, surv, n_surv, best,
                        tried_end, tried_now, next, n_next);
     return hipGetLastError();
   });
