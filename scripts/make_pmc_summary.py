@@ -94,5 +94,16 @@ if os.path.exists(nsf_path):
             na, "k_nsf_trainc", grid=512 * 256, alg_bytes=4.0 * (Dn + Cn) * 16384 + 4.0 * 2 * 91570,
             note="the same launch with SF_GRAD_ACC=atomic: f32 atomics into one gradient replica per XCD, nothing but inputs and the "
                  "u stash crosses the HBM")
+ar_path = os.path.join(P, f"{tag}_pmc_nsfar.csv")
+if os.path.exists(ar_path):   # the lampe backend's flow (bench.py --workload nsfar_cfg2): 16-candidate register-tile sampler, training kernel
+    ar = list(csv.DictReader(open(ar_path)))
+    out["nsfar"] = {
+        "command": "the same passes over  bench.py --workload nsfar_cfg2 --steps 3 --warmup 1",
+        "sampler": section(ar, "k_ar_samp16", alg_bytes=4.0 * D * M * S + 4.0 * C * M,
+                           note="persistent launch of the catalogue call: sixteen candidates per wave in register tiles, weight blocks straight "
+                                "from L2; survivors of 32 attempts go to k_ar_find16 / k_ar_resolve16"),
+        "find": section(ar, "k_ar_find16"),
+        "train": section(ar, "k_ar_train"),
+    }
 json.dump(out, open(os.path.join(P, f"{tag}_pmc_summary.json"), "w"), indent=1)
-print(json.dumps(out, indent=1)[:6000])
+print(json.dumps({k: (v if not isinstance(v, dict) else "...") for k, v in out.items()}, indent=1)[:3000])

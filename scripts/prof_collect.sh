@@ -4,7 +4,8 @@
 #   2. three separate --pmc passes of the default bench (FETCH_SIZE | WRITE_SIZE | SQ_*)  -> per-kernel counter rows
 #   3. the same for the NSF workload of BASELINE configs[2] (bench.py --workload nsf_cfg3)
 #   4. un-profiled bench lines of both workloads
-#   5. (round 4) bench.py --workload nsf_prod: the reference's production NSF (T = 15, H = 69, K = 10);
+#   5. (round 5) kernel trace + PMC passes of bench.py --workload nsfar_cfg2 (the lampe backend's flow: k_ar_samp16)
+#   6. (round 4) bench.py --workload nsf_prod: the reference's production NSF (T = 15, H = 69, K = 10);
 #      bench.py --workload nsfar_cfg2: the lampe backend's autoregressive NSF on the cfg2 mock (with its CPU baseline)
 # Only small summaries are kept (gpurun_out/prof_rNN/); scripts/make_pmc_summary.py rNN turns them into
 # profiles/rNN_pmc_summary.json, which bench.py reads `traffic` / `issue_busy` from.
@@ -77,6 +78,10 @@ say "PMC passes, nsf_cfg3 training with the gradient replicas (SF_GRAD_ACC=atomi
 export SF_GRAD_ACC=atomic
 pmc nsfatomic "--workload nsf_cfg3 --steps 2 --warmup 1 --skip-throughput-regime --skip-api --fit-steps 50" "k_nsf_train|k_gather_c"
 unset SF_GRAD_ACC
+say "kernel trace, nsfar_cfg2 (the lampe backend's flow)"
+trace nsfar "--workload nsfar_cfg2 --steps 3 --warmup 1"
+say "PMC passes, nsfar_cfg2"
+pmc nsfar "--workload nsfar_cfg2 --steps 3 --warmup 1 --skip-throughput-regime --skip-api" "k_ar_samp16|k_ar_find16|k_ar_resolve16|k_ar_train|k_ar_logprob"
 say "un-profiled bench lines"
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 say "default bench done"

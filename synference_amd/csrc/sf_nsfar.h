@@ -32,6 +32,9 @@ struct SfNsfAr {
   int affine = 0;               // SF_MAF_AR (zuko MAF): MonotonicAffineTransform instead of the spline
   float* d_ustash = nullptr;
   size_t ustash_cap = 0;
+  unsigned char* d_live = nullptr;   // [n_params] 1 = the parameter has a gradient (unmasked weight or bias)
+  float* d_gpart = nullptr;          // per-workgroup gradient partials of the training kernel (small batches)
+  size_t gpart_cap = 0;
   int32_t* d_gal = nullptr;              // [2][M]: attempts / accepted draws per row (progress rule of the uncapped sampler)
   size_t gal_cap = 0;
   unsigned long long* d_ctr = nullptr;   // [0] work cursor of the sampler, [1] slots written off, [2] evaluations, [3] first attempts rejected

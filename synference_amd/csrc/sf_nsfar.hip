@@ -37,6 +37,10 @@
 
 namespace {
 
+// one element of a weight gradient: k_ar_train<NWV, PART> -- PART: the workgroup's own partial (every element of a transform's
+// gradient is produced exactly once per workgroup: plain stores, summed in workgroup order by k_ar_gather: no atomics, bitwise
+// reproducible); else f32 atomics into the one gradient (256 workgroups adding the same 57 k elements in lockstep: 0.18 of 0.57 ms)
+#define AR_GADD(p, v) do { if (PART) *(p) = (v); else unsafeAtomicAdd((p), (v)); } while (0)
 constexpr int ARK = 8, ARQ = 24;   // bins capacity / parameter slots per dimension (K <= 8: 3K - 1 <= 23)
 constexpr int RS = 65;             // floats per LDS row (64 samples + 1: the MFMA operand reads of the training kernel walk rows
                                    // with the lane index -- a stride of 64 would put sixteen rows on one bank)
@@ -670,12 +674,13 @@ __global__ __launch_bounds__(64) void k_ar_resolve(ArArgs a, const float* __rest
 }
 
 // forward (with the inputs of every transform stashed) + loss, then the backward sweep
-template <int NWV>
+template <int NWV, bool PART>
 __global__ __launch_bounds__(64 * NWV) void k_ar_train(ArArgs a, const float* __restrict__ theta, const float* __restrict__ x,
                                                         const long long* __restrict__ idx, long B, float w, const float* __restrict__ wts,
-                                                        float* __restrict__ loss, double* __restrict__ loss_sum, float* __restrict__ grad,
-                                                        float* __restrict__ ustash) {
+                                                        float* __restrict__ loss, double* __restrict__ loss_sum, float* __restrict__ grad_in,
+                                                        long part_stride, float* __restrict__ ustash) {
   extern __shared__ float lds[];
+  float* grad = grad_in + (PART ? (size_t)blockIdx.x * part_stride : 0);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   float* E0 = lds;                       // [NIN16]: u, context, zeros
   float* H1 = E0 + a.NIN16 * RS;         // [Hp]
@@ -779,7 +784,7 @@ __global__ __launch_bounds__(64 * NWV) void k_ar_train(ArArgs a, const float* __
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int lr = ar_slot_row(a, it * 16 + 4 * (lane >> 4) + r);
-            if (kl >= 0 && lr >= 0) unsafeAtomicAdd(gt + a.l_W2 + (size_t)(d * a.NP + lr) * a.H + kl, g4[r]);
+            if (kl >= 0 && lr >= 0) AR_GADD(gt + a.l_W2 + (size_t)(d * a.NP + lr) * a.H + kl, g4[r]);
           }
         }
         const ar_f32x4 b4 = ar_rowsum16(QB, it * 16, lane);
@@ -787,7 +792,7 @@ __global__ __launch_bounds__(64 * NWV) void k_ar_train(ArArgs a, const float* __
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int lr = ar_slot_row(a, it * 16 + 4 * (lane >> 4) + r);
-            if (lr >= 0) unsafeAtomicAdd(gt + a.l_b2 + d * a.NP + lr, b4[r]);
+            if (lr >= 0) AR_GADD(gt + a.l_b2 + d * a.NP + lr, b4[r]);
           }
         }
       }
@@ -819,13 +824,13 @@ __global__ __launch_bounds__(64 * NWV) void k_ar_train(ArArgs a, const float* __
         const int k = k0 + (lane & 15), kl = PERM[k], kty = PTYP[k];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (kl >= 0 && ol[r] >= 0 && kty <= oty[r]) unsafeAtomicAdd(gt + a.l_W1 + (size_t)ol[r] * a.H + kl, g4[r]);
+          if (kl >= 0 && ol[r] >= 0 && kty <= oty[r]) AR_GADD(gt + a.l_W1 + (size_t)ol[r] * a.H + kl, g4[r]);
       }
       const ar_f32x4 b4 = ar_rowsum16(DH, o0, lane);
       if ((lane & 15) == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (ol[r] >= 0) unsafeAtomicAdd(gt + a.l_b1 + ol[r], b4[r]);
+          if (ol[r] >= 0) AR_GADD(gt + a.l_b1 + ol[r], b4[r]);
       }
     }
     __syncthreads();   // (the recomputed H1 is overwritten next)
@@ -851,13 +856,13 @@ __global__ __launch_bounds__(64 * NWV) void k_ar_train(ArArgs a, const float* __
         const int io = i < a.D ? a.ord[t * a.D + i] : -1;   // (context columns: seen by every unit)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (i < nin && ol[r] >= 0 && io < oty[r]) unsafeAtomicAdd(gt + a.l_W0 + (size_t)ol[r] * nin + i, g4[r]);
+          if (i < nin && ol[r] >= 0 && io < oty[r]) AR_GADD(gt + a.l_W0 + (size_t)ol[r] * nin + i, g4[r]);
       }
       const ar_f32x4 b4 = ar_rowsum16(H2, o0, lane);
       if ((lane & 15) == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (ol[r] >= 0) unsafeAtomicAdd(gt + a.l_b0 + ol[r], b4[r]);
+          if (ol[r] >= 0) AR_GADD(gt + a.l_b0 + ol[r], b4[r]);
       }
     }
     AR_TS(134);
@@ -867,6 +872,26 @@ __global__ __launch_bounds__(64 * NWV) void k_ar_train(ArArgs a, const float* __
     AR_TS(135);
     for (int d = wid; d < a.D; d += NWV) GG[d * RS + lane] = DV[d * RS + lane] + QB0[d * RS + lane];
   }
+}
+
+// grad[i] = sum over the workgroups' partials, in workgroup order; 0 where no workgroup writes (masked weights: live[i] = 0)
+__global__ __launch_bounds__(256) void k_ar_gather(const float* __restrict__ part, long stride, int nwg, const unsigned char* __restrict__ live,
+                                                   float* __restrict__ grad, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (live[i]) {
+    const float* p = part + i;
+    int w = 0;
+    for (; w + 4 <= nwg; w += 4) {
+      s0 += p[(size_t)w * stride];
+      s1 += p[(size_t)(w + 1) * stride];
+      s2 += p[(size_t)(w + 2) * stride];
+      s3 += p[(size_t)(w + 3) * stride];
+    }
+    for (; w < nwg; ++w) s0 += p[(size_t)w * stride];
+  }
+  grad[i] = (s0 + s1) + (s2 + s3);
 }
 
 #define AR_HIP(call)                                                        \
@@ -1075,7 +1100,7 @@ void sf_nsfar_destroy(SfNsfAr* n) {
   if (!n) return;
   (void)hipFree(n->d_img); (void)hipFree(n->d_src); (void)hipFree(n->d_none); (void)hipFree(n->d_perm); (void)hipFree(n->d_ptype); (void)hipFree(n->d_tend);
   (void)hipFree(n->d_ord); (void)hipFree(n->d_dimof); (void)hipFree(n->d_xmean); (void)hipFree(n->d_xstd); (void)hipFree(n->d_ustash);
-  (void)hipFree(n->d_ctr); (void)hipFree(n->d_gal); (void)hipFree(n->d_surv[0]); (void)hipFree(n->d_surv[1]); (void)hipFree(n->d_best);
+  (void)hipFree(n->d_ctr); (void)hipFree(n->d_live); (void)hipFree(n->d_gpart); (void)hipFree(n->d_gal); (void)hipFree(n->d_surv[0]); (void)hipFree(n->d_surv[1]); (void)hipFree(n->d_best);
   delete n;
 }
 
@@ -1090,6 +1115,12 @@ static int ar_ensure(SfNsfAr* n, std::string& err) {
   AR_HIP(hipMalloc(&n->d_img, n->src.size() * sizeof(float)));
   AR_HIP(up(n->d_src, n->src)); AR_HIP(up(n->d_perm, n->perm)); AR_HIP(up(n->d_ptype, n->ptype)); AR_HIP(up(n->d_tend, n->tend));
   AR_HIP(up(n->d_ord, n->ord)); AR_HIP(up(n->d_dimof, n->dimof)); AR_HIP(up(n->d_xmean, n->h_xmean)); AR_HIP(up(n->d_xstd, n->h_xstd));
+  {   // live[i] = 1 where logical parameter i appears in an image (an unmasked weight or a bias): the entries a training workgroup writes
+    std::vector<unsigned char> live((size_t)n->n_params, 0);
+    for (int32_t v : n->src)
+      if (v >= 0) live[(size_t)v] = 1;
+    AR_HIP(up(n->d_live, live));
+  }
   AR_HIP(hipMalloc(&n->d_ctr, 8 * sizeof(unsigned long long)));   // [0] cursor [1] unfilled [2] evaluations [3] rejected first attempts [4], [5] survivor counts
   {
     const std::vector<int32_t> none(n->src.size(), -1);
@@ -1097,7 +1128,8 @@ static int ar_ensure(SfNsfAr* n, std::string& err) {
   }
   const size_t lds = (size_t)160 * 1024 - 1024;   // (k_ar_sample also has 768 static bytes)
   AR_HIP(set_lds(k_ar_logprob<1>, lds)); AR_HIP(set_lds(k_ar_logprob<4>, lds)); AR_HIP(set_lds(k_ar_inverse, lds)); AR_HIP(set_lds(k_ar_sample, lds));
-  AR_HIP(set_lds(k_ar_train<1>, lds)); AR_HIP(set_lds(k_ar_train<4>, lds));
+  AR_HIP(set_lds(k_ar_train<1, false>, lds)); AR_HIP(set_lds(k_ar_train<4, false>, lds));
+  AR_HIP(set_lds(k_ar_train<1, true>, lds)); AR_HIP(set_lds(k_ar_train<4, true>, lds));
   AR_HIP(set_lds(k_ar_find, lds)); AR_HIP(set_lds(k_ar_resolve, lds));
   n->dev_ready = true;
   return SF_OK;
@@ -1303,8 +1335,10 @@ int sf_nsfar_loss_grad(SfNsfAr* n, const float* flat, const float* theta, const 
                        hipEvent_t ev1) {
   int rc = sf_nsfar_pack(n, flat, st, err);
   if (rc) return rc;
-  AR_HIP(hipMemsetAsync(grad, 0, (size_t)n->n_params * sizeof(float), st));
-  if (B == 0) return SF_OK;
+  if (B == 0) {
+    AR_HIP(hipMemsetAsync(grad, 0, (size_t)n->n_params * sizeof(float), st));
+    return SF_OK;
+  }
   const size_t need = (size_t)B * n->T * n->D;
   if (need > n->ustash_cap) {
     if (n->d_ustash) AR_HIP(hipFree(n->d_ustash));
@@ -1312,19 +1346,52 @@ int sf_nsfar_loss_grad(SfNsfAr* n, const float* flat, const float* theta, const 
     AR_HIP(hipMalloc(&n->d_ustash, need * sizeof(float)));
     n->ustash_cap = need;
   }
+  // Gradient accumulation: per-workgroup partials + k_ar_gather while they are few (<= 512 workgroups = 32 768 rows and <= 512 MiB:
+  // plain stores, summed in workgroup order -- bitwise reproducible; cfg1 shape at 16 384 rows: 0.57 -> 0.41 ms), f32 atomics into the
+  // one gradient beyond (SF_AR_GRAD=atomic | partial forces one).
+  const long nwg = (B + 63) / 64;
+  static int force = -1;
+  if (force < 0) { const char* e = std::getenv("SF_AR_GRAD"); force = !e ? 0 : (e[0] == 'a' ? 1 : (e[0] == 'p' ? 2 : 0)); }
+  const size_t part_bytes = (size_t)nwg * (size_t)n->n_params * sizeof(float);
+  const bool part = force == 2 ? part_bytes <= ((size_t)4 << 30) : (force != 1 && nwg <= 512 && part_bytes <= ((size_t)512 << 20));
+  if (part) {
+    if (part_bytes > n->gpart_cap) {
+      if (n->d_gpart) AR_HIP(hipFree(n->d_gpart));
+      n->d_gpart = nullptr; n->gpart_cap = 0;
+      AR_HIP(hipMalloc(&n->d_gpart, part_bytes));
+      n->gpart_cap = part_bytes;
+    }
+  } else {
+    AR_HIP(hipMemsetAsync(grad, 0, (size_t)n->n_params * sizeof(float), st));
+  }
+  float* gdst = part ? n->d_gpart : grad;
+  const long gstride = part ? (long)n->n_params : 0;
+  ArArgs aa = args_of(*n);
+#ifdef SF_AR_TRACE
+  static unsigned long long* d_tr = nullptr;
+  if (!d_tr) AR_HIP(hipMalloc(&d_tr, 256 * 8));
+  AR_HIP(hipMemsetAsync(d_tr, 0, 256 * 8, st));
+  aa.trace = d_tr;
+#endif
+  if (ev0) AR_HIP(hipEventRecord(ev0, st));
+  const int nwv = ar_waves(*n, 3);
+  const dim3 grid((unsigned)nwg), block(64 * nwv);
+  const size_t lds = sf_nsfar_lds_bytes(*n, 3, nwv);
+  if (nwv == 4) {
+    if (part) hipLaunchKernelGGL((k_ar_train<4, true>), grid, block, lds, st, aa, theta, x, idx, B, grad_scale, weights, loss, loss_sum, gdst, gstride, n->d_ustash);
+    else hipLaunchKernelGGL((k_ar_train<4, false>), grid, block, lds, st, aa, theta, x, idx, B, grad_scale, weights, loss, loss_sum, gdst, gstride, n->d_ustash);
+  } else {
+    if (part) hipLaunchKernelGGL((k_ar_train<1, true>), grid, block, lds, st, aa, theta, x, idx, B, grad_scale, weights, loss, loss_sum, gdst, gstride, n->d_ustash);
+    else hipLaunchKernelGGL((k_ar_train<1, false>), grid, block, lds, st, aa, theta, x, idx, B, grad_scale, weights, loss, loss_sum, gdst, gstride, n->d_ustash);
+  }
+  AR_HIP(hipGetLastError());
+  if (ev1) AR_HIP(hipEventRecord(ev1, st));
+  if (part) {
+    hipLaunchKernelGGL(k_ar_gather, dim3((unsigned)((n->n_params + 255) / 256)), dim3(256), 0, st, n->d_gpart, gstride, (int)nwg, n->d_live, grad, (long)n->n_params);
+    AR_HIP(hipGetLastError());
+  }
 #ifdef SF_AR_TRACE
   {
-    static unsigned long long* d_tr = nullptr;
-    if (!d_tr) AR_HIP(hipMalloc(&d_tr, 256 * 8));
-    AR_HIP(hipMemsetAsync(d_tr, 0, 256 * 8, st));
-    ArArgs aa = args_of(*n);
-    aa.trace = d_tr;
-    if (ar_waves(*n, 3) == 4)
-      hipLaunchKernelGGL(k_ar_train<4>, dim3((unsigned)((B + 63) / 64)), dim3(256), sf_nsfar_lds_bytes(*n, 3, 4), st, aa, theta, x, idx, B, grad_scale,
-                         weights, loss, loss_sum, grad, n->d_ustash);
-    else
-      hipLaunchKernelGGL(k_ar_train<1>, dim3((unsigned)((B + 63) / 64)), dim3(64), sf_nsfar_lds_bytes(*n, 3, 1), st, aa, theta, x, idx, B, grad_scale,
-                         weights, loss, loss_sum, grad, n->d_ustash);
     AR_HIP(hipStreamSynchronize(st));
     unsigned long long h[256];
     AR_HIP(hipMemcpy(h, d_tr, sizeof(h), hipMemcpyDeviceToHost));
@@ -1334,17 +1401,7 @@ int sf_nsfar_loss_grad(SfNsfAr* n, const float* flat, const float* theta, const 
       for (int i = 0; i < 256; ++i) if (h[i]) fprintf(stderr, " %d:%.1f", i, (double)(long long)(h[i] - h[0]) * 0.01);
       fprintf(stderr, "\n");
     }
-    return SF_OK;
   }
 #endif
-  if (ev0) AR_HIP(hipEventRecord(ev0, st));
-  if (ar_waves(*n, 3) == 4)
-    hipLaunchKernelGGL(k_ar_train<4>, dim3((unsigned)((B + 63) / 64)), dim3(256), sf_nsfar_lds_bytes(*n, 3, 4), st, args_of(*n), theta, x, idx, B,
-                       grad_scale, weights, loss, loss_sum, grad, n->d_ustash);
-  else
-    hipLaunchKernelGGL(k_ar_train<1>, dim3((unsigned)((B + 63) / 64)), dim3(64), sf_nsfar_lds_bytes(*n, 3, 1), st, args_of(*n), theta, x, idx, B,
-                       grad_scale, weights, loss, loss_sum, grad, n->d_ustash);
-  AR_HIP(hipGetLastError());
-  if (ev1) AR_HIP(hipEventRecord(ev1, st));
   return SF_OK;
 }
