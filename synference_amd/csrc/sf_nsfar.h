@@ -37,6 +37,7 @@ struct SfNsfAr {
   size_t gpart_cap = 0;
   int32_t* d_gal = nullptr;              // [2][M]: attempts / accepted draws per row (progress rule of the uncapped sampler)
   size_t gal_cap = 0;
+  unsigned long long* h_ctr = nullptr;   // pinned host copy of d_ctr (read back after the persistent launch and after every round)
   unsigned long long* d_ctr = nullptr;   // [0] work cursor of the sampler, [1] slots written off, [2] evaluations, [3] first attempts rejected
   uint32_t *d_surv[2] = {nullptr, nullptr}, *d_best = nullptr;   // survivor lists of the find / resolve rounds, lowest accepted attempt
   size_t surv_cap = 0;

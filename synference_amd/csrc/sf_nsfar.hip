@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <ctime>
 #include <cstdio>
 #include <string>
 #include <vector>
@@ -1100,7 +1101,7 @@ void sf_nsfar_destroy(SfNsfAr* n) {
   if (!n) return;
   (void)hipFree(n->d_img); (void)hipFree(n->d_src); (void)hipFree(n->d_none); (void)hipFree(n->d_perm); (void)hipFree(n->d_ptype); (void)hipFree(n->d_tend);
   (void)hipFree(n->d_ord); (void)hipFree(n->d_dimof); (void)hipFree(n->d_xmean); (void)hipFree(n->d_xstd); (void)hipFree(n->d_ustash);
-  (void)hipFree(n->d_ctr); (void)hipFree(n->d_live); (void)hipFree(n->d_gpart); (void)hipFree(n->d_gal); (void)hipFree(n->d_surv[0]); (void)hipFree(n->d_surv[1]); (void)hipFree(n->d_best);
+  (void)hipFree(n->d_ctr); (void)hipHostFree(n->h_ctr); (void)hipFree(n->d_live); (void)hipFree(n->d_gpart); (void)hipFree(n->d_gal); (void)hipFree(n->d_surv[0]); (void)hipFree(n->d_surv[1]); (void)hipFree(n->d_best);
   delete n;
 }
 
@@ -1121,7 +1122,8 @@ static int ar_ensure(SfNsfAr* n, std::string& err) {
       if (v >= 0) live[(size_t)v] = 1;
     AR_HIP(up(n->d_live, live));
   }
-  AR_HIP(hipMalloc(&n->d_ctr, 8 * sizeof(unsigned long long)));   // [0] cursor [1] unfilled [2] evaluations [3] rejected first attempts [4], [5] survivor counts
+  AR_HIP(hipMalloc(&n->d_ctr, 8 * sizeof(unsigned long long)));
+  AR_HIP(hipHostMalloc((void**)&n->h_ctr, 8 * sizeof(unsigned long long), hipHostMallocDefault));   // [0] cursor [1] unfilled [2] evaluations [3] rejected first attempts [4], [5] survivor counts
   {
     const std::vector<int32_t> none(n->src.size(), -1);
     AR_HIP(up(n->d_none, none));
@@ -1267,18 +1269,25 @@ int sf_nsfar_sample(SfNsfAr* n, const float* x, long M, long S, const uint32_t* 
   }
   AR_HIP(hipGetLastError());
   if (ev1) AR_HIP(hipEventRecord(ev1, st));
-  unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long* h = n->h_ctr;   // (pinned: a read-back into pageable memory is a staged, host-synchronous copy)
+  for (int i = 0; i < 8; ++i) h[i] = 0;
   if (rounds) {
     int cur = 0;
     uint32_t base = window;
     for (;;) {
-      AR_HIP(hipMemcpyAsync(h, n->d_ctr, sizeof(h), hipMemcpyDeviceToHost, st));
+      AR_HIP(hipMemcpyAsync(h, n->d_ctr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
       AR_HIP(hipStreamSynchronize(st));
       const unsigned int ns = reinterpret_cast<const unsigned int*>(h + 4)[cur];
       {
         static int dbg = -1;
         if (dbg < 0) dbg = std::getenv("SF_AR_DEBUG") ? 1 : 0;
-        if (dbg) fprintf(stderr, "[nsfar rounds] base %u survivors %u evaluations %llu\n", base, ns, h[2]);
+        if (dbg) {
+          static double t_prev = 0.0;
+          timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+          const double tn = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+          fprintf(stderr, "[nsfar rounds] base %u survivors %u evaluations %llu  (+%.3f ms since the previous read-back)\n", base, ns, h[2], tn - t_prev);
+          t_prev = tn;
+        }
       }
       if (ns == 0 || base >= cap) break;
       uint32_t A = 64;
@@ -1318,10 +1327,10 @@ int sf_nsfar_sample(SfNsfAr* n, const float* x, long M, long S, const uint32_t* 
       }
       AR_HIP(hipGetLastError());
     }
-    AR_HIP(hipMemcpyAsync(h, n->d_ctr, sizeof(h), hipMemcpyDeviceToHost, st));
+    AR_HIP(hipMemcpyAsync(h, n->d_ctr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     AR_HIP(hipStreamSynchronize(st));
   } else if (n_unfilled) {
-    AR_HIP(hipMemcpyAsync(h, n->d_ctr, sizeof(h), hipMemcpyDeviceToHost, st));
+    AR_HIP(hipMemcpyAsync(h, n->d_ctr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     AR_HIP(hipStreamSynchronize(st));
   }
   if (n_unfilled) *n_unfilled = (int64_t)(unsigned int)h[1];
