@@ -148,14 +148,19 @@ int sf_flow_inverse_from_noise(sf_flow* f, const float* z /*[B,D]*/, const float
                                int64_t B, float* theta /*[B,D]*/, float* logdet /*[B]*/,
                                void* stream);
 /* Parity hook of the SAMPLER's arithmetic: the same inverse from given noise, evaluated by the pass functions the
- * persistent sampler (sf_flow_sample) runs -- for a MAF with H <= 64 the hidden H x H blocks as split-bf16 x3 products
- * with fp32 accumulation, everything else fp32.  Returns 0, or 1 when this flow's sampler is the all-fp32 path (then
- * the result is sf_flow_inverse_from_noise's).  Replaces nothing in the reference: test surface of
- * posterior.sample's numerics (sbi_runner.py:6442). */
+ * persistent sampler (sf_flow_sample) runs in the current mode (sf_set_sampler_fp32).  Returns which arithmetic that was
+ * (negative: error):
+ *   0  split-bf16 x3 hidden blocks with fp32 accumulation (the opt-in mode of a MAF with H <= 64; the default of the coupling NSF)
+ *   1  the generic all-fp32 path (the result is sf_flow_inverse_from_noise's)
+ *   2  the 16-row fp32 kernels, both layers of block 0 as they are stored (SF_FUSE=0)
+ *   3  the 16-row fp32 kernels with the first block layer folded into the input layer (W' = W1 W0; the default of a MAF)
+ * Replaces nothing in the reference: test surface of posterior.sample's numerics (sbi_runner.py:6442). */
 int sf_flow_inverse_from_noise_sampler(sf_flow* f, const float* z /*[B,D]*/, const float* x /*[B,C]*/, int64_t B,
                                        float* theta /*[B,D]*/, void* stream);
-/* 1: the persistent sampler takes the all-fp32 kernels (also: environment SF_SAMPLER_FP32=1); 0: default
- * (split-bf16 x3 hidden blocks where the flow has them).  Process-wide. */
+/* Arithmetic of the persistent sampler's hidden blocks, process-wide (also: environment SF_SAMPLER_FP32):
+ *    1  fp32 everywhere;  0  split-bf16 x3 hidden blocks where the flow has them;
+ *   -1  the per-kind default (round 5): fp32 for a MAF -- configs[1] says fp32, and log p of a draw moved by up to 1.3e-3
+ *       under the split -- , split for the coupling NSF.  Returns 0. */
 int sf_set_sampler_fp32(int on);
 
 /* One rejection round over a list of output slots (slot = g*S + p).  For every listed slot the
