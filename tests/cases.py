@@ -49,6 +49,10 @@ CASES = {
     "nsfar_small": ("nsf_ar", 3, 4, 17, 2, 5, dict(tail_bound=5.0)),
     "nsfar_d1": ("nsf_ar", 1, 6, 16, 3, 8, dict(tail_bound=5.0)),
     "nsfar_wide": ("nsf_ar", 8, 20, 64, 3, 8, dict(tail_bound=5.0, ar_slope=1e-2)),
+    # sixteen units per type (all four k-steps of the 16-candidate sampler's hidden blocks: sf_nsfar16.hip, KS = 4) and two input tiles
+    # (D + C = 21), two units per type at D = 8 (KS = 2, half-empty tiles)
+    "nsfar_k4": ("nsf_ar", 4, 17, 64, 2, 6, dict(tail_bound=5.0)),
+    "nsfar_thin": ("nsf_ar", 8, 5, 16, 3, 4, dict(tail_bound=5.0)),
     # the widest member of the reference's own lampe example (examples/sbi/scripts/basic_model.py:31-41: hidden_features 180): seven
     # types of 25-26 units padded to 32 rows each; fits since the training sweep runs on two hidden buffers
     "nsfar_h180": ("nsf_ar", 7, 12, 180, 2, 8, dict(tail_bound=5.0)),

@@ -106,7 +106,8 @@ def test_tiny_and_empty_batches():
 
 
 @pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "nsf_odd", "nsf_h69", "maf_span6", "maf_d2_span", "maf_d4", "maf_d3", "maf_sig2", "nsf_d1",
-                                  "nsfar_cfg1", "nsfar_small", "nsfar_d1", "nsfar_wide", "nsfar_h180", "mafar_cfg1", "mafar_small"])
+                                  "nsfar_cfg1", "nsfar_small", "nsfar_d1", "nsfar_wide", "nsfar_h180", "nsfar_k4", "nsfar_thin", "mafar_cfg1",
+                                  "mafar_small"])
 def test_sampler_matches_oracle_draw_for_draw(name):
     _draw_for_draw(name)
 
@@ -194,6 +195,20 @@ def test_autoregressive_nsf_slots_acceptance_and_exhaustion():
     far_lo, far_hi = (hi + 50.0).astype(np.float32), (hi + 51.0).astype(np.float32)
     got, nd = f.sample(x[:2], 8, far_lo, far_hi, seed=1, max_attempts=5, return_counts=True)
     assert torch.isnan(got).all() and f.last_unfilled == 16 and (nd.cpu().numpy() == 8 * 5).all()
+
+
+def test_lampe_sampler_kernel_selection():
+    """Which sampling kernel a lampe-backend flow takes (describe()): the 16-candidate register-tile kernels (sf_nsfar16.hip) for
+    2 <= D <= 8 with at most sixteen hidden units per type and D + C <= 32, the 64-sample LDS kernel otherwise; k-steps per hidden
+    block = ceil(units per type / 4)."""
+    want = {"nsfar_cfg1": (1, 3), "nsfar_small": (1, 2), "nsfar_wide": (1, 2), "nsfar_k4": (1, 4), "nsfar_thin": (1, 2), "mafar_cfg1": (1, 3),
+            "nsfar_d1": (0, None), "nsfar_h180": (0, None)}
+    for name, (tiles16, ks) in want.items():
+        ospec, spec, flat, theta, x = make_case(name, B=2)
+        d = _flow(spec, flat).describe()
+        assert d["sampler_tiles16"] == tiles16, (name, d["sampler_tiles16"])
+        if tiles16:
+            assert d["s16_ks"] == ks and d["s16_nt"] == spec.D and d["s16_ni"] == (spec.D + spec.C + 15) // 16, (name, d)
 
 
 def test_autoregressive_nsf_deep_tail_rounds_keep_the_lowest_accepted_attempt():
