@@ -52,13 +52,22 @@ class RcclComm:
     def create(cls, device, nranks: int = 1, rank: int = 0, exchange=None) -> "RcclComm":
         """``exchange(id_bytes or None) -> id_bytes``: rank 0 passes the id in and every rank gets it back (default: one
         ``broadcast_object_list`` over the default process group; not called for a single rank)."""
-        _bind_library()
-        lib = _lib.load()
         device = torch.device(device)
         torch.cuda.set_device(device)
         uid = C.create_string_buffer(ID_BYTES)
-        if rank == 0:
-            _lib.check(lib.sf_comm_unique_id(uid, ID_BYTES))
+        # Everything that can fail on ONE rank (binding the library, drawing the id) is done before the first collective, and its
+        # outcome travels WITH the id: a rank that raised here while its peers waited in the broadcast -- or in ncclCommInitRank --
+        # would leave them there for good.  Every rank learns of a failure anywhere and raises the same error.
+        err = None
+        lib = None
+        try:
+            _bind_library()
+            lib = _lib.load()
+            library_info()
+            if rank == 0:
+                _lib.check(lib.sf_comm_unique_id(uid, ID_BYTES))
+        except Exception as e:   # noqa: BLE001 -- reported below, on every rank
+            err = f"rank {rank}: {type(e).__name__}: {e}"
         raw = bytes(uid.raw)
         if nranks > 1:
             if exchange is None:
@@ -68,7 +77,19 @@ class RcclComm:
                     box = [b]
                     dist.broadcast_object_list(box, src=0)
                     return box[0]
-            raw = exchange(raw if rank == 0 else None)
+
+                def agree(msg):
+                    msgs = [None] * dist.get_world_size()
+                    dist.all_gather_object(msgs, msg)
+                    return next((m for m in msgs if m), None)
+            else:
+                def agree(msg):
+                    return msg
+            raw = exchange((raw, err) if rank == 0 else None)
+            raw, err0 = raw if isinstance(raw, tuple) else (raw, None)
+            err = agree(err or err0)
+        if err:
+            raise RuntimeError(f"RCCL communicator not created ({err})")
         h = C.c_void_p()
         _lib.check(lib.sf_comm_create(raw, ID_BYTES, int(nranks), int(rank), C.byref(h)))
         return cls(h.value, int(nranks), int(rank), device)
