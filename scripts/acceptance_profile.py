@@ -27,7 +27,7 @@ for it in range(int(os.environ.get("FIT_STEPS", "4000"))):
     flow.loss_grad(flat, Ttr[bi], Xtr[bi], 1.0 / 2048, grad_out=grad); opt.step(grad, 5.0)
 flow.set_params(flat)
 X = torch.as_tensor(x_all).to(dev)
-acc = flow.acceptance(X, 20000, prior.low.to(dev), prior.high.to(dev), seed=5).cpu().numpy() / 20000.0
+acc = flow.acceptance(X, 20000, prior.low.to(dev), prior.high.to(dev), seed=5).cpu().numpy()   # (fractions)
 print("galaxies", len(acc), "mean acceptance", acc.mean(), "expected attempts per slot", (1 / np.maximum(acc, 1e-5)).mean())
 qs = [0, 0.001, 0.01, 0.05, 0.1, 0.25, 0.5]
 print("quantiles of p:", {q: float(np.quantile(acc, q)) for q in qs})
