@@ -15,7 +15,7 @@ struct SfNsfAr {
   float th_scale[16], th_shift[16];
   std::vector<float> h_xmean, h_xstd;
   // hidden rows sorted by type; perm[p] = logical unit of physical row p (-1: padding), ptype[p] its type, tend[r] = rows of type <= r
-  std::vector<int32_t> perm, ptype, tend, ord, dimof, src;
+  std::vector<int32_t> perm, ptype, tend, ord, dimof, dwave, src;
   int64_t n_params = 0;
   long P_t = 0, t_stride = 0;
   int l_W0 = 0, l_b0 = 0, l_W1 = 0, l_b1 = 0, l_W2 = 0, l_b2 = 0;                             // logical offsets in a transform
@@ -27,7 +27,7 @@ struct SfNsfAr {
   int s16_nt = 0, s16_ni = 0, s16_ks = 4, o_F0 = 0, o_fb0 = 0, o_F1 = 0, o_fb1 = 0, o_F2 = 0;
   bool dev_ready = false;
   float* d_img = nullptr;
-  int32_t *d_src = nullptr, *d_none = nullptr, *d_perm = nullptr, *d_ptype = nullptr, *d_tend = nullptr, *d_ord = nullptr, *d_dimof = nullptr;
+  int32_t *d_src = nullptr, *d_none = nullptr, *d_perm = nullptr, *d_ptype = nullptr, *d_tend = nullptr, *d_ord = nullptr, *d_dimof = nullptr, *d_dwave = nullptr;
   float *d_xmean = nullptr, *d_xstd = nullptr;
   int affine = 0;               // SF_MAF_AR (zuko MAF): MonotonicAffineTransform instead of the spline
   float* d_ustash = nullptr;

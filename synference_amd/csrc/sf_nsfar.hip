@@ -24,6 +24,7 @@
 // the stash and back-propagated by hand.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <ctime>
 #include <cstdio>
@@ -39,8 +40,8 @@
 namespace {
 
 // one element of a weight gradient: k_ar_train<NWV, PART> -- PART: the workgroup's own partial (every element of a transform's
-// gradient is produced exactly once per workgroup: plain stores, summed in workgroup order by k_ar_gather: no atomics, bitwise
-// reproducible); else f32 atomics into the one gradient (256 workgroups adding the same 57 k elements in lockstep: 0.18 of 0.57 ms)
+// gradient is produced exactly once per workgroup: plain stores, summed in workgroup order by k_ar_gather: no global atomics -- the
+// LDS adds of the hidden deltas inside a workgroup keep the hardware's order, so runs agree to rounding, not to the bit); else f32 atomics into the one gradient (256 workgroups adding the same 57 k elements in lockstep: 0.18 of 0.57 ms)
 #define AR_GADD(p, v) do { if (PART) *(p) = (v); else unsafeAtomicAdd((p), (v)); } while (0)
 constexpr int ARK = 8, ARQ = 24;   // bins capacity / parameter slots per dimension (K <= 8: 3K - 1 <= 23)
 constexpr int RS = 65;             // floats per LDS row (64 samples + 1: the MFMA operand reads of the training kernel walk rows
@@ -55,6 +56,7 @@ struct ArArgs {
   const int32_t* tend;    // [D]  rows of type <= r
   const int32_t* ord;     // [T][D] order value of dimension d
   const int32_t* dimof;   // [T][D] dimension with order value r
+  const int32_t* dwave;   // [T][D] wave (of four) that runs dimension d of transform t in the multi-wave density / training kernels
   const float* xmean;     // [C]
   const float* xstd;      // [C]
   int D, C, H, Hp, T, K, NP, NIN16, NIN4;
@@ -366,7 +368,8 @@ __global__ __launch_bounds__(64 * NWV) void k_ar_logprob(ArArgs a, const float* 
     AR_TS(1 + t * 40);
     ar_hidden(a, tp, E0, H1, H2, lane, wid, NWV);
     AR_TS(2 + t * 40);
-    for (int d = wid; d < a.D; d += NWV) {
+    for (int d = 0; d < a.D; ++d) {
+      if (NWV > 1 && a.dwave[t * a.D + d] != wid) continue;   // (dimensions dealt by cost: see sf_nsfar_create)
       float q[ARQ];
       ar_head(a, tp, d, (int)a.tendk[a.ord[t * a.D + d]], H2, QB, lane, q);
       AR_TS(3 + t * 40 + 2 * d);
@@ -687,7 +690,11 @@ __global__ __launch_bounds__(64 * NWV) void k_ar_train(ArArgs a, const float* __
   float* H1 = E0 + a.NIN16 * RS;         // [Hp]
   float* H2 = H1 + a.Hp * RS;            // [Hp]
   float* QB0 = H2 + a.Hp * RS;           // [NWV][32] per wave: head outputs of ONE dimension, then their deltas; wave 0: the input deltas
-  float* QB = QB0 + wid * 32 * RS;
+  // (24 rows per wave here: the head's 24 slots.  The 16-row tile routines read rows 24..31 of a wave's second tile -- the next wave's
+  //  buffer, or GG behind the last -- and everything computed from them lands in output rows that are never stored; 32 rows per wave
+  //  put the workgroup at 81.6 KB, two rows short of two workgroups per CU)
+  constexpr int QBR = 24;
+  float* QB = QB0 + wid * QBR * RS;
   // TWO hidden buffers serve the backward sweep (round 5; three before: 102 KB for cfg1's shape, one workgroup per CU, and the
   // reference's own lampe example -- 180 hidden units, examples/sbi/scripts/basic_model.py:31-41 -- did not fit at all):
   //   head phase     H2 = last hidden layer (operand of the head's weight gradients), DH = its delta, accumulated in H1's rows
@@ -695,7 +702,7 @@ __global__ __launch_bounds__(64 * NWV) void k_ar_train(ArArgs a, const float* __
   //   second layer   H1 is RECOMPUTED into H2's rows (dead after it has gated DH): weight gradients DH x H1;
   //   first layer    delta_h1 = L1m^T DH overwrites the recomputed H1, gated by the bits.
   float* DH = H1;                        // (alias: see above)
-  float* GG = QB0 + NWV * 32 * RS;       // [D] dL/du at the transform's output
+  float* GG = QB0 + NWV * QBR * RS;      // [D] dL/du at the transform's output
   float* DV = GG + a.D * RS;             // [D] what reaches the transform's input through the splines
   int* PERM = reinterpret_cast<int*>(DV + a.D * RS);   // [Hp] perm, [Hp] ptype: read per weight-gradient block
   int* PTYP = PERM + a.Hp;
@@ -715,7 +722,8 @@ __global__ __launch_bounds__(64 * NWV) void k_ar_train(ArArgs a, const float* __
     __syncthreads();   // (E0 complete)
     for (int d = wid; d < a.D; d += NWV) ust[t * a.D + d] = E0[d * RS + lane];
     ar_hidden(a, tp, E0, H1, H2, lane, wid, NWV);
-    for (int d = wid; d < a.D; d += NWV) {
+    for (int d = 0; d < a.D; ++d) {
+      if (NWV > 1 && a.dwave[t * a.D + d] != wid) continue;
       float q[ARQ];
       ar_head(a, tp, d, (int)a.tendk[a.ord[t * a.D + d]], H2, QB, lane, q);
       float v, lad;
@@ -729,7 +737,7 @@ __global__ __launch_bounds__(64 * NWV) void k_ar_train(ArArgs a, const float* __
     QB[lane] = ld;
     __syncthreads();
     if (wid == 0)
-      for (int w2 = 1; w2 < NWV; ++w2) ld += QB0[w2 * 32 * RS + lane];
+      for (int w2 = 1; w2 < NWV; ++w2) ld += QB0[w2 * QBR * RS + lane];
   }
   if (wid == 0) {
     float ss = 0.f;
@@ -762,7 +770,8 @@ __global__ __launch_bounds__(64 * NWV) void k_ar_train(ArArgs a, const float* __
     __syncthreads();
     AR_TS(101);
     // ---- head + splines, dimension by dimension (wave wid: dimensions wid, wid + NWV, ...)
-    for (int d = wid; d < a.D; d += NWV) {
+    for (int d = 0; d < a.D; ++d) {
+      if (NWV > 1 && a.dwave[t * a.D + d] != wid) continue;
       const int kend = (int)a.tendk[a.ord[t * a.D + d]];
       float q[ARQ], dq[ARQ];
       ar_head(a, tp, d, kend, H2, QB, lane, q);
@@ -906,7 +915,7 @@ __global__ __launch_bounds__(256) void k_ar_gather(const float* __restrict__ par
 
 ArArgs args_of(const SfNsfAr& n) {
   ArArgs a;
-  a.img = n.d_img; a.perm = n.d_perm; a.ptype = n.d_ptype; a.tend = n.d_tend; a.ord = n.d_ord; a.dimof = n.d_dimof;
+  a.img = n.d_img; a.perm = n.d_perm; a.ptype = n.d_ptype; a.tend = n.d_tend; a.ord = n.d_ord; a.dimof = n.d_dimof; a.dwave = n.d_dwave;
   a.xmean = n.d_xmean; a.xstd = n.d_xstd;
   a.affine = n.affine;
   a.D = n.D; a.C = n.C; a.H = n.H; a.Hp = n.Hp; a.T = n.T; a.K = n.K; a.NP = n.NP; a.NIN16 = (n.D + n.C + 15) / 16 * 16; a.NIN4 = (n.D + n.C + 3) / 4 * 4;
@@ -1003,13 +1012,13 @@ int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err) {
     n->o_F2 = (int)o; o += (long)D * 2 * NTs * 256;
   }
   n->t_stride = (o + 63) / 64 * 64;
-  if (sf_nsfar_lds_bytes(*n, 3, 1) > (size_t)160 * 1024 - 1024) {
-    err = "autoregressive NSF: (3 D + C + 2 Hp + 32) x 260 bytes of LDS per wave exceed the 160 KB of a CU (Hp = H with every type padded to a multiple of 8, in all a multiple of 16)";
+  if (std::max(sf_nsfar_lds_bytes(*n, 3, 1), sf_nsfar_lds_bytes(*n, 2, 1)) > (size_t)160 * 1024 - 1024) {
+    err = "autoregressive NSF: (3 D + C + 2 Hp + 32) x 260 bytes of LDS per wave (training: 24 head rows + 16 Hp bytes of tables) exceed the 160 KB of a CU (Hp = H with every type padded to a multiple of 8, in all a multiple of 16)";
     delete n;
     return SF_ERR_INVALID;
   }
   n->src.assign((size_t)T * n->t_stride, -1);
-  n->ord.assign((size_t)T * D, 0); n->dimof.assign((size_t)T * D, 0);
+  n->ord.assign((size_t)T * D, 0); n->dimof.assign((size_t)T * D, 0); n->dwave.assign((size_t)T * D, 0);
   for (int t = 0; t < T; ++t) {
     int32_t* s = n->src.data() + (size_t)t * n->t_stride;
     const long base = (long)t * n->P_t;
@@ -1019,6 +1028,21 @@ int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err) {
       n->dimof[(size_t)t * D + r] = dd;
     }
     const int32_t* ord = n->ord.data() + (size_t)t * D;
+    {   // Dimensions over the four waves of k_ar_logprob<4> / k_ar_train<4>: the head, spline and (training) gradient work of a dimension
+        // grows with the hidden rows it reads (tend[ord]) -- the one ordered last costs five times the first at D = 5.  Longest first
+        // onto the least loaded wave (round robin gave one wave the cheapest AND the dearest: 6 units of 15 against 5).
+      std::vector<int> by_cost(D);
+      for (int dd = 0; dd < D; ++dd) by_cost[dd] = dd;
+      std::sort(by_cost.begin(), by_cost.end(), [&](int x, int y) { return ord[x] != ord[y] ? ord[x] > ord[y] : x < y; });
+      long load[4] = {0, 0, 0, 0};
+      for (int dd : by_cost) {
+        int w = 0;
+        for (int k = 1; k < 4; ++k)
+          if (load[k] < load[w]) w = k;
+        n->dwave[(size_t)t * D + dd] = w;
+        load[w] += n->tend[ord[dd]] + 24;   // (+ the spline: the same for every dimension)
+      }
+    }
     for (int p = 0; p < Hp; ++p) {
       const int h = n->perm[p], ty = n->ptype[p];
       if (h < 0) continue;
@@ -1100,7 +1124,7 @@ int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err) {
 void sf_nsfar_destroy(SfNsfAr* n) {
   if (!n) return;
   (void)hipFree(n->d_img); (void)hipFree(n->d_src); (void)hipFree(n->d_none); (void)hipFree(n->d_perm); (void)hipFree(n->d_ptype); (void)hipFree(n->d_tend);
-  (void)hipFree(n->d_ord); (void)hipFree(n->d_dimof); (void)hipFree(n->d_xmean); (void)hipFree(n->d_xstd); (void)hipFree(n->d_ustash);
+  (void)hipFree(n->d_ord); (void)hipFree(n->d_dimof); (void)hipFree(n->d_dwave); (void)hipFree(n->d_xmean); (void)hipFree(n->d_xstd); (void)hipFree(n->d_ustash);
   (void)hipFree(n->d_ctr); (void)hipHostFree(n->h_ctr); (void)hipFree(n->d_live); (void)hipFree(n->d_gpart); (void)hipFree(n->d_gal); (void)hipFree(n->d_surv[0]); (void)hipFree(n->d_surv[1]); (void)hipFree(n->d_best);
   delete n;
 }
@@ -1115,7 +1139,7 @@ static int ar_ensure(SfNsfAr* n, std::string& err) {
   };
   AR_HIP(hipMalloc(&n->d_img, n->src.size() * sizeof(float)));
   AR_HIP(up(n->d_src, n->src)); AR_HIP(up(n->d_perm, n->perm)); AR_HIP(up(n->d_ptype, n->ptype)); AR_HIP(up(n->d_tend, n->tend));
-  AR_HIP(up(n->d_ord, n->ord)); AR_HIP(up(n->d_dimof, n->dimof)); AR_HIP(up(n->d_xmean, n->h_xmean)); AR_HIP(up(n->d_xstd, n->h_xstd));
+  AR_HIP(up(n->d_ord, n->ord)); AR_HIP(up(n->d_dimof, n->dimof)); AR_HIP(up(n->d_dwave, n->dwave)); AR_HIP(up(n->d_xmean, n->h_xmean)); AR_HIP(up(n->d_xstd, n->h_xstd));
   {   // live[i] = 1 where logical parameter i appears in an image (an unmasked weight or a bias): the entries a training workgroup writes
     std::vector<unsigned char> live((size_t)n->n_params, 0);
     for (int32_t v : n->src)
@@ -1142,7 +1166,7 @@ size_t sf_nsfar_lds_bytes(const SfNsfAr& n, int hidden_buffers, int waves) {
   // (hidden_buffers == 3 names the TRAINING kernel: it runs on two hidden buffers too since round 5, plus the row tables and the
   //  sign bits of the first hidden layer)
   const int hb = hidden_buffers == 3 ? 2 : hidden_buffers;
-  return (size_t)((n.D + n.C + 15) / 16 * 16 + hb * n.Hp + 32 * waves + 2 * n.D) * RS * sizeof(float) +
+  return (size_t)((n.D + n.C + 15) / 16 * 16 + hb * n.Hp + (hidden_buffers == 3 ? 24 : 32) * waves + 2 * n.D) * RS * sizeof(float) +
          (hidden_buffers == 3 ? (size_t)4 * n.Hp * sizeof(int) : 0);
 }
 // waves per 64 samples of the density / training kernels: four (tile pairs and dimensions dealt round robin) when the LDS takes it
@@ -1356,7 +1380,7 @@ int sf_nsfar_loss_grad(SfNsfAr* n, const float* flat, const float* theta, const 
     n->ustash_cap = need;
   }
   // Gradient accumulation: per-workgroup partials + k_ar_gather while they are few (<= 512 workgroups = 32 768 rows and <= 512 MiB:
-  // plain stores, summed in workgroup order -- bitwise reproducible; cfg1 shape at 16 384 rows: 0.57 -> 0.41 ms), f32 atomics into the
+  // plain stores, summed in workgroup order; cfg1 shape at 16 384 rows: 0.57 -> 0.41 ms), f32 atomics into the
   // one gradient beyond (SF_AR_GRAD=atomic | partial forces one).
   const long nwg = (B + 63) / 64;
   static int force = -1;

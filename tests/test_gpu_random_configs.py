@@ -108,8 +108,9 @@ def test_random_config_of_the_other_flow_kinds_matches_oracle(kind, D, C, H, T, 
     if kind in ("nsf_ar", "maf_ar"):   # a wave's rows must fit the CU's LDS: shapes beyond that are refused at creation, by name
         Hp = sum((len(range(r, H, D)) + 7) // 8 * 8 for r in range(D))
         Hp = (Hp + 15) // 16 * 16
-        rows = (D + C + 15) // 16 * 16 + 2 * Hp + 32 + 2 * D     # (two hidden buffers since round 5: training included)
-        if rows * 65 * 4 + 4 * Hp * 4 > 160 * 1024 - 1024:
+        rows = (D + C + 15) // 16 * 16 + 2 * Hp + 2 * D          # (two hidden buffers; + the head rows of one wave)
+        need = max((rows + 32) * 65 * 4, (rows + 24) * 65 * 4 + 4 * Hp * 4)   # density / sampling kernels, training kernel (+ its tables)
+        if need > 160 * 1024 - 1024:
             with pytest.raises(RuntimeError, match="LDS"):
                 HipFlow(spec, "cuda:0")
             return

@@ -258,7 +258,7 @@ def test_loss_grad_rows_equals_gathered_loss_grad():
 
 def test_lampe_gradient_partials_and_atomics_agree():
     """sf_nsfar_loss_grad: up to 512 workgroups (32 768 rows) every workgroup stores its own gradient partial and k_ar_gather sums
-    them in workgroup order -- the same bits call after call --, larger batches add with f32 atomics into the one gradient.  Both
+    them in workgroup order, larger batches add with f32 atomics into the one gradient.  Both
     forms of the same kernel: the gradient of 40 000 rows (atomics) equals the sum of the gradients of its two halves (partials)."""
     from synference_amd.engine import HipFlow
     ospec, spec, flat, theta, x = make_case("nsfar_cfg1", B=40000)
@@ -268,7 +268,9 @@ def test_lampe_gradient_partials_and_atomics_agree():
     la, ga = f.loss_grad(fl, T[:20000], X[:20000], 1.0 / 40000)
     la, ga = la.clone(), ga.clone()
     l2, g2 = f.loss_grad(fl, T[:20000], X[:20000], 1.0 / 40000)
-    assert torch.equal(ga, g2) and torch.equal(la, l2)          # partials: bitwise reproducible
+    # partials: summed in workgroup order, no global atomics -- what is left of the hardware's order is the LDS adds of the hidden
+    # deltas inside a workgroup (four waves add their dimensions' shares into the same rows): equal to rounding, and the losses bit for bit
+    assert torch.equal(la, l2) and (ga - g2).abs().max().item() <= 2e-6 * ga.abs().max().item()
     lb, gb = f.loss_grad(fl, T[20000:], X[20000:], 1.0 / 40000)
     lb, gb = lb.clone(), gb.clone()
     lw, gw = f.loss_grad(fl, T, X, 1.0 / 40000)                 # 625 workgroups: atomics
