@@ -42,7 +42,7 @@ namespace {
 // one element of a weight gradient: k_ar_train<NWV, PART> -- PART: the workgroup's own partial (every element of a transform's
 // gradient is produced exactly once per workgroup: plain stores, summed in workgroup order by k_ar_gather: no global atomics -- the
 // LDS adds of the hidden deltas inside a workgroup keep the hardware's order, so runs agree to rounding, not to the bit); else f32 atomics into the one gradient (256 workgroups adding the same 57 k elements in lockstep: 0.18 of 0.57 ms)
-#define AR_GADD(p, v) do { if (PART) *(p) = (v); else unsafeAtomicAdd((p), (v)); } while (0)
+#define AR_GADD(p, v) do { if (PART && first_chunk) *(p) = (v); else unsafeAtomicAdd((p), (v)); } while (0)
 constexpr int ARK = 8, ARQ = 24;   // bins capacity / parameter slots per dimension (K <= 8: 3K - 1 <= 23)
 constexpr int RS = 65;             // floats per LDS row (64 samples + 1: the MFMA operand reads of the training kernel walk rows
                                    // with the lane index -- a stride of 64 would put sixteen rows on one bank)
@@ -678,8 +678,9 @@ __global__ __launch_bounds__(64) void k_ar_resolve(ArArgs a, const float* __rest
 }
 
 // forward (with the inputs of every transform stashed) + loss, then the backward sweep
+// (four-wave form: held to 256 registers, so that two workgroups share a CU where the LDS takes them -- it asked for 230 + 44)
 template <int NWV, bool PART>
-__global__ __launch_bounds__(64 * NWV) void k_ar_train(ArArgs a, const float* __restrict__ theta, const float* __restrict__ x,
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_ar_train(ArArgs a, const float* __restrict__ theta, const float* __restrict__ x,
                                                         const long long* __restrict__ idx, long B, float w, const float* __restrict__ wts,
                                                         float* __restrict__ loss, double* __restrict__ loss_sum, float* __restrict__ grad_in,
                                                         long part_stride, float* __restrict__ ustash) {
@@ -708,13 +709,20 @@ __global__ __launch_bounds__(64 * NWV) void k_ar_train(ArArgs a, const float* __
   int* PTYP = PERM + a.Hp;
   unsigned int* M1 = reinterpret_cast<unsigned int*>(PTYP + a.Hp);   // [Hp][2] samples with H1 > 0
   for (int i = threadIdx.x; i < a.Hp; i += 64 * NWV) { PERM[i] = a.perm[i]; PTYP[i] = a.ptype[i]; }
-  const long b = (long)blockIdx.x * 64 + lane;
+  const ZSplC sc = {a.K, a.B, a.cw, a.cd};
+  // (the launches give every workgroup ONE chunk of 64 rows; a workgroup that is given more -- a smaller grid -- stores its first
+  //  chunk's gradient into its partial and adds the later ones with f32 atomics nobody contends for)
+  const long n_chunks = (B + 63) / 64;
+  for (long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+  const bool first_chunk = chunk == (long)blockIdx.x;
+  (void)first_chunk;
+  if (!first_chunk) __syncthreads();   // (the previous chunk's last reads of the LDS rows)
+  const long b = chunk * 64 + lane;
   const bool valid = b < B;
   const long bb = valid ? b : B - 1;
   const long row = idx ? (long)idx[bb] : bb;
   AR_TS(0);
   ar_load_inputs(a, theta, x, row, E0, lane, wid, NWV);
-  const ZSplC sc = {a.K, a.B, a.cw, a.cd};
   float* ust = ustash + (size_t)bb * a.T * a.D;   // (an invalid lane shares the last row's stash: same values)
   float ld = 0.f;
   for (int t = 0; t < a.T; ++t) {
@@ -882,6 +890,7 @@ __global__ __launch_bounds__(64 * NWV) void k_ar_train(ArArgs a, const float* __
     AR_TS(135);
     for (int d = wid; d < a.D; d += NWV) GG[d * RS + lane] = DV[d * RS + lane] + QB0[d * RS + lane];
   }
+  }   // chunks
 }
 
 // grad[i] = sum over the workgroups' partials, in workgroup order; 0 where no workgroup writes (masked weights: live[i] = 0)
@@ -1379,14 +1388,17 @@ int sf_nsfar_loss_grad(SfNsfAr* n, const float* flat, const float* theta, const 
     AR_HIP(hipMalloc(&n->d_ustash, need * sizeof(float)));
     n->ustash_cap = need;
   }
-  // Gradient accumulation: per-workgroup partials + k_ar_gather while they are few (<= 512 workgroups = 32 768 rows and <= 512 MiB:
-  // plain stores, summed in workgroup order; cfg1 shape at 16 384 rows: 0.57 -> 0.41 ms), f32 atomics into the
-  // one gradient beyond (SF_AR_GRAD=atomic | partial forces one).
-  const long nwg = (B + 63) / 64;
+  // Gradient accumulation: one partial per 64-row chunk + k_ar_gather (plain stores, summed in chunk order) while the partials fit
+  // 512 MiB -- cfg1 shape: up to 2 300 chunks = 147 000 rows; 16 384 rows: 0.57 -> 0.36 ms, 131 072 rows: 3.0 -> 1.6 ms -- else f32
+  // atomics into the one gradient (SF_AR_GRAD=atomic forces them).  Measured and dropped: 2 x CUs persistent workgroups that own a
+  // partial and ADD their later chunks -- with plain read-modify-writes 3.1 ms per 131 072 rows (an L2 round trip per weight-gradient
+  // block), with uncontended atomics 2.9: the atomic units, not the contention, bound that form.
+  const long n_chunks = (B + 63) / 64;
   static int force = -1;
   if (force < 0) { const char* e = std::getenv("SF_AR_GRAD"); force = !e ? 0 : (e[0] == 'a' ? 1 : (e[0] == 'p' ? 2 : 0)); }
-  const size_t part_bytes = (size_t)nwg * (size_t)n->n_params * sizeof(float);
-  const bool part = force == 2 ? part_bytes <= ((size_t)4 << 30) : (force != 1 && nwg <= 512 && part_bytes <= ((size_t)512 << 20));
+  const size_t part_bytes = (size_t)n_chunks * (size_t)n->n_params * sizeof(float);
+  const bool part = force != 1 && part_bytes <= ((size_t)512 << 20);
+  const long nwg = n_chunks;
   if (part) {
     if (part_bytes > n->gpart_cap) {
       if (n->d_gpart) AR_HIP(hipFree(n->d_gpart));
@@ -1410,6 +1422,16 @@ int sf_nsfar_loss_grad(SfNsfAr* n, const float* flat, const float* theta, const 
   const int nwv = ar_waves(*n, 3);
   const dim3 grid((unsigned)nwg), block(64 * nwv);
   const size_t lds = sf_nsfar_lds_bytes(*n, 3, nwv);
+  {
+    static int dbg = -1;
+    if (dbg < 0) dbg = std::getenv("SF_AR_DEBUG") ? 1 : 0;
+    if (dbg == 1) {
+      dbg = 2;
+      int occ = -1;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_ar_train<4, true>, 256, lds);
+      fprintf(stderr, "[nsfar train] %d waves, %zu bytes of LDS per workgroup, %d workgroups per CU by the occupancy query, partial mode %d\n", nwv, lds, occ, (int)part);
+    }
+  }
   if (nwv == 4) {
     if (part) hipLaunchKernelGGL((k_ar_train<4, true>), grid, block, lds, st, aa, theta, x, idx, B, grad_scale, weights, loss, loss_sum, gdst, gstride, n->d_ustash);
     else hipLaunchKernelGGL((k_ar_train<4, false>), grid, block, lds, st, aa, theta, x, idx, B, grad_scale, weights, loss, loss_sum, gdst, gstride, n->d_ustash);

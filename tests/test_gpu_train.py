@@ -256,10 +256,11 @@ def test_loss_grad_rows_equals_gathered_loss_grad():
     assert (grad - grad_ref).abs().max().item() < 1e-5 * max(1.0, grad_ref.abs().max().item())
 
 
-def test_lampe_gradient_partials_and_atomics_agree():
-    """sf_nsfar_loss_grad: up to 512 workgroups (32 768 rows) every workgroup stores its own gradient partial and k_ar_gather sums
-    them in workgroup order, larger batches add with f32 atomics into the one gradient.  Both
-    forms of the same kernel: the gradient of 40 000 rows (atomics) equals the sum of the gradients of its two halves (partials)."""
+def test_lampe_gradient_partials_and_atomics_agree(tmp_path):
+    """sf_nsfar_loss_grad: every 64-row chunk stores its own gradient partial and k_ar_gather sums them in chunk order while the
+    partials fit 512 MiB; f32 atomics into the one gradient beyond (or SF_AR_GRAD=atomic).  40 000 rows against the sum of the two
+    halves, and against the atomic form of the same kernel in a child process."""
+    import os, subprocess, sys
     from synference_amd.engine import HipFlow
     ospec, spec, flat, theta, x = make_case("nsfar_cfg1", B=40000)
     f = HipFlow(spec, "cuda:0")
@@ -268,17 +269,26 @@ def test_lampe_gradient_partials_and_atomics_agree():
     la, ga = f.loss_grad(fl, T[:20000], X[:20000], 1.0 / 40000)
     la, ga = la.clone(), ga.clone()
     l2, g2 = f.loss_grad(fl, T[:20000], X[:20000], 1.0 / 40000)
-    # partials: summed in workgroup order, no global atomics -- what is left of the hardware's order is the LDS adds of the hidden
-    # deltas inside a workgroup (four waves add their dimensions' shares into the same rows): equal to rounding, and the losses bit for bit
+    # no global atomics -- what is left of the hardware's order is the LDS adds of the hidden deltas inside a workgroup (four waves add
+    # their dimensions' shares into the same rows): equal to rounding, and the losses bit for bit
     assert torch.equal(la, l2) and (ga - g2).abs().max().item() <= 2e-6 * ga.abs().max().item()
     lb, gb = f.loss_grad(fl, T[20000:], X[20000:], 1.0 / 40000)
     lb, gb = lb.clone(), gb.clone()
-    lw, gw = f.loss_grad(fl, T, X, 1.0 / 40000)                 # 625 workgroups: atomics
+    lw, gw = f.loss_grad(fl, T, X, 1.0 / 40000)
     ref = (ga.double() + gb.double())
     assert (gw.double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
-    # (loss_grad returns the per-row losses or their weighted mean, whichever the engine hands out: compare what it is)
-    if lw.numel() == 40000:
-        assert torch.equal(lw[:20000], la) and torch.equal(lw[20000:], lb)
+    assert torch.equal(lw[:20000], la) and torch.equal(lw[20000:], lb)
+    out = tmp_path / "atomic.npy"
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from cases import make_case; from synference_amd.engine import HipFlow\n"
+            "ospec, spec, flat, theta, x = make_case('nsfar_cfg1', B=40000)\n"
+            "f = HipFlow(spec, 'cuda:0'); l, g = f.loss_grad(torch.as_tensor(flat), theta, x, 1.0 / 40000)\n"
+            "np.save(%r, g.cpu().numpy())\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), str(out))
+    env = dict(os.environ, SF_AR_GRAD="atomic")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    g_at = np.load(out).astype(np.float64)
+    assert np.abs(g_at - gw.cpu().double().numpy()).max() < 2e-5 * np.abs(g_at).max()
 
 
 @pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3"])
