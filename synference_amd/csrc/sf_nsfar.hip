@@ -678,9 +678,18 @@ __global__ __launch_bounds__(64) void k_ar_resolve(ArArgs a, const float* __rest
 }
 
 // forward (with the inputs of every transform stashed) + loss, then the backward sweep
-// (four-wave form: held to 256 registers, so that two workgroups share a CU where the LDS takes them -- it asked for 230 + 44)
+// Two workgroups per CU were tried (24 head rows per wave -> 74.6 KB of LDS, the four-wave form held to 256 registers: 219, no scratch):
+// 3.1 -> 2.3 ms per 131 072 rows -- and WRONG losses on thousands of rows whenever two workgroups really shared a CU (the same binary
+// with 8 KB of extra dynamic LDS, i.e. alone on its CU, is exact).  Not understood yet: the kernel keeps one workgroup per CU
+// (-DSF_AR_TRAIN_WGS=2 -DSF_AR_QBR=24 rebuilds the other form; scripts/probe_lampe_loss.py shows the rows).
+#ifndef SF_AR_TRAIN_WGS
+#define SF_AR_TRAIN_WGS 1
+#endif
+#ifndef SF_AR_QBR
+#define SF_AR_QBR 32
+#endif
 template <int NWV, bool PART>
-__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_ar_train(ArArgs a, const float* __restrict__ theta, const float* __restrict__ x,
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? SF_AR_TRAIN_WGS : 1) void k_ar_train(ArArgs a, const float* __restrict__ theta, const float* __restrict__ x,
                                                         const long long* __restrict__ idx, long B, float w, const float* __restrict__ wts,
                                                         float* __restrict__ loss, double* __restrict__ loss_sum, float* __restrict__ grad_in,
                                                         long part_stride, float* __restrict__ ustash) {
@@ -691,10 +700,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_ar_train(ArArgs 
   float* H1 = E0 + a.NIN16 * RS;         // [Hp]
   float* H2 = H1 + a.Hp * RS;            // [Hp]
   float* QB0 = H2 + a.Hp * RS;           // [NWV][32] per wave: head outputs of ONE dimension, then their deltas; wave 0: the input deltas
-  // (24 rows per wave here: the head's 24 slots.  The 16-row tile routines read rows 24..31 of a wave's second tile -- the next wave's
-  //  buffer, or GG behind the last -- and everything computed from them lands in output rows that are never stored; 32 rows per wave
-  //  put the workgroup at 81.6 KB, two rows short of two workgroups per CU)
-  constexpr int QBR = 24;
+  // (32 rows per wave: the head's 24 slots + the eight rows the 16-row tile routines read behind them)
+  constexpr int QBR = SF_AR_QBR;
   float* QB = QB0 + wid * QBR * RS;
   // TWO hidden buffers serve the backward sweep (round 5; three before: 102 KB for cfg1's shape, one workgroup per CU, and the
   // reference's own lampe example -- 180 hidden units, examples/sbi/scripts/basic_model.py:31-41 -- did not fit at all):
@@ -1022,7 +1029,7 @@ int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err) {
   }
   n->t_stride = (o + 63) / 64 * 64;
   if (std::max(sf_nsfar_lds_bytes(*n, 3, 1), sf_nsfar_lds_bytes(*n, 2, 1)) > (size_t)160 * 1024 - 1024) {
-    err = "autoregressive NSF: (3 D + C + 2 Hp + 32) x 260 bytes of LDS per wave (training: 24 head rows + 16 Hp bytes of tables) exceed the 160 KB of a CU (Hp = H with every type padded to a multiple of 8, in all a multiple of 16)";
+    err = "autoregressive NSF: (3 D + C + 2 Hp + 32) x 260 bytes of LDS per wave (training: + 16 Hp bytes of tables) exceed the 160 KB of a CU (Hp = H with every type padded to a multiple of 8, in all a multiple of 16)";
     delete n;
     return SF_ERR_INVALID;
   }
@@ -1175,7 +1182,7 @@ size_t sf_nsfar_lds_bytes(const SfNsfAr& n, int hidden_buffers, int waves) {
   // (hidden_buffers == 3 names the TRAINING kernel: it runs on two hidden buffers too since round 5, plus the row tables and the
   //  sign bits of the first hidden layer)
   const int hb = hidden_buffers == 3 ? 2 : hidden_buffers;
-  return (size_t)((n.D + n.C + 15) / 16 * 16 + hb * n.Hp + (hidden_buffers == 3 ? 24 : 32) * waves + 2 * n.D) * RS * sizeof(float) +
+  return (size_t)((n.D + n.C + 15) / 16 * 16 + hb * n.Hp + (hidden_buffers == 3 ? SF_AR_QBR : 32) * waves + 2 * n.D) * RS * sizeof(float) +
          (hidden_buffers == 3 ? (size_t)4 * n.Hp * sizeof(int) : 0);
 }
 // waves per 64 samples of the density / training kernels: four (tile pairs and dimensions dealt round robin) when the LDS takes it
@@ -1421,7 +1428,12 @@ int sf_nsfar_loss_grad(SfNsfAr* n, const float* flat, const float* theta, const 
   if (ev0) AR_HIP(hipEventRecord(ev0, st));
   const int nwv = ar_waves(*n, 3);
   const dim3 grid((unsigned)nwg), block(64 * nwv);
-  const size_t lds = sf_nsfar_lds_bytes(*n, 3, nwv);
+  size_t lds = sf_nsfar_lds_bytes(*n, 3, nwv);
+  {
+    static long pad = -1;
+    if (pad < 0) { const char* e = std::getenv("SF_AR_LDS_PAD"); pad = e ? std::atol(e) : 0; }
+    lds += (size_t)pad;
+  }
   {
     static int dbg = -1;
     if (dbg < 0) dbg = std::getenv("SF_AR_DEBUG") ? 1 : 0;

@@ -256,6 +256,23 @@ def test_loss_grad_rows_equals_gathered_loss_grad():
     assert (grad - grad_ref).abs().max().item() < 1e-5 * max(1.0, grad_ref.abs().max().item())
 
 
+@pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "nsfar_cfg1", "mafar_cfg1"])
+def test_training_losses_equal_the_density_kernel_at_a_full_chip_batch(name):
+    """The per-row losses of the training kernel are -log_prob of another kernel: at 20 000 rows -- every CU holds workgroups of the
+    training kernel side by side where its LDS and registers allow -- they must agree row by row.  (A form of the lampe training kernel
+    with two workgroups per CU passed every small-batch gradient test and got thousands of these rows wrong: csrc/sf_nsfar.hip.)"""
+    from synference_amd.engine import HipFlow
+    ospec, spec, flat, theta, x = make_case(name, B=20000)
+    f = HipFlow(spec, "cuda:0")
+    fl = torch.as_tensor(flat)
+    f.set_params(fl.cuda())
+    T, X = torch.as_tensor(theta).cuda(), torch.as_tensor(x).cuda()
+    ref = -f.log_prob(T, X)
+    for _ in range(2):
+        loss, _g = f.loss_grad(fl, T, X, 1.0 / 20000)
+        assert (loss - ref).abs().max().item() < 2e-4
+
+
 def test_lampe_gradient_partials_and_atomics_agree(tmp_path):
     """sf_nsfar_loss_grad: every 64-row chunk stores its own gradient partial and k_ar_gather sums them in chunk order while the
     partials fit 512 MiB; f32 atomics into the one gradient beyond (or SF_AR_GRAD=atomic).  40 000 rows against the sum of the two
