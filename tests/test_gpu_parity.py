@@ -211,6 +211,40 @@ def test_lampe_sampler_kernel_selection():
             assert d["s16_ks"] == ks and d["s16_nt"] == spec.D and d["s16_ni"] == (spec.D + spec.C + 15) // 16, (name, d)
 
 
+def test_lampe_register_tile_sampler_equals_the_lds_sampler_on_a_full_chip(tmp_path):
+    """A catalogue that fills the chip (2 000 rows x 256 draws, prior box, counts): the 16-candidate register-tile kernels
+    (three workgroups per CU side by side) against the 64-sample LDS kernel of a child process (SF_AR_SAMP16=0) -- same seeds, so the
+    same draws to rounding, except where a candidate within rounding of the box edge is accepted by one side only."""
+    import os, subprocess, sys
+    ospec, spec, flat, theta, x = make_case("nsfar_cfg1", B=2000, spread=0.2)
+    f = _flow(spec, flat)
+    S = 256
+    free = f.sample(x[:64], 256, seed=3).reshape(-1, spec.D)
+    lo = torch.quantile(free, 0.03, dim=0).cpu().numpy().astype(np.float32)
+    hi = torch.quantile(free, 0.97, dim=0).cpu().numpy().astype(np.float32)
+    got, nd = f.sample(x, S, lo, hi, seed=11, return_counts=True)
+    assert f.describe()["sampler_tiles16"] == 1 and f.last_unfilled == 0
+    got, nd = got.cpu().numpy(), nd.cpu().numpy()
+    np.save(tmp_path / "lo.npy", lo); np.save(tmp_path / "hi.npy", hi)
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from cases import make_case; from synference_amd.engine import HipFlow\n"
+            "ospec, spec, flat, theta, x = make_case('nsfar_cfg1', B=2000, spread=0.2)\n"
+            "f = HipFlow(spec, 'cuda:0'); f.set_params(torch.as_tensor(flat).cuda())\n"
+            "assert f.describe()['sampler_tiles16'] == 0\n"
+            "o, nd = f.sample(x, 256, np.load(%r), np.load(%r), seed=11, return_counts=True)\n"
+            "np.save(%r, o.cpu().numpy()); np.save(%r, nd.cpu().numpy())\n") % (
+                os.path.dirname(here), here, str(tmp_path / "lo.npy"), str(tmp_path / "hi.npy"), str(tmp_path / "o.npy"), str(tmp_path / "nd.npy"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SF_AR_SAMP16="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref, rnd = np.load(tmp_path / "o.npy"), np.load(tmp_path / "nd.npy")
+    assert np.isfinite(got).all() and ((got >= lo) & (got <= hi)).all()
+    err = np.abs((got - ref) / np.asarray(ospec.theta_std, dtype=np.float32)).max(-1)      # (rows, draws)
+    bad = err > 1e-4
+    # a slot whose accepted attempt differs changes its row's attempt count: allow only count-explained mismatches, and few of them
+    assert bad.sum() <= 8 and (bad.sum(1) <= np.abs(nd - rnd)).all(), (int(bad.sum()), np.abs(nd - rnd).sum())
+
+
 def test_autoregressive_nsf_deep_tail_rounds_keep_the_lowest_accepted_attempt():
     """A box that accepts about one draw in a thousand: every slot outlives the persistent launch's 256-attempt window and is
     finished by the chip-wide FIND / RESOLVE rounds (sf_nsfar_sample) -- the draws and the attempt counts must still be the
