@@ -680,9 +680,10 @@ __global__ __launch_bounds__(64) void k_ar_resolve(ArArgs a, const float* __rest
 // forward (with the inputs of every transform stashed) + loss, then the backward sweep
 // Two workgroups per CU were tried (24 head rows per wave -> 74.6 KB of LDS, the four-wave form held to 256 registers: 219, no scratch):
 // 3.1 -> 2.3 ms per 131 072 rows -- and WRONG losses on thousands of rows whenever two workgroups really shared a CU (the same binary
-// with 8 KB of extra dynamic LDS, i.e. alone on its CU, is exact; so is the forward sweep alone with two per CU -DSF_AR_FWD_ONLY-,
-// so a neighbour's BACKWARD sweep is what disturbs a forward one; the ISA has no flat or scratch access, 48 ds_add_f32, and the LDS
-// footprint is inside the allocation with 7 KB to spare).  Not understood yet: the kernel keeps one workgroup per CU
+// with 8 KB of extra dynamic LDS, i.e. alone on its CU, is exact; so is the forward sweep alone with two per CU, so a neighbour's
+// BACKWARD sweep is what disturbs a forward one; exchanging the log-determinants through other LDS rows or replacing the ds_add_f32 of the
+// hidden deltas by compare-and-swap loops changes nothing; the ISA has no flat or scratch access and the LDS footprint is inside the
+// allocation with 7 KB to spare).  Not understood yet: the kernel keeps one workgroup per CU
 // (-DSF_AR_TRAIN_WGS=2 -DSF_AR_QBR=24 rebuilds the other form; scripts/probe_lampe_loss.py shows the rows).
 #ifndef SF_AR_TRAIN_WGS
 #define SF_AR_TRAIN_WGS 1
@@ -751,17 +752,10 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? SF_AR_TRAIN_WGS : 1) void k_ar
   }
   __syncthreads();
   if (NWV > 1) {   // the log-determinants of the waves' dimensions
-#ifdef SF_AR_LDX
-    H1[wid * RS + lane] = ld;
-    __syncthreads();
-    if (wid == 0)
-      for (int w2 = 1; w2 < NWV; ++w2) ld += H1[w2 * RS + lane];
-#else
     QB[lane] = ld;
     __syncthreads();
     if (wid == 0)
       for (int w2 = 1; w2 < NWV; ++w2) ld += QB0[w2 * QBR * RS + lane];
-#endif
   }
   if (wid == 0) {
     float ss = 0.f;
@@ -776,9 +770,6 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? SF_AR_TRAIN_WGS : 1) void k_ar
       if (lane == 0) atomicAdd(loss_sum, (double)rintf(tsum * 1048576.0f) * (1.0 / 1048576.0));
     }
   }
-#ifdef SF_AR_FWD_ONLY
-  if (a.T > 0) return;   // (developer experiment: the forward sweep alone)
-#endif
   const float wb = valid ? (wts ? w * wts[b] : w) : 0.f;
   for (int d = wid; d < a.D; d += NWV) GG[d * RS + lane] = wb * E0[d * RS + lane];
   AR_TS(98);
