@@ -139,6 +139,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the sampling leg of the CPU baseline")
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps sampling steps (the first one is `value`; all of them: `repeats`)")
     ap.add_argument("--skip-nsf-leg", action="store_true", help="leave out the configs[2] (NSF cfg3) leg of the default run")
+    ap.add_argument("--skip-lampe-leg", action="store_true", help="leave out the lampe-backend (nsfar_cfg2) leg of the default run")
     ap.add_argument("--skip-per-object", action="store_true", help="leave out the per-object posterior.sample((S,), x=X[i]) loop")
     ap.add_argument("--skip-dp", action="store_true", help="leave out the RCCL leg of the train object (communicator over the ranks; one rank at N = 1)")
     return ap.parse_args()
@@ -428,6 +429,21 @@ def main():
             rec["nsf_cfg3"]["train"] = {k: sub["train"][k] for k in ("value", "unit", "per_gpu_batch", "steps", "ms_per_step",
                                                                    "batch64_ms_per_step", "batch64_pairs_per_s_1gpu")}
             rec["nsf_cfg3"]["log_prob"] = sub["log_prob"]
+    # ---------------- the reference's second backend beside it (row f4): the lampe flow (zuko NSF, 8 bins) on the configs[1] mock -- a
+    # few steps of sampling and training with both roofline objects (the full-length line is `--workload nsfar_cfg2`)
+    if a.workload == "maf_cfg2" and not a.skip_lampe_leg and not a.hidden_bf16 and not a.galaxies:
+        b = argparse.Namespace(**vars(a))
+        b.workload, b.steps, b.warmup, b.train_steps, b.repeats = "nsfar_cfg2", 5, 2, 20, 1
+        b.skip_api = b.skip_large_catalogue = b.no_cpu_baseline = b.skip_per_object = b.skip_dp = True
+        b.skip_throughput_regime = True
+        note("lampe leg (autoregressive NSF, cfg2 mock)")
+        sub = run_workload(b, world, rank, dev, gloo)
+        if rank == 0:
+            keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "roofline_train")
+            rec["lampe_nsfar_cfg2"] = {k: sub[k] for k in keep}
+            rec["lampe_nsfar_cfg2"]["train"] = {k: sub["train"][k] for k in ("value", "unit", "per_gpu_batch", "steps", "ms_per_step",
+                                                                           "batch64_ms_per_step", "batch64_pairs_per_s_1gpu")}
+            rec["lampe_nsfar_cfg2"]["log_prob"] = sub["log_prob"]
     if rank == 0:
         print(json.dumps(rec), flush=True)
     if world > 1:

@@ -16,7 +16,7 @@ OUT=gpurun_out/prof_$TAG; RAW=/tmp/sfprof_$TAG; rm -rf $RAW; mkdir -p $OUT $RAW
 say() { echo "[$(date +%H:%M:%S)] $*" | tee -a $OUT/progress.log; }
 
 trace() {  # tag, bench args
-  rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/stats_$1 -- python3 bench.py $2 --no-cpu-baseline --skip-large-catalogue --skip-nsf-leg --skip-per-object --repeats 1 > $OUT/bench_under_rocprof_$1.json 2> $RAW/stats_$1.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/stats_$1 -- python3 bench.py $2 --no-cpu-baseline --skip-large-catalogue --skip-nsf-leg --skip-lampe-leg --skip-per-object --repeats 1 > $OUT/bench_under_rocprof_$1.json 2> $RAW/stats_$1.err
   cp $RAW/stats_$1/*/*_kernel_stats.csv $OUT/kernel_stats_$1.csv
   python3 - "$RAW/stats_$1" "$OUT/kernels_$1.txt" <<'PY'
 import csv, glob, sys, statistics, collections
@@ -40,7 +40,7 @@ pmc() {  # tag, bench args, kernel regex
               "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_ANY" \
               "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VMEM"; do
     t=$(echo $pass | cut -d' ' -f1)
-    rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $RAW/pmc_$1_$t -- python3 bench.py $2 --no-cpu-baseline --skip-large-catalogue --skip-nsf-leg --skip-per-object --skip-dp --repeats 1 > /dev/null 2> $RAW/pmc_$1_$t.err
+    rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $RAW/pmc_$1_$t -- python3 bench.py $2 --no-cpu-baseline --skip-large-catalogue --skip-nsf-leg --skip-lampe-leg --skip-per-object --skip-dp --repeats 1 > /dev/null 2> $RAW/pmc_$1_$t.err
     say "pmc $1 $t done"
   done
   python3 - "$RAW" "$1" "$3" "$OUT/pmc_$1.csv" <<'PY'
