@@ -119,9 +119,16 @@ class FlowPosterior:
         counts = torch.empty(N, dtype=torch.int32, device=self.device)
         rows_per = max(1, _MAX_SLOTS_PER_CALL // max(S, 1))
         # keep the per-galaxy context table of a chunk within 2 GiB so that it is always built
-        per_gal = 4 * int(est.flow.describe().get("ctab_floats_per_galaxy", 0))
+        desc = est.flow.describe()
+        per_gal = 4 * int(desc.get("ctab_floats_per_galaxy", 0))
         if per_gal > 0:
             rows_per = max(1, min(rows_per, (2 << 30) // per_gal))
+        # shape cliffs are not silent: a lampe-backend flow outside the register-tile sampler's shapes draws ~5 x slower
+        if desc.get("sampler_tiles16", 1) == 0 and self.spec.D > 1 and N * S >= 100000 and not getattr(est, "_warned_sampler", False):
+            est._warned_sampler = True
+            sp = self.spec
+            logger.warning(f"{sp.kind} D={sp.D} C={sp.C} H={sp.H} T={sp.T}: this shape samples on the 64-sample LDS kernel (k_ar_sample), not on "
+                           "the 16-candidate register-tile kernels (2 <= D <= 8, at most 16 hidden units per parameter, D + C <= 32)")
         unfilled = 0
         try:
             for r0 in range(0, N, rows_per):
