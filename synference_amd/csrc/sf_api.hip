@@ -236,7 +236,7 @@ int sf_flow_describe(const sf_flow* f, char* buf, size_t buflen) {
     add("Hp", n.Hp); add("t_stride", n.t_stride); add("n_params", (long)n.n_params); add("n_packed", (long)n.src.size());
     add("o_L0t", n.o_L0t); add("o_b0", n.o_b0); add("o_L1t", n.o_L1t); add("o_L1m", n.o_L1m); add("o_b1", n.o_b1);
     add("o_L2t", n.o_L2t); add("o_b2", n.o_b2); add("o_L0m", n.o_L0m); add("o_L2m", n.o_L2m); add("lds_bytes_train", (long)sf_nsfar_lds_bytes(n, 3));
-    add("sampler_tiles16", sf_nsfar16_eligible(n) ? 1 : 0); add("s16_nt", n.s16_nt); add("s16_ni", n.s16_ni); add("s16_ks", n.s16_ks);
+    add("sampler_tiles16", sf_nsfar16_eligible(n) ? 1 : 0); add("s16_nt", n.s16_nt); add("s16_ni", n.s16_ni); add("s16_ks", n.s16_ks); add("s16_tpt", n.s16_tpt);
     add("o_F0", n.o_F0); add("o_fb0", n.o_fb0); add("o_F1", n.o_F1); add("o_fb1", n.o_fb1); add("o_F2", n.o_F2);
     auto arr = [&](const char* k, const std::vector<int32_t>& a, bool last) {
       s += "\"" + std::string(k) + "\": [";

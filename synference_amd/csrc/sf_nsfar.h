@@ -20,11 +20,12 @@ struct SfNsfAr {
   long P_t = 0, t_stride = 0;
   int l_W0 = 0, l_b0 = 0, l_W1 = 0, l_b1 = 0, l_W2 = 0, l_b2 = 0;                             // logical offsets in a transform
   int o_L0t = 0, o_b0 = 0, o_L1t = 0, o_L1m = 0, o_b1 = 0, o_L2t = 0, o_b2 = 0, o_L0m = 0, o_L2m = 0;   // image offsets in a transform
-  // 16-sample register-tile sampler (sf_nsfar16.hip): s16_nt = hidden tiles (= D: type r IS tile r) or 0 when the shape does not take it;
+  // 16-sample register-tile sampler (sf_nsfar16.hip): s16_nt = hidden tiles (= D x s16_tpt: type r is tile r, or tiles 2 r and 2 r + 1
+  // when it has 17..32 units) or 0 when the shape does not take it;
   // fragment-ordered blocks of a transform (lane l of block (ot, kt): W[16 ot + (l & 15)][16 kt + 4 (l >> 4) + 0..3]) in the sampler's
   // own hidden order (s16_ks = ceil(units per type / 4), at least 2: the units of a type sit on the rows with (row & 3) < s16_ks of
   // its tile), biases in that order
-  int s16_nt = 0, s16_ni = 0, s16_ks = 4, o_F0 = 0, o_fb0 = 0, o_F1 = 0, o_fb1 = 0, o_F2 = 0;
+  int s16_nt = 0, s16_ni = 0, s16_ks = 4, s16_tpt = 1, o_F0 = 0, o_fb0 = 0, o_F1 = 0, o_fb1 = 0, o_F2 = 0;
   bool dev_ready = false;
   float* d_img = nullptr;
   int32_t *d_src = nullptr, *d_none = nullptr, *d_perm = nullptr, *d_ptype = nullptr, *d_tend = nullptr, *d_ord = nullptr, *d_dimof = nullptr, *d_dwave = nullptr;

@@ -1018,10 +1018,17 @@ int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err) {
   n->o_b2 = (int)o; o += (long)D * ARQ;
   n->o_L0m = (int)o; o += (long)Hp * 16;
   n->o_L2m = (int)o; o += (long)D * ARQ * Hp;   // the head transposed: row (d, slot), column k
-  // the 16-sample sampler's blocks (sf_nsfar16.hip): every type fits one 16-row tile, D steps, one or two input tiles
-  n->s16_nt = ((H + D - 1) / D <= 16 && D >= 2 && D <= 8 && (nin + 15) / 16 <= 2) ? D : 0;
-  n->s16_ni = (nin + 15) / 16;
-  n->s16_ks = ((H + D - 1) / D + 3) / 4 < 2 ? 2 : ((H + D - 1) / D + 3) / 4;
+  // the 16-sample sampler's blocks (sf_nsfar16.hip): a type fits one 16-row tile, or two (17..32 units per type: the reference's lampe
+  // example), D steps, one or two input tiles
+  {
+    const int cnt_max = (H + D - 1) / D;
+    n->s16_tpt = cnt_max <= 16 ? 1 : 2;
+    const int per_tile = (cnt_max + n->s16_tpt - 1) / n->s16_tpt;
+    n->s16_ks = (per_tile + 3) / 4 < 2 ? 2 : (per_tile + 3) / 4;
+    if (n->s16_tpt == 2 && n->s16_ks < 3) n->s16_ks = 3;   // (two-tile types are built for three and four k-steps)
+    n->s16_ni = (nin + 15) / 16;
+    n->s16_nt = (cnt_max <= 32 && D >= 2 && D <= 8 && n->s16_ni <= 2) ? D * n->s16_tpt : 0;
+  }
   if (n->s16_nt) {
     const long NTs = n->s16_nt, NI = n->s16_ni;
     n->o_F0 = (int)o; o += NTs * NI * 256;
@@ -1092,18 +1099,18 @@ int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err) {
             s[n->o_L2m + (long)slot * Hp + k] = (int32_t)(base + n->l_W2 + (long)lrow * H + hk);
           }
         }
-    if (n->s16_nt) {   // fragment blocks in the sampler's hidden order (type r = tile r), -1 on the rows that hold no unit
-      const int NTs = n->s16_nt, NI = n->s16_ni;
-      const int KS = n->s16_ks;   // the n-th unit of type r sits on row 16 r + 4 (n / KS) + n % KS
+    if (n->s16_nt) {   // fragment blocks in the sampler's hidden order (type r = tile r, or tiles 2 r and 2 r + 1), -1 on the rows that hold no unit
+      const int NTs = n->s16_nt, NI = n->s16_ni, TPT = n->s16_tpt;
+      const int KS = n->s16_ks;   // a tile holds 4 KS units: the n-th unit of its tile sits on row 4 (n / KS) + n % KS
       auto unit = [&](int p) {
-        const int i = p & 15, j = i & 3;
+        const int tl = p >> 4, r = tl / TPT, sub = tl % TPT, i = p & 15, j = i & 3;
         if (j >= KS) return -1;
-        const int h = (p >> 4) + ((i >> 2) * KS + j) * D;
+        const int h = r + (sub * 4 * KS + (i >> 2) * KS + j) * D;
         return h < H ? h : -1;
       };
       for (int ot = 0; ot < NTs; ++ot)
         for (int l = 0; l < 64; ++l) {
-          const int p = 16 * ot + (l & 15), h = unit(p);
+          const int p = 16 * ot + (l & 15), h = unit(p), ty = ot / TPT;
           if (h < 0) continue;
           if (l < 16) {
             s[n->o_fb0 + p] = (int32_t)(base + n->l_b0 + h);
@@ -1112,9 +1119,9 @@ int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err) {
           for (int j = 0; j < 4; ++j) {
             for (int ti = 0; ti < NI; ++ti) {
               const int i = 16 * ti + 4 * (l >> 4) + j;
-              if (i < nin && (i >= D || ord[i] < ot)) s[n->o_F0 + (long)(ot * NI + ti) * 256 + l * 4 + j] = (int32_t)(base + n->l_W0 + (long)h * nin + i);
+              if (i < nin && (i >= D || ord[i] < ty)) s[n->o_F0 + (long)(ot * NI + ti) * 256 + l * 4 + j] = (int32_t)(base + n->l_W0 + (long)h * nin + i);
             }
-            for (int kt = 0; kt <= ot; ++kt) {   // (type of row k = kt <= type of row p = ot)
+            for (int kt = 0; kt < (ty + 1) * TPT; ++kt) {   // (type of row k = kt / TPT <= type of row p)
               const int hk = unit(16 * kt + 4 * (l >> 4) + j);
               if (hk >= 0) s[n->o_F1 + (long)(ot * NTs + kt) * 256 + l * 4 + j] = (int32_t)(base + n->l_W1 + (long)h * H + hk);
             }
@@ -1127,7 +1134,7 @@ int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err) {
             if (slot >= ARQ || fam >= (affine ? 1 : 3) || kk >= (fam < 2 ? K : K - 1)) continue;
             const int lrow = dd * NP + fam * K + kk;
             for (int kt = 0; kt < NTs; ++kt) {
-              if (kt > ord[dd]) continue;
+              if (kt / TPT > ord[dd]) continue;
               for (int j = 0; j < 4; ++j) {
                 const int hk = unit(16 * kt + 4 * (l >> 4) + j);
                 if (hk >= 0) s[n->o_F2 + (long)((dd * 2 + o2) * NTs + kt) * 256 + l * 4 + j] = (int32_t)(base + n->l_W2 + (long)lrow * H + hk);

@@ -139,6 +139,51 @@ __device__ __forceinline__ void a16_step(const Ar16Args& a, const float* __restr
   a16_mma2<KS>(wa[R], wb[R], H2[R], q0, q1);
 }
 
+// The same step when a type takes TWO tiles (17..32 hidden units per parameter: the reference's own lampe example trains 180 / 150 / 120
+// hidden units): tiles 2 R and 2 R + 1 from the 2 R + 2 tiles known by then, within the 256 registers of two workgroups per CU.
+// sum over input tiles [K0, K1) of two block rows that share the input tiles (rows ra / rb of the block array `base`, NT blocks per row):
+// four input tiles at a time -- eight fragments requested, then their products -- fenced, so that the scheduler does not hoist the
+// loads of a whole step (up to 64 fragments) above its first product and spill the hidden tiles to make room
+template <int K0, int K1, int NT, int KS>
+__device__ __forceinline__ void a16_rows2(const float* __restrict__ base, int ra, int rb, int lane, const f32x4 (&H)[NT], f32x4& acca, f32x4& accb) {
+#pragma unroll
+  for (int c0 = K0; c0 < K1; c0 += 4) {
+    float4 fa[4], fb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (c0 + i < K1) {
+        fa[i] = a16_frag(base, ra * NT + c0 + i, lane);
+        fb[i] = a16_frag(base, rb * NT + c0 + i, lane);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (c0 + i < K1) a16_mma2<KS>(fa[i], fb[i], H[c0 + i], acca, accb);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+template <int R, int DD, int NI, int KS>
+__device__ __forceinline__ void a16_step2(const Ar16Args& a, const float* __restrict__ tp, int d, int lane, const f32x4 (&E)[NI],
+                                          f32x4 (&H1)[2 * DD], f32x4 (&H2)[2 * DD], f32x4& q0, f32x4& q1) {
+  constexpr int NT = 2 * DD, O0 = 2 * R, O1 = 2 * R + 1;
+  const int g4 = lane >> 4;
+  f32x4 h0 = a16_ld4(tp + a.o_fb0 + 16 * O0 + 4 * g4), h1 = a16_ld4(tp + a.o_fb0 + 16 * O1 + 4 * g4);
+#pragma unroll
+  for (int ti = 0; ti < NI; ++ti) {
+    h0 = a16_mma<4>(a16_frag(tp + a.o_F0, O0 * NI + ti, lane), E[ti], h0);
+    h1 = a16_mma<4>(a16_frag(tp + a.o_F0, O1 * NI + ti, lane), E[ti], h1);
+  }
+  f32x4 accA = a16_ld4(tp + a.o_fb1 + 16 * O0 + 4 * g4), accB = a16_ld4(tp + a.o_fb1 + 16 * O1 + 4 * g4);
+  H1[O0] = a16_relu(h0);
+  H1[O1] = a16_relu(h1);
+  a16_rows2<0, O1 + 1, NT, KS>(tp + a.o_F1, O0, O1, lane, H1, accA, accB);
+  H2[O0] = a16_relu(accA);
+  H2[O1] = a16_relu(accB);
+  q0 = a16_ld4(tp + a.o_b2 + d * ARQ + 4 * g4);
+  q1 = a16_ld4(tp + a.o_b2 + d * ARQ + 16 + 4 * (g4 & 1));
+  a16_rows2<0, O1 + 1, NT, KS>(tp + a.o_F2, d * 2, d * 2 + 1, lane, H2, q0, q1);
+}
+
 // The inverse of zuko's MonotonicRQSTransform (ZSpl::inv, sf_spline_flat.h) on the head tiles AS THE MFMA LEFT THEM: of a sample's
 // slots, lane group g' = 0 / 1 holds widths 0..3 / 4..7 (q0), g' = 2 / 3 heights 0..3 / 4..7, and g' = 0 / 1 the knot derivatives
 // 1..4 / 5..7 (q1).  The width pair and the height pair run the SAME instructions on their four bins each -- soft clip, softmax
@@ -221,14 +266,21 @@ __device__ __forceinline__ float a16_spline_inv(const ZSplC& c, const f32x4 q0, 
   return inside ? xi * w_k + x_k : v;
 }
 
+template <int R, int DD, int NI, int KS, int TPT>
+__device__ __forceinline__ void a16_stepT(const Ar16Args& a, const float* __restrict__ tp, int d, int lane, const f32x4 (&E)[NI],
+                                          f32x4 (&H1)[DD * TPT], f32x4 (&H2)[DD * TPT], f32x4& q0, f32x4& q1) {
+  if constexpr (TPT == 1) a16_step<R, DD, NI, KS>(a, tp, d, lane, E, H1, H2, q0, q1);
+  else a16_step2<R, DD, NI, KS>(a, tp, d, lane, E, H1, H2, q0, q1);
+}
+
 // one candidate per lane group member: noise of (slot, attempt) through the inverse flow, prior-box test; th = the candidate
-template <int DD, int NI, int KS>
+template <int DD, int NI, int KS, int TPT>
 __device__ __forceinline__ bool a16_candidate(const Ar16Args& a, const ZSplC& sc, long g, unsigned long long slot, uint32_t att, int lane,
                                               bool active, float (&th)[DD]) {
   const int g4 = lane >> 4;
   const SfAr16Launch& L = a.L;
   A16_TS(0);
-  f32x4 E[NI], H1[DD], H2[DD];
+  f32x4 E[NI], H1[DD * TPT], H2[DD * TPT];
 #pragma unroll
   for (int ti = 0; ti < NI; ++ti)
 #pragma unroll
@@ -239,7 +291,7 @@ __device__ __forceinline__ bool a16_candidate(const Ar16Args& a, const ZSplC& sc
       E[ti][j] = (c >= 0 && c < a.C) ? v : 0.f;
     }
 #pragma unroll
-  for (int k = 0; k < DD; ++k) { H1[k] = f32x4{0.f, 0.f, 0.f, 0.f}; H2[k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int k = 0; k < DD * TPT; ++k) { H1[k] = f32x4{0.f, 0.f, 0.f, 0.f}; H2[k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   float vv[DD];
 #pragma unroll
   for (int d0 = 0; d0 < DD; d0 += 4) {
@@ -266,14 +318,14 @@ __device__ __forceinline__ bool a16_candidate(const Ar16Args& a, const ZSplC& sc
       f32x4 q0, q1;
       A16_TS(2 + ((a.T - 1 - t) * DD + r) * 3);
       switch (r) {
-        case 0: a16_step<0, DD, NI, KS>(a, tp, d, lane, E, H1, H2, q0, q1); break;
-        case 1: if constexpr (DD > 1) a16_step<1, DD, NI, KS>(a, tp, d, lane, E, H1, H2, q0, q1); break;
-        case 2: if constexpr (DD > 2) a16_step<2, DD, NI, KS>(a, tp, d, lane, E, H1, H2, q0, q1); break;
-        case 3: if constexpr (DD > 3) a16_step<3, DD, NI, KS>(a, tp, d, lane, E, H1, H2, q0, q1); break;
-        case 4: if constexpr (DD > 4) a16_step<4, DD, NI, KS>(a, tp, d, lane, E, H1, H2, q0, q1); break;
-        case 5: if constexpr (DD > 5) a16_step<5, DD, NI, KS>(a, tp, d, lane, E, H1, H2, q0, q1); break;
-        case 6: if constexpr (DD > 6) a16_step<6, DD, NI, KS>(a, tp, d, lane, E, H1, H2, q0, q1); break;
-        default: if constexpr (DD > 7) a16_step<7, DD, NI, KS>(a, tp, d, lane, E, H1, H2, q0, q1); break;
+        case 0: a16_stepT<0, DD, NI, KS, TPT>(a, tp, d, lane, E, H1, H2, q0, q1); break;
+        case 1: if constexpr (DD > 1) a16_stepT<1, DD, NI, KS, TPT>(a, tp, d, lane, E, H1, H2, q0, q1); break;
+        case 2: if constexpr (DD > 2) a16_stepT<2, DD, NI, KS, TPT>(a, tp, d, lane, E, H1, H2, q0, q1); break;
+        case 3: if constexpr (DD > 3) a16_stepT<3, DD, NI, KS, TPT>(a, tp, d, lane, E, H1, H2, q0, q1); break;
+        case 4: if constexpr (DD > 4) a16_stepT<4, DD, NI, KS, TPT>(a, tp, d, lane, E, H1, H2, q0, q1); break;
+        case 5: if constexpr (DD > 5) a16_stepT<5, DD, NI, KS, TPT>(a, tp, d, lane, E, H1, H2, q0, q1); break;
+        case 6: if constexpr (DD > 6) a16_stepT<6, DD, NI, KS, TPT>(a, tp, d, lane, E, H1, H2, q0, q1); break;
+        default: if constexpr (DD > 7) a16_stepT<7, DD, NI, KS, TPT>(a, tp, d, lane, E, H1, H2, q0, q1); break;
       }
       float v = 0.f;
 #pragma unroll
@@ -322,8 +374,8 @@ __device__ __forceinline__ void a16_wave_sync() {
 #ifndef SF_A16_WGS
 #define SF_A16_WGS 3
 #endif
-template <int DD, int NI, int KS>
-__global__ __launch_bounds__(256, SF_A16_WGS) void k_ar_samp16(Ar16Args a) {
+template <int DD, int NI, int KS, int TPT>
+__global__ __launch_bounds__(256, TPT == 1 ? SF_A16_WGS : (DD <= 5 ? 2 : 1)) void k_ar_samp16(Ar16Args a) {
   __shared__ unsigned long long r_slot[4][16];
   __shared__ uint32_t r_att[4][16];
   const SfAr16Launch& L = a.L;
@@ -398,7 +450,7 @@ __global__ __launch_bounds__(256, SF_A16_WGS) void k_ar_samp16(Ar16Args a) {
     a16_wave_sync();   // (the retry list has been read)
     const long g = !exists ? 0 : (small ? (long)((uint32_t)slot / (uint32_t)S) : (long)(slot / (unsigned long long)S));
     float th[DD];
-    const bool ok = a16_candidate<DD, NI, KS>(a, sc, g, slot, att, lane, active, th);
+    const bool ok = a16_candidate<DD, NI, KS, TPT>(a, sc, g, slot, att, lane, active, th);
     const unsigned long long m_ok = __ballot(ok && lead);
     // (statistics: kept in the wave and added once when it leaves -- per round they were two more atomics on the cache line of the
     //  queue head that every wave's next fetch waits for)
@@ -455,8 +507,8 @@ __global__ __launch_bounds__(256, SF_A16_WGS) void k_ar_samp16(Ar16Args a) {
 // FIND / RESOLVE of the chip-wide rounds (k_ar_find / k_ar_resolve of sf_nsfar.hip, same arguments) on the 16-sample candidate:
 // workgroup (e, j) of FIND tries attempts base + 64 j + 16 wave + (lane & 15) of survivor e and lowers best[e]; RESOLVE re-evaluates
 // exactly attempt best[e] of sixteen survivors per wave and writes the draw.
-template <int DD, int NI, int KS>
-__global__ __launch_bounds__(256, SF_A16_WGS) void k_ar_find16(Ar16Args a, const uint32_t* __restrict__ surv, unsigned int n_surv, uint32_t base,
+template <int DD, int NI, int KS, int TPT>
+__global__ __launch_bounds__(256, TPT == 1 ? SF_A16_WGS : (DD <= 5 ? 2 : 1)) void k_ar_find16(Ar16Args a, const uint32_t* __restrict__ surv, unsigned int n_surv, uint32_t base,
                                                                uint32_t chunks, uint32_t att_end, uint32_t* __restrict__ best,
                                                                unsigned long long* __restrict__ ctr) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -468,13 +520,13 @@ __global__ __launch_bounds__(256, SF_A16_WGS) void k_ar_find16(Ar16Args a, const
   const bool active = att < att_end;
   const long g = (long)(slot / (unsigned long long)a.L.S);
   float th[DD];
-  const bool ok = a16_candidate<DD, NI, KS>(a, sc, g, slot, att, lane, active, th);
+  const bool ok = a16_candidate<DD, NI, KS, TPT>(a, sc, g, slot, att, lane, active, th);
   if (ok && lane < 16) atomicMin(best + e, att);
   const unsigned long long ma = __ballot(active && lane < 16);
   if (lane == 0) atomicAdd(ctr + 2, (unsigned long long)__popcll(ma));
 }
-template <int DD, int NI, int KS>
-__global__ __launch_bounds__(256, SF_A16_WGS) void k_ar_resolve16(Ar16Args a, const uint32_t* __restrict__ surv, unsigned int n_surv,
+template <int DD, int NI, int KS, int TPT>
+__global__ __launch_bounds__(256, TPT == 1 ? SF_A16_WGS : (DD <= 5 ? 2 : 1)) void k_ar_resolve16(Ar16Args a, const uint32_t* __restrict__ surv, unsigned int n_surv,
                                                                   const uint32_t* __restrict__ best, uint32_t tried_end, uint32_t tried_now,
                                                                   uint32_t* __restrict__ next, unsigned int* __restrict__ n_next) {
   const SfAr16Launch& L = a.L;
@@ -487,7 +539,7 @@ __global__ __launch_bounds__(256, SF_A16_WGS) void k_ar_resolve16(Ar16Args a, co
   const bool found = exists && b != 0xffffffffu;
   const long g = exists ? (long)(slot / (unsigned long long)L.S) : 0;
   float th[DD];
-  const bool ok = a16_candidate<DD, NI, KS>(a, sc, g, slot, found ? b : 0u, lane, found, th);
+  const bool ok = a16_candidate<DD, NI, KS, TPT>(a, sc, g, slot, found ? b : 0u, lane, found, th);
   if (!lead) return;
   if (found) {   // (ok by construction: the find launch accepted this very attempt)
 #pragma unroll
@@ -512,19 +564,19 @@ __global__ __launch_bounds__(256, SF_A16_WGS) void k_ar_resolve16(Ar16Args a, co
   }
 }
 
-template <int DD, int NI, int KS>
+template <int DD, int NI, int KS, int TPT>
 hipError_t launch16(const Ar16Args& a, int cus, hipStream_t st) {
   static int occ = 0;
   if (!occ) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_ar_samp16<DD, NI, KS>, 256, 0) != hipSuccess || nb < 1) nb = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_ar_samp16<DD, NI, KS, TPT>, 256, 0) != hipSuccess || nb < 1) nb = 2;
     occ = nb > 8 ? 8 : nb;
   }
   long grid = (long)cus * occ;
   const long need = (a.L.n_slots + 63) / 64;
   if (grid > need) grid = need;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((k_ar_samp16<DD, NI, KS>), dim3((unsigned)grid), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((k_ar_samp16<DD, NI, KS, TPT>), dim3((unsigned)grid), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
@@ -533,7 +585,8 @@ hipError_t launch16(const Ar16Args& a, int cus, hipStream_t st) {
 bool sf_nsfar16_eligible(const SfNsfAr& n) {
   static int off = -1;
   if (off < 0) { const char* e = std::getenv("SF_AR_SAMP16"); off = (e && e[0] == '0') ? 1 : 0; }
-  return !off && n.s16_nt >= 2 && n.s16_nt <= 8 && n.s16_nt == n.D && (n.s16_ni == 1 || n.s16_ni == 2);
+  return !off && n.s16_nt >= 2 && n.D >= 2 && n.D <= 8 && (n.s16_tpt == 1 || n.s16_tpt == 2) && n.s16_nt == n.D * n.s16_tpt &&
+         (n.s16_ni == 1 || n.s16_ni == 2);
 }
 
 static Ar16Args a16_args(const SfNsfAr& n, const SfAr16Launch& L) {
@@ -550,14 +603,19 @@ static Ar16Args a16_args(const SfNsfAr& n, const SfAr16Launch& L) {
 #endif
   return a;
 }
-// (DD, NI, KS) of a flow -> the instantiation: F is called with three integral constants
+// (DD, NI, KS, TPT) of a flow -> the instantiation: F is called with four integral constants.  Two tiles per type are built for
+// three and four k-steps only (17..32 units per type: 9..16 per tile).
 template <typename F>
 static hipError_t a16_dispatch(const SfNsfAr& n, F f) {
   auto with_ks = [&](auto dd, auto ni) {
+    if (n.s16_tpt == 2) {
+      if (n.s16_ks == 3) return f(dd, ni, std::integral_constant<int, 3>(), std::integral_constant<int, 2>());
+      return f(dd, ni, std::integral_constant<int, 4>(), std::integral_constant<int, 2>());
+    }
     switch (n.s16_ks) {
-      case 2: return f(dd, ni, std::integral_constant<int, 2>());
-      case 3: return f(dd, ni, std::integral_constant<int, 3>());
-      default: return f(dd, ni, std::integral_constant<int, 4>());
+      case 2: return f(dd, ni, std::integral_constant<int, 2>(), std::integral_constant<int, 1>());
+      case 3: return f(dd, ni, std::integral_constant<int, 3>(), std::integral_constant<int, 1>());
+      default: return f(dd, ni, std::integral_constant<int, 4>(), std::integral_constant<int, 1>());
     }
   };
 #define A16_CASE(DD)                                                                                                             \
@@ -590,14 +648,14 @@ hipError_t sf_nsfar16_launch(const SfNsfAr& n, const SfAr16Launch& L, int cus, h
     fprintf(stderr, "\n");
   } } dump{d_tr, st};
 #endif
-  return a16_dispatch(n, [&](auto dd, auto ni, auto ks) { return launch16<decltype(dd)::value, decltype(ni)::value, decltype(ks)::value>(a, cus, st); });
+  return a16_dispatch(n, [&](auto dd, auto ni, auto ks, auto tpt) { return launch16<decltype(dd)::value, decltype(ni)::value, decltype(ks)::value, decltype(tpt)::value>(a, cus, st); });
 }
 
 hipError_t sf_nsfar16_find(const SfNsfAr& n, const SfAr16Launch& L, const uint32_t* surv, unsigned int n_surv, uint32_t base, uint32_t chunks,
                            uint32_t att_end, uint32_t* best, unsigned long long* ctr, hipStream_t st) {
   const Ar16Args a = a16_args(n, L);
-  return a16_dispatch(n, [&](auto dd, auto ni, auto ks) {
-    hipLaunchKernelGGL((k_ar_find16<decltype(dd)::value, decltype(ni)::value, decltype(ks)::value>), dim3(n_surv * chunks), dim3(256), 0, st, a, surv, n_surv, base, chunks,
+  return a16_dispatch(n, [&](auto dd, auto ni, auto ks, auto tpt) {
+    hipLaunchKernelGGL((k_ar_find16<decltype(dd)::value, decltype(ni)::value, decltype(ks)::value, decltype(tpt)::value>), dim3(n_surv * chunks), dim3(256), 0, st, a, surv, n_surv, base, chunks,
                        att_end, best, ctr);
     return hipGetLastError();
   });
@@ -606,8 +664,8 @@ hipError_t sf_nsfar16_find(const SfNsfAr& n, const SfAr16Launch& L, const uint32
 hipError_t sf_nsfar16_resolve(const SfNsfAr& n, const SfAr16Launch& L, const uint32_t* surv, unsigned int n_surv, const uint32_t* best,
                               uint32_t tried_end, uint32_t tried_now, uint32_t* next, unsigned int* n_next, hipStream_t st) {
   const Ar16Args a = a16_args(n, L);
-  return a16_dispatch(n, [&](auto dd, auto ni, auto ks) {
-    hipLaunchKernelGGL((k_ar_resolve16<decltype(dd)::value, decltype(ni)::value, decltype(ks)::value>), dim3((n_surv + 63u) / 64u), dim3(256), 0, st, a, surv, n_surv, best,
+  return a16_dispatch(n, [&](auto dd, auto ni, auto ks, auto tpt) {
+    hipLaunchKernelGGL((k_ar_resolve16<decltype(dd)::value, decltype(ni)::value, decltype(ks)::value, decltype(tpt)::value>), dim3((n_surv + 63u) / 64u), dim3(256), 0, st, a, surv, n_surv, best,
                        tried_end, tried_now, next, n_next);
     return hipGetLastError();
   });

@@ -128,7 +128,7 @@ class FlowPosterior:
             est._warned_sampler = True
             sp = self.spec
             logger.warning(f"{sp.kind} D={sp.D} C={sp.C} H={sp.H} T={sp.T}: this shape samples on the 64-sample LDS kernel (k_ar_sample), not on "
-                           "the 16-candidate register-tile kernels (2 <= D <= 8, at most 16 hidden units per parameter, D + C <= 32)")
+                           "the 16-candidate register-tile kernels (2 <= D <= 8, at most 32 hidden units per parameter, D + C <= 32)")
         unfilled = 0
         try:
             for r0 in range(0, N, rows_per):

@@ -53,6 +53,10 @@ CASES = {
     # (D + C = 21), two units per type at D = 8 (KS = 2, half-empty tiles)
     "nsfar_k4": ("nsf_ar", 4, 17, 64, 2, 6, dict(tail_bound=5.0)),
     "nsfar_thin": ("nsf_ar", 8, 5, 16, 3, 4, dict(tail_bound=5.0)),
+    # two tiles per type on the register-tile sampler, three k-steps (D = 5: two workgroups per CU) / wider than the sampler takes
+    # (33 units per type: the 64-sample kernel)
+    "nsfar_two": ("nsf_ar", 5, 9, 112, 2, 8, dict(tail_bound=5.0)),
+    "nsfar_33": ("nsf_ar", 3, 6, 99, 2, 6, dict(tail_bound=5.0)),
     # the widest member of the reference's own lampe example (examples/sbi/scripts/basic_model.py:31-41: hidden_features 180): seven
     # types of 25-26 units padded to 32 rows each; fits since the training sweep runs on two hidden buffers
     "nsfar_h180": ("nsf_ar", 7, 12, 180, 2, 8, dict(tail_bound=5.0)),

@@ -106,7 +106,7 @@ def test_tiny_and_empty_batches():
 
 
 @pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "nsf_odd", "nsf_h69", "maf_span6", "maf_d2_span", "maf_d4", "maf_d3", "maf_sig2", "nsf_d1",
-                                  "nsfar_cfg1", "nsfar_small", "nsfar_d1", "nsfar_wide", "nsfar_h180", "nsfar_k4", "nsfar_thin", "mafar_cfg1",
+                                  "nsfar_cfg1", "nsfar_small", "nsfar_d1", "nsfar_wide", "nsfar_h180", "nsfar_k4", "nsfar_thin", "nsfar_two", "nsfar_33", "mafar_cfg1",
                                   "mafar_small"])
 def test_sampler_matches_oracle_draw_for_draw(name):
     _draw_for_draw(name)
@@ -199,16 +199,16 @@ def test_autoregressive_nsf_slots_acceptance_and_exhaustion():
 
 def test_lampe_sampler_kernel_selection():
     """Which sampling kernel a lampe-backend flow takes (describe()): the 16-candidate register-tile kernels (sf_nsfar16.hip) for
-    2 <= D <= 8 with at most sixteen hidden units per type and D + C <= 32, the 64-sample LDS kernel otherwise; k-steps per hidden
-    block = ceil(units per type / 4)."""
-    want = {"nsfar_cfg1": (1, 3), "nsfar_small": (1, 2), "nsfar_wide": (1, 2), "nsfar_k4": (1, 4), "nsfar_thin": (1, 2), "mafar_cfg1": (1, 3),
-            "nsfar_d1": (0, None), "nsfar_h180": (0, None)}
-    for name, (tiles16, ks) in want.items():
+    2 <= D <= 8 with at most 32 hidden units per type (one tile per type up to 16, two above) and D + C <= 32, the 64-sample LDS kernel
+    otherwise; k-steps per hidden block = ceil(units per tile / 4)."""
+    want = {"nsfar_cfg1": (1, 3, 1), "nsfar_small": (1, 2, 1), "nsfar_wide": (1, 2, 1), "nsfar_k4": (1, 4, 1), "nsfar_thin": (1, 2, 1),
+            "mafar_cfg1": (1, 3, 1), "nsfar_h180": (1, 4, 2), "nsfar_two": (1, 3, 2), "nsfar_d1": (0, None, None), "nsfar_33": (0, None, None)}
+    for name, (tiles16, ks, tpt) in want.items():
         ospec, spec, flat, theta, x = make_case(name, B=2)
         d = _flow(spec, flat).describe()
         assert d["sampler_tiles16"] == tiles16, (name, d["sampler_tiles16"])
         if tiles16:
-            assert d["s16_ks"] == ks and d["s16_nt"] == spec.D and d["s16_ni"] == (spec.D + spec.C + 15) // 16, (name, d)
+            assert d["s16_ks"] == ks and d["s16_tpt"] == tpt and d["s16_nt"] == spec.D * tpt and d["s16_ni"] == (spec.D + spec.C + 15) // 16, (name, d)
 
 
 def test_lampe_register_tile_sampler_equals_the_lds_sampler_on_a_full_chip(tmp_path):
