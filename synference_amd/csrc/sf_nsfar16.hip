@@ -9,15 +9,17 @@
 //     l & 15), which IS the B-operand order of the next product when the weight block is stored lane-major with the same
 //     k-permutation (lane l: W[16 ot + (l & 15)][16 kt + 4 (l >> 4) + j], one 16-byte load per block, four products);
 //   * the sampler has its own hidden order: type r (the units that become final once the dimensions ordered before r are known)
-//     IS tile r -- its units on the rows with (row & 3) < KS = ceil(units / 4), so that the k-steps KS..3 of a block over a hidden
-//     tile are zeros and are not issued --, so step r of the sweep is static code -- L0 block(s) of tile r, blocks (r, 0..r) of the masked layer, blocks
-//     (0..r) of the two head tiles of the dimension ordered r -- with no masks, selects or row bounds; the steps of a transform
-//     are the cases of a switch inside the rolled loops over transforms and order values (one copy of the spline);
-//   * the 24 parameter slots of the step's dimension are gathered from the four row groups with ds_bpermute and the univariate
-//     inverse runs in all four lane groups of a sample redundantly (same instructions, no transposition through memory);
-//   * occupancy is set by registers alone: three to four waves per SIMD instead of half a wave.
-// Control flow (work queue, retry compaction, speculation once the list has run dry, survivor hand-over to k_ar_find /
-// k_ar_resolve) is k_ar_sample's with 16 entries per wave; the four waves of a workgroup never meet.
+//     IS tile r (tiles 2 r and 2 r + 1 when the type has 17..32 units: TPT = 2), its units on the rows with (row & 3) < KS =
+//     ceil(units per tile / 4), so that the k-steps KS..3 of a block over a hidden tile multiply zeros and are not issued.  Step r of
+//     the sweep is then static code -- the input block(s) of tile r, blocks (r, 0..r) of the masked layer, blocks 0..r of the two head
+//     tiles of the dimension ordered r -- with no masks, selects or row bounds; the steps of a transform are the cases of a switch
+//     inside the rolled loops over transforms and order values;
+//   * the spline inverse runs on the head tiles as the MFMA left them (a16_spline_inv: the width pair and the height pair of lane
+//     groups work on four bins each and exchange the selected bin: twelve cross-lane moves, no transposition through memory);
+//   * occupancy is set by registers alone: three waves per SIMD (two / one for the two-tile shapes) instead of half a wave.
+// Control flow (work queue, retry compaction, speculation once the list has run dry, survivor hand-over to the find / resolve
+// rounds, which run the same candidate routine) is k_ar_sample's with 16 entries per wave; the four waves of a workgroup never
+// meet; the evaluation statistics stay in the wave until it leaves (per round they were two atomics on the queue head's cache line).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
