@@ -253,8 +253,13 @@ __host__ __device__ inline int sf_trc_cb_floats(int NT, int NI, int TS) { return
 // NFS = fragment slots per masked layer and wave: 5 covers the aligned degree placement ((p + 1) + (NT - p) = NT + 1 blocks), 8 the
 // contiguous ("span") placements, whose degree groups straddle tiles and unmask more blocks (up to NT per tile: D = 6 with H = 50,
 // H = 64 with D >= 6 -- the width of the reference's example CLI); the three extra fragments per layer cost registers (scratch).
+// workgroups per CU the register allocation is made for: the 8-wave form (NG = 2) holds 145 KB of LDS -- ONE per CU, two waves per
+// SIMD, so a wave may take 256 registers (round 3-4 compiled it for two per CU: 128 registers, 48 B of scratch)
+#ifndef SF_TRC_WGS
+#define SF_TRC_WGS(NG) ((NG) == 2 ? 1 : 2)
+#endif
 template <int TS, int NI, int NT, int NG, int NFS = 5>
-__global__ __launch_bounds__(256 * NG, 2) void k_maf_trainc(SfTrcArgs a_in) {
+__global__ __launch_bounds__(256 * NG, SF_TRC_WGS(NG)) void k_maf_trainc(SfTrcArgs a_in) {
   extern __shared__ float lds[];
   constexpr int NQ = 2 * NG, NW = 4 * NG, NTH = 256 * NG;
   constexpr int NP = (NT + 1) / 2;  // wave rows (p) that own tiles
