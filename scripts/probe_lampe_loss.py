@@ -1,5 +1,5 @@
 """loss_grad's per-row losses of the lampe flow against -log_prob (another kernel) at batch sizes around chunk boundaries: prints the rows
-that disagree -- none with one training workgroup per CU (the shipped form; see the note above k_ar_train in csrc/sf_nsfar.hip)."""
+that disagree -- none since the barrier behind the loss (see the note above k_ar_train in csrc/sf_nsfar.hip)."""
 import sys, numpy as np, torch
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 from cases import make_case

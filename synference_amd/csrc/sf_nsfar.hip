@@ -678,18 +678,15 @@ __global__ __launch_bounds__(64) void k_ar_resolve(ArArgs a, const float* __rest
 }
 
 // forward (with the inputs of every transform stashed) + loss, then the backward sweep
-// Two workgroups per CU were tried (24 head rows per wave -> 74.6 KB of LDS, the four-wave form held to 256 registers: 219, no scratch):
-// 3.1 -> 2.3 ms per 131 072 rows -- and WRONG losses on thousands of rows whenever two workgroups really shared a CU (the same binary
-// with 8 KB of extra dynamic LDS, i.e. alone on its CU, is exact; so is the forward sweep alone with two per CU, so a neighbour's
-// BACKWARD sweep is what disturbs a forward one; exchanging the log-determinants through other LDS rows or replacing the ds_add_f32 of the
-// hidden deltas by compare-and-swap loops changes nothing; the ISA has no flat or scratch access and the LDS footprint is inside the
-// allocation with 7 KB to spare).  Not understood yet: the kernel keeps one workgroup per CU
-// (-DSF_AR_TRAIN_WGS=2 -DSF_AR_QBR=24 rebuilds the other form; scripts/probe_lampe_loss.py shows the rows).
+// Two workgroups per CU (round 5): 24 head rows per wave -> 74.6 KB of LDS for the bench shape, the four-wave form held to 256 registers
+// (219, no scratch): 3.1 -> 2.3 ms per 131 072 rows (one 64-row chunk per workgroup: only batches above 64 x CUs rows gain).  The first
+// build of it computed WRONG losses on thousands of rows whenever two workgroups really shared a CU: a latent race since round 4 (the
+// barrier behind the loss, see there) that one workgroup per CU never lost.  -DSF_AR_TRAIN_WGS=1 -DSF_AR_QBR=32 rebuilds the old form.
 #ifndef SF_AR_TRAIN_WGS
-#define SF_AR_TRAIN_WGS 1
+#define SF_AR_TRAIN_WGS 2
 #endif
 #ifndef SF_AR_QBR
-#define SF_AR_QBR 32
+#define SF_AR_QBR 24
 #endif
 template <int NWV, bool PART>
 __global__ __launch_bounds__(64 * NWV, NWV == 4 ? SF_AR_TRAIN_WGS : 1) void k_ar_train(ArArgs a, const float* __restrict__ theta, const float* __restrict__ x,
@@ -703,7 +700,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? SF_AR_TRAIN_WGS : 1) void k_ar
   float* H1 = E0 + a.NIN16 * RS;         // [Hp]
   float* H2 = H1 + a.Hp * RS;            // [Hp]
   float* QB0 = H2 + a.Hp * RS;           // [NWV][32] per wave: head outputs of ONE dimension, then their deltas; wave 0: the input deltas
-  // (32 rows per wave: the head's 24 slots + the eight rows the 16-row tile routines read behind them)
+  // (24 rows per wave: the head's 24 slots.  The 16-row tile routines read rows 24..31 of a wave's second tile -- the next wave's
+  //  buffer, or GG behind the last -- and everything computed from them lands in output rows that are never stored)
   constexpr int QBR = SF_AR_QBR;
   float* QB = QB0 + wid * QBR * RS;
   // TWO hidden buffers serve the backward sweep (round 5; three before: 102 KB for cfg1's shape, one workgroup per CU, and the
@@ -772,6 +770,11 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? SF_AR_TRAIN_WGS : 1) void k_ar
   }
   const float wb = valid ? (wts ? w * wts[b] : w) : 0.f;
   for (int d = wid; d < a.D; d += NWV) GG[d * RS + lane] = wb * E0[d * RS + lane];
+  // wave 0 has summed EVERY row of E0 for the loss above; the backward sweep below starts by putting the last transform's inputs back
+  // into the rows of the other waves.  Without this barrier a wave that runs ahead overwrites rows wave 0 has not read yet: the
+  // gradients stay right (every wave has taken its own rows for GG), the LOSS of some rows does not -- never seen with one workgroup
+  // per CU (wave 0's path is the short one), thousands of rows with two (round 5: the "two workgroups per CU" experiment).
+  if (NWV > 1) __syncthreads();
   AR_TS(98);
   const int nin = a.D + a.C;
   for (int t = a.T - 1; t >= 0; --t) {
@@ -1039,7 +1042,7 @@ int sf_nsfar_create(const sf_flow_desc& d, SfNsfAr** out, std::string& err) {
   }
   n->t_stride = (o + 63) / 64 * 64;
   if (std::max(sf_nsfar_lds_bytes(*n, 3, 1), sf_nsfar_lds_bytes(*n, 2, 1)) > (size_t)160 * 1024 - 1024) {
-    err = "autoregressive NSF: (3 D + C + 2 Hp + 32) x 260 bytes of LDS per wave (training: + 16 Hp bytes of tables) exceed the 160 KB of a CU (Hp = H with every type padded to a multiple of 8, in all a multiple of 16)";
+    err = "autoregressive NSF: (3 D + C + 2 Hp + 32) x 260 bytes of LDS per wave (training: 24 head rows + 16 Hp bytes of tables) exceed the 160 KB of a CU (Hp = H with every type padded to a multiple of 8, in all a multiple of 16)";
     delete n;
     return SF_ERR_INVALID;
   }

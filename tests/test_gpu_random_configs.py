@@ -109,7 +109,7 @@ def test_random_config_of_the_other_flow_kinds_matches_oracle(kind, D, C, H, T, 
         Hp = sum((len(range(r, H, D)) + 7) // 8 * 8 for r in range(D))
         Hp = (Hp + 15) // 16 * 16
         rows = (D + C + 15) // 16 * 16 + 2 * Hp + 2 * D          # (two hidden buffers; + the head rows of one wave)
-        need = max((rows + 32) * 65 * 4, (rows + 32) * 65 * 4 + 4 * Hp * 4)   # density / sampling kernels, training kernel (+ its tables)
+        need = max((rows + 32) * 65 * 4, (rows + 24) * 65 * 4 + 4 * Hp * 4)   # density / sampling kernels, training kernel (+ its tables)
         if need > 160 * 1024 - 1024:
             with pytest.raises(RuntimeError, match="LDS"):
                 HipFlow(spec, "cuda:0")

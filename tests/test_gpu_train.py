@@ -259,8 +259,9 @@ def test_loss_grad_rows_equals_gathered_loss_grad():
 @pytest.mark.parametrize("name", ["maf_cfg1", "nsf_cfg3", "nsfar_cfg1", "mafar_cfg1"])
 def test_training_losses_equal_the_density_kernel_at_a_full_chip_batch(name):
     """The per-row losses of the training kernel are -log_prob of another kernel: at 20 000 rows -- every CU holds workgroups of the
-    training kernel side by side where its LDS and registers allow -- they must agree row by row.  (A form of the lampe training kernel
-    with two workgroups per CU passed every small-batch gradient test and got thousands of these rows wrong: csrc/sf_nsfar.hip.)"""
+    training kernel side by side where its LDS and registers allow -- they must agree row by row.  (The lampe training kernel missed a
+    barrier between the loss and the backward sweep: every small-batch gradient test passed, and with two workgroups per CU thousands of
+    these rows were wrong: csrc/sf_nsfar.hip.)"""
     from synference_amd.engine import HipFlow
     ospec, spec, flat, theta, x = make_case(name, B=20000)
     f = HipFlow(spec, "cuda:0")
