@@ -6,6 +6,29 @@
 
 #include "sf_layout.h"
 
+// Developer build -DSF_FUZZ_SCHED (scripts/fuzz_sched.sh): behind EVERY workgroup barrier of the library -- __syncthreads() and the
+// s_barrier helpers of the cooperative kernels -- a wave sleeps for a time that depends on the wave and on the clock, so that the order
+// in which the waves reach the next phase changes from barrier to barrier: a missing barrier then loses its race sooner or later
+// (round 5: one in k_ar_train had never lost it with one workgroup per CU; this build shows it at once).
+#ifdef SF_FUZZ_SCHED
+__device__ __forceinline__ void sf_fuzz_delay() {
+  const unsigned int w = (unsigned int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned int t = (unsigned int)__builtin_amdgcn_s_memtime();
+  const unsigned int n = ((w * 2654435761u) ^ (t >> 3)) % 13u;
+  for (unsigned int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(20);
+}
+__device__ __forceinline__ void sf_syncthreads_fuzz() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  sf_fuzz_delay();
+}
+#define __syncthreads() sf_syncthreads_fuzz()
+#define SF_FUZZ() sf_fuzz_delay()
+#else
+#define SF_FUZZ() do { } while (0)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define SF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)

@@ -160,6 +160,11 @@ __device__ __forceinline__ int ar_slot_row(const ArArgs& a, int sl) {
   return (sl < ARQ - 1 && kk < (fam < 2 ? a.K : a.K - 1)) ? fam * a.K + kk : -1;
 }
 
+// workgroup barrier of the multi-wave kernels of this file
+__device__ __forceinline__ void ar_barrier() {
+  __syncthreads();   // (-DSF_FUZZ_SCHED: the macro of sf_device.h, barrier + delay)
+}
+
 // order the LDS traffic of ONE wave (its LDS operations execute in program order: a read issued after a write of another lane
 // of the same wave sees it; this only keeps the compiler from reordering them)
 __device__ __forceinline__ void ar_wave_sync() {
@@ -321,12 +326,12 @@ __device__ __forceinline__ void ar_hidden0(const ArArgs& a, const float* __restr
 // both hidden layers of a transform from the inputs in E0 (rows [0, NIN4): u, context, zeros)
 __device__ __forceinline__ void ar_hidden(const ArArgs& a, const float* __restrict__ tp, const float* E0, float* H1, float* H2, int lane,
                                           int wid = 0, int nwv = 1) {
-  __syncthreads();   // (E0 was written sample by sample)
+  ar_barrier();   // (E0 was written sample by sample)
   ar_rows<true>(tp + a.o_L0t, a.Hp, tp + a.o_b0, 0, a.Hp, 0, [&](int, int) { return a.NIN4; }, E0, H1, a.Hp, lane, wid, nwv);
-  __syncthreads();
+  ar_barrier();
   ar_rows<true>(tp + a.o_L1t, a.Hp, tp + a.o_b1, 0, a.Hp, 0, [&](int p0, int n) { return (int)a.tile_kend[(p0 >> 4) + n - 1]; }, H1, H2, a.Hp, lane,
                 wid, nwv);
-  __syncthreads();
+  ar_barrier();
 }
 // the 24 parameter slots of dimension d from the last hidden layer (rows < kend) -> q (through the 32 rows of QB)
 __device__ __forceinline__ void ar_head(const ArArgs& a, const float* __restrict__ tp, int d, int kend, const float* H2, float* QB, int lane,
@@ -380,10 +385,10 @@ __global__ __launch_bounds__(64 * NWV) void k_ar_logprob(ArArgs a, const float* 
       AR_TS(4 + t * 40 + 2 * d);
     }
   }
-  __syncthreads();
+  ar_barrier();
   if (NWV > 1) {   // the log-determinants of the waves' dimensions
     QB[lane] = ld;
-    __syncthreads();
+    ar_barrier();
     if (wid == 0)
       for (int w2 = 1; w2 < NWV; ++w2) ld += H2[a.Hp * RS + w2 * 32 * RS + lane];
   }
@@ -403,9 +408,9 @@ __device__ __forceinline__ float ar_inverse_transform(const ArArgs& a, const ZSp
   for (int d = 0; d < a.D; ++d) E0[d * RS + lane] = 0.f;   // (not yet known: masked weights are zeros, the values must be finite)
   for (int r = 0; r < a.D; ++r) {
     const int p_lo = r ? (int)a.tendk[r - 1] : 0, p_hi = (int)a.tendk[r];
-    __syncthreads();   // (E0 row of the dimension inverted last)
+    ar_barrier();   // (E0 row of the dimension inverted last)
     ar_rows<true>(tp + a.o_L0t, a.Hp, tp + a.o_b0, p_lo, p_hi, 0, [&](int, int) { return a.NIN4; }, E0, H1, p_hi, lane);
-    __syncthreads();
+    ar_barrier();
     ar_rows<true>(tp + a.o_L1t, a.Hp, tp + a.o_b1, p_lo, p_hi, 0, [&](int, int) { return p_hi; }, H1, H2, p_hi, lane);
     const int d = a.dimof[t * a.D + r];
     // the step after this one (the next order value, or the first of the transform below): which rows, which dimension
@@ -559,7 +564,7 @@ __global__ __launch_bounds__(64) void k_ar_sample(ArArgs a, const float* __restr
     }
     const uint32_t att = att0 + (uint32_t)sub;
     const bool active = exists && att < window_end;
-    __syncthreads();   // (the retry list has been read)
+    ar_barrier();   // (the retry list has been read)
     const long g = exists ? (long)(slot / (unsigned long long)S) : 0;
     const bool ok = ar_candidate(a, sc, x, g, slot, att, k0, k1, slot_offset, lo, hi, E0, V, H1, H2, QB, lane, active);
     const unsigned long long m_ok = __ballot(ok);
@@ -602,7 +607,7 @@ __global__ __launch_bounds__(64) void k_ar_sample(ArArgs a, const float* __restr
       r_att[pos] = att0 + (uint32_t)W;
     }
     n_retry = __popcll(m);
-    __syncthreads();
+    ar_barrier();
   }
 }
 
@@ -724,7 +729,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? SF_AR_TRAIN_WGS : 1) void k_ar
   for (long chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
   const bool first_chunk = chunk == (long)blockIdx.x;
   (void)first_chunk;
-  if (!first_chunk) __syncthreads();   // (the previous chunk's last reads of the LDS rows)
+  if (!first_chunk) ar_barrier();   // (the previous chunk's last reads of the LDS rows)
   const long b = chunk * 64 + lane;
   const bool valid = b < B;
   const long bb = valid ? b : B - 1;
@@ -735,7 +740,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? SF_AR_TRAIN_WGS : 1) void k_ar
   float ld = 0.f;
   for (int t = 0; t < a.T; ++t) {
     const float* tp = a.img + (size_t)t * a.t_stride;
-    __syncthreads();   // (E0 complete)
+    ar_barrier();   // (E0 complete)
     for (int d = wid; d < a.D; d += NWV) ust[t * a.D + d] = E0[d * RS + lane];
     ar_hidden(a, tp, E0, H1, H2, lane, wid, NWV);
     for (int d = 0; d < a.D; ++d) {
@@ -748,10 +753,10 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? SF_AR_TRAIN_WGS : 1) void k_ar
       ld += lad;
     }
   }
-  __syncthreads();
+  ar_barrier();
   if (NWV > 1) {   // the log-determinants of the waves' dimensions
     QB[lane] = ld;
-    __syncthreads();
+    ar_barrier();
     if (wid == 0)
       for (int w2 = 1; w2 < NWV; ++w2) ld += QB0[w2 * QBR * RS + lane];
   }
@@ -774,7 +779,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? SF_AR_TRAIN_WGS : 1) void k_ar
   // into the rows of the other waves.  Without this barrier a wave that runs ahead overwrites rows wave 0 has not read yet: the
   // gradients stay right (every wave has taken its own rows for GG), the LOSS of some rows does not -- never seen with one workgroup
   // per CU (wave 0's path is the short one), thousands of rows with two (round 5: the "two workgroups per CU" experiment).
-  if (NWV > 1) __syncthreads();
+  if (NWV > 1) ar_barrier();
   AR_TS(98);
   const int nin = a.D + a.C;
   for (int t = a.T - 1; t >= 0; --t) {
@@ -788,7 +793,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? SF_AR_TRAIN_WGS : 1) void k_ar
     for (int r0 = 8 * wid; r0 < a.Hp; r0 += 8 * NWV)
 #pragma unroll
       for (int i = 0; i < 8; ++i) DH[(r0 + i) * RS + lane] = 0.f;
-    __syncthreads();
+    ar_barrier();
     AR_TS(101);
     // ---- head + splines, dimension by dimension (wave wid: dimensions wid, wid + NWV, ...)
     for (int d = 0; d < a.D; ++d) {
@@ -838,12 +843,12 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? SF_AR_TRAIN_WGS : 1) void k_ar
       AR_TS(105 + 4 * d);
     }
     // ---- second hidden layer: delta through the ReLU, weight gradients, delta of the first hidden layer (into H2's rows)
-    __syncthreads();
+    ar_barrier();
     ar_mask_rows(DH, H2, a.Hp, lane, wid, NWV);   // DH <- DH where H2 > 0
-    __syncthreads();
+    ar_barrier();
     float* H1r = H2;                              // H2 is dead: the first hidden layer once more, into its rows
     ar_hidden0(a, tp, E0, H1r, lane, wid, NWV);
-    __syncthreads();
+    ar_barrier();
     AR_TS(130);
     for (int o0 = 16 * wid; o0 < a.Hp; o0 += 16 * NWV) {
       const int kend = (int)a.tile_kend[o0 >> 4];
@@ -864,17 +869,17 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? SF_AR_TRAIN_WGS : 1) void k_ar
           if (ol[r] >= 0) AR_GADD(gt + a.l_b1 + ol[r], b4[r]);
       }
     }
-    __syncthreads();   // (the recomputed H1 is overwritten next)
+    ar_barrier();   // (the recomputed H1 is overwritten next)
     AR_TS(131);
     // delta_h1[k] = sum_{o: type(o) >= type(k)} W1[o][k] delta_h2[o]
     for (int p0 = 32 * wid; p0 < a.Hp; p0 += 32 * NWV) {
       if (p0 + 16 < a.Hp) ar_tiles<false, false, 2>(tp + a.o_L1m, a.Hp, nullptr, p0, (int)a.tile_kbeg[p0 >> 4], a.Hp, DH, H2, a.Hp, lane);
       else ar_tiles<false, false, 1>(tp + a.o_L1m, a.Hp, nullptr, p0, (int)a.tile_kbeg[p0 >> 4], a.Hp, DH, H2, a.Hp, lane);
     }
-    __syncthreads();
+    ar_barrier();
     AR_TS(132);
     ar_mask_bits(H2, M1, a.Hp, lane, wid, NWV);   // H2 (delta_h1) <- where H1 > 0 (the bits taken before DH took its rows)
-    __syncthreads();
+    ar_barrier();
     AR_TS(133);
     // ---- first hidden layer: weight gradients, and what reaches the inputs
     for (int o0 = 16 * wid; o0 < a.Hp; o0 += 16 * NWV) {
@@ -899,7 +904,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? SF_AR_TRAIN_WGS : 1) void k_ar
     AR_TS(134);
     // d input[i] = sum_o W0[o][i] delta_h1[o], i < D  (L0m: [o][16]); the last wave has the fewest weight-gradient tiles
     if (wid == NWV - 1) ar_tiles<false, false, 1>(tp + a.o_L0m, 16, nullptr, 0, 0, a.Hp, H2, QB0, 16, lane);
-    __syncthreads();
+    ar_barrier();
     AR_TS(135);
     for (int d = wid; d < a.D; d += NWV) GG[d * RS + lane] = DV[d * RS + lane] + QB0[d * RS + lane];
   }

@@ -192,6 +192,7 @@ __device__ __forceinline__ void n_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  SF_FUZZ();
 }
 
 // NW waves: 4, or 5 when the flow has five hidden tiles (64 < H <= 80: the reference's production NSF has H = 69); one hidden

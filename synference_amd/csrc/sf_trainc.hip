@@ -203,6 +203,7 @@ __device__ __forceinline__ void c_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  SF_FUZZ();
 }
 
 // Block offsets of the cooperative image and of a gradient partial: functions of (NT, NI) alone (sf_layout.cpp emits the blocks
