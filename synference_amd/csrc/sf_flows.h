@@ -529,7 +529,10 @@ struct SfSplineBwd {
 };
 
 // BF: 0 = fp32 hidden blocks; 1 = single bf16 operands (sf_flow_desc.hidden_bf16); 2 = split bf16 x3 (sampler image)
-template <int HT, int PT, int NS, bool LDSW = false, int BF = 0>
+// MP: the image of a transform is staged in several PARTS (split sampler image of a wide flow: sf_layout.cpp, SfNsfSamp).  A template
+// argument, not a run-time test: with the part switch inside the block loop every persistent sampler spilled ~100 B per lane more
+// (staging loops and barriers between the blocks cut every live range), also where a transform is ONE part -- the usual case.
+template <int HT, int PT, int NS, bool LDSW = false, int BF = 0, bool MP = false>
 struct NsfOps {
   // ResidualNet conditioner -> hidden tiles
   // returns the (possibly LDS) base pointer valid for the spline head
@@ -556,7 +559,7 @@ struct NsfOps {
 #pragma unroll
     for (int k = 0; k < SF_NBMAX; ++k) {
       if (k < m.NB) {
-        if (LDSW && m.blk_part[k] != part) {
+        if (MP && LDSW && m.blk_part[k] != part) {
           part = m.blk_part[k];
           tp = sf_stage_part<LDSW>(m, t, part, lds);
         }
@@ -567,7 +570,7 @@ struct NsfOps {
           sf_init_bias<HT, NS>(t1, tp + m.o_b1[k], h);
           sf_init_bias<HT, NS>(t2, tp + m.o_b2[k], h);
           if (BF == 2) {
-            const unsigned short* tpB = sf_bf16_base<LDSW>(m, t, lds, part);
+            const unsigned short* tpB = sf_bf16_base<LDSW>(m, t, lds, MP ? part : 0);
             sf_mm_acc_bf16_split<HT, NS, HT, true>(t1, hid, tpB + m.oB_w1[k], m.nKS, m.nKS, lane);
             sf_mm_acc_bf16_split<HT, NS, HT, true>(t2, t1, tpB + m.oB_w2[k], m.nKS, m.nKS, lane);
           } else if (BF == 1) {
@@ -597,7 +600,7 @@ struct NsfOps {
         }
       }
     }
-    if (LDSW && m.head_part != part) tp = sf_stage_part<LDSW>(m, t, m.head_part, lds);
+    if (MP && LDSW && m.head_part != part) tp = sf_stage_part<LDSW>(m, t, m.head_part, lds);
     return tp;
   }
 
@@ -759,7 +762,7 @@ struct NsfOps {
       // LU parameters: from the staged image when the whole transform is one part, else from global
       // (two call sites, not a pointer select, so each keeps its address space)
       if (m.D > 1) {
-        if (LDSW && m.n_parts == 1) lu_forward(m, tp0 + m.o_lu, u, logdet);
+        if (LDSW && (!MP || m.n_parts == 1)) lu_forward(m, tp0 + m.o_lu, u, logdet);
         else lu_forward(m, m.packed + (size_t)t * m.t_stride + m.o_lu, u, logdet);
       }
     }
@@ -776,7 +779,7 @@ struct NsfOps {
       const SfDev m = sf_iter_view(m0);
       const float* tp0 = sf_stage_part<LDSW>(m, t, 0, lds);
       if (active && m.D > 1) {
-        if (LDSW && m.n_parts == 1) lu_inverse(m, tp0 + m.o_lu, u, logdet);
+        if (LDSW && (!MP || m.n_parts == 1)) lu_inverse(m, tp0 + m.o_lu, u, logdet);
         else lu_inverse(m, m.packed + (size_t)t * m.t_stride + m.o_lu, u, logdet);
       }
       coupling(m, t, lds, tp0, u, xr, logdet, true, lane, pre, cg, active);

@@ -149,19 +149,23 @@ static hipError_t launch_inverse(const SfDev& m, const SfSampleArgsHost& a, hipS
 #define SF_BF_SWITCH(FN, ...) { using OB = MafOps<SF_HT, 1, true, true>; return FN<OB>(__VA_ARGS__); }
 #define SF_BFS_SWITCH(FN, ...) SF_BF_SWITCH(FN, __VA_ARGS__)
 #else
+// (the last template argument of NsfOps: the transform's image is staged in several parts -- sf_flows.h)
+#define SF_NSF_MP(FN, PT_, BF_, ...)                                                                      \
+  if (m.n_parts > 1) { using OB = NsfOps<SF_HT, PT_, 1, true, BF_, true>; return FN<OB>(__VA_ARGS__); }   \
+  else { using OB = NsfOps<SF_HT, PT_, 1, true, BF_, false>; return FN<OB>(__VA_ARGS__); }
 #define SF_BF_SWITCH(FN, ...)                                                              \
   switch (m.PT) {                                                                          \
-    case 2: { using OB = NsfOps<SF_HT, 2, 1, true, 1>; return FN<OB>(__VA_ARGS__); }       \
-    case 3: { using OB = NsfOps<SF_HT, 3, 1, true, 1>; return FN<OB>(__VA_ARGS__); }       \
+    case 2: SF_NSF_MP(FN, 2, 1, __VA_ARGS__)                                               \
+    case 3: SF_NSF_MP(FN, 3, 1, __VA_ARGS__)                                               \
     default: return hipErrorInvalidValue;                                                  \
   }
 // sampling kernels: single bf16 (opt-in) or split bf16 x3 (the NSF sampler image)
 #define SF_BFS_SWITCH(FN, ...)                                                             \
   switch (m.PT * 10 + m.hidden_bf16) {                                                     \
-    case 21: { using OB = NsfOps<SF_HT, 2, 1, true, 1>; return FN<OB>(__VA_ARGS__); }      \
-    case 31: { using OB = NsfOps<SF_HT, 3, 1, true, 1>; return FN<OB>(__VA_ARGS__); }      \
-    case 22: { using OB = NsfOps<SF_HT, 2, 1, true, 2>; return FN<OB>(__VA_ARGS__); }      \
-    case 32: { using OB = NsfOps<SF_HT, 3, 1, true, 2>; return FN<OB>(__VA_ARGS__); }      \
+    case 21: SF_NSF_MP(FN, 2, 1, __VA_ARGS__)                                              \
+    case 31: SF_NSF_MP(FN, 3, 1, __VA_ARGS__)                                              \
+    case 22: SF_NSF_MP(FN, 2, 2, __VA_ARGS__)                                              \
+    case 32: SF_NSF_MP(FN, 3, 2, __VA_ARGS__)                                              \
     default: return hipErrorInvalidValue;                                                  \
   }
 #endif
@@ -171,12 +175,15 @@ static hipError_t launch_inverse(const SfDev& m, const SfSampleArgsHost& a, hipS
   { using OG = MafOps<SF_HT, NS, false>; using OL = MafOps<SF_HT, NS, true>;               \
     return FN<OG, OL, NS>(__VA_ARGS__); }
 #else
+#define SF_NSF_PT(NS, FN, PT_, ...)                                                                                              \
+  if (m.n_parts > 1) { using OG = NsfOps<SF_HT, PT_, NS, false>; using OL = NsfOps<SF_HT, PT_, NS, true, 0, true>;               \
+                       return FN<OG, OL, NS>(__VA_ARGS__); }                                                                     \
+  else { using OG = NsfOps<SF_HT, PT_, NS, false>; using OL = NsfOps<SF_HT, PT_, NS, true, 0, false>;                            \
+         return FN<OG, OL, NS>(__VA_ARGS__); }
 #define SF_PT_SWITCH(NS, FN, ...)                                                          \
   switch (m.PT) {                                                                          \
-    case 2: { using OG = NsfOps<SF_HT, 2, NS, false>; using OL = NsfOps<SF_HT, 2, NS, true>; \
-              return FN<OG, OL, NS>(__VA_ARGS__); }                                        \
-    case 3: { using OG = NsfOps<SF_HT, 3, NS, false>; using OL = NsfOps<SF_HT, 3, NS, true>; \
-              return FN<OG, OL, NS>(__VA_ARGS__); }                                        \
+    case 2: SF_NSF_PT(NS, FN, 2, __VA_ARGS__)                                              \
+    case 3: SF_NSF_PT(NS, FN, 3, __VA_ARGS__)                                              \
     default: return hipErrorInvalidValue;                                                  \
   }
 #endif
