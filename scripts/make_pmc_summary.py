@@ -79,8 +79,8 @@ if os.path.exists(nsf_path):
     Mn, Dn, Cn = 20000, 8, 20
     out["nsf"] = {
         "command": "the same passes over  bench.py --workload nsf_cfg3 --steps 2 --warmup 1  (BASELINE configs[2])",
-        "sampler": section(nsf, r"k_sample_persist<NsfOps<\d+, \d+, \d+, true, 2>", alg_bytes=4.0 * Dn * Mn * 1000 + 4.0 * Cn * Mn),
-        "sampler_fp32_leg": section(nsf, r"k_sample_persist<NsfOps<\d+, \d+, \d+, true, 0>", alg_bytes=4.0 * Dn * Mn * 1000 + 4.0 * Cn * Mn),
+        "sampler": section(nsf, r"k_sample_persist<NsfOps<\d+, \d+, \d+, true, 2(, \w+)?>", alg_bytes=4.0 * Dn * Mn * 1000 + 4.0 * Cn * Mn),
+        "sampler_fp32_leg": section(nsf, r"k_sample_persist<NsfOps<\d+, \d+, \d+, true, 0(, \w+)?>", alg_bytes=4.0 * Dn * Mn * 1000 + 4.0 * Cn * Mn),
         "log_prob": section(nsf, "k_logprob"),
         "train16384": section(nsf, "k_nsf_trainc", grid=512 * 256, alg_bytes=4.0 * (Dn + Cn) * 16384 + 4.0 * 2 * 91570,
                               note="cooperative 16-row kernel, batch 16 384, one chunk per workgroup: per-workgroup gradient partials "
