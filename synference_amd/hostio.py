@@ -76,7 +76,7 @@ def result_array(shape) -> np.ndarray:
 # hipHostMalloc of 80 MB costs milliseconds, so the pinned buffers are recycled by the same rule as the plain ones: a buffer
 # is handed out again only when neither the array nor a view of it is referenced outside this list.
 _pinned: "list[tuple[torch.Tensor, np.ndarray]]" = []
-_PINNED_MAX_BYTES = 1 << 30      # larger results (configs[4]: 4 GB) take the staged copy instead of pinning that much host memory
+_PINNED_MAX_BYTES = 2 << 30      # larger results (configs[4]: 4 GB) take the staged copy instead of pinning that much host memory
 
 
 def pinned_result(shape):
